@@ -1,0 +1,166 @@
+"""ctypes binding shared by the two oracle back-ends (TEST INFRASTRUCTURE ONLY).
+
+* ``load("ref")``  -> oracle/_ref/libliquid_ref.so : the reference's own vendored liquid-dsp 1.5.0 DLL
+  (reference external/liquid-dsp/gcc/64/libliquid.dll) executed through oracle/ref/pe_loader.c.
+* ``load("port")`` -> oracle/_ref/liboracle_port.so : the plain-C restatement in oracle/liquid_port.c.
+
+Both export the liquid function names CubicSDR calls (reference external/liquid-dsp/include/liquid/liquid.h),
+so the same harness drives either.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+may import this module; the product (cubicsdr_amd/) never does.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+c_f = C.c_float
+c_u = C.c_uint
+c_i = C.c_int
+c_p = C.c_void_p
+
+
+class cf32(C.Structure):
+    _fields_ = [("re", c_f), ("im", c_f)]
+
+
+_SIGS = {
+    # name: (restype, argtypes)
+    "nco_crcf_create": (c_p, [c_i]),
+    "nco_crcf_destroy": (c_i, [c_p]),
+    "nco_crcf_reset": (c_i, [c_p]),
+    "nco_crcf_set_frequency": (c_i, [c_p, c_f]),
+    "nco_crcf_get_frequency": (c_f, [c_p]),
+    "nco_crcf_set_phase": (c_i, [c_p, c_f]),
+    "nco_crcf_get_phase": (c_f, [c_p]),
+    "nco_crcf_step": (c_i, [c_p]),
+    "nco_crcf_cexpf": (c_i, [c_p, c_p]),
+    "nco_crcf_mix_up": (c_i, [c_p, cf32, c_p]),
+    "nco_crcf_mix_down": (c_i, [c_p, cf32, c_p]),
+    "nco_crcf_mix_block_up": (c_i, [c_p, c_p, c_p, c_u]),
+    "nco_crcf_mix_block_down": (c_i, [c_p, c_p, c_p, c_u]),
+    "msresamp_crcf_create": (c_p, [c_f, c_f]),
+    "msresamp_crcf_destroy": (c_i, [c_p]),
+    "msresamp_crcf_print": (c_i, [c_p]),
+    "msresamp_crcf_get_delay": (c_f, [c_p]),
+    "msresamp_crcf_execute": (c_i, [c_p, c_p, c_u, c_p, c_p]),
+    "msresamp_rrrf_create": (c_p, [c_f, c_f]),
+    "msresamp_rrrf_destroy": (c_i, [c_p]),
+    "msresamp_rrrf_print": (c_i, [c_p]),
+    "msresamp_rrrf_get_delay": (c_f, [c_p]),
+    "msresamp_rrrf_execute": (c_i, [c_p, c_p, c_u, c_p, c_p]),
+    "msresamp2_crcf_create": (c_p, [c_i, c_u, c_f, c_f, c_f]),
+    "msresamp2_crcf_destroy": (c_i, [c_p]),
+    "msresamp2_crcf_print": (c_i, [c_p]),
+    "msresamp2_crcf_execute": (c_i, [c_p, c_p, c_p]),
+    "resamp2_crcf_create": (c_p, [c_u, c_f, c_f]),
+    "resamp2_crcf_destroy": (c_i, [c_p]),
+    "resamp2_crcf_print": (c_i, [c_p]),
+    "resamp2_crcf_decim_execute": (c_i, [c_p, c_p, c_p]),
+    "resamp2_crcf_interp_execute": (c_i, [c_p, cf32, c_p]),
+    "resamp2_rrrf_create": (c_p, [c_u, c_f, c_f]),
+    "resamp2_rrrf_destroy": (c_i, [c_p]),
+    "resamp2_rrrf_interp_execute": (c_i, [c_p, c_f, c_p]),
+    "resamp2_rrrf_decim_execute": (c_i, [c_p, c_p, c_p]),
+    "resamp_crcf_create": (c_p, [c_f, c_u, c_f, c_f, c_u]),
+    "resamp_crcf_destroy": (c_i, [c_p]),
+    "resamp_crcf_print": (c_i, [c_p]),
+    "resamp_crcf_execute_block": (c_i, [c_p, c_p, c_u, c_p, c_p]),
+    "resamp_rrrf_create": (c_p, [c_f, c_u, c_f, c_f, c_u]),
+    "resamp_rrrf_destroy": (c_i, [c_p]),
+    "resamp_rrrf_execute_block": (c_i, [c_p, c_p, c_u, c_p, c_p]),
+    "firpfbch_crcf_create_kaiser": (c_p, [c_i, c_u, c_u, c_f]),
+    "firpfbch_crcf_destroy": (c_i, [c_p]),
+    "firpfbch_crcf_reset": (c_i, [c_p]),
+    "firpfbch_crcf_analyzer_execute": (c_i, [c_p, c_p, c_p]),
+    "firpfbch2_crcf_create_kaiser": (c_p, [c_i, c_u, c_u, c_f]),
+    "firpfbch2_crcf_destroy": (c_i, [c_p]),
+    "firpfbch2_crcf_execute": (c_i, [c_p, c_p, c_p]),
+    "iirfilt_crcf_create_dc_blocker": (c_p, [c_f]),
+    "iirfilt_crcf_create_lowpass": (c_p, [c_u, c_f]),
+    "iirfilt_crcf_destroy": (c_i, [c_p]),
+    "iirfilt_crcf_print": (c_i, [c_p]),
+    "iirfilt_crcf_reset": (c_i, [c_p]),
+    "iirfilt_crcf_execute": (c_i, [c_p, cf32, c_p]),
+    "iirfilt_crcf_execute_block": (c_i, [c_p, c_p, c_u, c_p]),
+    "fft_create_plan": (c_p, [c_u, c_p, c_p, c_i, c_i]),
+    "fft_destroy_plan": (c_i, [c_p]),
+    "fft_execute": (c_i, [c_p]),
+    "freqdem_create": (c_p, [c_f]),
+    "freqdem_destroy": (c_i, [c_p]),
+    "freqdem_reset": (c_i, [c_p]),
+    "freqdem_demodulate_block": (c_i, [c_p, c_p, c_u, c_p]),
+    "firfilt_rrrf_create_dc_blocker": (c_p, [c_u, c_f]),
+    "firfilt_rrrf_destroy": (c_i, [c_p]),
+    "firfilt_rrrf_push": (c_i, [c_p, c_f]),
+    "firfilt_rrrf_execute": (c_i, [c_p, c_p]),
+    "firfilt_rrrf_execute_block": (c_i, [c_p, c_p, c_u, c_p]),
+    "firfilt_rrrf_get_length": (c_u, [c_p]),
+    "firhilbf_create": (c_p, [c_u, c_f]),
+    "firhilbf_destroy": (c_i, [c_p]),
+    "firhilbf_print": (c_i, [c_p]),
+    "firhilbf_c2r_execute": (c_i, [c_p, cf32, c_p, c_p]),
+    "estimate_req_filter_len": (c_u, [c_f, c_f]),
+    "kaiser_beta_As": (c_f, [c_f]),
+    "liquid_firdes_kaiser": (c_i, [c_u, c_f, c_f, c_f, c_p]),
+    "liquid_firdes_notch": (c_i, [c_u, c_f, c_f, c_p]),
+    "liquid_besseli0f": (c_f, [c_f]),
+    "liquid_kaiser": (c_f, [c_u, c_u, c_f]),
+    "sincf": (c_f, [c_f]),
+}
+
+LIQUID_NCO, LIQUID_VCO = 0, 1
+LIQUID_ANALYZER, LIQUID_SYNTHESIZER = 0, 1
+LIQUID_RESAMP_INTERP, LIQUID_RESAMP_DECIM = 0, 1
+LIQUID_FFT_FORWARD, LIQUID_FFT_BACKWARD = 1, -1
+
+
+def lib_path(kind):
+    name = {"ref": "libliquid_ref.so", "port": "liboracle_port.so"}[kind]
+    return os.path.join(_HERE, "_ref", name)
+
+
+def available(kind):
+    if not os.path.exists(lib_path(kind)):
+        return False
+    if kind == "ref":
+        return os.path.exists(os.path.join(_HERE, "_ref", "libliquid.dll"))
+    return True
+
+
+def load(kind):
+    """Return a ctypes library exposing the liquid API for back-end ``kind`` ("ref" | "port")."""
+    if kind in _LIBS:
+        return _LIBS[kind]
+    lib = C.CDLL(lib_path(kind), mode=os.RTLD_LOCAL) if hasattr(os, "RTLD_LOCAL") else C.CDLL(lib_path(kind))
+    for name, (res, args) in _SIGS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if kind == "ref":
+        lib.liquid_ref_load.argtypes = [C.c_char_p]
+        rc = lib.liquid_ref_load(None)
+        if rc:
+            raise OSError("reference liquid DLL failed to load (rc=%d)" % rc)
+    _LIBS[kind] = lib
+    return lib
+
+
+def ptr(a):
+    return a.ctypes.data_as(c_p)
+
+
+def as_c64(a):
+    return np.ascontiguousarray(a, dtype=np.complex64)
+
+
+def as_f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def cpx(z):
+    return cf32(float(np.real(z)), float(np.imag(z)))
