@@ -1,0 +1,559 @@
+// kernels_demod.hpp -- DemodulatorPreThread + DemodulatorThread + Modem arithmetic, batched over demodulators.
+//
+// Replaces (reference file:line): nco_crcf_mix_block_{up,down} DemodulatorPreThread.cpp:186-195, msresamp_crcf_execute
+// :209 (K5, K6); freqdem_demodulate_block ModemNBFM.cpp:36 / ModemFM.cpp:36 (K7); ModemAM.cpp:41-47 (K8);
+// ModemUSB.cpp:54-61 / ModemLSB.cpp (K9); ModemAnalog::buildAudioOutput ModemAnalog.cpp:67-93 (K10);
+// level / peak loops DemodulatorThread.cpp:142-152,223-233 (K11, K12).
+//
+// Design: every filter on this path is FIR except the SSB Butterworth (whose impulse response is below fp32
+// resolution after ~100 samples).  So instead of carrying liquid's per-stage windows as state, each workgroup
+// (slot, block) re-derives the windows by running the cascade over a short warm-up span that precedes its block:
+// the only carried state is (i) the integer bookkeeping (NCO phase word, half-band input fill, 24-bit resampler
+// phase), tracked in closed form, and (ii) the tail of each sample stream.  Blocks of one batch are therefore
+// independent and run concurrently; outputs are bit-for-bit independent of the batching.
+#pragma once
+#include "common.hpp"
+
+namespace csdr {
+
+constexpr int kMaxHb = 10;        // half-band stages supported per resampler
+constexpr int kHbMaxM = 10;       // largest half-band m (taps: 2m on the filtered branch)
+constexpr int kArmTaps = 14;      // arbitrary resampler: 2 * 7 taps per arm
+constexpr int kArms = 256;
+constexpr int kMixHist = 16384;   // mixed-input history kept per slot (>= longest cascade span; S <= 8)
+constexpr int kIqHist = 256;      // resampled-IQ history kept per slot
+constexpr int kDHist = 64;        // scaled demodulator-output history kept per slot
+constexpr int kFeThreads = 256;
+constexpr int kFeChunk = 2048;    // input samples per inner iteration of the front-end
+constexpr int kFeTail = 24;       // per-stage carried tail (>= 2 * kHbMaxM)
+constexpr int kFeZTail = 16;      // carried tail of the half-band chain output (>= 13)
+
+struct ResampCfg {                // one msresamp (complex decimator or real interpolator/decimator)
+    int32_t interp;               // 1: arbitrary stage first then x2 stages; 0: /2 stages first then arbitrary
+    int32_t S;
+    int32_t m_x[kMaxHb];          // execution order
+    float h_x[kMaxHb][kHbMaxM];   // execution order; first half of the symmetric filtered-branch taps
+    uint32_t step;
+    int32_t arms_idx;             // which [256][14] bank
+};
+
+struct SlotCfg {                  // static per configuration, lives in HBM
+    ResampCfg rs_iq;              // msresamp_crcf  (DemodulatorWorkerThread.cpp:100)
+    ResampCfg rs_au;              // msresamp_rrrf  (ModemAnalog.cpp:30)
+    int32_t modem;
+    int32_t pad0;
+    float2 *mixhist;              // [2][kMixHist]
+    float2 *iq;                   // [kIqHist + cap_iq]
+    float *d;                     // [cap_iq]     unscaled demodulator output of the batch
+    float *dh;                    // [kDHist]     scaled demodulator-output history
+    float *audio;                 // [cap_audio]
+    float *gains;                 // [max_blocks + 1]; gains[0] unused, gains[b+1] = gain of block b
+    float *agc;                   // [3] aOutputCeil, aOutputCeilMA, aOutputCeilMAA (ModemAnalog.h)
+    float *blockmax;              // [max_blocks]
+    struct BlockOut *bout;        // [max_blocks]
+    int32_t cap_iq, cap_audio;
+};
+
+struct SlotDyn {                  // per batch
+    int32_t active;
+    int32_t chan;                 // data channel index in the post buffer
+    uint32_t theta0, dtheta;      // NCO phase word at batch start, increment
+    int32_t mixdir;               // 0: no shift, +1: mix up, -1: mix down
+    uint32_t buf0;                // msresamp_crcf buffer_index at batch start
+    uint32_t phase0;              // arbitrary resampler phase at batch start
+    uint32_t aphase0;             // audio arbitrary resampler phase at batch start
+    uint32_t abuf0;               // audio msresamp buffer_index (decimating audio path)
+    uint32_t ssb_theta0;          // SSB fs/4 oscillator phase word at batch start
+    int32_t hist_parity;
+    int32_t pad;
+};
+
+struct BlockPlan { int32_t j0, q0; };   // first IQ output / first audio-arbitrary output of the block (batch-relative)
+
+struct BlockOut {
+    double level_accum;
+    int32_t level_count;
+    float audio_peak;
+};
+
+// --- NCO: 1024-entry table, no interpolation (liquid 1.5.0 nco_crcf, both NCO and VCO types) -----------------
+__device__ inline void nco_sincos(const float *tab, uint32_t theta, float &s, float &c) {
+    const uint32_t idx = (theta + (1u << 21)) >> 22;
+    s = tab[idx & 1023u];
+    c = tab[(idx + 256u) & 1023u];
+}
+
+__device__ inline int64_t floor_div_pow2(int64_t v, int sh) { return v >> sh; }
+
+// closed form of the resampler loop: first output index whose phase lands at or after input K (K may be negative)
+__device__ inline int64_t resamp_first_out(int64_t K, uint32_t phase0, uint32_t step) {
+    const int64_t lim = K * (int64_t)(1 << 24) - (int64_t)phase0;   // need j*step >= lim
+    if (lim <= 0) {
+        // negative side: largest-magnitude j with j*step >= lim  ->  ceil(lim / step) for negative lim
+        return -((-lim) / (int64_t)step);
+    }
+    return (lim + step - 1) / step;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// D1: NCO shift + half-band decimator cascade + arbitrary polyphase resampler.   grid = (slot, block)
+// ------------------------------------------------------------------------------------------------------------
+// offset of stage e's (tail + data) region inside FeLds::E / FeLds::O
+__device__ inline int fe_off(int e) { return e * kFeTail + kFeChunk - (kFeChunk >> e); }
+
+struct FeLds {
+    float2 E[kFeChunk + kMaxHb * kFeTail];   // even-indexed inputs of every stage, stage after stage
+    float2 O[kFeChunk + kMaxHb * kFeTail];   // odd-indexed inputs
+    float2 Z[kFeZTail + kFeChunk];           // half-band chain output (input of the arbitrary resampler)
+    float tab[1024];
+    float hb[kMaxHb][kHbMaxM];
+};
+
+__global__ __launch_bounds__(kFeThreads) void demod_frontend(
+    const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
+    const float2 *__restrict__ chan_base, int64_t chan_stride, int Bc, int NB,
+    const float *__restrict__ arms_all, const float *__restrict__ sintab) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    FeLds &L = *reinterpret_cast<FeLds *>(smem_raw);
+
+    const int slot = slot_list[blockIdx.x];
+    const int b = blockIdx.y;
+    const SlotCfg &cfg = cfgs[slot];
+    const SlotDyn dyn = dyns[slot];
+    const int tid = threadIdx.x;
+    const int S = cfg.rs_iq.S;
+    const uint32_t step = cfg.rs_iq.step;
+    const float2 *__restrict__ chan = chan_base + (int64_t)dyn.chan * chan_stride;
+    const float2 *__restrict__ hist = cfg.mixhist + (size_t)dyn.hist_parity * kMixHist;
+    const float *__restrict__ arms = arms_all + (size_t)cfg.rs_iq.arms_idx * kArms * kArmTaps;
+
+    for (int i = tid; i < 1024; i += kFeThreads) L.tab[i] = sintab[i];
+    for (int i = tid; i < kMaxHb * kHbMaxM; i += kFeThreads) L.hb[i / kHbMaxM][i % kHbMaxM] = cfg.rs_iq.h_x[i / kHbMaxM][i % kHbMaxM];
+
+    // zeroed tails (stage e's buffers start at fe_off(e))
+    for (int i = tid; i < S * kFeTail; i += kFeThreads) {
+        const int e = i / kFeTail, k = i % kFeTail;
+        L.E[fe_off(e) + k] = make_float2(0.f, 0.f);
+        L.O[fe_off(e) + k] = make_float2(0.f, 0.f);
+    }
+    if (tid < kFeZTail) L.Z[tid] = make_float2(0.f, 0.f);
+
+    // --- index ranges (u-space: u = batch-relative input index + buf0; half-band output k covers u in [k 2^S, (k+1) 2^S))
+    const int64_t u_blk0 = (int64_t)dyn.buf0 + (int64_t)b * Bc, u_blk1 = u_blk0 + Bc;
+    const int64_t K0 = u_blk0 >> S, K1 = u_blk1 >> S;
+    const int64_t j0 = resamp_first_out(K0, dyn.phase0, step), j1 = resamp_first_out(K1, dyn.phase0, step);
+    int64_t lo = K0 - (kArmTaps - 1);
+    for (int e = S - 1; e >= 0; --e) lo = 2 * lo - (4 * cfg.rs_iq.m_x[e] - 2);
+    const int64_t u_lo = (lo >> S) << S;           // floor to a multiple of 2^S (also for negatives)
+    const int64_t u_stop = K1 << S;
+    const float zeta = 1.0f / (float)(1 << S);
+    const bool last_block = (b == NB - 1);
+
+    __syncthreads();
+
+    for (int64_t uc = u_lo; uc < u_stop; uc += kFeChunk) {
+        const int n = (int)min((int64_t)kFeChunk, u_stop - uc);
+        // 1. load + mix
+        for (int i = tid; i < n; i += kFeThreads) {
+            const int64_t rel = uc + i - (int64_t)dyn.buf0;
+            float2 v;
+            if (rel < 0) {
+                v = rel >= -(int64_t)kMixHist ? hist[kMixHist + rel] : make_float2(0.f, 0.f);
+            } else {
+                const float2 x = chan[rel];
+                if (dyn.mixdir == 0) v = x;
+                else {
+                    float s, c;
+                    nco_sincos(L.tab, dyn.theta0 + (uint32_t)rel * dyn.dtheta, s, c);
+                    if (dyn.mixdir < 0) v = make_float2(fmaf(x.x, c, x.y * s), fmaf(x.y, c, -x.x * s));   // x (c - j s)
+                    else                v = make_float2(fmaf(x.x, c, -x.y * s), fmaf(x.y, c, x.x * s));   // x (c + j s)
+                }
+            }
+            if (S == 0) L.Z[kFeZTail + i] = v;
+            else if (i & 1) L.O[fe_off(0) + kFeTail + (i >> 1)] = v;
+            else L.E[fe_off(0) + kFeTail + (i >> 1)] = v;
+        }
+        __syncthreads();
+        // 2. half-band stages:  y[k] = x[2(k-m)+1] + sum_{j<2m} h1[j] x[2(k-j)]   (no per-stage scaling; x 2^-S at the end)
+        int cnt = n;
+        for (int e = 0; e < S; ++e) {
+            cnt >>= 1;
+            const int m = cfg.rs_iq.m_x[e];
+            const float2 *Ein = L.E + fe_off(e) + kFeTail, *Oin = L.O + fe_off(e) + kFeTail;
+            for (int k = tid; k < cnt; k += kFeThreads) {
+                float2 d = Oin[k - m];
+                float ar = d.x, ai = d.y;
+                for (int j = 0; j < m; ++j) {
+                    const float h = L.hb[e][j];
+                    const float2 p = Ein[k - j], q = Ein[k - (2 * m - 1) + j];
+                    ar = fmaf(h, p.x + q.x, ar); ai = fmaf(h, p.y + q.y, ai);
+                }
+                if (e == S - 1) L.Z[kFeZTail + k] = make_float2(ar * zeta, ai * zeta);
+                else if (k & 1) L.O[fe_off(e + 1) + kFeTail + (k >> 1)] = make_float2(ar, ai);
+                else L.E[fe_off(e + 1) + kFeTail + (k >> 1)] = make_float2(ar, ai);
+            }
+            __syncthreads();
+        }
+        // 3. arbitrary resampler on Z for outputs whose input index falls in this chunk
+        const int64_t kz0 = uc >> S;
+        const int cz = n >> S;
+        int64_t ja = resamp_first_out(kz0, dyn.phase0, step), jb = resamp_first_out(kz0 + cz, dyn.phase0, step);
+        if (ja < j0) ja = j0;
+        if (jb > j1) jb = j1;
+        for (int64_t j = ja + tid; j < jb; j += kFeThreads) {
+            const int64_t P = (int64_t)dyn.phase0 + j * (int64_t)step;
+            const int kj = (int)((P >> 24) - kz0);
+            const int arm = (int)((P & 0xFFFFFF) >> 16);
+            const float *h = arms + arm * kArmTaps;
+            const float2 *z = L.Z + kFeZTail + kj - (kArmTaps - 1);
+            float ar = 0.f, ai = 0.f;
+#pragma unroll
+            for (int t = 0; t < kArmTaps; ++t) { ar = fmaf(h[t], z[t].x, ar); ai = fmaf(h[t], z[t].y, ai); }
+            cfg.iq[kIqHist + j] = make_float2(ar, ai);
+        }
+        __syncthreads();
+        // 4. carry tails to the front of every buffer
+        int c2 = n;
+        for (int e = 0; e < S; ++e) {
+            c2 >>= 1;
+            float2 ve, vo;
+            if (tid < kFeTail) { ve = L.E[fe_off(e) + c2 + tid]; vo = L.O[fe_off(e) + c2 + tid]; }
+            __syncthreads();
+            if (tid < kFeTail) { L.E[fe_off(e) + tid] = ve; L.O[fe_off(e) + tid] = vo; }
+        }
+        {
+            float2 vz;
+            const int czz = (S == 0) ? n : (n >> S);
+            if (tid < kFeZTail) vz = L.Z[czz + tid];
+            __syncthreads();
+            if (tid < kFeZTail) L.Z[tid] = vz;
+        }
+        __syncthreads();
+    }
+
+    // new mixed-input history (other parity): the last kMixHist samples of (old history ++ mixed batch)
+    if (last_block) {
+        float2 *hnew = cfg.mixhist + (size_t)(dyn.hist_parity ^ 1) * kMixHist;
+        const int64_t total = (int64_t)NB * Bc;
+        for (int i = tid; i < kMixHist; i += kFeThreads) {
+            const int64_t rel = total - kMixHist + i;
+            float2 v;
+            if (rel < 0) v = hist[kMixHist + rel];
+            else {
+                const float2 x = chan[rel];
+                if (dyn.mixdir == 0) v = x;
+                else {
+                    float s, c;
+                    nco_sincos(L.tab, dyn.theta0 + (uint32_t)rel * dyn.dtheta, s, c);
+                    if (dyn.mixdir < 0) v = make_float2(fmaf(x.x, c, x.y * s), fmaf(x.y, c, -x.x * s));
+                    else                v = make_float2(fmaf(x.x, c, -x.y * s), fmaf(x.y, c, x.x * s));
+                }
+            }
+            hnew[i] = v;
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// D2a: modem core -> unscaled demodulator output d[j] for the block, block maximum (auto-gain input) and the
+// IQ-based signal-level sum.   grid = (slot, block), 256 threads
+//   NBFM/FM : d = atan2f(Im(x conj x'), Re(x conj x')) / (2 pi kf), kf = 0.5      (freqdem, ModemNBFM.cpp:36)
+//   AM      : d = FIR51(|x|)                                                     (ModemAM.cpp:41-47)
+//   USB/LSB : fs/4 shift, 3 biquads, shift back, Hilbert c2r, keep upper/lower    (ModemUSB.cpp:54-61)
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kModemThreads = 256;
+constexpr int kModemMaxBlockIq = 4096;     // resampled samples of one block handled by one workgroup (LDS bound)
+constexpr int kAmTaps = 51;
+constexpr int kSsbWarm = 192;              // IIR warm-up span; |pole|^192 ~ 1e-22
+constexpr int kHilbM = 5;                  // firhilbf_create(5, 90): 21-tap half-band, 10 odd taps
+
+struct ModemConsts {
+    float am_taps[kAmTaps];                // h[i] multiplies |x|[j - i]
+    float sos_b[3][3], sos_a[3][3];        // Butterworth sections, execution order
+    float hilb[2 * kHilbM];                // hq[(n-1)/2] for odd delay n
+};
+
+__device__ inline double block_sum_double(double v, double *lds) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) lds[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += lds[i];
+    __syncthreads();
+    return r;   // valid in thread 0
+}
+__device__ inline float block_max_float(float v, float *lds) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) lds[w] = v;
+    __syncthreads();
+    float r = lds[0];
+    if (threadIdx.x == 0) for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = fmaxf(r, lds[i]);
+    __syncthreads();
+    return r;   // valid in thread 0
+}
+
+__global__ __launch_bounds__(kModemThreads) void demod_modem(
+    const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
+    const BlockPlan *__restrict__ plans, int NB, const ModemConsts *__restrict__ mc, const float *__restrict__ sintab) {
+    __shared__ float s_a[kModemMaxBlockIq + kSsbWarm + 64];   // AM: |x| ; SSB: real part stream
+    __shared__ float s_b[kModemMaxBlockIq + kSsbWarm + 64];   // SSB: imag part stream
+    __shared__ double s_red[kModemThreads / 64];
+    __shared__ float s_redf[kModemThreads / 64];
+
+    const int slot = slot_list[blockIdx.x], b = blockIdx.y, tid = threadIdx.x;
+    const SlotCfg &cfg = cfgs[slot];
+    const SlotDyn dyn = dyns[slot];
+    const BlockPlan *pl = plans + (size_t)slot * (NB + 1);
+    const int j0 = pl[b].j0, j1 = pl[b + 1].j0, n = j1 - j0;
+    const float2 *iq = cfg.iq + kIqHist;      // iq[j] valid for j >= -kIqHist
+    float *d = cfg.d;
+    float lmax = 0.0f;                         // aOutputCeil starts at 0 each block (ModemAnalog.cpp:73)
+    double lsum = 0.0;
+    int lcount = 0;
+
+    if (cfg.modem == CSDR_MODEM_NBFM || cfg.modem == CSDR_MODEM_FM) {
+        const float ref = 1.0f / (2.0f * 3.14159265358979323846f * 0.5f);
+        for (int i = tid; i < n; i += kModemThreads) {
+            const int j = j0 + i;
+            const float2 x = iq[j], p = iq[j - 1];
+            const float re = x.x * p.x + x.y * p.y, im = x.y * p.x - x.x * p.y;
+            const float v = atan2f(im, re) * ref;
+            d[j] = v;
+            lmax = fmaxf(lmax, v);
+            lsum += sqrt((double)x.x * (double)x.x + (double)x.y * (double)x.y);   // abMagnitude (DemodulatorThread.cpp:49-57)
+        }
+        lcount = n;
+    } else if (cfg.modem == CSDR_MODEM_AM) {
+        const int halo = kAmTaps - 1;
+        for (int i = tid; i < n + halo; i += kModemThreads) {
+            const float2 x = iq[j0 - halo + i];
+            s_a[i] = sqrtf(x.x * x.x + x.y * x.y);
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += kModemThreads) {
+            float acc = 0.f;
+            for (int t = 0; t < kAmTaps; ++t) acc = fmaf(mc->am_taps[t], s_a[i + halo - t], acc);
+            d[j0 + i] = acc;
+            lmax = fmaxf(lmax, acc);
+        }
+    } else {  // USB / LSB
+        const bool usb = (cfg.modem == CSDR_MODEM_USB);
+        const int hh = 4 * kHilbM;                 // Hilbert span
+        const int pre = kSsbWarm + hh;             // samples before j0 that are processed
+        const int tot = n + pre;
+        // 1. shift by fs/4 (oscillator is stepped BEFORE use: theta_j = theta0 + (j+1) * 2^30)
+        for (int i = tid; i < tot; i += kModemThreads) {
+            const int j = j0 - pre + i;
+            const float2 x = iq[j];
+            float s, c;
+            nco_sincos(sintab, dyn.ssb_theta0 + (uint32_t)(j + 1) * (1u << 30), s, c);
+            float2 v = usb ? make_float2(x.x * c + x.y * s, x.y * c - x.x * s)      // mix down
+                           : make_float2(x.x * c - x.y * s, x.y * c + x.x * s);     // mix up
+            s_a[i] = v.x; s_b[i] = v.y;
+        }
+        __syncthreads();
+        // 2. three direct-form-II biquads, real coefficients: real and imaginary streams are independent (lanes 0, 1)
+        if (tid < 2) {
+            float *st = tid ? s_b : s_a;
+            float v1[3] = {0.f, 0.f, 0.f}, v2[3] = {0.f, 0.f, 0.f};
+            for (int i = 0; i < tot; ++i) {
+                float t = st[i];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const float v0 = t - mc->sos_a[q][1] * v1[q] - mc->sos_a[q][2] * v2[q];
+                    t = mc->sos_b[q][0] * v0 + mc->sos_b[q][1] * v1[q] + mc->sos_b[q][2] * v2[q];
+                    v2[q] = v1[q]; v1[q] = v0;
+                }
+                st[i] = t;
+            }
+        }
+        __syncthreads();
+        // 3. shift back (same oscillator phase), in place
+        for (int i = tid; i < tot; i += kModemThreads) {
+            const int j = j0 - pre + i;
+            float s, c;
+            nco_sincos(sintab, dyn.ssb_theta0 + (uint32_t)(j + 1) * (1u << 30), s, c);
+            const float xr = s_a[i], xi = s_b[i];
+            float2 v = usb ? make_float2(xr * c - xi * s, xi * c + xr * s) : make_float2(xr * c + xi * s, xi * c - xr * s);
+            s_a[i] = v.x; s_b[i] = v.y;
+        }
+        __syncthreads();
+        // 4. Hilbert c2r: yi = re[k - 2m], yq = sum_{n odd} hq[(n-1)/2] im[k - n]; lower = yi + yq, upper = yi - yq
+        for (int i = tid; i < n; i += kModemThreads) {
+            const int k = i + pre;
+            const float yi = s_a[k - 2 * kHilbM];
+            float yq = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2 * kHilbM; ++t) yq = fmaf(mc->hilb[t], s_b[k - (2 * t + 1)], yq);
+            const float v = usb ? (yi - yq) : (yi + yq);
+            d[j0 + i] = v;
+            lmax = fmaxf(lmax, v);
+        }
+    }
+    const float bm = block_max_float(lmax, s_redf);
+    const double bs = block_sum_double(lsum, s_red);
+    if (tid == 0) {
+        cfg.blockmax[b] = bm;
+        cfg.bout[b].level_accum = bs;
+        cfg.bout[b].level_count = lcount;
+        cfg.bout[b].audio_peak = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// D2g: auto-gain recurrence across blocks (ModemAnalog.cpp:70-86): one thread per slot, sequential over the batch
+// ------------------------------------------------------------------------------------------------------------
+__global__ void demod_gain(const SlotCfg *__restrict__ cfgs, const int *__restrict__ slot_list, int n_slots, int NB) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    const SlotCfg &cfg = cfgs[slot_list[i]];
+    const bool autogain = !(cfg.modem == CSDR_MODEM_NBFM || cfg.modem == CSDR_MODEM_FM);
+    float ceil_ = cfg.agc[0], ma = cfg.agc[1], maa = cfg.agc[2];
+    for (int b = 0; b < NB; ++b) {
+        float g = 1.0f;
+        if (autogain) {
+            ma = ma + (ceil_ - ma) * 0.025f;
+            maa = maa + (ma - maa) * 0.025f;
+            ceil_ = cfg.blockmax[b];
+            g = 0.5f / maa;
+        }
+        cfg.gains[b + 1] = g;
+    }
+    cfg.agc[0] = ceil_; cfg.agc[1] = ma; cfg.agc[2] = maa;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// D2b: auto-gain scaling + msresamp_rrrf to the audio rate (interpolating form: arbitrary stage then x2 stages),
+// audio peak and (for useSignalOutput modems) the audio-based level sum.   grid = (slot, block)
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kAudioMaxOut = 4096;         // audio samples of one block handled by one workgroup
+
+__global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
+    const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
+    const BlockPlan *__restrict__ plans, int NB, const float *__restrict__ arms_all) {
+    __shared__ float s_w0[kAudioMaxOut + 64];
+    __shared__ float s_w1[kAudioMaxOut + 64];
+    __shared__ double s_red[kModemThreads / 64];
+    __shared__ float s_redf[kModemThreads / 64];
+    __shared__ int s_jb[66];
+
+    const int slot = slot_list[blockIdx.x], b = blockIdx.y, tid = threadIdx.x;
+    const SlotCfg &cfg = cfgs[slot];
+    const SlotDyn dyn = dyns[slot];
+    const BlockPlan *pl = plans + (size_t)slot * (NB + 1);
+    const ResampCfg &au = cfg.rs_au;
+    const int aS = au.S;
+    const int64_t Q0 = pl[b].q0, Q1 = pl[b + 1].q0;               // arbitrary-stage outputs of this block
+    const int64_t A0 = Q0 << aS, A1 = Q1 << aS;                    // audio samples of this block
+    const int n_audio = (int)(A1 - A0);
+    const float *arms = arms_all + (size_t)au.arms_idx * kArms * kArmTaps;
+
+    // backward range propagation: lo[s] = first needed index of the input of stage s (s = 0 is v = arbitrary-stage output)
+    int64_t lo[kMaxHb + 1];
+    lo[aS] = A0;
+    for (int s = aS - 1; s >= 0; --s) lo[s] = (lo[s + 1] >> 1) - (2 * au.m_x[s] - 1);
+    int64_t hi[kMaxHb + 1];
+    hi[aS] = A1;
+    for (int s = aS - 1; s >= 0; --s) hi[s] = (hi[s + 1] + 1) >> 1;
+
+    // 1. arbitrary stage: v[q] for q in [lo[0], hi[0]) into s_w0
+    const int nv = (int)(hi[0] - lo[0]);
+    for (int i = tid; i < nv; i += kModemThreads) {
+        const int64_t q = lo[0] + i;
+        const int64_t P = (int64_t)dyn.aphase0 + q * (int64_t)au.step;
+        const int64_t jq = P >> 24;
+        const int arm = (int)((P & 0xFFFFFF) >> 16);
+        const float *h = arms + arm * kArmTaps;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < kArmTaps; ++t) {
+            const int64_t j = jq - (kArmTaps - 1) + t;
+            float x;
+            if (j < 0) x = j >= -(int64_t)kDHist ? cfg.dh[kDHist + j] : 0.f;
+            else {
+                // gain of the block that sample j belongs to (blocks are short lists: walk back from b)
+                int bb = b;
+                while (bb > 0 && j < pl[bb].j0) --bb;
+                while (bb < NB - 1 && j >= pl[bb + 1].j0) ++bb;
+                x = cfg.d[j] * cfg.gains[bb + 1];
+            }
+            acc = fmaf(h[t], x, acc);
+        }
+        s_w0[i] = acc;
+    }
+    __syncthreads();
+    // 2. x2 stages: w'[2q] = w[q - m], w'[2q+1] = sum_j h1[j] w[q - j]
+    float *src = s_w0, *dst = s_w1;
+    for (int s = 0; s < aS; ++s) {
+        const int m = au.m_x[s];
+        const int64_t olo = lo[s + 1], ohi = hi[s + 1], ilo = lo[s];
+        const int nout = (int)(ohi - olo);
+        for (int i = tid; i < nout; i += kModemThreads) {
+            const int64_t a = olo + i;
+            const int64_t q = a >> 1;
+            const int qi = (int)(q - ilo);
+            float v;
+            if ((a & 1) == 0) v = src[qi - m];
+            else {
+                v = 0.f;
+                for (int j = 0; j < m; ++j) v = fmaf(au.h_x[s][j], src[qi - j] + src[qi - (2 * m - 1) + j], v);
+            }
+            dst[i] = v;
+        }
+        __syncthreads();
+        float *t = src; src = dst; dst = t;
+    }
+    // 3. write audio, peak, level
+    float lpk = 0.f;
+    double lsum = 0.0;
+    const int aoff = (int)A0;
+    for (int i = tid; i < n_audio; i += kModemThreads) {
+        const float v = src[i];
+        cfg.audio[aoff + i] = v;
+        lpk = fmaxf(lpk, fabsf(v));
+        lsum += (double)fabsf(v);
+    }
+    const float pk = block_max_float(lpk, s_redf);
+    const double sm = block_sum_double(lsum, s_red);
+    if (tid == 0) {
+        cfg.bout[b].audio_peak = pk;
+        if (!(cfg.modem == CSDR_MODEM_NBFM || cfg.modem == CSDR_MODEM_FM)) {   // useSignalOutput(true) modems
+            cfg.bout[b].level_accum = sm;
+            cfg.bout[b].level_count = n_audio;
+        }
+    }
+    (void)s_jb;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// tails: carry the last kIqHist resampled-IQ samples and the last kDHist scaled demodulator outputs to the
+// history regions for the next batch.   grid = slots, 256 threads
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void demod_tails(const SlotCfg *__restrict__ cfgs, const int *__restrict__ slot_list,
+                                                    const BlockPlan *__restrict__ plans, int NB) {
+    const int slot = slot_list[blockIdx.x], tid = threadIdx.x;
+    const SlotCfg &cfg = cfgs[slot];
+    const BlockPlan *pl = plans + (size_t)slot * (NB + 1);
+    const int J = pl[NB].j0;
+    // iq: new history = stream positions [J - kIqHist, J) (stream index j maps to cfg.iq[kIqHist + j])
+    float2 v = make_float2(0.f, 0.f);
+    if (tid < kIqHist) v = cfg.iq[J + tid];
+    float dv = 0.f;
+    if (tid < kDHist) {
+        const int j = J - kDHist + tid;
+        if (j < 0) dv = cfg.dh[kDHist + j];
+        else {
+            int bb = NB - 1;
+            while (bb > 0 && j < pl[bb].j0) --bb;
+            dv = cfg.d[j] * cfg.gains[bb + 1];
+        }
+    }
+    __syncthreads();
+    if (tid < kIqHist) cfg.iq[tid] = v;
+    if (tid < kDHist) cfg.dh[tid] = dv;
+}
+
+}  // namespace csdr

@@ -1,0 +1,209 @@
+"""Thin Python host objects over the C ABI (tests, bench, smoke).  Names follow the reference objects whose
+arithmetic each handle replaces: SDRPostThread (src/sdr/SDRPostThread.cpp), DemodulatorInstance's Pre/Demod
+threads + Modem (src/demod/, src/modules/modem/), SpectrumVisualProcessor (src/process/).
+
+Inputs may be numpy complex64 arrays (host, staged by the library) or torch CUDA tensors (HBM resident, passed by
+device pointer).  No computation happens in Python; without the HIP library or a GPU everything raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import hip as H
+
+
+def _as_iq_arg(iq):
+    """-> (pointer, is_dev, n_complex, keepalive)"""
+    if isinstance(iq, np.ndarray):
+        a = np.ascontiguousarray(iq, dtype=np.complex64)
+        return a.ctypes.data_as(C.c_void_p), 0, a.size, a
+    # torch tensor on the GPU: complex64 [n] or float32 [n, 2] / [2n]
+    import torch
+    if not isinstance(iq, torch.Tensor) or not iq.is_cuda:
+        raise TypeError("iq must be a numpy array or a CUDA torch tensor")
+    t = iq.contiguous()
+    if t.dtype == torch.complex64:
+        n = t.numel()
+    elif t.dtype == torch.float32:
+        n = t.numel() // 2
+    else:
+        raise TypeError("iq tensor must be complex64 or float32")
+    return C.c_void_p(t.data_ptr()), 1, n, t
+
+
+class Context:
+    """device + stream (csdr_ctx).  stream=None creates a private stream; pass torch's raw stream to share it."""
+
+    def __init__(self, device=0, stream=None):
+        self._l = H.lib()
+        self.h = C.c_void_p()
+        H.check(self._l.csdr_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self.h)))
+
+    def synchronize(self):
+        H.check(self._l.csdr_ctx_synchronize(self.h))
+
+    def timer_start(self):
+        H.check(self._l.csdr_ctx_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        H.check(self._l.csdr_ctx_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self.h:
+            self._l.csdr_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SDRPost:
+    """SDRPostThread's arithmetic (csdr_post): DC blocker (1 channel) or firpfbch analyzer (M channels)."""
+
+    def __init__(self, ctx, sample_rate, num_channels, max_block_len, max_blocks=1):
+        self._l = H.lib()
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        H.check(self._l.csdr_post_create(ctx.h, C.byref(self.h)))
+        mode = H.CSDR_POST_SINGLE if num_channels == 1 else H.CSDR_POST_PFBCH
+        H.check(self._l.csdr_post_configure(self.h, int(sample_rate), int(num_channels), mode, int(max_block_len), int(max_blocks)))
+        self.num_channels = num_channels
+        self.sample_rate = sample_rate
+
+    def set_active_channels(self, channels=None):
+        if channels is None:
+            H.check(self._l.csdr_post_set_active_channels(self.h, None, 0))
+        else:
+            a = np.ascontiguousarray(channels, dtype=np.int32)
+            H.check(self._l.csdr_post_set_active_channels(self.h, a.ctypes.data_as(C.c_void_p), a.size))
+
+    def execute(self, iq, n_blocks, block_len, frequency):
+        p, is_dev, n, keep = _as_iq_arg(iq)
+        if n < n_blocks * block_len:
+            raise ValueError("iq holds %d samples, need %d" % (n, n_blocks * block_len))
+        H.check(self._l.csdr_post_execute(self.h, p, is_dev, int(n_blocks), int(block_len), int(frequency)))
+        self._keep = keep
+        self._last = (n_blocks, block_len)
+
+    @property
+    def channel_bandwidth(self):
+        return self._l.csdr_post_channel_bandwidth(self.h)
+
+    def channel_center(self, i):
+        return self._l.csdr_post_channel_center(self.h, i)
+
+    def channel_at(self, f):
+        return self._l.csdr_post_channel_at(self.h, int(f))
+
+    def read_channel(self, ch):
+        nb, bl = self._last
+        cap = nb * (bl // self.num_channels)
+        out = np.empty(cap, np.complex64)
+        n = C.c_int()
+        H.check(self._l.csdr_post_read_channel(self.h, int(ch), out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        return out[:n.value]
+
+    def close(self):
+        if self.h:
+            self._l.csdr_post_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class DemodBank:
+    """N demodulator slots (csdr_bank); one slot = one DemodulatorInstance's Pre + Demod thread arithmetic."""
+
+    def __init__(self, ctx, max_demods, max_blocks=1):
+        self._l = H.lib()
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        self.max_blocks = max_blocks
+        H.check(self._l.csdr_bank_create(ctx.h, int(max_demods), int(max_blocks), C.byref(self.h)))
+
+    def configure(self, slot, post, modem, bandwidth, frequency, audio_sample_rate=48000):
+        m = H.MODEM_BY_NAME[modem] if isinstance(modem, str) else int(modem)
+        p = H.DemodParams(m, int(bandwidth), int(audio_sample_rate), 0, int(frequency))
+        H.check(self._l.csdr_bank_configure_slot(self.h, int(slot), C.byref(p), post.h))
+
+    def set_frequency(self, slot, f):
+        H.check(self._l.csdr_bank_set_frequency(self.h, int(slot), int(f)))
+
+    def set_active(self, slot, active):
+        H.check(self._l.csdr_bank_set_active(self.h, int(slot), int(bool(active))))
+
+    def execute(self, post):
+        H.check(self._l.csdr_bank_execute(self.h, post.h))
+
+    def results(self, slot):
+        arr = (H.BlockResult * self.max_blocks)()
+        n = C.c_int()
+        H.check(self._l.csdr_bank_fetch_results(self.h, int(slot), arr, self.max_blocks, C.byref(n)))
+        return [arr[i] for i in range(n.value)]
+
+    def audio(self, slot, cap=1 << 22):
+        out = np.empty(cap, np.float32)
+        n = C.c_int()
+        H.check(self._l.csdr_bank_fetch_audio(self.h, int(slot), out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def iq(self, slot, cap=1 << 22):
+        out = np.empty(cap, np.complex64)
+        n = C.c_int()
+        H.check(self._l.csdr_bank_fetch_iq(self.h, int(slot), out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def total_audio(self):
+        n = C.c_int64()
+        H.check(self._l.csdr_bank_total_audio(self.h, C.byref(n)))
+        return n.value
+
+    def close(self):
+        if self.h:
+            self._l.csdr_bank_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class SpectrumProcessor:
+    """SpectrumVisualProcessor's arithmetic (csdr_spec), full-span view."""
+
+    def __init__(self, ctx, fft_size, max_frames=1):
+        self._l = H.lib()
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        self.fft_size = fft_size
+        H.check(self._l.csdr_spec_create(ctx.h, C.byref(self.h)))
+        H.check(self._l.csdr_spec_setup(self.h, int(fft_size), int(max_frames)))
+
+    def set_average_rate(self, r):
+        H.check(self._l.csdr_spec_set_average_rate(self.h, float(r)))
+
+    def process(self, iq, n_blocks, block_len, contiguous=False):
+        p, is_dev, n, keep = _as_iq_arg(iq)
+        if n < n_blocks * block_len:
+            raise ValueError("iq holds %d samples, need %d" % (n, n_blocks * block_len))
+        mode = H.CSDR_SPEC_CONTIGUOUS if contiguous else H.CSDR_SPEC_FIRST_FRAME
+        H.check(self._l.csdr_spec_process(self.h, p, is_dev, int(n_blocks), int(block_len), mode))
+        self._keep = keep
+        return self._l.csdr_spec_frames(self.h)
+
+    def fetch(self, frame):
+        pts = np.empty(2 * self.fft_size, np.float32)
+        ce, fl = C.c_double(), C.c_double()
+        H.check(self._l.csdr_spec_fetch(self.h, int(frame), pts.ctypes.data_as(C.c_void_p), pts.size, C.byref(ce), C.byref(fl)))
+        return pts, ce.value, fl.value
+
+    def fft_only(self, x):
+        a = np.ascontiguousarray(x, dtype=np.complex64)
+        assert a.size == 2 * self.fft_size
+        out = np.empty(a.size, np.complex64)
+        H.check(self._l.csdr_spec_fft_only(self.h, a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def close(self):
+        if self.h:
+            self._l.csdr_spec_destroy(self.h)
+            self.h = C.c_void_p()

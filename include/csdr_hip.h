@@ -1,0 +1,165 @@
+/*
+ * csdr_hip.h -- C ABI of the MI355X-native streaming-IQ DSP hot path of CubicSDR.
+ *
+ * The reference (cjcliffe/CubicSDR v0.2.8) has no FFI: its hot path is C++ classes calling liquid-dsp
+ * (SURVEY.md section 8b).  This header is the boundary a maintainer binds from those classes; every entry
+ * point names the reference code it replaces (file:line relative to the reference tree).  Plain pointers
+ * and sizes only; every call returns 0 on success or a negative CSDR_E* code and never throws.  A handle
+ * must be used from one thread at a time (same rule as the reference objects: one owning IOThread each).
+ *
+ * Sample format everywhere: interleaved complex float32 {re, im} (liquid_float_complex, liquid.h:149-157).
+ * "dev" pointers are HIP device pointers resident in HBM; "host" pointers are ordinary host memory.
+ *
+ * Batching: the reference handles one SDRThreadIQData block per loop turn (60 blocks/s,
+ * SoapySDRThread.cpp:12,668-674).  Every *_execute call here takes `n_blocks` consecutive blocks of
+ * `block_len` samples and produces exactly the per-block results the reference would produce for that
+ * sequence (per-block output counts included); n_blocks = 1 is the real-time case.
+ */
+#ifndef CSDR_HIP_H
+#define CSDR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSDR_OK            0
+#define CSDR_EINVAL       -1   /* bad argument / unsupported parameter */
+#define CSDR_ENOMEM       -2   /* host or device allocation failed */
+#define CSDR_EHIP         -3   /* a HIP runtime call failed (see csdr_last_error) */
+#define CSDR_ESTATE       -4   /* object not configured / wrong call order */
+#define CSDR_ERANGE       -5   /* capacity exceeded (block too long, too many demods, ...) */
+#define CSDR_EUNSUPPORTED -6   /* valid in the reference, not built yet (see DESIGN.md out-of-scope) */
+
+typedef struct csdr_ctx   csdr_ctx;    /* device + stream */
+typedef struct csdr_post  csdr_post;   /* SDRPostThread's arithmetic: DC blocker | firpfbch channelizer */
+typedef struct csdr_bank  csdr_bank;   /* N x {DemodulatorPreThread + DemodulatorThread + Modem} arithmetic */
+typedef struct csdr_spec  csdr_spec;   /* SpectrumVisualProcessor's arithmetic */
+
+/* ------------------------------------------------------------------ context */
+int         csdr_abi_version(void);
+const char *csdr_strerror(int code);
+const char *csdr_last_error(void);                 /* thread-local detail string of the last failure */
+
+/* `hip_stream`: an existing hipStream_t to launch on (e.g. PyTorch's current stream) or NULL to create one. */
+int  csdr_ctx_create(int device, void *hip_stream, csdr_ctx **out);
+void csdr_ctx_destroy(csdr_ctx *ctx);
+int  csdr_ctx_synchronize(csdr_ctx *ctx);
+void *csdr_ctx_stream(csdr_ctx *ctx);              /* the hipStream_t every kernel of this ctx is launched on */
+/* HIP-event timer on the ctx stream (bench.py roofline leg): start/stop bracket, returns milliseconds. */
+int  csdr_ctx_timer_start(csdr_ctx *ctx);
+int  csdr_ctx_timer_stop(csdr_ctx *ctx, float *ms);
+/* raw device memory for callers without a GPU array library (tests written in C/C++) */
+int  csdr_dev_alloc(csdr_ctx *ctx, uint64_t bytes, void **dev);
+int  csdr_dev_free(csdr_ctx *ctx, void *dev);
+int  csdr_dev_upload(csdr_ctx *ctx, void *dev, const void *host, uint64_t bytes);
+int  csdr_dev_download(csdr_ctx *ctx, void *host, const void *dev, uint64_t bytes);
+
+/* ------------------------------------------------------------------ SDRPostThread (src/sdr/SDRPostThread.cpp)
+ * replaces: iirfilt_crcf_create_dc_blocker :29, runSingleCH :248-299 (iirfilt_crcf_execute_block :284),
+ * initPFBCH :401-414 (firpfbch_crcf_create_kaiser(ANALYZER,M,4,60) :406, chanBw = sampleRate/numChannels :408),
+ * runPFBCH :416-455 (firpfbch_crcf_analyzer_execute :449-451), de-interleave + channel-0 DC block :364-382,
+ * updateChannels :116-124, getChannelAt :128-139. */
+#define CSDR_POST_SINGLE 0   /* numChannels == 1 : DC-blocked full-rate stream is "channel 0" */
+#define CSDR_POST_PFBCH  1   /* SDRPostPFBCH  (SDRPostThread.h:9-12), critically sampled analyzer */
+
+int  csdr_post_create(csdr_ctx *ctx, csdr_post **out);
+void csdr_post_destroy(csdr_post *post);
+/* (re)build for a sample rate / channel count; resets filter state like initPFBCH(). max_* size the HBM buffers. */
+int  csdr_post_configure(csdr_post *post, int64_t sample_rate, int num_channels, int mode,
+                         int max_block_len, int max_blocks);
+/* Process n_blocks x block_len input samples (block_len % num_channels == 0).  `iq` is device memory when
+ * iq_is_dev != 0, else host memory that is staged through a pinned buffer.  Output stays in HBM, channel-major. */
+int  csdr_post_execute(csdr_post *post, const float *iq, int iq_is_dev, int n_blocks, int block_len,
+                       int64_t frequency);
+/* Optional: produce only these channels (the reference skips channels without consumers, :336-339).  NULL = all.
+ * The wrap channel index M is accepted as an alias of M/2. */
+int  csdr_post_set_active_channels(csdr_post *post, const int *channels, int n);
+int64_t csdr_post_channel_bandwidth(const csdr_post *post);                  /* chanBw (:408) */
+int     csdr_post_num_channels(const csdr_post *post);
+int64_t csdr_post_channel_center(const csdr_post *post, int i);              /* chanCenters[i], i in [0, M] (:116-124) */
+int     csdr_post_channel_at(const csdr_post *post, int64_t frequency);      /* getChannelAt (:128-139) */
+/* copy one channel's samples of the last execute to the host (tests / demod-visual tap); ch == M is the wrap
+ * channel (alias of M/2, :359-361).  *n receives the number of complex samples written. */
+int  csdr_post_read_channel(csdr_post *post, int ch, float *host_out, int cap_samples, int *n);
+
+/* ------------------------------------------------------------------ demodulator bank
+ * One slot == one DemodulatorInstance's DSP state: NCO shift + msresamp_crcf decimator
+ * (src/demod/DemodulatorPreThread.cpp:154-209, built by DemodulatorWorkerThread.cpp:63-101), the modem
+ * (src/modules/modem/analog/Modem{NBFM,FM,AM,USB,LSB}.cpp ::demodulate), ModemAnalog::buildAudioOutput
+ * (ModemAnalog.cpp:67-93) and the level / peak measurements of DemodulatorThread::run
+ * (DemodulatorThread.cpp:142-152,223-233). */
+#define CSDR_MODEM_NBFM 0   /* ModemNBFM.cpp:26-39  freqdem kf=0.5, no auto-gain */
+#define CSDR_MODEM_FM   1   /* ModemFM.cpp:26-39    same arithmetic, 200 kHz default bandwidth */
+#define CSDR_MODEM_AM   2   /* ModemAM.cpp:29-50    |x| -> 51-tap DC notch, auto-gain */
+#define CSDR_MODEM_USB  3   /* ModemUSB.cpp:43-64   fs/4 shift, 6th-order Butterworth, Hilbert, upper sideband */
+#define CSDR_MODEM_LSB  4   /* ModemLSB.cpp         mirror of USB, lower sideband */
+
+typedef struct csdr_demod_params {
+    int32_t modem;             /* CSDR_MODEM_* (DemodulatorInstance::setDemodulatorType) */
+    int32_t bandwidth;         /* Hz, modem input rate after checkSampleRate() (setBandwidth) */
+    int32_t audio_sample_rate; /* Hz (setAudioSampleRate; 48000 in the reference, DemodulatorInstance.cpp:345) */
+    int32_t reserved;
+    int64_t frequency;         /* Hz, demodulator centre (setFrequency) */
+} csdr_demod_params;
+
+/* per (slot, block) results, fetched after csdr_bank_execute */
+typedef struct csdr_block_result {
+    int32_t  n_iq;          /* samples written by msresamp_crcf_execute for this block (numWritten, :209) */
+    int32_t  n_audio;       /* numAudioWritten (ModemAnalog.cpp:88) */
+    int32_t  audio_offset;  /* offset of this block's audio inside the slot's audio buffer of this execute */
+    int32_t  skipped;       /* 1 when the block was skipped by the |shift| > 0.75*rate rule (:161-165) */
+    double   level_accum;   /* sum of |x| (IQ for NBFM/FM, audio for AM/USB/LSB: useSignalOutput) */
+    int32_t  level_count;   /* number of terms in level_accum */
+    float    audio_peak;    /* max |audio| (DemodulatorThread.cpp:223-233) */
+    uint32_t nco_theta;     /* NCO phase word after the block (bit-exact item) */
+    uint32_t resamp_phase;  /* arbitrary-resampler 24-bit phase after the block (bit-exact item) */
+    uint32_t buffer_index;  /* msresamp half-band input buffer fill after the block (bit-exact item) */
+    uint32_t reserved;
+} csdr_block_result;
+
+int  csdr_bank_create(csdr_ctx *ctx, int max_demods, int max_blocks, csdr_bank **out);
+void csdr_bank_destroy(csdr_bank *bank);
+/* (Re)build slot `slot` (MAKE_DEMOD / BUILD_FILTERS of DemodulatorWorkerThread.cpp:40-101): designs the filters
+ * on the host for the CURRENT channel rate of `post` and resets the slot's state, like the worker thread
+ * handing over a fresh msresamp/modem/kit.  Changing only `frequency` later: csdr_bank_set_frequency. */
+int  csdr_bank_configure_slot(csdr_bank *bank, int slot, const csdr_demod_params *p, const csdr_post *post);
+int  csdr_bank_set_frequency(csdr_bank *bank, int slot, int64_t frequency);
+int  csdr_bank_set_active(csdr_bank *bank, int slot, int active);
+/* Route every active slot to its channel of `post`'s last execute (runDemodChannels :303-398) and run
+ * NCO + decimator + modem + audio resampler for all of them, all blocks, in a handful of launches. */
+int  csdr_bank_execute(csdr_bank *bank, const csdr_post *post);
+/* results of the last execute (blocks in order); synchronises the stream */
+int  csdr_bank_fetch_results(csdr_bank *bank, int slot, csdr_block_result *out, int cap_blocks, int *n_blocks);
+int  csdr_bank_fetch_audio(csdr_bank *bank, int slot, float *host_out, int cap_samples, int *n);
+int  csdr_bank_fetch_iq(csdr_bank *bank, int slot, float *host_out, int cap_samples, int *n);   /* resampled IQ */
+/* device-side total of audio samples produced by the last execute over all slots (bench sanity) */
+int  csdr_bank_total_audio(csdr_bank *bank, int64_t *n);
+
+/* ------------------------------------------------------------------ SpectrumVisualProcessor (src/process/SpectrumVisualProcessor.cpp)
+ * replaces: setup :140-178 (fft_create_plan(2*fftSize, FORWARD)), process :212-637 full-span view:
+ * frame selection :387-421, fft_execute :439, magnitude + fftshift :441-452, double EMA + min/max :494-530,
+ * floor/ceil EMAs :518-530, display resample + log10 scaling :532-576. */
+#define CSDR_SPEC_FIRST_FRAME 0  /* reference cadence: only the first 2*fftSize samples of each block (:387-397) */
+#define CSDR_SPEC_CONTIGUOUS  1  /* every sample belongs to one non-overlapping 2*fftSize frame */
+
+int  csdr_spec_create(csdr_ctx *ctx, csdr_spec **out);
+void csdr_spec_destroy(csdr_spec *spec);
+int  csdr_spec_setup(csdr_spec *spec, int fft_size, int max_frames);      /* setup(fftSize_in) */
+int  csdr_spec_set_average_rate(csdr_spec *spec, float rate);             /* setFFTAverageRate, default 0.65 (:36) */
+int  csdr_spec_set_scale_factor(csdr_spec *spec, float sf);               /* setScaleFactor, default 1 */
+/* Run the spectrum path over n_blocks x block_len samples; frames are taken per `mode`.  Every frame updates the
+ * averagers in order, exactly as one process() call per frame would. */
+int  csdr_spec_process(csdr_spec *spec, const float *iq, int iq_is_dev, int n_blocks, int block_len, int mode);
+int  csdr_spec_frames(const csdr_spec *spec);                             /* frames produced by the last process */
+/* SpectrumVisualData of frame `frame` of the last process: spectrum_points[2*fftSize] = (x, y) pairs,
+ * fft_ceiling, fft_floor (SpectrumVisualProcessor.h:14-23; :626-627). */
+int  csdr_spec_fetch(csdr_spec *spec, int frame, float *points_host, int cap_floats, double *fft_ceiling, double *fft_floor);
+/* raw forward FFT of one 2*fftSize frame (K13 alone), for parity tests against fft_execute */
+int  csdr_spec_fft_only(csdr_spec *spec, const float *iq_host, float *out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSDR_HIP_H */

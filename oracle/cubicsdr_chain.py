@@ -1,0 +1,224 @@
+"""CPU ORACLE (TEST INFRASTRUCTURE ONLY): restatement of CubicSDR's hot-path control flow around liquid-dsp.
+
+Each class follows one reference object and calls the liquid functions that object calls, in the same order,
+through oracle/liquid_api.py -- so it runs either on the reference's own liquid-dsp 1.5.0 binary (backend "ref")
+or on the C restatement oracle/liquid_port.c (backend "port").  File:line citations are into /root/reference.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import liquid_api as A
+
+
+def _cptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class RefSDRPost:
+    """SDRPostThread (src/sdr/SDRPostThread.cpp): runSingleCH :248-299, runPFBCH :416-455, runDemodChannels :303-398."""
+
+    def __init__(self, backend, sample_rate, num_channels):
+        self.L = A.load(backend)
+        self.sample_rate = int(sample_rate)
+        self.M = int(num_channels)
+        self.dc = self.L.iirfilt_crcf_create_dc_blocker(0.0005)          # :29
+        self.frequency = 0
+        if self.M > 1:
+            self.chan = self.L.firpfbch_crcf_create_kaiser(A.LIQUID_ANALYZER, self.M, 4, 60.0)   # :406
+            self.chan_bw = self.sample_rate // self.M                    # :408 (integer division)
+        else:
+            self.chan = None
+            self.chan_bw = self.sample_rate
+        self.centers = [0] * (self.M + 1)
+        self.data_out = None
+
+    def update_channels(self):                                           # :116-124
+        M = self.M
+        for i in range(M // 2):
+            ofs = self.chan_bw * i
+            self.centers[i] = self.frequency + ofs
+            self.centers[i + M // 2] = self.frequency - (self.sample_rate // 2) + ofs
+        self.centers[M] = self.frequency + (self.sample_rate // 2)
+
+    def channel_at(self, f):                                             # :128-139
+        if self.M == 1:
+            return 0
+        chan, min_delta = -1, self.sample_rate
+        for i in range(self.M + 1):
+            d = abs(f - self.centers[i])
+            if d < min_delta:
+                min_delta, chan = d, i
+        return chan
+
+    def run_block(self, x, frequency):
+        """x: complex64[block_len].  Leaves channelizer output (time-major) in self.data_out."""
+        x = A.as_c64(x)
+        self.frequency = int(frequency)
+        if self.M == 1:
+            y = np.empty_like(x)
+            self.L.iirfilt_crcf_execute_block(self.dc, _cptr(x), x.size, _cptr(y))      # :284
+            self.data_out = y
+            return
+        self.update_channels()
+        y = np.empty_like(x)
+        self.L.oracle_firpfbch_analyzer_block(C.c_void_p(self.chan), self.M, _cptr(x), x.size // self.M, _cptr(y))   # :449-451
+        self.data_out = y
+
+    def channel_data(self, i):
+        """runDemodChannels :341-382 -> (samples, centre frequency, sample rate) for channel index i in [0, M]."""
+        if self.M == 1:
+            return self.data_out, self.frequency, self.sample_rate
+        idx = self.M // 2 if i == self.M else i                         # :359-361
+        d = np.ascontiguousarray(self.data_out[idx::self.M])
+        if i == 0:                                                       # :364-375
+            y = np.empty_like(d)
+            self.L.iirfilt_crcf_execute_block(self.dc, _cptr(d), d.size, _cptr(y))
+            d = y
+        return d, self.centers[i], self.chan_bw
+
+
+class RefDemod:
+    """DemodulatorPreThread::run (src/demod/DemodulatorPreThread.cpp:154-220) + DemodulatorThread::run
+    (src/demod/DemodulatorThread.cpp:119-233) + the analog modems (src/modules/modem/)."""
+
+    def __init__(self, backend, modem, bandwidth, frequency, chan_rate, audio_rate=48000):
+        L = self.L = A.load(backend)
+        self.modem = modem
+        self.frequency = int(frequency)
+        self.audio_rate = int(audio_rate)
+        bw = max(int(bandwidth), 500)                                    # checkSampleRate, ModemAnalog.cpp:14-19
+        if modem in ("USB", "LSB") and bw % 2:
+            bw += 1                                                      # ModemUSB.cpp:29-37
+        self.bandwidth = bw
+        self.chan_rate = int(chan_rate)
+        self.nco = L.nco_crcf_create(A.LIQUID_VCO)                       # DemodulatorPreThread.cpp:22
+        self.shift = None
+        self.iq_ratio = float(bw) / float(chan_rate)                     # DemodulatorWorkerThread.cpp:99
+        self.resamp = L.msresamp_crcf_create(self.iq_ratio, 60.0)        # :100
+        self.au_ratio = float(audio_rate) / float(bw)                    # ModemAnalog.cpp:29
+        self.au = L.msresamp_rrrf_create(self.au_ratio, 60.0)            # :30
+        self.ceil, self.ceil_ma, self.ceil_maa = 1.0, 1.0, 1.0           # ModemAnalog ctor
+        self.use_signal_output = modem in ("AM", "USB", "LSB")
+        if modem in ("NBFM", "FM"):
+            self.fm = L.freqdem_create(0.5)                              # ModemNBFM.cpp:7
+        elif modem == "AM":
+            self.dcb = L.firfilt_rrrf_create_dc_blocker(25, 30.0)        # ModemAM.cpp:9
+        else:
+            self.ssb_filt = L.iirfilt_crcf_create_lowpass(6, 0.25)       # ModemUSB.cpp:8
+            self.ssb_nco = L.nco_crcf_create(A.LIQUID_NCO)               # :9
+            L.nco_crcf_set_frequency(self.ssb_nco, float(np.float32((2.0 * math.pi) * 0.25)))   # :10
+            self.hilb = L.firhilbf_create(5, 90.0)                       # :11
+
+    def pre(self, data, in_freq, in_rate):
+        """NCO shift + decimate; returns resampled IQ or None when the block is skipped (:154-165)."""
+        L = self.L
+        shift = self.frequency - int(in_freq)
+        bound = int(float(in_rate // 2) * 1.5)
+        if shift != self.shift:
+            self.shift = shift
+            if abs(shift) <= bound:
+                L.nco_crcf_set_frequency(self.nco, float(np.float32((2.0 * math.pi) * (float(abs(shift)) / float(in_rate)))))
+        if abs(shift) > bound:
+            return None
+        x = A.as_c64(data).copy()
+        if shift != 0:                                                   # :186-195
+            y = np.empty_like(x)
+            if shift < 0:
+                L.nco_crcf_mix_block_up(self.nco, _cptr(x), _cptr(y), x.size)
+            else:
+                L.nco_crcf_mix_block_down(self.nco, _cptr(x), _cptr(y), x.size)
+            x = y
+        out = np.empty(int(math.ceil(x.size * self.iq_ratio)) + 512, np.complex64)   # :199
+        nw = C.c_uint()
+        L.msresamp_crcf_execute(self.resamp, _cptr(x), x.size, _cptr(out), C.byref(nw))   # :209
+        return out[:nw.value].copy()
+
+    def demodulate(self, iq):
+        """Modem::demodulate + buildAudioOutput -> dict(audio, level_accum, level_count, peak, demod)"""
+        L = self.L
+        n = iq.size
+        if n == 0:
+            return None
+        iq = A.as_c64(iq)
+        d = np.empty(n, np.float32)
+        if self.modem in ("NBFM", "FM"):
+            L.freqdem_demodulate_block(self.fm, _cptr(iq), n, _cptr(d))                  # ModemNBFM.cpp:36
+            autogain = False
+        elif self.modem == "AM":
+            L.oracle_am_block(C.c_void_p(self.dcb), _cptr(iq), n, _cptr(d))              # ModemAM.cpp:41-47
+            autogain = True
+        else:
+            L.oracle_ssb_block(C.c_void_p(self.ssb_nco), C.c_void_p(self.ssb_filt), C.c_void_p(self.hilb),
+                               1 if self.modem == "USB" else 0, _cptr(iq), n, _cptr(d))  # ModemUSB.cpp:54-61
+            autogain = True
+        demod_unscaled = d.copy()
+        if autogain:                                                     # ModemAnalog.cpp:70-86 (float arithmetic)
+            f32 = np.float32
+            self.ceil_ma = f32(self.ceil_ma + f32(f32(self.ceil - self.ceil_ma) * f32(0.025)))
+            self.ceil_maa = f32(self.ceil_maa + f32(f32(self.ceil_ma - self.ceil_maa) * f32(0.025)))
+            self.ceil = f32(max(0.0, float(d.max())))
+            gain = f32(0.5) / f32(self.ceil_maa)
+            d = (d * gain).astype(np.float32)
+        out = np.empty(int(math.ceil(n * self.au_ratio)) + 512, np.float32)               # ModemAnalog.cpp:51
+        nw = C.c_uint()
+        L.msresamp_rrrf_execute(self.au, _cptr(d), n, _cptr(out), C.byref(nw))           # :88
+        audio = out[:nw.value].copy()
+        # DemodulatorThread.cpp:142-152 (double accumulation of magnitudes)
+        if self.use_signal_output:
+            accum = float(np.sum(np.abs(audio.astype(np.float64))))
+            cnt = audio.size
+        else:
+            accum = float(np.sum(np.sqrt(iq.real.astype(np.float64) ** 2 + iq.imag.astype(np.float64) ** 2)))
+            cnt = n
+        peak = float(np.max(np.abs(audio))) if audio.size else 0.0      # :223-233
+        return dict(audio=audio, level_accum=accum, level_count=cnt, peak=peak, demod=demod_unscaled)
+
+
+class RefSpectrum:
+    """SpectrumVisualProcessor::process, full-span view (src/process/SpectrumVisualProcessor.cpp:387-576, 626-627)."""
+
+    def __init__(self, backend, fft_size, average_rate=0.65, scale=1.0):
+        self.L = A.load(backend)
+        self.F = int(fft_size)
+        self.N = 2 * self.F                                              # SPECTRUM_VZM, .h:11, .cpp:145
+        self.x = np.zeros(self.N, np.complex64)
+        self.y = np.zeros(self.N, np.complex64)
+        self.plan = self.L.fft_create_plan(self.N, _cptr(self.x), _cptr(self.y), A.LIQUID_FFT_FORWARD, 0)   # :177
+        self.ma = np.zeros(self.N, np.float64)
+        self.maa = np.zeros(self.N, np.float64)
+        self.ceil_ma = self.ceil_maa = 100.0                             # :32
+        self.floor_ma = self.floor_maa = 0.0                             # :33
+        self.rate = float(np.float32(average_rate))                      # float member, :36
+        self.sf = float(np.float32(scale))
+
+    def fft(self, frame):
+        self.x[:] = A.as_c64(frame)
+        self.L.fft_execute(self.plan)                                    # :439
+        return self.y.copy()
+
+    def process_frame(self, frame):
+        """frame: the 2*fftSize samples process() would FFT.  Returns (spectrum_points[2F], fft_ceiling, fft_floor)."""
+        N, F = self.N, self.F
+        Y = self.fft(frame)
+        mag = np.sqrt((Y.real * Y.real + Y.imag * Y.imag).astype(np.float32)).astype(np.float32)   # float sqrt :443-448
+        res = np.concatenate([mag[N // 2:], mag[:N // 2]]).astype(np.float64)                       # :450-451
+        self.maa += (self.ma - self.maa) * self.rate                     # :494-497
+        self.ma += (res - self.ma) * self.rate
+        fft_ceil = np.float32(max(0.0, self.maa.max()))                  # float locals :436, :499-504
+        fft_floor = np.float32(min(1.0, self.maa.min()))
+        self.ceil_ma += (float(fft_ceil) - self.ceil_ma) * 0.05          # :513-516
+        self.ceil_maa += (self.ceil_ma - self.ceil_maa) * 0.05
+        self.floor_ma += (float(fft_floor) - self.floor_ma) * 0.05       # :518-521
+        self.floor_maa += (self.floor_ma - self.floor_maa) * 0.05
+        pc, pf = self.ceil_maa, self.floor_maa
+        acc = self.maa[0::2] + self.maa[1::2]                            # visualRatio = 1 -> 2 bins per point :538-560
+        acc[0] = pf + self.maa[1]                                        # idx == 0 is replaced by fft_floor_maa :546-551
+        y = (np.log10(acc / 2.0 + 0.25 - (pf - 0.75)) / np.log10((pc + 0.25) - (pf - 0.75))) * self.sf   # :566
+        pts = np.empty(2 * F, np.float32)
+        pts[0::2] = (np.arange(F, dtype=np.float32) / np.float32(F))     # :562
+        pts[1::2] = y.astype(np.float32)
+        return pts, pc / self.sf, pf                                     # :626-627
