@@ -67,10 +67,40 @@ struct PinBuf {
 
 }  // namespace csdr
 
+// kernel ids for the optional per-kernel HIP-event profile (csdr_ctx_profile_*)
+enum CsdrKernelId {
+    KID_CHAN_ANALYZE = 0, KID_CHAN_HIST, KID_DC_ENDS, KID_DC_CARRY, KID_DC_APPLY,
+    KID_FRONTEND, KID_MODEM, KID_GAIN, KID_AUDIO, KID_TAILS,
+    KID_FFT_COLS, KID_FFT_ROWS, KID_SPEC_AVG, KID_SPEC_TRACK, KID_SPEC_DISPLAY, KID_SPEC_MISC,
+    KID_COUNT
+};
+
 struct csdr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     csdr::DevBuf<float> sintab;  // 1024-entry sine table of the reference's NCO
+    // per-kernel profile: event pairs recorded around launches while enabled
+    bool prof_on = false;
+    struct ProfRec { int id; hipEvent_t a, b; };
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[KID_COUNT] = {0};
+    long long prof_n[KID_COUNT] = {0};
+    hipEvent_t prof_event() {
+        if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
 };
+
+// bracket one kernel launch with events when profiling is on
+struct ProfScope {
+    csdr_ctx *c; int id; hipEvent_t a = nullptr;
+    ProfScope(csdr_ctx *c_, int id_) : c(c_), id(id_) { if (c->prof_on) { a = c->prof_event(); (void)hipEventRecord(a, c->stream); } }
+    ~ProfScope() { if (a) { hipEvent_t b = c->prof_event(); (void)hipEventRecord(b, c->stream); c->prof_pending.push_back({id, a, b}); } }
+};
+#define CSDR_LAUNCH(ctx_, kid_, kern_, grid_, block_, lds_, ...) \
+    do { ProfScope ps__((ctx_), (kid_)); hipLaunchKernelGGL(kern_, grid_, block_, lds_, (ctx_)->stream, __VA_ARGS__); } while (0)

@@ -54,6 +54,8 @@ extern "C" void csdr_ctx_destroy(csdr_ctx *c) {
     if (!c) return;
     (void)hipStreamSynchronize(c->stream);
     c->sintab.release();
+    for (auto &r : c->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -77,6 +79,37 @@ extern "C" int csdr_ctx_timer_stop(csdr_ctx *c, float *ms) {
     CSDR_HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
     return CSDR_OK;
 }
+// ---- per-kernel HIP-event profile (bench.py roofline leg) ----
+static const char *kKernelNames[KID_COUNT] = {
+    "chan_analyze", "chan_update_hist", "dc_tile_ends", "dc_tile_carry", "dc_apply",
+    "demod_frontend", "demod_modem", "demod_gain", "demod_audio_interp", "demod_tails",
+    "spec_fft_cols", "spec_fft_rows", "spec_average", "spec_trackers", "spec_display", "spec_misc"};
+static int prof_drain(csdr_ctx *c) {
+    CSDR_HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto &r : c->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->prof_ms[r.id] += ms; c->prof_n[r.id] += 1; }
+        c->prof_pool.push_back(r.a); c->prof_pool.push_back(r.b);
+    }
+    c->prof_pending.clear();
+    return CSDR_OK;
+}
+extern "C" int csdr_ctx_profile_enable(csdr_ctx *c, int on) {
+    if (!c) return fail(CSDR_EINVAL, "ctx is null");
+    if (int rc = prof_drain(c)) return rc;
+    c->prof_on = on != 0;
+    if (on) for (int i = 0; i < KID_COUNT; i++) { c->prof_ms[i] = 0.0; c->prof_n[i] = 0; }
+    return CSDR_OK;
+}
+extern "C" int csdr_ctx_profile_num_kernels(void) { return KID_COUNT; }
+extern "C" const char *csdr_ctx_profile_kernel_name(int id) { return (id >= 0 && id < KID_COUNT) ? kKernelNames[id] : ""; }
+extern "C" int csdr_ctx_profile_fetch(csdr_ctx *c, int id, double *total_ms, int64_t *launches) {
+    if (!c || id < 0 || id >= KID_COUNT || !total_ms || !launches) return fail(CSDR_EINVAL, "bad argument");
+    if (int rc = prof_drain(c)) return rc;
+    *total_ms = c->prof_ms[id]; *launches = c->prof_n[id];
+    return CSDR_OK;
+}
+
 extern "C" int csdr_dev_alloc(csdr_ctx *c, uint64_t bytes, void **dev) {
     if (!c || !dev) return fail(CSDR_EINVAL, "null argument");
     if (hipMalloc(dev, bytes) != hipSuccess) return fail(CSDR_ENOMEM, "hipMalloc(%llu) failed", (unsigned long long)bytes);
@@ -211,9 +244,9 @@ extern "C" int csdr_post_set_active_channels(csdr_post *p, const int *channels, 
 static int run_dc_blocker(csdr_post *p, const float2 *x, float2 *y, int64_t n) {
     hipStream_t st = p->ctx->stream;
     const int ntiles = (int)((n + kDcTile - 1) / kDcTile);
-    hipLaunchKernelGGL(dc_tile_ends, dim3(ntiles), dim3(kDcThreads), 0, st, x, n, p->dc_c, p->tile_end.p);
-    hipLaunchKernelGGL(dc_tile_carry, dim3(1), dim3(64), 0, st, p->tile_end.p, ntiles, p->dc_c, p->dc_state.p, p->tile_in.p);
-    hipLaunchKernelGGL(dc_apply, dim3(ntiles), dim3(kDcThreads), 0, st, x, y, n, p->dc_c, p->tile_in.p, p->dc_state.p);
+    CSDR_LAUNCH(p->ctx, KID_DC_ENDS, dc_tile_ends, dim3(ntiles), dim3(kDcThreads), 0, x, n, p->dc_c, p->tile_end.p);
+    CSDR_LAUNCH(p->ctx, KID_DC_CARRY, dc_tile_carry, dim3(1), dim3(64), 0, p->tile_end.p, ntiles, p->dc_c, p->dc_state.p, p->tile_in.p);
+    CSDR_LAUNCH(p->ctx, KID_DC_APPLY, dc_apply, dim3(ntiles), dim3(kDcThreads), 0, x, y, n, p->dc_c, p->tile_in.p, p->dc_state.p);
     CSDR_HIP_TRY(hipGetLastError());
     return CSDR_OK;
 }
@@ -251,11 +284,11 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
     float2 *hist = p->hist_parity ? p->hist1.p : p->hist0.p, *hist_new = p->hist_parity ? p->hist0.p : p->hist1.p;
     if (n_active > 0) {
         const int ntiles = (int)((n_frames + TF - 1) / TF);
-        hipLaunchKernelGGL(chan_analyze, dim3(ntiles), dim3(kChanThreads), lds_bytes(TF), st, x, hist, p->taps.p, p->tw.p, p->active.p,
+        CSDR_LAUNCH(p->ctx, KID_CHAN_ANALYZE, chan_analyze, dim3(ntiles), dim3(kChanThreads), lds_bytes(TF), x, hist, p->taps.p, p->tw.p, p->active.p,
                            n_active, M, TF, n_frames, p->out.p, p->chan_stride);
     }
     const int H = (kChanTaps - 1) * M;
-    hipLaunchKernelGGL(chan_update_hist, dim3((H + 255) / 256), dim3(256), 0, st, x, n, hist, hist_new, H);
+    CSDR_LAUNCH(p->ctx, KID_CHAN_HIST, chan_update_hist, dim3((H + 255) / 256), dim3(256), 0, x, n, hist, hist_new, H);
     p->hist_parity ^= 1;
     CSDR_HIP_TRY(hipGetLastError());
     // channel 0 carries the DC spike: block it after de-interleave (:364-375)
@@ -329,7 +362,7 @@ struct csdr_bank {
     std::map<uint32_t, int> arm_index;       // key: bit pattern of rate_arb
     std::vector<float> arms_host;
     int n_run = 0, last_nb = 0;
-    bool fe_attr_set = false;
+    size_t fe_lds_attr = 0;
 };
 
 static int bank_arm_bank(csdr_bank *b, const design::MsresampPlan &p, int *idx) {
@@ -573,17 +606,35 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     CSDR_HIP_TRY(hipMemcpyAsync(b->dyns.p, b->dyns_h.p, b->max_demods * sizeof(SlotDyn), hipMemcpyHostToDevice, st));
     CSDR_HIP_TRY(hipMemcpyAsync(b->slot_list.p, b->slot_list_h.p, n_run * sizeof(int), hipMemcpyHostToDevice, st));
     CSDR_HIP_TRY(hipMemcpyAsync(b->plans.p, b->plans_h.p, (size_t)b->max_demods * (NB + 1) * sizeof(BlockPlan), hipMemcpyHostToDevice, st));
-    if (!b->fe_attr_set) {
-        CSDR_HIP_TRY(hipFuncSetAttribute((const void *)demod_frontend, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FeLds)));
-        b->fe_attr_set = true;
+    // front-end geometry: split each block into P parts so that (part + warm-up) fits one LDS chunk of ~4K inputs
+    int Smax = 0, warm_max = 0;
+    for (int i = 0; i < n_run; ++i) {
+        const SlotHost &s = b->slots[b->slot_list_h.p[i]];
+        const int S = (int)s.iq.S;
+        int64_t lo = -(int64_t)(kArmTaps - 1);
+        for (int e = S - 1; e >= 0; --e) lo = 2 * lo - (4 * (int)s.iq.m[S - 1 - e] - 2);
+        Smax = std::max(Smax, S);
+        warm_max = std::max(warm_max, (int)(-lo) + (2 << S));
+    }
+    if (warm_max + (1 << Smax) > kMixHist) return fail(CSDR_EUNSUPPORTED, "cascade span %d exceeds the carried history", warm_max);
+    const int P = std::max(1, (Bc + 3071) / 3072);
+    const int gran = 1 << Smax;
+    int chunk = ((Bc + P - 1) / P + warm_max + gran + gran - 1) / gran * gran;
+    chunk = std::min(chunk, kFeChunkMax / gran * gran);
+    if (chunk < gran) return fail(CSDR_EUNSUPPORTED, "half-band depth %d too deep for the front-end chunk", Smax);
+    size_t fe_lds = 0;
+    for (int i = 0; i < n_run; ++i) fe_lds = std::max(fe_lds, fe_lds_bytes((int)b->slots[b->slot_list_h.p[i]].iq.S, chunk));
+    if (fe_lds > b->fe_lds_attr) {
+        CSDR_HIP_TRY(hipFuncSetAttribute((const void *)demod_frontend, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fe_lds));
+        b->fe_lds_attr = fe_lds;
     }
     const dim3 grid(n_run, NB);
-    hipLaunchKernelGGL(demod_frontend, grid, dim3(kFeThreads), sizeof(FeLds), st, b->cfgs.p, b->dyns.p, b->slot_list.p,
-                       post->out.p, post->chan_stride, Bc, NB, b->arms.p, b->ctx->sintab.p);
-    hipLaunchKernelGGL(demod_modem, grid, dim3(kModemThreads), 0, st, b->cfgs.p, b->dyns.p, b->slot_list.p, b->plans.p, NB, b->mconsts.p, b->ctx->sintab.p);
-    hipLaunchKernelGGL(demod_gain, dim3((n_run + 63) / 64), dim3(64), 0, st, b->cfgs.p, b->slot_list.p, n_run, NB);
-    hipLaunchKernelGGL(demod_audio_interp, grid, dim3(kModemThreads), 0, st, b->cfgs.p, b->dyns.p, b->slot_list.p, b->plans.p, NB, b->arms.p);
-    hipLaunchKernelGGL(demod_tails, dim3(n_run), dim3(256), 0, st, b->cfgs.p, b->slot_list.p, b->plans.p, NB);
+    CSDR_LAUNCH(b->ctx, KID_FRONTEND, demod_frontend, dim3(n_run, NB, P), dim3(kFeThreads), fe_lds, b->cfgs.p, b->dyns.p, b->slot_list.p,
+                       post->out.p, post->chan_stride, Bc, NB, chunk, b->arms.p, b->ctx->sintab.p);
+    CSDR_LAUNCH(b->ctx, KID_MODEM, demod_modem, grid, dim3(kModemThreads), 0, b->cfgs.p, b->dyns.p, b->slot_list.p, b->plans.p, NB, b->mconsts.p, b->ctx->sintab.p);
+    CSDR_LAUNCH(b->ctx, KID_GAIN, demod_gain, dim3((n_run + 63) / 64), dim3(64), 0, b->cfgs.p, b->slot_list.p, n_run, NB);
+    CSDR_LAUNCH(b->ctx, KID_AUDIO, demod_audio_interp, grid, dim3(kModemThreads), 0, b->cfgs.p, b->dyns.p, b->slot_list.p, b->plans.p, NB, b->arms.p);
+    CSDR_LAUNCH(b->ctx, KID_TAILS, demod_tails, dim3(n_run), dim3(256), 0, b->cfgs.p, b->slot_list.p, b->plans.p, NB);
     CSDR_HIP_TRY(hipGetLastError());
     return CSDR_OK;
 }
@@ -646,9 +697,11 @@ struct csdr_spec {
     int F = 0, N = 0, N1 = 1, N2 = 0, C = 1, R = 1, max_frames = 0, nf_last = 0;
     float avg_rate = 0.65f, scale = 1.0f;
     DevBuf<float2> tw4096, tw_hi, tw_lo, tmp, carry, frame0, stage_in, raw;
-    DevBuf<float> mag, pairsum, first_b, points;
+    DevBuf<float2> mag2;
+    DevBuf<float> pairsum, first_b, points;
     DevBuf<double> ma, maa;
-    DevBuf<SpecMinMax> mm;
+    DevBuf<float2> ext;
+    int n_avg_waves = 0;
     DevBuf<SpecFrameOut> fo;
     DevBuf<SpecScalars> scal;
     int carry_len = 0;
@@ -665,8 +718,8 @@ extern "C" void csdr_spec_destroy(csdr_spec *s) {
     if (!s) return;
     (void)hipStreamSynchronize(s->ctx->stream);
     s->tw4096.release(); s->tw_hi.release(); s->tw_lo.release(); s->tmp.release(); s->carry.release(); s->frame0.release();
-    s->stage_in.release(); s->raw.release(); s->mag.release(); s->pairsum.release(); s->first_b.release(); s->points.release();
-    s->ma.release(); s->maa.release(); s->mm.release(); s->fo.release(); s->scal.release();
+    s->stage_in.release(); s->raw.release(); s->mag2.release(); s->ext.release(); s->pairsum.release(); s->first_b.release(); s->points.release();
+    s->ma.release(); s->maa.release(); s->fo.release(); s->scal.release();
     delete s;
 }
 
@@ -681,7 +734,7 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     s->F = fft_size; s->N = N; s->max_frames = max_frames;
     if (N <= kFftMaxLds) { s->N1 = 1; s->N2 = N; s->C = 1; s->R = 1; }
     else {
-        s->N1 = std::max(128, N / kFftMaxLds); s->N2 = N / s->N1;
+        s->N1 = std::max(128, N / (kFftMaxLds / 2)); s->N2 = N / s->N1;     // N2 <= 2048 so one workgroup holds a row PAIR
         s->C = kFftMaxLds / s->N1; s->R = kFftMaxLds / s->N2;
         if (s->C > s->N2) s->C = s->N2;
         if (s->R > s->N1) s->R = s->N1;
@@ -699,13 +752,14 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     CSDR_HIP_TRY(hipMemcpy(s->tw_hi.p, hi.data(), hi.size() * sizeof(float2), hipMemcpyHostToDevice));
     const size_t nfN = (size_t)max_frames * N;
     if (s->N1 > 1) if (int rc = s->tmp.reserve(nfN)) return rc;
-    if (int rc = s->mag.reserve(nfN)) return rc;
+    if (int rc = s->mag2.reserve(nfN / 2)) return rc;
+    s->n_avg_waves = (N / 2 + kAvgThreads - 1) / kAvgThreads;
+    if (int rc = s->ext.reserve(nfN / 2)) return rc;
     if (int rc = s->pairsum.reserve(nfN / 2)) return rc;
     if (int rc = s->first_b.reserve(max_frames)) return rc;
     if (int rc = s->points.reserve(nfN)) return rc;               // 2 * F floats per frame
     if (int rc = s->ma.reserve(N)) return rc;
     if (int rc = s->maa.reserve(N)) return rc;
-    if (int rc = s->mm.reserve(max_frames)) return rc;
     if (int rc = s->fo.reserve(max_frames)) return rc;
     if (int rc = s->scal.reserve(1)) return rc;
     if (int rc = s->carry.reserve(N)) return rc;
@@ -722,15 +776,15 @@ extern "C" int csdr_spec_set_average_rate(csdr_spec *s, float r) { if (!s) retur
 extern "C" int csdr_spec_set_scale_factor(csdr_spec *s, float f) { if (!s) return fail(CSDR_EINVAL, "null"); s->scale = f; return CSDR_OK; }
 extern "C" int csdr_spec_frames(const csdr_spec *s) { return s ? s->nf_last : 0; }
 
-static int spec_run_fft(csdr_spec *s, const FrameSrc &fs, int nf, float *mag, float2 *raw) {
+static int spec_run_fft(csdr_spec *s, const FrameSrc &fs, int nf, float2 *mag, float2 *raw) {
     hipStream_t st = s->ctx->stream;
     FrameSrc rows = fs;
     if (s->N1 > 1) {
-        hipLaunchKernelGGL(spec_fft_cols, dim3(s->N2 / s->C, nf), dim3(kFftThreads), 0, st, fs, s->N1, s->N2, s->C,
+        CSDR_LAUNCH(s->ctx, KID_FFT_COLS, spec_fft_cols, dim3(s->N2 / s->C, nf), dim3(kFftThreads), 0, fs, s->N1, s->N2, s->C,
                            s->tw4096.p, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
         rows.first = s->tmp.p; rows.rest = s->tmp.p + s->N; rows.stride = s->N;
     }
-    hipLaunchKernelGGL(spec_fft_rows, dim3(s->N1 / s->R, nf), dim3(kFftThreads), 0, st, rows, s->N1, s->N2, s->R, s->tw4096.p, mag, raw);
+    CSDR_LAUNCH(s->ctx, KID_FFT_ROWS, spec_fft_rows, dim3(s->N1 / s->R, nf), dim3(kFftThreads), 0, rows, s->N1, s->N2, s->R, s->tw4096.p, mag, raw);
     CSDR_HIP_TRY(hipGetLastError());
     return CSDR_OK;
 }
@@ -757,7 +811,7 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
         nf = (int)(total / N);
         if (nf > 0) {
             if (s->carry_len > 0) {
-                hipLaunchKernelGGL(spec_assemble, dim3((N + 255) / 256), dim3(256), 0, st, s->carry.p, s->carry_len, x, N, s->frame0.p);
+                CSDR_LAUNCH(s->ctx, KID_SPEC_MISC, spec_assemble, dim3((N + 255) / 256), dim3(256), 0, s->carry.p, s->carry_len, x, N, s->frame0.p);
                 fs.first = s->frame0.p;
             } else fs.first = x;
             fs.rest = x + (N - s->carry_len); fs.stride = N;
@@ -766,12 +820,12 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
     if (nf > s->max_frames) return fail(CSDR_ERANGE, "%d frames exceed max_frames %d", nf, s->max_frames);
     s->nf_last = nf;
     if (nf > 0) {
-        hipLaunchKernelGGL(spec_reset_minmax, dim3((nf + 255) / 256), dim3(256), 0, st, s->mm.p, nf);
-        if (int rc = spec_run_fft(s, fs, nf, s->mag.p, nullptr)) return rc;
-        hipLaunchKernelGGL(spec_average, dim3((N / 2 + 255) / 256), dim3(256), 0, st, s->mag.p, nf, s->N1, s->N2, (double)s->avg_rate,
-                           s->ma.p, s->maa.p, s->pairsum.p, s->first_b.p, s->mm.p);
-        hipLaunchKernelGGL(spec_trackers, dim3(1), dim3(64), 0, st, s->mm.p, nf, s->scal.p, s->fo.p);
-        hipLaunchKernelGGL(spec_display, dim3((s->F + 255) / 256, nf), dim3(256), 0, st, s->pairsum.p, s->first_b.p, s->fo.p, s->N1, s->N2, s->scale, s->points.p);
+        if (int rc = spec_run_fft(s, fs, nf, s->mag2.p, nullptr)) return rc;
+        CSDR_LAUNCH(s->ctx, KID_SPEC_AVG, spec_average, dim3(s->n_avg_waves), dim3(kAvgThreads), 0, s->mag2.p, nf, s->N1, s->N2, (double)s->avg_rate,
+                    s->ma.p, s->maa.p, s->pairsum.p, s->first_b.p, s->ext.p);
+        CSDR_LAUNCH(s->ctx, KID_SPEC_MISC, spec_minmax, dim3(nf), dim3(256), 0, s->ext.p, N / 2, s->fo.p);
+        CSDR_LAUNCH(s->ctx, KID_SPEC_TRACK, spec_trackers, dim3(1), dim3(64), 0, nf, s->scal.p, s->fo.p);
+        CSDR_LAUNCH(s->ctx, KID_SPEC_DISPLAY, spec_display, dim3((s->F + 255) / 256, nf), dim3(256), 0, s->pairsum.p, s->first_b.p, s->fo.p, s->N1, s->N2, s->scale, s->points.p);
         CSDR_HIP_TRY(hipGetLastError());
     }
     if (mode == CSDR_SPEC_CONTIGUOUS) {

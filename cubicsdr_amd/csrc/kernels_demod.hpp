@@ -24,7 +24,7 @@ constexpr int kMixHist = 16384;   // mixed-input history kept per slot (>= longe
 constexpr int kIqHist = 256;      // resampled-IQ history kept per slot
 constexpr int kDHist = 64;        // scaled demodulator-output history kept per slot
 constexpr int kFeThreads = 256;
-constexpr int kFeChunk = 2048;    // input samples per inner iteration of the front-end
+constexpr int kFeChunkMax = 8192; // largest input span one inner iteration of the front-end stages through LDS
 constexpr int kFeTail = 24;       // per-stage carried tail (>= 2 * kHbMaxM)
 constexpr int kFeZTail = 16;      // carried tail of the half-band chain output (>= 13)
 
@@ -96,28 +96,93 @@ __device__ inline int64_t resamp_first_out(int64_t K, uint32_t phase0, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// D1: NCO shift + half-band decimator cascade + arbitrary polyphase resampler.   grid = (slot, block)
+// D1: NCO shift + half-band decimator cascade + arbitrary polyphase resampler.   grid = (slot, block, part)
+//
+// A workgroup owns a contiguous range of half-band-chain outputs [Ka, Kb) of one block of one demodulator and the
+// resampler outputs that fall on them.  It starts `warm` input samples earlier (the span of the whole cascade) with
+// empty windows, so that every window is fully populated by true samples when the first wanted output is formed.
+// The first half-band stage reads its 2m + 1 inputs straight from HBM/L2 (mixing each with the table NCO on the fly);
+// later stages ping through LDS in even/odd-split arrays (unit-stride ds_read_b64, no bank conflicts).  Normally the
+// whole range is one chunk (ch >= span); longer ranges loop over chunks carrying per-stage tails in LDS.
 // ------------------------------------------------------------------------------------------------------------
-// offset of stage e's (tail + data) region inside FeLds::E / FeLds::O
-__device__ inline int fe_off(int e) { return e * kFeTail + kFeChunk - (kFeChunk >> e); }
+__host__ __device__ inline int fe_off(int e, int ch) { return (e - 1) * kFeTail + (ch >> 1) - (ch >> e); }   // stage e >= 1 input region
+__host__ __device__ inline int fe_arr_len(int S, int ch) { return S > 1 ? (S - 1) * kFeTail + (ch >> 1) - (ch >> S) : 0; }
+__host__ __device__ inline int fe_z_len(int S, int ch) { return kFeZTail + (S ? (ch >> S) : ch); }
+__host__ __device__ inline size_t fe_lds_bytes(int S, int ch) {
+    return (size_t)(2 * fe_arr_len(S, ch) + fe_z_len(S, ch)) * sizeof(float2) + 1024 * sizeof(float) + kMaxHb * kHbMaxM * sizeof(float);
+}
 
-struct FeLds {
-    float2 E[kFeChunk + kMaxHb * kFeTail];   // even-indexed inputs of every stage, stage after stage
-    float2 O[kFeChunk + kMaxHb * kFeTail];   // odd-indexed inputs
-    float2 Z[kFeZTail + kFeChunk];           // half-band chain output (input of the arbitrary resampler)
-    float tab[1024];
-    float hb[kMaxHb][kHbMaxM];
-};
+__device__ inline float2 fe_load_mixed(const float2 *__restrict__ chan, const float2 *__restrict__ hist, const float *tab,
+                                       const SlotDyn &dyn, int64_t rel) {
+    if (rel < 0) return rel >= -(int64_t)kMixHist ? hist[kMixHist + rel] : make_float2(0.f, 0.f);
+    const float2 x = chan[rel];
+    if (dyn.mixdir == 0) return x;
+    float s, c;
+    nco_sincos(tab, dyn.theta0 + (uint32_t)rel * dyn.dtheta, s, c);
+    if (dyn.mixdir < 0) return make_float2(fmaf(x.x, c, x.y * s), fmaf(x.y, c, -x.x * s));   // x (c - j s)
+    return make_float2(fmaf(x.x, c, -x.y * s), fmaf(x.y, c, x.x * s));                        // x (c + j s)
+}
+
+
+// ---- half-band stage bodies, specialised on m so the tap loops unroll and all loads of one output issue together ----
+// stage 0: two adjacent outputs per thread straight from memory (2m + 1 even samples + 2 odd samples, each mixed once)
+template <int M>
+__device__ inline void fe_stage0(const float2 *__restrict__ chan, const float2 *__restrict__ hist, const float *tab, const float *h,
+                                 const SlotDyn &dyn, int64_t rel0, int cnt, float zeta, bool to_z,
+                                 float2 *__restrict__ outE, float2 *__restrict__ outO, float2 *__restrict__ outZ) {
+    const int npair = (cnt + 1) >> 1;
+    for (int pk = threadIdx.x; pk < npair; pk += kFeThreads) {
+        const int k = 2 * pk;
+        const int64_t r = rel0 + 2 * (int64_t)k;          // even sample of output k; output k+1 uses r + 2
+        float2 ev[2 * M + 1];                               // ev[i] = x[r + 2 - 2 i], i = 0 .. 2M
+#pragma unroll
+        for (int i = 0; i <= 2 * M; ++i) ev[i] = fe_load_mixed(chan, hist, tab, dyn, r + 2 - 2 * i);
+        const float2 od0 = fe_load_mixed(chan, hist, tab, dyn, r - 2 * M + 1), od1 = fe_load_mixed(chan, hist, tab, dyn, r - 2 * M + 3);
+        float a0r = od0.x, a0i = od0.y, a1r = od1.x, a1i = od1.y;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            const float hj = h[j];
+            // output k: x[r - 2j] = ev[j + 1], x[r - 2(2M-1-j)] = ev[2M - j];  output k+1: ev[j], ev[2M - 1 - j]
+            a0r = fmaf(hj, ev[j + 1].x + ev[2 * M - j].x, a0r); a0i = fmaf(hj, ev[j + 1].y + ev[2 * M - j].y, a0i);
+            a1r = fmaf(hj, ev[j].x + ev[2 * M - 1 - j].x, a1r); a1i = fmaf(hj, ev[j].y + ev[2 * M - 1 - j].y, a1i);
+        }
+        if (to_z) {
+            outZ[k] = make_float2(a0r * zeta, a0i * zeta);
+            if (k + 1 < cnt) outZ[k + 1] = make_float2(a1r * zeta, a1i * zeta);
+        } else {
+            outE[pk] = make_float2(a0r, a0i);               // k even -> E[k / 2]
+            if (k + 1 < cnt) outO[pk] = make_float2(a1r, a1i);
+        }
+    }
+}
+
+// stage e >= 1 through LDS
+template <int M>
+__device__ inline void fe_stage_lds(const float2 *__restrict__ Ein, const float2 *__restrict__ Oin, const float *h, int cnt, float zeta,
+                                    bool to_z, float2 *__restrict__ outE, float2 *__restrict__ outO, float2 *__restrict__ outZ) {
+    for (int k = threadIdx.x; k < cnt; k += kFeThreads) {
+        const float2 d = Oin[k - M];
+        float ar = d.x, ai = d.y;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            const float hj = h[j];
+            const float2 p = Ein[k - j], q = Ein[k - (2 * M - 1) + j];
+            ar = fmaf(hj, p.x + q.x, ar); ai = fmaf(hj, p.y + q.y, ai);
+        }
+        if (to_z) outZ[k] = make_float2(ar * zeta, ai * zeta);
+        else if (k & 1) outO[k >> 1] = make_float2(ar, ai);
+        else outE[k >> 1] = make_float2(ar, ai);
+    }
+}
 
 __global__ __launch_bounds__(kFeThreads) void demod_frontend(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
-    const float2 *__restrict__ chan_base, int64_t chan_stride, int Bc, int NB,
+    const float2 *__restrict__ chan_base, int64_t chan_stride, int Bc, int NB, int ch,
     const float *__restrict__ arms_all, const float *__restrict__ sintab) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    FeLds &L = *reinterpret_cast<FeLds *>(smem_raw);
 
     const int slot = slot_list[blockIdx.x];
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, part = blockIdx.z, P = gridDim.z;
     const SlotCfg &cfg = cfgs[slot];
     const SlotDyn dyn = dyns[slot];
     const int tid = threadIdx.x;
@@ -127,133 +192,111 @@ __global__ __launch_bounds__(kFeThreads) void demod_frontend(
     const float2 *__restrict__ hist = cfg.mixhist + (size_t)dyn.hist_parity * kMixHist;
     const float *__restrict__ arms = arms_all + (size_t)cfg.rs_iq.arms_idx * kArms * kArmTaps;
 
-    for (int i = tid; i < 1024; i += kFeThreads) L.tab[i] = sintab[i];
-    for (int i = tid; i < kMaxHb * kHbMaxM; i += kFeThreads) L.hb[i / kHbMaxM][i % kHbMaxM] = cfg.rs_iq.h_x[i / kHbMaxM][i % kHbMaxM];
+    const int alen = fe_arr_len(S, ch);
+    float2 *LE = reinterpret_cast<float2 *>(smem_raw);
+    float2 *LO = LE + alen;
+    float2 *LZ = LO + alen;
+    float *tab = reinterpret_cast<float *>(LZ + fe_z_len(S, ch));
+    float *hb = tab + 1024;
 
-    // zeroed tails (stage e's buffers start at fe_off(e))
-    for (int i = tid; i < S * kFeTail; i += kFeThreads) {
-        const int e = i / kFeTail, k = i % kFeTail;
-        L.E[fe_off(e) + k] = make_float2(0.f, 0.f);
-        L.O[fe_off(e) + k] = make_float2(0.f, 0.f);
+    for (int i = tid; i < 1024; i += kFeThreads) tab[i] = sintab[i];
+    for (int i = tid; i < kMaxHb * kHbMaxM; i += kFeThreads) hb[i] = cfg.rs_iq.h_x[i / kHbMaxM][i % kHbMaxM];
+    for (int i = tid; i < (S - 1) * kFeTail; i += kFeThreads) {
+        const int e = 1 + i / kFeTail, k = i % kFeTail;
+        LE[fe_off(e, ch) + k] = make_float2(0.f, 0.f);
+        LO[fe_off(e, ch) + k] = make_float2(0.f, 0.f);
     }
-    if (tid < kFeZTail) L.Z[tid] = make_float2(0.f, 0.f);
+    if (tid < kFeZTail) LZ[tid] = make_float2(0.f, 0.f);
 
     // --- index ranges (u-space: u = batch-relative input index + buf0; half-band output k covers u in [k 2^S, (k+1) 2^S))
     const int64_t u_blk0 = (int64_t)dyn.buf0 + (int64_t)b * Bc, u_blk1 = u_blk0 + Bc;
     const int64_t K0 = u_blk0 >> S, K1 = u_blk1 >> S;
-    const int64_t j0 = resamp_first_out(K0, dyn.phase0, step), j1 = resamp_first_out(K1, dyn.phase0, step);
-    int64_t lo = K0 - (kArmTaps - 1);
+    const int64_t Ka = K0 + ((K1 - K0) * part) / P, Kb = K0 + ((K1 - K0) * (part + 1)) / P;
+    const int64_t j0 = resamp_first_out(Ka, dyn.phase0, step), j1 = resamp_first_out(Kb, dyn.phase0, step);
+    int64_t lo = Ka - (kArmTaps - 1);
     for (int e = S - 1; e >= 0; --e) lo = 2 * lo - (4 * cfg.rs_iq.m_x[e] - 2);
     const int64_t u_lo = (lo >> S) << S;           // floor to a multiple of 2^S (also for negatives)
-    const int64_t u_stop = K1 << S;
+    const int64_t u_stop = Kb << S;
     const float zeta = 1.0f / (float)(1 << S);
-    const bool last_block = (b == NB - 1);
 
     __syncthreads();
 
-    for (int64_t uc = u_lo; uc < u_stop; uc += kFeChunk) {
-        const int n = (int)min((int64_t)kFeChunk, u_stop - uc);
-        // 1. load + mix
-        for (int i = tid; i < n; i += kFeThreads) {
-            const int64_t rel = uc + i - (int64_t)dyn.buf0;
-            float2 v;
-            if (rel < 0) {
-                v = rel >= -(int64_t)kMixHist ? hist[kMixHist + rel] : make_float2(0.f, 0.f);
-            } else {
-                const float2 x = chan[rel];
-                if (dyn.mixdir == 0) v = x;
-                else {
-                    float s, c;
-                    nco_sincos(L.tab, dyn.theta0 + (uint32_t)rel * dyn.dtheta, s, c);
-                    if (dyn.mixdir < 0) v = make_float2(fmaf(x.x, c, x.y * s), fmaf(x.y, c, -x.x * s));   // x (c - j s)
-                    else                v = make_float2(fmaf(x.x, c, -x.y * s), fmaf(x.y, c, x.x * s));   // x (c + j s)
-                }
-            }
-            if (S == 0) L.Z[kFeZTail + i] = v;
-            else if (i & 1) L.O[fe_off(0) + kFeTail + (i >> 1)] = v;
-            else L.E[fe_off(0) + kFeTail + (i >> 1)] = v;
-        }
-        __syncthreads();
-        // 2. half-band stages:  y[k] = x[2(k-m)+1] + sum_{j<2m} h1[j] x[2(k-j)]   (no per-stage scaling; x 2^-S at the end)
+    for (int64_t uc = u_lo; uc < u_stop; uc += ch) {
+        const int n = (int)min((int64_t)ch, u_stop - uc);
+        const int64_t rel0 = uc - (int64_t)dyn.buf0;          // batch-relative index of the chunk's first input
         int cnt = n;
-        for (int e = 0; e < S; ++e) {
+        if (S == 0) {
+            for (int i = tid; i < n; i += kFeThreads) LZ[kFeZTail + i] = fe_load_mixed(chan, hist, tab, dyn, rel0 + i);
+            __syncthreads();
+        } else {
+            // stage 0 straight from memory:  y[k] = x[2(k-m)+1] + sum_{j<m} h[j] (x[2(k-j)] + x[2(k-2m+1+j)])
             cnt >>= 1;
-            const int m = cfg.rs_iq.m_x[e];
-            const float2 *Ein = L.E + fe_off(e) + kFeTail, *Oin = L.O + fe_off(e) + kFeTail;
-            for (int k = tid; k < cnt; k += kFeThreads) {
-                float2 d = Oin[k - m];
-                float ar = d.x, ai = d.y;
-                for (int j = 0; j < m; ++j) {
-                    const float h = L.hb[e][j];
-                    const float2 p = Ein[k - j], q = Ein[k - (2 * m - 1) + j];
-                    ar = fmaf(h, p.x + q.x, ar); ai = fmaf(h, p.y + q.y, ai);
-                }
-                if (e == S - 1) L.Z[kFeZTail + k] = make_float2(ar * zeta, ai * zeta);
-                else if (k & 1) L.O[fe_off(e + 1) + kFeTail + (k >> 1)] = make_float2(ar, ai);
-                else L.E[fe_off(e + 1) + kFeTail + (k >> 1)] = make_float2(ar, ai);
+            {
+                const int m = cfg.rs_iq.m_x[0];
+                const bool tz = (S == 1);
+                float2 *oE = LE + (tz ? 0 : fe_off(1, ch) + kFeTail), *oO = LO + (tz ? 0 : fe_off(1, ch) + kFeTail), *oZ = LZ + kFeZTail;
+                if (m == 3) fe_stage0<3>(chan, hist, tab, hb, dyn, rel0, cnt, zeta, tz, oE, oO, oZ);
+                else if (m == 5) fe_stage0<5>(chan, hist, tab, hb, dyn, rel0, cnt, zeta, tz, oE, oO, oZ);
+                else fe_stage0<10>(chan, hist, tab, hb, dyn, rel0, cnt, zeta, tz, oE, oO, oZ);
             }
             __syncthreads();
+            // later stages through LDS
+            for (int e = 1; e < S; ++e) {
+                cnt >>= 1;
+                const int me = cfg.rs_iq.m_x[e];
+                const float2 *Ein = LE + fe_off(e, ch) + kFeTail, *Oin = LO + fe_off(e, ch) + kFeTail;
+                const float *he = hb + e * kHbMaxM;
+                const bool tz = (e == S - 1);
+                float2 *oE = LE + (tz ? 0 : fe_off(e + 1, ch) + kFeTail), *oO = LO + (tz ? 0 : fe_off(e + 1, ch) + kFeTail), *oZ = LZ + kFeZTail;
+                if (me == 3) fe_stage_lds<3>(Ein, Oin, he, cnt, zeta, tz, oE, oO, oZ);
+                else if (me == 5) fe_stage_lds<5>(Ein, Oin, he, cnt, zeta, tz, oE, oO, oZ);
+                else fe_stage_lds<10>(Ein, Oin, he, cnt, zeta, tz, oE, oO, oZ);
+                __syncthreads();
+            }
         }
-        // 3. arbitrary resampler on Z for outputs whose input index falls in this chunk
+        // arbitrary resampler on Z for outputs whose input index falls in this chunk
         const int64_t kz0 = uc >> S;
         const int cz = n >> S;
         int64_t ja = resamp_first_out(kz0, dyn.phase0, step), jb = resamp_first_out(kz0 + cz, dyn.phase0, step);
         if (ja < j0) ja = j0;
         if (jb > j1) jb = j1;
         for (int64_t j = ja + tid; j < jb; j += kFeThreads) {
-            const int64_t P = (int64_t)dyn.phase0 + j * (int64_t)step;
-            const int kj = (int)((P >> 24) - kz0);
-            const int arm = (int)((P & 0xFFFFFF) >> 16);
+            const int64_t Pj = (int64_t)dyn.phase0 + j * (int64_t)step;
+            const int kj = (int)((Pj >> 24) - kz0);
+            const int arm = (int)((Pj & 0xFFFFFF) >> 16);
             const float *h = arms + arm * kArmTaps;
-            const float2 *z = L.Z + kFeZTail + kj - (kArmTaps - 1);
+            const float2 *z = LZ + kFeZTail + kj - (kArmTaps - 1);
             float ar = 0.f, ai = 0.f;
 #pragma unroll
             for (int t = 0; t < kArmTaps; ++t) { ar = fmaf(h[t], z[t].x, ar); ai = fmaf(h[t], z[t].y, ai); }
             cfg.iq[kIqHist + j] = make_float2(ar, ai);
         }
-        __syncthreads();
-        // 4. carry tails to the front of every buffer
-        int c2 = n;
-        for (int e = 0; e < S; ++e) {
-            c2 >>= 1;
-            float2 ve, vo;
-            if (tid < kFeTail) { ve = L.E[fe_off(e) + c2 + tid]; vo = L.O[fe_off(e) + c2 + tid]; }
+        if (uc + ch < u_stop) {      // another chunk follows: carry tails to the front of every buffer
             __syncthreads();
-            if (tid < kFeTail) { L.E[fe_off(e) + tid] = ve; L.O[fe_off(e) + tid] = vo; }
-        }
-        {
+            int c2 = n >> 1;
+            for (int e = 1; e < S; ++e) {
+                c2 >>= 1;
+                float2 ve, vo;
+                if (tid < kFeTail) { ve = LE[fe_off(e, ch) + c2 + tid]; vo = LO[fe_off(e, ch) + c2 + tid]; }
+                __syncthreads();
+                if (tid < kFeTail) { LE[fe_off(e, ch) + tid] = ve; LO[fe_off(e, ch) + tid] = vo; }
+            }
             float2 vz;
             const int czz = (S == 0) ? n : (n >> S);
-            if (tid < kFeZTail) vz = L.Z[czz + tid];
+            if (tid < kFeZTail) vz = LZ[czz + tid];
             __syncthreads();
-            if (tid < kFeZTail) L.Z[tid] = vz;
+            if (tid < kFeZTail) LZ[tid] = vz;
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     // new mixed-input history (other parity): the last kMixHist samples of (old history ++ mixed batch)
-    if (last_block) {
+    if (b == NB - 1 && part == P - 1) {
         float2 *hnew = cfg.mixhist + (size_t)(dyn.hist_parity ^ 1) * kMixHist;
         const int64_t total = (int64_t)NB * Bc;
-        for (int i = tid; i < kMixHist; i += kFeThreads) {
-            const int64_t rel = total - kMixHist + i;
-            float2 v;
-            if (rel < 0) v = hist[kMixHist + rel];
-            else {
-                const float2 x = chan[rel];
-                if (dyn.mixdir == 0) v = x;
-                else {
-                    float s, c;
-                    nco_sincos(L.tab, dyn.theta0 + (uint32_t)rel * dyn.dtheta, s, c);
-                    if (dyn.mixdir < 0) v = make_float2(fmaf(x.x, c, x.y * s), fmaf(x.y, c, -x.x * s));
-                    else                v = make_float2(fmaf(x.x, c, -x.y * s), fmaf(x.y, c, x.x * s));
-                }
-            }
-            hnew[i] = v;
-        }
+        for (int i = tid; i < kMixHist; i += kFeThreads) hnew[i] = fe_load_mixed(chan, hist, tab, dyn, total - kMixHist + i);
     }
 }
-
 
 // ------------------------------------------------------------------------------------------------------------
 // D2a: modem core -> unscaled demodulator output d[j] for the block, block maximum (auto-gain input) and the

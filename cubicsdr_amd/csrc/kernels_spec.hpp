@@ -103,90 +103,113 @@ __global__ __launch_bounds__(kFftThreads) void spec_fft_cols(FrameSrc fs, int N1
     }
 }
 
-// pass B: row FFTs + magnitude.  grid = (N1 / R, frames).  src rows are contiguous (tmp, or the frame itself if N1 == 1)
+// pass B: row FFTs + magnitude.  grid = (N1 / R, frames).  src rows are contiguous (tmp, or the frame itself if N1 == 1).
+// Magnitudes are stored as float2 pairs {|X[k_a]|, |X[k_a + 1]|} of the two adjacent bins that one display point
+// averages: pair index t = (k1 / 2) N2 + k2 for N1 > 1 (rows k1, k1 + 1 of one workgroup), t = k / 2 for N1 == 1.
 __global__ __launch_bounds__(kFftThreads) void spec_fft_rows(FrameSrc fs, int N1, int N2, int R,
                                                              const float2 *__restrict__ tw4096,
-                                                             float *__restrict__ mag, float2 *__restrict__ raw_out) {
+                                                             float2 *__restrict__ mag2, float2 *__restrict__ raw_out) {
     __shared__ float2 sa[kFftMaxLds], sb[kFftMaxLds];
     const int f = blockIdx.y, r0 = blockIdx.x * R, tid = threadIdx.x;
     const float2 *x = frame_ptr(fs, f) + (int64_t)r0 * N2;
     for (int i = tid; i < R * N2; i += kFftThreads) sa[i] = x[i];
     __syncthreads();
     float2 *r = lds_fft(sa, sb, N2, R, tw4096);
-    const int64_t base = (int64_t)f * N1 * N2 + (int64_t)r0 * N2;
-    if (mag) {
-        for (int i = tid; i < R * N2; i += kFftThreads) {
-            const float2 v = r[i];
-            mag[base + i] = sqrtf(v.x * v.x + v.y * v.y);
+    const int64_t N = (int64_t)N1 * N2;
+    if (mag2) {
+        float2 *o = mag2 + (int64_t)f * (N / 2);
+        if (N1 > 1) {
+            for (int i = tid; i < (R / 2) * N2; i += kFftThreads) {
+                const int rp = i / N2, k2 = i - rp * N2;
+                const float2 va = r[(2 * rp) * N2 + k2], vb = r[(2 * rp + 1) * N2 + k2];
+                o[(int64_t)(r0 / 2 + rp) * N2 + k2] = make_float2(sqrtf(va.x * va.x + va.y * va.y), sqrtf(vb.x * vb.x + vb.y * vb.y));
+            }
+        } else {
+            for (int i = tid; i < N2 / 2; i += kFftThreads) {
+                const float2 va = r[2 * i], vb = r[2 * i + 1];
+                o[i] = make_float2(sqrtf(va.x * va.x + va.y * va.y), sqrtf(vb.x * vb.x + vb.y * vb.y));
+            }
         }
     }
     if (raw_out) {   // natural-order complex output (parity tests of K13 alone): bin k = k1 + N1 k2
         for (int i = tid; i < R * N2; i += kFftThreads) {
             const int rr = i / N2, k2 = i - rr * N2;
-            raw_out[(int64_t)f * N1 * N2 + (int64_t)(r0 + rr) + (int64_t)N1 * k2] = r[i];
+            raw_out[(int64_t)f * N + (int64_t)(r0 + rr) + (int64_t)N1 * k2] = r[i];
         }
     }
 }
 
 // K15: per display point (= two adjacent shifted bins) run the averaging recurrence over the frames of the batch.
-// thread t <-> (k1 pair, k2): bins k_a = 2 k1p + N1 k2 and k_a + 1 at permuted positions p_a, p_a + N2 (N1 > 1)
-// or p_a = 2 t, p_a + 1 (N1 == 1).  ma / maa (fft_result_ma / _maa, double) live in permuted order.
-struct SpecMinMax { unsigned long long mx, mn; };   // bit patterns of non-negative doubles (order-preserving)
+// thread t owns pair t; ma / maa (fft_result_ma / _maa, double) are kept per pair as [2][N/2] arrays.
+// One wave per workgroup so the N/2 pairs spread over all CUs; loads of 4 frames are issued ahead of the recurrence.
+// The per-frame extrema the reference tracks are (float) max / min of maa; float rounding is monotonic, so each thread
+// emits its own (float max, float min) per frame and spec_minmax reduces them -- nothing cross-lane in the serial loop.
+constexpr int kAvgThreads = 64;
+constexpr int kAvgUnroll = 4;
 
-__global__ __launch_bounds__(256) void spec_average(const float *__restrict__ mag, int nf, int N1, int N2, double rate,
-                                                    double *__restrict__ ma, double *__restrict__ maa,
-                                                    float *__restrict__ pairsum, float *__restrict__ first_b,
-                                                    SpecMinMax *__restrict__ mm) {
-    const int N = N1 * N2;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = t < N / 2;
-    int pa = 0, pb = 0;
-    bool is_x0 = false;
-    if (live) {
-        if (N1 > 1) { const int k1p = t / N2, k2 = t - k1p * N2; pa = (2 * k1p) * N2 + k2; pb = pa + N2; is_x0 = (k1p == 0 && k2 == N2 / 2); }
-        else { pa = 2 * t; pb = pa + 1; is_x0 = (pa == N / 2); }
-    }
-    // shifted index 0 <-> bin N/2: k1 = 0, k2 = N2/2 (N1 > 1) ; that thread's first bin is the "idx == 0" element
-    double ma_a = 0, ma_b = 0, maa_a = 0, maa_b = 0;
-    if (live) { ma_a = ma[pa]; ma_b = ma[pb]; maa_a = maa[pa]; maa_b = maa[pb]; }
-    for (int f = 0; f < nf; ++f) {
-        double lmx = 0.0, lmn = 1e300;
-        if (live) {
-            const float *m = mag + (int64_t)f * N;
-            const double xa = (double)m[pa], xb = (double)m[pb];
-            if (maa_a != maa_a) maa_a = xa;
-            maa_a += (ma_a - maa_a) * rate;
-            if (ma_a != ma_a) ma_a = xa;
-            ma_a += (xa - ma_a) * rate;
-            if (maa_b != maa_b) maa_b = xb;
-            maa_b += (ma_b - maa_b) * rate;
-            if (ma_b != ma_b) ma_b = xb;
-            ma_b += (xb - ma_b) * rate;
-            lmx = fmax(maa_a, maa_b); lmn = fmin(maa_a, maa_b);
-            pairsum[(int64_t)f * (N / 2) + t] = (float)(maa_a + maa_b);
-            if (is_x0) first_b[f] = (float)maa_b;
-        }
-        for (int o = 32; o > 0; o >>= 1) { lmx = fmax(lmx, __shfl_down(lmx, o, 64)); lmn = fmin(lmn, __shfl_down(lmn, o, 64)); }
-        if ((threadIdx.x & 63) == 0) {
-            atomicMax(&mm[f].mx, (unsigned long long)__double_as_longlong(lmx));
-            atomicMin(&mm[f].mn, (unsigned long long)__double_as_longlong(lmn));
+__global__ __launch_bounds__(kAvgThreads) void spec_average(const float2 *__restrict__ mag2, int nf, int N1, int N2, double rate,
+                                                            double *__restrict__ ma, double *__restrict__ maa,
+                                                            float *__restrict__ pairsum, float *__restrict__ first_b,
+                                                            float2 *__restrict__ ext) {
+    const int H = (N1 * N2) / 2;
+    const int t = blockIdx.x * kAvgThreads + threadIdx.x;
+    if (t >= H) return;
+    // shifted index 0 <-> bin N/2: k1 = 0, k2 = N2/2 (N1 > 1)  or  pair N/4 (N1 == 1)
+    const bool is_x0 = (N1 > 1 ? (t == N2 / 2) : (t == H / 2));
+    double ma_a = ma[t], ma_b = ma[H + t], maa_a = maa[t], maa_b = maa[H + t];
+    for (int f0 = 0; f0 < nf; f0 += kAvgUnroll) {
+        float2 m[kAvgUnroll];
+#pragma unroll
+        for (int u = 0; u < kAvgUnroll; ++u) m[u] = (f0 + u < nf) ? mag2[(int64_t)(f0 + u) * H + t] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < kAvgUnroll; ++u) {
+            const int f = f0 + u;
+            if (f < nf) {
+                const double xa = (double)m[u].x, xb = (double)m[u].y;
+                if (maa_a != maa_a) maa_a = xa;
+                maa_a += (ma_a - maa_a) * rate;
+                if (ma_a != ma_a) ma_a = xa;
+                ma_a += (xa - ma_a) * rate;
+                if (maa_b != maa_b) maa_b = xb;
+                maa_b += (ma_b - maa_b) * rate;
+                if (ma_b != ma_b) ma_b = xb;
+                ma_b += (xb - ma_b) * rate;
+                pairsum[(int64_t)f * H + t] = (float)(maa_a + maa_b);
+                ext[(int64_t)f * H + t] = make_float2((float)fmax(maa_a, maa_b), (float)fmin(maa_a, maa_b));
+                if (is_x0) first_b[f] = (float)maa_b;
+            }
         }
     }
-    if (live) { ma[pa] = ma_a; ma[pb] = ma_b; maa[pa] = maa_a; maa[pb] = maa_b; }
+    ma[t] = ma_a; ma[H + t] = ma_b; maa[t] = maa_a; maa[H + t] = maa_b;
 }
 
-// floor / ceil trackers across the frames of the batch (sequential, one thread)  SpectrumVisualProcessor.cpp:494-521
-struct SpecScalars { double ceil_ma, ceil_maa, floor_ma, floor_maa; };
+// per-frame reduction of the extrema: grid = frames, 256 threads
 struct SpecFrameOut { double point_ceil, point_floor; };
+__global__ __launch_bounds__(256) void spec_minmax(const float2 *__restrict__ ext, int H, SpecFrameOut *fo) {
+    __shared__ float smx[4], smn[4];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    float mx = 0.f, mn = 3.0e38f;
+    for (int i = tid; i < H; i += 256) { const float2 v = ext[(int64_t)f * H + i]; mx = fmaxf(mx, v.x); mn = fminf(mn, v.y); }
+    for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_down(mx, o, 64)); mn = fminf(mn, __shfl_down(mn, o, 64)); }
+    if ((tid & 63) == 0) { smx[tid >> 6] = mx; smn[tid >> 6] = mn; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < 4; ++i) { mx = fmaxf(mx, smx[i]); mn = fminf(mn, smn[i]); }
+        fo[f].point_ceil = (double)mx; fo[f].point_floor = (double)mn;
+    }
+}
 
-__global__ void spec_trackers(const SpecMinMax *__restrict__ mm, int nf, SpecScalars *st, SpecFrameOut *fo) {
+// floor / ceil trackers across the frames of the batch (short serial recurrences)  SpectrumVisualProcessor.cpp:494-521
+struct SpecScalars { double ceil_ma, ceil_maa, floor_ma, floor_maa; };
+
+__global__ void spec_trackers(int nf, SpecScalars *st, SpecFrameOut *fo) {
     if (threadIdx.x || blockIdx.x) return;
     SpecScalars s = *st;
     for (int f = 0; f < nf; ++f) {
-        const double mx = __longlong_as_double((long long)mm[f].mx), mn = __longlong_as_double((long long)mm[f].mn);
+        const float mx = (float)fo[f].point_ceil, mn = (float)fo[f].point_floor;
         float fft_ceil = 0.f, fft_floor = 1.f;          // the reference keeps these two in float (:436)
-        if (mx > (double)fft_ceil) fft_ceil = (float)mx;
-        if (mn < (double)fft_floor) fft_floor = (float)mn;
+        if (mx > fft_ceil) fft_ceil = mx;
+        if (mn < fft_floor) fft_floor = mn;
         if (s.ceil_ma != s.ceil_ma) s.ceil_ma = fft_ceil;
         s.ceil_ma = s.ceil_ma + ((double)fft_ceil - s.ceil_ma) * 0.05;
         if (s.ceil_maa != s.ceil_maa) s.ceil_maa = fft_ceil;
@@ -220,11 +243,6 @@ __global__ __launch_bounds__(256) void spec_display(const float *__restrict__ pa
     float *o = points + ((int64_t)f * F + x) * 2;
     o[0] = (float)x / (float)F;
     o[1] = (float)v;
-}
-
-__global__ void spec_reset_minmax(SpecMinMax *mm, int nf) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nf) { mm[i].mx = 0ull; mm[i].mn = (unsigned long long)__double_as_longlong(1e300); }
 }
 
 // assemble frame 0 of a contiguous run from (carry ++ head of the new data)

@@ -50,6 +50,19 @@ class Context:
         H.check(self._l.csdr_ctx_timer_stop(self.h, C.byref(ms)))
         return ms.value
 
+    def profile_enable(self, on=True):
+        H.check(self._l.csdr_ctx_profile_enable(self.h, int(bool(on))))
+
+    def profile(self):
+        """-> {kernel name: (total_ms, launches)} accumulated since profile_enable(True)"""
+        out = {}
+        for i in range(self._l.csdr_ctx_profile_num_kernels()):
+            ms, n = C.c_double(), C.c_int64()
+            H.check(self._l.csdr_ctx_profile_fetch(self.h, i, C.byref(ms), C.byref(n)))
+            if n.value:
+                out[self._l.csdr_ctx_profile_kernel_name(i).decode()] = (ms.value, n.value)
+        return out
+
     def close(self):
         if self.h:
             self._l.csdr_ctx_destroy(self.h)

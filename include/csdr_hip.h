@@ -50,6 +50,12 @@ void *csdr_ctx_stream(csdr_ctx *ctx);              /* the hipStream_t every kern
 /* HIP-event timer on the ctx stream (bench.py roofline leg): start/stop bracket, returns milliseconds. */
 int  csdr_ctx_timer_start(csdr_ctx *ctx);
 int  csdr_ctx_timer_stop(csdr_ctx *ctx, float *ms);
+/* Optional per-kernel profile: while enabled every kernel launch of this ctx is bracketed by HIP events on the
+ * ctx stream; fetch returns the accumulated device time and launch count of kernel `id` (0 .. num_kernels-1). */
+int  csdr_ctx_profile_enable(csdr_ctx *ctx, int on);
+int  csdr_ctx_profile_num_kernels(void);
+const char *csdr_ctx_profile_kernel_name(int id);
+int  csdr_ctx_profile_fetch(csdr_ctx *ctx, int id, double *total_ms, int64_t *launches);
 /* raw device memory for callers without a GPU array library (tests written in C/C++) */
 int  csdr_dev_alloc(csdr_ctx *ctx, uint64_t bytes, void **dev);
 int  csdr_dev_free(csdr_ctx *ctx, void *dev);

@@ -725,3 +725,4 @@ int oracle_ssb_block(void *nco, void *iir, void *hilb, int usb, cf32 *in, unsign
     }
     return 0;
 }
+#include "chain_bench.inc"

@@ -282,3 +282,4 @@ int oracle_ssb_block(obj nco, obj iir, obj hilb, int usb, cf32 *in, unsigned n, 
 }
 /* raw object peek for pinning integer state (nco theta/d_theta at +0x1004/+0x1008) */
 void ref_peek(const void *p, unsigned off, void *dst, unsigned n) { memcpy(dst, (const char *)p + off, n); }
+#include "../chain_bench.inc"
