@@ -18,6 +18,22 @@ def hipcc():
     raise RuntimeError("hipcc not found: the HIP extension cannot be built")
 
 
+DESIGN_SRC = os.path.join(HERE, "csrc", "design_capi.cpp")
+DESIGN_OUT = os.path.join(HERE, "libcsdr_design.so")
+
+
+def build_design(force=False, verbose=True):
+    """host-only helper library (g++): the cold-path filter design, testable without a GPU"""
+    deps = [DESIGN_SRC, os.path.join(HERE, "csrc", "design.hpp")]
+    if not force and os.path.exists(DESIGN_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(DESIGN_OUT) for d in deps):
+        return DESIGN_OUT
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", DESIGN_SRC, "-o", DESIGN_OUT]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return DESIGN_OUT
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True
@@ -26,6 +42,7 @@ def needs_build():
 
 
 def build(force=False, verbose=True):
+    build_design(force, verbose)
     if not force and not needs_build():
         return OUT
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",

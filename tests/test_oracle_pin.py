@@ -1,0 +1,187 @@
+"""CPU tests that PIN the oracle: the plain-C restatement (oracle/liquid_port.c) and the CubicSDR control-flow
+restatement (oracle/cubicsdr_chain.py) against tests/golden/liquid_1_5_0.npz, a fixture generated from the reference's
+own liquid-dsp 1.5.0 binary by tests/golden/gen_golden.py.  Integer items must be exact; float samples within 5e-6 of
+the peak (the restatement's rounding differs from the -ffast-math SSE build of the reference at the 1e-6 level).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle.liquid_api as A
+from oracle.cubicsdr_chain import RefDemod, RefSDRPost, RefSpectrum
+from tests.util import rel_err
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 5e-6
+
+
+@pytest.fixture(scope="module")
+def G():
+    return np.load(os.path.join(ROOT, "tests", "golden", "liquid_1_5_0.npz"))
+
+
+@pytest.fixture(scope="module")
+def P():
+    if not A.available("port"):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "_ref/liboracle_port.so"], check=True)
+    return A.load("port")
+
+
+def backends():
+    out = ["port"]
+    if A.available("ref"):
+        out.append("ref")
+    return out
+
+
+def test_design_helpers(G, P):
+    for name, n, fc, As in [("kaiser33", 33, 0.1, 60.0), ("kaiser161", 161, 0.025, 60.0)]:
+        h = np.zeros(n, np.float32)
+        P.liquid_firdes_kaiser(n, fc, As, 0.0, A.ptr(h))
+        assert rel_err(h, G["firdes_" + name]) < TOL
+    h = np.zeros(51, np.float32)
+    P.liquid_firdes_notch(25, 0.0, 30.0, A.ptr(h))
+    assert rel_err(h, G["firdes_notch_25_30"]) < TOL
+    got = [P.estimate_req_filter_len(df, As) for df, As in [(0.1, 60.0), (0.05, 65.0), (0.35, 65.0), (0.2, 65.0)]]
+    assert got == list(G["estimate_req_filter_len"])
+
+
+def test_halfband_tables_are_the_reference_designs(G, P):
+    for m in (3, 5, 10):
+        q = P.resamp2_crcf_create(m, 0.0, 65.0)
+        yy = np.zeros(8 * m + 4, np.complex64)
+        for k in range(4 * m + 2):
+            P.resamp2_crcf_interp_execute(q, A.cpx(1.0 if k == 0 else 0.0), A.ptr(yy[2 * k:2 * k + 2]))
+        assert np.array_equal(yy.real[1::2][:2 * m], G["halfband_h1_m%d" % m])      # exact: the taps are tabulated
+
+
+def test_nco_phase_words_bit_exact(G, P):
+    x = G["nco_in"]
+    for i, f in enumerate(G["nco_freqs"]):
+        q = P.nco_crcf_create(A.LIQUID_VCO)
+        P.nco_crcf_set_frequency(q, float(f))
+        y = np.zeros_like(x)
+        P.nco_crcf_mix_block_down(q, A.ptr(x), A.ptr(y), x.size)
+        th, dth = C.c_uint32(), C.c_uint32()
+        P.port_nco_get_state(C.c_void_p(q), C.byref(th), C.byref(dth))
+        assert (th.value, dth.value) == tuple(int(v) for v in G["nco_words_after_600"][i])
+        assert rel_err(y, G["nco_mix_down"][i]) < TOL
+
+
+@pytest.mark.parametrize("tag,bs", [("r0025", 2500), ("r0119", 2111), ("r0108", 2500), ("r04", 777), ("r06", 500)])
+def test_msresamp_crcf(G, P, tag, bs):
+    q = P.msresamp_crcf_create(float(G["msresamp_crcf_%s_rate" % tag]), 60.0)
+    xin = G["msresamp_crcf_%s_in" % tag]
+    outs, cnts = [], []
+    for b in range(3):
+        xb = np.ascontiguousarray(xin[b * bs:(b + 1) * bs])
+        y = np.zeros(bs + 600, np.complex64); ny = C.c_uint()
+        P.msresamp_crcf_execute(q, A.ptr(xb), bs, A.ptr(y), C.byref(ny))
+        outs.append(y[:ny.value].copy()); cnts.append(ny.value)
+    assert cnts == list(G["msresamp_crcf_%s_counts" % tag])                       # bit-exact decimation indices
+    assert rel_err(np.concatenate(outs), G["msresamp_crcf_%s_out" % tag]) < TOL
+
+
+@pytest.mark.parametrize("tag,bs", [("r384", 120), ("r8", 60), ("r889", 55)])
+def test_msresamp_rrrf(G, P, tag, bs):
+    r = float(G["msresamp_rrrf_%s_rate" % tag])
+    q = P.msresamp_rrrf_create(r, 60.0)
+    xin = G["msresamp_rrrf_%s_in" % tag]
+    outs, cnts = [], []
+    for b in range(3):
+        xb = np.ascontiguousarray(xin[b * bs:(b + 1) * bs])
+        y = np.zeros(int(bs * r) + 600, np.float32); ny = C.c_uint()
+        P.msresamp_rrrf_execute(q, A.ptr(xb), bs, A.ptr(y), C.byref(ny))
+        outs.append(y[:ny.value].copy()); cnts.append(ny.value)
+    assert cnts == list(G["msresamp_rrrf_%s_counts" % tag])
+    assert rel_err(np.concatenate(outs), G["msresamp_rrrf_%s_out" % tag]) < TOL
+
+
+@pytest.mark.parametrize("M", [4, 20, 122])
+def test_firpfbch(G, P, M):
+    q = P.firpfbch_crcf_create_kaiser(A.LIQUID_ANALYZER, M, 4, 60.0)
+    xin = np.ascontiguousarray(G["firpfbch_M%d_in" % M]); y = np.zeros_like(xin)
+    P.oracle_firpfbch_analyzer_block(C.c_void_p(q), M, A.ptr(xin), xin.size // M, A.ptr(y))
+    assert rel_err(y, G["firpfbch_M%d_out" % M]) < TOL
+
+
+def test_filters_and_modems(G, P):
+    x = np.ascontiguousarray(G["dcblock_in"]); y = np.zeros_like(x)
+    P.iirfilt_crcf_execute_block(P.iirfilt_crcf_create_dc_blocker(0.0005), A.ptr(x), x.size, A.ptr(y))
+    assert rel_err(y, G["dcblock_out"]) < TOL
+    x = np.ascontiguousarray(G["butter6_in"]); y = np.zeros_like(x)
+    P.iirfilt_crcf_execute_block(P.iirfilt_crcf_create_lowpass(6, 0.25), A.ptr(x), x.size, A.ptr(y))
+    assert rel_err(y, G["butter6_out"]) < TOL
+    x = np.ascontiguousarray(G["freqdem_in"]); yf = np.zeros(x.size, np.float32)
+    P.freqdem_demodulate_block(P.freqdem_create(0.5), A.ptr(x), x.size, A.ptr(yf))
+    assert rel_err(yf, G["freqdem_out"]) < TOL
+    x = np.ascontiguousarray(G["am_in"]); yf = np.zeros(x.size, np.float32)
+    P.oracle_am_block(C.c_void_p(P.firfilt_rrrf_create_dc_blocker(25, 30.0)), A.ptr(x), x.size, A.ptr(yf))
+    assert rel_err(yf, G["am_out"]) < TOL
+    for usb in (1, 0):
+        x = np.ascontiguousarray(G["ssb_usb%d_in" % usb]); yf = np.zeros(x.size, np.float32)
+        nco = P.nco_crcf_create(A.LIQUID_NCO); P.nco_crcf_set_frequency(nco, float(np.float32(2 * np.pi * 0.25)))
+        P.oracle_ssb_block(C.c_void_p(nco), C.c_void_p(P.iirfilt_crcf_create_lowpass(6, 0.25)), C.c_void_p(P.firhilbf_create(5, 90.0)),
+                           usb, A.ptr(x), x.size, A.ptr(yf))
+        assert rel_err(yf, G["ssb_usb%d_out" % usb]) < TOL
+
+
+@pytest.mark.parametrize("n", [8, 256, 4096])
+def test_fft(G, P, n):
+    x = np.ascontiguousarray(G["fft%d_in" % n]); y = np.zeros_like(x)
+    P.fft_execute(P.fft_create_plan(n, A.ptr(x), A.ptr(y), A.LIQUID_FFT_FORWARD, 0))
+    assert rel_err(y, G["fft%d_out" % n]) < TOL
+    assert rel_err(np.fft.fft(x.astype(np.complex128)), G["fft%d_out" % n]) < TOL   # unnormalised forward DFT
+
+
+@pytest.mark.parametrize("backend", backends())
+def test_cubicsdr_chain_end_to_end(G, backend):
+    """SDRPostThread -> DemodulatorPreThread -> Modem -> audio, 3 blocks, 4 modem kinds; plus the spectrum processor."""
+    fs, M, block, center = 2400000, 4, 8000, 100000000
+    kinds = ["NBFM", "AM", "USB", "LSB"]; bws = [12500, 6000, 5400, 5400]
+    fr = [int(v) for v in G["chain_freqs"]]
+    xin = G["chain_in"]
+    rp = RefSDRPost(backend, fs, M)
+    rds = [RefDemod(backend, k, bw, f, rp.chan_bw) for k, bw, f in zip(kinds, bws, fr)]
+    audio = [[] for _ in kinds]; n_iq = [[] for _ in kinds]; lev = [[] for _ in kinds]
+    for b in range(3):
+        rp.run_block(xin[b * block:(b + 1) * block], center)
+        cache = {}
+        for i, rd in enumerate(rds):
+            ch = rp.channel_at(rd.frequency)
+            if ch not in cache:
+                cache[ch] = rp.channel_data(ch)
+            riq = rd.pre(*cache[ch]); o = rd.demodulate(riq)
+            audio[i].append(o["audio"]); n_iq[i].append(riq.size); lev[i].append(o["level_accum"])
+    for i, k in enumerate(kinds):
+        assert n_iq[i] == list(G["chain_%s_n_iq" % k])
+        assert [a.size for a in audio[i]] == list(G["chain_%s_n_audio" % k])
+        assert rel_err(np.concatenate(audio[i]), G["chain_%s_audio" % k]) < 2 * TOL, k
+        assert np.allclose(lev[i], G["chain_%s_level" % k], rtol=1e-5)
+    sp = RefSpectrum(backend, 512)
+    for b in range(3):
+        p, c, f = sp.process_frame(xin[b * block:b * block + 1024])
+        assert rel_err(p, G["spec512_points"][b]) < 2 * TOL
+        assert abs(c - G["spec512_ceil"][b]) <= 1e-6 * abs(c)
+
+
+@pytest.mark.skipif(not A.available("ref"), reason="reference DLL not staged (oracle/_ref/libliquid.dll)")
+def test_port_tracks_reference_on_fresh_inputs(P):
+    """beyond the fixture: random ratios / block sizes, restatement vs the reference binary run here"""
+    R = A.load("ref")
+    rng = np.random.default_rng(99)
+    for trial in range(6):
+        r = float(rng.uniform(0.004, 0.95)); bs = int(rng.integers(300, 3000))
+        qa, qb = R.msresamp_crcf_create(r, 60.0), P.msresamp_crcf_create(r, 60.0)
+        for blk in range(3):
+            x = ((rng.standard_normal(bs) + 1j * rng.standard_normal(bs)) * 0.3).astype(np.complex64)
+            ya = np.zeros(bs + 600, np.complex64); yb = np.zeros(bs + 600, np.complex64); na, nb = C.c_uint(), C.c_uint()
+            R.msresamp_crcf_execute(qa, A.ptr(x), bs, A.ptr(ya), C.byref(na)); P.msresamp_crcf_execute(qb, A.ptr(x), bs, A.ptr(yb), C.byref(nb))
+            assert na.value == nb.value, (r, bs, blk)
+            assert rel_err(yb[:nb.value], ya[:na.value]) < TOL if na.value else True
+        S, bi, ph, st = C.c_uint(), C.c_uint(), C.c_uint32(), C.c_uint32()
+        P.port_msresamp_get_state(C.c_void_p(qb), C.byref(S), C.byref(bi), C.byref(ph), C.byref(st))
+        assert ph.value < (1 << 25)
