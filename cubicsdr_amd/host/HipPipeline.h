@@ -1,0 +1,302 @@
+// HipPipeline.h -- the reference's hot-path objects re-hosted on the HIP library (include/csdr_hip.h).
+//
+//   DemodulatorInstance / DemodulatorMgr : setters/getters of src/demod/DemodulatorInstance.h:36-136 and
+//       DemodulatorMgr.cpp:35-48; each instance owns one slot of a csdr_bank instead of three threads.
+//   SDRPostThread : IOThread with the queue names of src/sdr/SDRPostThread.cpp:162-165; per input block it runs the
+//       channelizer + every active demodulator on the GPU, then applies DemodulatorThread::run's host-side state
+//       machine (level / floor / ceil / squelch, DemodulatorThread.cpp:142-220) and try_pushes the audio
+//       (:318-328) -- drop-on-full exactly where the reference drops.
+//   SpectrumVisualProcessor : VisualProcessor<DemodulatorThreadIQData, SpectrumVisualData> with the setters of
+//       src/process/SpectrumVisualProcessor.h:29-58 (full-span view).
+#pragma once
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/csdr_hip.h"
+#include "DataTypes.h"
+#include "IOThread.h"
+#include "VisualProcessor.h"
+
+#define HEARTBEAT_CHECK_PERIOD_MICROS (50 * 1000)
+
+inline void csdr_must(int rc, const char *what) {
+    if (rc != CSDR_OK) throw std::runtime_error(std::string(what) + ": " + csdr_strerror(rc) + " (" + csdr_last_error() + ")");
+}
+
+class DemodulatorMgr;
+
+class DemodulatorInstance {
+public:
+    DemodulatorInstance(DemodulatorMgr *mgr, int slot) : mgr_(mgr), slot_(slot) {
+        audioQueue_ = std::make_shared<AudioThreadInputQueue>();
+        audioQueue_->set_max_num_items(100);
+    }
+    // --- configuration (applied at the next block, like the atomics of DemodulatorPreThread.cpp:293-336)
+    void setDemodulatorType(const std::string &t) { std::lock_guard<std::mutex> g(mu_); type_ = t; bandwidth_ = defaultBandwidth(t); dirty_ = true; }
+    std::string getDemodulatorType() { std::lock_guard<std::mutex> g(mu_); return type_; }
+    void setBandwidth(int bw) { std::lock_guard<std::mutex> g(mu_); bandwidth_ = bw; dirty_ = true; }
+    int getBandwidth() { std::lock_guard<std::mutex> g(mu_); return bandwidth_; }
+    void setFrequency(long long f) { frequency_.store(f); }
+    long long getFrequency() { return frequency_.load(); }
+    void setAudioSampleRate(int r) { std::lock_guard<std::mutex> g(mu_); audioRate_ = r; dirty_ = true; }
+    int getAudioSampleRate() { std::lock_guard<std::mutex> g(mu_); return audioRate_; }
+    void setActive(bool a) { active_.store(a); }
+    bool isActive() { return active_.load(); }
+    void setSquelchEnabled(bool e) { squelchEnabled_.store(e); }
+    bool isSquelchEnabled() { return squelchEnabled_.load(); }
+    void setSquelchLevel(float l) { squelchLevel_.store(l); }
+    float getSquelchLevel() { return squelchLevel_.load(); }
+    void setMuted(bool m) { muted_.store(m); }
+    bool isMuted() { return muted_.load(); }
+    float getSignalLevel() { return signalLevel_.load(); }
+    float getSignalFloor() { return signalFloor_.load(); }
+    float getSignalCeil() { return signalCeil_.load(); }
+    AudioThreadInputQueuePtr getAudioOutputQueue() { return audioQueue_; }   // "AudioDataOutput" (DemodulatorThread.cpp:80)
+    int slot() const { return slot_; }
+
+    static int defaultBandwidth(const std::string &t) {      // factory table, CubicSDR.cpp:305-313
+        if (t == "FM") return 200000;
+        if (t == "NBFM") return 12500;
+        if (t == "AM") return 6000;
+        if (t == "USB" || t == "LSB") return 5400;
+        return 12500;
+    }
+    static int modemId(const std::string &t) {
+        if (t == "NBFM") return CSDR_MODEM_NBFM;
+        if (t == "FM") return CSDR_MODEM_FM;
+        if (t == "AM") return CSDR_MODEM_AM;
+        if (t == "USB") return CSDR_MODEM_USB;
+        if (t == "LSB") return CSDR_MODEM_LSB;
+        return -1;
+    }
+
+private:
+    friend class SDRPostThread;
+    DemodulatorMgr *mgr_;
+    int slot_;
+    std::mutex mu_;
+    std::string type_ = "NBFM";
+    int bandwidth_ = 12500, audioRate_ = 48000;
+    bool dirty_ = true;                       // needs csdr_bank_configure_slot
+    long long builtRate_ = 0;
+    std::atomic<long long> frequency_{0};
+    std::atomic_bool active_{false}, squelchEnabled_{false}, muted_{false};
+    std::atomic<float> squelchLevel_{-100.0f}, signalLevel_{-100.0f}, signalFloor_{-30.0f}, signalCeil_{30.0f};
+    bool squelchBreak_ = false;
+    AudioThreadInputQueuePtr audioQueue_;
+    ReBuffer<AudioThreadInput> outputBuffers_{"DemodulatorThreadBuffers"};
+};
+typedef std::shared_ptr<DemodulatorInstance> DemodulatorInstancePtr;
+
+class DemodulatorMgr {
+public:
+    explicit DemodulatorMgr(int maxDemods = 256) : max_(maxDemods) {}
+    DemodulatorInstancePtr newThread() {                     // DemodulatorMgr.cpp:35-48
+        std::lock_guard<std::recursive_mutex> g(mu_);
+        if ((int)demods_.size() >= max_) throw std::runtime_error("DemodulatorMgr: bank is full");
+        int slot = 0;
+        while (used_.count(slot)) ++slot;
+        used_[slot] = true;
+        auto d = std::make_shared<DemodulatorInstance>(this, slot);
+        demods_.push_back(d);
+        return d;
+    }
+    std::vector<DemodulatorInstancePtr> getDemodulators() { std::lock_guard<std::recursive_mutex> g(mu_); return demods_; }
+    void deleteThread(const DemodulatorInstancePtr &d) {
+        std::lock_guard<std::recursive_mutex> g(mu_);
+        for (auto it = demods_.begin(); it != demods_.end(); ++it)
+            if (*it == d) { used_.erase(d->slot()); demods_.erase(it); break; }
+    }
+    int capacity() const { return max_; }
+
+private:
+    std::recursive_mutex mu_;
+    std::vector<DemodulatorInstancePtr> demods_;
+    std::map<int, bool> used_;
+    int max_;
+};
+
+class SDRPostThread : public IOThread {
+public:
+    SDRPostThread(csdr_ctx *ctx, DemodulatorMgr *mgr) : ctx_(ctx), mgr_(mgr) {
+        csdr_must(csdr_post_create(ctx_, &post_), "csdr_post_create");
+        csdr_must(csdr_bank_create(ctx_, mgr->capacity(), 1, &bank_), "csdr_bank_create");
+    }
+    ~SDRPostThread() override { if (bank_) csdr_bank_destroy(bank_); if (post_) csdr_post_destroy(post_); }
+
+    void run() override {
+        auto iqIn = std::static_pointer_cast<SDRThreadIQDataQueue>(getInputQueue("IQDataInput"));
+        auto iqOut = std::static_pointer_cast<DemodulatorThreadInputQueue>(getOutputQueue("IQDataOutput"));
+        auto iqVisual = std::static_pointer_cast<DemodulatorThreadInputQueue>(getOutputQueue("IQVisualDataOutput"));
+        if (!iqIn) throw std::runtime_error("SDRPostThread: IQDataInput is not bound");
+        while (!stopping) {
+            SDRThreadIQDataPtr in;
+            if (!iqIn->pop(in, HEARTBEAT_CHECK_PERIOD_MICROS)) continue;      // SDRPostThread.cpp:170
+            if (!in || in->data.empty()) continue;
+            processBlock(*in, iqOut, iqVisual);
+            ++blocksProcessed;
+        }
+        if (iqVisual) iqVisual->flush();
+        iqIn->flush();
+        if (iqOut) iqOut->flush();
+    }
+    void terminate() override {
+        IOThread::terminate();
+        auto iqIn = std::static_pointer_cast<SDRThreadIQDataQueue>(getInputQueue("IQDataInput"));
+        if (iqIn) iqIn->flush();
+    }
+    std::atomic<long long> blocksProcessed{0};
+
+private:
+    void processBlock(SDRThreadIQData &in, const DemodulatorThreadInputQueuePtr &iqOut, const DemodulatorThreadInputQueuePtr &iqVisual) {
+        const int n = (int)in.data.size();
+        const int M = in.numChannels > 1 ? in.numChannels : 1;
+        if (in.sampleRate != sampleRate_ || M != numChannels_ || n > maxBlock_) {      // initPFBCH, :401-414
+            sampleRate_ = in.sampleRate; numChannels_ = M; maxBlock_ = n;
+            csdr_must(csdr_post_configure(post_, sampleRate_, M, M > 1 ? CSDR_POST_PFBCH : CSDR_POST_SINGLE, n, 1), "csdr_post_configure");
+        }
+        // full-rate copy to the visual queues first (getFullSampleRateIqData + pushVisualData, :221-245): never blocks
+        if (iqOut || iqVisual) {
+            DemodulatorThreadIQDataPtr vis = visualBuffers_.getBuffer();
+            vis->frequency = in.frequency; vis->sampleRate = in.sampleRate; vis->data = in.data;
+            if (iqOut) iqOut->try_push(vis);
+            if (iqVisual) iqVisual->try_push(vis);
+        }
+        // active set: in range of this block's span (updateActiveDemodulators, :44-98)
+        auto demods = mgr_->getDemodulators();
+        const long long chanRate = csdr_post_channel_bandwidth(post_);
+        std::vector<DemodulatorInstancePtr> run;
+        for (auto &d : demods) {
+            const bool inRange = std::llabs(in.frequency - d->getFrequency()) <= in.sampleRate / 2;
+            d->setActive(inRange);
+            bool rebuild;
+            csdr_demod_params p{};
+            {
+                std::lock_guard<std::mutex> g(d->mu_);
+                rebuild = d->dirty_ || d->builtRate_ != chanRate;
+                p.modem = DemodulatorInstance::modemId(d->type_); p.bandwidth = d->bandwidth_; p.audio_sample_rate = d->audioRate_;
+                p.frequency = d->getFrequency();
+                if (rebuild && inRange) { d->dirty_ = false; d->builtRate_ = chanRate; }
+            }
+            if (!inRange) { (void)csdr_bank_set_active(bank_, d->slot(), 0); continue; }
+            if (rebuild) csdr_must(csdr_bank_configure_slot(bank_, d->slot(), &p, post_), "csdr_bank_configure_slot");
+            csdr_must(csdr_bank_set_frequency(bank_, d->slot(), d->getFrequency()), "csdr_bank_set_frequency");
+            csdr_must(csdr_bank_set_active(bank_, d->slot(), 1), "csdr_bank_set_active");
+            run.push_back(d);
+        }
+        if (run.empty()) return;                                                     // :436 "if (!runDemods.empty())"
+        csdr_must(csdr_post_execute(post_, (const float *)in.data.data(), 0, 1, n, in.frequency), "csdr_post_execute");
+        csdr_must(csdr_bank_execute(bank_, post_), "csdr_bank_execute");
+        for (auto &d : run) finishDemod(*d);
+    }
+
+    static double linearToDb(double linear) { if (linear <= 1e-20) linear = 1e-20; return 20.0 * std::log10(linear); }   // DemodulatorThread.cpp:59-67
+
+    // DemodulatorThread::run after demodulate(): :142-233, :318-328
+    void finishDemod(DemodulatorInstance &d) {
+        csdr_block_result r;
+        int nb = 0;
+        csdr_must(csdr_bank_fetch_results(bank_, d.slot(), &r, 1, &nb), "csdr_bank_fetch_results");
+        if (nb != 1 || r.skipped || r.n_iq == 0) return;
+        AudioThreadInputPtr ati = d.outputBuffers_.getBuffer();
+        ati->sampleRate = d.getAudioSampleRate(); ati->inputRate = d.getBandwidth(); ati->channels = 1; ati->frequency = d.getFrequency();
+        ati->data.resize(r.n_audio);
+        int got = 0;
+        if (r.n_audio) csdr_must(csdr_bank_fetch_audio(bank_, d.slot(), ati->data.data(), r.n_audio, &got), "csdr_bank_fetch_audio");
+        const double sampleTime = double(r.n_iq) / double(d.getBandwidth());
+        double currentSignalLevel = 0;
+        if (!ati->data.empty()) {
+            currentSignalLevel = linearToDb(r.level_accum / double(r.level_count));
+            float sf = d.signalFloor_, sc = d.signalCeil_, sl = d.squelchLevel_;
+            if (currentSignalLevel > sc) sc = (float)currentSignalLevel;
+            if (currentSignalLevel < sf) sf = (float)currentSignalLevel;
+            if (sl + 1.0f > sc) sc = sl + 1.0f;
+            if ((sf + 2.0f) > sc) sc = sf + 2.0f;
+            sc -= (sc - (currentSignalLevel + 2.0f)) * sampleTime * 0.05f;
+            sf += ((currentSignalLevel - 5.0f) - sf) * sampleTime * 0.15f;
+            d.signalFloor_ = sf; d.signalCeil_ = sc;
+        }
+        float lvl = d.signalLevel_;
+        if (currentSignalLevel > lvl) lvl = lvl + (currentSignalLevel - lvl) * 0.5;
+        else lvl = lvl + (currentSignalLevel - lvl) * 0.05 * sampleTime * 30.0;
+        d.signalLevel_ = lvl;
+        const bool squelched = d.squelchEnabled_ && (lvl < d.squelchLevel_);
+        if (d.squelchEnabled_) {
+            if (!squelched && !d.squelchBreak_) d.squelchBreak_ = true;
+            else if (squelched && d.squelchBreak_) d.squelchBreak_ = false;
+        }
+        ati->peak = r.audio_peak;
+        ati->is_squelch_active = squelched;
+        if (!squelched && !d.muted_) (void)d.audioQueue_->try_push(ati);            // never blocks (:322)
+    }
+
+    csdr_ctx *ctx_;
+    DemodulatorMgr *mgr_;
+    csdr_post *post_ = nullptr;
+    csdr_bank *bank_ = nullptr;
+    long long sampleRate_ = 0;
+    int numChannels_ = 0, maxBlock_ = 0;
+    ReBuffer<DemodulatorThreadIQData> visualBuffers_{"SDRPostThreadVisualDataBuffers"};
+};
+
+class SpectrumVisualProcessor : public VisualProcessor<DemodulatorThreadIQData, SpectrumVisualData> {
+public:
+    explicit SpectrumVisualProcessor(csdr_ctx *ctx) : ctx_(ctx) { csdr_must(csdr_spec_create(ctx_, &spec_), "csdr_spec_create"); }
+    ~SpectrumVisualProcessor() override { if (spec_) csdr_spec_destroy(spec_); }
+
+    void setup(unsigned int fftSize_in) {                                            // :140-178
+        std::lock_guard<std::mutex> g(busy_run);
+        fftSize = fftSize_in;
+        csdr_must(csdr_spec_setup(spec_, (int)fftSize, 1), "csdr_spec_setup");
+        csdr_must(csdr_spec_set_average_rate(spec_, fft_average_rate), "csdr_spec_set_average_rate");
+        csdr_must(csdr_spec_set_scale_factor(spec_, scaleFactor), "csdr_spec_set_scale_factor");
+    }
+    void setFFTSize(unsigned int n) { std::lock_guard<std::mutex> g(busy_run); if (n != fftSize) { newFFTSize = n; fftSizeChanged = true; } }
+    unsigned int getFFTSize() { std::lock_guard<std::mutex> g(busy_run); return fftSizeChanged ? newFFTSize : fftSize; }
+    void setFFTAverageRate(float r) { std::lock_guard<std::mutex> g(busy_run); fft_average_rate = r; if (fftSize) csdr_spec_set_average_rate(spec_, r); }
+    float getFFTAverageRate() { std::lock_guard<std::mutex> g(busy_run); return fft_average_rate; }
+    void setScaleFactor(float sf) { std::lock_guard<std::mutex> g(busy_run); scaleFactor = sf; if (fftSize) csdr_spec_set_scale_factor(spec_, sf); }
+    float getScaleFactor() { std::lock_guard<std::mutex> g(busy_run); return scaleFactor; }
+    void setCenterFrequency(long long f) { std::lock_guard<std::mutex> g(busy_run); centerFreq = f; }
+    long long getCenterFrequency() { std::lock_guard<std::mutex> g(busy_run); return centerFreq; }
+    void setBandwidth(long b) { std::lock_guard<std::mutex> g(busy_run); bandwidth = b; }
+    long getBandwidth() { std::lock_guard<std::mutex> g(busy_run); return bandwidth; }
+    int getDesiredInputSize() { std::lock_guard<std::mutex> g(busy_run); return (int)(2 * fftSize); }
+
+protected:
+    void process() override {                                                        // :212-637, full-span branch
+        if (!isOutputEmpty()) return;
+        if (!input || input->empty()) return;
+        bool doSetup = false;
+        { std::lock_guard<std::mutex> g(busy_run); if (fftSizeChanged) { doSetup = true; fftSizeChanged = false; } }
+        if (doSetup) setup(newFFTSize);
+        DemodulatorThreadIQDataPtr iq;
+        if (!input->pop(iq, HEARTBEAT_CHECK_PERIOD_MICROS) || !iq || iq->data.empty()) return;
+        std::lock_guard<std::mutex> g(busy_run);
+        if (!fftSize || iq->data.size() < 2 * (size_t)fftSize) return;              // short-block overlap path (:399-421) not built
+        csdr_must(csdr_spec_process(spec_, (const float *)iq->data.data(), 0, 1, (int)iq->data.size(), CSDR_SPEC_FIRST_FRAME), "csdr_spec_process");
+        SpectrumVisualDataPtr out = outputBuffers.getBuffer();
+        out->spectrum_points.resize(fftSize * 2);
+        out->spectrum_hold_points.resize(0);
+        csdr_must(csdr_spec_fetch(spec_, 0, out->spectrum_points.data(), (int)out->spectrum_points.size(), &out->fft_ceiling, &out->fft_floor), "csdr_spec_fetch");
+        out->centerFreq = centerFreq; out->bandwidth = (int)bandwidth;
+        distribute(out);
+    }
+
+private:
+    csdr_ctx *ctx_;
+    csdr_spec *spec_ = nullptr;
+    std::mutex busy_run;
+    unsigned int fftSize = 0, newFFTSize = 0;
+    bool fftSizeChanged = false;
+    float fft_average_rate = 0.65f, scaleFactor = 1.0f;
+    long long centerFreq = 0;
+    long bandwidth = 0;
+    ReBuffer<SpectrumVisualData> outputBuffers{"SpectrumVisualProcessorBuffers"};
+};

@@ -1,0 +1,216 @@
+// test_host.cpp -- tests of the C++ host mirror (cubicsdr_amd/host/).
+//   ./test_host cpu   : ThreadBlockingQueue timeout semantics, ReBuffer reuse rule, IOThread lifecycle, VisualProcessor
+//                       distribute (reference behaviours listed in SURVEY.md section 4, item 2); no GPU needed.
+//   ./test_host gpu   : end-to-end: synthetic SDRThreadIQData blocks -> SDRPostThread (HIP) -> audio queue of an
+//                       NBFM DemodulatorInstance + SpectrumVisualProcessor output queue.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+
+#include "../../cubicsdr_amd/host/HipPipeline.h"
+
+static int g_fail = 0;
+#define CHECK(cond) do { if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); ++g_fail; } } while (0)
+
+struct Item { int v; };
+typedef std::shared_ptr<Item> ItemPtr;
+
+static void test_queue() {
+    ThreadBlockingQueue<ItemPtr> q;
+    ItemPtr a = std::make_shared<Item>(Item{1}), b = std::make_shared<Item>(Item{2}), out;
+    CHECK(q.empty() && !q.full() && q.size() == 0);
+    CHECK(q.try_push(a));                      // capacity defaults to 1
+    CHECK(q.full() && !q.try_push(b));
+    CHECK(!q.push(b, NON_BLOCKING_TIMEOUT));   // <= 100 us == try_push
+    auto t0 = std::chrono::steady_clock::now();
+    CHECK(!q.push(b, 20000));                  // timed wait expires
+    auto dt = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+    CHECK(dt >= 15 && dt < 500);
+    q.set_max_num_items(3);
+    CHECK(q.push(b, 20000) && q.size() == 2);
+    q.set_max_num_items(1);                    // never shrinks
+    CHECK(q.try_push(a) && q.full());
+    CHECK(q.pop(out) && out->v == 1);          // FIFO
+    CHECK(q.try_pop(out) && out->v == 2);
+    q.flush();
+    CHECK(q.empty() && !q.try_pop(out) && !q.pop(out, NON_BLOCKING_TIMEOUT));
+    t0 = std::chrono::steady_clock::now();
+    CHECK(!q.pop(out, 20000));
+    dt = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+    CHECK(dt >= 15 && dt < 500);
+    // blocking pop is released by a producer thread; blocking push by a consumer
+    std::thread prod([&] { std::this_thread::sleep_for(std::chrono::milliseconds(20)); q.push(a); });
+    CHECK(q.pop(out) && out->v == 1);
+    prod.join();
+    ThreadBlockingQueue<ItemPtr> q1;
+    q1.push(a);
+    std::thread cons([&] { std::this_thread::sleep_for(std::chrono::milliseconds(20)); ItemPtr o; q1.pop(o); });
+    CHECK(q1.push(b));                         // infinite wait until the consumer makes room
+    cons.join();
+    CHECK(q1.size() == 1);
+}
+
+static void test_rebuffer() {
+    ReBuffer<Item> pool("test");
+    ItemPtr a = pool.getBuffer();
+    Item *pa = a.get();
+    ItemPtr b = pool.getBuffer();              // a still referenced -> a new buffer
+    CHECK(b.get() != pa && pool.size() == 2);
+    a.reset();
+    ItemPtr c = pool.getBuffer();              // a's buffer is free again (use_count == 1) -> re-used
+    CHECK(c.get() == pa && pool.size() == 2);
+    b.reset(); c.reset();
+    for (int i = 0; i < 3 * REBUFFER_GC_LIMIT; ++i) { ItemPtr t = pool.getBuffer(); }
+    CHECK(pool.size() == 1);                   // the idle second entry aged out
+    pool.purge();
+    CHECK(pool.size() == 0);
+}
+
+struct CountThread : IOThread {
+    std::atomic<int> n{0};
+    void run() override {
+        auto q = std::static_pointer_cast<ThreadBlockingQueue<ItemPtr>>(getInputQueue("In"));
+        while (!stopping) { ItemPtr it; if (q->pop(it, 10000)) n += it->v; }
+    }
+};
+static void test_iothread() {
+    CountThread t;
+    auto q = std::make_shared<ThreadBlockingQueue<ItemPtr>>();
+    q->set_max_num_items(10);
+    t.setInputQueue("In", q);
+    CHECK(t.getInputQueue("In") == q && t.getInputQueue("nope") == nullptr);
+    std::thread th(&IOThread::threadMain, &t);
+    for (int i = 0; i < 5; ++i) q->push(std::make_shared<Item>(Item{2}));
+    std::this_thread::sleep_for(std::chrono::milliseconds(50));
+    CHECK(!t.isTerminated());
+    t.terminate();
+    CHECK(t.isTerminated(1000));
+    th.join();
+    CHECK(t.n == 10);
+}
+
+struct Doubler : VisualProcessor<Item, Item> {
+    int processed = 0;
+    void process() override {
+        ItemPtr in;
+        if (!input->pop(in, 1000)) return;
+        ++processed;
+        distribute(std::make_shared<Item>(Item{in->v * 2}), 1000);
+    }
+};
+static void test_visual_processor() {
+    Doubler p;
+    auto in = std::make_shared<Doubler::VisualInputQueueType>();
+    auto o1 = std::make_shared<Doubler::VisualOutputQueueType>(), o2 = std::make_shared<Doubler::VisualOutputQueueType>();
+    in->set_max_num_items(4);
+    p.setInput(in); p.attachOutput(o1); p.attachOutput(o2);
+    CHECK(p.isInputEmpty() && p.isOutputEmpty() && p.isAnyOutputEmpty());
+    p.run();                                   // empty input: nothing happens
+    CHECK(p.processed == 0);
+    in->push(std::make_shared<Item>(Item{21}));
+    p.run();
+    ItemPtr a, b;
+    CHECK(p.processed == 1 && o1->full() && !p.isOutputEmpty() && !p.isAnyOutputEmpty());
+    CHECK(o1->try_pop(a) && o2->try_pop(b) && a == b && a->v == 42);      // the SAME shared_ptr fans out
+    p.removeOutput(o2);
+    in->push(std::make_shared<Item>(Item{1}));
+    p.run();
+    CHECK(o1->size() == 1 && o2->empty());
+    p.flushQueues();
+    CHECK(o1->empty() && in->empty());
+}
+
+static int run_gpu() {
+    csdr_ctx *ctx = nullptr;
+    csdr_must(csdr_ctx_create(0, nullptr, &ctx), "csdr_ctx_create");
+    {
+        DemodulatorMgr mgr(8);
+        SDRPostThread post(ctx, &mgr);
+        SpectrumVisualProcessor spec(ctx);
+        auto pipeSDRIQData = std::make_shared<SDRThreadIQDataQueue>();               // CubicSDR.cpp:352-353
+        pipeSDRIQData->set_max_num_items(100);
+        auto pipeIQVisualData = std::make_shared<DemodulatorThreadInputQueue>();      // :342-343
+        auto spectrumOut = std::make_shared<SpectrumVisualDataQueue>();
+        post.setInputQueue("IQDataInput", pipeSDRIQData);
+        post.setOutputQueue("IQVisualDataOutput", pipeIQVisualData);
+        spec.setInput(pipeIQVisualData);
+        spec.attachOutput(spectrumOut);
+        spec.setup(2048);
+        spec.setCenterFrequency(100000000); spec.setBandwidth(2400000);
+
+        const long long fs = 2400000, center = 100000000;
+        const int M = 4, block = 40000;
+        auto d = mgr.newThread();
+        d->setDemodulatorType("NBFM");
+        d->setFrequency(center + 250000);
+        std::thread tp(&IOThread::threadMain, &post);
+        // FM carrier at +250 kHz, 1 kHz tone, 2.5 kHz deviation; 12 blocks = 0.2 s
+        const double dev = 2500.0, ft = 1000.0, amp = 0.5;
+        long long n0 = 0;
+        int nspec = 0;
+        for (int b = 0; b < 12; ++b) {
+            auto blk = std::make_shared<SDRThreadIQData>();
+            blk->frequency = center; blk->sampleRate = fs; blk->numChannels = M; blk->data.resize(block);
+            for (int i = 0; i < block; ++i) {
+                const double t = double(n0 + i) / fs;
+                const double ph = 2 * M_PI * 250000.0 * t + (dev / ft) * std::sin(2 * M_PI * ft * t);
+                blk->data[i].real = (float)(amp * std::cos(ph)); blk->data[i].imag = (float)(amp * std::sin(ph));
+            }
+            n0 += block;
+            CHECK(pipeSDRIQData->push(blk, 2000000));
+            while (post.blocksProcessed.load() <= b) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            spec.run();
+            SpectrumVisualDataPtr sv;
+            if (spectrumOut->try_pop(sv)) {
+                ++nspec;
+                CHECK(sv->spectrum_points.size() == 4096);
+                // carrier at +250 kHz of a 2.4 MHz span -> display point ~ (0.5 + 250/2400) * 2048 = 1237
+                int best = 0; float bv = -1e9f;
+                for (int x = 0; x < 2048; ++x) if (sv->spectrum_points[2 * x + 1] > bv) { bv = sv->spectrum_points[2 * x + 1]; best = x; }
+                if (b >= 3) CHECK(std::abs(best - 1237) <= 3);
+            }
+        }
+        CHECK(nspec >= 10);
+        // audio: ~800 samples per block at 48 kHz; after the filters settle the output is a 1 kHz tone of amplitude
+        // dev / (kf * fs_demod) = 2500 / (0.5 * 12500) = 0.4
+        auto aq = d->getAudioOutputQueue();
+        std::vector<float> audio;
+        AudioThreadInputPtr ati;
+        int nblk = 0;
+        while (aq->try_pop(ati)) { ++nblk; CHECK(ati->sampleRate == 48000 && ati->channels == 1); audio.insert(audio.end(), ati->data.begin(), ati->data.end()); }
+        CHECK(nblk == 12);
+        CHECK(std::abs((long)audio.size() - 9600) <= 4);
+        double re = 0, im = 0;
+        const int a0 = 4800, na = (int)audio.size() - a0;
+        for (int i = 0; i < na; ++i) { re += audio[a0 + i] * std::cos(2 * M_PI * 1000.0 * i / 48000.0); im += audio[a0 + i] * std::sin(2 * M_PI * 1000.0 * i / 48000.0); }
+        const double tone = 2.0 * std::sqrt(re * re + im * im) / na;
+        std::printf("audio blocks %d samples %zu tone amplitude %.4f (expect 0.40) level %.1f dB\n", nblk, audio.size(), tone, d->getSignalLevel());
+        CHECK(std::fabs(tone - 0.4) < 0.02);
+        // out-of-range demodulator is deactivated like updateActiveDemodulators() does (:66-72)
+        d->setFrequency(center + 5000000);
+        auto blk = std::make_shared<SDRThreadIQData>();
+        blk->frequency = center; blk->sampleRate = fs; blk->numChannels = M; blk->data.assign(block, liquid_float_complex_t{0.1f, 0.0f});
+        const long long before = post.blocksProcessed.load();
+        pipeSDRIQData->push(blk);
+        while (post.blocksProcessed.load() == before) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        CHECK(!d->isActive() && aq->empty());
+        post.terminate();
+        tp.join();
+        CHECK(post.isTerminated());
+    }
+    csdr_ctx_destroy(ctx);
+    return g_fail;
+}
+
+int main(int argc, char **argv) {
+    const bool gpu = argc > 1 && !std::strcmp(argv[1], "gpu");
+    if (gpu) { int f = run_gpu(); std::printf(f ? "GPU HOST TEST FAILED (%d)\n" : "gpu host test ok\n", f); return f ? 1 : 0; }
+    test_queue();
+    test_rebuffer();
+    test_iothread();
+    test_visual_processor();
+    std::printf(g_fail ? "HOST TEST FAILED (%d)\n" : "host test ok\n", g_fail);
+    return g_fail ? 1 : 0;
+}

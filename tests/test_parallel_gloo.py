@@ -1,0 +1,73 @@
+"""N > 1 path on CPU: world size 2, gloo.  Covers the demodulator sharding map, the per-rank channel sets, the IQ-batch
+broadcast and the max-/sum-over-ranks reductions bench.py relies on."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from cubicsdr_amd import parallel as P
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_demods, M = 64, 20
+        rng = np.random.default_rng(7)
+        channels = [int(c) for c in rng.integers(0, M, n_demods)]
+        pl = P.plan(n_demods, channels, world, rank)
+        # every rank publishes its shard: together they must partition the demods, with disjoint channel sets
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (pl.demods, pl.active_channels))
+        batch = torch.zeros(4096, 2)
+        if rank == 0:
+            batch = torch.arange(8192, dtype=torch.float32).reshape(4096, 2)
+        P.broadcast_iq(batch, src=0)
+        tmax = P.max_over_ranks(1.0 + rank)
+        tot = P.sum_over_ranks(len(pl.demods))
+        q.put((rank, gathered, float(batch.sum()), tmax, tot, channels))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_broadcast():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, gathered, bsum, tmax, tot, channels in res:
+        all_demods = sorted(i for shard, _ in gathered for i in shard)
+        assert all_demods == list(range(64))                                   # a partition
+        chsets = [set(c) for _, c in gathered]
+        assert not (chsets[0] & chsets[1])                                      # one channel -> one rank
+        for shard, chs in gathered:
+            assert sorted({channels[i] for i in shard}) == chs
+        assert abs(len(gathered[0][0]) - len(gathered[1][0])) <= 8              # balanced
+        assert bsum == float(sum(range(8192)))                                  # broadcast delivered rank 0's batch
+        assert tmax == 2.0 and tot == 64
+
+
+def test_contiguous_shards_cover_everything():
+    from cubicsdr_amd.parallel import shard_demods
+    for n, w in [(64, 8), (256, 8), (7, 4), (3, 8), (1024, 2)]:
+        got = [i for r in range(w) for i in shard_demods(n, w, r)]
+        assert got == list(range(n))
+        sizes = [len(shard_demods(n, w, r)) for r in range(w)]
+        assert max(sizes) - min(sizes) <= 1
