@@ -69,7 +69,7 @@ def algorithmic_bytes_per_sample(kernel, n_demods, m, fft_n):
         "demod_frontend": 8.0 * n_demods / m,
         "demod_modem": 0.0,
         "demod_audio_interp": audio,
-        "spec_fft_cols": 8.0,          # the frame is read once from HBM ...
+        "spec_fft_radix": 8.0,         # the frame is read once from HBM ...
         "spec_fft_rows": 0.0,          # ... the second pass re-reads an intermediate that is not algorithmic traffic
         "spec_average": 0.0,
         "spec_display": 4.0,

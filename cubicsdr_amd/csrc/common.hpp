@@ -65,12 +65,24 @@ struct PinBuf {
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
+// ---- small device helpers shared by the kernel headers ----
+__device__ inline float2 cmul(float2 a, float2 b) { return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x)); }
+__device__ inline float2 cfma(float2 v, float2 w, float2 acc) {   // acc + v * w
+    acc.x = fmaf(v.x, w.x, acc.x); acc.x = fmaf(-v.y, w.y, acc.x);
+    acc.y = fmaf(v.x, w.y, acc.y); acc.y = fmaf(v.y, w.x, acc.y);
+    return acc;
+}
+// a value that is the same in every lane of the wave by construction: tell the compiler (scalar registers, scalar loads)
+__device__ inline int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// 16 bytes that are only guaranteed 8-byte aligned (two adjacent complex samples at an odd sample offset)
+struct __attribute__((aligned(8))) f4u { float x, y, z, w; };
+
 }  // namespace csdr
 
 // kernel ids for the optional per-kernel HIP-event profile (csdr_ctx_profile_*)
 enum CsdrKernelId {
-    KID_CHAN_ANALYZE = 0, KID_CHAN_HIST, KID_DC_ENDS, KID_DC_CARRY, KID_DC_APPLY,
-    KID_FRONTEND, KID_MODEM, KID_GAIN, KID_AUDIO, KID_TAILS,
+    KID_CHAN_ANALYZE = 0, KID_DC_ENDS, KID_DC_APPLY,
+    KID_FRONTEND, KID_MODEM, KID_AUDIO,
     KID_FFT_COLS, KID_FFT_ROWS, KID_SPEC_AVG, KID_SPEC_TRACK, KID_SPEC_DISPLAY, KID_SPEC_MISC,
     KID_COUNT
 };

@@ -81,9 +81,9 @@ extern "C" int csdr_ctx_timer_stop(csdr_ctx *c, float *ms) {
 }
 // ---- per-kernel HIP-event profile (bench.py roofline leg) ----
 static const char *kKernelNames[KID_COUNT] = {
-    "chan_analyze", "chan_update_hist", "dc_tile_ends", "dc_tile_carry", "dc_apply",
-    "demod_frontend", "demod_modem", "demod_gain", "demod_audio_interp", "demod_tails",
-    "spec_fft_cols", "spec_fft_rows", "spec_average", "spec_trackers", "spec_display", "spec_misc"};
+    "chan_analyze", "dc_tile_ends", "dc_apply",
+    "demod_frontend", "demod_modem", "demod_audio_interp",
+    "spec_fft_radix", "spec_fft_rows", "spec_average", "spec_trackers", "spec_display", "spec_misc"};
 static int prof_drain(csdr_ctx *c) {
     CSDR_HIP_TRY(hipStreamSynchronize(c->stream));
     for (auto &r : c->prof_pending) {
@@ -136,16 +136,17 @@ struct csdr_post {
     int mode = CSDR_POST_SINGLE, M = 1;
     int64_t sample_rate = 0, chan_bw = 0, frequency = 0;
     int max_block_len = 0, max_blocks = 0;
-    int64_t chan_stride = 0;                 // samples per channel row in `out`
+    int64_t chan_stride = 0;                 // samples per channel row in `out` (even: rows stay 16-byte aligned)
     int n_blocks = 0, block_len = 0;         // of the last execute
     std::vector<int64_t> centers;            // chanCenters[M + 1]
-    std::vector<int> active_host;
+    std::vector<int> active_host;            // sorted list of produced channels
     bool active_dirty = true;
-    DevBuf<float2> out, hist0, hist1, stage_in, tw;
+    ChanGeom geom{};
+    DevBuf<float2> out, hist0, hist1, stage_in, twA, twB, twM;
     DevBuf<float> taps;
-    DevBuf<int> active;
-    DevBuf<d2> dc_state, tile_end, tile_in;
-    int hist_parity = 0;
+    DevBuf<int> active;                      // [M] flags
+    DevBuf<d2> dc_state, tile_end;           // dc_state[2]: ping-pong carried state
+    int hist_parity = 0, dc_parity = 0;
     double dc_c = 0.0;                       // feedback coefficient of the DC blocker recurrence
 };
 
@@ -170,9 +171,35 @@ extern "C" int csdr_post_create(csdr_ctx *ctx, csdr_post **out) {
 extern "C" void csdr_post_destroy(csdr_post *p) {
     if (!p) return;
     (void)hipStreamSynchronize(p->ctx->stream);
-    p->out.release(); p->hist0.release(); p->hist1.release(); p->stage_in.release(); p->tw.release();
-    p->taps.release(); p->active.release(); p->dc_state.release(); p->tile_end.release(); p->tile_in.release();
+    p->out.release(); p->hist0.release(); p->hist1.release(); p->stage_in.release();
+    p->twA.release(); p->twB.release(); p->twM.release();
+    p->taps.release(); p->active.release(); p->dc_state.release(); p->tile_end.release();
     delete p;
+}
+
+// geometry of the channelizer kernel for M channels (see kernels_post.hpp)
+static int chan_geometry(int M, ChanGeom &g) {
+    memset(&g, 0, sizeof g);
+    g.M = M;
+    int B = 1;
+    for (int d = 1; (int64_t)d * d <= M; ++d) if (M % d == 0) B = d;     // largest divisor <= sqrt(M)
+    g.B = B; g.A = M / B;
+    g.A4 = (g.A + 3) & ~3; g.B4 = (g.B + 3) & ~3;
+    g.magicM = (unsigned)((1ull << 32) / (unsigned)M) + 1u;
+    g.taps_lds = (M <= 512) ? 1 : 0;
+    // frames per workgroup: the largest power of two <= 64 whose two row arrays fit the LDS budget
+    const size_t budget = (M <= 512) ? 64 * 1024 : 72 * 1024;
+    for (int tf = 64; tf >= 1; tf >>= 1) {
+        g.TF = tf;
+        g.lgTF = 0; while ((1 << g.lgTF) < tf) ++g.lgTF;
+        const int q = 32 / std::min(tf, 32);              // row stride = q * odd: lanes along t hit distinct banks
+        int S = (M + q - 1) / q; if (!(S & 1)) ++S; S *= q;
+        g.S = S;
+        if (chan_lds_bytes(g) <= budget) break;
+        if (tf == 1) return fail(CSDR_EUNSUPPORTED, "numChannels %d does not fit the channelizer's LDS tile", M);
+    }
+    if ((int64_t)g.TF * M * M >= (1ll << 31)) return fail(CSDR_EUNSUPPORTED, "numChannels %d too large", M);
+    return CSDR_OK;
 }
 
 extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_channels, int mode, int max_block_len, int max_blocks) {
@@ -181,37 +208,53 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
     if (mode != CSDR_POST_SINGLE && mode != CSDR_POST_PFBCH) return fail(CSDR_EUNSUPPORTED, "channelizer mode %d (PFBCH2 is a later tier)", mode);
     if ((mode == CSDR_POST_SINGLE) != (num_channels == 1)) return fail(CSDR_EINVAL, "SINGLE mode <=> num_channels == 1");
     if (max_block_len % num_channels) return fail(CSDR_EINVAL, "max_block_len must be a multiple of num_channels");
+    if (num_channels > 1 && (num_channels & 1)) return fail(CSDR_EUNSUPPORTED, "odd numChannels %d (the reference only produces even counts, SoapySDRThread.cpp:676-693)", num_channels);
     hipStream_t st = p->ctx->stream;
     CSDR_HIP_TRY(hipStreamSynchronize(st));
+    p->configured = false;
     p->mode = mode; p->M = num_channels; p->sample_rate = sample_rate;
     p->chan_bw = sample_rate / num_channels;                       // integer division, SDRPostThread.cpp:408
     p->max_block_len = max_block_len; p->max_blocks = max_blocks;
     const int M = p->M;
-    p->chan_stride = (int64_t)max_blocks * (max_block_len / M);
+    p->chan_stride = ((int64_t)max_blocks * (max_block_len / M) + 1) & ~(int64_t)1;
     if (int rc = p->out.reserve((size_t)p->chan_stride * M)) return rc;
-    if (int rc = p->dc_state.reserve(1)) return rc;
-    CSDR_HIP_TRY(hipMemsetAsync(p->dc_state.p, 0, sizeof(d2), st));
+    if (int rc = p->dc_state.reserve(2)) return rc;
+    CSDR_HIP_TRY(hipMemsetAsync(p->dc_state.p, 0, 2 * sizeof(d2), st));
+    p->dc_parity = 0;
     const int64_t dc_n = (mode == CSDR_POST_SINGLE) ? (int64_t)max_blocks * max_block_len : p->chan_stride;
     const size_t ntiles = (size_t)((dc_n + kDcTile - 1) / kDcTile);
     if (int rc = p->tile_end.reserve(ntiles)) return rc;
-    if (int rc = p->tile_in.reserve(ntiles)) return rc;
     // iirfilt_crcf_create_dc_blocker(0.0005f): b = {1, -1}, a = {1, -1 + alpha}  (float)  ->  v = x - a1 v'
     const float a1 = -1.0f + 0.0005f;
     p->dc_c = -(double)a1;
     if (mode == CSDR_POST_PFBCH) {
+        if (int rc = chan_geometry(M, p->geom)) return rc;
+        const ChanGeom &g = p->geom;
+        // prototype taps transposed to [n][c]: tapsT[n M + c] multiplies x[(t - n) M + c]
         std::vector<float> taps = design::channelizer_taps((unsigned)M, 4, 60.0f);
-        if (int rc = p->taps.reserve(taps.size())) return rc;
-        CSDR_HIP_TRY(hipMemcpyAsync(p->taps.p, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice, st));
-        std::vector<float2> tw(M);
-        for (int i = 0; i < M; i++) { double a = -2.0 * M_PI * (double)i / (double)M; tw[i] = make_float2((float)std::cos(a), (float)std::sin(a)); }
-        if (int rc = p->tw.reserve(M)) return rc;
-        CSDR_HIP_TRY(hipMemcpyAsync(p->tw.p, tw.data(), M * sizeof(float2), hipMemcpyHostToDevice, st));
+        std::vector<float> tapsT((size_t)kChanTaps * M);
+        for (int c = 0; c < M; c++) for (int n = 0; n < kChanTaps; n++) tapsT[(size_t)n * M + c] = taps[(size_t)c * kChanTaps + n];
+        std::vector<float2> twA((size_t)g.A * g.A4, make_float2(0.f, 0.f)), twB((size_t)g.B * g.B4, make_float2(0.f, 0.f)), twM((size_t)g.A * g.B);
+        auto W = [](int64_t num, int den) { const double a = -2.0 * M_PI * (double)(num % den) / (double)den; return make_float2((float)std::cos(a), (float)std::sin(a)); };
+        for (int c1 = 0; c1 < g.A; c1++) for (int k1 = 0; k1 < g.A; k1++) twA[(size_t)c1 * g.A4 + k1] = W((int64_t)c1 * k1, g.A);
+        for (int c2 = 0; c2 < g.B; c2++) for (int k2 = 0; k2 < g.B; k2++) twB[(size_t)c2 * g.B4 + k2] = W((int64_t)c2 * k2, g.B);
+        for (int k1 = 0; k1 < g.A; k1++) for (int c2 = 0; c2 < g.B; c2++) twM[(size_t)k1 * g.B + c2] = W((int64_t)k1 * c2, M);
+        if (int rc = p->taps.reserve(tapsT.size())) return rc;
+        if (int rc = p->twA.reserve(twA.size())) return rc;
+        if (int rc = p->twB.reserve(twB.size())) return rc;
+        if (int rc = p->twM.reserve(twM.size())) return rc;
+        CSDR_HIP_TRY(hipMemcpyAsync(p->taps.p, tapsT.data(), tapsT.size() * sizeof(float), hipMemcpyHostToDevice, st));
+        CSDR_HIP_TRY(hipMemcpyAsync(p->twA.p, twA.data(), twA.size() * sizeof(float2), hipMemcpyHostToDevice, st));
+        CSDR_HIP_TRY(hipMemcpyAsync(p->twB.p, twB.data(), twB.size() * sizeof(float2), hipMemcpyHostToDevice, st));
+        CSDR_HIP_TRY(hipMemcpyAsync(p->twM.p, twM.data(), twM.size() * sizeof(float2), hipMemcpyHostToDevice, st));
         const size_t H = (size_t)(kChanTaps - 1) * M;
         if (int rc = p->hist0.reserve(H)) return rc;
         if (int rc = p->hist1.reserve(H)) return rc;
         CSDR_HIP_TRY(hipMemsetAsync(p->hist0.p, 0, H * sizeof(float2), st));
         CSDR_HIP_TRY(hipMemsetAsync(p->hist1.p, 0, H * sizeof(float2), st));
         CSDR_HIP_TRY(hipStreamSynchronize(st));   // host vectors above go out of scope
+        const size_t lds = chan_lds_bytes(g);
+        if (lds > 64 * 1024) CSDR_HIP_TRY(hipFuncSetAttribute((const void *)chan_analyze, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     p->hist_parity = 0;
     p->active_host.resize(M);
@@ -228,7 +271,7 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
 // optional: restrict the channelizer to the channels that have consumers (reference: SDRPostThread.cpp:336-339)
 extern "C" int csdr_post_set_active_channels(csdr_post *p, const int *channels, int n) {
     if (!p || !p->configured) return fail(CSDR_ESTATE, "post not configured");
-    if (n < 0 || n > p->M) return fail(CSDR_EINVAL, "bad channel count");
+    if (n < 0 || n > p->M + 1) return fail(CSDR_EINVAL, "bad channel count");
     std::vector<int> v;
     if (!channels) { v.resize(p->M); for (int i = 0; i < p->M; i++) v[i] = i; }
     else {
@@ -242,11 +285,11 @@ extern "C" int csdr_post_set_active_channels(csdr_post *p, const int *channels, 
 }
 
 static int run_dc_blocker(csdr_post *p, const float2 *x, float2 *y, int64_t n) {
-    hipStream_t st = p->ctx->stream;
     const int ntiles = (int)((n + kDcTile - 1) / kDcTile);
-    CSDR_LAUNCH(p->ctx, KID_DC_ENDS, dc_tile_ends, dim3(ntiles), dim3(kDcThreads), 0, x, n, p->dc_c, p->tile_end.p);
-    CSDR_LAUNCH(p->ctx, KID_DC_CARRY, dc_tile_carry, dim3(1), dim3(64), 0, p->tile_end.p, ntiles, p->dc_c, p->dc_state.p, p->tile_in.p);
-    CSDR_LAUNCH(p->ctx, KID_DC_APPLY, dc_apply, dim3(ntiles), dim3(kDcThreads), 0, x, y, n, p->dc_c, p->tile_in.p, p->dc_state.p);
+    d2 *s_in = p->dc_state.p + p->dc_parity, *s_out = p->dc_state.p + (p->dc_parity ^ 1);
+    CSDR_LAUNCH(p->ctx, KID_DC_ENDS, dc_tile_ends, dim3(ntiles), dim3(kDcThreads), kDcLds, x, n, p->dc_c, p->tile_end.p);
+    CSDR_LAUNCH(p->ctx, KID_DC_APPLY, dc_apply, dim3(ntiles), dim3(kDcThreads), kDcLds, x, y, n, p->dc_c, p->tile_end.p, s_in, s_out);
+    p->dc_parity ^= 1;
     CSDR_HIP_TRY(hipGetLastError());
     return CSDR_OK;
 }
@@ -263,36 +306,29 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
         if (int rc = p->stage_in.reserve((size_t)p->max_blocks * p->max_block_len)) return rc;
         CSDR_HIP_TRY(hipMemcpyAsync(p->stage_in.p, iq, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, st));
         x = p->stage_in.p;
-    }
+    } else if ((uintptr_t)iq & 15) return fail(CSDR_EINVAL, "device IQ pointer must be 16-byte aligned");
     if (frequency != p->frequency || p->centers.empty()) { p->frequency = frequency; post_update_channels(p); }
     p->n_blocks = n_blocks; p->block_len = block_len;
     if (p->mode == CSDR_POST_SINGLE) return run_dc_blocker(p, x, p->out.p, n);       // runSingleCH :284
 
     const int M = p->M;
     if (p->active_dirty) {
-        CSDR_HIP_TRY(hipMemcpyAsync(p->active.p, p->active_host.data(), p->active_host.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        std::vector<int> flags(M, 0);
+        for (int c : p->active_host) flags[c] = 1;
+        CSDR_HIP_TRY(hipMemcpyAsync(p->active.p, flags.data(), flags.size() * sizeof(int), hipMemcpyHostToDevice, st));
         CSDR_HIP_TRY(hipStreamSynchronize(st));
         p->active_dirty = false;
     }
-    const int n_active = (int)p->active_host.size();
     const int64_t n_frames = n / M;
-    // tile size: keep LDS under ~60 KB
-    int TF = 128;
-    auto lds_bytes = [&](int tf) { return (size_t)((tf + kChanTaps - 1) * M + tf * (M | 1) + M) * sizeof(float2) + (size_t)M * kChanTaps * sizeof(float); };
-    while (TF > 1 && lds_bytes(TF) > 60 * 1024) TF >>= 1;
-    if (lds_bytes(TF) > 64 * 1024) return fail(CSDR_EUNSUPPORTED, "numChannels %d too large for the direct-DFT channelizer", M);
+    const ChanGeom &g = p->geom;
     float2 *hist = p->hist_parity ? p->hist1.p : p->hist0.p, *hist_new = p->hist_parity ? p->hist0.p : p->hist1.p;
-    if (n_active > 0) {
-        const int ntiles = (int)((n_frames + TF - 1) / TF);
-        CSDR_LAUNCH(p->ctx, KID_CHAN_ANALYZE, chan_analyze, dim3(ntiles), dim3(kChanThreads), lds_bytes(TF), x, hist, p->taps.p, p->tw.p, p->active.p,
-                           n_active, M, TF, n_frames, p->out.p, p->chan_stride);
-    }
-    const int H = (kChanTaps - 1) * M;
-    CSDR_LAUNCH(p->ctx, KID_CHAN_HIST, chan_update_hist, dim3((H + 255) / 256), dim3(256), 0, x, n, hist, hist_new, H);
+    const int ntiles = (int)((n_frames + g.TF - 1) / g.TF);
+    CSDR_LAUNCH(p->ctx, KID_CHAN_ANALYZE, chan_analyze, dim3(ntiles), dim3(kChanThreads), chan_lds_bytes(g), x, hist, hist_new, p->taps.p,
+                p->twA.p, p->twB.p, p->twM.p, p->active.p, g, n_frames, p->out.p, p->chan_stride);
     p->hist_parity ^= 1;
     CSDR_HIP_TRY(hipGetLastError());
     // channel 0 carries the DC spike: block it after de-interleave (:364-375)
-    if (n_active > 0 && p->active_host[0] == 0) return run_dc_blocker(p, p->out.p, p->out.p, n_frames);
+    if (!p->active_host.empty() && p->active_host[0] == 0) return run_dc_blocker(p, p->out.p, p->out.p, n_frames);
     return CSDR_OK;
 }
 
@@ -337,12 +373,14 @@ struct SlotHost {
     long long shift_frequency = 0;
     bool shift_valid = false;
     int hist_parity = 0;
+    int warm = 0;                            // cascade span in input samples (+ one output period)
     void *slab = nullptr;
     SlotCfg cfg{};
     // results of the last execute
     std::vector<csdr_block_result> results;
     int last_J = 0, last_A = 0;
 };
+constexpr int kStageRing = 4;                // pinned staging sets for the per-batch uploads
 }  // namespace
 
 struct csdr_bank {
@@ -355,14 +393,17 @@ struct csdr_bank {
     DevBuf<BlockPlan> plans;
     DevBuf<float> arms;
     DevBuf<ModemConsts> mconsts;
-    PinBuf<SlotDyn> dyns_h;
-    PinBuf<int> slot_list_h;
-    PinBuf<BlockPlan> plans_h;
+    PinBuf<SlotDyn> dyns_h[kStageRing];
+    PinBuf<int> slot_list_h[kStageRing];
+    PinBuf<BlockPlan> plans_h[kStageRing];
+    hipEvent_t stage_ev[kStageRing] = {nullptr, nullptr, nullptr, nullptr};
+    bool stage_used[kStageRing] = {false, false, false, false};
+    int stage_next = 0;
     PinBuf<BlockOut> bout_h;
     std::map<uint32_t, int> arm_index;       // key: bit pattern of rate_arb
     std::vector<float> arms_host;
     int n_run = 0, last_nb = 0;
-    size_t fe_lds_attr = 0;
+    size_t lds_attr[3] = {0, 0, 0};
 };
 
 static int bank_arm_bank(csdr_bank *b, const design::MsresampPlan &p, int *idx) {
@@ -410,9 +451,12 @@ extern "C" int csdr_bank_create(csdr_ctx *ctx, int max_demods, int max_blocks, c
     if (int rc = b->slot_list.reserve(max_demods)) return rc;
     if (int rc = b->plans.reserve((size_t)max_demods * (max_blocks + 1))) return rc;
     if (int rc = b->mconsts.reserve(1)) return rc;
-    if (int rc = b->dyns_h.reserve(max_demods)) return rc;
-    if (int rc = b->slot_list_h.reserve(max_demods)) return rc;
-    if (int rc = b->plans_h.reserve((size_t)max_demods * (max_blocks + 1))) return rc;
+    for (int r = 0; r < kStageRing; ++r) {
+        if (int rc = b->dyns_h[r].reserve(max_demods)) return rc;
+        if (int rc = b->slot_list_h[r].reserve(max_demods)) return rc;
+        if (int rc = b->plans_h[r].reserve((size_t)max_demods * (max_blocks + 1))) return rc;
+        CSDR_HIP_TRY(hipEventCreate(&b->stage_ev[r]));
+    }
     if (int rc = b->bout_h.reserve(max_blocks)) return rc;
     CSDR_HIP_TRY(hipMemset(b->cfgs.p, 0, max_demods * sizeof(SlotCfg)));
     // modem constants (cold): AM notch ModemAM.cpp:9, SSB filters ModemUSB.cpp:8-11
@@ -434,7 +478,11 @@ extern "C" void csdr_bank_destroy(csdr_bank *b) {
     (void)hipStreamSynchronize(b->ctx->stream);
     for (auto &s : b->slots) if (s.slab) (void)hipFree(s.slab);
     b->cfgs.release(); b->dyns.release(); b->slot_list.release(); b->plans.release(); b->arms.release(); b->mconsts.release();
-    b->dyns_h.release(); b->slot_list_h.release(); b->plans_h.release(); b->bout_h.release();
+    for (int r = 0; r < kStageRing; ++r) {
+        b->dyns_h[r].release(); b->slot_list_h[r].release(); b->plans_h[r].release();
+        if (b->stage_ev[r]) (void)hipEventDestroy(b->stage_ev[r]);
+    }
+    b->bout_h.release();
     delete b;
 }
 
@@ -452,6 +500,7 @@ extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod
     if (prm->bandwidth <= 0 || prm->audio_sample_rate <= 0) return fail(CSDR_EINVAL, "bad rates");
     SlotHost &s = b->slots[slot];
     CSDR_HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    s.configured = false;
     s.prm = *prm;
     s.prm.bandwidth = modem_check_rate(prm->modem, prm->bandwidth);
     s.chan_rate = csdr_post_channel_bandwidth(post);
@@ -465,6 +514,15 @@ extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod
     int ia = 0, aa = 0;
     if (int rc = bank_arm_bank(b, s.iq, &ia)) return rc;
     if (int rc = bank_arm_bank(b, s.au, &aa)) return rc;
+    // cascade span: input samples before an output that can influence it (front-end warm-up, carried history)
+    {
+        const int S = (int)s.iq.S;
+        int64_t lo = -(int64_t)(kArmTaps - 1);
+        for (int e = S - 1; e >= 0; --e) lo = 2 * lo - (4 * (int)s.iq.m[S - 1 - e] - 2);
+        s.warm = (int)(-lo) + (2 << S);
+    }
+    const int hist_len = (s.warm + 63) & ~63;
+    if (hist_len > kMixHist) return fail(CSDR_EUNSUPPORTED, "cascade span %d exceeds the carried history", s.warm);
     // capacities for one execute
     const int64_t max_bc = post->max_block_len / post->M;
     const int64_t cap_iq = (int64_t)std::ceil((double)b->max_blocks * (double)max_bc * iq_ratio) + b->max_blocks + 64;
@@ -472,13 +530,12 @@ extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod
     // one slab per slot
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_mix = carve(2 * kMixHist * sizeof(float2));
+    const size_t o_mix = carve((size_t)2 * hist_len * sizeof(float2));
     const size_t o_iq = carve((kIqHist + cap_iq) * sizeof(float2));
     const size_t o_d = carve(cap_iq * sizeof(float));
-    const size_t o_dh = carve(kDHist * sizeof(float));
+    const size_t o_dh = carve(2 * kDHist * sizeof(float));
     const size_t o_au = carve(cap_audio * sizeof(float));
-    const size_t o_g = carve((b->max_blocks + 1) * sizeof(float));
-    const size_t o_agc = carve(4 * sizeof(float));
+    const size_t o_agc = carve(8 * sizeof(float));
     const size_t o_bm = carve(b->max_blocks * sizeof(float));
     const size_t o_bo = carve(b->max_blocks * sizeof(BlockOut));
     if (s.slab) { (void)hipFree(s.slab); s.slab = nullptr; }
@@ -490,14 +547,13 @@ extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod
     fill_resamp_cfg(c.rs_iq, s.iq, ia);
     fill_resamp_cfg(c.rs_au, s.au, aa);
     c.modem = s.prm.modem;
+    c.hist_len = hist_len;
     c.mixhist = (float2 *)(base + o_mix); c.iq = (float2 *)(base + o_iq); c.d = (float *)(base + o_d); c.dh = (float *)(base + o_dh);
-    c.audio = (float *)(base + o_au); c.gains = (float *)(base + o_g); c.agc = (float *)(base + o_agc);
+    c.audio = (float *)(base + o_au); c.agc = (float *)(base + o_agc);
     c.blockmax = (float *)(base + o_bm); c.bout = (BlockOut *)(base + o_bo);
     c.cap_iq = (int)cap_iq; c.cap_audio = (int)cap_audio;
-    const float agc0[3] = {1.0f, 1.0f, 1.0f};                 // ModemAnalog::ModemAnalog(): aOutputCeil(1), MA(1), MAA(1)
+    const float agc0[8] = {1.0f, 1.0f, 1.0f, 0.f, 1.0f, 1.0f, 1.0f, 0.f};   // ModemAnalog::ModemAnalog(): aOutputCeil(1), MA(1), MAA(1)
     CSDR_HIP_TRY(hipMemcpy(c.agc, agc0, sizeof agc0, hipMemcpyHostToDevice));
-    const float g0[1] = {1.0f};
-    CSDR_HIP_TRY(hipMemcpy(c.gains, g0, sizeof g0, hipMemcpyHostToDevice));
     CSDR_HIP_TRY(hipMemcpy(b->cfgs.p + slot, &c, sizeof c, hipMemcpyHostToDevice));
     // fresh objects: nco_crcf_create / msresamp create / modem ctor all start from zero state
     s.theta = 0; s.dtheta = 0; s.buf_idx = 0; s.phase = 0; s.aphase = 0; s.hist_parity = 0;
@@ -533,9 +589,15 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     const int NB = post->n_blocks, M = post->M, Bc = post->block_len / M;
     if (NB > b->max_blocks) return fail(CSDR_ERANGE, "batch of %d blocks exceeds bank capacity %d", NB, b->max_blocks);
     const int64_t rate = csdr_post_channel_bandwidth(post);
-    // results of the previous execute are overwritten below: make sure the previous launches are done with the pinned plans
-    CSDR_HIP_TRY(hipStreamSynchronize(st));
-    int n_run = 0;
+    // pinned staging set for this batch: wait only for the upload that last used it (kStageRing batches ago)
+    const int ring = b->stage_next;
+    b->stage_next = (b->stage_next + 1) % kStageRing;
+    if (b->stage_used[ring]) CSDR_HIP_TRY(hipEventSynchronize(b->stage_ev[ring]));
+    SlotDyn *dyns_h = b->dyns_h[ring].p;
+    int *slot_list_h = b->slot_list_h[ring].p;
+    BlockPlan *plans_h = b->plans_h[ring].p;
+    int n_run = 0, max_n_iq = 0, max_n_audio = 0, warm_max = 0, max_aS = 0;
+    bool need_streams = false;
     for (int si = 0; si < b->max_demods; ++si) {
         SlotHost &s = b->slots[si];
         s.results.clear(); s.last_J = 0; s.last_A = 0;
@@ -546,7 +608,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         if (ch < 0) continue;
         const int64_t centre = (M == 1) ? post->frequency : post->centers[ch];
         const int data_ch = (M > 1 && ch == M) ? M / 2 : ch;
-        if (M > 1 && std::find(post->active_host.begin(), post->active_host.end(), data_ch) == post->active_host.end())
+        if (M > 1 && !std::binary_search(post->active_host.begin(), post->active_host.end(), data_ch))
             return fail(CSDR_ESTATE, "slot %d needs channel %d which the channelizer was told not to produce", si, data_ch);
         // DemodulatorPreThread.cpp:154-165
         const long long shift = (long long)s.prm.frequency - (long long)centre;
@@ -562,13 +624,13 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
             for (auto &r : s.results) { memset(&r, 0, sizeof r); r.skipped = 1; r.nco_theta = s.theta; r.resamp_phase = s.phase; r.buffer_index = s.buf_idx; }
             continue;
         }
-        SlotDyn &d = b->dyns_h.p[si];
+        SlotDyn &d = dyns_h[si];
         memset(&d, 0, sizeof d);
         d.active = 1; d.chan = data_ch; d.theta0 = s.theta; d.dtheta = s.dtheta;
         d.mixdir = shift == 0 ? 0 : (shift < 0 ? +1 : -1);          // :186-191: shift < 0 -> mix up
         d.buf0 = s.buf_idx; d.phase0 = s.phase; d.aphase0 = s.aphase; d.ssb_theta0 = s.ssb_theta; d.hist_parity = s.hist_parity;
         // per-block plan
-        BlockPlan *pl = b->plans_h.p + (size_t)si * (NB + 1);
+        BlockPlan *pl = plans_h + (size_t)si * (NB + 1);
         const int S = (int)s.iq.S, aS = (int)s.au.S;
         for (int bb = 0; bb <= NB; ++bb) {
             const int64_t K = ((int64_t)s.buf_idx + (int64_t)bb * Bc) >> S;
@@ -585,6 +647,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
             r.n_audio = (int)(((int64_t)(pl[bb + 1].q0 - pl[bb].q0)) << aS);
             r.audio_offset = (int)(((int64_t)pl[bb].q0) << aS);
             if (r.n_iq > kModemMaxBlockIq || r.n_audio > kAudioMaxOut) return fail(CSDR_EUNSUPPORTED, "slot %d: %d IQ / %d audio samples per block exceed the per-workgroup limits", si, r.n_iq, r.n_audio);
+            max_n_iq = std::max(max_n_iq, r.n_iq); max_n_audio = std::max(max_n_audio, r.n_audio);
             const int64_t Kb = ((int64_t)s.buf_idx + (int64_t)(bb + 1) * Bc) >> S;
             r.buffer_index = (uint32_t)(((int64_t)s.buf_idx + (int64_t)(bb + 1) * Bc) & ((1 << S) - 1));
             r.resamp_phase = (uint32_t)((int64_t)s.phase + (int64_t)pl[bb + 1].j0 * s.iq.step - (Kb << 24));
@@ -599,42 +662,41 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         s.ssb_theta += (uint32_t)Jtot * (1u << 30);
         s.hist_parity ^= 1;
         s.last_J = (int)Jtot; s.last_A = (int)(Qtot << aS);
-        b->slot_list_h.p[n_run++] = si;
+        warm_max = std::max(warm_max, s.warm); max_aS = std::max(max_aS, aS);
+        if (s.prm.modem != CSDR_MODEM_NBFM && s.prm.modem != CSDR_MODEM_FM) need_streams = true;
+        slot_list_h[n_run++] = si;
     }
     b->n_run = n_run; b->last_nb = NB;
     if (n_run == 0) return CSDR_OK;
-    CSDR_HIP_TRY(hipMemcpyAsync(b->dyns.p, b->dyns_h.p, b->max_demods * sizeof(SlotDyn), hipMemcpyHostToDevice, st));
-    CSDR_HIP_TRY(hipMemcpyAsync(b->slot_list.p, b->slot_list_h.p, n_run * sizeof(int), hipMemcpyHostToDevice, st));
-    CSDR_HIP_TRY(hipMemcpyAsync(b->plans.p, b->plans_h.p, (size_t)b->max_demods * (NB + 1) * sizeof(BlockPlan), hipMemcpyHostToDevice, st));
-    // front-end geometry: split each block into P parts so that (part + warm-up) fits one LDS chunk of ~4K inputs
-    int Smax = 0, warm_max = 0;
-    for (int i = 0; i < n_run; ++i) {
-        const SlotHost &s = b->slots[b->slot_list_h.p[i]];
-        const int S = (int)s.iq.S;
-        int64_t lo = -(int64_t)(kArmTaps - 1);
-        for (int e = S - 1; e >= 0; --e) lo = 2 * lo - (4 * (int)s.iq.m[S - 1 - e] - 2);
-        Smax = std::max(Smax, S);
-        warm_max = std::max(warm_max, (int)(-lo) + (2 << S));
-    }
-    if (warm_max + (1 << Smax) > kMixHist) return fail(CSDR_EUNSUPPORTED, "cascade span %d exceeds the carried history", warm_max);
-    const int P = std::max(1, (Bc + 3071) / 3072);
-    const int gran = 1 << Smax;
-    int chunk = ((Bc + P - 1) / P + warm_max + gran + gran - 1) / gran * gran;
-    chunk = std::min(chunk, kFeChunkMax / gran * gran);
-    if (chunk < gran) return fail(CSDR_EUNSUPPORTED, "half-band depth %d too deep for the front-end chunk", Smax);
+    CSDR_HIP_TRY(hipMemcpyAsync(b->dyns.p, dyns_h, b->max_demods * sizeof(SlotDyn), hipMemcpyHostToDevice, st));
+    CSDR_HIP_TRY(hipMemcpyAsync(b->slot_list.p, slot_list_h, n_run * sizeof(int), hipMemcpyHostToDevice, st));
+    CSDR_HIP_TRY(hipMemcpyAsync(b->plans.p, plans_h, (size_t)b->max_demods * (NB + 1) * sizeof(BlockPlan), hipMemcpyHostToDevice, st));
+    CSDR_HIP_TRY(hipEventRecord(b->stage_ev[ring], st));
+    b->stage_used[ring] = true;
+    // front-end geometry: every slot's batch is cut into P ranges; a range re-runs `warm` inputs in front of it
+    const int64_t total = (int64_t)NB * Bc;
+    const int64_t range = std::max<int64_t>(8192, 6 * (int64_t)warm_max);
+    int P = (int)std::max<int64_t>(1, std::min<int64_t>(total / range, 4096));
     size_t fe_lds = 0;
-    for (int i = 0; i < n_run; ++i) fe_lds = std::max(fe_lds, fe_lds_bytes((int)b->slots[b->slot_list_h.p[i]].iq.S, chunk));
-    if (fe_lds > b->fe_lds_attr) {
-        CSDR_HIP_TRY(hipFuncSetAttribute((const void *)demod_frontend, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fe_lds));
-        b->fe_lds_attr = fe_lds;
-    }
+    for (int i = 0; i < n_run; ++i) fe_lds = std::max(fe_lds, fe_lds_bytes((int)b->slots[slot_list_h[i]].iq.S));
+    const int cap_stream = need_streams ? ((max_n_iq + kSsbWarm + 64 + 3) & ~3) : 4;
+    const size_t modem_lds = (size_t)2 * cap_stream * sizeof(float) + 64;
+    const int cap_out = (max_n_audio + 32 * max_aS + 64 + 3) & ~3, cap_win = (max_n_iq + 128 + 3) & ~3;
+    const size_t audio_lds = (size_t)(2 * cap_out + cap_win) * sizeof(float) + 64;
+    const size_t want[3] = {fe_lds, modem_lds, audio_lds};
+    const void *fn[3] = {(const void *)demod_frontend, (const void *)demod_modem, (const void *)demod_audio_interp};
+    for (int k = 0; k < 3; ++k)
+        if (want[k] > 64 * 1024 && want[k] > b->lds_attr[k]) {
+            CSDR_HIP_TRY(hipFuncSetAttribute(fn[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)want[k]));
+            b->lds_attr[k] = want[k];
+        }
     const dim3 grid(n_run, NB);
-    CSDR_LAUNCH(b->ctx, KID_FRONTEND, demod_frontend, dim3(n_run, NB, P), dim3(kFeThreads), fe_lds, b->cfgs.p, b->dyns.p, b->slot_list.p,
-                       post->out.p, post->chan_stride, Bc, NB, chunk, b->arms.p, b->ctx->sintab.p);
-    CSDR_LAUNCH(b->ctx, KID_MODEM, demod_modem, grid, dim3(kModemThreads), 0, b->cfgs.p, b->dyns.p, b->slot_list.p, b->plans.p, NB, b->mconsts.p, b->ctx->sintab.p);
-    CSDR_LAUNCH(b->ctx, KID_GAIN, demod_gain, dim3((n_run + 63) / 64), dim3(64), 0, b->cfgs.p, b->slot_list.p, n_run, NB);
-    CSDR_LAUNCH(b->ctx, KID_AUDIO, demod_audio_interp, grid, dim3(kModemThreads), 0, b->cfgs.p, b->dyns.p, b->slot_list.p, b->plans.p, NB, b->arms.p);
-    CSDR_LAUNCH(b->ctx, KID_TAILS, demod_tails, dim3(n_run), dim3(256), 0, b->cfgs.p, b->slot_list.p, b->plans.p, NB);
+    CSDR_LAUNCH(b->ctx, KID_FRONTEND, demod_frontend, dim3(P, n_run), dim3(kFeThreads), fe_lds, b->cfgs.p, b->dyns.p, b->slot_list.p,
+                post->out.p, post->chan_stride, total, b->arms.p, b->ctx->sintab.p);
+    CSDR_LAUNCH(b->ctx, KID_MODEM, demod_modem, grid, dim3(kModemThreads), modem_lds, b->cfgs.p, b->dyns.p, b->slot_list.p, b->plans.p, NB, cap_stream,
+                b->mconsts.p, b->ctx->sintab.p);
+    CSDR_LAUNCH(b->ctx, KID_AUDIO, demod_audio_interp, grid, dim3(kModemThreads), audio_lds, b->cfgs.p, b->dyns.p, b->slot_list.p, b->plans.p, NB,
+                cap_out, cap_win, b->arms.p);
     CSDR_HIP_TRY(hipGetLastError());
     return CSDR_OK;
 }
@@ -675,8 +737,7 @@ extern "C" int csdr_bank_fetch_iq(csdr_bank *b, int slot, float *host_out, int c
     if (s.last_J > cap_samples) return fail(CSDR_ERANGE, "need room for %d samples", s.last_J);
     *n = s.last_J;
     if (s.last_J) {
-        // after demod_tails the batch samples still sit at [kIqHist, kIqHist + J) except the first kIqHist slots' worth of
-        // history region, which is separate: the batch region itself is untouched by the tail copy.
+        // the batch region [kIqHist, kIqHist + J) is untouched by the tail copy into the history region in front of it
         CSDR_HIP_TRY(hipMemcpyAsync(host_out, s.cfg.iq + kIqHist, (size_t)s.last_J * sizeof(float2), hipMemcpyDeviceToHost, b->ctx->stream));
         CSDR_HIP_TRY(hipStreamSynchronize(b->ctx->stream));
     }
@@ -694,18 +755,17 @@ extern "C" int csdr_bank_total_audio(csdr_bank *b, int64_t *n) {
 struct csdr_spec {
     csdr_ctx *ctx = nullptr;
     bool ready = false;
-    int F = 0, N = 0, N1 = 1, N2 = 0, C = 1, R = 1, max_frames = 0, nf_last = 0;
+    SpecGeom g{};
+    int max_frames = 0, nf_last = 0;
     float avg_rate = 0.65f, scale = 1.0f;
     DevBuf<float2> tw4096, tw_hi, tw_lo, tmp, carry, frame0, stage_in, raw;
-    DevBuf<float2> mag2;
-    DevBuf<float> pairsum, first_b, points;
+    DevBuf<float> mag, pairsum, first_b, points;
     DevBuf<double> ma, maa;
-    DevBuf<float2> ext;
+    DevBuf<float2> ext_w;
     int n_avg_waves = 0;
     DevBuf<SpecFrameOut> fo;
     DevBuf<SpecScalars> scal;
     int carry_len = 0;
-    size_t stage_cap = 0;
 };
 
 extern "C" int csdr_spec_create(csdr_ctx *ctx, csdr_spec **out) {
@@ -718,27 +778,31 @@ extern "C" void csdr_spec_destroy(csdr_spec *s) {
     if (!s) return;
     (void)hipStreamSynchronize(s->ctx->stream);
     s->tw4096.release(); s->tw_hi.release(); s->tw_lo.release(); s->tmp.release(); s->carry.release(); s->frame0.release();
-    s->stage_in.release(); s->raw.release(); s->mag2.release(); s->ext.release(); s->pairsum.release(); s->first_b.release(); s->points.release();
+    s->stage_in.release(); s->raw.release(); s->mag.release(); s->ext_w.release(); s->pairsum.release(); s->first_b.release(); s->points.release();
     s->ma.release(); s->maa.release(); s->fo.release(); s->scal.release();
     delete s;
 }
+
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     if (!s) return fail(CSDR_EINVAL, "spec is null");
     if (fft_size < 2 || (fft_size & (fft_size - 1))) return fail(CSDR_EUNSUPPORTED, "fft_size %d: only powers of two are built", fft_size);
     if (max_frames <= 0) return fail(CSDR_EINVAL, "max_frames");
     const int N = 2 * fft_size;                                      // SPECTRUM_VZM 2, SpectrumVisualProcessor.h:11, .cpp:145
-    if (N > (1 << 21)) return fail(CSDR_EUNSUPPORTED, "internal FFT of %d points exceeds 2^21", N);
+    if (N > (1 << 22)) return fail(CSDR_EUNSUPPORTED, "internal FFT of %d points exceeds 2^22", N);
     hipStream_t st = s->ctx->stream;
     CSDR_HIP_TRY(hipStreamSynchronize(st));
-    s->F = fft_size; s->N = N; s->max_frames = max_frames;
-    if (N <= kFftMaxLds) { s->N1 = 1; s->N2 = N; s->C = 1; s->R = 1; }
-    else {
-        s->N1 = std::max(128, N / (kFftMaxLds / 2)); s->N2 = N / s->N1;     // N2 <= 2048 so one workgroup holds a row PAIR
-        s->C = kFftMaxLds / s->N1; s->R = kFftMaxLds / s->N2;
-        if (s->C > s->N2) s->C = s->N2;
-        if (s->R > s->N1) s->R = s->N1;
+    s->ready = false;
+    SpecGeom &g = s->g;
+    g.N = N; g.F = fft_size; g.Ra = 1; g.Rb = 1; g.N2 = N;
+    if (N >= 4096) {
+        g.N2 = 4096;
+        const int R = N / 4096;                                       // 1 .. 1024
+        g.Ra = std::min(R, 32); g.Rb = R / g.Ra;
     }
+    g.lgRa = ilog2(g.Ra); g.lgRb = ilog2(g.Rb);
+    s->max_frames = max_frames;
     std::vector<float2> t(kTwTab);
     for (int i = 0; i < kTwTab; i++) { double a = -2.0 * M_PI * i / kTwTab; t[i] = make_float2((float)std::cos(a), (float)std::sin(a)); }
     if (int rc = s->tw4096.reserve(kTwTab)) return rc;
@@ -750,22 +814,22 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     if (int rc = s->tw_hi.reserve(hi.size())) return rc;
     CSDR_HIP_TRY(hipMemcpy(s->tw_lo.p, lo.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
     CSDR_HIP_TRY(hipMemcpy(s->tw_hi.p, hi.data(), hi.size() * sizeof(float2), hipMemcpyHostToDevice));
-    const size_t nfN = (size_t)max_frames * N;
-    if (s->N1 > 1) if (int rc = s->tmp.reserve(nfN)) return rc;
-    if (int rc = s->mag2.reserve(nfN / 2)) return rc;
-    s->n_avg_waves = (N / 2 + kAvgThreads - 1) / kAvgThreads;
-    if (int rc = s->ext.reserve(nfN / 2)) return rc;
+    const size_t nfN = (size_t)max_frames * N, F = (size_t)g.F;
+    if (g.Ra > 1) if (int rc = s->tmp.reserve(nfN)) return rc;
+    if (int rc = s->mag.reserve(nfN)) return rc;
+    s->n_avg_waves = (g.F + kAvgThreads - 1) / kAvgThreads;
+    if (int rc = s->ext_w.reserve((size_t)max_frames * s->n_avg_waves)) return rc;
     if (int rc = s->pairsum.reserve(nfN / 2)) return rc;
     if (int rc = s->first_b.reserve(max_frames)) return rc;
     if (int rc = s->points.reserve(nfN)) return rc;               // 2 * F floats per frame
-    if (int rc = s->ma.reserve(N)) return rc;
-    if (int rc = s->maa.reserve(N)) return rc;
+    if (int rc = s->ma.reserve(2 * F)) return rc;
+    if (int rc = s->maa.reserve(2 * F)) return rc;
     if (int rc = s->fo.reserve(max_frames)) return rc;
     if (int rc = s->scal.reserve(1)) return rc;
     if (int rc = s->carry.reserve(N)) return rc;
     if (int rc = s->frame0.reserve(N)) return rc;
-    CSDR_HIP_TRY(hipMemset(s->ma.p, 0, N * sizeof(double)));      // vector<double>::resize -> zeros (:243-257)
-    CSDR_HIP_TRY(hipMemset(s->maa.p, 0, N * sizeof(double)));
+    CSDR_HIP_TRY(hipMemset(s->ma.p, 0, 2 * F * sizeof(double)));      // vector<double>::resize -> zeros (:243-257)
+    CSDR_HIP_TRY(hipMemset(s->maa.p, 0, 2 * F * sizeof(double)));
     SpecScalars sc = {100.0, 100.0, 0.0, 0.0};                     // ctor :32-33
     CSDR_HIP_TRY(hipMemcpy(s->scal.p, &sc, sizeof sc, hipMemcpyHostToDevice));
     s->carry_len = 0; s->nf_last = 0;
@@ -776,15 +840,40 @@ extern "C" int csdr_spec_set_average_rate(csdr_spec *s, float r) { if (!s) retur
 extern "C" int csdr_spec_set_scale_factor(csdr_spec *s, float f) { if (!s) return fail(CSDR_EINVAL, "null"); s->scale = f; return CSDR_OK; }
 extern "C" int csdr_spec_frames(const csdr_spec *s) { return s ? s->nf_last : 0; }
 
-static int spec_run_fft(csdr_spec *s, const FrameSrc &fs, int nf, float2 *mag, float2 *raw) {
-    hipStream_t st = s->ctx->stream;
-    FrameSrc rows = fs;
-    if (s->N1 > 1) {
-        CSDR_LAUNCH(s->ctx, KID_FFT_COLS, spec_fft_cols, dim3(s->N2 / s->C, nf), dim3(kFftThreads), 0, fs, s->N1, s->N2, s->C,
-                           s->tw4096.p, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
-        rows.first = s->tmp.p; rows.rest = s->tmp.p + s->N; rows.stride = s->N;
+template <int COLS>
+static void launch_radix(csdr_ctx *c, int R, const FrameSrc &fs, int L, unsigned tw_scale, int nseq, const float2 *hi, const float2 *lo, float2 *dst) {
+    const int Lr = L / R;
+    const dim3 grid((Lr / COLS + kFftThreads - 1) / kFftThreads, nseq), block(kFftThreads);
+    switch (R) {
+        case 2: CSDR_LAUNCH(c, KID_FFT_COLS, (spec_fft_radix<2, COLS>), grid, block, 0, fs, L, tw_scale, hi, lo, dst); break;
+        case 4: CSDR_LAUNCH(c, KID_FFT_COLS, (spec_fft_radix<4, COLS>), grid, block, 0, fs, L, tw_scale, hi, lo, dst); break;
+        case 8: CSDR_LAUNCH(c, KID_FFT_COLS, (spec_fft_radix<8, COLS>), grid, block, 0, fs, L, tw_scale, hi, lo, dst); break;
+        case 16: CSDR_LAUNCH(c, KID_FFT_COLS, (spec_fft_radix<16, COLS>), grid, block, 0, fs, L, tw_scale, hi, lo, dst); break;
+        default: CSDR_LAUNCH(c, KID_FFT_COLS, (spec_fft_radix<32, COLS>), grid, block, 0, fs, L, tw_scale, hi, lo, dst); break;
     }
-    CSDR_LAUNCH(s->ctx, KID_FFT_ROWS, spec_fft_rows, dim3(s->N1 / s->R, nf), dim3(kFftThreads), 0, rows, s->N1, s->N2, s->R, s->tw4096.p, mag, raw);
+}
+
+static int spec_run_fft(csdr_spec *s, const FrameSrc &fs, int nf, float *mag, float2 *raw) {
+    const SpecGeom &g = s->g;
+    csdr_ctx *c = s->ctx;
+    if (g.N < 4096) {
+        CSDR_LAUNCH(c, KID_FFT_ROWS, spec_fft_small, dim3(1, nf), dim3(kFftThreads), (size_t)2 * g.N * sizeof(float2), fs, g.N, s->tw4096.p, mag, raw);
+    } else if (g.Ra == 1) {
+        CSDR_LAUNCH(c, KID_FFT_ROWS, spec_fft_rows4096, dim3(1, nf), dim3(kFftThreads), kRowLdsPts * sizeof(float2), fs, g, s->tw4096.p, mag, raw);
+    } else {
+        // radix passes: Ra-point columns of each frame, then (optionally) Rb-point columns inside each of the Ra sub-sequences
+        if (g.Ra <= 16) launch_radix<2>(c, g.Ra, fs, g.N, 1u, nf, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
+        else launch_radix<1>(c, g.Ra, fs, g.N, 1u, nf, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
+        if (g.Rb > 1) {
+            const int L2 = g.N / g.Ra;
+            FrameSrc sub{s->tmp.p, s->tmp.p + L2, L2};
+            if (g.Rb <= 16) launch_radix<2>(c, g.Rb, sub, L2, (unsigned)g.Ra, nf * g.Ra, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
+            else launch_radix<1>(c, g.Rb, sub, L2, (unsigned)g.Ra, nf * g.Ra, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
+        }
+        FrameSrc rows{s->tmp.p, s->tmp.p + g.N, g.N};
+        CSDR_LAUNCH(c, KID_FFT_ROWS, spec_fft_rows4096, dim3(g.Ra * g.Rb, nf), dim3(kFftThreads), kRowLdsPts * sizeof(float2), rows, g,
+                    s->tw4096.p, mag, raw);
+    }
     CSDR_HIP_TRY(hipGetLastError());
     return CSDR_OK;
 }
@@ -793,15 +882,16 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
     if (!s || !s->ready) return fail(CSDR_ESTATE, "spec not set up");
     if (!iq || n_blocks <= 0 || block_len <= 0) return fail(CSDR_EINVAL, "bad block arguments");
     hipStream_t st = s->ctx->stream;
-    const int N = s->N;
+    const SpecGeom &g = s->g;
+    const int N = g.N;
     const int64_t n = (int64_t)n_blocks * block_len;
     const float2 *x = (const float2 *)iq;
     if (!iq_is_dev) {
         if (int rc = s->stage_in.reserve((size_t)n)) return rc;
         CSDR_HIP_TRY(hipMemcpyAsync(s->stage_in.p, iq, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, st));
         x = s->stage_in.p;
-    }
-    FrameSrc fs;
+    } else if ((uintptr_t)iq & 7) return fail(CSDR_EINVAL, "device IQ pointer must be 8-byte aligned");
+    FrameSrc fs{nullptr, nullptr, 0};
     int nf = 0;
     if (mode == CSDR_SPEC_FIRST_FRAME) {
         if (block_len < N) return fail(CSDR_EUNSUPPORTED, "block_len %d < internal FFT size %d (overlap priming path :399-421 not built)", block_len, N);
@@ -809,6 +899,7 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
     } else if (mode == CSDR_SPEC_CONTIGUOUS) {
         const int64_t total = s->carry_len + n;
         nf = (int)(total / N);
+        if (nf > s->max_frames) return fail(CSDR_ERANGE, "%d frames exceed max_frames %d", nf, s->max_frames);
         if (nf > 0) {
             if (s->carry_len > 0) {
                 CSDR_LAUNCH(s->ctx, KID_SPEC_MISC, spec_assemble, dim3((N + 255) / 256), dim3(256), 0, s->carry.p, s->carry_len, x, N, s->frame0.p);
@@ -820,12 +911,13 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
     if (nf > s->max_frames) return fail(CSDR_ERANGE, "%d frames exceed max_frames %d", nf, s->max_frames);
     s->nf_last = nf;
     if (nf > 0) {
-        if (int rc = spec_run_fft(s, fs, nf, s->mag2.p, nullptr)) return rc;
-        CSDR_LAUNCH(s->ctx, KID_SPEC_AVG, spec_average, dim3(s->n_avg_waves), dim3(kAvgThreads), 0, s->mag2.p, nf, s->N1, s->N2, (double)s->avg_rate,
-                    s->ma.p, s->maa.p, s->pairsum.p, s->first_b.p, s->ext.p);
-        CSDR_LAUNCH(s->ctx, KID_SPEC_MISC, spec_minmax, dim3(nf), dim3(256), 0, s->ext.p, N / 2, s->fo.p);
-        CSDR_LAUNCH(s->ctx, KID_SPEC_TRACK, spec_trackers, dim3(1), dim3(64), 0, nf, s->scal.p, s->fo.p);
-        CSDR_LAUNCH(s->ctx, KID_SPEC_DISPLAY, spec_display, dim3((s->F + 255) / 256, nf), dim3(256), 0, s->pairsum.p, s->first_b.p, s->fo.p, s->N1, s->N2, s->scale, s->points.p);
+        if (int rc = spec_run_fft(s, fs, nf, s->mag.p, nullptr)) return rc;
+        CSDR_LAUNCH(s->ctx, KID_SPEC_AVG, spec_average, dim3(s->n_avg_waves), dim3(kAvgThreads), 0, s->mag.p, nf, g, (double)s->avg_rate,
+                    s->ma.p, s->maa.p, s->pairsum.p, s->first_b.p, s->ext_w.p);
+        CSDR_LAUNCH(s->ctx, KID_SPEC_TRACK, spec_trackers, dim3(1), dim3(kTrackThreads), kTrackChunk * sizeof(float2), s->ext_w.p, s->n_avg_waves, nf,
+                    s->scal.p, s->fo.p);
+        CSDR_LAUNCH(s->ctx, KID_SPEC_DISPLAY, spec_display, dim3((g.F / 2 + 255) / 256, nf), dim3(256), 0, s->pairsum.p, s->first_b.p, s->fo.p, g.F,
+                    s->scale, s->points.p);
         CSDR_HIP_TRY(hipGetLastError());
     }
     if (mode == CSDR_SPEC_CONTIGUOUS) {
@@ -845,10 +937,11 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
 extern "C" int csdr_spec_fetch(csdr_spec *s, int frame, float *points_host, int cap_floats, double *fft_ceiling, double *fft_floor) {
     if (!s || !s->ready || !points_host) return fail(CSDR_EINVAL, "bad argument");
     if (frame < 0 || frame >= s->nf_last) return fail(CSDR_EINVAL, "frame %d of %d", frame, s->nf_last);
-    if (cap_floats < 2 * s->F) return fail(CSDR_ERANGE, "need %d floats", 2 * s->F);
+    const int F = s->g.F;
+    if (cap_floats < 2 * F) return fail(CSDR_ERANGE, "need %d floats", 2 * F);
     hipStream_t st = s->ctx->stream;
     SpecFrameOut fo;
-    CSDR_HIP_TRY(hipMemcpyAsync(points_host, s->points.p + (size_t)frame * 2 * s->F, (size_t)2 * s->F * sizeof(float), hipMemcpyDeviceToHost, st));
+    CSDR_HIP_TRY(hipMemcpyAsync(points_host, s->points.p + (size_t)frame * 2 * F, (size_t)2 * F * sizeof(float), hipMemcpyDeviceToHost, st));
     CSDR_HIP_TRY(hipMemcpyAsync(&fo, s->fo.p + frame, sizeof fo, hipMemcpyDeviceToHost, st));
     CSDR_HIP_TRY(hipStreamSynchronize(st));
     if (fft_ceiling) *fft_ceiling = fo.point_ceil / (double)s->scale;     // :626
@@ -859,7 +952,7 @@ extern "C" int csdr_spec_fetch(csdr_spec *s, int frame, float *points_host, int 
 extern "C" int csdr_spec_fft_only(csdr_spec *s, const float *iq_host, float *out_host) {
     if (!s || !s->ready || !iq_host || !out_host) return fail(CSDR_EINVAL, "bad argument");
     hipStream_t st = s->ctx->stream;
-    const int N = s->N;
+    const int N = s->g.N;
     if (int rc = s->stage_in.reserve((size_t)N)) return rc;
     if (int rc = s->raw.reserve((size_t)N)) return rc;
     CSDR_HIP_TRY(hipMemcpyAsync(s->stage_in.p, iq_host, (size_t)N * sizeof(float2), hipMemcpyHostToDevice, st));

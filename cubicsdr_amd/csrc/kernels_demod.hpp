@@ -7,10 +7,12 @@
 //
 // Design: every filter on this path is FIR except the SSB Butterworth (whose impulse response is below fp32
 // resolution after ~100 samples).  So instead of carrying liquid's per-stage windows as state, each workgroup
-// (slot, block) re-derives the windows by running the cascade over a short warm-up span that precedes its block:
-// the only carried state is (i) the integer bookkeeping (NCO phase word, half-band input fill, 24-bit resampler
-// phase), tracked in closed form, and (ii) the tail of each sample stream.  Blocks of one batch are therefore
-// independent and run concurrently; outputs are bit-for-bit independent of the batching.
+// re-derives the windows by running the cascade over a short warm-up span that precedes its range: the only carried
+// state is (i) the integer bookkeeping (NCO phase word, half-band input fill, 24-bit resampler phase), tracked in
+// closed form, and (ii) the tail of each sample stream.  Ranges are therefore independent and run concurrently;
+// outputs are bit-for-bit independent of the batching.
+//
+// All LDS is dynamic (`smem`).
 #pragma once
 #include "common.hpp"
 
@@ -20,11 +22,12 @@ constexpr int kMaxHb = 10;        // half-band stages supported per resampler
 constexpr int kHbMaxM = 10;       // largest half-band m (taps: 2m on the filtered branch)
 constexpr int kArmTaps = 14;      // arbitrary resampler: 2 * 7 taps per arm
 constexpr int kArms = 256;
-constexpr int kMixHist = 16384;   // mixed-input history kept per slot (>= longest cascade span; S <= 8)
+constexpr int kMixHist = 16384;   // upper bound of the mixed-input history kept per slot (cascade span; S <= 8)
 constexpr int kIqHist = 256;      // resampled-IQ history kept per slot
 constexpr int kDHist = 64;        // scaled demodulator-output history kept per slot
 constexpr int kFeThreads = 256;
-constexpr int kFeChunkMax = 8192; // largest input span one inner iteration of the front-end stages through LDS
+constexpr int kFeChunk = 2048;    // input samples one inner iteration of the front-end stages through LDS
+constexpr int kFePairs = kFeChunk / 2 / kFeThreads;   // 16-byte loads per thread per chunk
 constexpr int kFeTail = 24;       // per-stage carried tail (>= 2 * kHbMaxM)
 constexpr int kFeZTail = 16;      // carried tail of the half-band chain output (>= 13)
 
@@ -41,14 +44,13 @@ struct SlotCfg {                  // static per configuration, lives in HBM
     ResampCfg rs_iq;              // msresamp_crcf  (DemodulatorWorkerThread.cpp:100)
     ResampCfg rs_au;              // msresamp_rrrf  (ModemAnalog.cpp:30)
     int32_t modem;
-    int32_t pad0;
-    float2 *mixhist;              // [2][kMixHist]
+    int32_t hist_len;             // mixed-input history actually kept (cascade span of this slot, multiple of 64)
+    float2 *mixhist;              // [2][hist_len]  ping-pong by SlotDyn::hist_parity
     float2 *iq;                   // [kIqHist + cap_iq]
     float *d;                     // [cap_iq]     unscaled demodulator output of the batch
-    float *dh;                    // [kDHist]     scaled demodulator-output history
+    float *dh;                    // [2][kDHist]  scaled demodulator-output history, ping-pong
     float *audio;                 // [cap_audio]
-    float *gains;                 // [max_blocks + 1]; gains[0] unused, gains[b+1] = gain of block b
-    float *agc;                   // [3] aOutputCeil, aOutputCeilMA, aOutputCeilMAA (ModemAnalog.h)
+    float *agc;                   // [2][4] aOutputCeil, aOutputCeilMA, aOutputCeilMAA (ModemAnalog.h), ping-pong
     float *blockmax;              // [max_blocks]
     struct BlockOut *bout;        // [max_blocks]
     int32_t cap_iq, cap_audio;
@@ -83,80 +85,56 @@ __device__ inline void nco_sincos(const float *tab, uint32_t theta, float &s, fl
     c = tab[(idx + 256u) & 1023u];
 }
 
-__device__ inline int64_t floor_div_pow2(int64_t v, int sh) { return v >> sh; }
-
 // closed form of the resampler loop: first output index whose phase lands at or after input K (K may be negative)
 __device__ inline int64_t resamp_first_out(int64_t K, uint32_t phase0, uint32_t step) {
     const int64_t lim = K * (int64_t)(1 << 24) - (int64_t)phase0;   // need j*step >= lim
-    if (lim <= 0) {
-        // negative side: largest-magnitude j with j*step >= lim  ->  ceil(lim / step) for negative lim
-        return -((-lim) / (int64_t)step);
-    }
+    if (lim <= 0) return -((-lim) / (int64_t)step);                  // ceil(lim / step) for lim <= 0
     return (lim + step - 1) / step;
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// D1: NCO shift + half-band decimator cascade + arbitrary polyphase resampler.   grid = (slot, block, part)
+// D1: NCO shift + half-band decimator cascade + arbitrary polyphase resampler.   grid = (part, slot)
 //
-// A workgroup owns a contiguous range of half-band-chain outputs [Ka, Kb) of one block of one demodulator and the
-// resampler outputs that fall on them.  It starts `warm` input samples earlier (the span of the whole cascade) with
-// empty windows, so that every window is fully populated by true samples when the first wanted output is formed.
-// The first half-band stage reads its 2m + 1 inputs straight from HBM/L2 (mixing each with the table NCO on the fly);
-// later stages ping through LDS in even/odd-split arrays (unit-stride ds_read_b64, no bank conflicts).  Normally the
-// whole range is one chunk (ch >= span); longer ranges loop over chunks carrying per-stage tails in LDS.
+// A workgroup owns a contiguous range [Ka, Kb) of half-band-chain outputs of one demodulator over the WHOLE batch
+// (block boundaries only matter for the per-block output counts, which are closed-form integers) and the resampler
+// outputs that fall on them.  It starts `warm` input samples earlier (the span of the whole cascade) with empty
+// windows, so every window is fully populated by true samples when the first wanted output is formed.
+// Per chunk of kFeChunk inputs: 16-byte coalesced loads (prefetched one chunk ahead into registers), table-NCO mix,
+// even/odd-split LDS arrays per stage (unit-stride ds_read_b64), per-stage tails carried in LDS between chunks.
 // ------------------------------------------------------------------------------------------------------------
-__host__ __device__ inline int fe_off(int e, int ch) { return (e - 1) * kFeTail + (ch >> 1) - (ch >> e); }   // stage e >= 1 input region
-__host__ __device__ inline int fe_arr_len(int S, int ch) { return S > 1 ? (S - 1) * kFeTail + (ch >> 1) - (ch >> S) : 0; }
-__host__ __device__ inline int fe_z_len(int S, int ch) { return kFeZTail + (S ? (ch >> S) : ch); }
-__host__ __device__ inline size_t fe_lds_bytes(int S, int ch) {
-    return (size_t)(2 * fe_arr_len(S, ch) + fe_z_len(S, ch)) * sizeof(float2) + 1024 * sizeof(float) + kMaxHb * kHbMaxM * sizeof(float);
+__host__ __device__ inline int fe_off(int e) { return e * kFeTail + kFeChunk - (kFeChunk >> e); }   // stage e input region (tail first)
+__host__ __device__ inline int fe_arr_len(int S) { return S * kFeTail + kFeChunk - (kFeChunk >> S); }
+__host__ __device__ inline int fe_z_len(int S) { return kFeZTail + (kFeChunk >> S); }
+__host__ __device__ inline size_t fe_lds_bytes(int S) {
+    return (size_t)(2 * fe_arr_len(S) + fe_z_len(S)) * sizeof(float2) + 1024 * sizeof(float) + kMaxHb * kHbMaxM * sizeof(float);
 }
 
-__device__ inline float2 fe_load_mixed(const float2 *__restrict__ chan, const float2 *__restrict__ hist, const float *tab,
-                                       const SlotDyn &dyn, int64_t rel) {
-    if (rel < 0) return rel >= -(int64_t)kMixHist ? hist[kMixHist + rel] : make_float2(0.f, 0.f);
-    const float2 x = chan[rel];
-    if (dyn.mixdir == 0) return x;
+// two adjacent stream samples (rel, rel + 1): batch samples come raw from the channel row, samples before the batch
+// come (already mixed) from the slot's history; positions outside both are zero.
+__device__ inline float4 fe_fetch_pair(const float2 *__restrict__ chan, const float2 *__restrict__ hist, int hist_len,
+                                       int64_t rel, int64_t total) {
+    if (rel >= 0 && rel + 1 < total) {
+        const f4u v = *reinterpret_cast<const f4u *>(chan + rel);
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    float2 a = make_float2(0.f, 0.f), b = a;
+    if (rel >= 0) { if (rel < total) a = chan[rel]; }
+    else if (rel >= -(int64_t)hist_len) a = hist[hist_len + rel];
+    const int64_t r1 = rel + 1;
+    if (r1 >= 0) { if (r1 < total) b = chan[r1]; }
+    else if (r1 >= -(int64_t)hist_len) b = hist[hist_len + r1];
+    return make_float4(a.x, a.y, b.x, b.y);
+}
+
+__device__ inline float2 fe_mix(float2 x, int64_t rel, const SlotDyn &dyn, const float *tab) {
+    if (dyn.mixdir == 0 || rel < 0) return x;          // history samples are stored mixed
     float s, c;
     nco_sincos(tab, dyn.theta0 + (uint32_t)rel * dyn.dtheta, s, c);
     if (dyn.mixdir < 0) return make_float2(fmaf(x.x, c, x.y * s), fmaf(x.y, c, -x.x * s));   // x (c - j s)
     return make_float2(fmaf(x.x, c, -x.y * s), fmaf(x.y, c, x.x * s));                        // x (c + j s)
 }
 
-
-// ---- half-band stage bodies, specialised on m so the tap loops unroll and all loads of one output issue together ----
-// stage 0: two adjacent outputs per thread straight from memory (2m + 1 even samples + 2 odd samples, each mixed once)
-template <int M>
-__device__ inline void fe_stage0(const float2 *__restrict__ chan, const float2 *__restrict__ hist, const float *tab, const float *h,
-                                 const SlotDyn &dyn, int64_t rel0, int cnt, float zeta, bool to_z,
-                                 float2 *__restrict__ outE, float2 *__restrict__ outO, float2 *__restrict__ outZ) {
-    const int npair = (cnt + 1) >> 1;
-    for (int pk = threadIdx.x; pk < npair; pk += kFeThreads) {
-        const int k = 2 * pk;
-        const int64_t r = rel0 + 2 * (int64_t)k;          // even sample of output k; output k+1 uses r + 2
-        float2 ev[2 * M + 1];                               // ev[i] = x[r + 2 - 2 i], i = 0 .. 2M
-#pragma unroll
-        for (int i = 0; i <= 2 * M; ++i) ev[i] = fe_load_mixed(chan, hist, tab, dyn, r + 2 - 2 * i);
-        const float2 od0 = fe_load_mixed(chan, hist, tab, dyn, r - 2 * M + 1), od1 = fe_load_mixed(chan, hist, tab, dyn, r - 2 * M + 3);
-        float a0r = od0.x, a0i = od0.y, a1r = od1.x, a1i = od1.y;
-#pragma unroll
-        for (int j = 0; j < M; ++j) {
-            const float hj = h[j];
-            // output k: x[r - 2j] = ev[j + 1], x[r - 2(2M-1-j)] = ev[2M - j];  output k+1: ev[j], ev[2M - 1 - j]
-            a0r = fmaf(hj, ev[j + 1].x + ev[2 * M - j].x, a0r); a0i = fmaf(hj, ev[j + 1].y + ev[2 * M - j].y, a0i);
-            a1r = fmaf(hj, ev[j].x + ev[2 * M - 1 - j].x, a1r); a1i = fmaf(hj, ev[j].y + ev[2 * M - 1 - j].y, a1i);
-        }
-        if (to_z) {
-            outZ[k] = make_float2(a0r * zeta, a0i * zeta);
-            if (k + 1 < cnt) outZ[k + 1] = make_float2(a1r * zeta, a1i * zeta);
-        } else {
-            outE[pk] = make_float2(a0r, a0i);               // k even -> E[k / 2]
-            if (k + 1 < cnt) outO[pk] = make_float2(a1r, a1i);
-        }
-    }
-}
-
-// stage e >= 1 through LDS
+// one half-band stage through LDS:  y[k] = O[k - m] + sum_{j<m} h[j] (E[k - j] + E[k - (2m-1) + j])
 template <int M>
 __device__ inline void fe_stage_lds(const float2 *__restrict__ Ein, const float2 *__restrict__ Oin, const float *h, int cnt, float zeta,
                                     bool to_z, float2 *__restrict__ outE, float2 *__restrict__ outO, float2 *__restrict__ outZ) {
@@ -174,44 +152,59 @@ __device__ inline void fe_stage_lds(const float2 *__restrict__ Ein, const float2
         else outE[k >> 1] = make_float2(ar, ai);
     }
 }
+__device__ inline void fe_stage_any(int m, const float2 *__restrict__ Ein, const float2 *__restrict__ Oin, const float *h, int cnt, float zeta,
+                                    bool to_z, float2 *__restrict__ outE, float2 *__restrict__ outO, float2 *__restrict__ outZ) {
+    for (int k = threadIdx.x; k < cnt; k += kFeThreads) {
+        const float2 d = Oin[k - m];
+        float ar = d.x, ai = d.y;
+        for (int j = 0; j < m; ++j) {
+            const float hj = h[j];
+            const float2 p = Ein[k - j], q = Ein[k - (2 * m - 1) + j];
+            ar = fmaf(hj, p.x + q.x, ar); ai = fmaf(hj, p.y + q.y, ai);
+        }
+        if (to_z) outZ[k] = make_float2(ar * zeta, ai * zeta);
+        else if (k & 1) outO[k >> 1] = make_float2(ar, ai);
+        else outE[k >> 1] = make_float2(ar, ai);
+    }
+}
 
-__global__ __launch_bounds__(kFeThreads) void demod_frontend(
+__global__ __launch_bounds__(kFeThreads, 4) void demod_frontend(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
-    const float2 *__restrict__ chan_base, int64_t chan_stride, int Bc, int NB, int ch,
+    const float2 *__restrict__ chan_base, int64_t chan_stride, int64_t total /* batch samples per channel */,
     const float *__restrict__ arms_all, const float *__restrict__ sintab) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int slot = slot_list[blockIdx.x];
-    const int b = blockIdx.y, part = blockIdx.z, P = gridDim.z;
+    const int slot = slot_list[blockIdx.y];
+    const int part = blockIdx.x, P = gridDim.x;
     const SlotCfg &cfg = cfgs[slot];
     const SlotDyn dyn = dyns[slot];
     const int tid = threadIdx.x;
     const int S = cfg.rs_iq.S;
     const uint32_t step = cfg.rs_iq.step;
+    const int hist_len = cfg.hist_len;
     const float2 *__restrict__ chan = chan_base + (int64_t)dyn.chan * chan_stride;
-    const float2 *__restrict__ hist = cfg.mixhist + (size_t)dyn.hist_parity * kMixHist;
+    const float2 *__restrict__ hist = cfg.mixhist + (size_t)dyn.hist_parity * hist_len;
     const float *__restrict__ arms = arms_all + (size_t)cfg.rs_iq.arms_idx * kArms * kArmTaps;
 
-    const int alen = fe_arr_len(S, ch);
-    float2 *LE = reinterpret_cast<float2 *>(smem_raw);
+    const int alen = fe_arr_len(S);
+    float2 *LE = reinterpret_cast<float2 *>(smem);
     float2 *LO = LE + alen;
     float2 *LZ = LO + alen;
-    float *tab = reinterpret_cast<float *>(LZ + fe_z_len(S, ch));
+    float *tab = reinterpret_cast<float *>(LZ + fe_z_len(S));
     float *hb = tab + 1024;
 
     for (int i = tid; i < 1024; i += kFeThreads) tab[i] = sintab[i];
     for (int i = tid; i < kMaxHb * kHbMaxM; i += kFeThreads) hb[i] = cfg.rs_iq.h_x[i / kHbMaxM][i % kHbMaxM];
-    for (int i = tid; i < (S - 1) * kFeTail; i += kFeThreads) {
-        const int e = 1 + i / kFeTail, k = i % kFeTail;
-        LE[fe_off(e, ch) + k] = make_float2(0.f, 0.f);
-        LO[fe_off(e, ch) + k] = make_float2(0.f, 0.f);
+    for (int i = tid; i < S * kFeTail; i += kFeThreads) {
+        const int e = i / kFeTail, k = i % kFeTail;
+        LE[fe_off(e) + k] = make_float2(0.f, 0.f);
+        LO[fe_off(e) + k] = make_float2(0.f, 0.f);
     }
     if (tid < kFeZTail) LZ[tid] = make_float2(0.f, 0.f);
 
     // --- index ranges (u-space: u = batch-relative input index + buf0; half-band output k covers u in [k 2^S, (k+1) 2^S))
-    const int64_t u_blk0 = (int64_t)dyn.buf0 + (int64_t)b * Bc, u_blk1 = u_blk0 + Bc;
-    const int64_t K0 = u_blk0 >> S, K1 = u_blk1 >> S;
-    const int64_t Ka = K0 + ((K1 - K0) * part) / P, Kb = K0 + ((K1 - K0) * (part + 1)) / P;
+    const int64_t K1 = ((int64_t)dyn.buf0 + total) >> S;
+    const int64_t Ka = (K1 * part) / P, Kb = (K1 * (part + 1)) / P;
     const int64_t j0 = resamp_first_out(Ka, dyn.phase0, step), j1 = resamp_first_out(Kb, dyn.phase0, step);
     int64_t lo = Ka - (kArmTaps - 1);
     for (int e = S - 1; e >= 0; --e) lo = 2 * lo - (4 * cfg.rs_iq.m_x[e] - 2);
@@ -219,40 +212,59 @@ __global__ __launch_bounds__(kFeThreads) void demod_frontend(
     const int64_t u_stop = Kb << S;
     const float zeta = 1.0f / (float)(1 << S);
 
+    // prefetch of the first chunk
+    float4 pf[kFePairs];
+    {
+        const int64_t rel0 = u_lo - (int64_t)dyn.buf0;
+        const int n = (int)min((int64_t)kFeChunk, u_stop - u_lo);
+#pragma unroll
+        for (int q = 0; q < kFePairs; ++q) {
+            const int p = tid + q * kFeThreads;
+            pf[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (2 * p < n) pf[q] = fe_fetch_pair(chan, hist, hist_len, rel0 + 2 * p, total);
+        }
+    }
     __syncthreads();
 
-    for (int64_t uc = u_lo; uc < u_stop; uc += ch) {
-        const int n = (int)min((int64_t)ch, u_stop - uc);
+    for (int64_t uc = u_lo; uc < u_stop; uc += kFeChunk) {
+        const int n = (int)min((int64_t)kFeChunk, u_stop - uc);
         const int64_t rel0 = uc - (int64_t)dyn.buf0;          // batch-relative index of the chunk's first input
+        // mix the prefetched chunk into the stage-0 arrays (or straight into Z when there is no half-band stage)
+#pragma unroll
+        for (int q = 0; q < kFePairs; ++q) {
+            const int p = tid + q * kFeThreads;
+            if (2 * p < n) {
+                const int64_t r = rel0 + 2 * p;
+                const float2 a = fe_mix(make_float2(pf[q].x, pf[q].y), r, dyn, tab);
+                const float2 b = fe_mix(make_float2(pf[q].z, pf[q].w), r + 1, dyn, tab);
+                if (S == 0) { LZ[kFeZTail + 2 * p] = a; if (2 * p + 1 < n) LZ[kFeZTail + 2 * p + 1] = b; }
+                else { LE[kFeTail + p] = a; LO[kFeTail + p] = b; }
+            }
+        }
+        // prefetch the next chunk while this one runs through the cascade
+        if (uc + kFeChunk < u_stop) {
+            const int64_t un = uc + kFeChunk;
+            const int nn = (int)min((int64_t)kFeChunk, u_stop - un);
+#pragma unroll
+            for (int q = 0; q < kFePairs; ++q) {
+                const int p = tid + q * kFeThreads;
+                if (2 * p < nn) pf[q] = fe_fetch_pair(chan, hist, hist_len, un - (int64_t)dyn.buf0 + 2 * p, total);
+            }
+        }
+        __syncthreads();
         int cnt = n;
-        if (S == 0) {
-            for (int i = tid; i < n; i += kFeThreads) LZ[kFeZTail + i] = fe_load_mixed(chan, hist, tab, dyn, rel0 + i);
-            __syncthreads();
-        } else {
-            // stage 0 straight from memory:  y[k] = x[2(k-m)+1] + sum_{j<m} h[j] (x[2(k-j)] + x[2(k-2m+1+j)])
+        for (int e = 0; e < S; ++e) {
             cnt >>= 1;
-            {
-                const int m = cfg.rs_iq.m_x[0];
-                const bool tz = (S == 1);
-                float2 *oE = LE + (tz ? 0 : fe_off(1, ch) + kFeTail), *oO = LO + (tz ? 0 : fe_off(1, ch) + kFeTail), *oZ = LZ + kFeZTail;
-                if (m == 3) fe_stage0<3>(chan, hist, tab, hb, dyn, rel0, cnt, zeta, tz, oE, oO, oZ);
-                else if (m == 5) fe_stage0<5>(chan, hist, tab, hb, dyn, rel0, cnt, zeta, tz, oE, oO, oZ);
-                else fe_stage0<10>(chan, hist, tab, hb, dyn, rel0, cnt, zeta, tz, oE, oO, oZ);
-            }
+            const int me = cfg.rs_iq.m_x[e];
+            const float2 *Ein = LE + fe_off(e) + kFeTail, *Oin = LO + fe_off(e) + kFeTail;
+            const float *he = hb + e * kHbMaxM;
+            const bool tz = (e == S - 1);
+            float2 *oE = LE + (tz ? 0 : fe_off(e + 1) + kFeTail), *oO = LO + (tz ? 0 : fe_off(e + 1) + kFeTail), *oZ = LZ + kFeZTail;
+            if (me == 3) fe_stage_lds<3>(Ein, Oin, he, cnt, zeta, tz, oE, oO, oZ);
+            else if (me == 5) fe_stage_lds<5>(Ein, Oin, he, cnt, zeta, tz, oE, oO, oZ);
+            else if (me == 10) fe_stage_lds<10>(Ein, Oin, he, cnt, zeta, tz, oE, oO, oZ);
+            else fe_stage_any(me, Ein, Oin, he, cnt, zeta, tz, oE, oO, oZ);
             __syncthreads();
-            // later stages through LDS
-            for (int e = 1; e < S; ++e) {
-                cnt >>= 1;
-                const int me = cfg.rs_iq.m_x[e];
-                const float2 *Ein = LE + fe_off(e, ch) + kFeTail, *Oin = LO + fe_off(e, ch) + kFeTail;
-                const float *he = hb + e * kHbMaxM;
-                const bool tz = (e == S - 1);
-                float2 *oE = LE + (tz ? 0 : fe_off(e + 1, ch) + kFeTail), *oO = LO + (tz ? 0 : fe_off(e + 1, ch) + kFeTail), *oZ = LZ + kFeZTail;
-                if (me == 3) fe_stage_lds<3>(Ein, Oin, he, cnt, zeta, tz, oE, oO, oZ);
-                else if (me == 5) fe_stage_lds<5>(Ein, Oin, he, cnt, zeta, tz, oE, oO, oZ);
-                else fe_stage_lds<10>(Ein, Oin, he, cnt, zeta, tz, oE, oO, oZ);
-                __syncthreads();
-            }
         }
         // arbitrary resampler on Z for outputs whose input index falls in this chunk
         const int64_t kz0 = uc >> S;
@@ -271,30 +283,46 @@ __global__ __launch_bounds__(kFeThreads) void demod_frontend(
             for (int t = 0; t < kArmTaps; ++t) { ar = fmaf(h[t], z[t].x, ar); ai = fmaf(h[t], z[t].y, ai); }
             cfg.iq[kIqHist + j] = make_float2(ar, ai);
         }
-        if (uc + ch < u_stop) {      // another chunk follows: carry tails to the front of every buffer
+        if (uc + kFeChunk < u_stop) {      // another chunk follows: carry tails to the front of every buffer
             __syncthreads();
-            int c2 = n >> 1;
-            for (int e = 1; e < S; ++e) {
-                c2 >>= 1;
-                float2 ve, vo;
-                if (tid < kFeTail) { ve = LE[fe_off(e, ch) + c2 + tid]; vo = LO[fe_off(e, ch) + c2 + tid]; }
-                __syncthreads();
-                if (tid < kFeTail) { LE[fe_off(e, ch) + tid] = ve; LO[fe_off(e, ch) + tid] = vo; }
+            float2 cv[2];
+            const int ntail = 2 * kFeTail * S;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int idx = tid + r * kFeThreads;
+                if (idx < ntail) {
+                    const int e = idx / (2 * kFeTail), k = idx % (2 * kFeTail);
+                    const float2 *arr = k < kFeTail ? LE : LO;
+                    cv[r] = arr[fe_off(e) + (n >> (e + 1)) + (k % kFeTail)];
+                }
             }
             float2 vz;
-            const int czz = (S == 0) ? n : (n >> S);
-            if (tid < kFeZTail) vz = LZ[czz + tid];
+            if (tid < kFeZTail) vz = LZ[cz + tid];
             __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int idx = tid + r * kFeThreads;
+                if (idx < ntail) {
+                    const int e = idx / (2 * kFeTail), k = idx % (2 * kFeTail);
+                    float2 *arr = k < kFeTail ? LE : LO;
+                    arr[fe_off(e) + (k % kFeTail)] = cv[r];
+                }
+            }
             if (tid < kFeZTail) LZ[tid] = vz;
             __syncthreads();
         }
     }
 
-    // new mixed-input history (other parity): the last kMixHist samples of (old history ++ mixed batch)
-    if (b == NB - 1 && part == P - 1) {
-        float2 *hnew = cfg.mixhist + (size_t)(dyn.hist_parity ^ 1) * kMixHist;
-        const int64_t total = (int64_t)NB * Bc;
-        for (int i = tid; i < kMixHist; i += kFeThreads) hnew[i] = fe_load_mixed(chan, hist, tab, dyn, total - kMixHist + i);
+    // new mixed-input history (other parity): the last hist_len samples of (old history ++ mixed batch)
+    if (part == P - 1) {
+        float2 *hnew = cfg.mixhist + (size_t)(dyn.hist_parity ^ 1) * hist_len;
+        for (int i = tid; i < hist_len; i += kFeThreads) {
+            const int64_t rel = total - hist_len + i;
+            float2 v = make_float2(0.f, 0.f);
+            if (rel >= 0) v = fe_mix(chan[rel], rel, dyn, tab);
+            else if (rel >= -(int64_t)hist_len) v = hist[hist_len + rel];
+            hnew[i] = v;
+        }
     }
 }
 
@@ -310,6 +338,7 @@ constexpr int kModemMaxBlockIq = 4096;     // resampled samples of one block han
 constexpr int kAmTaps = 51;
 constexpr int kSsbWarm = 192;              // IIR warm-up span; |pole|^192 ~ 1e-22
 constexpr int kHilbM = 5;                  // firhilbf_create(5, 90): 21-tap half-band, 10 odd taps
+// dynamic LDS: two float streams of `cap_stream` samples (max block + warm-up, multiple of 4) + 64 bytes of reduction scratch
 
 struct ModemConsts {
     float am_taps[kAmTaps];                // h[i] multiplies |x|[j - i]
@@ -340,11 +369,12 @@ __device__ inline float block_max_float(float v, float *lds) {
 
 __global__ __launch_bounds__(kModemThreads) void demod_modem(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
-    const BlockPlan *__restrict__ plans, int NB, const ModemConsts *__restrict__ mc, const float *__restrict__ sintab) {
-    __shared__ float s_a[kModemMaxBlockIq + kSsbWarm + 64];   // AM: |x| ; SSB: real part stream
-    __shared__ float s_b[kModemMaxBlockIq + kSsbWarm + 64];   // SSB: imag part stream
-    __shared__ double s_red[kModemThreads / 64];
-    __shared__ float s_redf[kModemThreads / 64];
+    const BlockPlan *__restrict__ plans, int NB, int cap_stream, const ModemConsts *__restrict__ mc, const float *__restrict__ sintab) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_a = reinterpret_cast<float *>(smem);              // AM: |x| ; SSB: real part stream
+    float *s_b = s_a + cap_stream;                             // SSB: imag part stream
+    double *s_red = reinterpret_cast<double *>(s_b + cap_stream);
+    float *s_redf = reinterpret_cast<float *>(s_red + 4);
 
     const int slot = slot_list[blockIdx.x], b = blockIdx.y, tid = threadIdx.x;
     const SlotCfg &cfg = cfgs[slot];
@@ -447,41 +477,25 @@ __global__ __launch_bounds__(kModemThreads) void demod_modem(
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// D2g: auto-gain recurrence across blocks (ModemAnalog.cpp:70-86): one thread per slot, sequential over the batch
-// ------------------------------------------------------------------------------------------------------------
-__global__ void demod_gain(const SlotCfg *__restrict__ cfgs, const int *__restrict__ slot_list, int n_slots, int NB) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_slots) return;
-    const SlotCfg &cfg = cfgs[slot_list[i]];
-    const bool autogain = !(cfg.modem == CSDR_MODEM_NBFM || cfg.modem == CSDR_MODEM_FM);
-    float ceil_ = cfg.agc[0], ma = cfg.agc[1], maa = cfg.agc[2];
-    for (int b = 0; b < NB; ++b) {
-        float g = 1.0f;
-        if (autogain) {
-            ma = ma + (ceil_ - ma) * 0.025f;
-            maa = maa + (ma - maa) * 0.025f;
-            ceil_ = cfg.blockmax[b];
-            g = 0.5f / maa;
-        }
-        cfg.gains[b + 1] = g;
-    }
-    cfg.agc[0] = ceil_; cfg.agc[1] = ma; cfg.agc[2] = maa;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// D2b: auto-gain scaling + msresamp_rrrf to the audio rate (interpolating form: arbitrary stage then x2 stages),
-// audio peak and (for useSignalOutput modems) the audio-based level sum.   grid = (slot, block)
+// D2b: auto-gain (ModemAnalog.cpp:70-86) + msresamp_rrrf to the audio rate (interpolating form: arbitrary stage then
+// x2 stages), audio peak and (for useSignalOutput modems) the audio-based level sum.   grid = (slot, block)
+// The gain of block b depends on the maxima of the blocks before it: every workgroup replays that short recurrence
+// from the batch-start state (ping-pong copy, so the last block's workgroup can publish the end state).  The
+// workgroup of the last block also carries the stream tails (resampled IQ, scaled demodulator output) to the
+// history regions for the next batch.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kAudioMaxOut = 4096;         // audio samples of one block handled by one workgroup
+// dynamic LDS: two ping-pong arrays of `cap_out` floats, `cap_win` staged demodulator samples, 64 bytes of scratch
 
 __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
-    const BlockPlan *__restrict__ plans, int NB, const float *__restrict__ arms_all) {
-    __shared__ float s_w0[kAudioMaxOut + 64];
-    __shared__ float s_w1[kAudioMaxOut + 64];
-    __shared__ double s_red[kModemThreads / 64];
-    __shared__ float s_redf[kModemThreads / 64];
-    __shared__ int s_jb[66];
+    const BlockPlan *__restrict__ plans, int NB, int cap_out, int cap_win, const float *__restrict__ arms_all) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_w0 = reinterpret_cast<float *>(smem);
+    float *s_w1 = s_w0 + cap_out;
+    float *s_d = s_w1 + cap_out;                               // scaled demodulator samples [jlo, jhi)
+    double *s_red = reinterpret_cast<double *>(s_d + cap_win);
+    float *s_redf = reinterpret_cast<float *>(s_red + 4);
 
     const int slot = slot_list[blockIdx.x], b = blockIdx.y, tid = threadIdx.x;
     const SlotCfg &cfg = cfgs[slot];
@@ -493,6 +507,21 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     const int64_t A0 = Q0 << aS, A1 = Q1 << aS;                    // audio samples of this block
     const int n_audio = (int)(A1 - A0);
     const float *arms = arms_all + (size_t)au.arms_idx * kArms * kArmTaps;
+    const bool autogain = !(cfg.modem == CSDR_MODEM_NBFM || cfg.modem == CSDR_MODEM_FM);
+    const float *agc_in = cfg.agc + 4 * dyn.hist_parity;
+    const float *dh_in = cfg.dh + (size_t)kDHist * dyn.hist_parity;
+
+    // gains of block b (g_cur) and of the block before it (g_prev); block -1 means "previous batch" (already scaled)
+    float g_cur = 1.0f, g_prev = 1.0f, ceil_ = agc_in[0], ma = agc_in[1], maa = agc_in[2];
+    if (autogain) {
+        for (int bb = 0; bb <= b; ++bb) {
+            ma = ma + (ceil_ - ma) * 0.025f;
+            maa = maa + (ma - maa) * 0.025f;
+            ceil_ = cfg.blockmax[bb];
+            g_prev = g_cur;
+            g_cur = 0.5f / maa;
+        }
+    }
 
     // backward range propagation: lo[s] = first needed index of the input of stage s (s = 0 is v = arbitrary-stage output)
     int64_t lo[kMaxHb + 1];
@@ -502,29 +531,40 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     hi[aS] = A1;
     for (int s = aS - 1; s >= 0; --s) hi[s] = (hi[s + 1] + 1) >> 1;
 
-    // 1. arbitrary stage: v[q] for q in [lo[0], hi[0]) into s_w0
+    // 0. stage the scaled demodulator samples the arbitrary stage touches
     const int nv = (int)(hi[0] - lo[0]);
+    const int64_t jlo = (((int64_t)dyn.aphase0 + lo[0] * (int64_t)au.step) >> 24) - (kArmTaps - 1);
+    const int64_t jhi = nv > 0 ? (((int64_t)dyn.aphase0 + (hi[0] - 1) * (int64_t)au.step) >> 24) + 1 : jlo;
+    const int nwin = (int)(jhi - jlo);
+    const int jb0 = pl[b].j0, jbp = b > 0 ? pl[b - 1].j0 : 0;
+    for (int i = tid; i < nwin; i += kModemThreads) {
+        const int64_t j = jlo + i;
+        float x;
+        if (j < 0) x = j >= -(int64_t)kDHist ? dh_in[kDHist + j] : 0.f;
+        else if (j >= jb0) x = cfg.d[j] * g_cur;
+        else if (j >= jbp) x = cfg.d[j] * g_prev;
+        else {
+            // more than one block back (tiny blocks): replay the gain of that block
+            int bb = b - 1;
+            while (bb > 0 && j < pl[bb].j0) --bb;
+            float c2 = agc_in[0], m2 = agc_in[1], mm2 = agc_in[2], gg = 1.0f;
+            if (autogain) for (int q = 0; q <= bb; ++q) { m2 = m2 + (c2 - m2) * 0.025f; mm2 = mm2 + (m2 - mm2) * 0.025f; c2 = cfg.blockmax[q]; gg = 0.5f / mm2; }
+            x = cfg.d[j] * gg;
+        }
+        s_d[i] = x;
+    }
+    __syncthreads();
+    // 1. arbitrary stage: v[q] for q in [lo[0], hi[0]) into s_w0
     for (int i = tid; i < nv; i += kModemThreads) {
         const int64_t q = lo[0] + i;
         const int64_t P = (int64_t)dyn.aphase0 + q * (int64_t)au.step;
         const int64_t jq = P >> 24;
         const int arm = (int)((P & 0xFFFFFF) >> 16);
         const float *h = arms + arm * kArmTaps;
+        const float *z = s_d + (jq - (kArmTaps - 1) - jlo);
         float acc = 0.f;
 #pragma unroll
-        for (int t = 0; t < kArmTaps; ++t) {
-            const int64_t j = jq - (kArmTaps - 1) + t;
-            float x;
-            if (j < 0) x = j >= -(int64_t)kDHist ? cfg.dh[kDHist + j] : 0.f;
-            else {
-                // gain of the block that sample j belongs to (blocks are short lists: walk back from b)
-                int bb = b;
-                while (bb > 0 && j < pl[bb].j0) --bb;
-                while (bb < NB - 1 && j >= pl[bb + 1].j0) ++bb;
-                x = cfg.d[j] * cfg.gains[bb + 1];
-            }
-            acc = fmaf(h[t], x, acc);
-        }
+        for (int t = 0; t < kArmTaps; ++t) acc = fmaf(h[t], z[t], acc);
         s_w0[i] = acc;
     }
     __syncthreads();
@@ -563,40 +603,39 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     const double sm = block_sum_double(lsum, s_red);
     if (tid == 0) {
         cfg.bout[b].audio_peak = pk;
-        if (!(cfg.modem == CSDR_MODEM_NBFM || cfg.modem == CSDR_MODEM_FM)) {   // useSignalOutput(true) modems
+        if (autogain) {   // useSignalOutput(true) modems
             cfg.bout[b].level_accum = sm;
             cfg.bout[b].level_count = n_audio;
         }
     }
-    (void)s_jb;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// tails: carry the last kIqHist resampled-IQ samples and the last kDHist scaled demodulator outputs to the
-// history regions for the next batch.   grid = slots, 256 threads
-// ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void demod_tails(const SlotCfg *__restrict__ cfgs, const int *__restrict__ slot_list,
-                                                    const BlockPlan *__restrict__ plans, int NB) {
-    const int slot = slot_list[blockIdx.x], tid = threadIdx.x;
-    const SlotCfg &cfg = cfgs[slot];
-    const BlockPlan *pl = plans + (size_t)slot * (NB + 1);
-    const int J = pl[NB].j0;
-    // iq: new history = stream positions [J - kIqHist, J) (stream index j maps to cfg.iq[kIqHist + j])
-    float2 v = make_float2(0.f, 0.f);
-    if (tid < kIqHist) v = cfg.iq[J + tid];
-    float dv = 0.f;
-    if (tid < kDHist) {
-        const int j = J - kDHist + tid;
-        if (j < 0) dv = cfg.dh[kDHist + j];
-        else {
-            int bb = NB - 1;
-            while (bb > 0 && j < pl[bb].j0) --bb;
-            dv = cfg.d[j] * cfg.gains[bb + 1];
+    // 4. last block: publish the auto-gain state and the stream tails for the next batch (other parity)
+    if (b == NB - 1) {
+        if (tid == 0) {
+            float *agc_out = cfg.agc + 4 * (dyn.hist_parity ^ 1);
+            agc_out[0] = ceil_; agc_out[1] = ma; agc_out[2] = maa;
         }
+        const int J = pl[NB].j0;
+        // iq: new history = stream positions [J - kIqHist, J) (stream index j maps to cfg.iq[kIqHist + j]); read, sync, write
+        float2 v = make_float2(0.f, 0.f);
+        if (tid < kIqHist) v = cfg.iq[J + tid];
+        float dv = 0.f;
+        if (tid < kDHist) {
+            const int j = J - kDHist + tid;
+            if (j < 0) dv = dh_in[kDHist + j];
+            else if (j >= jb0) dv = cfg.d[j] * g_cur;
+            else if (j >= jbp) dv = cfg.d[j] * g_prev;
+            else {
+                int bb = b - 1;
+                while (bb > 0 && j < pl[bb].j0) --bb;
+                float c2 = agc_in[0], m2 = agc_in[1], mm2 = agc_in[2], gg = 1.0f;
+                if (autogain) for (int q = 0; q <= bb; ++q) { m2 = m2 + (c2 - m2) * 0.025f; mm2 = mm2 + (m2 - mm2) * 0.025f; c2 = cfg.blockmax[q]; gg = 0.5f / mm2; }
+                dv = cfg.d[j] * gg;
+            }
+        }
+        __syncthreads();
+        if (tid < kIqHist) cfg.iq[tid] = v;
+        if (tid < kDHist) (cfg.dh + (size_t)kDHist * (dyn.hist_parity ^ 1))[tid] = dv;
     }
-    __syncthreads();
-    if (tid < kIqHist) cfg.iq[tid] = v;
-    if (tid < kDHist) cfg.dh[tid] = dv;
 }
 
 }  // namespace csdr

@@ -3,6 +3,8 @@
 // Replaces (reference file:line): iirfilt_crcf_execute_block SDRPostThread.cpp:284,375 (DC blocker, liquid
 // iirfilt_crcf_create_dc_blocker(0.0005) :29), firpfbch_crcf_analyzer_execute :449-451 (liquid firpfbch, Kaiser
 // prototype m=4, As=60 :406) and the strided channel gather :364-381.
+//
+// All LDS is dynamic (`smem`, 16-byte aligned base, carve offsets multiples of 16).
 #pragma once
 #include "common.hpp"
 
@@ -10,13 +12,15 @@ namespace csdr {
 
 // ------------------------------------------------------------------------------------------------------------
 // K1: first-order DC blocker  v[n] = x[n] - a1 v[n-1];  y[n] = v[n] - v[n-1]   (direct form II, b={1,-1}, a={1,a1})
-// A linear recurrence: evaluated as a three-kernel blocked affine scan in fp64 (tile-local ends, cross-tile carry,
-// apply), so a stream of any length runs in parallel while the carried state (one complex v) stays exact.
+// A linear recurrence: evaluated as a two-kernel blocked affine scan in fp64 (tile-local ends; then every tile
+// derives its entering state from the ends of the tiles before it and applies), so a stream of any length runs in
+// parallel while the carried state (one complex v) stays exact to fp64 rounding.
 // Tile = 256 threads x 16 samples, staged through LDS so global accesses stay coalesced.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kDcSeg = 16;
 constexpr int kDcThreads = 256;
 constexpr int kDcTile = kDcSeg * kDcThreads;
+constexpr size_t kDcLds = kDcTile * sizeof(float2) + kDcThreads * (2 * sizeof(double) + sizeof(double));
 
 struct d2 { double x, y; };
 
@@ -52,161 +56,240 @@ __device__ inline d2 dc_block_scan(d2 b, double A, d2 v_in, d2 *lds_b, double *l
     return ent;
 }
 
-// pass 1: each tile computes its end value assuming zero entering state
-__global__ __launch_bounds__(kDcThreads) void dc_tile_ends(const float2 *__restrict__ x, int64_t n, double c, d2 *tile_end) {
-    __shared__ float2 sx[kDcTile];
-    __shared__ d2 sb[kDcThreads];
-    __shared__ double sa[kDcThreads];
-    const int64_t base = (int64_t)blockIdx.x * kDcTile;
-    for (int i = threadIdx.x; i < kDcTile; i += kDcThreads) {
-        int64_t g = base + i;
-        sx[i] = g < n ? x[g] : make_float2(0.f, 0.f);
+__device__ inline void dc_stage_in(const float2 *__restrict__ x, int64_t n, int64_t base, float2 *sx) {
+    // 16-byte loads: two samples per lane
+    const float4 *x4 = reinterpret_cast<const float4 *>(x + base);
+    for (int i = threadIdx.x; i < kDcTile / 2; i += kDcThreads) {
+        const int64_t g = base + 2 * (int64_t)i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g + 1 < n) v = x4[i];
+        else if (g < n) { const float2 s = x[g]; v.x = s.x; v.y = s.y; }
+        sx[2 * i] = make_float2(v.x, v.y);
+        sx[2 * i + 1] = make_float2(v.z, v.w);
     }
+}
+
+// pass 1: each tile computes its end value assuming zero entering state
+__global__ __launch_bounds__(kDcThreads) void dc_tile_ends(const float2 *__restrict__ x, int64_t n, double c, d2 *__restrict__ tile_end) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *sx = reinterpret_cast<float2 *>(smem);
+    d2 *sb = reinterpret_cast<d2 *>(smem + kDcTile * sizeof(float2));
+    double *sa = reinterpret_cast<double *>(smem + kDcTile * sizeof(float2) + kDcThreads * sizeof(d2));
+    const int64_t base = (int64_t)blockIdx.x * kDcTile;
+    dc_stage_in(x, n, base, sx);
     __syncthreads();
     d2 v = {0.0, 0.0};
-    int cnt = 0;
     for (int i = 0; i < kDcSeg; ++i) {
         int64_t g = base + threadIdx.x * kDcSeg + i;
-        if (g < n) { float2 s = sx[threadIdx.x * kDcSeg + i]; v.x = (double)s.x + c * v.x; v.y = (double)s.y + c * v.y; ++cnt; }
+        if (g < n) { float2 s = sx[threadIdx.x * kDcSeg + i]; v.x = (double)s.x + c * v.x; v.y = (double)s.y + c * v.y; }
     }
-    // threads past the end of the stream act as identity maps (A = 1, b = 0): handled by using A^cnt
-    // -> the scan below assumes a uniform A, so give short segments their own multiplier through b only when cnt == kDcSeg;
-    // partial segments occur only in the last tile, whose end value is never consumed by a later tile except as the
-    // final carried state, which dc_apply recomputes exactly.  So a uniform A is sufficient here.
+    // partial segments occur only in the last tile, whose end value is never consumed (the carried state is recomputed
+    // exactly by dc_apply), so a uniform per-thread multiplier is sufficient here.
     d2 total;
     (void)dc_block_scan(v, dc_pow(c, kDcSeg), d2{0.0, 0.0}, sb, sa, &total);
     if (threadIdx.x == 0) tile_end[blockIdx.x] = total;
 }
 
-// pass 2: sequential carry across tiles (a few hundred tiles at most); state[0] = v entering the stream
-__global__ void dc_tile_carry(const d2 *tile_end, int ntiles, double c, d2 *state, d2 *tile_in) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// pass 2: entering state of tile T = A^T state_in + sum_{i<T} A^(T-1-i) tile_end[i]  (A = c^tile), then recompute with
+// the true entering state and write y (in place allowed); the last tile stores the new carried state in state_out.
+__global__ __launch_bounds__(kDcThreads) void dc_apply(const float2 *x, float2 *y, int64_t n, double c,
+                                                       const d2 *__restrict__ tile_end, const d2 *__restrict__ state_in,
+                                                       d2 *__restrict__ state_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *sx = reinterpret_cast<float2 *>(smem);
+    d2 *sb = reinterpret_cast<d2 *>(smem + kDcTile * sizeof(float2));
+    double *sa = reinterpret_cast<double *>(smem + kDcTile * sizeof(float2) + kDcThreads * sizeof(d2));
+    const int T = blockIdx.x, tid = threadIdx.x;
+    const int64_t base = (int64_t)T * kDcTile;
+    dc_stage_in(x, n, base, sx);
+    // carry from the tiles before this one
     const double A = dc_pow(c, kDcTile);
-    d2 v = state[0];
-    for (int t = 0; t < ntiles; ++t) {
-        tile_in[t] = v;
-        d2 e = tile_end[t];
-        v.x = A * v.x + e.x; v.y = A * v.y + e.y;
+    d2 part = {0.0, 0.0};
+    for (int i = tid; i < T; i += kDcThreads) {
+        const double w = dc_pow(A, T - 1 - i);
+        const d2 e = tile_end[i];
+        part.x += w * e.x; part.y += w * e.y;
     }
-}
-
-// pass 3: recompute with the true entering state and write y (in place allowed); the last tile stores the new state
-__global__ __launch_bounds__(kDcThreads) void dc_apply(const float2 *x, float2 *y, int64_t n, double c, const d2 *tile_in, d2 *state) {
-    __shared__ float2 sx[kDcTile];
-    __shared__ d2 sb[kDcThreads];
-    __shared__ double sa[kDcThreads];
-    const int64_t base = (int64_t)blockIdx.x * kDcTile;
-    for (int i = threadIdx.x; i < kDcTile; i += kDcThreads) {
-        int64_t g = base + i;
-        sx[i] = g < n ? x[g] : make_float2(0.f, 0.f);
-    }
+    sb[tid] = part;
     __syncthreads();
+    for (int off = kDcThreads / 2; off > 0; off >>= 1) {
+        if (tid < off) { sb[tid].x += sb[tid + off].x; sb[tid].y += sb[tid + off].y; }
+        __syncthreads();
+    }
+    const d2 s0 = state_in[0];
+    const double wT = dc_pow(A, T);
+    const d2 v_tile = {wT * s0.x + sb[0].x, wT * s0.y + sb[0].y};
+    __syncthreads();
+
     d2 v = {0.0, 0.0};
     for (int i = 0; i < kDcSeg; ++i) {
-        float2 s = sx[threadIdx.x * kDcSeg + i];
+        float2 s = sx[tid * kDcSeg + i];
         v.x = (double)s.x + c * v.x; v.y = (double)s.y + c * v.y;
     }
-    d2 ent = dc_block_scan(v, dc_pow(c, kDcSeg), tile_in[blockIdx.x], sb, sa, nullptr);
+    d2 ent = dc_block_scan(v, dc_pow(c, kDcSeg), v_tile, sb, sa, nullptr);
     v = ent;
     for (int i = 0; i < kDcSeg; ++i) {
-        int64_t g = base + threadIdx.x * kDcSeg + i;
-        float2 s = sx[threadIdx.x * kDcSeg + i];
+        int64_t g = base + tid * kDcSeg + i;
+        float2 s = sx[tid * kDcSeg + i];
         d2 v0 = {(double)s.x + c * v.x, (double)s.y + c * v.y};
-        sx[threadIdx.x * kDcSeg + i] = make_float2((float)(v0.x - v.x), (float)(v0.y - v.y));
+        sx[tid * kDcSeg + i] = make_float2((float)(v0.x - v.x), (float)(v0.y - v.y));
         if (g < n) {
             v = v0;
-            if (g == n - 1) state[0] = v0;
+            if (g == n - 1) state_out[0] = v0;
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < kDcTile; i += kDcThreads) {
-        int64_t g = base + i;
-        if (g < n) y[g] = sx[i];
+    float4 *y4 = reinterpret_cast<float4 *>(y + base);
+    for (int i = tid; i < kDcTile / 2; i += kDcThreads) {
+        const int64_t g = base + 2 * (int64_t)i;
+        const float2 a = sx[2 * i], b = sx[2 * i + 1];
+        if (g + 1 < n) y4[i] = make_float4(a.x, a.y, b.x, b.y);
+        else if (g < n) y[g] = a;
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // K2 + K4: critically-sampled polyphase analysis bank, M channels, 8 taps per branch, channel-major output.
 //   X_t[c] = sum_{n<8} taps[c][n] x[(t-n) M + c];   y_t[k] = sum_c X_t[c] exp(-j 2 pi k c / M);   out[k][t]
-// A workgroup owns TF consecutive frames: it stages (TF+7) M input samples in LDS with coalesced loads, forms X
-// (8 real x complex MACs per sample), then evaluates the M-point DFT for the REQUESTED channels only (the reference
-// computes all M with an FFT and then copies just the channels that have demodulators, SDRPostThread.cpp:336-339).
-// Lanes run along t so the channel-major stores are coalesced; the twiddle index is wave-uniform.
-// M is arbitrary (4, 20, 122, 200 ...): direct DFT, cost ~ n_active * M per frame.
+//
+// A workgroup owns TF consecutive frames.
+//  phase 0  polyphase FIR straight from HBM/L2: the input is one flat stream, so lane i reads x[i - n M], n = 0..7,
+//           fully coalesced 16-byte loads (two samples per lane); X goes to LDS as X[t][c] with a padded row stride.
+//  phase 1  M = A B.  c = c1 B + c2, k = k1 + A k2:  Z[t][c2][k1] = W_M^(k1 c2) sum_c1 X[t][c1 B + c2] W_A^(k1 c1)
+//           work item = (t, c2); four k1 accumulators per pass; the W_A twiddles are wave-uniform (scalar loads).
+//  phase 2  y[t][k1 + A k2] = sum_c2 Z[t][c2][k1] W_B^(k2 c2);  work item = (t, k1); lanes run along t, so every
+//           channel-major store instruction writes up to 512 contiguous bytes of one channel row.
+// Cost per frame M (A + B) complex MACs for any M (4, 20, 122, 200, 1024 ...); the reference computes the same DFT
+// with liquid's mixed-radix FFT and then copies out the channels that have consumers (SDRPostThread.cpp:336-339,
+// :364-381); here only rows whose `active` flag is set are stored.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kChanThreads = 256;
 constexpr int kChanTaps = 8;
 
+struct ChanGeom {
+    int M, A, B, A4, B4;      // M = A * B; A4 / B4 = A / B rounded up to a multiple of 4 (twiddle row pitch)
+    int TF, lgTF;             // frames per workgroup (power of two)
+    int S;                    // LDS row stride in float2 units (>= M, conflict-free for lanes along t)
+    unsigned magicM;          // floor(2^32 / M) + 1 : i / M for i < 2^20
+    int taps_lds;             // 1: the [8][M] tap table is staged in LDS
+};
+__host__ __device__ inline size_t chan_lds_bytes(const ChanGeom &g) {
+    size_t b = (size_t)2 * g.TF * g.S * sizeof(float2);
+    if (g.taps_lds) b += (size_t)kChanTaps * g.M * sizeof(float);
+    return (b + 15) & ~(size_t)15;
+}
+
 __global__ __launch_bounds__(kChanThreads) void chan_analyze(
     const float2 *__restrict__ x,        // batch input, n_frames * M samples
     const float2 *__restrict__ hist,     // 7 * M samples preceding x
-    const float *__restrict__ taps,      // [M][8]
-    const float2 *__restrict__ tw,       // [M] exp(-j 2 pi i / M)
-    const int *__restrict__ active,      // channel indices to produce
-    int n_active, int M, int TF, int64_t n_frames,
+    float2 *__restrict__ hist_new,       // receives the last 7 * M samples of (hist ++ x)
+    const float *__restrict__ tapsT,     // [8][M]  tapsT[n M + c] multiplies x[(t - n) M + c]
+    const float2 *__restrict__ twA,      // [A][A4] exp(-j 2 pi k1 c1 / A) at [c1 A4 + k1], zero padded
+    const float2 *__restrict__ twB,      // [B][B4] exp(-j 2 pi k2 c2 / B) at [c2 B4 + k2], zero padded
+    const float2 *__restrict__ twM,      // [A][B]  exp(-j 2 pi k1 c2 / M) at [k1 B + c2]
+    const int *__restrict__ active,      // [M] 1: store channel row k
+    ChanGeom g, int64_t n_frames,
     float2 *__restrict__ out, int64_t out_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int Mp = M | 1;  // padded row length (odd number of float2) against bank conflicts
-    float2 *s_in = (float2 *)smem;                        // (TF + 7) * M
-    float2 *s_x = s_in + (size_t)(TF + kChanTaps - 1) * M;  // TF * Mp
-    float2 *s_tw = s_x + (size_t)TF * Mp;                 // M
-    float *s_taps = (float *)(s_tw + M);                  // M * 8
-
+    const int M = g.M, A = g.A, B = g.B, TF = g.TF, S = g.S;
+    float2 *s_x = reinterpret_cast<float2 *>(smem);
+    float2 *s_z = s_x + (size_t)TF * S;
+    float *s_taps = reinterpret_cast<float *>(s_z + (size_t)TF * S);
+    const int tid = threadIdx.x;
     const int64_t f0 = (int64_t)blockIdx.x * TF;          // first frame of this tile
     const int nf = (int)min((int64_t)TF, n_frames - f0);
-    const int tid = threadIdx.x;
+    const int64_t H = (int64_t)(kChanTaps - 1) * M;
 
-    // stage input: frames f0-7 .. f0+nf-1
-    const int64_t s0 = (f0 - (kChanTaps - 1)) * M;        // global sample index of s_in[0] (may be negative)
-    const int n_in = (nf + kChanTaps - 1) * M;
-    for (int i = tid; i < n_in; i += kChanThreads) {
-        int64_t g = s0 + i;
-        s_in[i] = g >= 0 ? x[g] : hist[g + (int64_t)(kChanTaps - 1) * M];
+    if (g.taps_lds) {
+        for (int i = tid; i < kChanTaps * M; i += kChanThreads) s_taps[i] = tapsT[i];
+        __syncthreads();
     }
-    for (int i = tid; i < M; i += kChanThreads) s_tw[i] = tw[i];
-    for (int i = tid; i < M * kChanTaps; i += kChanThreads) s_taps[i] = taps[i];
-    __syncthreads();
+    const float *tp = g.taps_lds ? s_taps : tapsT;
 
-    // polyphase FIR
-    for (int i = tid; i < nf * M; i += kChanThreads) {
-        const int t = i / M, c = i - t * M;
-        float ar = 0.f, ai = 0.f;
+    // ---- phase 0: polyphase FIR, two adjacent samples (same frame: M is even) per lane
+    const int64_t base = f0 * M;
+    const int npairs = (nf * M) >> 1;
+    for (int p = tid; p < npairs; p += kChanThreads) {
+        const unsigned i = 2u * (unsigned)p;
+        const unsigned t = __umulhi(i, g.magicM);
+        const unsigned c = i - t * (unsigned)M;
+        const int64_t gi0 = base + i;
+        float2 a0 = make_float2(0.f, 0.f), a1 = make_float2(0.f, 0.f);
 #pragma unroll
         for (int n = 0; n < kChanTaps; ++n) {
-            const float h = s_taps[c * kChanTaps + n];
-            const float2 v = s_in[(t + kChanTaps - 1 - n) * M + c];
-            ar = fmaf(h, v.x, ar); ai = fmaf(h, v.y, ai);
+            const int64_t gi = gi0 - (int64_t)n * M;
+            const float2 *src = gi >= 0 ? x + gi : hist + (gi + H);
+            const float4 v = *reinterpret_cast<const float4 *>(src);
+            const float2 h = *reinterpret_cast<const float2 *>(tp + n * M + c);
+            a0.x = fmaf(h.x, v.x, a0.x); a0.y = fmaf(h.x, v.y, a0.y);
+            a1.x = fmaf(h.y, v.z, a1.x); a1.y = fmaf(h.y, v.w, a1.y);
         }
-        s_x[t * Mp + c] = make_float2(ar, ai);
+        float2 *d = s_x + (size_t)t * S + c;
+        d[0] = a0; d[1] = a1;
+    }
+    // the last workgroup also writes the new input history (the launch runs even with no consumers)
+    if (blockIdx.x == gridDim.x - 1) {
+        const int64_t n = n_frames * M;
+        for (int64_t j = tid; j < H; j += kChanThreads) {
+            const int64_t gsrc = n - H + j;
+            hist_new[j] = gsrc >= 0 ? x[gsrc] : hist[gsrc + H];
+        }
     }
     __syncthreads();
 
-    // DFT for requested channels: thread = (t, kgroup)
-    const int t = tid % TF, kg = tid / TF, KG = kChanThreads / TF;
-    if (t < nf) {
-        for (int a = kg; a < n_active; a += KG) {
-            const int k = active[a];
-            float yr = 0.f, yi = 0.f;
-            int wi = 0;
-            const float2 *row = s_x + t * Mp;
-            for (int c = 0; c < M; ++c) {
-                const float2 w = s_tw[wi];
-                const float2 v = row[c];
-                yr = fmaf(v.x, w.x, yr); yr = fmaf(-v.y, w.y, yr);
-                yi = fmaf(v.x, w.y, yi); yi = fmaf(v.y, w.x, yi);
-                wi += k; if (wi >= M) wi -= M;
+    // ---- phase 1: A-point DFTs over c1 for every (t, c2), times W_M^(k1 c2).
+    // wave item = (block of four k1, 64 consecutive (t, c2) items): k1b is wave-uniform, so the W_A rows are scalar loads.
+    const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+    const int tmask = TF - 1;
+    {
+        const int items = TF * B, nch = (items + 63) >> 6, nkb = g.A4 >> 2;
+        for (int w = wave; w < nkb * nch; w += kChanThreads / 64) {
+            const int kb = w / nch, k1b = kb * 4;
+            const int it = (w - kb * nch) * 64 + lane;
+            const int t = it & tmask, c2 = it >> g.lgTF;
+            if (it >= items || t >= nf) continue;
+            const float2 *xr = s_x + (size_t)t * S + c2;
+            float2 acc0 = make_float2(0.f, 0.f), acc1 = acc0, acc2 = acc0, acc3 = acc0;
+            const float2 *wr = twA + k1b;
+            for (int c1 = 0; c1 < A; ++c1, wr += g.A4) {
+                const float2 v = xr[c1 * B];
+                acc0 = cfma(v, wr[0], acc0); acc1 = cfma(v, wr[1], acc1);
+                acc2 = cfma(v, wr[2], acc2); acc3 = cfma(v, wr[3], acc3);
             }
-            out[(int64_t)k * out_stride + f0 + t] = make_float2(yr, yi);
+            float2 *zr = s_z + (size_t)t * S + c2 * A + k1b;
+            const float2 *wm = twM + (size_t)k1b * B + c2;
+            zr[0] = cmul(acc0, wm[0]);
+            if (k1b + 1 < A) zr[1] = cmul(acc1, wm[B]);
+            if (k1b + 2 < A) zr[2] = cmul(acc2, wm[2 * B]);
+            if (k1b + 3 < A) zr[3] = cmul(acc3, wm[3 * B]);
         }
     }
-}
+    __syncthreads();
 
-// new history = last 7*M samples of (old history ++ x[0..n))
-__global__ void chan_update_hist(const float2 *x, int64_t n, float2 *hist, float2 *hist_new, int H) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= H) return;
-    int64_t g = n - H + i;  // index into x; negative -> old history
-    hist_new[i] = g >= 0 ? x[g] : hist[g + H];
+    // ---- phase 2: B-point DFTs over c2 for every (t, k1); channel-major stores, lanes along t
+    {
+        const int items = TF * A, nch = (items + 63) >> 6, nkb = g.B4 >> 2;
+        for (int w = wave; w < nkb * nch; w += kChanThreads / 64) {
+            const int kb = w / nch, k2b = kb * 4;
+            const int it = (w - kb * nch) * 64 + lane;
+            const int t = it & tmask, k1 = it >> g.lgTF;
+            if (it >= items || t >= nf) continue;
+            const float2 *zr = s_z + (size_t)t * S + k1;
+            float2 acc0 = make_float2(0.f, 0.f), acc1 = acc0, acc2 = acc0, acc3 = acc0;
+            const float2 *wr = twB + k2b;
+            for (int c2 = 0; c2 < B; ++c2, wr += g.B4) {
+                const float2 v = zr[c2 * A];
+                acc0 = cfma(v, wr[0], acc0); acc1 = cfma(v, wr[1], acc1);
+                acc2 = cfma(v, wr[2], acc2); acc3 = cfma(v, wr[3], acc3);
+            }
+            const int k = k1 + A * k2b;
+            float2 *o = out + (int64_t)k * out_stride + f0 + t;
+            if (active[k]) o[0] = acc0;
+            if (k2b + 1 < B && active[k + A]) o[(int64_t)A * out_stride] = acc1;
+            if (k2b + 2 < B && active[k + 2 * A]) o[(int64_t)2 * A * out_stride] = acc2;
+            if (k2b + 3 < B && active[k + 3 * A]) o[(int64_t)3 * A * out_stride] = acc3;
+        }
+    }
 }
 
 }  // namespace csdr

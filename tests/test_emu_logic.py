@@ -1,0 +1,85 @@
+"""Kernel-LOGIC checks on the CPU-only container (TEST INFRASTRUCTURE, not a product path).
+
+tests/emu builds the unmodified HIP sources against a host-thread emulation of the few HIP constructs they use
+(tests/emu/hip/hip_runtime.h) and these tests run the same parity cases as tests/test_gpu_parity.py through it, against
+the oracle.  They catch indexing / barrier / bookkeeping mistakes before GPU minutes are spent; they say nothing about
+the device (the `-m gpu` tests are the parity tests proper) and the emulated library is never importable from
+cubicsdr_amd/ (checked by tests/test_abi.py).
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import tests.test_gpu_parity as G
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "emu"))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import build_emu
+    import cubicsdr_amd.hip as H
+    from cubicsdr_amd.engine import Context
+    path = build_emu.build(os.environ.get("CSDR_EMU_FLAVOR", ""))
+    lib = C.CDLL(path)
+    for name, (res, args) in H.ABI.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    saved = H._lib
+    H._lib = lib            # the engine objects created inside this module talk to the emulated library
+    c = Context(0)
+    try:
+        yield c
+    finally:
+        c.close()
+        H._lib = saved
+
+
+def test_emu_channelizer_c1(ctx):
+    G.test_channelizer_matches_firpfbch(ctx, 2400000, 4, 40000)
+
+
+def test_emu_channelizer_m6(ctx):
+    G.test_channelizer_matches_firpfbch(ctx, 3000000, 6, 50004)
+
+
+def test_emu_channelizer_batched(ctx):
+    G.test_channelizer_batched_equals_blockwise(ctx)
+
+
+def test_emu_dc_blocker(ctx):
+    G.test_single_channel_dc_blocker(ctx)
+
+
+def test_emu_nbfm_c1(ctx):
+    G.test_nbfm_c1_config(ctx)
+
+
+def test_emu_mixed_modems(ctx):
+    G.test_mixed_modems_streaming(ctx)
+
+
+def test_emu_batched(ctx):
+    G.test_batched_equals_reference(ctx)
+
+
+def test_emu_single_channel_demod(ctx):
+    G.test_single_channel_mode_demod(ctx)
+
+
+@pytest.mark.parametrize("F", [512, 2048, 16384])
+def test_emu_fft(ctx, F):
+    G.test_fft_matches_liquid(ctx, F)
+
+
+def test_emu_spectrum_first_frame(ctx):
+    G.test_spectrum_points_first_frame_mode(ctx, 2048, 40000)
+
+
+def test_emu_spectrum_contiguous(ctx):
+    G.test_spectrum_contiguous_mode(ctx)
