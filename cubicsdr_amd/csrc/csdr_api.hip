@@ -83,7 +83,7 @@ extern "C" int csdr_ctx_timer_stop(csdr_ctx *c, float *ms) {
 static const char *kKernelNames[KID_COUNT] = {
     "chan_analyze", "dc_tile_ends", "dc_apply",
     "demod_frontend", "demod_modem", "demod_audio_interp",
-    "spec_fft_radix", "spec_fft_rows", "spec_average", "spec_trackers", "spec_display", "spec_misc"};
+    "spec_fft_radix", "spec_fft_rows", "spec_average", "spec_extrema", "spec_display", "spec_misc"};
 static int prof_drain(csdr_ctx *c) {
     CSDR_HIP_TRY(hipStreamSynchronize(c->stream));
     for (auto &r : c->prof_pending) {
@@ -187,6 +187,7 @@ static int chan_geometry(int M, ChanGeom &g) {
     g.A4 = (g.A + 3) & ~3; g.B4 = (g.B + 3) & ~3;
     g.magicM = (unsigned)((1ull << 32) / (unsigned)M) + 1u;
     g.taps_lds = (M <= 512) ? 1 : 0;
+    g.stage_in = (M <= 256) ? 1 : 0;
     // frames per workgroup: the largest power of two <= 64 whose two row arrays fit the LDS budget
     const size_t budget = (M <= 512) ? 64 * 1024 : 72 * 1024;
     for (int tf = 64; tf >= 1; tf >>= 1) {
@@ -372,7 +373,8 @@ struct SlotHost {
     uint32_t theta = 0, dtheta = 0, buf_idx = 0, phase = 0, aphase = 0, ssb_theta = 0;
     long long shift_frequency = 0;
     bool shift_valid = false;
-    int hist_parity = 0;
+    int hist_parity = 0, last_parity = 0;
+    int prev_J = 0;                          // resampled-IQ samples of the previous executed batch
     int warm = 0;                            // cascade span in input samples (+ one output period)
     void *slab = nullptr;
     SlotCfg cfg{};
@@ -389,7 +391,7 @@ struct csdr_bank {
     std::vector<SlotHost> slots;
     DevBuf<SlotCfg> cfgs;
     DevBuf<SlotDyn> dyns;
-    DevBuf<int> slot_list;
+    DevBuf<int> slot_list;                   // [3][max_demods]: all running slots | running auto-gain slots | running slots grouped by front-end kernel
     DevBuf<BlockPlan> plans;
     DevBuf<float> arms;
     DevBuf<ModemConsts> mconsts;
@@ -448,12 +450,12 @@ extern "C" int csdr_bank_create(csdr_ctx *ctx, int max_demods, int max_blocks, c
     b->slots.resize(max_demods);
     if (int rc = b->cfgs.reserve(max_demods)) return rc;
     if (int rc = b->dyns.reserve(max_demods)) return rc;
-    if (int rc = b->slot_list.reserve(max_demods)) return rc;
+    if (int rc = b->slot_list.reserve(3 * (size_t)max_demods)) return rc;
     if (int rc = b->plans.reserve((size_t)max_demods * (max_blocks + 1))) return rc;
     if (int rc = b->mconsts.reserve(1)) return rc;
     for (int r = 0; r < kStageRing; ++r) {
         if (int rc = b->dyns_h[r].reserve(max_demods)) return rc;
-        if (int rc = b->slot_list_h[r].reserve(max_demods)) return rc;
+        if (int rc = b->slot_list_h[r].reserve(3 * (size_t)max_demods)) return rc;
         if (int rc = b->plans_h[r].reserve((size_t)max_demods * (max_blocks + 1))) return rc;
         CSDR_HIP_TRY(hipEventCreate(&b->stage_ev[r]));
     }
@@ -531,7 +533,7 @@ extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_mix = carve((size_t)2 * hist_len * sizeof(float2));
-    const size_t o_iq = carve((kIqHist + cap_iq) * sizeof(float2));
+    const size_t o_iq = carve(2 * (kIqHist + cap_iq) * sizeof(float2));
     const size_t o_d = carve(cap_iq * sizeof(float));
     const size_t o_dh = carve(2 * kDHist * sizeof(float));
     const size_t o_au = carve(cap_audio * sizeof(float));
@@ -556,7 +558,7 @@ extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod
     CSDR_HIP_TRY(hipMemcpy(c.agc, agc0, sizeof agc0, hipMemcpyHostToDevice));
     CSDR_HIP_TRY(hipMemcpy(b->cfgs.p + slot, &c, sizeof c, hipMemcpyHostToDevice));
     // fresh objects: nco_crcf_create / msresamp create / modem ctor all start from zero state
-    s.theta = 0; s.dtheta = 0; s.buf_idx = 0; s.phase = 0; s.aphase = 0; s.hist_parity = 0;
+    s.theta = 0; s.dtheta = 0; s.buf_idx = 0; s.phase = 0; s.aphase = 0; s.hist_parity = 0; s.last_parity = 0; s.prev_J = 0;
     s.shift_valid = false; s.shift_frequency = 0;
     // ModemUSB/LSB ctor: nco_crcf_set_frequency(ssbShift, 2 pi 0.25) -> the oscillator advances 2^30 per sample
     s.ssb_theta = 0;
@@ -596,8 +598,8 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     SlotDyn *dyns_h = b->dyns_h[ring].p;
     int *slot_list_h = b->slot_list_h[ring].p;
     BlockPlan *plans_h = b->plans_h[ring].p;
-    int n_run = 0, max_n_iq = 0, max_n_audio = 0, warm_max = 0, max_aS = 0;
-    bool need_streams = false;
+    int n_run = 0, n_ag = 0, max_n_iq = 0, max_n_audio = 0, warm_max = 0, max_aS = 0;
+    int *ag_list_h = slot_list_h + b->max_demods;
     for (int si = 0; si < b->max_demods; ++si) {
         SlotHost &s = b->slots[si];
         s.results.clear(); s.last_J = 0; s.last_A = 0;
@@ -629,6 +631,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         d.active = 1; d.chan = data_ch; d.theta0 = s.theta; d.dtheta = s.dtheta;
         d.mixdir = shift == 0 ? 0 : (shift < 0 ? +1 : -1);          // :186-191: shift < 0 -> mix up
         d.buf0 = s.buf_idx; d.phase0 = s.phase; d.aphase0 = s.aphase; d.ssb_theta0 = s.ssb_theta; d.hist_parity = s.hist_parity;
+        d.prev_j = s.prev_J;
         // per-block plan
         BlockPlan *pl = plans_h + (size_t)si * (NB + 1);
         const int S = (int)s.iq.S, aS = (int)s.au.S;
@@ -660,30 +663,51 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         if (d.mixdir) s.theta += (uint32_t)((int64_t)NB * Bc) * s.dtheta;
         s.aphase = (uint32_t)((int64_t)s.aphase + Qtot * (int64_t)s.au.step - (Jtot << 24));
         s.ssb_theta += (uint32_t)Jtot * (1u << 30);
+        s.last_parity = s.hist_parity;
         s.hist_parity ^= 1;
         s.last_J = (int)Jtot; s.last_A = (int)(Qtot << aS);
+        s.prev_J = (int)Jtot;
         warm_max = std::max(warm_max, s.warm); max_aS = std::max(max_aS, aS);
-        if (s.prm.modem != CSDR_MODEM_NBFM && s.prm.modem != CSDR_MODEM_FM) need_streams = true;
+        if (s.prm.modem != CSDR_MODEM_NBFM && s.prm.modem != CSDR_MODEM_FM) ag_list_h[n_ag++] = si;
         slot_list_h[n_run++] = si;
     }
     b->n_run = n_run; b->last_nb = NB;
     if (n_run == 0) return CSDR_OK;
+    // running slots grouped by front-end kernel (filled before the staging set is handed to the copy engine)
+    int *grp_h = slot_list_h + 2 * (size_t)b->max_demods;
+    int grp_off[8] = {0}, grp_n[8] = {0};        // index 0: generic, 3..6: specialised by S
+    {
+        auto klass = [&](const SlotHost &s) {
+            const int S = (int)s.iq.S;
+            if (S < 3 || S > 6) return 0;
+            for (int e = 0; e < S; ++e) if ((int)s.iq.m[S - 1 - e] != fes_m(S, e)) return 0;
+            return S;
+        };
+        int pos = 0;
+        for (int k = 0; k < 7; ++k) {
+            grp_off[k] = pos;
+            for (int i = 0; i < n_run; ++i) if (klass(b->slots[slot_list_h[i]]) == k) grp_h[pos++] = slot_list_h[i];
+            grp_n[k] = pos - grp_off[k];
+        }
+    }
     CSDR_HIP_TRY(hipMemcpyAsync(b->dyns.p, dyns_h, b->max_demods * sizeof(SlotDyn), hipMemcpyHostToDevice, st));
-    CSDR_HIP_TRY(hipMemcpyAsync(b->slot_list.p, slot_list_h, n_run * sizeof(int), hipMemcpyHostToDevice, st));
+    CSDR_HIP_TRY(hipMemcpyAsync(b->slot_list.p, slot_list_h, 3 * (size_t)b->max_demods * sizeof(int), hipMemcpyHostToDevice, st));
     CSDR_HIP_TRY(hipMemcpyAsync(b->plans.p, plans_h, (size_t)b->max_demods * (NB + 1) * sizeof(BlockPlan), hipMemcpyHostToDevice, st));
     CSDR_HIP_TRY(hipEventRecord(b->stage_ev[ring], st));
     b->stage_used[ring] = true;
-    // front-end geometry: every slot's batch is cut into P ranges; a range re-runs `warm` inputs in front of it
+    // front-end geometry: every slot's batch is cut into P ranges; a range re-runs `warm` inputs in front of it.
+    // Slots whose cascade has the reference's standard shape (m = 3..3, 5, 10; 3 <= S <= 6) run the specialised kernel,
+    // one launch per depth S; anything else runs the generic one.
     const int64_t total = (int64_t)NB * Bc;
     const int64_t range = std::max<int64_t>(8192, 6 * (int64_t)warm_max);
     int P = (int)std::max<int64_t>(1, std::min<int64_t>(total / range, 4096));
     size_t fe_lds = 0;
-    for (int i = 0; i < n_run; ++i) fe_lds = std::max(fe_lds, fe_lds_bytes((int)b->slots[slot_list_h[i]].iq.S));
-    const int cap_stream = need_streams ? ((max_n_iq + kSsbWarm + 64 + 3) & ~3) : 4;
+    for (int i = 0; i < grp_n[0]; ++i) fe_lds = std::max(fe_lds, fe_lds_bytes((int)b->slots[grp_h[grp_off[0] + i]].iq.S));
+    const int cap_stream = (max_n_iq + kSsbWarm + 64 + 3) & ~3;
     const size_t modem_lds = (size_t)2 * cap_stream * sizeof(float) + 64;
     const int cap_out = (max_n_audio + 32 * max_aS + 64 + 3) & ~3, cap_win = (max_n_iq + 128 + 3) & ~3;
     const size_t audio_lds = (size_t)(2 * cap_out + cap_win) * sizeof(float) + 64;
-    const size_t want[3] = {fe_lds, modem_lds, audio_lds};
+    const size_t want[3] = {fe_lds, modem_lds, audio_lds};     // (the specialised front-end kernels stay below 64 KB)
     const void *fn[3] = {(const void *)demod_frontend, (const void *)demod_modem, (const void *)demod_audio_interp};
     for (int k = 0; k < 3; ++k)
         if (want[k] > 64 * 1024 && want[k] > b->lds_attr[k]) {
@@ -691,10 +715,19 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
             b->lds_attr[k] = want[k];
         }
     const dim3 grid(n_run, NB);
-    CSDR_LAUNCH(b->ctx, KID_FRONTEND, demod_frontend, dim3(P, n_run), dim3(kFeThreads), fe_lds, b->cfgs.p, b->dyns.p, b->slot_list.p,
-                post->out.p, post->chan_stride, total, b->arms.p, b->ctx->sintab.p);
-    CSDR_LAUNCH(b->ctx, KID_MODEM, demod_modem, grid, dim3(kModemThreads), modem_lds, b->cfgs.p, b->dyns.p, b->slot_list.p, b->plans.p, NB, cap_stream,
-                b->mconsts.p, b->ctx->sintab.p);
+    const int *grp_d = b->slot_list.p + 2 * (size_t)b->max_demods;
+    if (grp_n[0] > 0)
+        CSDR_LAUNCH(b->ctx, KID_FRONTEND, demod_frontend, dim3(P, grp_n[0]), dim3(kFeThreads), fe_lds, b->cfgs.p, b->dyns.p, grp_d + grp_off[0],
+                    post->out.p, post->chan_stride, total, b->arms.p, b->ctx->sintab.p);
+#define CSDR_FE_S(S_)                                                                                                                   \
+    if (grp_n[S_] > 0)                                                                                                                  \
+        CSDR_LAUNCH(b->ctx, KID_FRONTEND, (demod_frontend_s<S_, 2048>), dim3(P + 1, grp_n[S_]), dim3(kFeThreads), (fes_lds_bytes<S_, 2048>()), \
+                    b->cfgs.p, b->dyns.p, grp_d + grp_off[S_], post->out.p, post->chan_stride, total, b->arms.p, b->ctx->sintab.p)
+    CSDR_FE_S(3); CSDR_FE_S(4); CSDR_FE_S(5); CSDR_FE_S(6);
+#undef CSDR_FE_S
+    if (n_ag > 0)     // freqdem modems need no block-wide pre-pass: only the auto-gain modems run the modem kernel
+        CSDR_LAUNCH(b->ctx, KID_MODEM, demod_modem, dim3(n_ag, NB), dim3(kModemThreads), modem_lds, b->cfgs.p, b->dyns.p, b->slot_list.p + b->max_demods,
+                    b->plans.p, NB, cap_stream, b->mconsts.p, b->ctx->sintab.p);
     CSDR_LAUNCH(b->ctx, KID_AUDIO, demod_audio_interp, grid, dim3(kModemThreads), audio_lds, b->cfgs.p, b->dyns.p, b->slot_list.p, b->plans.p, NB,
                 cap_out, cap_win, b->arms.p);
     CSDR_HIP_TRY(hipGetLastError());
@@ -737,8 +770,8 @@ extern "C" int csdr_bank_fetch_iq(csdr_bank *b, int slot, float *host_out, int c
     if (s.last_J > cap_samples) return fail(CSDR_ERANGE, "need room for %d samples", s.last_J);
     *n = s.last_J;
     if (s.last_J) {
-        // the batch region [kIqHist, kIqHist + J) is untouched by the tail copy into the history region in front of it
-        CSDR_HIP_TRY(hipMemcpyAsync(host_out, s.cfg.iq + kIqHist, (size_t)s.last_J * sizeof(float2), hipMemcpyDeviceToHost, b->ctx->stream));
+        const float2 *cur = s.cfg.iq + (size_t)s.last_parity * ((size_t)kIqHist + s.cfg.cap_iq) + kIqHist;
+        CSDR_HIP_TRY(hipMemcpyAsync(host_out, cur, (size_t)s.last_J * sizeof(float2), hipMemcpyDeviceToHost, b->ctx->stream));
         CSDR_HIP_TRY(hipStreamSynchronize(b->ctx->stream));
     }
     return CSDR_OK;
@@ -758,11 +791,11 @@ struct csdr_spec {
     SpecGeom g{};
     int max_frames = 0, nf_last = 0;
     float avg_rate = 0.65f, scale = 1.0f;
-    DevBuf<float2> tw4096, tw_hi, tw_lo, tmp, carry, frame0, stage_in, raw;
+    DevBuf<float2> tw4096, tw_hi, tw_lo, tmp, carry, stage_in, raw;
     DevBuf<float> mag, pairsum, first_b, points;
     DevBuf<double> ma, maa;
-    DevBuf<float2> ext_w;
-    int n_avg_waves = 0;
+    DevBuf<float2> ext_w, ext;
+    int n_avg_tiles = 0, scal_parity = 0;
     DevBuf<SpecFrameOut> fo;
     DevBuf<SpecScalars> scal;
     int carry_len = 0;
@@ -777,8 +810,8 @@ extern "C" int csdr_spec_create(csdr_ctx *ctx, csdr_spec **out) {
 extern "C" void csdr_spec_destroy(csdr_spec *s) {
     if (!s) return;
     (void)hipStreamSynchronize(s->ctx->stream);
-    s->tw4096.release(); s->tw_hi.release(); s->tw_lo.release(); s->tmp.release(); s->carry.release(); s->frame0.release();
-    s->stage_in.release(); s->raw.release(); s->mag.release(); s->ext_w.release(); s->pairsum.release(); s->first_b.release(); s->points.release();
+    s->tw4096.release(); s->tw_hi.release(); s->tw_lo.release(); s->tmp.release(); s->carry.release();
+    s->stage_in.release(); s->raw.release(); s->mag.release(); s->ext_w.release(); s->ext.release(); s->pairsum.release(); s->first_b.release(); s->points.release();
     s->ma.release(); s->maa.release(); s->fo.release(); s->scal.release();
     delete s;
 }
@@ -817,21 +850,23 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     const size_t nfN = (size_t)max_frames * N, F = (size_t)g.F;
     if (g.Ra > 1) if (int rc = s->tmp.reserve(nfN)) return rc;
     if (int rc = s->mag.reserve(nfN)) return rc;
-    s->n_avg_waves = (g.F + kAvgThreads - 1) / kAvgThreads;
-    if (int rc = s->ext_w.reserve((size_t)max_frames * s->n_avg_waves)) return rc;
+    s->n_avg_tiles = (g.F + kAvgLanes - 1) / kAvgLanes;
+    if (int rc = s->ext_w.reserve((size_t)max_frames * s->n_avg_tiles)) return rc;
+    if (int rc = s->ext.reserve(max_frames)) return rc;
     if (int rc = s->pairsum.reserve(nfN / 2)) return rc;
     if (int rc = s->first_b.reserve(max_frames)) return rc;
     if (int rc = s->points.reserve(nfN)) return rc;               // 2 * F floats per frame
     if (int rc = s->ma.reserve(2 * F)) return rc;
     if (int rc = s->maa.reserve(2 * F)) return rc;
     if (int rc = s->fo.reserve(max_frames)) return rc;
-    if (int rc = s->scal.reserve(1)) return rc;
+    if (int rc = s->scal.reserve(2)) return rc;
     if (int rc = s->carry.reserve(N)) return rc;
-    if (int rc = s->frame0.reserve(N)) return rc;
     CSDR_HIP_TRY(hipMemset(s->ma.p, 0, 2 * F * sizeof(double)));      // vector<double>::resize -> zeros (:243-257)
     CSDR_HIP_TRY(hipMemset(s->maa.p, 0, 2 * F * sizeof(double)));
     SpecScalars sc = {100.0, 100.0, 0.0, 0.0};                     // ctor :32-33
     CSDR_HIP_TRY(hipMemcpy(s->scal.p, &sc, sizeof sc, hipMemcpyHostToDevice));
+    CSDR_HIP_TRY(hipMemcpy(s->scal.p + 1, &sc, sizeof sc, hipMemcpyHostToDevice));
+    s->scal_parity = 0;
     s->carry_len = 0; s->nf_last = 0;
     s->ready = true;
     return CSDR_OK;
@@ -866,11 +901,11 @@ static int spec_run_fft(csdr_spec *s, const FrameSrc &fs, int nf, float *mag, fl
         else launch_radix<1>(c, g.Ra, fs, g.N, 1u, nf, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
         if (g.Rb > 1) {
             const int L2 = g.N / g.Ra;
-            FrameSrc sub{s->tmp.p, s->tmp.p + L2, L2};
+            FrameSrc sub{s->tmp.p, nullptr, s->tmp.p + L2, L2, 1 << 30};
             if (g.Rb <= 16) launch_radix<2>(c, g.Rb, sub, L2, (unsigned)g.Ra, nf * g.Ra, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
             else launch_radix<1>(c, g.Rb, sub, L2, (unsigned)g.Ra, nf * g.Ra, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
         }
-        FrameSrc rows{s->tmp.p, s->tmp.p + g.N, g.N};
+        FrameSrc rows{s->tmp.p, nullptr, s->tmp.p + g.N, g.N, 1 << 30};
         CSDR_LAUNCH(c, KID_FFT_ROWS, spec_fft_rows4096, dim3(g.Ra * g.Rb, nf), dim3(kFftThreads), kRowLdsPts * sizeof(float2), rows, g,
                     s->tw4096.p, mag, raw);
     }
@@ -891,7 +926,7 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
         CSDR_HIP_TRY(hipMemcpyAsync(s->stage_in.p, iq, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, st));
         x = s->stage_in.p;
     } else if ((uintptr_t)iq & 7) return fail(CSDR_EINVAL, "device IQ pointer must be 8-byte aligned");
-    FrameSrc fs{nullptr, nullptr, 0};
+    FrameSrc fs{nullptr, nullptr, nullptr, 0, 1 << 30};
     int nf = 0;
     if (mode == CSDR_SPEC_FIRST_FRAME) {
         if (block_len < N) return fail(CSDR_EUNSUPPORTED, "block_len %d < internal FFT size %d (overlap priming path :399-421 not built)", block_len, N);
@@ -901,10 +936,9 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
         nf = (int)(total / N);
         if (nf > s->max_frames) return fail(CSDR_ERANGE, "%d frames exceed max_frames %d", nf, s->max_frames);
         if (nf > 0) {
-            if (s->carry_len > 0) {
-                CSDR_LAUNCH(s->ctx, KID_SPEC_MISC, spec_assemble, dim3((N + 255) / 256), dim3(256), 0, s->carry.p, s->carry_len, x, N, s->frame0.p);
-                fs.first = s->frame0.p;
-            } else fs.first = x;
+            // frame 0 = carry ++ head of the new data (read in place, two pieces); the rest are contiguous in x
+            if (s->carry_len > 0) { fs.first = s->carry.p; fs.first2 = x; fs.split = s->carry_len; }
+            else fs.first = x;
             fs.rest = x + (N - s->carry_len); fs.stride = N;
         }
     } else return fail(CSDR_EINVAL, "mode");
@@ -912,12 +946,12 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
     s->nf_last = nf;
     if (nf > 0) {
         if (int rc = spec_run_fft(s, fs, nf, s->mag.p, nullptr)) return rc;
-        CSDR_LAUNCH(s->ctx, KID_SPEC_AVG, spec_average, dim3(s->n_avg_waves), dim3(kAvgThreads), 0, s->mag.p, nf, g, (double)s->avg_rate,
+        CSDR_LAUNCH(s->ctx, KID_SPEC_AVG, spec_average, dim3(s->n_avg_tiles), dim3(kAvgThreads), kAvgLds, s->mag.p, nf, g, (double)s->avg_rate,
                     s->ma.p, s->maa.p, s->pairsum.p, s->first_b.p, s->ext_w.p);
-        CSDR_LAUNCH(s->ctx, KID_SPEC_TRACK, spec_trackers, dim3(1), dim3(kTrackThreads), kTrackChunk * sizeof(float2), s->ext_w.p, s->n_avg_waves, nf,
-                    s->scal.p, s->fo.p);
-        CSDR_LAUNCH(s->ctx, KID_SPEC_DISPLAY, spec_display, dim3((g.F / 2 + 255) / 256, nf), dim3(256), 0, s->pairsum.p, s->first_b.p, s->fo.p, g.F,
-                    s->scale, s->points.p);
+        CSDR_LAUNCH(s->ctx, KID_SPEC_TRACK, spec_extrema, dim3(nf), dim3(256), 64, s->ext_w.p, s->n_avg_tiles, s->ext.p);
+        CSDR_LAUNCH(s->ctx, KID_SPEC_DISPLAY, spec_display, dim3((g.F / 2 + kDispThreads - 1) / kDispThreads, nf), dim3(kDispThreads), kDispLds, s->pairsum.p, s->first_b.p,
+                    s->ext.p, nf, g.F, s->scale, s->scal.p + s->scal_parity, s->scal.p + (s->scal_parity ^ 1), s->fo.p, s->points.p);
+        s->scal_parity ^= 1;
         CSDR_HIP_TRY(hipGetLastError());
     }
     if (mode == CSDR_SPEC_CONTIGUOUS) {
@@ -956,7 +990,7 @@ extern "C" int csdr_spec_fft_only(csdr_spec *s, const float *iq_host, float *out
     if (int rc = s->stage_in.reserve((size_t)N)) return rc;
     if (int rc = s->raw.reserve((size_t)N)) return rc;
     CSDR_HIP_TRY(hipMemcpyAsync(s->stage_in.p, iq_host, (size_t)N * sizeof(float2), hipMemcpyHostToDevice, st));
-    FrameSrc fs{s->stage_in.p, s->stage_in.p, 0};
+    FrameSrc fs{s->stage_in.p, nullptr, s->stage_in.p, 0, 1 << 30};
     if (int rc = spec_run_fft(s, fs, 1, nullptr, s->raw.p)) return rc;
     CSDR_HIP_TRY(hipMemcpyAsync(out_host, s->raw.p, (size_t)N * sizeof(float2), hipMemcpyDeviceToHost, st));
     CSDR_HIP_TRY(hipStreamSynchronize(st));

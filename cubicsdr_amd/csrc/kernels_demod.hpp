@@ -46,7 +46,7 @@ struct SlotCfg {                  // static per configuration, lives in HBM
     int32_t modem;
     int32_t hist_len;             // mixed-input history actually kept (cascade span of this slot, multiple of 64)
     float2 *mixhist;              // [2][hist_len]  ping-pong by SlotDyn::hist_parity
-    float2 *iq;                   // [kIqHist + cap_iq]
+    float2 *iq;                   // [2][kIqHist + cap_iq]  resampled IQ: [history | batch], ping-pong by hist_parity
     float *d;                     // [cap_iq]     unscaled demodulator output of the batch
     float *dh;                    // [2][kDHist]  scaled demodulator-output history, ping-pong
     float *audio;                 // [cap_audio]
@@ -67,7 +67,7 @@ struct SlotDyn {                  // per batch
     uint32_t abuf0;               // audio msresamp buffer_index (decimating audio path)
     uint32_t ssb_theta0;          // SSB fs/4 oscillator phase word at batch start
     int32_t hist_parity;
-    int32_t pad;
+    int32_t prev_j;               // resampled-IQ samples the previous batch produced (its tail is this batch's history)
 };
 
 struct BlockPlan { int32_t j0, q0; };   // first IQ output / first audio-arbitrary output of the block (batch-relative)
@@ -85,11 +85,15 @@ __device__ inline void nco_sincos(const float *tab, uint32_t theta, float &s, fl
     c = tab[(idx + 256u) & 1023u];
 }
 
-// closed form of the resampler loop: first output index whose phase lands at or after input K (K may be negative)
-__device__ inline int64_t resamp_first_out(int64_t K, uint32_t phase0, uint32_t step) {
+// closed form of the resampler loop: first output index whose phase lands at or after input K (K may be negative):
+// the smallest j with j * step >= K 2^24 - phase0.  |lim| < 2^53, so a double quotient is within one of the answer
+// and two integer corrections make it exact (a 64-bit integer division costs several hundred cycles on the device).
+__host__ __device__ inline int64_t resamp_first_out(int64_t K, uint32_t phase0, uint32_t step) {
     const int64_t lim = K * (int64_t)(1 << 24) - (int64_t)phase0;   // need j*step >= lim
-    if (lim <= 0) return -((-lim) / (int64_t)step);                  // ceil(lim / step) for lim <= 0
-    return (lim + step - 1) / step;
+    int64_t j = (int64_t)((double)lim / (double)step);
+    while (j * (int64_t)step < lim) ++j;
+    while ((j - 1) * (int64_t)step >= lim) --j;
+    return j;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -112,8 +116,8 @@ __host__ __device__ inline size_t fe_lds_bytes(int S) {
 // two adjacent stream samples (rel, rel + 1): batch samples come raw from the channel row, samples before the batch
 // come (already mixed) from the slot's history; positions outside both are zero.
 __device__ inline float4 fe_fetch_pair(const float2 *__restrict__ chan, const float2 *__restrict__ hist, int hist_len,
-                                       int64_t rel, int64_t total) {
-    if (rel >= 0 && rel + 1 < total) {
+                                       int64_t rel, int64_t total, bool inside) {
+    if (inside || (rel >= 0 && rel + 1 < total)) {     // `inside` is chunk-uniform: the whole chunk lies in the batch
         const f4u v = *reinterpret_cast<const f4u *>(chan + rel);
         return make_float4(v.x, v.y, v.z, v.w);
     }
@@ -135,21 +139,34 @@ __device__ inline float2 fe_mix(float2 x, int64_t rel, const SlotDyn &dyn, const
 }
 
 // one half-band stage through LDS:  y[k] = O[k - m] + sum_{j<m} h[j] (E[k - j] + E[k - (2m-1) + j])
+// Each thread forms the two adjacent outputs k = 2t, 2t + 1 from E[2t - 2m .. 2t + 1] (m + 1 aligned 16-byte reads,
+// lanes contiguous: conflict-free) and O[2t - m], O[2t - m + 1]; y[2t] goes to the next stage's even array and
+// y[2t + 1] to its odd array at index t (contiguous 8-byte writes, no lane divergence).
 template <int M>
 __device__ inline void fe_stage_lds(const float2 *__restrict__ Ein, const float2 *__restrict__ Oin, const float *h, int cnt, float zeta,
                                     bool to_z, float2 *__restrict__ outE, float2 *__restrict__ outO, float2 *__restrict__ outZ) {
-    for (int k = threadIdx.x; k < cnt; k += kFeThreads) {
-        const float2 d = Oin[k - M];
-        float ar = d.x, ai = d.y;
+    for (int t = threadIdx.x; 2 * t < cnt; t += kFeThreads) {
+        float2 ev[2 * M + 2];                               // ev[i] = E[2t - 2M + i]
+        const float4 *e4 = reinterpret_cast<const float4 *>(Ein + 2 * t - 2 * M);
+#pragma unroll
+        for (int i = 0; i <= M; ++i) { const float4 v = e4[i]; ev[2 * i] = make_float2(v.x, v.y); ev[2 * i + 1] = make_float2(v.z, v.w); }
+        float2 o0, o1;
+        if (M % 2 == 0) { const float4 v = *reinterpret_cast<const float4 *>(Oin + 2 * t - M); o0 = make_float2(v.x, v.y); o1 = make_float2(v.z, v.w); }
+        else { o0 = Oin[2 * t - M]; o1 = Oin[2 * t - M + 1]; }
+        float a0r = o0.x, a0i = o0.y, a1r = o1.x, a1i = o1.y;
 #pragma unroll
         for (int j = 0; j < M; ++j) {
             const float hj = h[j];
-            const float2 p = Ein[k - j], q = Ein[k - (2 * M - 1) + j];
-            ar = fmaf(hj, p.x + q.x, ar); ai = fmaf(hj, p.y + q.y, ai);
+            a0r = fmaf(hj, ev[2 * M - j].x + ev[1 + j].x, a0r); a0i = fmaf(hj, ev[2 * M - j].y + ev[1 + j].y, a0i);
+            a1r = fmaf(hj, ev[2 * M + 1 - j].x + ev[2 + j].x, a1r); a1i = fmaf(hj, ev[2 * M + 1 - j].y + ev[2 + j].y, a1i);
         }
-        if (to_z) outZ[k] = make_float2(ar * zeta, ai * zeta);
-        else if (k & 1) outO[k >> 1] = make_float2(ar, ai);
-        else outE[k >> 1] = make_float2(ar, ai);
+        if (to_z) {
+            outZ[2 * t] = make_float2(a0r * zeta, a0i * zeta);
+            if (2 * t + 1 < cnt) outZ[2 * t + 1] = make_float2(a1r * zeta, a1i * zeta);
+        } else {
+            outE[t] = make_float2(a0r, a0i);
+            outO[t] = make_float2(a1r, a1i);             // cnt is even whenever another stage follows
+        }
     }
 }
 __device__ inline void fe_stage_any(int m, const float2 *__restrict__ Ein, const float2 *__restrict__ Oin, const float *h, int cnt, float zeta,
@@ -185,6 +202,13 @@ __global__ __launch_bounds__(kFeThreads, 4) void demod_frontend(
     const float2 *__restrict__ chan = chan_base + (int64_t)dyn.chan * chan_stride;
     const float2 *__restrict__ hist = cfg.mixhist + (size_t)dyn.hist_parity * hist_len;
     const float *__restrict__ arms = arms_all + (size_t)cfg.rs_iq.arms_idx * kArms * kArmTaps;
+    const size_t iq_stride = (size_t)kIqHist + cfg.cap_iq;
+    float2 *__restrict__ iq_cur = cfg.iq + (size_t)dyn.hist_parity * iq_stride;
+    if (part == 0 && tid < kIqHist) {
+        // resampled-IQ history of this batch = the last kIqHist samples of (previous history ++ previous batch)
+        const float2 *iq_prev = cfg.iq + (size_t)(dyn.hist_parity ^ 1) * iq_stride;
+        iq_cur[tid] = iq_prev[dyn.prev_j + tid];
+    }
 
     const int alen = fe_arr_len(S);
     float2 *LE = reinterpret_cast<float2 *>(smem);
@@ -192,6 +216,11 @@ __global__ __launch_bounds__(kFeThreads, 4) void demod_frontend(
     float2 *LZ = LO + alen;
     float *tab = reinterpret_cast<float *>(LZ + fe_z_len(S));
     float *hb = tab + 1024;
+    unsigned mcode = 0;                                // 2 bits per stage: 0 -> m = 3, 1 -> 5, 2 -> 10, 3 -> anything else
+    for (int e = 0; e < S; ++e) {
+        const int me = cfg.rs_iq.m_x[e];
+        mcode |= (unsigned)(me == 3 ? 0 : me == 5 ? 1 : me == 10 ? 2 : 3) << (2 * e);
+    }
 
     for (int i = tid; i < 1024; i += kFeThreads) tab[i] = sintab[i];
     for (int i = tid; i < kMaxHb * kHbMaxM; i += kFeThreads) hb[i] = cfg.rs_iq.h_x[i / kHbMaxM][i % kHbMaxM];
@@ -217,11 +246,12 @@ __global__ __launch_bounds__(kFeThreads, 4) void demod_frontend(
     {
         const int64_t rel0 = u_lo - (int64_t)dyn.buf0;
         const int n = (int)min((int64_t)kFeChunk, u_stop - u_lo);
+        const bool inside = rel0 >= 0 && rel0 + kFeChunk <= total;
 #pragma unroll
         for (int q = 0; q < kFePairs; ++q) {
             const int p = tid + q * kFeThreads;
             pf[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (2 * p < n) pf[q] = fe_fetch_pair(chan, hist, hist_len, rel0 + 2 * p, total);
+            if (2 * p < n) pf[q] = fe_fetch_pair(chan, hist, hist_len, rel0 + 2 * p, total, inside);
         }
     }
     __syncthreads();
@@ -241,47 +271,71 @@ __global__ __launch_bounds__(kFeThreads, 4) void demod_frontend(
                 else { LE[kFeTail + p] = a; LO[kFeTail + p] = b; }
             }
         }
+        // arbitrary-resampler outputs whose newest input falls in this chunk: fetch their filter arms NOW (before the
+        // prefetch below: vector-memory waits retire in order, so the arms must not queue behind the next chunk's loads)
+        const int64_t kz0 = uc >> S;
+        const int cz = n >> S;
+        int64_t ja = resamp_first_out(kz0, dyn.phase0, step), jb = resamp_first_out(kz0 + cz, dyn.phase0, step);
+        if (ja < j0) ja = j0;
+        if (jb > j1) jb = j1;
+        const int64_t jmine = ja + tid;                          // first (for S >= 3: only) output of this thread in the chunk
+        float2 hv[kArmTaps / 2];
+        int kj = 0;
+        if (jmine < jb) {
+            const int64_t Pj = (int64_t)dyn.phase0 + jmine * (int64_t)step;
+            kj = (int)((Pj >> 24) - kz0);
+            const int arm = (int)((Pj & 0xFFFFFF) >> 16);
+            const float2 *h2 = reinterpret_cast<const float2 *>(arms + arm * kArmTaps);
+#pragma unroll
+            for (int t = 0; t < kArmTaps / 2; ++t) hv[t] = h2[t];
+        }
         // prefetch the next chunk while this one runs through the cascade
         if (uc + kFeChunk < u_stop) {
             const int64_t un = uc + kFeChunk;
             const int nn = (int)min((int64_t)kFeChunk, u_stop - un);
+            const int64_t reln = un - (int64_t)dyn.buf0;
+            const bool inside = reln >= 0 && reln + kFeChunk <= total;
 #pragma unroll
             for (int q = 0; q < kFePairs; ++q) {
                 const int p = tid + q * kFeThreads;
-                if (2 * p < nn) pf[q] = fe_fetch_pair(chan, hist, hist_len, un - (int64_t)dyn.buf0 + 2 * p, total);
+                if (2 * p < nn) pf[q] = fe_fetch_pair(chan, hist, hist_len, reln + 2 * p, total, inside);
             }
         }
         __syncthreads();
         int cnt = n;
         for (int e = 0; e < S; ++e) {
             cnt >>= 1;
-            const int me = cfg.rs_iq.m_x[e];
+            const unsigned mc = (mcode >> (2 * e)) & 3u;
             const float2 *Ein = LE + fe_off(e) + kFeTail, *Oin = LO + fe_off(e) + kFeTail;
             const float *he = hb + e * kHbMaxM;
             const bool tz = (e == S - 1);
             float2 *oE = LE + (tz ? 0 : fe_off(e + 1) + kFeTail), *oO = LO + (tz ? 0 : fe_off(e + 1) + kFeTail), *oZ = LZ + kFeZTail;
-            if (me == 3) fe_stage_lds<3>(Ein, Oin, he, cnt, zeta, tz, oE, oO, oZ);
-            else if (me == 5) fe_stage_lds<5>(Ein, Oin, he, cnt, zeta, tz, oE, oO, oZ);
-            else if (me == 10) fe_stage_lds<10>(Ein, Oin, he, cnt, zeta, tz, oE, oO, oZ);
-            else fe_stage_any(me, Ein, Oin, he, cnt, zeta, tz, oE, oO, oZ);
+            if (mc == 0) fe_stage_lds<3>(Ein, Oin, he, cnt, zeta, tz, oE, oO, oZ);
+            else if (mc == 1) fe_stage_lds<5>(Ein, Oin, he, cnt, zeta, tz, oE, oO, oZ);
+            else fe_stage_any(mc == 2 ? 10 : cfg.rs_iq.m_x[e], Ein, Oin, he, cnt, zeta, tz, oE, oO, oZ);   // m = 10 runs at the lowest rate
             __syncthreads();
         }
-        // arbitrary resampler on Z for outputs whose input index falls in this chunk
-        const int64_t kz0 = uc >> S;
-        const int cz = n >> S;
-        int64_t ja = resamp_first_out(kz0, dyn.phase0, step), jb = resamp_first_out(kz0 + cz, dyn.phase0, step);
-        if (ja < j0) ja = j0;
-        if (jb > j1) jb = j1;
-        for (int64_t j = ja + tid; j < jb; j += kFeThreads) {
-            const int64_t Pj = (int64_t)dyn.phase0 + j * (int64_t)step;
-            const int kj = (int)((Pj >> 24) - kz0);
-            const int arm = (int)((Pj & 0xFFFFFF) >> 16);
-            const float *h = arms + arm * kArmTaps;
+        // arbitrary resampler on Z
+        if (jmine < jb) {
             const float2 *z = LZ + kFeZTail + kj - (kArmTaps - 1);
             float ar = 0.f, ai = 0.f;
 #pragma unroll
+            for (int t = 0; t < kArmTaps / 2; ++t) {
+                ar = fmaf(hv[t].x, z[2 * t].x, ar); ai = fmaf(hv[t].x, z[2 * t].y, ai);
+                ar = fmaf(hv[t].y, z[2 * t + 1].x, ar); ai = fmaf(hv[t].y, z[2 * t + 1].y, ai);
+            }
+            iq_cur[kIqHist + jmine] = make_float2(ar, ai);
+        }
+        for (int64_t j = jmine + kFeThreads; j < jb; j += kFeThreads) {      // shallow cascades (S <= 2) only
+            const int64_t Pj = (int64_t)dyn.phase0 + j * (int64_t)step;
+            const int kq = (int)((Pj >> 24) - kz0);
+            const int arm = (int)((Pj & 0xFFFFFF) >> 16);
+            const float *h = arms + arm * kArmTaps;
+            const float2 *z = LZ + kFeZTail + kq - (kArmTaps - 1);
+            float ar = 0.f, ai = 0.f;
+#pragma unroll
             for (int t = 0; t < kArmTaps; ++t) { ar = fmaf(h[t], z[t].x, ar); ai = fmaf(h[t], z[t].y, ai); }
-            cfg.iq[kIqHist + j] = make_float2(ar, ai);
+            iq_cur[kIqHist + j] = make_float2(ar, ai);
         }
         if (uc + kFeChunk < u_stop) {      // another chunk follows: carry tails to the front of every buffer
             __syncthreads();
@@ -327,9 +381,245 @@ __global__ __launch_bounds__(kFeThreads, 4) void demod_frontend(
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// D2a: modem core -> unscaled demodulator output d[j] for the block, block maximum (auto-gain input) and the
-// IQ-based signal-level sum.   grid = (slot, block), 256 threads
-//   NBFM/FM : d = atan2f(Im(x conj x'), Re(x conj x')) / (2 pi kf), kf = 0.5      (freqdem, ModemNBFM.cpp:36)
+// D1s: the same arithmetic, specialised for the half-band pattern every msresamp_crcf of the reference has with
+// As = 60 dB: execution order m = 3, ..., 3, 5, 10 (the two lowest-rate stages are m = 5 and m = 10), S stages.
+// Compile-time stage sizes (every chunk is full: the warm-up is lengthened to a whole number of chunks), S + 1
+// barriers per chunk (the per-stage tails move to the front of their arrays while the next stage computes), the sine
+// table carries a 256-entry wrap so sin/cos come from one two-address LDS read, and the carried streams (mixed-input
+// history, resampled-IQ history) are written by one extra workgroup per demodulator (blockIdx.x == P).
+// grid = (P + 1, slots of this S).  Bit-identical to demod_frontend.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kFeTabLen = 1024 + 256;
+template <int CH>
+__host__ __device__ constexpr int fes_off(int e) { return e * kFeTail + CH - (CH >> e); }
+template <int S, int CH>
+__host__ __device__ constexpr size_t fes_lds_bytes() {
+    return (size_t)(2 * (S * kFeTail + CH - (CH >> S)) + kFeZTail + (CH >> S)) * sizeof(float2) + kFeTabLen * sizeof(float) +
+           (S * kHbMaxM) * sizeof(float);
+}
+constexpr int fes_m(int S, int e) { return e == S - 1 ? 10 : (e == S - 2 ? 5 : 3); }
+
+// CNT outputs of stage `E` (compile-time), two per thread
+template <int M, int CNT>
+__device__ inline void fes_stage_pairs(const float2 *__restrict__ Ein, const float2 *__restrict__ Oin, const float *__restrict__ h,
+                                       float2 *__restrict__ outE, float2 *__restrict__ outO) {
+    constexpr int NP = CNT / 2;
+#pragma unroll
+    for (int t0 = 0; t0 < NP; t0 += kFeThreads) {
+        const int t = t0 + (int)threadIdx.x;
+        if (NP >= kFeThreads || t < NP) {
+            float2 ev[2 * M + 2];                               // ev[i] = E[2t - 2M + i]
+            const float4 *e4 = reinterpret_cast<const float4 *>(Ein + 2 * t - 2 * M);
+#pragma unroll
+            for (int i = 0; i <= M; ++i) { const float4 v = e4[i]; ev[2 * i] = make_float2(v.x, v.y); ev[2 * i + 1] = make_float2(v.z, v.w); }
+            float2 o0, o1;
+            if (M % 2 == 0) { const float4 v = *reinterpret_cast<const float4 *>(Oin + 2 * t - M); o0 = make_float2(v.x, v.y); o1 = make_float2(v.z, v.w); }
+            else { o0 = Oin[2 * t - M]; o1 = Oin[2 * t - M + 1]; }
+            float a0r = o0.x, a0i = o0.y, a1r = o1.x, a1i = o1.y;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                const float hj = h[j];
+                a0r = fmaf(hj, ev[2 * M - j].x + ev[1 + j].x, a0r); a0i = fmaf(hj, ev[2 * M - j].y + ev[1 + j].y, a0i);
+                a1r = fmaf(hj, ev[2 * M + 1 - j].x + ev[2 + j].x, a1r); a1i = fmaf(hj, ev[2 * M + 1 - j].y + ev[2 + j].y, a1i);
+            }
+            outE[t] = make_float2(a0r, a0i);
+            outO[t] = make_float2(a1r, a1i);
+        }
+    }
+}
+// last stage (m = 10, CNT <= 256 outputs, one per thread) -> Z, scaled by 2^-S
+template <int CNT>
+__device__ inline void fes_stage_last(const float2 *__restrict__ Ein, const float2 *__restrict__ Oin, const float *__restrict__ h, float zeta,
+                                      float2 *__restrict__ outZ) {
+    constexpr int M = 10;
+    const int k = threadIdx.x;
+    if (k < CNT) {
+        const float2 d = Oin[k - M];
+        float ar = d.x, ai = d.y;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            const float hj = h[j];
+            const float2 p = Ein[k - j], q = Ein[k - (2 * M - 1) + j];
+            ar = fmaf(hj, p.x + q.x, ar); ai = fmaf(hj, p.y + q.y, ai);
+        }
+        outZ[k] = make_float2(ar * zeta, ai * zeta);
+    }
+}
+// move the last kFeTail entries of stage region E (data count CNT >= kFeTail) to its front; threads 256-48 .. 255
+template <int CNT>
+__device__ inline void fes_carry_tail(float2 *__restrict__ LE, float2 *__restrict__ LO, int off) {
+    const int c = (int)threadIdx.x - (kFeThreads - 2 * kFeTail);
+    if (c >= 0) {
+        float2 *arr = c < kFeTail ? LE : LO;
+        const int k = c < kFeTail ? c : c - kFeTail;
+        arr[off + k] = arr[off + CNT + k];
+    }
+}
+
+template <int S, int CH, int E>
+struct FesStages {
+    static __device__ inline void run(float2 *LE, float2 *LO, float2 *LZ, const float *hb, float zeta) {
+        constexpr int CNT = CH >> (E + 1);                       // outputs of stage E
+        constexpr int M = fes_m(S, E);
+        const float2 *Ein = LE + fes_off<CH>(E) + kFeTail, *Oin = LO + fes_off<CH>(E) + kFeTail;
+        if constexpr (E == S - 1) fes_stage_last<CNT>(Ein, Oin, hb + E * kHbMaxM, zeta, LZ + kFeZTail);
+        else fes_stage_pairs<M, CNT>(Ein, Oin, hb + E * kHbMaxM, LE + fes_off<CH>(E + 1) + kFeTail, LO + fes_off<CH>(E + 1) + kFeTail);
+        // the tail of the PREVIOUS stage's input region is free to move now (its consumer finished at the last barrier)
+        if constexpr (E >= 1) fes_carry_tail<(CH >> E)>(LE, LO, fes_off<CH>(E - 1));
+        __syncthreads();
+        FesStages<S, CH, E + 1>::run(LE, LO, LZ, hb, zeta);
+    }
+};
+template <int S, int CH>
+struct FesStages<S, CH, S> {
+    static __device__ inline void run(float2 *, float2 *, float2 *, const float *, float) {}
+};
+
+template <int S, int CH>
+__global__ __launch_bounds__(kFeThreads, 4) void demod_frontend_s(
+    const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
+    const float2 *__restrict__ chan_base, int64_t chan_stride, int64_t total /* batch samples per channel */,
+    const float *__restrict__ arms_all, const float *__restrict__ sintab) {
+    static_assert(S >= 2 && (CH >> S) >= 32 && (CH >> S) <= kFeThreads && CH % (2 * kFeThreads) == 0, "chunk does not suit this cascade depth");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NPF = CH / 2 / kFeThreads;
+    constexpr int CZ = CH >> S;                                  // half-band chain outputs per chunk
+    constexpr int ALEN = S * kFeTail + CH - (CH >> S);
+
+    const int slot = slot_list[blockIdx.y];
+    const int part = blockIdx.x, P = (int)gridDim.x - 1;
+    const SlotCfg &cfg = cfgs[slot];
+    const SlotDyn dyn = dyns[slot];
+    const int tid = threadIdx.x;
+    const uint32_t step = cfg.rs_iq.step;
+    const int hist_len = cfg.hist_len;
+    const float2 *__restrict__ chan = chan_base + (int64_t)dyn.chan * chan_stride;
+    const float2 *__restrict__ hist = cfg.mixhist + (size_t)dyn.hist_parity * hist_len;
+    const size_t iq_stride = (size_t)kIqHist + cfg.cap_iq;
+    float2 *__restrict__ iq_cur = cfg.iq + (size_t)dyn.hist_parity * iq_stride;
+    const float sgn = dyn.mixdir < 0 ? -1.0f : 1.0f;             // x (c + j sgn s)
+
+    float2 *LE = reinterpret_cast<float2 *>(smem);
+    float2 *LO = LE + ALEN;
+    float2 *LZ = LO + ALEN;
+    float *tab = reinterpret_cast<float *>(LZ + kFeZTail + CZ);
+    float *hb = tab + kFeTabLen;
+    for (int i = tid; i < kFeTabLen; i += kFeThreads) tab[i] = sintab[i & 1023];
+
+    if (part == P) {
+        // ---- carried streams of this demodulator (one workgroup): resampled-IQ history and mixed-input history
+        if (tid < kIqHist) {
+            const float2 *iq_prev = cfg.iq + (size_t)(dyn.hist_parity ^ 1) * iq_stride;
+            iq_cur[tid] = iq_prev[dyn.prev_j + tid];             // last kIqHist samples of (previous history ++ previous batch)
+        }
+        __syncthreads();
+        float2 *hnew = cfg.mixhist + (size_t)(dyn.hist_parity ^ 1) * hist_len;
+        for (int i = tid; i < hist_len; i += kFeThreads) {
+            const int64_t rel = total - hist_len + i;
+            float2 v = make_float2(0.f, 0.f);
+            if (rel >= 0) v = fe_mix(chan[rel], rel, dyn, tab);
+            else if (rel >= -(int64_t)hist_len) v = hist[hist_len + rel];
+            hnew[i] = v;
+        }
+        return;
+    }
+
+    const float *__restrict__ arms = arms_all + (size_t)cfg.rs_iq.arms_idx * kArms * kArmTaps;
+    for (int i = tid; i < S * kHbMaxM; i += kFeThreads) hb[i] = cfg.rs_iq.h_x[i / kHbMaxM][i % kHbMaxM];
+    for (int i = tid; i < S * kFeTail; i += kFeThreads) {
+        const int e = i / kFeTail, k = i % kFeTail;
+        LE[fes_off<CH>(e) + k] = make_float2(0.f, 0.f);
+        LO[fes_off<CH>(e) + k] = make_float2(0.f, 0.f);
+    }
+    if (tid < kFeZTail) LZ[tid] = make_float2(0.f, 0.f);
+
+    // --- index ranges (u-space: u = batch-relative input index + buf0; half-band output k covers u in [k 2^S, (k+1) 2^S))
+    const int64_t K1 = ((int64_t)dyn.buf0 + total) >> S;
+    const int64_t Ka = (K1 * part) / P, Kb = (K1 * (part + 1)) / P;
+    const int64_t j0 = resamp_first_out(Ka, dyn.phase0, step), j1 = resamp_first_out(Kb, dyn.phase0, step);
+    int64_t lo = Ka - (kArmTaps - 1);
+#pragma unroll
+    for (int e = S - 1; e >= 0; --e) lo = 2 * lo - (4 * fes_m(S, e) - 2);
+    const int64_t u_stop = Kb << S;
+    int64_t u_lo = (lo >> S) << S;                               // floor to a multiple of 2^S (also for negatives)
+    u_lo = u_stop - ((u_stop - u_lo + CH - 1) / CH) * CH;        // ... and a whole number of chunks before u_stop
+    const float zeta = 1.0f / (float)(1 << S);
+
+    float4 pf[NPF];
+    {
+        const int64_t rel0 = u_lo - (int64_t)dyn.buf0;
+        const bool inside = rel0 >= 0 && rel0 + CH <= total;
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) pf[q] = fe_fetch_pair(chan, hist, hist_len, rel0 + 2 * (tid + q * kFeThreads), total, inside);
+    }
+    int64_t ja = resamp_first_out(u_lo >> S, dyn.phase0, step);
+    __syncthreads();
+
+    for (int64_t uc = u_lo; uc < u_stop; uc += CH) {
+        const int64_t rel0 = uc - (int64_t)dyn.buf0;          // batch-relative index of the chunk's first input
+        // ---- mix the prefetched chunk into the stage-0 arrays
+        {
+            const bool do_mix = dyn.mixdir != 0;
+            const uint32_t th0 = dyn.theta0 + (uint32_t)rel0 * dyn.dtheta;
+#pragma unroll
+            for (int q = 0; q < NPF; ++q) {
+                const int p = tid + q * kFeThreads;
+                float2 a = make_float2(pf[q].x, pf[q].y), b = make_float2(pf[q].z, pf[q].w);
+                if (do_mix) {
+                    const uint32_t tha = th0 + (uint32_t)(2 * p) * dyn.dtheta, thb = tha + dyn.dtheta;
+                    const uint32_t ia = (tha + (1u << 21)) >> 22, ib = (thb + (1u << 21)) >> 22;      // 0 .. 1023
+                    const float sa = tab[ia] * sgn, ca = tab[ia + 256], sb = tab[ib] * sgn, cb = tab[ib + 256];
+                    // samples before the batch (rel < 0) come from the history and are mixed already
+                    if (rel0 + 2 * p >= 0) a = make_float2(fmaf(a.x, ca, -(a.y * sa)), fmaf(a.y, ca, a.x * sa));
+                    if (rel0 + 2 * p + 1 >= 0) b = make_float2(fmaf(b.x, cb, -(b.y * sb)), fmaf(b.y, cb, b.x * sb));
+                }
+                LE[kFeTail + p] = a; LO[kFeTail + p] = b;
+            }
+        }
+        // ---- resampler outputs of this chunk: fetch their filter arms before the prefetch (vector-memory waits retire in order)
+        const int64_t kz0 = uc >> S;
+        int64_t jb = resamp_first_out(kz0 + CZ, dyn.phase0, step);
+        const int64_t jlo = ja < j0 ? j0 : ja, jhi = jb > j1 ? j1 : jb;
+        ja = jb;
+        const int64_t jmine = jlo + tid;                         // CZ <= 256 half-band outputs, rate < 1: at most one per thread
+        float2 hv[kArmTaps / 2];
+        int kj = 0;
+        if (jmine < jhi) {
+            const int64_t Pj = (int64_t)dyn.phase0 + jmine * (int64_t)step;
+            kj = (int)((Pj >> 24) - kz0);
+            const int arm = (int)((Pj & 0xFFFFFF) >> 16);
+            const float2 *h2 = reinterpret_cast<const float2 *>(arms + arm * kArmTaps);
+#pragma unroll
+            for (int t = 0; t < kArmTaps / 2; ++t) hv[t] = h2[t];
+        }
+        if (uc + CH < u_stop) {
+            const int64_t reln = rel0 + CH;
+            const bool inside = reln >= 0 && reln + CH <= total;
+#pragma unroll
+            for (int q = 0; q < NPF; ++q) pf[q] = fe_fetch_pair(chan, hist, hist_len, reln + 2 * (tid + q * kFeThreads), total, inside);
+        }
+        __syncthreads();
+        // the previous chunk's resampler is done (barrier above): its Z tail may move to the front now
+        if (uc > u_lo && tid >= kFeThreads - kFeZTail) { const int k = tid - (kFeThreads - kFeZTail); LZ[k] = LZ[CZ + k]; }
+        FesStages<S, CH, 0>::run(LE, LO, LZ, hb, zeta);
+        // ---- tail of the last stage's input region, then the arbitrary resampler on Z
+        fes_carry_tail<(CH >> S)>(LE, LO, fes_off<CH>(S - 1));
+        if (jmine < jhi) {
+            const float2 *z = LZ + kFeZTail + kj - (kArmTaps - 1);
+            float ar = 0.f, ai = 0.f;
+#pragma unroll
+            for (int t = 0; t < kArmTaps / 2; ++t) {
+                ar = fmaf(hv[t].x, z[2 * t].x, ar); ai = fmaf(hv[t].x, z[2 * t].y, ai);
+                ar = fmaf(hv[t].y, z[2 * t + 1].x, ar); ai = fmaf(hv[t].y, z[2 * t + 1].y, ai);
+            }
+            iq_cur[kIqHist + jmine] = make_float2(ar, ai);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// D2a: modem core of the auto-gain modems -> unscaled demodulator output d[j] for the block and the block maximum
+// (auto-gain input).   grid = (auto-gain slot, block), 256 threads
 //   AM      : d = FIR51(|x|)                                                     (ModemAM.cpp:41-47)
 //   USB/LSB : fs/4 shift, 3 biquads, shift back, Hilbert c2r, keep upper/lower    (ModemUSB.cpp:54-61)
 // ------------------------------------------------------------------------------------------------------------
@@ -381,24 +671,14 @@ __global__ __launch_bounds__(kModemThreads) void demod_modem(
     const SlotDyn dyn = dyns[slot];
     const BlockPlan *pl = plans + (size_t)slot * (NB + 1);
     const int j0 = pl[b].j0, j1 = pl[b + 1].j0, n = j1 - j0;
-    const float2 *iq = cfg.iq + kIqHist;      // iq[j] valid for j >= -kIqHist
+    const float2 *iq = cfg.iq + (size_t)dyn.hist_parity * ((size_t)kIqHist + cfg.cap_iq) + kIqHist;   // iq[j] valid for j >= -kIqHist
     float *d = cfg.d;
     float lmax = 0.0f;                         // aOutputCeil starts at 0 each block (ModemAnalog.cpp:73)
     double lsum = 0.0;
     int lcount = 0;
 
     if (cfg.modem == CSDR_MODEM_NBFM || cfg.modem == CSDR_MODEM_FM) {
-        const float ref = 1.0f / (2.0f * 3.14159265358979323846f * 0.5f);
-        for (int i = tid; i < n; i += kModemThreads) {
-            const int j = j0 + i;
-            const float2 x = iq[j], p = iq[j - 1];
-            const float re = x.x * p.x + x.y * p.y, im = x.y * p.x - x.x * p.y;
-            const float v = atan2f(im, re) * ref;
-            d[j] = v;
-            lmax = fmaxf(lmax, v);
-            lsum += sqrt((double)x.x * (double)x.x + (double)x.y * (double)x.y);   // abMagnitude (DemodulatorThread.cpp:49-57)
-        }
-        lcount = n;
+        return;                                 // freqdem needs no block-wide maximum: done inside demod_audio_interp
     } else if (cfg.modem == CSDR_MODEM_AM) {
         const int halo = kAmTaps - 1;
         for (int i = tid; i < n + halo; i += kModemThreads) {
@@ -508,6 +788,8 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     const int n_audio = (int)(A1 - A0);
     const float *arms = arms_all + (size_t)au.arms_idx * kArms * kArmTaps;
     const bool autogain = !(cfg.modem == CSDR_MODEM_NBFM || cfg.modem == CSDR_MODEM_FM);
+    const float2 *iq = cfg.iq + (size_t)dyn.hist_parity * ((size_t)kIqHist + cfg.cap_iq) + kIqHist;   // iq[j], j >= -kIqHist
+    const float fm_ref = 1.0f / (2.0f * 3.14159265358979323846f * 0.5f);   // freqdem_create(kf = 0.5): 1 / (2 pi kf)
     const float *agc_in = cfg.agc + 4 * dyn.hist_parity;
     const float *dh_in = cfg.dh + (size_t)kDHist * dyn.hist_parity;
 
@@ -537,6 +819,19 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     const int64_t jhi = nv > 0 ? (((int64_t)dyn.aphase0 + (hi[0] - 1) * (int64_t)au.step) >> 24) + 1 : jlo;
     const int nwin = (int)(jhi - jlo);
     const int jb0 = pl[b].j0, jbp = b > 0 ? pl[b - 1].j0 : 0;
+    if (!autogain) {
+        // NBFM / FM (ModemNBFM.cpp:36, ModemFM.cpp:36): m[j] = atan2f(Im(x_j conj x_{j-1}), Re(..)) / (2 pi kf), gain 1.
+        // Formed here from the resampled IQ stream (history included: x_{-1} of a fresh demodulator is 0 -> m = 0).
+        for (int i = tid; i < nwin; i += kModemThreads) {
+            const int64_t j = jlo + i;
+            float x = 0.f;
+            if (j >= -(int64_t)(kIqHist - 1)) {
+                const float2 c = iq[j], p = iq[j - 1];
+                x = atan2f(c.y * p.x - c.x * p.y, c.x * p.x + c.y * p.y) * fm_ref;
+            }
+            s_d[i] = x;
+        }
+    } else
     for (int i = tid; i < nwin; i += kModemThreads) {
         const int64_t j = jlo + i;
         float x;
@@ -548,7 +843,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
             int bb = b - 1;
             while (bb > 0 && j < pl[bb].j0) --bb;
             float c2 = agc_in[0], m2 = agc_in[1], mm2 = agc_in[2], gg = 1.0f;
-            if (autogain) for (int q = 0; q <= bb; ++q) { m2 = m2 + (c2 - m2) * 0.025f; mm2 = mm2 + (m2 - mm2) * 0.025f; c2 = cfg.blockmax[q]; gg = 0.5f / mm2; }
+            for (int q = 0; q <= bb; ++q) { m2 = m2 + (c2 - m2) * 0.025f; mm2 = mm2 + (m2 - mm2) * 0.025f; c2 = cfg.blockmax[q]; gg = 0.5f / mm2; }
             x = cfg.d[j] * gg;
         }
         s_d[i] = x;
@@ -589,7 +884,8 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
         __syncthreads();
         float *t = src; src = dst; dst = t;
     }
-    // 3. write audio, peak, level
+    // 3. write audio, peak, level (audio-based for the useSignalOutput modems, IQ-based |x| sum for NBFM / FM:
+    //    DemodulatorThread.cpp:142-152, abMagnitude :49-57)
     float lpk = 0.f;
     double lsum = 0.0;
     const int aoff = (int)A0;
@@ -597,30 +893,31 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
         const float v = src[i];
         cfg.audio[aoff + i] = v;
         lpk = fmaxf(lpk, fabsf(v));
-        lsum += (double)fabsf(v);
+        if (autogain) lsum += (double)fabsf(v);
     }
+    const int n_iq = pl[b + 1].j0 - jb0;
+    if (!autogain)
+        for (int i = tid; i < n_iq; i += kModemThreads) {
+            const float2 x = iq[jb0 + i];
+            lsum += sqrt((double)x.x * (double)x.x + (double)x.y * (double)x.y);
+        }
     const float pk = block_max_float(lpk, s_redf);
     const double sm = block_sum_double(lsum, s_red);
     if (tid == 0) {
         cfg.bout[b].audio_peak = pk;
-        if (autogain) {   // useSignalOutput(true) modems
-            cfg.bout[b].level_accum = sm;
-            cfg.bout[b].level_count = n_audio;
-        }
+        cfg.bout[b].level_accum = sm;
+        cfg.bout[b].level_count = autogain ? n_audio : n_iq;
     }
-    // 4. last block: publish the auto-gain state and the stream tails for the next batch (other parity)
-    if (b == NB - 1) {
+    // 4. last block of an auto-gain modem: publish the gain state and the scaled demodulator tail (other parity)
+    if (b == NB - 1 && autogain) {
         if (tid == 0) {
             float *agc_out = cfg.agc + 4 * (dyn.hist_parity ^ 1);
             agc_out[0] = ceil_; agc_out[1] = ma; agc_out[2] = maa;
         }
         const int J = pl[NB].j0;
-        // iq: new history = stream positions [J - kIqHist, J) (stream index j maps to cfg.iq[kIqHist + j]); read, sync, write
-        float2 v = make_float2(0.f, 0.f);
-        if (tid < kIqHist) v = cfg.iq[J + tid];
-        float dv = 0.f;
         if (tid < kDHist) {
             const int j = J - kDHist + tid;
+            float dv;
             if (j < 0) dv = dh_in[kDHist + j];
             else if (j >= jb0) dv = cfg.d[j] * g_cur;
             else if (j >= jbp) dv = cfg.d[j] * g_prev;
@@ -628,13 +925,11 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
                 int bb = b - 1;
                 while (bb > 0 && j < pl[bb].j0) --bb;
                 float c2 = agc_in[0], m2 = agc_in[1], mm2 = agc_in[2], gg = 1.0f;
-                if (autogain) for (int q = 0; q <= bb; ++q) { m2 = m2 + (c2 - m2) * 0.025f; mm2 = mm2 + (m2 - mm2) * 0.025f; c2 = cfg.blockmax[q]; gg = 0.5f / mm2; }
+                for (int q = 0; q <= bb; ++q) { m2 = m2 + (c2 - m2) * 0.025f; mm2 = mm2 + (m2 - mm2) * 0.025f; c2 = cfg.blockmax[q]; gg = 0.5f / mm2; }
                 dv = cfg.d[j] * gg;
             }
+            (cfg.dh + (size_t)kDHist * (dyn.hist_parity ^ 1))[tid] = dv;
         }
-        __syncthreads();
-        if (tid < kIqHist) cfg.iq[tid] = v;
-        if (tid < kDHist) (cfg.dh + (size_t)kDHist * (dyn.hist_parity ^ 1))[tid] = dv;
     }
 }
 

@@ -172,9 +172,14 @@ struct ChanGeom {
     int S;                    // LDS row stride in float2 units (>= M, conflict-free for lanes along t)
     unsigned magicM;          // floor(2^32 / M) + 1 : i / M for i < 2^20
     int taps_lds;             // 1: the [8][M] tap table is staged in LDS
+    int stage_in;             // 1: the (TF + 7) M input samples of the tile are staged in LDS (aliasing the Z array)
 };
+__host__ __device__ inline size_t chan_zin_floats2(const ChanGeom &g) {      // Z array, or the staged input tile if larger
+    const size_t z = (size_t)g.TF * g.S, in = g.stage_in ? (size_t)(g.TF + kChanTaps - 1) * g.M : 0;
+    return ((z > in ? z : in) + 1) & ~(size_t)1;
+}
 __host__ __device__ inline size_t chan_lds_bytes(const ChanGeom &g) {
-    size_t b = (size_t)2 * g.TF * g.S * sizeof(float2);
+    size_t b = ((size_t)g.TF * g.S + chan_zin_floats2(g)) * sizeof(float2);
     if (g.taps_lds) b += (size_t)kChanTaps * g.M * sizeof(float);
     return (b + 15) & ~(size_t)15;
 }
@@ -193,36 +198,55 @@ __global__ __launch_bounds__(kChanThreads) void chan_analyze(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = g.M, A = g.A, B = g.B, TF = g.TF, S = g.S;
     float2 *s_x = reinterpret_cast<float2 *>(smem);
-    float2 *s_z = s_x + (size_t)TF * S;
-    float *s_taps = reinterpret_cast<float *>(s_z + (size_t)TF * S);
+    float2 *s_z = s_x + (size_t)TF * S;                   // also the staged input tile during phase 0
+    float *s_taps = reinterpret_cast<float *>(s_z + chan_zin_floats2(g));
     const int tid = threadIdx.x;
     const int64_t f0 = (int64_t)blockIdx.x * TF;          // first frame of this tile
     const int nf = (int)min((int64_t)TF, n_frames - f0);
     const int64_t H = (int64_t)(kChanTaps - 1) * M;
 
-    if (g.taps_lds) {
-        for (int i = tid; i < kChanTaps * M; i += kChanThreads) s_taps[i] = tapsT[i];
-        __syncthreads();
+    const int64_t base = f0 * M;
+    if (g.stage_in) {
+        // one memory round trip: every input sample of the tile (7 frames of halo first) is loaded once, 16 bytes per lane
+        float4 *s_in4 = reinterpret_cast<float4 *>(s_z);
+        const int n_in2 = ((nf + kChanTaps - 1) * M) >> 1;
+        for (int p = tid; p < n_in2; p += kChanThreads) {
+            const int64_t gi = base - H + 2 * (int64_t)p;
+            const float2 *src = gi >= 0 ? x + gi : hist + (gi + H);
+            s_in4[p] = *reinterpret_cast<const float4 *>(src);
+        }
     }
+    if (g.taps_lds) for (int i = tid; i < kChanTaps * M; i += kChanThreads) s_taps[i] = tapsT[i];
+    if (g.stage_in || g.taps_lds) __syncthreads();
     const float *tp = g.taps_lds ? s_taps : tapsT;
 
     // ---- phase 0: polyphase FIR, two adjacent samples (same frame: M is even) per lane
-    const int64_t base = f0 * M;
     const int npairs = (nf * M) >> 1;
     for (int p = tid; p < npairs; p += kChanThreads) {
         const unsigned i = 2u * (unsigned)p;
         const unsigned t = __umulhi(i, g.magicM);
         const unsigned c = i - t * (unsigned)M;
-        const int64_t gi0 = base + i;
         float2 a0 = make_float2(0.f, 0.f), a1 = make_float2(0.f, 0.f);
+        if (g.stage_in) {
+            const float2 *sp = s_z + (size_t)(kChanTaps - 1) * M + i;      // x[(f0 + t) M + c] inside the staged tile
 #pragma unroll
-        for (int n = 0; n < kChanTaps; ++n) {
-            const int64_t gi = gi0 - (int64_t)n * M;
-            const float2 *src = gi >= 0 ? x + gi : hist + (gi + H);
-            const float4 v = *reinterpret_cast<const float4 *>(src);
-            const float2 h = *reinterpret_cast<const float2 *>(tp + n * M + c);
-            a0.x = fmaf(h.x, v.x, a0.x); a0.y = fmaf(h.x, v.y, a0.y);
-            a1.x = fmaf(h.y, v.z, a1.x); a1.y = fmaf(h.y, v.w, a1.y);
+            for (int n = 0; n < kChanTaps; ++n) {
+                const float4 v = *reinterpret_cast<const float4 *>(sp - n * M);
+                const float2 h = *reinterpret_cast<const float2 *>(tp + n * M + c);
+                a0.x = fmaf(h.x, v.x, a0.x); a0.y = fmaf(h.x, v.y, a0.y);
+                a1.x = fmaf(h.y, v.z, a1.x); a1.y = fmaf(h.y, v.w, a1.y);
+            }
+        } else {
+            const int64_t gi0 = base + i;
+#pragma unroll
+            for (int n = 0; n < kChanTaps; ++n) {
+                const int64_t gi = gi0 - (int64_t)n * M;
+                const float2 *src = gi >= 0 ? x + gi : hist + (gi + H);
+                const float4 v = *reinterpret_cast<const float4 *>(src);
+                const float2 h = *reinterpret_cast<const float2 *>(tp + n * M + c);
+                a0.x = fmaf(h.x, v.x, a0.x); a0.y = fmaf(h.x, v.y, a0.y);
+                a1.x = fmaf(h.y, v.z, a1.x); a1.y = fmaf(h.y, v.w, a1.y);
+            }
         }
         float2 *d = s_x + (size_t)t * S + c;
         d[0] = a0; d[1] = a1;

@@ -178,12 +178,19 @@ __device__ inline float2 *lds_fft(float2 *a, float2 *b, int L, const float2 *__r
     return src;
 }
 
-struct FrameSrc {             // where sequence f starts: sequence 0 may live in the carry buffer
-    const float2 *first;      // sequence 0
+struct FrameSrc {             // where sequence f starts
+    const float2 *first;      // sequence 0: elements [0, split) ...
+    const float2 *first2;     // ... and elements [split, L) at first2[i - split] (contiguous run: carry ++ head of the new data)
     const float2 *rest;       // sequence f >= 1 starts at rest + (f - 1) * stride
     int64_t stride;
+    int split;                // >= L when sequence 0 is one piece
 };
 __device__ inline const float2 *frame_ptr(const FrameSrc &fs, int f) { return f == 0 ? fs.first : fs.rest + (int64_t)(f - 1) * fs.stride; }
+// element i of sequence f (sequence 0 may be split in two pieces)
+__device__ inline float2 frame_at(const FrameSrc &fs, int f, const float2 *base, int64_t i) {
+    if (f == 0 && i >= fs.split) return fs.first2[i - fs.split];
+    return base[i];
+}
 
 __device__ inline float cabs_f(float2 v) { return sqrtf(v.x * v.x + v.y * v.y); }
 
@@ -197,10 +204,17 @@ __global__ __launch_bounds__(kFftThreads) void spec_fft_radix(FrameSrc fs, int L
     const int c = COLS * (blockIdx.x * kFftThreads + threadIdx.x);
     if (c >= Lr) return;
     const int s = blockIdx.y;
-    const float2 *x = frame_ptr(fs, s) + c;
+    const float2 *xb = frame_ptr(fs, s);
+    const float2 *x = xb + c;
     float2 *o = dst + (int64_t)s * L + c;
     float2 a[R], b[R];
-    if (COLS == 2) {
+    if (s == 0 && fs.split < L) {                       // block-uniform: the split sequence is read element-wise
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            a[r] = frame_at(fs, 0, xb, (int64_t)r * Lr + c);
+            if (COLS == 2) b[r] = frame_at(fs, 0, xb, (int64_t)r * Lr + c + 1);
+        }
+    } else if (COLS == 2) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const f4u v = *reinterpret_cast<const f4u *>(x + (int64_t)r * Lr);
@@ -239,10 +253,10 @@ __global__ __launch_bounds__(kFftThreads) void spec_fft_rows4096(FrameSrc fs, Sp
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *lds = reinterpret_cast<float2 *>(smem);
     const int f = blockIdx.y, row = blockIdx.x, tid = threadIdx.x;
-    const float2 *x = frame_ptr(fs, f) + (int64_t)row * 4096;
+    const float2 *xb = frame_ptr(fs, f);
     float2 v[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = x[tid + 256 * r];
+    for (int r = 0; r < 16; ++r) v[r] = frame_at(fs, f, xb, (int64_t)row * 4096 + tid + 256 * r);
     fft4096_regs(v, lds, tw4096);
     if (mag) {
         float *o = mag + (int64_t)f * g.N + (int64_t)row * 4096;
@@ -264,7 +278,7 @@ __global__ __launch_bounds__(kFftThreads) void spec_fft_small(FrameSrc fs, int N
     float2 *sa = reinterpret_cast<float2 *>(smem), *sb = sa + N;
     const int f = blockIdx.y, tid = threadIdx.x;
     const float2 *x = frame_ptr(fs, f);
-    for (int i = tid; i < N; i += kFftThreads) sa[i] = x[i];
+    for (int i = tid; i < N; i += kFftThreads) sa[i] = frame_at(fs, f, x, i);
     __syncthreads();
     const float2 *r = lds_fft(sa, sb, N, tw4096);
     if (mag) {
@@ -275,13 +289,23 @@ __global__ __launch_bounds__(kFftThreads) void spec_fft_small(FrameSrc fs, int N
 }
 
 // ---- K15: averaging recurrences, display order -----------------------------------------------------------------
-// thread x owns display point x = the two adjacent shifted bins ka = (2 x + N / 2) mod N and ka + 1; ma / maa
-// (fft_result_ma / _maa, double) are kept per pair as [2][F] arrays.  One wave per workgroup so the F pairs spread
-// over all CUs; the magnitudes of kAvgU frames are loaded ahead of the serial recurrence.  The per-frame extrema the
-// reference tracks are (float) max / min of maa; float rounding is monotonic, so each thread keeps (float max, float
-// min) per frame and the wave reduces kAvgU frames at a time -- nothing cross-lane inside the serial chain.
-constexpr int kAvgThreads = 64;
-constexpr int kAvgU = 8;
+// Display point x owns the two adjacent shifted bins ka = (2 x + N / 2) mod N and ka + 1; fft_result_ma / _maa (double)
+// are kept per point as [2][F] arrays.  The reference runs, per bin and per frame,
+//     maa += (ma - maa) rate;   ma += (x - ma) rate                                  (SpectrumVisualProcessor.cpp:494-511)
+// a linear recurrence in the frame index.  A workgroup owns 64 points; its 16 waves split the frames of the batch into
+// 16 consecutive groups: every thread loads the magnitudes of its group, runs the recurrence from a zero state, the
+// group end states are combined through LDS (state_in(g) = M^G state_in(g-1) + local_end(g-1), M = [[a,0],[rate,a]],
+// a = 1 - rate), and the thread re-runs its frames from the true entering state with the reference's statements.
+// In exact arithmetic this is the sequential result; in double it differs by ~1e-16 relative.  (A NaN magnitude
+// poisons the entering states of the later groups of that batch, where the reference would have recovered after two
+// frames: NaN input is outside the parity contract.)
+// The per-frame extrema the reference tracks are (float) max / min of maa; float rounding is monotonic, so each thread
+// forms (float max, float min) per frame and the wave (= 64 points of one frame) reduces them.
+constexpr int kAvgLanes = 64;
+constexpr int kAvgGroups = 16;
+constexpr int kAvgThreads = kAvgLanes * kAvgGroups;
+constexpr int kAvgGMax = 16;               // frames per thread per round -> 256 frames per round
+constexpr size_t kAvgLds = (size_t)(kAvgGroups + 1) * kAvgLanes * 4 * sizeof(double);
 
 // offsets (in floats, inside one frame of `mag`) of the two bins of display point x; db = distance between them
 __device__ inline int64_t spec_pair_offset(const SpecGeom &g, int x, int64_t &db) {
@@ -297,112 +321,167 @@ __device__ inline float2 spec_load_pair(const float *__restrict__ mag, int64_t o
     return make_float2(mag[off], mag[off + db]);
 }
 
+struct AvgState { double ma_a, maa_a, ma_b, maa_b; };
+__device__ inline void avg_step(AvgState &s, double xa, double xb, double rate) {   // the reference's statements, both bins
+    if (s.maa_a != s.maa_a) s.maa_a = xa;
+    s.maa_a += (s.ma_a - s.maa_a) * rate;
+    if (s.ma_a != s.ma_a) s.ma_a = xa;
+    s.ma_a += (xa - s.ma_a) * rate;
+    if (s.maa_b != s.maa_b) s.maa_b = xb;
+    s.maa_b += (s.ma_b - s.maa_b) * rate;
+    if (s.ma_b != s.ma_b) s.ma_b = xb;
+    s.ma_b += (xb - s.ma_b) * rate;
+}
+
 __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restrict__ mag, int nf, SpecGeom g, double rate,
                                                             double *__restrict__ ma, double *__restrict__ maa,
                                                             float *__restrict__ pairsum, float *__restrict__ first_b,
                                                             float2 *__restrict__ ext_w) {
-    const int F = g.F;
-    const int x = blockIdx.x * kAvgThreads + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    AvgState *s_loc = reinterpret_cast<AvgState *>(smem);               // [kAvgGroups][64] group end states (zero entering state)
+    AvgState *s_carry = s_loc + kAvgGroups * kAvgLanes;                  // [64] state after the round
+    const int F = g.F, lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int x = blockIdx.x * kAvgLanes + lane;
     const bool valid = x < F;
     const int xs = valid ? x : 0;
     int64_t db;
     const int64_t t = spec_pair_offset(g, xs, db);
     const int64_t NN = g.N;
-    const int nwaves = gridDim.x;
-    double ma_a = ma[xs], ma_b = ma[F + xs], maa_a = maa[xs], maa_b = maa[F + xs];
-    float2 cur[kAvgU], nxt[kAvgU];
+    const int ntiles = gridDim.x;
+    const double a = 1.0 - rate;
+    AvgState s0 = {ma[xs], maa[xs], ma[F + xs], maa[F + xs]};            // state entering the batch
+    for (int fb = 0; fb < nf; fb += kAvgGroups * kAvgGMax) {
+        const int nfb = min(kAvgGroups * kAvgGMax, nf - fb);
+        const int G = (nfb + kAvgGroups - 1) / kAvgGroups;               // frames per group (block-uniform)
+        const int fg = grp * G;                                           // first frame of my group inside the round
+        float2 m[kAvgGMax];
 #pragma unroll
-    for (int u = 0; u < kAvgU; ++u) cur[u] = (u < nf) ? spec_load_pair(mag, (int64_t)u * NN + t, db) : make_float2(0.f, 0.f);
-    for (int f0 = 0; f0 < nf; f0 += kAvgU) {
+        for (int i = 0; i < kAvgGMax; ++i)
+            m[i] = (i < G && fg + i < nfb) ? spec_load_pair(mag, (int64_t)(fb + fg + i) * NN + t, db) : make_float2(0.f, 0.f);
+        // M^G = [[aG, 0], [cG, aG]] with aG = a^G, cG = G rate a^(G-1)
+        double aG = 1.0, aGm1 = 1.0;
+        for (int i = 0; i < G; ++i) { aGm1 = aG; aG *= a; }
+        const double cG = (double)G * rate * aGm1;
+        // 1. local pass from a zero state
+        AvgState loc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int u = 0; u < kAvgU; ++u) nxt[u] = (f0 + kAvgU + u < nf) ? spec_load_pair(mag, (int64_t)(f0 + kAvgU + u) * NN + t, db) : make_float2(0.f, 0.f);
-        float mx[kAvgU], mn[kAvgU];
+        for (int i = 0; i < kAvgGMax; ++i)
+            if (i < G && fg + i < nfb) avg_step(loc, (double)m[i].x, (double)m[i].y, rate);
+        s_loc[grp * kAvgLanes + lane] = loc;
+        __syncthreads();
+        // 2. entering state of my group
+        AvgState s = s0;
+        for (int q = 0; q < grp; ++q) {
+            const AvgState e = s_loc[q * kAvgLanes + lane];
+            const AvgState o = s;
+            s.ma_a = aG * o.ma_a + e.ma_a;  s.maa_a = aG * o.maa_a + cG * o.ma_a + e.maa_a;
+            s.ma_b = aG * o.ma_b + e.ma_b;  s.maa_b = aG * o.maa_b + cG * o.ma_b + e.maa_b;
+        }
+        // 3. final pass with the reference's statements; per-frame extrema reduced over the wave's 64 points
 #pragma unroll
-        for (int u = 0; u < kAvgU; ++u) {
-            const int f = f0 + u;
-            mx[u] = 0.f; mn[u] = 3.0e38f;
-            if (f < nf) {
-                const double xa = (double)cur[u].x, xb = (double)cur[u].y;
-                if (maa_a != maa_a) maa_a = xa;
-                maa_a += (ma_a - maa_a) * rate;
-                if (ma_a != ma_a) ma_a = xa;
-                ma_a += (xa - ma_a) * rate;
-                if (maa_b != maa_b) maa_b = xb;
-                maa_b += (ma_b - maa_b) * rate;
-                if (ma_b != ma_b) ma_b = xb;
-                ma_b += (xb - ma_b) * rate;
-                if (valid) {
-                    pairsum[(int64_t)f * F + x] = (float)(maa_a + maa_b);
-                    mx[u] = (float)fmax(maa_a, maa_b); mn[u] = (float)fmin(maa_a, maa_b);
-                    if (x == 0) first_b[f] = (float)maa_b;
+        for (int i = 0; i < kAvgGMax; ++i) {
+            if (i < G) {                                                  // block-uniform
+                const int f = fb + fg + i;
+                const bool fv = fg + i < nfb;
+                float mx = 0.f, mn = 3.0e38f;
+                if (fv) {
+                    avg_step(s, (double)m[i].x, (double)m[i].y, rate);
+                    if (valid) {
+                        pairsum[(int64_t)f * F + x] = (float)(s.maa_a + s.maa_b);
+                        mx = (float)fmax(s.maa_a, s.maa_b); mn = (float)fmin(s.maa_a, s.maa_b);
+                        if (x == 0) first_b[f] = (float)s.maa_b;
+                    }
                 }
+                for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_down(mx, o, 64)); mn = fminf(mn, __shfl_down(mn, o, 64)); }
+                if (lane == 0 && fv) ext_w[(int64_t)f * ntiles + blockIdx.x] = make_float2(mx, mn);
             }
         }
-#pragma unroll
-        for (int u = 0; u < kAvgU; ++u) {
-            float a = mx[u], b = mn[u];
-            for (int o = 32; o > 0; o >>= 1) { a = fmaxf(a, __shfl_down(a, o, 64)); b = fminf(b, __shfl_down(b, o, 64)); }
-            if (threadIdx.x == 0 && f0 + u < nf) ext_w[(int64_t)(f0 + u) * nwaves + blockIdx.x] = make_float2(a, b);
-            cur[u] = nxt[u];
-        }
+        // 4. the group that holds the last frame of the round publishes the state entering the next round
+        if (grp == (nfb - 1) / G) s_carry[lane] = s;
+        __syncthreads();
+        s0 = s_carry[lane];
     }
-    if (valid) { ma[x] = ma_a; ma[F + x] = ma_b; maa[x] = maa_a; maa[F + x] = maa_b; }
+    if (grp == 0 && valid) { ma[x] = s0.ma_a; maa[x] = s0.maa_a; ma[F + x] = s0.ma_b; maa[F + x] = s0.maa_b; }
 }
 
-// ---- floor / ceil trackers across the frames of the batch (SpectrumVisualProcessor.cpp:494-521) ------------------
-// one workgroup: the waves reduce the per-wave extrema of each frame, then thread 0 runs the short serial recurrences.
+// ---- per-frame extrema over the tiles of spec_average.  grid = frames, 256 threads -------------------------------
+__global__ __launch_bounds__(256) void spec_extrema(const float2 *__restrict__ ext_w, int ntiles, float2 *__restrict__ ext) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *s_r = reinterpret_cast<float2 *>(smem);
+    const int f = blockIdx.x, tid = threadIdx.x;
+    float mx = 0.f, mn = 3.0e38f;
+    for (int w = tid; w < ntiles; w += 256) { const float2 v = ext_w[(int64_t)f * ntiles + w]; mx = fmaxf(mx, v.x); mn = fminf(mn, v.y); }
+    for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_down(mx, o, 64)); mn = fminf(mn, __shfl_down(mn, o, 64)); }
+    if ((tid & 63) == 0) s_r[tid >> 6] = make_float2(mx, mn);
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < 4; ++i) { mx = fmaxf(mx, s_r[i].x); mn = fminf(mn, s_r[i].y); }
+        ext[f] = make_float2(mx, mn);
+    }
+}
+
+// ---- K16 + floor / ceil trackers.  grid = (F / 512, frames), 256 threads -----------------------------------------
+// The trackers (SpectrumVisualProcessor.cpp:513-521) are short linear recurrences over the frames; every workgroup
+// evaluates them in closed form from the batch-entering state up to its own frame, the first workgroup of each frame
+// records them and that of the last frame publishes the end state (ping-pong copy).  Then two display points per
+// thread, full-span view (visualRatio = 1: two bins per point), :532-576:
+//     y = log10(acc / 2 + 0.25 - (floor - 0.75)) / log10(ceil + 0.25 - (floor - 0.75)) * scale
+// Both arguments are 1 + u with u formed in double; the logarithms are taken as log1pf(u) (relative error ~1e-7 of the
+// logarithm itself, also when the dynamic range is tiny), their ratio needs no base conversion.
 struct SpecFrameOut { double point_ceil, point_floor; };
 struct SpecScalars { double ceil_ma, ceil_maa, floor_ma, floor_maa; };
-constexpr int kTrackThreads = 1024;
-constexpr int kTrackChunk = 2048;          // frames staged in LDS per round
+constexpr int kDispThreads = 256;
+constexpr size_t kDispLds = (4 * (kDispThreads / 64) + 2) * sizeof(double);
 
-__global__ __launch_bounds__(kTrackThreads) void spec_trackers(const float2 *__restrict__ ext_w, int nwaves, int nf,
-                                                               SpecScalars *st, SpecFrameOut *fo) {
+__global__ __launch_bounds__(kDispThreads) void spec_display(const float *__restrict__ pairsum, const float *__restrict__ first_b,
+                                                             const float2 *__restrict__ ext, int nf, int F, float sf,
+                                                             const SpecScalars *__restrict__ st_in, SpecScalars *__restrict__ st_out,
+                                                             SpecFrameOut *__restrict__ fo, float *__restrict__ points) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2 *s_ext = reinterpret_cast<float2 *>(smem);          // [kTrackChunk] (max, min) per frame
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    SpecScalars s = *st;
-    for (int fc = 0; fc < nf; fc += kTrackChunk) {
-        const int cn = min(kTrackChunk, nf - fc);
-        for (int i0 = 0; i0 < cn; i0 += kTrackThreads / 64) {     // block-uniform trip count
-            const int i = i0 + wave;
-            float mx = 0.f, mn = 3.0e38f;
-            if (i < cn) for (int w = lane; w < nwaves; w += 64) { const float2 v = ext_w[(int64_t)(fc + i) * nwaves + w]; mx = fmaxf(mx, v.x); mn = fminf(mn, v.y); }
-            for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_down(mx, o, 64)); mn = fminf(mn, __shfl_down(mn, o, 64)); }
-            if (lane == 0 && i < cn) s_ext[i] = make_float2(mx, mn);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            for (int i = 0; i < cn; ++i) {
-                const float mx = s_ext[i].x, mn = s_ext[i].y;
-                float fft_ceil = 0.f, fft_floor = 1.f;          // the reference keeps these two in float (:436)
-                if (mx > fft_ceil) fft_ceil = mx;
-                if (mn < fft_floor) fft_floor = mn;
-                if (s.ceil_ma != s.ceil_ma) s.ceil_ma = fft_ceil;
-                s.ceil_ma = s.ceil_ma + ((double)fft_ceil - s.ceil_ma) * 0.05;
-                if (s.ceil_maa != s.ceil_maa) s.ceil_maa = fft_ceil;
-                s.ceil_maa = s.ceil_maa + (s.ceil_ma - s.ceil_maa) * 0.05;
-                if (s.floor_ma != s.floor_ma) s.floor_ma = fft_floor;
-                s.floor_ma = s.floor_ma + ((double)fft_floor - s.floor_ma) * 0.05;
-                if (s.floor_maa != s.floor_maa) s.floor_maa = fft_floor;
-                s.floor_maa = s.floor_maa + (s.floor_ma - s.floor_maa) * 0.05;
-                fo[fc + i].point_ceil = s.ceil_maa;
-                fo[fc + i].point_floor = s.floor_maa;
-            }
-        }
-        __syncthreads();
+    double *s_sum = reinterpret_cast<double *>(smem);          // reduction scratch [waves][4]
+    double *s_pc = s_sum + 4 * (kDispThreads / 64);            // [2] point_ceil, point_floor of this frame
+    const int f = blockIdx.y, tid = threadIdx.x;
+    // trackers after frame f, closed form of the recurrences (a = 0.95, b = 0.05; c_i = float ceiling, d_i = float floor
+    // of frame i):   ma_f  = a^(f+1) ma_in + b sum_i a^(f-i) c_i
+    //                maa_f = a^(f+1) maa_in + b (f+1) a^(f+1) ma_in + b^2 sum_i (f-i+1) a^(f-i) c_i      (maa uses the NEW ma)
+    // evaluated as parallel weighted sums over i <= f (double; equal to the serial loop to ~1e-15 relative).
+    const SpecScalars s_in = *st_in;
+    double w_c = 0.0, w_c2 = 0.0, w_d = 0.0, w_d2 = 0.0;
+    for (int i = tid; i <= f; i += kDispThreads) {
+        const float2 e = ext[i];
+        float fft_ceil = 0.f, fft_floor = 1.f;              // the reference keeps these two in float (:436)
+        if (e.x > fft_ceil) fft_ceil = e.x;
+        if (e.y < fft_floor) fft_floor = e.y;
+        const double w = dc_pow(0.95, f - i), w2 = (double)(f - i + 1) * w;
+        w_c += w * (double)fft_ceil; w_c2 += w2 * (double)fft_ceil;
+        w_d += w * (double)fft_floor; w_d2 += w2 * (double)fft_floor;
     }
-    if (tid == 0) *st = s;
-}
-
-// ---- K16: display points, full-span view (visualRatio = 1: two bins per point).  grid = (F / 512, frames) ---------
-__global__ __launch_bounds__(256) void spec_display(const float *__restrict__ pairsum, const float *__restrict__ first_b,
-                                                    const SpecFrameOut *__restrict__ fo, int F, float sf,
-                                                    float *__restrict__ points) {
-    const int x0 = 2 * (blockIdx.x * blockDim.x + threadIdx.x), f = blockIdx.y;
+    for (int o = 32; o > 0; o >>= 1) {
+        w_c += __shfl_down(w_c, o, 64); w_c2 += __shfl_down(w_c2, o, 64);
+        w_d += __shfl_down(w_d, o, 64); w_d2 += __shfl_down(w_d2, o, 64);
+    }
+    if ((tid & 63) == 0) { double *q = s_sum + 4 * (tid >> 6); q[0] = w_c; q[1] = w_c2; q[2] = w_d; q[3] = w_d2; }
+    __syncthreads();
+    if (tid == 0) {
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        for (int q = 0; q < kDispThreads / 64; ++q) { t0 += s_sum[4 * q]; t1 += s_sum[4 * q + 1]; t2 += s_sum[4 * q + 2]; t3 += s_sum[4 * q + 3]; }
+        const double af = dc_pow(0.95, f + 1), b = 0.05;
+        SpecScalars s;
+        s.ceil_ma = af * s_in.ceil_ma + b * t0;
+        s.ceil_maa = af * s_in.ceil_maa + b * (double)(f + 1) * af * s_in.ceil_ma + b * b * t1;
+        s.floor_ma = af * s_in.floor_ma + b * t2;
+        s.floor_maa = af * s_in.floor_maa + b * (double)(f + 1) * af * s_in.floor_ma + b * b * t3;
+        s_pc[0] = s.ceil_maa; s_pc[1] = s.floor_maa;
+        if (blockIdx.x == 0) {
+            fo[f].point_ceil = s.ceil_maa; fo[f].point_floor = s.floor_maa;
+            if (f == nf - 1) *st_out = s;
+        }
+    }
+    __syncthreads();
+    const double pc = s_pc[0], pf = s_pc[1];
+    const float inv_den = 1.0f / log1pf((float)(pc - pf));          // (pc + 0.25) - (pf - 0.75) = 1 + (pc - pf)
+    const int x0 = 2 * (blockIdx.x * kDispThreads + tid);
     if (x0 >= F) return;
-    const double pc = fo[f].point_ceil, pf = fo[f].point_floor;
-    const double den = log10((pc + 0.25) - (pf - 0.75));
     float y[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -410,17 +489,11 @@ __global__ __launch_bounds__(256) void spec_display(const float *__restrict__ pa
         double acc = 0.0;
         if (x < F) acc = (x == 0) ? pf + (double)first_b[f]       // idx == 0 is replaced by fft_floor_maa (:546-556)
                                   : (double)pairsum[(int64_t)f * F + x];
-        y[u] = (float)((log10((acc / 2.0) + 0.25 - (pf - 0.75)) / den) * (double)sf);
+        y[u] = log1pf((float)(acc / 2.0 - pf)) * inv_den * sf;      // acc / 2 + 0.25 - (pf - 0.75) = 1 + (acc / 2 - pf)
     }
     float *o = points + ((int64_t)f * F + x0) * 2;
     if (x0 + 1 < F) *reinterpret_cast<float4 *>(o) = make_float4((float)x0 / (float)F, y[0], (float)(x0 + 1) / (float)F, y[1]);
     else { o[0] = (float)x0 / (float)F; o[1] = y[0]; }
-}
-
-// assemble frame 0 of a contiguous run from (carry ++ head of the new data)
-__global__ void spec_assemble(const float2 *carry, int ncarry, const float2 *x, int n, float2 *dst) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = i < ncarry ? carry[i] : x[i - ncarry];
 }
 
 }  // namespace csdr

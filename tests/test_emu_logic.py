@@ -83,3 +83,7 @@ def test_emu_spectrum_first_frame(ctx):
 
 def test_emu_spectrum_contiguous(ctx):
     G.test_spectrum_contiguous_mode(ctx)
+
+
+def test_emu_spectrum_many_frames(ctx):
+    G.test_spectrum_many_frames_one_batch(ctx)

@@ -260,3 +260,31 @@ def test_spectrum_contiguous_mode(ctx):
             done += 1
     assert done == (nb * block) // (2 * F)
     sp.close()
+
+
+def test_spectrum_many_frames_one_batch(ctx):
+    """300 frames in ONE process() call (the averaging kernel splits a batch into 16 frame groups per round of 256
+    frames and chains rounds): every frame must equal the frame-at-a-time reference."""
+    from cubicsdr_amd.engine import SpectrumProcessor
+    from oracle.cubicsdr_chain import RefSpectrum
+    F, nfr = 512, 300
+    N = 2 * F
+    x = synth_iq(nfr * N, 2.4e6, 0, [("NBFM", 300000.0), ("AM", -400000.0)], seed=12)
+    sp = SpectrumProcessor(ctx, F, max_frames=nfr)
+    ref = RefSpectrum(_backend(), F)
+    assert sp.process(x, 1, nfr * N, contiguous=True) == nfr
+    for k in range(nfr):
+        wp, wce, wfl = ref.process_frame(x[k * N:(k + 1) * N])
+        if k in (0, 1, 15, 16, 17, 18, 19, 37, 255, 256, 257, 271, 272, 298, 299):
+            pts, ce, fl = sp.fetch(k)
+            assert rel_err(pts, wp) < TOL, k
+            assert abs(ce - wce) <= TOL * abs(wce) and abs(fl - wfl) <= TOL * abs(wce), k
+    # a second batch continues from the carried averager / tracker state
+    y = synth_iq(20 * N, 2.4e6, 0, [("NBFM", 300000.0)], seed=13)
+    assert sp.process(y, 1, 20 * N, contiguous=True) == 20
+    for k in range(20):
+        wp, wce, wfl = ref.process_frame(y[k * N:(k + 1) * N])
+    pts, ce, fl = sp.fetch(19)
+    assert rel_err(pts, wp) < TOL
+    assert abs(ce - wce) <= TOL * abs(wce)
+    sp.close()
