@@ -119,7 +119,6 @@ def main():
     ap.add_argument("--blocks", type=int, default=32, help="IQ blocks per step (batch resident in HBM)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 disables)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event profile")
-    ap.add_argument("--one-stream", action="store_true", help="run the spectrum on the same HIP stream (solo kernel times)")
     args = ap.parse_args()
 
     import torch
@@ -146,14 +145,13 @@ def main():
     NB = args.blocks
     ring = make_ring(torch, device, NB, seed=0xC0B1C5D2 + rank)
     torch.cuda.synchronize()
-    ctx = Context(local_rank)        # SDRPostThread + demodulators: one HIP stream
-    ctx2 = ctx if args.one_stream else Context(local_rank)   # SpectrumVisualProcessor: its own stream (its own thread in the reference)
+    ctx = Context(local_rank)        # one HIP stream per pipeline stage inside (include/csdr_hip.h "Streams")
     post = SDRPost(ctx, FS, M, BLOCK, max_blocks=NB)
     bank = DemodBank(ctx, N_DEMODS, max_blocks=NB)
     for i, f in enumerate(demod_frequencies(CENTER, FS, N_DEMODS)):
         bank.configure(i, post, "NBFM", NBFM_BW, f, AUDIO_RATE)
     n_frames_max = (NB * BLOCK) // (2 * FFT_SIZE) + 2
-    spec = SpectrumProcessor(ctx2, FFT_SIZE, max_frames=n_frames_max)
+    spec = SpectrumProcessor(ctx, FFT_SIZE, max_frames=n_frames_max)
 
     def step():
         post.execute(ring, NB, BLOCK, CENTER)
@@ -162,20 +160,18 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ctx.synchronize(); ctx2.synchronize()
+    ctx.synchronize()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     if not args.no_profile:
-        ctx.profile_enable(True); ctx2.profile_enable(True)
+        ctx.profile_enable(True)
     ctx.timer_start()
-    if ctx2 is not ctx:
-        ctx2.timer_start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    ev_ms = ctx.timer_stop() if ctx2 is ctx else max(ctx.timer_stop(), ctx2.timer_stop())
-    ctx.synchronize(); ctx2.synchronize()
+    ev_ms = ctx.timer_stop()
+    ctx.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist:
@@ -185,8 +181,8 @@ def main():
         elapsed = float(tt.item())
     prof = {}
     if not args.no_profile:
-        prof.update(ctx.profile()); prof.update(ctx2.profile())
-        ctx.profile_enable(False); ctx2.profile_enable(False)
+        prof.update(ctx.profile())
+        ctx.profile_enable(False)
     audio_total = bank.total_audio()
 
     samples = args.steps * NB * BLOCK * world
@@ -199,7 +195,7 @@ def main():
         "config": {"workload": "C2: 64x NBFM demods (12.5 kHz -> 48 kHz audio), 10 MS/s complex-float IQ, firpfbch M=20, 16384-pt spectrum FFT (internal 32768) over every sample",
                    "blocks_per_step": NB, "block_len": BLOCK, "n_demods": N_DEMODS, "fft_size": FFT_SIZE,
                    "realtime_multiple": value / world / (FS / 1e6), "audio_samples_per_step": audio_total,
-                   "event_ms_per_step": ev_ms / args.steps, "parallelism": "one independent IQ stream per GPU; spectrum on its own HIP stream"},
+                   "event_ms_per_step": ev_ms / args.steps, "parallelism": "one independent IQ stream per GPU; one HIP stream per pipeline stage, consecutive batches overlap"},
     }
     if prof:
         dom = max(prof, key=lambda k: prof[k][0])
@@ -222,8 +218,6 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     spec.close(); bank.close(); post.close(); ctx.close()
-    if ctx2 is not ctx:
-        ctx2.close()
     if dist:
         dist.destroy_process_group()
 

@@ -74,6 +74,13 @@ __device__ inline float2 cfma(float2 v, float2 w, float2 acc) {   // acc + v * w
 }
 // a value that is the same in every lane of the wave by construction: tell the compiler (scalar registers, scalar loads)
 __device__ inline int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// LDS hand-off between lanes of ONE wave (no other wave involved): the wave executes its LDS operations in order, so
+// only the compiler has to be kept from moving them across this point
+__device__ inline void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 // 16 bytes that are only guaranteed 8-byte aligned (two adjacent complex samples at an odd sample offset)
 struct __attribute__((aligned(8))) f4u { float x, y, z, w; };
 
@@ -87,11 +94,20 @@ enum CsdrKernelId {
     KID_COUNT
 };
 
+// One HIP stream per pipeline stage, like one IOThread per stage in the reference: consecutive batches overlap across
+// stages (SDRPostThread works on block i+1 while the demodulators work on block i); events order the hand-offs.
+enum CsdrLane { LANE_POST = 0, LANE_FE, LANE_AUDIO, LANE_FFT, LANE_AVG, LANE_COUNT };
+
 struct csdr_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;            // boundary stream: the caller's producer / consumer work is ordered on it
     bool own_stream = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t lanes[LANE_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // logical stage -> physical stream
+    hipStream_t phys[LANE_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};    // streams this ctx created
+    int n_phys = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; // timing
+    hipEvent_t ev_in = nullptr;              // fork: boundary stream -> lane
+    hipEvent_t ev_lane[LANE_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // join: lane -> boundary stream
     csdr::DevBuf<float> sintab;  // 1024-entry sine table of the reference's NCO
     // per-kernel profile: event pairs recorded around launches while enabled
     bool prof_on = false;
@@ -106,13 +122,47 @@ struct csdr_ctx {
         (void)hipEventCreate(&e);
         return e;
     }
+    // work the caller enqueued on the boundary stream (e.g. the producer of a device IQ buffer) precedes this lane's next work
+    int lane_begin(int lane) {
+        if (own_stream) return CSDR_OK;      // nobody else can enqueue on a stream we created
+        CSDR_HIP_TRY(hipEventRecord(ev_in, stream));
+        CSDR_HIP_TRY(hipStreamWaitEvent(lanes[lane], ev_in, 0));
+        return CSDR_OK;
+    }
+    // everything enqueued on the lanes so far precedes whatever is enqueued on the boundary stream next
+    int join() {
+        for (int l = 0; l < n_phys; ++l) {
+            if (phys[l] == stream) continue;
+            CSDR_HIP_TRY(hipEventRecord(ev_lane[l], phys[l]));
+            CSDR_HIP_TRY(hipStreamWaitEvent(stream, ev_lane[l], 0));
+        }
+        return CSDR_OK;
+    }
+    // hand-off between two stages: only a real cross-stream edge needs an event (on this stack one costs far more than
+    // a kernel boundary), stages that share a physical stream are ordered by it
+    bool same(int lane_a, int lane_b) const { return lanes[lane_a] == lanes[lane_b]; }
+    int signal(hipEvent_t ev, int from_lane, int to_lane) {
+        if (same(from_lane, to_lane)) return CSDR_OK;
+        CSDR_HIP_TRY(hipEventRecord(ev, lanes[from_lane]));
+        return CSDR_OK;
+    }
+    int wait(hipEvent_t ev, int from_lane, int to_lane) {
+        if (same(from_lane, to_lane)) return CSDR_OK;
+        CSDR_HIP_TRY(hipStreamWaitEvent(lanes[to_lane], ev, 0));
+        return CSDR_OK;
+    }
+    int sync_all() {
+        for (int l = 0; l < n_phys; ++l) CSDR_HIP_TRY(hipStreamSynchronize(phys[l]));
+        CSDR_HIP_TRY(hipStreamSynchronize(stream));
+        return CSDR_OK;
+    }
 };
 
 // bracket one kernel launch with events when profiling is on
 struct ProfScope {
-    csdr_ctx *c; int id; hipEvent_t a = nullptr;
-    ProfScope(csdr_ctx *c_, int id_) : c(c_), id(id_) { if (c->prof_on) { a = c->prof_event(); (void)hipEventRecord(a, c->stream); } }
-    ~ProfScope() { if (a) { hipEvent_t b = c->prof_event(); (void)hipEventRecord(b, c->stream); c->prof_pending.push_back({id, a, b}); } }
+    csdr_ctx *c; int id; hipStream_t st; hipEvent_t a = nullptr;
+    ProfScope(csdr_ctx *c_, int id_, hipStream_t st_) : c(c_), id(id_), st(st_) { if (c->prof_on) { a = c->prof_event(); (void)hipEventRecord(a, st); } }
+    ~ProfScope() { if (a) { hipEvent_t b = c->prof_event(); (void)hipEventRecord(b, st); c->prof_pending.push_back({id, a, b}); } }
 };
-#define CSDR_LAUNCH(ctx_, kid_, kern_, grid_, block_, lds_, ...) \
-    do { ProfScope ps__((ctx_), (kid_)); hipLaunchKernelGGL(kern_, grid_, block_, lds_, (ctx_)->stream, __VA_ARGS__); } while (0)
+#define CSDR_LAUNCH(ctx_, lane_, kid_, kern_, grid_, block_, lds_, ...) \
+    do { ProfScope ps__((ctx_), (kid_), (ctx_)->lanes[lane_]); hipLaunchKernelGGL(kern_, grid_, block_, lds_, (ctx_)->lanes[lane_], __VA_ARGS__); } while (0)

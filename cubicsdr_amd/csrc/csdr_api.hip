@@ -1,6 +1,7 @@
 // csdr_api.hip -- implementation of include/csdr_hip.h (gfx950).  Host-side bookkeeping mirrors the reference's
 // control flow (file:line cited per function); all sample arithmetic is in the kernels_*.hpp kernels.
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <map>
 #include <memory>
@@ -40,8 +41,23 @@ extern "C" int csdr_ctx_create(int device, void *hip_stream, csdr_ctx **out) {
     CSDR_HIP_TRY(hipSetDevice(device));
     std::unique_ptr<csdr_ctx> c(new csdr_ctx());
     c->device = device;
+    // Physical streams.  Measured on MI355X / ROCm 7.2: a per-batch cross-stream event edge costs ~0.3 ms, two orders
+    // of magnitude more than an in-stream kernel boundary, so by default the stages are folded onto the two chains that
+    // share no data: {SDRPostThread, demodulators} and {spectrum}.  CSDR_STREAMS = 1 | 2 | 3 | 5 selects other foldings
+    // (3: channelizer | demodulators | spectrum, 5: one stream per stage); the event protocol is the same for all.
+    int want = 2;
+    if (const char *e = getenv("CSDR_STREAMS")) want = atoi(e);
+    if (want != 1 && want != 2 && want != 3 && want != 5) want = 2;
+    static const int kMap[6][LANE_COUNT] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 1, 1}, {0, 1, 1, 2, 2}, {0, 0, 0, 0, 0}, {0, 1, 2, 3, 4}};
+    c->n_phys = want;
+    for (int l = 0; l < want; ++l) {
+        CSDR_HIP_TRY(hipStreamCreateWithFlags(&c->phys[l], hipStreamNonBlocking));
+        CSDR_HIP_TRY(hipEventCreateWithFlags(&c->ev_lane[l], hipEventDisableTiming));
+    }
+    for (int l = 0; l < LANE_COUNT; ++l) c->lanes[l] = c->phys[kMap[want][l]];
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
-    else { CSDR_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    else { c->stream = c->phys[0]; c->own_stream = true; }      // a private boundary stream is just the first stage stream
+    CSDR_HIP_TRY(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     CSDR_HIP_TRY(hipEventCreate(&c->ev0));
     CSDR_HIP_TRY(hipEventCreate(&c->ev1));
     std::vector<float> tab = design::nco_sine_table();
@@ -52,28 +68,39 @@ extern "C" int csdr_ctx_create(int device, void *hip_stream, csdr_ctx **out) {
 }
 extern "C" void csdr_ctx_destroy(csdr_ctx *c) {
     if (!c) return;
-    (void)hipStreamSynchronize(c->stream);
+    (void)c->sync_all();
     c->sintab.release();
     for (auto &r : c->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+    for (int l = 0; l < c->n_phys; ++l) {
+        if (c->ev_lane[l]) (void)hipEventDestroy(c->ev_lane[l]);
+        if (c->phys[l]) (void)hipStreamDestroy(c->phys[l]);
+    }
     delete c;
 }
 extern "C" int csdr_ctx_synchronize(csdr_ctx *c) {
     if (!c) return fail(CSDR_EINVAL, "ctx is null");
-    CSDR_HIP_TRY(hipStreamSynchronize(c->stream));
-    return CSDR_OK;
+    return c->sync_all();
+}
+extern "C" int csdr_ctx_join(csdr_ctx *c) {
+    if (!c) return fail(CSDR_EINVAL, "ctx is null");
+    return c->join();
 }
 extern "C" void *csdr_ctx_stream(csdr_ctx *c) { return c ? (void *)c->stream : nullptr; }
 extern "C" int csdr_ctx_timer_start(csdr_ctx *c) {
     if (!c) return fail(CSDR_EINVAL, "ctx is null");
+    if (int rc = c->join()) return rc;
     CSDR_HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    // nothing the stage streams receive from now on may start before the timer's start mark
+    for (int l = 0; l < c->n_phys; ++l) if (c->phys[l] != c->stream) CSDR_HIP_TRY(hipStreamWaitEvent(c->phys[l], c->ev0, 0));
     return CSDR_OK;
 }
 extern "C" int csdr_ctx_timer_stop(csdr_ctx *c, float *ms) {
     if (!c || !ms) return fail(CSDR_EINVAL, "null argument");
+    if (int rc = c->join()) return rc;
     CSDR_HIP_TRY(hipEventRecord(c->ev1, c->stream));
     CSDR_HIP_TRY(hipEventSynchronize(c->ev1));
     CSDR_HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
@@ -85,7 +112,7 @@ static const char *kKernelNames[KID_COUNT] = {
     "demod_frontend", "demod_modem", "demod_audio_interp",
     "spec_fft_radix", "spec_fft_rows", "spec_average", "spec_extrema", "spec_display", "spec_misc"};
 static int prof_drain(csdr_ctx *c) {
-    CSDR_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = c->sync_all()) return rc;
     for (auto &r : c->prof_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->prof_ms[r.id] += ms; c->prof_n[r.id] += 1; }
@@ -124,6 +151,7 @@ extern "C" int csdr_dev_upload(csdr_ctx *c, void *dev, const void *host, uint64_
 }
 extern "C" int csdr_dev_download(csdr_ctx *c, void *host, const void *dev, uint64_t bytes) {
     if (!c) return fail(CSDR_EINVAL, "ctx is null");
+    if (int rc = c->sync_all()) return rc;
     CSDR_HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
     CSDR_HIP_TRY(hipStreamSynchronize(c->stream));
     return CSDR_OK;
@@ -142,6 +170,14 @@ struct csdr_post {
     std::vector<int> active_host;            // sorted list of produced channels
     bool active_dirty = true;
     ChanGeom geom{};
+    // `out` holds kPostBufs batches in rotation: the channelizer fills the next one while the demodulators still read
+    // the previous (the reference hands ReBuffer blocks through a queue, SDRPostThread.cpp:341-396)
+    static constexpr int kPostBufs = 3, kMaxConsumers = 4;
+    int cur = 0;                             // buffer of the last execute
+    uint64_t seq = 0;
+    hipEvent_t ev_ready[kPostBufs] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_consumed[kPostBufs][kMaxConsumers] = {};
+    int n_consumed[kPostBufs] = {0, 0, 0};
     DevBuf<float2> out, hist0, hist1, stage_in, twA, twB, twM;
     DevBuf<float> taps;
     DevBuf<int> active;                      // [M] flags
@@ -164,13 +200,22 @@ static void post_update_channels(csdr_post *p) {   // SDRPostThread::updateChann
 
 extern "C" int csdr_post_create(csdr_ctx *ctx, csdr_post **out) {
     if (!ctx || !out) return fail(CSDR_EINVAL, "null argument");
-    *out = new csdr_post();
-    (*out)->ctx = ctx;
+    std::unique_ptr<csdr_post> p(new csdr_post());
+    p->ctx = ctx;
+    for (int k = 0; k < csdr_post::kPostBufs; ++k) {
+        CSDR_HIP_TRY(hipEventCreateWithFlags(&p->ev_ready[k], hipEventDisableTiming));
+        for (int c = 0; c < csdr_post::kMaxConsumers; ++c) CSDR_HIP_TRY(hipEventCreateWithFlags(&p->ev_consumed[k][c], hipEventDisableTiming));
+    }
+    *out = p.release();
     return CSDR_OK;
 }
 extern "C" void csdr_post_destroy(csdr_post *p) {
     if (!p) return;
-    (void)hipStreamSynchronize(p->ctx->stream);
+    (void)p->ctx->sync_all();
+    for (int k = 0; k < csdr_post::kPostBufs; ++k) {
+        if (p->ev_ready[k]) (void)hipEventDestroy(p->ev_ready[k]);
+        for (int c = 0; c < csdr_post::kMaxConsumers; ++c) if (p->ev_consumed[k][c]) (void)hipEventDestroy(p->ev_consumed[k][c]);
+    }
     p->out.release(); p->hist0.release(); p->hist1.release(); p->stage_in.release();
     p->twA.release(); p->twB.release(); p->twM.release();
     p->taps.release(); p->active.release(); p->dc_state.release(); p->tile_end.release();
@@ -210,20 +255,22 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
     if ((mode == CSDR_POST_SINGLE) != (num_channels == 1)) return fail(CSDR_EINVAL, "SINGLE mode <=> num_channels == 1");
     if (max_block_len % num_channels) return fail(CSDR_EINVAL, "max_block_len must be a multiple of num_channels");
     if (num_channels > 1 && (num_channels & 1)) return fail(CSDR_EUNSUPPORTED, "odd numChannels %d (the reference only produces even counts, SoapySDRThread.cpp:676-693)", num_channels);
-    hipStream_t st = p->ctx->stream;
-    CSDR_HIP_TRY(hipStreamSynchronize(st));
+    hipStream_t st = p->ctx->lanes[LANE_POST];
+    if (int rc = p->ctx->sync_all()) return rc;
     p->configured = false;
+    p->cur = 0; p->seq = 0;
+    for (int k = 0; k < csdr_post::kPostBufs; ++k) p->n_consumed[k] = 0;
     p->mode = mode; p->M = num_channels; p->sample_rate = sample_rate;
     p->chan_bw = sample_rate / num_channels;                       // integer division, SDRPostThread.cpp:408
     p->max_block_len = max_block_len; p->max_blocks = max_blocks;
     const int M = p->M;
     p->chan_stride = ((int64_t)max_blocks * (max_block_len / M) + 1) & ~(int64_t)1;
-    if (int rc = p->out.reserve((size_t)p->chan_stride * M)) return rc;
+    if (int rc = p->out.reserve((size_t)p->chan_stride * M * csdr_post::kPostBufs)) return rc;
     if (int rc = p->dc_state.reserve(2)) return rc;
     CSDR_HIP_TRY(hipMemsetAsync(p->dc_state.p, 0, 2 * sizeof(d2), st));
     p->dc_parity = 0;
     const int64_t dc_n = (mode == CSDR_POST_SINGLE) ? (int64_t)max_blocks * max_block_len : p->chan_stride;
-    const size_t ntiles = (size_t)((dc_n + kDcTile - 1) / kDcTile);
+    const size_t ntiles = (size_t)(dc_n / 16 + 2);          // channelizer tiles hold >= 16 frames when they emit end values
     if (int rc = p->tile_end.reserve(ntiles)) return rc;
     // iirfilt_crcf_create_dc_blocker(0.0005f): b = {1, -1}, a = {1, -1 + alpha}  (float)  ->  v = x - a1 v'
     const float a1 = -1.0f + 0.0005f;
@@ -285,24 +332,33 @@ extern "C" int csdr_post_set_active_channels(csdr_post *p, const int *channels, 
     return CSDR_OK;
 }
 
-static int run_dc_blocker(csdr_post *p, const float2 *x, float2 *y, int64_t n) {
-    const int ntiles = (int)((n + kDcTile - 1) / kDcTile);
+// DC blocker over n samples: `have_ends` = the mini-tile end values (tile_len samples each) are already in tile_end
+// (the channelizer wrote them); otherwise a first pass computes them per kDcTile samples.
+static int run_dc_blocker(csdr_post *p, const float2 *x, float2 *y, int64_t n, bool have_ends, int tile_len) {
+    const int nblocks = (int)((n + kDcTile - 1) / kDcTile);
     d2 *s_in = p->dc_state.p + p->dc_parity, *s_out = p->dc_state.p + (p->dc_parity ^ 1);
-    CSDR_LAUNCH(p->ctx, KID_DC_ENDS, dc_tile_ends, dim3(ntiles), dim3(kDcThreads), kDcLds, x, n, p->dc_c, p->tile_end.p);
-    CSDR_LAUNCH(p->ctx, KID_DC_APPLY, dc_apply, dim3(ntiles), dim3(kDcThreads), kDcLds, x, y, n, p->dc_c, p->tile_end.p, s_in, s_out);
+    if (!have_ends) {
+        tile_len = kDcTile;
+        CSDR_LAUNCH(p->ctx, LANE_POST, KID_DC_ENDS, dc_tile_ends, dim3(nblocks), dim3(kDcThreads), kDcLds, x, n, p->dc_c, p->tile_end.p);
+    }
+    CSDR_LAUNCH(p->ctx, LANE_POST, KID_DC_APPLY, dc_apply, dim3(nblocks), dim3(kDcThreads), kDcLds, x, y, n, p->dc_c, tile_len, p->tile_end.p, s_in, s_out);
     p->dc_parity ^= 1;
     CSDR_HIP_TRY(hipGetLastError());
     return CSDR_OK;
 }
+
+static float2 *post_buf(const csdr_post *p, int k) { return p->out.p + (size_t)k * p->chan_stride * p->M; }
 
 extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, int n_blocks, int block_len, int64_t frequency) {
     if (!p || !p->configured) return fail(CSDR_ESTATE, "post not configured");
     if (!iq || n_blocks <= 0 || block_len <= 0) return fail(CSDR_EINVAL, "bad block arguments");
     if (n_blocks > p->max_blocks || block_len > p->max_block_len) return fail(CSDR_ERANGE, "batch %d x %d exceeds configured %d x %d", n_blocks, block_len, p->max_blocks, p->max_block_len);
     if (block_len % p->M) return fail(CSDR_EINVAL, "block_len %d is not a multiple of numChannels %d", block_len, p->M);
-    hipStream_t st = p->ctx->stream;
+    csdr_ctx *c = p->ctx;
+    hipStream_t st = c->lanes[LANE_POST];
     const int64_t n = (int64_t)n_blocks * block_len;
     const float2 *x = (const float2 *)iq;
+    if (int rc = c->lane_begin(LANE_POST)) return rc;
     if (!iq_is_dev) {
         if (int rc = p->stage_in.reserve((size_t)p->max_blocks * p->max_block_len)) return rc;
         CSDR_HIP_TRY(hipMemcpyAsync(p->stage_in.p, iq, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, st));
@@ -310,26 +366,41 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
     } else if ((uintptr_t)iq & 15) return fail(CSDR_EINVAL, "device IQ pointer must be 16-byte aligned");
     if (frequency != p->frequency || p->centers.empty()) { p->frequency = frequency; post_update_channels(p); }
     p->n_blocks = n_blocks; p->block_len = block_len;
-    if (p->mode == CSDR_POST_SINGLE) return run_dc_blocker(p, x, p->out.p, n);       // runSingleCH :284
-
-    const int M = p->M;
-    if (p->active_dirty) {
-        std::vector<int> flags(M, 0);
-        for (int c : p->active_host) flags[c] = 1;
-        CSDR_HIP_TRY(hipMemcpyAsync(p->active.p, flags.data(), flags.size() * sizeof(int), hipMemcpyHostToDevice, st));
-        CSDR_HIP_TRY(hipStreamSynchronize(st));
-        p->active_dirty = false;
+    // next output buffer of the rotation: its previous readers (demodulator front-ends, three batches ago) must be done
+    const int k = (int)(p->seq % csdr_post::kPostBufs);
+    if (!c->same(LANE_FE, LANE_POST))
+        for (int q = 0; q < p->n_consumed[k]; ++q) CSDR_HIP_TRY(hipStreamWaitEvent(st, p->ev_consumed[k][q], 0));
+    p->n_consumed[k] = 0;
+    float2 *out = post_buf(p, k);
+    int rc = CSDR_OK;
+    if (p->mode == CSDR_POST_SINGLE) rc = run_dc_blocker(p, x, out, n, false, 0);       // runSingleCH :284
+    else {
+        const int M = p->M;
+        if (p->active_dirty) {
+            std::vector<int> flags(M, 0);
+            for (int ch : p->active_host) flags[ch] = 1;
+            CSDR_HIP_TRY(hipStreamSynchronize(st));                              // earlier launches still read the old flags
+            CSDR_HIP_TRY(hipMemcpy(p->active.p, flags.data(), flags.size() * sizeof(int), hipMemcpyHostToDevice));
+            p->active_dirty = false;
+        }
+        const int64_t n_frames = n / M;
+        const ChanGeom &g = p->geom;
+        float2 *hist = p->hist_parity ? p->hist1.p : p->hist0.p, *hist_new = p->hist_parity ? p->hist0.p : p->hist1.p;
+        const int ntiles = (int)((n_frames + g.TF - 1) / g.TF);
+        // channel 0 carries the DC spike: it is blocked after de-interleave (:364-375); when the tile size allows, the
+        // channelizer itself emits the per-tile end values the blocked scan needs
+        const bool dc0 = !p->active_host.empty() && p->active_host[0] == 0;
+        const bool fused_ends = dc0 && g.TF >= 16;
+        CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, chan_analyze, dim3(ntiles), dim3(kChanThreads), chan_lds_bytes(g), x, hist, hist_new, p->taps.p,
+                    p->twA.p, p->twB.p, p->twM.p, p->active.p, g, n_frames, out, p->chan_stride, fused_ends ? p->tile_end.p : (d2 *)nullptr, p->dc_c);
+        p->hist_parity ^= 1;
+        CSDR_HIP_TRY(hipGetLastError());
+        if (dc0) rc = run_dc_blocker(p, out, out, n_frames, fused_ends, g.TF);
     }
-    const int64_t n_frames = n / M;
-    const ChanGeom &g = p->geom;
-    float2 *hist = p->hist_parity ? p->hist1.p : p->hist0.p, *hist_new = p->hist_parity ? p->hist0.p : p->hist1.p;
-    const int ntiles = (int)((n_frames + g.TF - 1) / g.TF);
-    CSDR_LAUNCH(p->ctx, KID_CHAN_ANALYZE, chan_analyze, dim3(ntiles), dim3(kChanThreads), chan_lds_bytes(g), x, hist, hist_new, p->taps.p,
-                p->twA.p, p->twB.p, p->twM.p, p->active.p, g, n_frames, p->out.p, p->chan_stride);
-    p->hist_parity ^= 1;
-    CSDR_HIP_TRY(hipGetLastError());
-    // channel 0 carries the DC spike: block it after de-interleave (:364-375)
-    if (!p->active_host.empty() && p->active_host[0] == 0) return run_dc_blocker(p, p->out.p, p->out.p, n_frames);
+    if (rc) return rc;
+    if (int rc2 = c->signal(p->ev_ready[k], LANE_POST, LANE_FE)) return rc2;
+    p->cur = k;
+    p->seq++;
     return CSDR_OK;
 }
 
@@ -356,8 +427,9 @@ extern "C" int csdr_post_read_channel(csdr_post *p, int ch, float *host_out, int
     if (ch < 0 || ch >= p->M) return fail(CSDR_EINVAL, "channel out of range");
     const int64_t cnt = (int64_t)p->n_blocks * (p->block_len / p->M);
     if (cnt > cap_samples) return fail(CSDR_ERANGE, "need %lld samples", (long long)cnt);
-    CSDR_HIP_TRY(hipMemcpyAsync(host_out, p->out.p + (int64_t)ch * p->chan_stride, (size_t)cnt * sizeof(float2), hipMemcpyDeviceToHost, p->ctx->stream));
-    CSDR_HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    hipStream_t st = p->ctx->lanes[LANE_POST];
+    CSDR_HIP_TRY(hipMemcpyAsync(host_out, post_buf(p, p->cur) + (int64_t)ch * p->chan_stride, (size_t)cnt * sizeof(float2), hipMemcpyDeviceToHost, st));
+    CSDR_HIP_TRY(hipStreamSynchronize(st));
     *n = (int)cnt;
     return CSDR_OK;
 }
@@ -390,9 +462,14 @@ struct csdr_bank {
     int max_demods = 0, max_blocks = 0;
     std::vector<SlotHost> slots;
     DevBuf<SlotCfg> cfgs;
-    DevBuf<SlotDyn> dyns;
-    DevBuf<int> slot_list;                   // [3][max_demods]: all running slots | running auto-gain slots | running slots grouped by front-end kernel
-    DevBuf<BlockPlan> plans;
+    // per-batch device tables, two copies: the front-end of batch i+1 uploads its set while the audio kernels of batch i
+    // still read theirs
+    DevBuf<SlotDyn> dyns;                    // [2][max_demods]
+    DevBuf<int> slot_list;                   // [2][3][max_demods]: all running slots | running auto-gain slots | grouped by front-end kernel
+    DevBuf<BlockPlan> plans;                 // [2][max_demods][max_blocks + 1]
+    uint64_t seq = 0;
+    hipEvent_t ev_fe_done[2] = {nullptr, nullptr}, ev_audio_done[2] = {nullptr, nullptr};
+    bool audio_pending[2] = {false, false};
     DevBuf<float> arms;
     DevBuf<ModemConsts> mconsts;
     PinBuf<SlotDyn> dyns_h[kStageRing];
@@ -418,7 +495,7 @@ static int bank_arm_bank(csdr_bank *b, const design::MsresampPlan &p, int *idx) 
     const size_t need = b->arms_host.size();
     if (need > b->arms.cap) {
         // grow: re-upload everything (cold path)
-        CSDR_HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+        if (int rc = b->ctx->sync_all()) return rc;
         if (int rc = b->arms.reserve(std::max(need, b->arms.cap * 2 + (size_t)kArms * kArmTaps * 8))) return rc;
         CSDR_HIP_TRY(hipMemcpy(b->arms.p, b->arms_host.data(), need * sizeof(float), hipMemcpyHostToDevice));
     } else {
@@ -449,9 +526,13 @@ extern "C" int csdr_bank_create(csdr_ctx *ctx, int max_demods, int max_blocks, c
     b->ctx = ctx; b->max_demods = max_demods; b->max_blocks = max_blocks;
     b->slots.resize(max_demods);
     if (int rc = b->cfgs.reserve(max_demods)) return rc;
-    if (int rc = b->dyns.reserve(max_demods)) return rc;
-    if (int rc = b->slot_list.reserve(3 * (size_t)max_demods)) return rc;
-    if (int rc = b->plans.reserve((size_t)max_demods * (max_blocks + 1))) return rc;
+    if (int rc = b->dyns.reserve(2 * (size_t)max_demods)) return rc;
+    if (int rc = b->slot_list.reserve(2 * 3 * (size_t)max_demods)) return rc;
+    if (int rc = b->plans.reserve(2 * (size_t)max_demods * (max_blocks + 1))) return rc;
+    for (int k = 0; k < 2; ++k) {
+        CSDR_HIP_TRY(hipEventCreateWithFlags(&b->ev_fe_done[k], hipEventDisableTiming));
+        CSDR_HIP_TRY(hipEventCreateWithFlags(&b->ev_audio_done[k], hipEventDisableTiming));
+    }
     if (int rc = b->mconsts.reserve(1)) return rc;
     for (int r = 0; r < kStageRing; ++r) {
         if (int rc = b->dyns_h[r].reserve(max_demods)) return rc;
@@ -477,7 +558,11 @@ extern "C" int csdr_bank_create(csdr_ctx *ctx, int max_demods, int max_blocks, c
 
 extern "C" void csdr_bank_destroy(csdr_bank *b) {
     if (!b) return;
-    (void)hipStreamSynchronize(b->ctx->stream);
+    (void)b->ctx->sync_all();
+    for (int k = 0; k < 2; ++k) {
+        if (b->ev_fe_done[k]) (void)hipEventDestroy(b->ev_fe_done[k]);
+        if (b->ev_audio_done[k]) (void)hipEventDestroy(b->ev_audio_done[k]);
+    }
     for (auto &s : b->slots) if (s.slab) (void)hipFree(s.slab);
     b->cfgs.release(); b->dyns.release(); b->slot_list.release(); b->plans.release(); b->arms.release(); b->mconsts.release();
     for (int r = 0; r < kStageRing; ++r) {
@@ -501,7 +586,7 @@ extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod
     if (prm->modem < CSDR_MODEM_NBFM || prm->modem > CSDR_MODEM_LSB) return fail(CSDR_EUNSUPPORTED, "modem %d", prm->modem);
     if (prm->bandwidth <= 0 || prm->audio_sample_rate <= 0) return fail(CSDR_EINVAL, "bad rates");
     SlotHost &s = b->slots[slot];
-    CSDR_HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    if (int rc = b->ctx->sync_all()) return rc;
     s.configured = false;
     s.prm = *prm;
     s.prm.bandwidth = modem_check_rate(prm->modem, prm->bandwidth);
@@ -587,9 +672,14 @@ static inline int64_t first_out(int64_t K, uint32_t phase0, uint32_t step) {
 extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     if (!b || !post) return fail(CSDR_EINVAL, "null argument");
     if (!post->configured || post->n_blocks <= 0) return fail(CSDR_ESTATE, "post has no data");
-    hipStream_t st = b->ctx->stream;
+    csdr_ctx *c = b->ctx;
+    hipStream_t st = c->lanes[LANE_FE], st_a = c->lanes[LANE_AUDIO];
     const int NB = post->n_blocks, M = post->M, Bc = post->block_len / M;
     if (NB > b->max_blocks) return fail(CSDR_ERANGE, "batch of %d blocks exceeds bank capacity %d", NB, b->max_blocks);
+    const int bpar = (int)(b->seq & 1);      // which copy of the per-batch device tables this batch uses
+    SlotDyn *dyns_d = b->dyns.p + (size_t)bpar * b->max_demods;
+    int *lists_d = b->slot_list.p + (size_t)bpar * 3 * b->max_demods;
+    BlockPlan *plans_d = b->plans.p + (size_t)bpar * b->max_demods * (b->max_blocks + 1);
     const int64_t rate = csdr_post_channel_bandwidth(post);
     // pinned staging set for this batch: wait only for the upload that last used it (kStageRing batches ago)
     const int ring = b->stage_next;
@@ -690,9 +780,17 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
             grp_n[k] = pos - grp_off[k];
         }
     }
-    CSDR_HIP_TRY(hipMemcpyAsync(b->dyns.p, dyns_h, b->max_demods * sizeof(SlotDyn), hipMemcpyHostToDevice, st));
-    CSDR_HIP_TRY(hipMemcpyAsync(b->slot_list.p, slot_list_h, 3 * (size_t)b->max_demods * sizeof(int), hipMemcpyHostToDevice, st));
-    CSDR_HIP_TRY(hipMemcpyAsync(b->plans.p, plans_h, (size_t)b->max_demods * (NB + 1) * sizeof(BlockPlan), hipMemcpyHostToDevice, st));
+    // lane FE: the channelizer output of this batch must be complete; the tables and the resampled-IQ buffers of this
+    // parity were last read by the audio kernels two batches ago
+    const int pk = post->cur;
+    if (post->ctx != c || !c->same(LANE_POST, LANE_FE)) {
+        if (post->ctx != c) CSDR_HIP_TRY(hipEventRecord(post->ev_ready[pk], post->ctx->lanes[LANE_POST]));
+        CSDR_HIP_TRY(hipStreamWaitEvent(st, post->ev_ready[pk], 0));
+    }
+    if (b->audio_pending[bpar]) if (int rc = c->wait(b->ev_audio_done[bpar], LANE_AUDIO, LANE_FE)) return rc;
+    CSDR_HIP_TRY(hipMemcpyAsync(dyns_d, dyns_h, b->max_demods * sizeof(SlotDyn), hipMemcpyHostToDevice, st));
+    CSDR_HIP_TRY(hipMemcpyAsync(lists_d, slot_list_h, 3 * (size_t)b->max_demods * sizeof(int), hipMemcpyHostToDevice, st));
+    CSDR_HIP_TRY(hipMemcpyAsync(plans_d, plans_h, (size_t)b->max_demods * (NB + 1) * sizeof(BlockPlan), hipMemcpyHostToDevice, st));
     CSDR_HIP_TRY(hipEventRecord(b->stage_ev[ring], st));
     b->stage_used[ring] = true;
     // front-end geometry: every slot's batch is cut into P ranges; a range re-runs `warm` inputs in front of it.
@@ -715,22 +813,42 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
             b->lds_attr[k] = want[k];
         }
     const dim3 grid(n_run, NB);
-    const int *grp_d = b->slot_list.p + 2 * (size_t)b->max_demods;
+    const float2 *chan_out = post_buf(post, pk);
+    const int *grp_d = lists_d + 2 * (size_t)b->max_demods;
     if (grp_n[0] > 0)
-        CSDR_LAUNCH(b->ctx, KID_FRONTEND, demod_frontend, dim3(P, grp_n[0]), dim3(kFeThreads), fe_lds, b->cfgs.p, b->dyns.p, grp_d + grp_off[0],
-                    post->out.p, post->chan_stride, total, b->arms.p, b->ctx->sintab.p);
-#define CSDR_FE_S(S_)                                                                                                                   \
+        CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, demod_frontend, dim3(P, grp_n[0]), dim3(kFeThreads), fe_lds, b->cfgs.p, dyns_d, grp_d + grp_off[0],
+                    chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
+#define CSDR_FE_S(S_, CH_)                                                                                                              \
     if (grp_n[S_] > 0)                                                                                                                  \
-        CSDR_LAUNCH(b->ctx, KID_FRONTEND, (demod_frontend_s<S_, 2048>), dim3(P + 1, grp_n[S_]), dim3(kFeThreads), (fes_lds_bytes<S_, 2048>()), \
-                    b->cfgs.p, b->dyns.p, grp_d + grp_off[S_], post->out.p, post->chan_stride, total, b->arms.p, b->ctx->sintab.p)
-    CSDR_FE_S(3); CSDR_FE_S(4); CSDR_FE_S(5); CSDR_FE_S(6);
+        CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, (demod_frontend_s<S_, CH_>), dim3(P + 1, grp_n[S_]), dim3(kFeThreads), (fes_lds_bytes<S_, CH_>()), \
+                    b->cfgs.p, dyns_d, grp_d + grp_off[S_], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p)
+    static const int fe_chunk = getenv("CSDR_FE_CHUNK") ? atoi(getenv("CSDR_FE_CHUNK")) : 2048;   // experiment knob
+    if (fe_chunk == 1024) { CSDR_FE_S(3, 1024); CSDR_FE_S(4, 1024); CSDR_FE_S(5, 1024); }
+    else { CSDR_FE_S(3, 2048); CSDR_FE_S(4, 2048); CSDR_FE_S(5, 2048); }
+    CSDR_FE_S(6, 2048);
 #undef CSDR_FE_S
+    CSDR_HIP_TRY(hipGetLastError());
+    // the front-end was the only reader of the channelizer buffer: hand it back to the post object's rotation
+    {
+        csdr_post *pw = const_cast<csdr_post *>(post);
+        if (pw->ctx != c || !c->same(LANE_POST, LANE_FE)) {
+            if (pw->n_consumed[pk] >= csdr_post::kMaxConsumers) return fail(CSDR_ERANGE, "too many demodulator banks read one channelizer batch");
+            CSDR_HIP_TRY(hipEventRecord(pw->ev_consumed[pk][pw->n_consumed[pk]++], st));
+        }
+    }
+    if (int rc = c->signal(b->ev_fe_done[bpar], LANE_FE, LANE_AUDIO)) return rc;
+    // lane AUDIO: modem + audio kernels of this batch
+    if (int rc = c->wait(b->ev_fe_done[bpar], LANE_FE, LANE_AUDIO)) return rc;
     if (n_ag > 0)     // freqdem modems need no block-wide pre-pass: only the auto-gain modems run the modem kernel
-        CSDR_LAUNCH(b->ctx, KID_MODEM, demod_modem, dim3(n_ag, NB), dim3(kModemThreads), modem_lds, b->cfgs.p, b->dyns.p, b->slot_list.p + b->max_demods,
-                    b->plans.p, NB, cap_stream, b->mconsts.p, b->ctx->sintab.p);
-    CSDR_LAUNCH(b->ctx, KID_AUDIO, demod_audio_interp, grid, dim3(kModemThreads), audio_lds, b->cfgs.p, b->dyns.p, b->slot_list.p, b->plans.p, NB,
+        CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, demod_modem, dim3(n_ag, NB), dim3(kModemThreads), modem_lds, b->cfgs.p, dyns_d, lists_d + b->max_demods,
+                    plans_d, NB, cap_stream, b->mconsts.p, c->sintab.p);
+    CSDR_LAUNCH(c, LANE_AUDIO, KID_AUDIO, demod_audio_interp, grid, dim3(kModemThreads), audio_lds, b->cfgs.p, dyns_d, lists_d, plans_d, NB,
                 cap_out, cap_win, b->arms.p);
     CSDR_HIP_TRY(hipGetLastError());
+    if (int rc = c->signal(b->ev_audio_done[bpar], LANE_AUDIO, LANE_FE)) return rc;
+    b->audio_pending[bpar] = true;
+    (void)st_a;
+    b->seq++;
     return CSDR_OK;
 }
 
@@ -742,8 +860,9 @@ extern "C" int csdr_bank_fetch_results(csdr_bank *b, int slot, csdr_block_result
     *n_blocks = nb;
     if (!nb) return CSDR_OK;
     if (!s.results[0].skipped) {
-        CSDR_HIP_TRY(hipMemcpyAsync(b->bout_h.p, s.cfg.bout, nb * sizeof(BlockOut), hipMemcpyDeviceToHost, b->ctx->stream));
-        CSDR_HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+        hipStream_t st = b->ctx->lanes[LANE_AUDIO];
+        CSDR_HIP_TRY(hipMemcpyAsync(b->bout_h.p, s.cfg.bout, nb * sizeof(BlockOut), hipMemcpyDeviceToHost, st));
+        CSDR_HIP_TRY(hipStreamSynchronize(st));
         for (int i = 0; i < nb; i++) {
             s.results[i].level_accum = b->bout_h.p[i].level_accum;
             s.results[i].level_count = b->bout_h.p[i].level_count;
@@ -759,8 +878,9 @@ extern "C" int csdr_bank_fetch_audio(csdr_bank *b, int slot, float *host_out, in
     if (s.last_A > cap_samples) return fail(CSDR_ERANGE, "need room for %d samples", s.last_A);
     *n = s.last_A;
     if (s.last_A) {
-        CSDR_HIP_TRY(hipMemcpyAsync(host_out, s.cfg.audio, (size_t)s.last_A * sizeof(float), hipMemcpyDeviceToHost, b->ctx->stream));
-        CSDR_HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+        hipStream_t st = b->ctx->lanes[LANE_AUDIO];
+        CSDR_HIP_TRY(hipMemcpyAsync(host_out, s.cfg.audio, (size_t)s.last_A * sizeof(float), hipMemcpyDeviceToHost, st));
+        CSDR_HIP_TRY(hipStreamSynchronize(st));
     }
     return CSDR_OK;
 }
@@ -771,8 +891,9 @@ extern "C" int csdr_bank_fetch_iq(csdr_bank *b, int slot, float *host_out, int c
     *n = s.last_J;
     if (s.last_J) {
         const float2 *cur = s.cfg.iq + (size_t)s.last_parity * ((size_t)kIqHist + s.cfg.cap_iq) + kIqHist;
-        CSDR_HIP_TRY(hipMemcpyAsync(host_out, cur, (size_t)s.last_J * sizeof(float2), hipMemcpyDeviceToHost, b->ctx->stream));
-        CSDR_HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+        hipStream_t st = b->ctx->lanes[LANE_FE];
+        CSDR_HIP_TRY(hipMemcpyAsync(host_out, cur, (size_t)s.last_J * sizeof(float2), hipMemcpyDeviceToHost, st));
+        CSDR_HIP_TRY(hipStreamSynchronize(st));
     }
     return CSDR_OK;
 }
@@ -792,7 +913,11 @@ struct csdr_spec {
     int max_frames = 0, nf_last = 0;
     float avg_rate = 0.65f, scale = 1.0f;
     DevBuf<float2> tw4096, tw_hi, tw_lo, tmp, carry, stage_in, raw;
-    DevBuf<float> mag, pairsum, first_b, points;
+    DevBuf<float> mag;                       // [2][max_frames][N]: the FFT lane fills one copy while the averaging lane reads the other
+    DevBuf<float> pairsum, first_b, points;
+    uint64_t seq = 0;
+    hipEvent_t ev_fft_done[2] = {nullptr, nullptr}, ev_avg_done[2] = {nullptr, nullptr};
+    bool avg_pending[2] = {false, false};
     DevBuf<double> ma, maa;
     DevBuf<float2> ext_w, ext;
     int n_avg_tiles = 0, scal_parity = 0;
@@ -803,13 +928,22 @@ struct csdr_spec {
 
 extern "C" int csdr_spec_create(csdr_ctx *ctx, csdr_spec **out) {
     if (!ctx || !out) return fail(CSDR_EINVAL, "null argument");
-    *out = new csdr_spec();
-    (*out)->ctx = ctx;
+    std::unique_ptr<csdr_spec> s(new csdr_spec());
+    s->ctx = ctx;
+    for (int k = 0; k < 2; ++k) {
+        CSDR_HIP_TRY(hipEventCreateWithFlags(&s->ev_fft_done[k], hipEventDisableTiming));
+        CSDR_HIP_TRY(hipEventCreateWithFlags(&s->ev_avg_done[k], hipEventDisableTiming));
+    }
+    *out = s.release();
     return CSDR_OK;
 }
 extern "C" void csdr_spec_destroy(csdr_spec *s) {
     if (!s) return;
-    (void)hipStreamSynchronize(s->ctx->stream);
+    (void)s->ctx->sync_all();
+    for (int k = 0; k < 2; ++k) {
+        if (s->ev_fft_done[k]) (void)hipEventDestroy(s->ev_fft_done[k]);
+        if (s->ev_avg_done[k]) (void)hipEventDestroy(s->ev_avg_done[k]);
+    }
     s->tw4096.release(); s->tw_hi.release(); s->tw_lo.release(); s->tmp.release(); s->carry.release();
     s->stage_in.release(); s->raw.release(); s->mag.release(); s->ext_w.release(); s->ext.release(); s->pairsum.release(); s->first_b.release(); s->points.release();
     s->ma.release(); s->maa.release(); s->fo.release(); s->scal.release();
@@ -824,9 +958,9 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     if (max_frames <= 0) return fail(CSDR_EINVAL, "max_frames");
     const int N = 2 * fft_size;                                      // SPECTRUM_VZM 2, SpectrumVisualProcessor.h:11, .cpp:145
     if (N > (1 << 22)) return fail(CSDR_EUNSUPPORTED, "internal FFT of %d points exceeds 2^22", N);
-    hipStream_t st = s->ctx->stream;
-    CSDR_HIP_TRY(hipStreamSynchronize(st));
+    if (int rc = s->ctx->sync_all()) return rc;
     s->ready = false;
+    s->seq = 0; s->avg_pending[0] = s->avg_pending[1] = false;
     SpecGeom &g = s->g;
     g.N = N; g.F = fft_size; g.Ra = 1; g.Rb = 1; g.N2 = N;
     if (N >= 4096) {
@@ -849,7 +983,7 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     CSDR_HIP_TRY(hipMemcpy(s->tw_hi.p, hi.data(), hi.size() * sizeof(float2), hipMemcpyHostToDevice));
     const size_t nfN = (size_t)max_frames * N, F = (size_t)g.F;
     if (g.Ra > 1) if (int rc = s->tmp.reserve(nfN)) return rc;
-    if (int rc = s->mag.reserve(nfN)) return rc;
+    if (int rc = s->mag.reserve(2 * nfN)) return rc;
     s->n_avg_tiles = (g.F + kAvgLanes - 1) / kAvgLanes;
     if (int rc = s->ext_w.reserve((size_t)max_frames * s->n_avg_tiles)) return rc;
     if (int rc = s->ext.reserve(max_frames)) return rc;
@@ -880,11 +1014,11 @@ static void launch_radix(csdr_ctx *c, int R, const FrameSrc &fs, int L, unsigned
     const int Lr = L / R;
     const dim3 grid((Lr / COLS + kFftThreads - 1) / kFftThreads, nseq), block(kFftThreads);
     switch (R) {
-        case 2: CSDR_LAUNCH(c, KID_FFT_COLS, (spec_fft_radix<2, COLS>), grid, block, 0, fs, L, tw_scale, hi, lo, dst); break;
-        case 4: CSDR_LAUNCH(c, KID_FFT_COLS, (spec_fft_radix<4, COLS>), grid, block, 0, fs, L, tw_scale, hi, lo, dst); break;
-        case 8: CSDR_LAUNCH(c, KID_FFT_COLS, (spec_fft_radix<8, COLS>), grid, block, 0, fs, L, tw_scale, hi, lo, dst); break;
-        case 16: CSDR_LAUNCH(c, KID_FFT_COLS, (spec_fft_radix<16, COLS>), grid, block, 0, fs, L, tw_scale, hi, lo, dst); break;
-        default: CSDR_LAUNCH(c, KID_FFT_COLS, (spec_fft_radix<32, COLS>), grid, block, 0, fs, L, tw_scale, hi, lo, dst); break;
+        case 2: CSDR_LAUNCH(c, LANE_FFT, KID_FFT_COLS, (spec_fft_radix<2, COLS>), grid, block, 0, fs, L, tw_scale, hi, lo, dst); break;
+        case 4: CSDR_LAUNCH(c, LANE_FFT, KID_FFT_COLS, (spec_fft_radix<4, COLS>), grid, block, 0, fs, L, tw_scale, hi, lo, dst); break;
+        case 8: CSDR_LAUNCH(c, LANE_FFT, KID_FFT_COLS, (spec_fft_radix<8, COLS>), grid, block, 0, fs, L, tw_scale, hi, lo, dst); break;
+        case 16: CSDR_LAUNCH(c, LANE_FFT, KID_FFT_COLS, (spec_fft_radix<16, COLS>), grid, block, 0, fs, L, tw_scale, hi, lo, dst); break;
+        default: CSDR_LAUNCH(c, LANE_FFT, KID_FFT_COLS, (spec_fft_radix<32, COLS>), grid, block, 0, fs, L, tw_scale, hi, lo, dst); break;
     }
 }
 
@@ -892,9 +1026,9 @@ static int spec_run_fft(csdr_spec *s, const FrameSrc &fs, int nf, float *mag, fl
     const SpecGeom &g = s->g;
     csdr_ctx *c = s->ctx;
     if (g.N < 4096) {
-        CSDR_LAUNCH(c, KID_FFT_ROWS, spec_fft_small, dim3(1, nf), dim3(kFftThreads), (size_t)2 * g.N * sizeof(float2), fs, g.N, s->tw4096.p, mag, raw);
+        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_small, dim3(1, nf), dim3(kFftThreads), (size_t)2 * g.N * sizeof(float2), fs, g.N, s->tw4096.p, mag, raw);
     } else if (g.Ra == 1) {
-        CSDR_LAUNCH(c, KID_FFT_ROWS, spec_fft_rows4096, dim3(1, nf), dim3(kFftThreads), kRowLdsPts * sizeof(float2), fs, g, s->tw4096.p, mag, raw);
+        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_rows4096, dim3(1, nf), dim3(kFftThreads), kRowLdsPts * sizeof(float2), fs, g, s->tw4096.p, mag, raw);
     } else {
         // radix passes: Ra-point columns of each frame, then (optionally) Rb-point columns inside each of the Ra sub-sequences
         if (g.Ra <= 16) launch_radix<2>(c, g.Ra, fs, g.N, 1u, nf, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
@@ -906,7 +1040,7 @@ static int spec_run_fft(csdr_spec *s, const FrameSrc &fs, int nf, float *mag, fl
             else launch_radix<1>(c, g.Rb, sub, L2, (unsigned)g.Ra, nf * g.Ra, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
         }
         FrameSrc rows{s->tmp.p, nullptr, s->tmp.p + g.N, g.N, 1 << 30};
-        CSDR_LAUNCH(c, KID_FFT_ROWS, spec_fft_rows4096, dim3(g.Ra * g.Rb, nf), dim3(kFftThreads), kRowLdsPts * sizeof(float2), rows, g,
+        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_rows4096, dim3(g.Ra * g.Rb, nf), dim3(kFftThreads), kRowLdsPts * sizeof(float2), rows, g,
                     s->tw4096.p, mag, raw);
     }
     CSDR_HIP_TRY(hipGetLastError());
@@ -916,11 +1050,13 @@ static int spec_run_fft(csdr_spec *s, const FrameSrc &fs, int nf, float *mag, fl
 extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, int n_blocks, int block_len, int mode) {
     if (!s || !s->ready) return fail(CSDR_ESTATE, "spec not set up");
     if (!iq || n_blocks <= 0 || block_len <= 0) return fail(CSDR_EINVAL, "bad block arguments");
-    hipStream_t st = s->ctx->stream;
+    csdr_ctx *c = s->ctx;
+    hipStream_t st = c->lanes[LANE_FFT], st_y = c->lanes[LANE_AVG];
     const SpecGeom &g = s->g;
     const int N = g.N;
     const int64_t n = (int64_t)n_blocks * block_len;
     const float2 *x = (const float2 *)iq;
+    if (int rc = c->lane_begin(LANE_FFT)) return rc;
     if (!iq_is_dev) {
         if (int rc = s->stage_in.reserve((size_t)n)) return rc;
         CSDR_HIP_TRY(hipMemcpyAsync(s->stage_in.p, iq, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, st));
@@ -945,17 +1081,29 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
     if (nf > s->max_frames) return fail(CSDR_ERANGE, "%d frames exceed max_frames %d", nf, s->max_frames);
     s->nf_last = nf;
     if (nf > 0) {
-        if (int rc = spec_run_fft(s, fs, nf, s->mag.p, nullptr)) return rc;
-        CSDR_LAUNCH(s->ctx, KID_SPEC_AVG, spec_average, dim3(s->n_avg_tiles), dim3(kAvgThreads), kAvgLds, s->mag.p, nf, g, (double)s->avg_rate,
+        // lane FFT fills magnitude copy `mp`; its previous reader was the averaging kernel two batches ago
+        const int mp = (int)(s->seq & 1);
+        float *mag = s->mag.p + (size_t)mp * s->max_frames * N;
+        if (s->avg_pending[mp]) if (int rc = c->wait(s->ev_avg_done[mp], LANE_AVG, LANE_FFT)) return rc;
+        if (int rc = spec_run_fft(s, fs, nf, mag, nullptr)) return rc;
+        if (int rc = c->signal(s->ev_fft_done[mp], LANE_FFT, LANE_AVG)) return rc;
+        // lane AVG: averaging, extrema, trackers + display points
+        if (int rc = c->wait(s->ev_fft_done[mp], LANE_FFT, LANE_AVG)) return rc;
+        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_average, dim3(s->n_avg_tiles), dim3(kAvgThreads), kAvgLds, mag, nf, g, (double)s->avg_rate,
                     s->ma.p, s->maa.p, s->pairsum.p, s->first_b.p, s->ext_w.p);
-        CSDR_LAUNCH(s->ctx, KID_SPEC_TRACK, spec_extrema, dim3(nf), dim3(256), 64, s->ext_w.p, s->n_avg_tiles, s->ext.p);
-        CSDR_LAUNCH(s->ctx, KID_SPEC_DISPLAY, spec_display, dim3((g.F / 2 + kDispThreads - 1) / kDispThreads, nf), dim3(kDispThreads), kDispLds, s->pairsum.p, s->first_b.p,
-                    s->ext.p, nf, g.F, s->scale, s->scal.p + s->scal_parity, s->scal.p + (s->scal_parity ^ 1), s->fo.p, s->points.p);
+        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_extrema, dim3(nf), dim3(256), 64, s->ext_w.p, s->n_avg_tiles, s->ext.p);
+        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_DISPLAY, spec_display, dim3((g.F / 2 + kDispThreads - 1) / kDispThreads, nf), dim3(kDispThreads), kDispLds,
+                    s->pairsum.p, s->first_b.p, s->ext.p, nf, g.F, s->scale, s->scal.p + s->scal_parity, s->scal.p + (s->scal_parity ^ 1), s->fo.p,
+                    s->points.p);
         s->scal_parity ^= 1;
         CSDR_HIP_TRY(hipGetLastError());
+        if (int rc = c->signal(s->ev_avg_done[mp], LANE_AVG, LANE_FFT)) return rc;
+        s->avg_pending[mp] = true;
+        (void)st_y;
+        s->seq++;
     }
     if (mode == CSDR_SPEC_CONTIGUOUS) {
-        // new carry = samples after the last whole frame
+        // new carry = samples after the last whole frame (lane FFT: ordered behind the kernels that read the old carry)
         const int64_t total = s->carry_len + n;
         const int rem = (int)(total - (int64_t)nf * N);
         if (nf == 0) {
@@ -973,7 +1121,7 @@ extern "C" int csdr_spec_fetch(csdr_spec *s, int frame, float *points_host, int 
     if (frame < 0 || frame >= s->nf_last) return fail(CSDR_EINVAL, "frame %d of %d", frame, s->nf_last);
     const int F = s->g.F;
     if (cap_floats < 2 * F) return fail(CSDR_ERANGE, "need %d floats", 2 * F);
-    hipStream_t st = s->ctx->stream;
+    hipStream_t st = s->ctx->lanes[LANE_AVG];
     SpecFrameOut fo;
     CSDR_HIP_TRY(hipMemcpyAsync(points_host, s->points.p + (size_t)frame * 2 * F, (size_t)2 * F * sizeof(float), hipMemcpyDeviceToHost, st));
     CSDR_HIP_TRY(hipMemcpyAsync(&fo, s->fo.p + frame, sizeof fo, hipMemcpyDeviceToHost, st));
@@ -985,7 +1133,7 @@ extern "C" int csdr_spec_fetch(csdr_spec *s, int frame, float *points_host, int 
 
 extern "C" int csdr_spec_fft_only(csdr_spec *s, const float *iq_host, float *out_host) {
     if (!s || !s->ready || !iq_host || !out_host) return fail(CSDR_EINVAL, "bad argument");
-    hipStream_t st = s->ctx->stream;
+    hipStream_t st = s->ctx->lanes[LANE_FFT];
     const int N = s->g.N;
     if (int rc = s->stage_in.reserve((size_t)N)) return rc;
     if (int rc = s->raw.reserve((size_t)N)) return rc;

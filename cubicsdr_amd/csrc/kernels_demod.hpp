@@ -456,7 +456,17 @@ __device__ inline void fes_carry_tail(float2 *__restrict__ LE, float2 *__restric
     }
 }
 
-template <int S, int CH, int E>
+// Stages [0, fes_blk) run on the whole workgroup, one barrier each; when the remaining stages are small enough for
+// one wave (<= 64 output pairs, and <= 64 chain outputs for the resampler) they run on wave 0 alone with wave-level
+// hand-offs while the other waves already start on the next chunk.
+template <int S, int CH>
+__host__ __device__ constexpr int fes_blk() {
+    if ((CH >> S) > 64) return S;                                  // resampler needs more than one wave: no wave tail
+    int e = 0;
+    while (e < S && (CH >> (e + 2)) > 64) ++e;
+    return e;
+}
+template <int S, int CH, int E, int END, bool WAVE>
 struct FesStages {
     static __device__ inline void run(float2 *LE, float2 *LO, float2 *LZ, const float *hb, float zeta) {
         constexpr int CNT = CH >> (E + 1);                       // outputs of stage E
@@ -464,14 +474,25 @@ struct FesStages {
         const float2 *Ein = LE + fes_off<CH>(E) + kFeTail, *Oin = LO + fes_off<CH>(E) + kFeTail;
         if constexpr (E == S - 1) fes_stage_last<CNT>(Ein, Oin, hb + E * kHbMaxM, zeta, LZ + kFeZTail);
         else fes_stage_pairs<M, CNT>(Ein, Oin, hb + E * kHbMaxM, LE + fes_off<CH>(E + 1) + kFeTail, LO + fes_off<CH>(E + 1) + kFeTail);
-        // the tail of the PREVIOUS stage's input region is free to move now (its consumer finished at the last barrier)
-        if constexpr (E >= 1) fes_carry_tail<(CH >> E)>(LE, LO, fes_off<CH>(E - 1));
-        __syncthreads();
-        FesStages<S, CH, E + 1>::run(LE, LO, LZ, hb, zeta);
+        if constexpr (!WAVE) {
+            // the tail of the PREVIOUS stage's input region is free to move now (its consumer finished at the last barrier)
+            if constexpr (E >= 1) fes_carry_tail<(CH >> E)>(LE, LO, fes_off<CH>(E - 1));
+            __syncthreads();
+        } else {
+            // wave 0 alone: its own stage input is free once every lane has read it
+            wave_sync();
+            const int c = (int)threadIdx.x;
+            if (c < 2 * kFeTail) {
+                float2 *arr = c < kFeTail ? LE : LO;
+                const int k = c < kFeTail ? c : c - kFeTail;
+                arr[fes_off<CH>(E) + k] = arr[fes_off<CH>(E) + (CH >> (E + 1)) + k];
+            }
+        }
+        FesStages<S, CH, E + 1, END, WAVE>::run(LE, LO, LZ, hb, zeta);
     }
 };
-template <int S, int CH>
-struct FesStages<S, CH, S> {
+template <int S, int CH, int END, bool WAVE>
+struct FesStages<S, CH, END, END, WAVE> {
     static __device__ inline void run(float2 *, float2 *, float2 *, const float *, float) {}
 };
 
@@ -601,9 +622,13 @@ __global__ __launch_bounds__(kFeThreads, 4) void demod_frontend_s(
         __syncthreads();
         // the previous chunk's resampler is done (barrier above): its Z tail may move to the front now
         if (uc > u_lo && tid >= kFeThreads - kFeZTail) { const int k = tid - (kFeThreads - kFeZTail); LZ[k] = LZ[CZ + k]; }
-        FesStages<S, CH, 0>::run(LE, LO, LZ, hb, zeta);
-        // ---- tail of the last stage's input region, then the arbitrary resampler on Z
-        fes_carry_tail<(CH >> S)>(LE, LO, fes_off<CH>(S - 1));
+        constexpr int BLK = fes_blk<S, CH>();
+        FesStages<S, CH, 0, BLK, false>::run(LE, LO, LZ, hb, zeta);
+        // tail of the last block-wide stage's input region (threads 208 .. 255)
+        if constexpr (BLK >= 1) fes_carry_tail<(CH >> BLK)>(LE, LO, fes_off<CH>(BLK - 1));
+        if (BLK < S && tid >= 64) continue;                      // waves 1..3 go on to the next chunk
+        FesStages<S, CH, BLK, S, true>::run(LE, LO, LZ, hb, zeta);
+        // ---- the arbitrary resampler on Z
         if (jmine < jhi) {
             const float2 *z = LZ + kFeZTail + kj - (kArmTaps - 1);
             float ar = 0.f, ai = 0.f;
@@ -848,9 +873,34 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
         }
         s_d[i] = x;
     }
+    // the filter arms of this thread's first two arbitrary-stage outputs travel while the staging above lands
+    float2 hv[2][kArmTaps / 2];
+    int zoff[2] = {0, 0};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = tid + r * kModemThreads;
+        if (i < nv) {
+            const int64_t P = (int64_t)dyn.aphase0 + (lo[0] + i) * (int64_t)au.step;
+            zoff[r] = (int)((P >> 24) - (kArmTaps - 1) - jlo);
+            const float2 *h2 = reinterpret_cast<const float2 *>(arms + (int)((P & 0xFFFFFF) >> 16) * kArmTaps);
+#pragma unroll
+            for (int t = 0; t < kArmTaps / 2; ++t) hv[r][t] = h2[t];
+        }
+    }
     __syncthreads();
     // 1. arbitrary stage: v[q] for q in [lo[0], hi[0]) into s_w0
-    for (int i = tid; i < nv; i += kModemThreads) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = tid + r * kModemThreads;
+        if (i < nv) {
+            const float *z = s_d + zoff[r];
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < kArmTaps / 2; ++t) { acc = fmaf(hv[r][t].x, z[2 * t], acc); acc = fmaf(hv[r][t].y, z[2 * t + 1], acc); }
+            s_w0[i] = acc;
+        }
+    }
+    for (int i = tid + 2 * kModemThreads; i < nv; i += kModemThreads) {
         const int64_t q = lo[0] + i;
         const int64_t P = (int64_t)dyn.aphase0 + q * (int64_t)au.step;
         const int64_t jq = P >> 24;

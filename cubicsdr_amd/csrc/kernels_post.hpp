@@ -90,35 +90,63 @@ __global__ __launch_bounds__(kDcThreads) void dc_tile_ends(const float2 *__restr
     if (threadIdx.x == 0) tile_end[blockIdx.x] = total;
 }
 
-// pass 2: entering state of tile T = A^T state_in + sum_{i<T} A^(T-1-i) tile_end[i]  (A = c^tile), then recompute with
-// the true entering state and write y (in place allowed); the last tile stores the new carried state in state_out.
-__global__ __launch_bounds__(kDcThreads) void dc_apply(const float2 *x, float2 *y, int64_t n, double c,
+// inclusive scan of V[t+1] = a V[t] + b[t] over the 256 threads of the workgroup (same multiplier `a` for every
+// thread): Kogge-Stone inside each wave with shuffles (multipliers a^(2^k)), wave totals through LDS.
+// Returns the value ENTERING thread t's segment, given v_in entering thread 0.
+__device__ inline d2 dc_scan256(d2 b, double a, d2 v_in, d2 *lds4) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    d2 cur = b;
+    double ap = a;                                           // a^(2^k)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double ox = __shfl_up(cur.x, 1u << k, 64), oy = __shfl_up(cur.y, 1u << k, 64);
+        if (lane >= (1 << k)) { cur.x += ap * ox; cur.y += ap * oy; }
+        ap *= ap;
+    }
+    // ap == a^64 now; cur = inclusive value of this thread inside its wave (zero entering state)
+    if (lane == 63) lds4[w] = cur;
+    double px = __shfl_up(cur.x, 1, 64), py = __shfl_up(cur.y, 1, 64);   // exclusive inside the wave
+    if (lane == 0) { px = 0.0; py = 0.0; }
+    __syncthreads();
+    d2 pre = v_in;                                           // value entering this wave
+    for (int u = 0; u < w; ++u) { const d2 t = lds4[u]; pre.x = ap * pre.x + t.x; pre.y = ap * pre.y + t.y; }
+    const double al = dc_pow(a, lane);
+    __syncthreads();
+    return d2{al * pre.x + px, al * pre.y + py};
+}
+
+// pass 2: block = kDcTile consecutive samples.  The entering state of the block comes from the carried state and the
+// end values e_i (zero entering state) of the mini-tiles of `tile_len` samples before it:
+//     v_in(n0) = c^n0 state + sum_{i < n0 / tile_len} c^(n0 - (i+1) tile_len) e_i
+// (terms older than ~80000 samples are below 1e-17 of the newest and are dropped), then the recurrence is re-run with
+// that state and y is written (in place allowed); the block holding the last sample stores the new carried state.
+__global__ __launch_bounds__(kDcThreads) void dc_apply(const float2 *x, float2 *y, int64_t n, double c, int tile_len,
                                                        const d2 *__restrict__ tile_end, const d2 *__restrict__ state_in,
                                                        d2 *__restrict__ state_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *sx = reinterpret_cast<float2 *>(smem);
     d2 *sb = reinterpret_cast<d2 *>(smem + kDcTile * sizeof(float2));
-    double *sa = reinterpret_cast<double *>(smem + kDcTile * sizeof(float2) + kDcThreads * sizeof(d2));
-    const int T = blockIdx.x, tid = threadIdx.x;
-    const int64_t base = (int64_t)T * kDcTile;
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * kDcTile;
     dc_stage_in(x, n, base, sx);
-    // carry from the tiles before this one
-    const double A = dc_pow(c, kDcTile);
+    // carry from the mini-tiles before this block
+    const int64_t m0 = base / tile_len;                      // kDcTile is a multiple of tile_len
+    const int64_t reach = (80000 + tile_len - 1) / tile_len;
+    const int64_t mlo = m0 > reach ? m0 - reach : 0;
+    const double A = dc_pow(c, tile_len);
     d2 part = {0.0, 0.0};
-    for (int i = tid; i < T; i += kDcThreads) {
-        const double w = dc_pow(A, T - 1 - i);
+    for (int64_t i = mlo + tid; i < m0; i += kDcThreads) {
+        const double w = dc_pow(A, (int)(m0 - 1 - i));
         const d2 e = tile_end[i];
         part.x += w * e.x; part.y += w * e.y;
     }
-    sb[tid] = part;
+    for (int o = 32; o > 0; o >>= 1) { part.x += __shfl_down(part.x, o, 64); part.y += __shfl_down(part.y, o, 64); }
+    if ((tid & 63) == 0) sb[tid >> 6] = part;
     __syncthreads();
-    for (int off = kDcThreads / 2; off > 0; off >>= 1) {
-        if (tid < off) { sb[tid].x += sb[tid + off].x; sb[tid].y += sb[tid + off].y; }
-        __syncthreads();
-    }
     const d2 s0 = state_in[0];
-    const double wT = dc_pow(A, T);
-    const d2 v_tile = {wT * s0.x + sb[0].x, wT * s0.y + sb[0].y};
+    const double wT = base < 200000 ? dc_pow(c, (int)base) : 0.0;
+    d2 v_tile = {wT * s0.x, wT * s0.y};
+    for (int u = 0; u < kDcThreads / 64; ++u) { v_tile.x += sb[u].x; v_tile.y += sb[u].y; }
     __syncthreads();
 
     d2 v = {0.0, 0.0};
@@ -126,8 +154,7 @@ __global__ __launch_bounds__(kDcThreads) void dc_apply(const float2 *x, float2 *
         float2 s = sx[tid * kDcSeg + i];
         v.x = (double)s.x + c * v.x; v.y = (double)s.y + c * v.y;
     }
-    d2 ent = dc_block_scan(v, dc_pow(c, kDcSeg), v_tile, sb, sa, nullptr);
-    v = ent;
+    v = dc_scan256(v, dc_pow(c, kDcSeg), v_tile, sb);
     for (int i = 0; i < kDcSeg; ++i) {
         int64_t g = base + tid * kDcSeg + i;
         float2 s = sx[tid * kDcSeg + i];
@@ -194,7 +221,8 @@ __global__ __launch_bounds__(kChanThreads) void chan_analyze(
     const float2 *__restrict__ twM,      // [A][B]  exp(-j 2 pi k1 c2 / M) at [k1 B + c2]
     const int *__restrict__ active,      // [M] 1: store channel row k
     ChanGeom g, int64_t n_frames,
-    float2 *__restrict__ out, int64_t out_stride) {
+    float2 *__restrict__ out, int64_t out_stride,
+    d2 *__restrict__ dc_ends, double dc_c /* DC blocker of channel 0: end value of this tile's recurrence (zero entering state) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = g.M, A = g.A, B = g.B, TF = g.TF, S = g.S;
     float2 *s_x = reinterpret_cast<float2 *>(smem);
@@ -308,10 +336,25 @@ __global__ __launch_bounds__(kChanThreads) void chan_analyze(
             }
             const int k = k1 + A * k2b;
             float2 *o = out + (int64_t)k * out_stride + f0 + t;
+            if (k == 0 && dc_ends) s_x[t] = acc0;                 // channel 0 of this tile (s_x is free after phase 1)
             if (active[k]) o[0] = acc0;
             if (k2b + 1 < B && active[k + A]) o[(int64_t)A * out_stride] = acc1;
             if (k2b + 2 < B && active[k + 2 * A]) o[(int64_t)2 * A * out_stride] = acc2;
             if (k2b + 3 < B && active[k + 3 * A]) o[(int64_t)3 * A * out_stride] = acc3;
+        }
+    }
+    if (dc_ends) {
+        // v_end = sum_t c^(nf-1-t) y0[t]: the DC blocker's state after this tile if it entered with zero (iirfilt, :375)
+        __syncthreads();
+        if (wave == 0) {
+            double vx = 0.0, vy = 0.0;
+            for (int t = lane; t < nf; t += 64) {
+                const double wgt = dc_pow(dc_c, nf - 1 - t);
+                const float2 v = s_x[t];
+                vx += wgt * (double)v.x; vy += wgt * (double)v.y;
+            }
+            for (int o = 32; o > 0; o >>= 1) { vx += __shfl_down(vx, o, 64); vy += __shfl_down(vy, o, 64); }
+            if (lane == 0) dc_ends[blockIdx.x] = d2{vx, vy};
         }
     }
 }

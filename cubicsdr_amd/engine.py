@@ -32,7 +32,8 @@ def _as_iq_arg(iq):
 
 
 class Context:
-    """device + stream (csdr_ctx).  stream=None creates a private stream; pass torch's raw stream to share it."""
+    """device + streams (csdr_ctx): one internal HIP stream per pipeline stage; `stream` is the boundary stream the
+    caller's own GPU work is ordered on (None creates a private one; pass torch's raw stream to chain with torch)."""
 
     def __init__(self, device=0, stream=None):
         self._l = H.lib()
@@ -41,6 +42,10 @@ class Context:
 
     def synchronize(self):
         H.check(self._l.csdr_ctx_synchronize(self.h))
+
+    def join(self):
+        """the boundary stream waits for everything enqueued on the internal stage streams so far"""
+        H.check(self._l.csdr_ctx_join(self.h))
 
     def timer_start(self):
         H.check(self._l.csdr_ctx_timer_start(self.h))

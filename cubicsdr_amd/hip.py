@@ -40,6 +40,7 @@ ABI = {
     "csdr_ctx_create": (_i, [_i, _p, _pp]),
     "csdr_ctx_destroy": (None, [_p]),
     "csdr_ctx_synchronize": (_i, [_p]),
+    "csdr_ctx_join": (_i, [_p]),
     "csdr_ctx_stream": (_p, [_p]),
     "csdr_ctx_timer_start": (_i, [_p]),
     "csdr_ctx_timer_stop": (_i, [_p, C.POINTER(_f)]),

@@ -42,16 +42,26 @@ int         csdr_abi_version(void);
 const char *csdr_strerror(int code);
 const char *csdr_last_error(void);                 /* thread-local detail string of the last failure */
 
-/* `hip_stream`: an existing hipStream_t to launch on (e.g. PyTorch's current stream) or NULL to create one. */
+/* Streams.  The reference runs one IOThread per stage (SDRPostThread, DemodulatorPreThread/DemodulatorThread per
+ * demodulator, SpectrumVisualDataThread) joined by queues, so block i+1 is channelized while block i is demodulated.
+ * The ctx mirrors that with one internal HIP stream per stage (channelizer, demodulator front-end, modem + audio,
+ * spectrum FFT, spectrum averaging + display); events order the hand-offs and the buffer rotations, so consecutive
+ * *_execute / *_process calls overlap on the device and every call returns as soon as its work is enqueued.
+ * `hip_stream` is the BOUNDARY stream: an existing hipStream_t (e.g. PyTorch's current stream) on which the caller
+ * produces device-resident IQ -- every execute first waits for what is enqueued there -- or NULL for a private one.
+ * csdr_ctx_join makes the boundary stream wait for everything enqueued so far (for consumers chained on it);
+ * csdr_ctx_synchronize blocks the host until all of it is done.  The fetch / read calls synchronise what they need. */
 int  csdr_ctx_create(int device, void *hip_stream, csdr_ctx **out);
 void csdr_ctx_destroy(csdr_ctx *ctx);
 int  csdr_ctx_synchronize(csdr_ctx *ctx);
-void *csdr_ctx_stream(csdr_ctx *ctx);              /* the hipStream_t every kernel of this ctx is launched on */
-/* HIP-event timer on the ctx stream (bench.py roofline leg): start/stop bracket, returns milliseconds. */
+int  csdr_ctx_join(csdr_ctx *ctx);
+void *csdr_ctx_stream(csdr_ctx *ctx);              /* the boundary hipStream_t */
+/* HIP-event timer (bench.py roofline leg): start / stop marks on the boundary stream, joined with every internal
+ * stream on both sides, so the bracket covers exactly the work enqueued between the two calls; returns milliseconds. */
 int  csdr_ctx_timer_start(csdr_ctx *ctx);
 int  csdr_ctx_timer_stop(csdr_ctx *ctx, float *ms);
 /* Optional per-kernel profile: while enabled every kernel launch of this ctx is bracketed by HIP events on the
- * ctx stream; fetch returns the accumulated device time and launch count of kernel `id` (0 .. num_kernels-1). */
+ * stream it is launched on; fetch returns the accumulated device time and launch count of kernel `id`. */
 int  csdr_ctx_profile_enable(csdr_ctx *ctx, int on);
 int  csdr_ctx_profile_num_kernels(void);
 const char *csdr_ctx_profile_kernel_name(int id);

@@ -11,7 +11,7 @@
 //
 // Model: one workgroup at a time; every work-item is a std::thread; __syncthreads() is a std::barrier; a work-item
 // that returns from the kernel drops out of the barrier (as an exited wave does on the hardware); dynamic LDS is one
-// global buffer; wave64 cross-lane ops go through an exchange buffer and require block-uniform control flow.
+// global buffer; wave64 cross-lane ops go through an exchange buffer and a per-wave barrier (wave-uniform control flow).
 #pragma once
 #include <algorithm>
 #include <barrier>
@@ -61,6 +61,7 @@ namespace hip_emu {
 struct State {
     dim3 grid, block;
     std::unique_ptr<std::barrier<>> bar;   // __syncthreads of the running workgroup
+    std::unique_ptr<std::barrier<>> wbar[16];   // wave-level barriers (64 work-items each)
     unsigned char xch[1024][16];           // cross-lane exchange
 };
 State &state();
@@ -74,13 +75,13 @@ inline T lane_exchange(T v, int src_lane_in_wave, bool valid) {
     State &s = state();
     const unsigned tid = flat_tid();
     std::memcpy(s.xch[tid], &v, sizeof(T));
-    sync();
+    s.wbar[tid >> 6]->arrive_and_wait();           // cross-lane ops involve the 64 lanes of one wave only
     T r = v;
     if (valid) {
         const unsigned src = (tid & ~63u) + (unsigned)src_lane_in_wave;
         if (src < s.block.x) std::memcpy(&r, s.xch[src], sizeof(T));
     }
-    sync();
+    s.wbar[tid >> 6]->arrive_and_wait();
     return r;
 }
 }  // namespace hip_emu
@@ -92,6 +93,9 @@ inline T lane_exchange(T v, int src_lane_in_wave, bool valid) {
 static const int warpSize = 64;
 
 static inline void __syncthreads() { hip_emu::sync(); }
+// wave-level synchronisation: on the device the 64 lanes run in lockstep; here they are 64 host threads
+static inline void __builtin_amdgcn_wave_barrier() { hip_emu::state().wbar[hip_emu::flat_tid() >> 6]->arrive_and_wait(); }
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
 template <typename T>
 static inline T __shfl_down(T v, unsigned delta, int width = 64) {
     const int lane = (int)(hip_emu::flat_tid() & 63u);

@@ -24,6 +24,10 @@ void run(dim3 grid, dim3 block, size_t lds_bytes, void (*thunk)(void *), void *a
     if (nblocks == 0) return;
     std::barrier<> end_bar((std::ptrdiff_t)n);
     s.bar.reset(new std::barrier<>((std::ptrdiff_t)n));
+    auto reset_wave_barriers = [&]() {
+        for (unsigned w = 0; w * 64 < n; ++w) s.wbar[w].reset(new std::barrier<>((std::ptrdiff_t)std::min(64u, n - w * 64)));
+    };
+    reset_wave_barriers();
     // canary behind the requested dynamic-LDS size: a kernel that carves more than it asked for is a bug on the device
     const size_t canary = std::min<size_t>(8192, sizeof(csdr::smem) - lds_bytes);
     std::memset(csdr::smem + lds_bytes, 0xEE, canary);
@@ -35,6 +39,7 @@ void run(dim3 grid, dim3 block, size_t lds_bytes, void (*thunk)(void *), void *a
                     t_blockIdx = dim3(bx, by, bz);
                     thunk(arg);
                     s.bar->arrive_and_drop();       // an exited work-item no longer takes part in __syncthreads
+                    s.wbar[tid >> 6]->arrive_and_drop();
                     end_bar.arrive_and_wait();
                     if (tid == 0) {
                         for (size_t i = 0; i < canary; ++i)
@@ -45,6 +50,7 @@ void run(dim3 grid, dim3 block, size_t lds_bytes, void (*thunk)(void *), void *a
                         // poison LDS between workgroups: nothing may rely on another workgroup's leftovers
                         std::memset(csdr::smem, 0xCD, lds_bytes);
                         s.bar.reset(new std::barrier<>((std::ptrdiff_t)n));
+                        reset_wave_barriers();
                     }
                     end_bar.arrive_and_wait();
                 }
