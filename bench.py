@@ -114,9 +114,9 @@ def cpu_baseline(ring_host, target_seconds):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--blocks", type=int, default=32, help="IQ blocks per step (batch resident in HBM)")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--blocks", type=int, default=64, help="IQ blocks per step (batch resident in HBM)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 disables)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event profile")
     args = ap.parse_args()

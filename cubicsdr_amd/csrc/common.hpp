@@ -100,6 +100,7 @@ enum CsdrLane { LANE_POST = 0, LANE_FE, LANE_AUDIO, LANE_FFT, LANE_AVG, LANE_COU
 
 struct csdr_ctx {
     int device = 0;
+    int n_cu = 256;                          // compute units (grid sizing: whole rounds of resident workgroups)
     hipStream_t stream = nullptr;            // boundary stream: the caller's producer / consumer work is ordered on it
     bool own_stream = false;
     hipStream_t lanes[LANE_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // logical stage -> physical stream
@@ -150,6 +151,13 @@ struct csdr_ctx {
         if (same(from_lane, to_lane)) return CSDR_OK;
         CSDR_HIP_TRY(hipStreamWaitEvent(lanes[to_lane], ev, 0));
         return CSDR_OK;
+    }
+    // workgroups of this kernel that are resident at once on the whole chip
+    template <typename K>
+    int wg_slots(K kernel, int threads, size_t lds) const {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kernel, threads, lds) != hipSuccess || nb < 1) nb = 1;
+        return nb * n_cu;
     }
     int sync_all() {
         for (int l = 0; l < n_phys; ++l) CSDR_HIP_TRY(hipStreamSynchronize(phys[l]));

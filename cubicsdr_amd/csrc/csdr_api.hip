@@ -41,6 +41,7 @@ extern "C" int csdr_ctx_create(int device, void *hip_stream, csdr_ctx **out) {
     CSDR_HIP_TRY(hipSetDevice(device));
     std::unique_ptr<csdr_ctx> c(new csdr_ctx());
     c->device = device;
+    if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cu < 1) c->n_cu = 256;
     // Physical streams.  Measured on MI355X / ROCm 7.2: a per-batch cross-stream event edge costs ~0.3 ms, two orders
     // of magnitude more than an in-stream kernel boundary, so by default the stages are folded onto the two chains that
     // share no data: {SDRPostThread, demodulators} and {spectrum}.  CSDR_STREAMS = 1 | 2 | 3 | 5 selects other foldings
@@ -233,6 +234,7 @@ static int chan_geometry(int M, ChanGeom &g) {
     g.magicM = (unsigned)((1ull << 32) / (unsigned)M) + 1u;
     g.taps_lds = (M <= 512) ? 1 : 0;
     g.stage_in = (M <= 256) ? 1 : 0;
+    g.fpw = 0;   // set per launch
     // frames per workgroup: the largest power of two <= 64 whose two row arrays fit the LDS budget
     const size_t budget = (M <= 512) ? 64 * 1024 : 72 * 1024;
     for (int tf = 64; tf >= 1; tf >>= 1) {
@@ -335,12 +337,14 @@ extern "C" int csdr_post_set_active_channels(csdr_post *p, const int *channels, 
 // DC blocker over n samples: `have_ends` = the mini-tile end values (tile_len samples each) are already in tile_end
 // (the channelizer wrote them); otherwise a first pass computes them per kDcTile samples.
 static int run_dc_blocker(csdr_post *p, const float2 *x, float2 *y, int64_t n, bool have_ends, int tile_len) {
-    const int nblocks = (int)((n + kDcTile - 1) / kDcTile);
     d2 *s_in = p->dc_state.p + p->dc_parity, *s_out = p->dc_state.p + (p->dc_parity ^ 1);
     if (!have_ends) {
         tile_len = kDcTile;
-        CSDR_LAUNCH(p->ctx, LANE_POST, KID_DC_ENDS, dc_tile_ends, dim3(nblocks), dim3(kDcThreads), kDcLds, x, n, p->dc_c, p->tile_end.p);
+        const int nt = (int)((n + kDcTile - 1) / kDcTile);
+        CSDR_LAUNCH(p->ctx, LANE_POST, KID_DC_ENDS, dc_tile_ends, dim3(nt), dim3(kDcThreads), kDcLds, x, n, p->dc_c, p->tile_end.p);
     }
+    const int64_t blk_len = (int64_t)(kDcTile / tile_len) * tile_len;     // whole mini-tiles per block
+    const int nblocks = (int)((n + blk_len - 1) / blk_len);
     CSDR_LAUNCH(p->ctx, LANE_POST, KID_DC_APPLY, dc_apply, dim3(nblocks), dim3(kDcThreads), kDcLds, x, y, n, p->dc_c, tile_len, p->tile_end.p, s_in, s_out);
     p->dc_parity ^= 1;
     CSDR_HIP_TRY(hipGetLastError());
@@ -367,7 +371,8 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
     if (frequency != p->frequency || p->centers.empty()) { p->frequency = frequency; post_update_channels(p); }
     p->n_blocks = n_blocks; p->block_len = block_len;
     // next output buffer of the rotation: its previous readers (demodulator front-ends, three batches ago) must be done
-    const int k = (int)(p->seq % csdr_post::kPostBufs);
+    // (stages that share one stream are ordered by it: a single buffer keeps the working set inside the Infinity Cache)
+    const int k = c->same(LANE_POST, LANE_FE) ? 0 : (int)(p->seq % csdr_post::kPostBufs);
     if (!c->same(LANE_FE, LANE_POST))
         for (int q = 0; q < p->n_consumed[k]; ++q) CSDR_HIP_TRY(hipStreamWaitEvent(st, p->ev_consumed[k][q], 0));
     p->n_consumed[k] = 0;
@@ -384,18 +389,19 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
             p->active_dirty = false;
         }
         const int64_t n_frames = n / M;
-        const ChanGeom &g = p->geom;
         float2 *hist = p->hist_parity ? p->hist1.p : p->hist0.p, *hist_new = p->hist_parity ? p->hist0.p : p->hist1.p;
-        const int ntiles = (int)((n_frames + g.TF - 1) / g.TF);
+        ChanGeom g = p->geom;
+        g.fpw = g.TF;                         // frames per workgroup (full tiles measured fastest on MI355X)
+        const int ntiles = (int)((n_frames + g.fpw - 1) / g.fpw);
         // channel 0 carries the DC spike: it is blocked after de-interleave (:364-375); when the tile size allows, the
         // channelizer itself emits the per-tile end values the blocked scan needs
         const bool dc0 = !p->active_host.empty() && p->active_host[0] == 0;
-        const bool fused_ends = dc0 && g.TF >= 16;
+        const bool fused_ends = dc0 && g.fpw >= 16;
         CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, chan_analyze, dim3(ntiles), dim3(kChanThreads), chan_lds_bytes(g), x, hist, hist_new, p->taps.p,
                     p->twA.p, p->twB.p, p->twM.p, p->active.p, g, n_frames, out, p->chan_stride, fused_ends ? p->tile_end.p : (d2 *)nullptr, p->dc_c);
         p->hist_parity ^= 1;
         CSDR_HIP_TRY(hipGetLastError());
-        if (dc0) rc = run_dc_blocker(p, out, out, n_frames, fused_ends, g.TF);
+        if (dc0) rc = run_dc_blocker(p, out, out, n_frames, fused_ends, g.fpw);
     }
     if (rc) return rc;
     if (int rc2 = c->signal(p->ev_ready[k], LANE_POST, LANE_FE)) return rc2;
@@ -797,8 +803,18 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     // Slots whose cascade has the reference's standard shape (m = 3..3, 5, 10; 3 <= S <= 6) run the specialised kernel,
     // one launch per depth S; anything else runs the generic one.
     const int64_t total = (int64_t)NB * Bc;
-    const int64_t range = std::max<int64_t>(8192, 6 * (int64_t)warm_max);
-    int P = (int)std::max<int64_t>(1, std::min<int64_t>(total / range, 4096));
+    // ranges per slot: as many as make the grid ONE round of resident workgroups (each range re-runs `warm` inputs, so
+    // fewer, longer ranges waste less), but never shorter than 4 warm-up spans and never fewer than one
+    const int fe_slots = c->wg_slots(demod_frontend_s<5, 2048>, kFeThreads, fes_lds_bytes<5, 2048>());
+    int P = (int)std::max<int64_t>(1, std::min<int64_t>(total / std::max<int64_t>(4096, 4 * (int64_t)warm_max), 4096));
+    {
+        const int per_slot = fe_slots / std::max(1, n_run) - 1;        // one extra workgroup per slot carries the histories
+        if (per_slot >= 1) P = std::min(P, per_slot);
+        else {                                                           // more slots than resident workgroups: whole rounds
+            const int rounds = (n_run * 2 + fe_slots - 1) / fe_slots;
+            P = std::max(1, std::min(P, rounds * fe_slots / std::max(1, n_run) - 1));
+        }
+    }
     size_t fe_lds = 0;
     for (int i = 0; i < grp_n[0]; ++i) fe_lds = std::max(fe_lds, fe_lds_bytes((int)b->slots[grp_h[grp_off[0] + i]].iq.S));
     const int cap_stream = (max_n_iq + kSsbWarm + 64 + 3) & ~3;
@@ -1028,7 +1044,7 @@ static int spec_run_fft(csdr_spec *s, const FrameSrc &fs, int nf, float *mag, fl
     if (g.N < 4096) {
         CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_small, dim3(1, nf), dim3(kFftThreads), (size_t)2 * g.N * sizeof(float2), fs, g.N, s->tw4096.p, mag, raw);
     } else if (g.Ra == 1) {
-        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_rows4096, dim3(1, nf), dim3(kFftThreads), kRowLdsPts * sizeof(float2), fs, g, s->tw4096.p, mag, raw);
+        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_rows4096, dim3(1, nf), dim3(kFftThreads), kRowLdsBytes, fs, g, s->tw4096.p, mag, raw);
     } else {
         // radix passes: Ra-point columns of each frame, then (optionally) Rb-point columns inside each of the Ra sub-sequences
         if (g.Ra <= 16) launch_radix<2>(c, g.Ra, fs, g.N, 1u, nf, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
@@ -1040,7 +1056,7 @@ static int spec_run_fft(csdr_spec *s, const FrameSrc &fs, int nf, float *mag, fl
             else launch_radix<1>(c, g.Rb, sub, L2, (unsigned)g.Ra, nf * g.Ra, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
         }
         FrameSrc rows{s->tmp.p, nullptr, s->tmp.p + g.N, g.N, 1 << 30};
-        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_rows4096, dim3(g.Ra * g.Rb, nf), dim3(kFftThreads), kRowLdsPts * sizeof(float2), rows, g,
+        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_rows4096, dim3(g.Ra * g.Rb, nf), dim3(kFftThreads), kRowLdsBytes, rows, g,
                     s->tw4096.p, mag, raw);
     }
     CSDR_HIP_TRY(hipGetLastError());
@@ -1082,7 +1098,7 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
     s->nf_last = nf;
     if (nf > 0) {
         // lane FFT fills magnitude copy `mp`; its previous reader was the averaging kernel two batches ago
-        const int mp = (int)(s->seq & 1);
+        const int mp = c->same(LANE_FFT, LANE_AVG) ? 0 : (int)(s->seq & 1);
         float *mag = s->mag.p + (size_t)mp * s->max_frames * N;
         if (s->avg_pending[mp]) if (int rc = c->wait(s->ev_avg_done[mp], LANE_AVG, LANE_FFT)) return rc;
         if (int rc = spec_run_fft(s, fs, nf, mag, nullptr)) return rc;
@@ -1092,7 +1108,9 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
         CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_average, dim3(s->n_avg_tiles), dim3(kAvgThreads), kAvgLds, mag, nf, g, (double)s->avg_rate,
                     s->ma.p, s->maa.p, s->pairsum.p, s->first_b.p, s->ext_w.p);
         CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_extrema, dim3(nf), dim3(256), 64, s->ext_w.p, s->n_avg_tiles, s->ext.p);
-        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_DISPLAY, spec_display, dim3((g.F / 2 + kDispThreads - 1) / kDispThreads, nf), dim3(kDispThreads), kDispLds,
+        // display: column blocks per frame sized so that the grid is about one round of resident workgroups
+        const int disp_gx = std::max(1, std::min((g.F / 2 + kDispThreads - 1) / kDispThreads, c->wg_slots(spec_display, kDispThreads, kDispLds) / std::max(1, nf)));
+        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_DISPLAY, spec_display, dim3(disp_gx, nf), dim3(kDispThreads), kDispLds,
                     s->pairsum.p, s->first_b.p, s->ext.p, nf, g.F, s->scale, s->scal.p + s->scal_parity, s->scal.p + (s->scal_parity ^ 1), s->fo.p,
                     s->points.p);
         s->scal_parity ^= 1;

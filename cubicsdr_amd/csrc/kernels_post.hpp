@@ -57,12 +57,11 @@ __device__ inline d2 dc_block_scan(d2 b, double A, d2 v_in, d2 *lds_b, double *l
 }
 
 __device__ inline void dc_stage_in(const float2 *__restrict__ x, int64_t n, int64_t base, float2 *sx) {
-    // 16-byte loads: two samples per lane
-    const float4 *x4 = reinterpret_cast<const float4 *>(x + base);
+    // 16-byte loads: two samples per lane (the block start is only guaranteed 8-byte aligned)
     for (int i = threadIdx.x; i < kDcTile / 2; i += kDcThreads) {
         const int64_t g = base + 2 * (int64_t)i;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g + 1 < n) v = x4[i];
+        if (g + 1 < n) { const f4u t = *reinterpret_cast<const f4u *>(x + g); v = make_float4(t.x, t.y, t.z, t.w); }
         else if (g < n) { const float2 s = x[g]; v.x = s.x; v.y = s.y; }
         sx[2 * i] = make_float2(v.x, v.y);
         sx[2 * i + 1] = make_float2(v.z, v.w);
@@ -127,10 +126,12 @@ __global__ __launch_bounds__(kDcThreads) void dc_apply(const float2 *x, float2 *
     float2 *sx = reinterpret_cast<float2 *>(smem);
     d2 *sb = reinterpret_cast<d2 *>(smem + kDcTile * sizeof(float2));
     const int tid = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * kDcTile;
-    dc_stage_in(x, n, base, sx);
+    const int blk_tiles = kDcTile / tile_len;                // whole mini-tiles per block
+    const int64_t base = (int64_t)blockIdx.x * blk_tiles * tile_len;
+    const int64_t nb_end = min(n, base + (int64_t)blk_tiles * tile_len);    // this block's samples are [base, nb_end)
+    dc_stage_in(x, nb_end, base, sx);
     // carry from the mini-tiles before this block
-    const int64_t m0 = base / tile_len;                      // kDcTile is a multiple of tile_len
+    const int64_t m0 = (int64_t)blockIdx.x * blk_tiles;
     const int64_t reach = (80000 + tile_len - 1) / tile_len;
     const int64_t mlo = m0 > reach ? m0 - reach : 0;
     const double A = dc_pow(c, tile_len);
@@ -160,18 +161,17 @@ __global__ __launch_bounds__(kDcThreads) void dc_apply(const float2 *x, float2 *
         float2 s = sx[tid * kDcSeg + i];
         d2 v0 = {(double)s.x + c * v.x, (double)s.y + c * v.y};
         sx[tid * kDcSeg + i] = make_float2((float)(v0.x - v.x), (float)(v0.y - v.y));
-        if (g < n) {
+        if (g < nb_end) {
             v = v0;
             if (g == n - 1) state_out[0] = v0;
         }
     }
     __syncthreads();
-    float4 *y4 = reinterpret_cast<float4 *>(y + base);
     for (int i = tid; i < kDcTile / 2; i += kDcThreads) {
         const int64_t g = base + 2 * (int64_t)i;
         const float2 a = sx[2 * i], b = sx[2 * i + 1];
-        if (g + 1 < n) y4[i] = make_float4(a.x, a.y, b.x, b.y);
-        else if (g < n) y[g] = a;
+        if (g + 1 < nb_end) *reinterpret_cast<f4u *>(y + g) = f4u{a.x, a.y, b.x, b.y};
+        else if (g < nb_end) y[g] = a;
     }
 }
 
@@ -200,6 +200,7 @@ struct ChanGeom {
     unsigned magicM;          // floor(2^32 / M) + 1 : i / M for i < 2^20
     int taps_lds;             // 1: the [8][M] tap table is staged in LDS
     int stage_in;             // 1: the (TF + 7) M input samples of the tile are staged in LDS (aliasing the Z array)
+    int fpw;                  // frames one workgroup processes (<= TF): set per launch so the grid fills whole rounds
 };
 __host__ __device__ inline size_t chan_zin_floats2(const ChanGeom &g) {      // Z array, or the staged input tile if larger
     const size_t z = (size_t)g.TF * g.S, in = g.stage_in ? (size_t)(g.TF + kChanTaps - 1) * g.M : 0;
@@ -229,8 +230,8 @@ __global__ __launch_bounds__(kChanThreads) void chan_analyze(
     float2 *s_z = s_x + (size_t)TF * S;                   // also the staged input tile during phase 0
     float *s_taps = reinterpret_cast<float *>(s_z + chan_zin_floats2(g));
     const int tid = threadIdx.x;
-    const int64_t f0 = (int64_t)blockIdx.x * TF;          // first frame of this tile
-    const int nf = (int)min((int64_t)TF, n_frames - f0);
+    const int64_t f0 = (int64_t)blockIdx.x * g.fpw;       // first frame of this tile (g.fpw <= TF frames per workgroup)
+    const int nf = (int)min((int64_t)g.fpw, n_frames - f0);
     const int64_t H = (int64_t)(kChanTaps - 1) * M;
 
     const int64_t base = f0 * M;

@@ -26,7 +26,7 @@ namespace csdr {
 constexpr int kFftThreads = 256;
 constexpr int kFftMaxLds = 4096;           // complex points per workgroup in the Stockham path (2 x 32 KB ping-pong)
 constexpr int kTwTab = 4096;               // base twiddle table exp(-2 pi i k / 4096)
-constexpr int kRowLdsPts = 16 * 272;       // float2 slots of the 4096-point row FFT's exchange buffer
+constexpr size_t kRowLdsBytes = 8 * 272 * sizeof(float2);   // exchange buffer of the 4096-point row FFT (half of the points at a time)
 
 struct SpecGeom {
     int N, F;                 // internal FFT size, display points (= N / 2)
@@ -110,14 +110,23 @@ __device__ inline void fft4096_regs(float2 (&v)[16], float2 *lds, const float2 *
         leaf[0] = tw4096[b]; leaf[1] = tw4096[2 * b]; leaf[2] = tw4096[4 * b]; leaf[3] = tw4096[8 * b]; leaf[4] = leaf[3];
         twiddle_powers<16>(v, leaf);
     }
-    __syncthreads();                                           // previous users of the exchange buffer are done
+    // exchange 1, [k2][n1][n0] with rows padded to 272, in two halves of eight k2 (the buffer holds 2048 points):
+    // the threads whose k2 (= hi) lies in the half that is resident pick up their sixteen n1 values
+    float2 u[16];
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) lds[tid + 272 * k2] = v[k2];          // [k2][n1][n0], rows padded to 272
-    __syncthreads();
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();                                       // previous users of the exchange buffer are done
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) lds[tid + 272 * k2] = v[8 * half + k2];
+        __syncthreads();
+        if ((hi >> 3) == half) {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) u[n1] = lds[n0 + 16 * n1 + 272 * (hi & 7)];
+        }
+    }
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) v[n1] = u[n1];
     // stage 2: thread (n0, k2 = hi): DFT over n1, times W4096^(n0 (16 k1 + k2))
-#pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) v[n1] = lds[n0 + 16 * n1 + 272 * hi];
-    __syncthreads();
     dft_reg<16>(v);
     {
         const int b = 16 * n0;
@@ -127,12 +136,22 @@ __device__ inline void fft4096_regs(float2 (&v)[16], float2 *lds, const float2 *
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) v[k1] = cmul(v[k1], b0);
     }
+    // exchange 2, [n0][k1][k2] with rows padded to 257, in two halves of eight n0: the threads whose n0 lies in the half
+    // write their sixteen k1 values, every thread (tid = k2 + 16 k1) reads eight n0 values
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) lds[hi + 16 * k1 + 257 * n0] = v[k1];  // [n0][k1][k2], rows padded to 257
-    __syncthreads();
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        if ((n0 >> 3) == half) {
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) lds[hi + 16 * k1 + 257 * (n0 & 7)] = v[k1];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) u[8 * half + m] = lds[tid + 257 * m];
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = u[m];
     // stage 3: thread tid = k2 + 16 k1: DFT over n0
-#pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = lds[tid + 257 * m];
     dft_reg<16>(v);
 }
 
@@ -480,8 +499,7 @@ __global__ __launch_bounds__(kDispThreads) void spec_display(const float *__rest
     __syncthreads();
     const double pc = s_pc[0], pf = s_pc[1];
     const float inv_den = 1.0f / log1pf((float)(pc - pf));          // (pc + 0.25) - (pf - 0.75) = 1 + (pc - pf)
-    const int x0 = 2 * (blockIdx.x * kDispThreads + tid);
-    if (x0 >= F) return;
+    for (int x0 = 2 * (blockIdx.x * kDispThreads + tid); x0 < F; x0 += 2 * kDispThreads * gridDim.x) {
     float y[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -494,6 +512,7 @@ __global__ __launch_bounds__(kDispThreads) void spec_display(const float *__rest
     float *o = points + ((int64_t)f * F + x0) * 2;
     if (x0 + 1 < F) *reinterpret_cast<float4 *>(o) = make_float4((float)x0 / (float)F, y[0], (float)(x0 + 1) / (float)F, y[1]);
     else { o[0] = (float)x0 / (float)F; o[1] = y[0]; }
+    }
 }
 
 }  // namespace csdr

@@ -158,6 +158,9 @@ hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventQuery(hipEvent_t e);
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipFuncSetAttribute(const void *f, hipFuncAttribute a, int v);
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 16 };
+hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t a, int dev);
+hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *nb, const void *f, int threads, size_t lds);
 
 template <typename... P, typename... A>
 static inline void hipLaunchKernelGGL(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t, A &&...a) {

@@ -93,3 +93,5 @@ hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
+hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 8; return hipSuccess; }      // a small "chip": exercises multi-round grids
+hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *nb, const void *, int, size_t) { *nb = 2; return hipSuccess; }

@@ -18,6 +18,10 @@ import tests.test_gpu_parity as G
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "emu"))
 
+# the quick subset (~2 min on 8 cores) runs by default; CSDR_EMU_FULL=1 runs every case (add CSDR_EMU_FLAVOR=asan|tsan and
+# LD_PRELOAD=$(gcc -print-file-name=libasan.so|libtsan.so) for the sanitizer builds)
+full = pytest.mark.skipif(os.environ.get("CSDR_EMU_FULL", "0") != "1", reason="set CSDR_EMU_FULL=1 for the full emulation suite")
+
 
 @pytest.fixture(scope="module")
 def ctx():
@@ -44,10 +48,12 @@ def test_emu_channelizer_c1(ctx):
     G.test_channelizer_matches_firpfbch(ctx, 2400000, 4, 40000)
 
 
+@full
 def test_emu_channelizer_m6(ctx):
     G.test_channelizer_matches_firpfbch(ctx, 3000000, 6, 50004)
 
 
+@full
 def test_emu_channelizer_batched(ctx):
     G.test_channelizer_batched_equals_blockwise(ctx)
 
@@ -60,23 +66,27 @@ def test_emu_nbfm_c1(ctx):
     G.test_nbfm_c1_config(ctx)
 
 
+@full
 def test_emu_mixed_modems(ctx):
     G.test_mixed_modems_streaming(ctx)
 
 
+@full
 def test_emu_batched(ctx):
     G.test_batched_equals_reference(ctx)
 
 
+@full
 def test_emu_single_channel_demod(ctx):
     G.test_single_channel_mode_demod(ctx)
 
 
-@pytest.mark.parametrize("F", [512, 2048, 16384])
+@pytest.mark.parametrize("F", [pytest.param(512, marks=full), 2048, pytest.param(16384, marks=full)])
 def test_emu_fft(ctx, F):
     G.test_fft_matches_liquid(ctx, F)
 
 
+@full
 def test_emu_spectrum_first_frame(ctx):
     G.test_spectrum_points_first_frame_mode(ctx, 2048, 40000)
 
@@ -85,5 +95,6 @@ def test_emu_spectrum_contiguous(ctx):
     G.test_spectrum_contiguous_mode(ctx)
 
 
+@full
 def test_emu_spectrum_many_frames(ctx):
     G.test_spectrum_many_frames_one_batch(ctx)

@@ -326,3 +326,100 @@ def test_pipelined_batches_equal_synchronised_batches(ctx):
         assert ra == rb
         for u, v in zip(a, b):
             assert np.array_equal(u, v)
+
+
+# ----------------------------------------------------------------------------------------------- BASELINE config shapes
+def test_c3_shape_mixed_m122(ctx):
+    """BASELINE config 3 shape: 61.44 MS/s, M = 122 (channel rate 503606 by integer division), block 1 024 068, mixed
+    NBFM / AM / USB demodulators (24 of the 256 are checked against the oracle), 2 blocks in one batch."""
+    got, want = _run_demods(ctx, 61440000, 122, 1024068, ["NBFM", "AM", "USB"] * 8, 2, 2, seed=41)
+    print(_compare(got, want, "c3"))
+
+
+def test_c4_shape_m1024_channelizer_and_nbfm(ctx):
+    """BASELINE config 4 shape: 100 MS/s, firpfbch M = 1024 (32 x 32 two-step DFT path, FIR straight from HBM), NBFM on a
+    97 656 S/s channel (two half-band stages: the generic front-end kernel)."""
+    from cubicsdr_amd.engine import SDRPost
+    from oracle.cubicsdr_chain import RefSDRPost
+    fs, M, block, center = 100000000, 1024, 1667072, 400000000
+    x = synth_iq(block, fs, center, [("NBFM", center + 1234567), ("NBFM", center - 33000000)], seed=51)
+    ref = RefSDRPost(_backend(), fs, M)
+    post = SDRPost(ctx, fs, M, block, max_blocks=1)
+    ref.run_block(x, center)
+    post.execute(x, 1, block, center)
+    for ch in (0, 1, 13, 511, 512, 513, 686, 1023, 1024):
+        want, fc, rate = ref.channel_data(ch)
+        got = post.read_channel(ch)
+        assert post.channel_center(ch) == fc
+        if ch == 0:
+            # the analyzer has DC gain M, so channel 0 carries 0.01 * 1024 and the reference's float32 DC-blocker state
+            # sits near 10.24 / 0.0005 = 20480: its own rounding noise (see test_dc_blocker_large_offset_state_noise)
+            floor = 4 * np.spacing(np.float32(0.01 * M / 0.0005))
+            assert np.max(np.abs(got - want)) < TOL * np.max(np.abs(want)) + floor
+        else:
+            assert rel_err(got, want) < TOL, ch
+    post.close()
+    got, want = _run_demods(ctx, fs, M, block, ["NBFM"] * 4, 2, 1, seed=52)
+    print(_compare(got, want, "c4"))
+
+
+def test_c5_shape_m200_and_1m_point_spectrum(ctx):
+    """BASELINE config 5 shape: 100 MS/s, M = 200, block 1 666 800; spectrum fftSize 1 048 576 (internal 2^21 points:
+    radix-16 and radix-32 passes in front of the 4096-point rows)."""
+    from cubicsdr_amd.engine import SDRPost, SpectrumProcessor
+    from oracle.cubicsdr_chain import RefSDRPost, RefSpectrum
+    fs, M, block, center = 100000000, 200, 1666800, 400000000
+    x = synth_iq(2 * block, fs, center, [("NBFM", center + 7654321), ("AM", center - 21000000)], seed=61)
+    ref = RefSDRPost(_backend(), fs, M)
+    post = SDRPost(ctx, fs, M, block, max_blocks=1)
+    ref.run_block(x[:block], center)
+    post.execute(x[:block], 1, block, center)
+    for ch in (0, 15, 99, 100, 158, 199, 200):
+        want, fc, rate = ref.channel_data(ch)
+        got = post.read_channel(ch)
+        if ch == 0:     # DC gain M: the reference's float32 DC-blocker state noise, as in the M = 1024 test
+            assert np.max(np.abs(got - want)) < TOL * np.max(np.abs(want)) + 4 * np.spacing(np.float32(0.01 * M / 0.0005))
+        else:
+            assert rel_err(got, want) < TOL, ch
+    post.close()
+    F = 1 << 20
+    sp = SpectrumProcessor(ctx, F, max_frames=2)
+    rs = RefSpectrum(_backend(), F)
+    assert rel_err(sp.fft_only(x[:2 * F]), rs.fft(x[:2 * F])) < TOL
+    assert sp.process(x, 2, block, contiguous=True) == 1        # 3 333 600 samples hold one 2 097 152-point frame
+    pts, ce, fl = sp.fetch(0)
+    wp, wce, wfl = rs.process_frame(x[:2 * F])
+    assert rel_err(pts, wp) < TOL
+    assert abs(ce - wce) <= TOL * abs(wce) and abs(fl - wfl) <= TOL * abs(wce)
+    sp.close()
+
+
+def test_c2_full_size_batching_invariance(ctx):
+    """Size-independent property at the full C2 size: 64 NBFM demodulators, 16 blocks -- the audio, the resampled IQ and
+    the per-block counts of one 16-block batch equal, bit for bit, those of 16 one-block batches."""
+    from cubicsdr_amd.engine import DemodBank, SDRPost
+    fs, M, block, center, nb, nd = 10000000, 20, 166680, 100000000, 16, 64
+    freqs = demod_frequencies(center, fs, nd)
+    x = synth_iq(nb * block, fs, center, [("NBFM", f) for f in freqs[:6]], seed=71)
+
+    def run(batch):
+        post = SDRPost(ctx, fs, M, block, max_blocks=batch)
+        bank = DemodBank(ctx, nd, max_blocks=batch)
+        for i, f in enumerate(freqs):
+            bank.configure(i, post, "NBFM", 12500, f)
+        audio = [[] for _ in range(nd)]
+        counts = []
+        for b0 in range(0, nb, batch):
+            post.execute(x[b0 * block:(b0 + batch) * block], batch, block, center)
+            bank.execute(post)
+            for i in range(nd):
+                audio[i].append(bank.audio(i))
+                counts += [(r.n_iq, r.n_audio, r.level_count, r.nco_theta, r.resamp_phase, r.buffer_index) for r in bank.results(i)] if i < 4 else []
+        post.close(); bank.close()
+        return [np.concatenate(a) for a in audio], counts
+
+    a1, c1 = run(nb)
+    a2, c2 = run(1)
+    assert sorted(c1) == sorted(c2)
+    for u, v in zip(a1, a2):
+        assert np.array_equal(u, v)
