@@ -77,6 +77,21 @@ def algorithmic_bytes_per_sample(kernel, n_demods, m, fft_n):
     return table.get(kernel, 0.0)
 
 
+def measured_traffic_bytes(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/collect.sh: FETCH_SIZE and WRITE_SIZE in their
+    own rocprofv3 runs of this same command; gfx950 reports half of a wide coalesced read stream, MI355X_MICROARCH.md "HBM",
+    so the read side is doubled).  None when no pass is on file for this kernel."""
+    path = os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")
+    try:
+        t = json.load(open(path))
+    except Exception:
+        return None
+    for name, v in t.items():
+        if name.split("<")[0] == kernel and "FETCH_SIZE_KiB_avg_per_launch" in v and "WRITE_SIZE_KiB_avg_per_launch" in v:
+            return (2.0 * v["FETCH_SIZE_KiB_avg_per_launch"] + v["WRITE_SIZE_KiB_avg_per_launch"]) * 1024.0
+    return None
+
+
 def cpu_baseline(ring_host, target_seconds):
     """time the reference CPU path (single thread) on a bounded sample of the same workload"""
     import numpy as np
@@ -205,7 +220,9 @@ def main():
         bps = algorithmic_bytes_per_sample(dom, N_DEMODS, M, 2 * FFT_SIZE)
         achieved = bps * units / (avg_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                           "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": (measured_traffic_bytes(dom) if NB == 64 else None), "traffic_unit": "bytes per launch (PMC, 64-block launches)",
+                           "avg_launch_ms": avg_ms,
                            "algorithmic_bytes_per_launch": bps * units,
                            "whole_path": {"bytes_per_sample": 54.8, "achieved": 54.8 * value / world * 1e6 / 1e9,
                                           "frac": 54.8 * value / world * 1e6 / 1e9 / HBM_PEAK_GBS},
