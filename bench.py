@@ -87,7 +87,7 @@ def measured_traffic_bytes(kernel):
     except Exception:
         return None
     for name, v in t.items():
-        if name.split("<")[0] == kernel and "FETCH_SIZE_KiB_avg_per_launch" in v and "WRITE_SIZE_KiB_avg_per_launch" in v:
+        if name.split("<")[0] in (kernel, kernel + "_s") and "FETCH_SIZE_KiB_avg_per_launch" in v and "WRITE_SIZE_KiB_avg_per_launch" in v:
             return (2.0 * v["FETCH_SIZE_KiB_avg_per_launch"] + v["WRITE_SIZE_KiB_avg_per_launch"]) * 1024.0
     return None
 
@@ -129,9 +129,9 @@ def cpu_baseline(ring_host, target_seconds):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--blocks", type=int, default=64, help="IQ blocks per step (batch resident in HBM)")
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--blocks", type=int, default=128, help="IQ blocks per step (batch resident in HBM)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 disables)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event profile")
     args = ap.parse_args()
@@ -221,7 +221,8 @@ def main():
         achieved = bps * units / (avg_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": (measured_traffic_bytes(dom) if NB == 64 else None), "traffic_unit": "bytes per launch (PMC, 64-block launches)",
+                           "traffic": (None if measured_traffic_bytes(dom) is None else measured_traffic_bytes(dom) * NB / 64.0),
+                           "traffic_unit": "bytes per launch (PMC pass at 64 blocks per launch, scaled to this launch size)",
                            "avg_launch_ms": avg_ms,
                            "algorithmic_bytes_per_launch": bps * units,
                            "whole_path": {"bytes_per_sample": 54.8, "achieved": 54.8 * value / world * 1e6 / 1e9,

@@ -237,7 +237,8 @@ static int chan_geometry(int M, ChanGeom &g) {
     g.fpw = 0;   // set per launch
     // frames per workgroup: the largest power of two <= 64 whose two row arrays fit the LDS budget
     const size_t budget = (M <= 512) ? 64 * 1024 : 72 * 1024;
-    for (int tf = 64; tf >= 1; tf >>= 1) {
+    static const int tf_cap = getenv("CSDR_CHAN_TF") ? atoi(getenv("CSDR_CHAN_TF")) : 64;    // experiment knob
+    for (int tf = std::max(1, std::min(128, tf_cap)); tf >= 1; tf >>= 1) {
         g.TF = tf;
         g.lgTF = 0; while ((1 << g.lgTF) < tf) ++g.lgTF;
         const int q = 32 / std::min(tf, 32);              // row stride = q * odd: lanes along t hit distinct banks
@@ -808,7 +809,8 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     const int fe_slots = c->wg_slots(demod_frontend_s<5, 2048>, kFeThreads, fes_lds_bytes<5, 2048>());
     int P = (int)std::max<int64_t>(1, std::min<int64_t>(total / std::max<int64_t>(4096, 4 * (int64_t)warm_max), 4096));
     {
-        const int per_slot = fe_slots / std::max(1, n_run) - 1;        // one extra workgroup per slot carries the histories
+        static const int p_env = getenv("CSDR_FE_P") ? atoi(getenv("CSDR_FE_P")) : 0;      // experiment knob
+        const int per_slot = p_env > 0 ? p_env : fe_slots / std::max(1, n_run) - 1;        // one extra workgroup per slot carries the histories
         if (per_slot >= 1) P = std::min(P, per_slot);
         else {                                                           // more slots than resident workgroups: whole rounds
             const int rounds = (n_run * 2 + fe_slots - 1) / fe_slots;

@@ -65,4 +65,6 @@ def test_product_never_imports_the_oracle():
                     txt = open(os.path.join(dp, f), errors="ignore").read()
                     if re.search(r"(import|from)\s+oracle|oracle/|liquid_port|liquid_ref|libliquid", txt):
                         bad.append(os.path.join(dp, f))
+                    if re.search(r"tests/emu|hip_emu|libcsdr_emu|build_emu", txt):      # the host-thread emulation is test-only too
+                        bad.append(os.path.join(dp, f))
     assert not bad, bad
