@@ -449,7 +449,7 @@ struct SlotHost {
     design::MsresampPlan iq, au;
     int64_t chan_rate = 0;
     // integer state mirrored on the host (closed-form bookkeeping)
-    uint32_t theta = 0, dtheta = 0, buf_idx = 0, phase = 0, aphase = 0, ssb_theta = 0;
+    uint32_t theta = 0, dtheta = 0, buf_idx = 0, phase = 0, aphase = 0, abuf = 0, ssb_theta = 0;
     long long shift_frequency = 0;
     bool shift_valid = false;
     int hist_parity = 0, last_parity = 0;
@@ -603,8 +603,12 @@ extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod
     s.iq = design::plan_msresamp((float)iq_ratio, 60.0f);
     const double au_ratio = double(s.prm.audio_sample_rate) / double(s.prm.bandwidth);   // ModemAnalog.cpp:29-30
     s.au = design::plan_msresamp((float)au_ratio, 60.0f);
-    if (!s.au.interp) return fail(CSDR_EUNSUPPORTED, "audio decimation (bandwidth %d > audio rate %d) is not built yet", s.prm.bandwidth, s.prm.audio_sample_rate);
     if (s.iq.S > 8 || s.au.S > kMaxHb) return fail(CSDR_EUNSUPPORTED, "resampling ratio needs %u half-band stages", s.iq.S);
+    if (!s.au.interp) {      // decimating audio resampler: its cascade must fit the carried demodulator-output history
+        int64_t lo = -(int64_t)(kArmTaps - 1);
+        for (int e = (int)s.au.S - 1; e >= 0; --e) lo = 2 * lo - (4 * (int)s.au.m[s.au.S - 1 - e] - 2);
+        if (-lo + (1 << s.au.S) > kDHist) return fail(CSDR_EUNSUPPORTED, "audio decimation by %d / %d needs %lld samples of history", s.prm.bandwidth, s.prm.audio_sample_rate, (long long)-lo);
+    }
     int ia = 0, aa = 0;
     if (int rc = bank_arm_bank(b, s.iq, &ia)) return rc;
     if (int rc = bank_arm_bank(b, s.au, &aa)) return rc;
@@ -620,7 +624,7 @@ extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod
     // capacities for one execute
     const int64_t max_bc = post->max_block_len / post->M;
     const int64_t cap_iq = (int64_t)std::ceil((double)b->max_blocks * (double)max_bc * iq_ratio) + b->max_blocks + 64;
-    const int64_t cap_audio = (int64_t)std::ceil((double)cap_iq * au_ratio) + (int64_t)b->max_blocks * (2 << s.au.S) + 64;
+    const int64_t cap_audio = (int64_t)std::ceil((double)cap_iq * au_ratio) + (int64_t)b->max_blocks * (2 << (s.au.interp ? s.au.S : 0)) + 64;
     // one slab per slot
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -650,7 +654,7 @@ extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod
     CSDR_HIP_TRY(hipMemcpy(c.agc, agc0, sizeof agc0, hipMemcpyHostToDevice));
     CSDR_HIP_TRY(hipMemcpy(b->cfgs.p + slot, &c, sizeof c, hipMemcpyHostToDevice));
     // fresh objects: nco_crcf_create / msresamp create / modem ctor all start from zero state
-    s.theta = 0; s.dtheta = 0; s.buf_idx = 0; s.phase = 0; s.aphase = 0; s.hist_parity = 0; s.last_parity = 0; s.prev_J = 0;
+    s.theta = 0; s.dtheta = 0; s.buf_idx = 0; s.phase = 0; s.aphase = 0; s.abuf = 0; s.hist_parity = 0; s.last_parity = 0; s.prev_J = 0;
     s.shift_valid = false; s.shift_frequency = 0;
     // ModemUSB/LSB ctor: nco_crcf_set_frequency(ssbShift, 2 pi 0.25) -> the oscillator advances 2^30 per sample
     s.ssb_theta = 0;
@@ -727,25 +731,30 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         memset(&d, 0, sizeof d);
         d.active = 1; d.chan = data_ch; d.theta0 = s.theta; d.dtheta = s.dtheta;
         d.mixdir = shift == 0 ? 0 : (shift < 0 ? +1 : -1);          // :186-191: shift < 0 -> mix up
-        d.buf0 = s.buf_idx; d.phase0 = s.phase; d.aphase0 = s.aphase; d.ssb_theta0 = s.ssb_theta; d.hist_parity = s.hist_parity;
+        d.buf0 = s.buf_idx; d.phase0 = s.phase; d.aphase0 = s.aphase; d.abuf0 = s.abuf; d.ssb_theta0 = s.ssb_theta; d.hist_parity = s.hist_parity;
         d.prev_j = s.prev_J;
         // per-block plan
         BlockPlan *pl = plans_h + (size_t)si * (NB + 1);
         const int S = (int)s.iq.S, aS = (int)s.au.S;
+        const bool au_interp = s.au.interp;
+        const int ash = au_interp ? aS : 0;      // audio samples per arbitrary-stage output = 2^ash
         for (int bb = 0; bb <= NB; ++bb) {
             const int64_t K = ((int64_t)s.buf_idx + (int64_t)bb * Bc) >> S;
             const int64_t J = first_out(K, s.phase, s.iq.step);
-            const int64_t Q = first_out(J, s.aphase, s.au.step);
+            // audio msresamp_rrrf (ModemAnalog.cpp:88): interpolating = arbitrary stage first (input index J);
+            // decimating = half-band /2 stages first: the arbitrary stage sees (abuf + J) >> aS chain outputs
+            const int64_t Ka = au_interp ? J : (((int64_t)s.abuf + J) >> aS);
+            const int64_t Q = first_out(Ka, s.aphase, s.au.step);
             pl[bb].j0 = (int)J; pl[bb].q0 = (int)Q;
         }
         const int64_t Jtot = pl[NB].j0, Qtot = pl[NB].q0;
-        if (Jtot > s.cfg.cap_iq - 8 || (Qtot << aS) > s.cfg.cap_audio - 8) return fail(CSDR_ERANGE, "slot %d output exceeds its buffers", si);
+        if (Jtot > s.cfg.cap_iq - 8 || (Qtot << ash) > s.cfg.cap_audio - 8) return fail(CSDR_ERANGE, "slot %d output exceeds its buffers", si);
         for (int bb = 0; bb < NB; ++bb) {
             csdr_block_result &r = s.results[bb];
             memset(&r, 0, sizeof r);
             r.n_iq = pl[bb + 1].j0 - pl[bb].j0;
-            r.n_audio = (int)(((int64_t)(pl[bb + 1].q0 - pl[bb].q0)) << aS);
-            r.audio_offset = (int)(((int64_t)pl[bb].q0) << aS);
+            r.n_audio = (int)(((int64_t)(pl[bb + 1].q0 - pl[bb].q0)) << ash);
+            r.audio_offset = (int)(((int64_t)pl[bb].q0) << ash);
             if (r.n_iq > kModemMaxBlockIq || r.n_audio > kAudioMaxOut) return fail(CSDR_EUNSUPPORTED, "slot %d: %d IQ / %d audio samples per block exceed the per-workgroup limits", si, r.n_iq, r.n_audio);
             max_n_iq = std::max(max_n_iq, r.n_iq); max_n_audio = std::max(max_n_audio, r.n_audio);
             const int64_t Kb = ((int64_t)s.buf_idx + (int64_t)(bb + 1) * Bc) >> S;
@@ -758,11 +767,15 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         s.phase = (uint32_t)((int64_t)s.phase + Jtot * (int64_t)s.iq.step - (Ktot << 24));
         s.buf_idx = (uint32_t)(((int64_t)s.buf_idx + (int64_t)NB * Bc) & ((1 << S) - 1));
         if (d.mixdir) s.theta += (uint32_t)((int64_t)NB * Bc) * s.dtheta;
-        s.aphase = (uint32_t)((int64_t)s.aphase + Qtot * (int64_t)s.au.step - (Jtot << 24));
+        {
+            const int64_t Ka_tot = au_interp ? Jtot : (((int64_t)s.abuf + Jtot) >> aS);
+            s.aphase = (uint32_t)((int64_t)s.aphase + Qtot * (int64_t)s.au.step - (Ka_tot << 24));
+            if (!au_interp) s.abuf = (uint32_t)(((int64_t)s.abuf + Jtot) & ((1 << aS) - 1));
+        }
         s.ssb_theta += (uint32_t)Jtot * (1u << 30);
         s.last_parity = s.hist_parity;
         s.hist_parity ^= 1;
-        s.last_J = (int)Jtot; s.last_A = (int)(Qtot << aS);
+        s.last_J = (int)Jtot; s.last_A = (int)(Qtot << ash);
         s.prev_J = (int)Jtot;
         warm_max = std::max(warm_max, s.warm); max_aS = std::max(max_aS, aS);
         if (s.prm.modem != CSDR_MODEM_NBFM && s.prm.modem != CSDR_MODEM_FM) ag_list_h[n_ag++] = si;
@@ -821,7 +834,10 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     for (int i = 0; i < grp_n[0]; ++i) fe_lds = std::max(fe_lds, fe_lds_bytes((int)b->slots[grp_h[grp_off[0] + i]].iq.S));
     const int cap_stream = (max_n_iq + kSsbWarm + 64 + 3) & ~3;
     const size_t modem_lds = (size_t)2 * cap_stream * sizeof(float) + 64;
-    const int cap_out = (max_n_audio + 32 * max_aS + 64 + 3) & ~3, cap_win = (max_n_iq + 128 + 3) & ~3;
+    // LDS of the audio kernel: two ping-pong arrays (stage outputs) and the staged demodulator window (decimating
+    // cascades reach back up to kDHist samples and their first stage outputs half the window)
+    const int cap_win = (max_n_iq + kDHist + 64 + 3) & ~3;
+    const int cap_out = (std::max(max_n_audio + 32 * max_aS + 64, cap_win / 2 + 64) + 3) & ~3;
     const size_t audio_lds = (size_t)(2 * cap_out + cap_win) * sizeof(float) + 64;
     const size_t want[3] = {fe_lds, modem_lds, audio_lds};     // (the specialised front-end kernels stay below 64 KB)
     const void *fn[3] = {(const void *)demod_frontend, (const void *)demod_modem, (const void *)demod_audio_interp};

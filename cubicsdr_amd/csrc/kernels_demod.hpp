@@ -24,7 +24,7 @@ constexpr int kArmTaps = 14;      // arbitrary resampler: 2 * 7 taps per arm
 constexpr int kArms = 256;
 constexpr int kMixHist = 16384;   // upper bound of the mixed-input history kept per slot (cascade span; S <= 8)
 constexpr int kIqHist = 256;      // resampled-IQ history kept per slot
-constexpr int kDHist = 64;        // scaled demodulator-output history kept per slot
+constexpr int kDHist = 256;       // scaled demodulator-output history kept per slot (>= span of a decimating audio cascade)
 constexpr int kFeThreads = 256;
 constexpr int kFeChunk = 2048;    // input samples one inner iteration of the front-end stages through LDS
 constexpr int kFePairs = kFeChunk / 2 / kFeThreads;   // 16-byte loads per thread per chunk
@@ -809,7 +809,10 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     const ResampCfg &au = cfg.rs_au;
     const int aS = au.S;
     const int64_t Q0 = pl[b].q0, Q1 = pl[b + 1].q0;               // arbitrary-stage outputs of this block
-    const int64_t A0 = Q0 << aS, A1 = Q1 << aS;                    // audio samples of this block
+    const bool interp = au.interp != 0;
+    // audio samples of this block: interpolating form = arbitrary stage then x2 stages; decimating form (bandwidth above
+    // the audio rate, e.g. FM 200 kHz) = /2 stages then arbitrary stage, one audio sample per arbitrary-stage output
+    const int64_t A0 = interp ? (Q0 << aS) : Q0, A1 = interp ? (Q1 << aS) : Q1;
     const int n_audio = (int)(A1 - A0);
     const float *arms = arms_all + (size_t)au.arms_idx * kArms * kArmTaps;
     const bool autogain = !(cfg.modem == CSDR_MODEM_NBFM || cfg.modem == CSDR_MODEM_FM);
@@ -830,18 +833,30 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
         }
     }
 
-    // backward range propagation: lo[s] = first needed index of the input of stage s (s = 0 is v = arbitrary-stage output)
-    int64_t lo[kMaxHb + 1];
-    lo[aS] = A0;
-    for (int s = aS - 1; s >= 0; --s) lo[s] = (lo[s + 1] >> 1) - (2 * au.m_x[s] - 1);
-    int64_t hi[kMaxHb + 1];
-    hi[aS] = A1;
-    for (int s = aS - 1; s >= 0; --s) hi[s] = (hi[s + 1] + 1) >> 1;
+    // backward range propagation.
+    //  interpolating: lo[s] / hi[s] = range of the input of x2 stage s (s = 0 is v = arbitrary-stage output), in samples
+    //  decimating:    lo[e] / hi[e] = range of the input of /2 stage e in its own index space (e = 0: u = j + abuf0;
+    //                 e = aS: the half-band chain output Z the arbitrary stage reads)
+    int64_t lo[kMaxHb + 1], hi[kMaxHb + 1];
+    int64_t jlo, jhi;
+    int nv = 0;
+    if (interp) {
+        lo[aS] = A0;
+        for (int s = aS - 1; s >= 0; --s) lo[s] = (lo[s + 1] >> 1) - (2 * au.m_x[s] - 1);
+        hi[aS] = A1;
+        for (int s = aS - 1; s >= 0; --s) hi[s] = (hi[s + 1] + 1) >> 1;
+        nv = (int)(hi[0] - lo[0]);
+        jlo = (((int64_t)dyn.aphase0 + lo[0] * (int64_t)au.step) >> 24) - (kArmTaps - 1);
+        jhi = nv > 0 ? (((int64_t)dyn.aphase0 + (hi[0] - 1) * (int64_t)au.step) >> 24) + 1 : jlo;
+    } else {
+        lo[aS] = (((int64_t)dyn.aphase0 + Q0 * (int64_t)au.step) >> 24) - (kArmTaps - 1);
+        hi[aS] = n_audio > 0 ? (((int64_t)dyn.aphase0 + (Q1 - 1) * (int64_t)au.step) >> 24) + 1 : lo[aS];
+        for (int e = aS - 1; e >= 0; --e) { lo[e] = 2 * lo[e + 1] - (4 * au.m_x[e] - 2); hi[e] = 2 * hi[e + 1] - 1; }
+        jlo = lo[0] - (int64_t)dyn.abuf0;
+        jhi = hi[0] > lo[0] ? hi[0] - (int64_t)dyn.abuf0 : jlo;
+    }
 
-    // 0. stage the scaled demodulator samples the arbitrary stage touches
-    const int nv = (int)(hi[0] - lo[0]);
-    const int64_t jlo = (((int64_t)dyn.aphase0 + lo[0] * (int64_t)au.step) >> 24) - (kArmTaps - 1);
-    const int64_t jhi = nv > 0 ? (((int64_t)dyn.aphase0 + (hi[0] - 1) * (int64_t)au.step) >> 24) + 1 : jlo;
+    // 0. stage the scaled demodulator samples [jlo, jhi) the cascade touches
     const int nwin = (int)(jhi - jlo);
     const int jb0 = pl[b].j0, jbp = b > 0 ? pl[b - 1].j0 : 0;
     if (!autogain) {
@@ -876,6 +891,8 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     // the filter arms of this thread's first two arbitrary-stage outputs travel while the staging above lands
     float2 hv[2][kArmTaps / 2];
     int zoff[2] = {0, 0};
+    float *src = s_w0, *dst = s_w1;
+    if (interp) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int i = tid + r * kModemThreads;
@@ -914,7 +931,6 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     }
     __syncthreads();
     // 2. x2 stages: w'[2q] = w[q - m], w'[2q+1] = sum_j h1[j] w[q - j]
-    float *src = s_w0, *dst = s_w1;
     for (int s = 0; s < aS; ++s) {
         const int m = au.m_x[s];
         const int64_t olo = lo[s + 1], ohi = hi[s + 1], ilo = lo[s];
@@ -933,6 +949,43 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
         }
         __syncthreads();
         float *t = src; src = dst; dst = t;
+    }
+    } else {
+        // ---- decimating form (msresamp_rrrf with rate < 1): /2 half-band stages, then the arbitrary stage
+        __syncthreads();
+        const float *in = s_d;                                  // in[i - lo[e]] = input i of stage e
+        float *ping = s_w0, *pong = s_w1;
+        const float zeta = 1.0f / (float)(1 << aS);
+        for (int e = 0; e < aS; ++e) {
+            const int m = au.m_x[e];
+            const int64_t ilo = lo[e], olo = lo[e + 1];
+            const int nout = (int)(hi[e + 1] - olo);
+            const float sc = (e == aS - 1) ? zeta : 1.0f;
+            // y[k] = x[2k - 2m + 1] + sum_j h[j] (x[2k - 2j] + x[2k - 4m + 2 + 2j])
+            for (int i = tid; i < nout; i += kModemThreads) {
+                const int64_t k = olo + i;
+                const float *x = in + (2 * k - ilo);
+                float v = x[-2 * m + 1];
+                for (int j = 0; j < m; ++j) v = fmaf(au.h_x[e][j], x[-2 * j] + x[-4 * m + 2 + 2 * j], v);
+                ping[i] = v * sc;
+            }
+            __syncthreads();
+            in = ping;
+            float *t = ping; ping = pong; pong = t;
+        }
+        // arbitrary stage on the chain output Z = in[k - lo[aS]]
+        for (int i = tid; i < n_audio; i += kModemThreads) {
+            const int64_t P = (int64_t)dyn.aphase0 + (Q0 + i) * (int64_t)au.step;
+            const int64_t kq = P >> 24;
+            const float *h = arms + (int)((P & 0xFFFFFF) >> 16) * kArmTaps;
+            const float *z = in + (kq - (kArmTaps - 1) - lo[aS]);
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < kArmTaps; ++t) acc = fmaf(h[t], z[t], acc);
+            ping[i] = acc;
+        }
+        __syncthreads();
+        src = ping;
     }
     // 3. write audio, peak, level (audio-based for the useSignalOutput modems, IQ-based |x| sum for NBFM / FM:
     //    DemodulatorThread.cpp:142-152, abMagnitude :49-57)

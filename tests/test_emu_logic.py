@@ -72,6 +72,11 @@ def test_emu_mixed_modems(ctx):
 
 
 @full
+def test_emu_wide_fm(ctx):
+    G.test_wide_fm_audio_decimation(ctx)
+
+
+@full
 def test_emu_batched(ctx):
     G.test_batched_equals_reference(ctx)
 
@@ -98,3 +103,8 @@ def test_emu_spectrum_contiguous(ctx):
 @full
 def test_emu_spectrum_many_frames(ctx):
     G.test_spectrum_many_frames_one_batch(ctx)
+
+
+@full
+def test_emu_retune_skip_inactive(ctx):
+    G.test_retune_skip_and_inactive(ctx)

@@ -189,6 +189,13 @@ def test_mixed_modems_streaming(ctx):
     print(_compare(got, want, "mixed"))
 
 
+def test_wide_fm_audio_decimation(ctx):
+    """ModemFM at its default 200 kHz (CubicSDR.cpp:305): the IQ resampler has a single half-band stage (generic front-end
+    kernel) and the audio msresamp_rrrf DECIMATES (200 k -> 48 k: two half-band stages, then the arbitrary stage)."""
+    got, want = _run_demods(ctx, 2400000, 4, 40000, ["FM", "NBFM", "FM"], 6, 2, seed=17)
+    print(_compare(got, want, "fm"))
+
+
 def test_batched_equals_reference(ctx):
     """6 blocks in two batches of 3: results must equal the block-at-a-time reference (counts exact)."""
     got, want = _run_demods(ctx, 2400000, 4, 40000, ["NBFM", "AM", "USB"], 6, 3)
@@ -423,3 +430,51 @@ def test_c2_full_size_batching_invariance(ctx):
     assert sorted(c1) == sorted(c2)
     for u, v in zip(a1, a2):
         assert np.array_equal(u, v)
+
+
+def test_retune_skip_and_inactive(ctx):
+    """Control-flow edges of DemodulatorPreThread::run (:154-165): a demodulator that is retuned between blocks keeps its NCO
+    phase and resampler state and only changes the phase increment; a demodulator tuned more than 0.75 x rate away from the
+    block's centre skips blocks without touching its state; an inactive demodulator is not fed at all."""
+    from cubicsdr_amd.engine import DemodBank, SDRPost
+    from oracle.cubicsdr_chain import RefDemod, RefSDRPost
+    fs, block, center = 480000, 8000, 50000000           # single-channel mode: shifts can exceed the skip bound
+    be = _backend()
+    x = synth_iq(8 * block, fs, center, [("NBFM", center + 50000), ("AM", center - 120000)], seed=81)
+    post, ref_post = SDRPost(ctx, fs, 1, block, max_blocks=1), RefSDRPost(be, fs, 1)
+    bank = DemodBank(ctx, 3, max_blocks=1)
+    plan = [  # per block: frequency of demod 0 (NBFM, stays on its carrier), frequency of demod 1 (AM), demod 2 active?
+        (center + 50000, center - 120000, True), (center + 50000, center - 120000, True),
+        (center + 51500, center - 120000, False), (center + 51500, center + 400000, False),      # retune; skip (|shift| > 360 k)
+        (center + 49000, center + 400000, True), (center + 49000, center - 120000, True),
+        (center + 50500, center - 119000, True), (center + 50000, center, True)]                  # retunes; zero shift (no mixing)
+    kinds, bws = ["NBFM", "AM", "NBFM"], [12500, 6000, 12500]
+    refs = []
+    for i, k in enumerate(kinds):
+        f0 = (plan[0][0], plan[0][1], center + 50000)[i]
+        bank.configure(i, post, k, bws[i], f0)
+        refs.append(RefDemod(be, k, bws[i], f0, fs))
+    for b, (f0, f1, act2) in enumerate(plan):
+        xb = x[b * block:(b + 1) * block]
+        bank.set_frequency(0, f0); refs[0].frequency = f0
+        bank.set_frequency(1, f1); refs[1].frequency = f1
+        bank.set_active(2, act2)
+        post.execute(xb, 1, block, center)
+        bank.execute(post)
+        ref_post.run_block(xb, center)
+        data, fc, rate = ref_post.channel_data(0)
+        for i in range(3):
+            res = bank.results(i)
+            if i == 2 and not act2:
+                assert res == []
+                continue
+            riq = refs[i].pre(data, fc, rate)
+            if riq is None:
+                assert len(res) == 1 and res[0].skipped == 1 and res[0].n_audio == 0, (b, i)
+                continue
+            want = refs[i].demodulate(riq)
+            r = res[0]
+            assert r.skipped == 0 and r.n_iq == riq.size and r.n_audio == want["audio"].size, (b, i, r.n_iq, riq.size)
+            assert rel_err(bank.iq(i), riq) < TOL, (b, i)
+            assert rel_err(bank.audio(i), want["audio"]) < TOL, (b, i)
+    post.close(); bank.close()
