@@ -84,6 +84,37 @@ __device__ inline void wave_sync() {
 // 16 bytes that are only guaranteed 8-byte aligned (two adjacent complex samples at an odd sample offset)
 struct __attribute__((aligned(8))) f4u { float x, y, z, w; };
 
+// N + 1 LDS reads of 16 bytes: N consecutive ones from pe, one from po (both 16-byte aligned), issued back to back and
+// waited for once.  Written as ds_read_b128 by hand: when a window is only partly used the compiler narrows float4 loads to
+// ds_read2_b64 pairs, and lanes 16 bytes apart then hit every bank twice (measured: half of the front-end's LDS cycles).
+template <int N> __device__ __forceinline__ void lds_read128(const float2 *pe, const float2 *po, float4 (&e)[N], float4 &o);
+#if defined(__AMDGCN__)
+typedef float csdr_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char *)p; }
+template <> __device__ __forceinline__ void lds_read128<4>(const float2 *pe, const float2 *po, float4 (&e)[4], float4 &o) {
+    csdr_v4f a, b, c, d, q;
+    asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\tds_read_b128 %3, %5 offset:48\n\t"
+                 "ds_read_b128 %4, %6\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(q) : "v"(lds_addr(pe)), "v"(lds_addr(po)) : "memory");
+    e[0] = make_float4(a.x, a.y, a.z, a.w); e[1] = make_float4(b.x, b.y, b.z, b.w); e[2] = make_float4(c.x, c.y, c.z, c.w);
+    e[3] = make_float4(d.x, d.y, d.z, d.w); o = make_float4(q.x, q.y, q.z, q.w);
+}
+template <> __device__ __forceinline__ void lds_read128<6>(const float2 *pe, const float2 *po, float4 (&e)[6], float4 &o) {
+    csdr_v4f a, b, c, d, f, g, q;
+    asm volatile("ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:16\n\tds_read_b128 %2, %7 offset:32\n\tds_read_b128 %3, %7 offset:48\n\t"
+                 "ds_read_b128 %4, %7 offset:64\n\tds_read_b128 %5, %7 offset:80\n\tds_read_b128 %6, %8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(f), "=&v"(g), "=&v"(q) : "v"(lds_addr(pe)), "v"(lds_addr(po)) : "memory");
+    e[0] = make_float4(a.x, a.y, a.z, a.w); e[1] = make_float4(b.x, b.y, b.z, b.w); e[2] = make_float4(c.x, c.y, c.z, c.w);
+    e[3] = make_float4(d.x, d.y, d.z, d.w); e[4] = make_float4(f.x, f.y, f.z, f.w); e[5] = make_float4(g.x, g.y, g.z, g.w);
+    o = make_float4(q.x, q.y, q.z, q.w);
+}
+#else
+template <int N> __device__ __forceinline__ void lds_read128(const float2 *pe, const float2 *po, float4 (&e)[N], float4 &o) {
+    for (int i = 0; i < N; ++i) e[i] = reinterpret_cast<const float4 *>(pe)[i];
+    o = *reinterpret_cast<const float4 *>(po);
+}
+#endif
+
 }  // namespace csdr
 
 // kernel ids for the optional per-kernel HIP-event profile (csdr_ctx_profile_*)

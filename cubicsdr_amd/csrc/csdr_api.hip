@@ -230,7 +230,11 @@ static int chan_geometry(int M, ChanGeom &g) {
     int B = 1;
     for (int d = 1; (int64_t)d * d <= M; ++d) if (M % d == 0) B = d;     // largest divisor <= sqrt(M)
     g.B = B; g.A = M / B;
-    g.A4 = (g.A + 3) & ~3; g.B4 = (g.B + 3) & ~3;
+    // DFT outputs per pass: the k range is cut into the fewest passes of <= 8 accumulators, then evened out (A = 5 -> one
+    // pass of 5, not two of 4); rows of the twiddle tables are padded to whole passes
+    auto passes = [](int n, int &K, int &nk, int &pitch) { nk = (n + 7) / 8; K = std::max(4, (n + nk - 1) / nk); pitch = nk * K; };
+    passes(g.A, g.KA, g.nkA, g.PA);
+    passes(g.B, g.KB, g.nkB, g.PB);
     g.magicM = (unsigned)((1ull << 32) / (unsigned)M) + 1u;
     g.taps_lds = (M <= 512) ? 1 : 0;
     g.stage_in = (M <= 256) ? 1 : 0;
@@ -248,7 +252,18 @@ static int chan_geometry(int M, ChanGeom &g) {
         if (tf == 1) return fail(CSDR_EUNSUPPORTED, "numChannels %d does not fit the channelizer's LDS tile", M);
     }
     if ((int64_t)g.TF * M * M >= (1ll << 31)) return fail(CSDR_EUNSUPPORTED, "numChannels %d too large", M);
+    // workgroup size: four waves, one per SIMD (five waves balance M = 20 better on paper -- 10 FIR wave-iterations, 4 + 5 DFT
+    // wave-items -- but measured 20 % slower on MI355X: the fifth wave doubles up on one SIMD)
+    g.threads = 256;
+    static const int thr_env = getenv("CSDR_CHAN_THREADS") ? atoi(getenv("CSDR_CHAN_THREADS")) : 0;    // experiment knob
+    if (thr_env >= 64 && thr_env <= 64 * kChanMaxWaves && thr_env % 64 == 0) g.threads = thr_env;
     return CSDR_OK;
+}
+
+typedef void (*chan_kernel_t)(const float2 *, const float2 *, float2 *, const float *, const float2 *, const float2 *, const float2 *,
+                              const int *, ChanGeom, int64_t, float2 *, int64_t, d2 *, double);
+static chan_kernel_t chan_kernel(const ChanGeom &g) {
+    return g.stage_in ? chan_analyze<1, 1> : g.taps_lds ? chan_analyze<0, 1> : chan_analyze<0, 0>;
 }
 
 extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_channels, int mode, int max_block_len, int max_blocks) {
@@ -285,10 +300,10 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
         std::vector<float> taps = design::channelizer_taps((unsigned)M, 4, 60.0f);
         std::vector<float> tapsT((size_t)kChanTaps * M);
         for (int c = 0; c < M; c++) for (int n = 0; n < kChanTaps; n++) tapsT[(size_t)n * M + c] = taps[(size_t)c * kChanTaps + n];
-        std::vector<float2> twA((size_t)g.A * g.A4, make_float2(0.f, 0.f)), twB((size_t)g.B * g.B4, make_float2(0.f, 0.f)), twM((size_t)g.A * g.B);
+        std::vector<float2> twA((size_t)g.A * g.PA, make_float2(0.f, 0.f)), twB((size_t)g.B * g.PB, make_float2(0.f, 0.f)), twM((size_t)g.A * g.B);
         auto W = [](int64_t num, int den) { const double a = -2.0 * M_PI * (double)(num % den) / (double)den; return make_float2((float)std::cos(a), (float)std::sin(a)); };
-        for (int c1 = 0; c1 < g.A; c1++) for (int k1 = 0; k1 < g.A; k1++) twA[(size_t)c1 * g.A4 + k1] = W((int64_t)c1 * k1, g.A);
-        for (int c2 = 0; c2 < g.B; c2++) for (int k2 = 0; k2 < g.B; k2++) twB[(size_t)c2 * g.B4 + k2] = W((int64_t)c2 * k2, g.B);
+        for (int c1 = 0; c1 < g.A; c1++) for (int k1 = 0; k1 < g.A; k1++) twA[(size_t)c1 * g.PA + k1] = W((int64_t)c1 * k1, g.A);
+        for (int c2 = 0; c2 < g.B; c2++) for (int k2 = 0; k2 < g.B; k2++) twB[(size_t)c2 * g.PB + k2] = W((int64_t)c2 * k2, g.B);
         for (int k1 = 0; k1 < g.A; k1++) for (int c2 = 0; c2 < g.B; c2++) twM[(size_t)k1 * g.B + c2] = W((int64_t)k1 * c2, M);
         if (int rc = p->taps.reserve(tapsT.size())) return rc;
         if (int rc = p->twA.reserve(twA.size())) return rc;
@@ -305,7 +320,7 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
         CSDR_HIP_TRY(hipMemsetAsync(p->hist1.p, 0, H * sizeof(float2), st));
         CSDR_HIP_TRY(hipStreamSynchronize(st));   // host vectors above go out of scope
         const size_t lds = chan_lds_bytes(g);
-        if (lds > 64 * 1024) CSDR_HIP_TRY(hipFuncSetAttribute((const void *)chan_analyze, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 64 * 1024) CSDR_HIP_TRY(hipFuncSetAttribute((const void *)chan_kernel(g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     p->hist_parity = 0;
     p->active_host.resize(M);
@@ -398,7 +413,8 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
         // channelizer itself emits the per-tile end values the blocked scan needs
         const bool dc0 = !p->active_host.empty() && p->active_host[0] == 0;
         const bool fused_ends = dc0 && g.fpw >= 16;
-        CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, chan_analyze, dim3(ntiles), dim3(kChanThreads), chan_lds_bytes(g), x, hist, hist_new, p->taps.p,
+        const chan_kernel_t kern = chan_kernel(g);
+        CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, kern, dim3(ntiles), dim3(g.threads), chan_lds_bytes(g), x, hist, hist_new, p->taps.p,
                     p->twA.p, p->twB.p, p->twM.p, p->active.p, g, n_frames, out, p->chan_stride, fused_ends ? p->tile_end.p : (d2 *)nullptr, p->dc_c);
         p->hist_parity ^= 1;
         CSDR_HIP_TRY(hipGetLastError());

@@ -394,10 +394,14 @@ template <int CH>
 __host__ __device__ constexpr int fes_off(int e) { return e * kFeTail + CH - (CH >> e); }
 template <int S, int CH>
 __host__ __device__ constexpr size_t fes_lds_bytes() {
-    return (size_t)(2 * (S * kFeTail + CH - (CH >> S)) + kFeZTail + (CH >> S)) * sizeof(float2) + kFeTabLen * sizeof(float) +
+    return (size_t)(2 * (S * kFeTail + CH - (CH >> S)) + 2 + kFeZTail + (CH >> S)) * sizeof(float2) + kFeTabLen * sizeof(float) +
            (S * kHbMaxM) * sizeof(float);
 }
 constexpr int fes_m(int S, int e) { return e == S - 1 ? 10 : (e == S - 2 ? 5 : 3); }
+// the odd-sample array of a stage with odd m starts one entry later, so that the pair O[2t - m], O[2t - m + 1] a thread
+// reads is 16-byte aligned like its even-sample window
+template <int S, int CH>
+__host__ __device__ constexpr int fes_offo(int e) { return fes_off<CH>(e) + (fes_m(S, e) & 1); }
 
 // CNT outputs of stage `E` (compile-time), two per thread
 template <int M, int CNT>
@@ -409,13 +413,11 @@ __device__ inline void fes_stage_pairs(const float2 *__restrict__ Ein, const flo
         const int t = t0 + (int)threadIdx.x;
         if (NP >= kFeThreads || t < NP) {
             float2 ev[2 * M + 2];                               // ev[i] = E[2t - 2M + i]
-            const float4 *e4 = reinterpret_cast<const float4 *>(Ein + 2 * t - 2 * M);
+            float4 e4[M + 1], o4;                               // both windows are 16-byte aligned (fes_offo)
+            lds_read128<M + 1>(Ein + 2 * t - 2 * M, Oin + 2 * t - M, e4, o4);
 #pragma unroll
-            for (int i = 0; i <= M; ++i) { const float4 v = e4[i]; ev[2 * i] = make_float2(v.x, v.y); ev[2 * i + 1] = make_float2(v.z, v.w); }
-            float2 o0, o1;
-            if (M % 2 == 0) { const float4 v = *reinterpret_cast<const float4 *>(Oin + 2 * t - M); o0 = make_float2(v.x, v.y); o1 = make_float2(v.z, v.w); }
-            else { o0 = Oin[2 * t - M]; o1 = Oin[2 * t - M + 1]; }
-            float a0r = o0.x, a0i = o0.y, a1r = o1.x, a1i = o1.y;
+            for (int i = 0; i <= M; ++i) { ev[2 * i] = make_float2(e4[i].x, e4[i].y); ev[2 * i + 1] = make_float2(e4[i].z, e4[i].w); }
+            float a0r = o4.x, a0i = o4.y, a1r = o4.z, a1i = o4.w;
 #pragma unroll
             for (int j = 0; j < M; ++j) {
                 const float hj = h[j];
@@ -447,12 +449,12 @@ __device__ inline void fes_stage_last(const float2 *__restrict__ Ein, const floa
 }
 // move the last kFeTail entries of stage region E (data count CNT >= kFeTail) to its front; threads 256-48 .. 255
 template <int CNT>
-__device__ inline void fes_carry_tail(float2 *__restrict__ LE, float2 *__restrict__ LO, int off) {
+__device__ inline void fes_carry_tail(float2 *__restrict__ LE, float2 *__restrict__ LO, int off, int offo) {
     const int c = (int)threadIdx.x - (kFeThreads - 2 * kFeTail);
     if (c >= 0) {
-        float2 *arr = c < kFeTail ? LE : LO;
+        float2 *arr = c < kFeTail ? LE + off : LO + offo;
         const int k = c < kFeTail ? c : c - kFeTail;
-        arr[off + k] = arr[off + CNT + k];
+        arr[k] = arr[CNT + k];
     }
 }
 
@@ -471,21 +473,21 @@ struct FesStages {
     static __device__ inline void run(float2 *LE, float2 *LO, float2 *LZ, const float *hb, float zeta) {
         constexpr int CNT = CH >> (E + 1);                       // outputs of stage E
         constexpr int M = fes_m(S, E);
-        const float2 *Ein = LE + fes_off<CH>(E) + kFeTail, *Oin = LO + fes_off<CH>(E) + kFeTail;
+        const float2 *Ein = LE + fes_off<CH>(E) + kFeTail, *Oin = LO + fes_offo<S, CH>(E) + kFeTail;
         if constexpr (E == S - 1) fes_stage_last<CNT>(Ein, Oin, hb + E * kHbMaxM, zeta, LZ + kFeZTail);
-        else fes_stage_pairs<M, CNT>(Ein, Oin, hb + E * kHbMaxM, LE + fes_off<CH>(E + 1) + kFeTail, LO + fes_off<CH>(E + 1) + kFeTail);
+        else fes_stage_pairs<M, CNT>(Ein, Oin, hb + E * kHbMaxM, LE + fes_off<CH>(E + 1) + kFeTail, LO + fes_offo<S, CH>(E + 1) + kFeTail);
         if constexpr (!WAVE) {
             // the tail of the PREVIOUS stage's input region is free to move now (its consumer finished at the last barrier)
-            if constexpr (E >= 1) fes_carry_tail<(CH >> E)>(LE, LO, fes_off<CH>(E - 1));
+            if constexpr (E >= 1) fes_carry_tail<(CH >> E)>(LE, LO, fes_off<CH>(E - 1), fes_offo<S, CH>(E - 1));
             __syncthreads();
         } else {
             // wave 0 alone: its own stage input is free once every lane has read it
             wave_sync();
             const int c = (int)threadIdx.x;
             if (c < 2 * kFeTail) {
-                float2 *arr = c < kFeTail ? LE : LO;
+                float2 *arr = c < kFeTail ? LE + fes_off<CH>(E) : LO + fes_offo<S, CH>(E);
                 const int k = c < kFeTail ? c : c - kFeTail;
-                arr[fes_off<CH>(E) + k] = arr[fes_off<CH>(E) + (CH >> (E + 1)) + k];
+                arr[k] = arr[(CH >> (E + 1)) + k];
             }
         }
         FesStages<S, CH, E + 1, END, WAVE>::run(LE, LO, LZ, hb, zeta);
@@ -522,7 +524,7 @@ __global__ __launch_bounds__(kFeThreads, 4) void demod_frontend_s(
 
     float2 *LE = reinterpret_cast<float2 *>(smem);
     float2 *LO = LE + ALEN;
-    float2 *LZ = LO + ALEN;
+    float2 *LZ = LO + ALEN + 2;
     float *tab = reinterpret_cast<float *>(LZ + kFeZTail + CZ);
     float *hb = tab + kFeTabLen;
     for (int i = tid; i < kFeTabLen; i += kFeThreads) tab[i] = sintab[i & 1023];
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(kFeThreads, 4) void demod_frontend_s(
     for (int i = tid; i < S * kFeTail; i += kFeThreads) {
         const int e = i / kFeTail, k = i % kFeTail;
         LE[fes_off<CH>(e) + k] = make_float2(0.f, 0.f);
-        LO[fes_off<CH>(e) + k] = make_float2(0.f, 0.f);
+        LO[fes_offo<S, CH>(e) + k] = make_float2(0.f, 0.f);
     }
     if (tid < kFeZTail) LZ[tid] = make_float2(0.f, 0.f);
 
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(kFeThreads, 4) void demod_frontend_s(
                     if (rel0 + 2 * p >= 0) a = make_float2(fmaf(a.x, ca, -(a.y * sa)), fmaf(a.y, ca, a.x * sa));
                     if (rel0 + 2 * p + 1 >= 0) b = make_float2(fmaf(b.x, cb, -(b.y * sb)), fmaf(b.y, cb, b.x * sb));
                 }
-                LE[kFeTail + p] = a; LO[kFeTail + p] = b;
+                LE[kFeTail + p] = a; LO[fes_offo<S, CH>(0) + kFeTail + p] = b;
             }
         }
         // ---- resampler outputs of this chunk: fetch their filter arms before the prefetch (vector-memory waits retire in order)
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(kFeThreads, 4) void demod_frontend_s(
         constexpr int BLK = fes_blk<S, CH>();
         FesStages<S, CH, 0, BLK, false>::run(LE, LO, LZ, hb, zeta);
         // tail of the last block-wide stage's input region (threads 208 .. 255)
-        if constexpr (BLK >= 1) fes_carry_tail<(CH >> BLK)>(LE, LO, fes_off<CH>(BLK - 1));
+        if constexpr (BLK >= 1) fes_carry_tail<(CH >> BLK)>(LE, LO, fes_off<CH>(BLK - 1), fes_offo<S, CH>(BLK - 1));
         if (BLK < S && tid >= 64) continue;                      // waves 1..3 go on to the next chunk
         FesStages<S, CH, BLK, S, true>::run(LE, LO, LZ, hb, zeta);
         // ---- the arbitrary resampler on Z

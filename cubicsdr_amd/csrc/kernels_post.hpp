@@ -183,24 +183,28 @@ __global__ __launch_bounds__(kDcThreads) void dc_apply(const float2 *x, float2 *
 //  phase 0  polyphase FIR straight from HBM/L2: the input is one flat stream, so lane i reads x[i - n M], n = 0..7,
 //           fully coalesced 16-byte loads (two samples per lane); X goes to LDS as X[t][c] with a padded row stride.
 //  phase 1  M = A B.  c = c1 B + c2, k = k1 + A k2:  Z[t][c2][k1] = W_M^(k1 c2) sum_c1 X[t][c1 B + c2] W_A^(k1 c1)
-//           work item = (t, c2); four k1 accumulators per pass; the W_A twiddles are wave-uniform (scalar loads).
+//           work item = (t, c2); KA (4..8) k1 accumulators per pass; the W_A twiddles are wave-uniform (scalar loads).
 //  phase 2  y[t][k1 + A k2] = sum_c2 Z[t][c2][k1] W_B^(k2 c2);  work item = (t, k1); lanes run along t, so every
 //           channel-major store instruction writes up to 512 contiguous bytes of one channel row.
 // Cost per frame M (A + B) complex MACs for any M (4, 20, 122, 200, 1024 ...); the reference computes the same DFT
 // with liquid's mixed-radix FFT and then copies out the channels that have consumers (SDRPostThread.cpp:336-339,
 // :364-381); here only rows whose `active` flag is set are stored.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int kChanThreads = 256;
 constexpr int kChanTaps = 8;
+constexpr int kChanMaxWaves = 8;
 
 struct ChanGeom {
-    int M, A, B, A4, B4;      // M = A * B; A4 / B4 = A / B rounded up to a multiple of 4 (twiddle row pitch)
+    int M, A, B;              // M = A * B
+    int KA, KB;               // DFT outputs accumulated per pass (4..8): ceil(A / nkA), ceil(B / nkB)
+    int nkA, nkB;             // passes over the k1 / k2 range
+    int PA, PB;               // twiddle row pitch: nkA * KA, nkB * KB (rows zero padded)
     int TF, lgTF;             // frames per workgroup (power of two)
     int S;                    // LDS row stride in float2 units (>= M, conflict-free for lanes along t)
     unsigned magicM;          // floor(2^32 / M) + 1 : i / M for i < 2^20
     int taps_lds;             // 1: the [8][M] tap table is staged in LDS
     int stage_in;             // 1: the (TF + 7) M input samples of the tile are staged in LDS (aliasing the Z array)
-    int fpw;                  // frames one workgroup processes (<= TF): set per launch so the grid fills whole rounds
+    int fpw;                  // frames one workgroup processes (<= TF)
+    int threads;              // workgroup size (whole waves, 256..512): chosen so each phase splits evenly over the waves
 };
 __host__ __device__ inline size_t chan_zin_floats2(const ChanGeom &g) {      // Z array, or the staged input tile if larger
     const size_t z = (size_t)g.TF * g.S, in = g.stage_in ? (size_t)(g.TF + kChanTaps - 1) * g.M : 0;
@@ -212,51 +216,99 @@ __host__ __device__ inline size_t chan_lds_bytes(const ChanGeom &g) {
     return (b + 15) & ~(size_t)15;
 }
 
-__global__ __launch_bounds__(kChanThreads) void chan_analyze(
+// K accumulators of an n-point DFT: acc[j] = sum_c v[c * vstride] * w[c * wpitch + j]; `w` is wave-uniform (scalar loads)
+template <int K>
+__device__ __forceinline__ void chan_dft(const float2 *v, int vstride, const float2 *__restrict__ w, int wpitch, int n, float2 (&acc)[K]) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc[j] = make_float2(0.f, 0.f);
+    for (int c = 0; c < n; ++c, w += wpitch) {
+        const float2 x = v[c * vstride];
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc[j] = cfma(x, w[j], acc[j]);
+    }
+}
+
+// phase 1 for one wave item: A-point DFTs over c1 (K of the k1 outputs) for 64 (t, c2) pairs, times W_M^(k1 c2)
+template <int K>
+__device__ __forceinline__ void chan_phase1(const ChanGeom &g, const float2 *s_x, float2 *s_z, const float2 *__restrict__ twA,
+                                            const float2 *__restrict__ twM, int k1b, int t, int c2) {
+    const int A = g.A, B = g.B;
+    // the W_M factors are fetched (row index clamped) before the DFT so one memory latency covers all of them
+    float2 m[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) m[j] = twM[(size_t)min(k1b + j, A - 1) * B + c2];
+    float2 acc[K];
+    chan_dft<K>(s_x + (size_t)t * g.S + c2, B, twA + k1b, g.PA, A, acc);
+    float2 *zr = s_z + (size_t)t * g.S + c2 * A + k1b;
+#pragma unroll
+    for (int j = 0; j < K; ++j) if (k1b + j < A) zr[j] = cmul(acc[j], m[j]);
+}
+
+// phase 2 for one wave item: B-point DFTs over c2 (K of the k2 outputs) for 64 (t, k1) pairs; channel-major stores
+template <int K>
+__device__ __forceinline__ void chan_phase2(const ChanGeom &g, float2 *s_x, const float2 *s_z, const float2 *__restrict__ twB,
+                                            const int *__restrict__ active, float2 *__restrict__ out, int64_t out_stride,
+                                            int64_t f0, bool keep0, int k2b, int t, int k1) {
+    const int A = g.A, B = g.B, M = g.M;
+    const int k = k1 + A * k2b;
+    // consumer flags of the K rows, fetched (index clamped) ahead of the DFT: one latency, not K in a chain
+    int on[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) on[j] = active[min(k + j * A, M - 1)];
+    float2 acc[K];
+    chan_dft<K>(s_z + (size_t)t * g.S + k1, A, twB + k2b, g.PB, B, acc);
+    float2 *o = out + (int64_t)k * out_stride + f0 + t;
+    if (k == 0 && keep0) s_x[t] = acc[0];                 // channel 0 of this tile (s_x is free after phase 1)
+#pragma unroll
+    for (int j = 0; j < K; ++j) if (k2b + j < B && on[j]) o[(int64_t)j * A * out_stride] = acc[j];
+}
+
+template <int STAGE_IN, int TAPS_LDS>
+__global__ __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
     const float2 *__restrict__ x,        // batch input, n_frames * M samples
     const float2 *__restrict__ hist,     // 7 * M samples preceding x
     float2 *__restrict__ hist_new,       // receives the last 7 * M samples of (hist ++ x)
     const float *__restrict__ tapsT,     // [8][M]  tapsT[n M + c] multiplies x[(t - n) M + c]
-    const float2 *__restrict__ twA,      // [A][A4] exp(-j 2 pi k1 c1 / A) at [c1 A4 + k1], zero padded
-    const float2 *__restrict__ twB,      // [B][B4] exp(-j 2 pi k2 c2 / B) at [c2 B4 + k2], zero padded
+    const float2 *__restrict__ twA,      // [A][PA] exp(-j 2 pi k1 c1 / A) at [c1 PA + k1], zero padded
+    const float2 *__restrict__ twB,      // [B][PB] exp(-j 2 pi k2 c2 / B) at [c2 PB + k2], zero padded
     const float2 *__restrict__ twM,      // [A][B]  exp(-j 2 pi k1 c2 / M) at [k1 B + c2]
     const int *__restrict__ active,      // [M] 1: store channel row k
     ChanGeom g, int64_t n_frames,
     float2 *__restrict__ out, int64_t out_stride,
     d2 *__restrict__ dc_ends, double dc_c /* DC blocker of channel 0: end value of this tile's recurrence (zero entering state) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int M = g.M, A = g.A, B = g.B, TF = g.TF, S = g.S;
+    const int M = g.M, TF = g.TF, S = g.S;
     float2 *s_x = reinterpret_cast<float2 *>(smem);
     float2 *s_z = s_x + (size_t)TF * S;                   // also the staged input tile during phase 0
     float *s_taps = reinterpret_cast<float *>(s_z + chan_zin_floats2(g));
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;
     const int64_t f0 = (int64_t)blockIdx.x * g.fpw;       // first frame of this tile (g.fpw <= TF frames per workgroup)
     const int nf = (int)min((int64_t)g.fpw, n_frames - f0);
     const int64_t H = (int64_t)(kChanTaps - 1) * M;
 
     const int64_t base = f0 * M;
-    if (g.stage_in) {
+    if (STAGE_IN) {
         // one memory round trip: every input sample of the tile (7 frames of halo first) is loaded once, 16 bytes per lane
         float4 *s_in4 = reinterpret_cast<float4 *>(s_z);
         const int n_in2 = ((nf + kChanTaps - 1) * M) >> 1;
-        for (int p = tid; p < n_in2; p += kChanThreads) {
+        for (int p = tid; p < n_in2; p += nthr) {
             const int64_t gi = base - H + 2 * (int64_t)p;
             const float2 *src = gi >= 0 ? x + gi : hist + (gi + H);
             s_in4[p] = *reinterpret_cast<const float4 *>(src);
         }
     }
-    if (g.taps_lds) for (int i = tid; i < kChanTaps * M; i += kChanThreads) s_taps[i] = tapsT[i];
-    if (g.stage_in || g.taps_lds) __syncthreads();
-    const float *tp = g.taps_lds ? s_taps : tapsT;
+    if (TAPS_LDS) for (int i = tid; i < kChanTaps * M; i += nthr) s_taps[i] = tapsT[i];
+    if (STAGE_IN || TAPS_LDS) __syncthreads();
+    const float *tp = TAPS_LDS ? s_taps : tapsT;
 
     // ---- phase 0: polyphase FIR, two adjacent samples (same frame: M is even) per lane
     const int npairs = (nf * M) >> 1;
-    for (int p = tid; p < npairs; p += kChanThreads) {
+    for (int p = tid; p < npairs; p += nthr) {
         const unsigned i = 2u * (unsigned)p;
         const unsigned t = __umulhi(i, g.magicM);
         const unsigned c = i - t * (unsigned)M;
         float2 a0 = make_float2(0.f, 0.f), a1 = make_float2(0.f, 0.f);
-        if (g.stage_in) {
+        if (STAGE_IN) {
             const float2 *sp = s_z + (size_t)(kChanTaps - 1) * M + i;      // x[(f0 + t) M + c] inside the staged tile
 #pragma unroll
             for (int n = 0; n < kChanTaps; ++n) {
@@ -283,7 +335,7 @@ __global__ __launch_bounds__(kChanThreads) void chan_analyze(
     // the last workgroup also writes the new input history (the launch runs even with no consumers)
     if (blockIdx.x == gridDim.x - 1) {
         const int64_t n = n_frames * M;
-        for (int64_t j = tid; j < H; j += kChanThreads) {
+        for (int64_t j = tid; j < H; j += nthr) {
             const int64_t gsrc = n - H + j;
             hist_new[j] = gsrc >= 0 ? x[gsrc] : hist[gsrc + H];
         }
@@ -291,57 +343,43 @@ __global__ __launch_bounds__(kChanThreads) void chan_analyze(
     __syncthreads();
 
     // ---- phase 1: A-point DFTs over c1 for every (t, c2), times W_M^(k1 c2).
-    // wave item = (block of four k1, 64 consecutive (t, c2) items): k1b is wave-uniform, so the W_A rows are scalar loads.
-    const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+    // wave item = (block of KA k1, 64 consecutive (t, c2) items): k1b is wave-uniform, so the W_A rows are scalar loads.
+    const int lane = tid & 63, wave = wave_uniform(tid >> 6), nw = nthr >> 6;
     const int tmask = TF - 1;
     {
-        const int items = TF * B, nch = (items + 63) >> 6, nkb = g.A4 >> 2;
-        for (int w = wave; w < nkb * nch; w += kChanThreads / 64) {
-            const int kb = w / nch, k1b = kb * 4;
+        const int items = TF * g.B, nch = (items + 63) >> 6;
+        for (int w = wave; w < g.nkA * nch; w += nw) {
+            const int kb = w / nch, k1b = kb * g.KA;
             const int it = (w - kb * nch) * 64 + lane;
             const int t = it & tmask, c2 = it >> g.lgTF;
             if (it >= items || t >= nf) continue;
-            const float2 *xr = s_x + (size_t)t * S + c2;
-            float2 acc0 = make_float2(0.f, 0.f), acc1 = acc0, acc2 = acc0, acc3 = acc0;
-            const float2 *wr = twA + k1b;
-            for (int c1 = 0; c1 < A; ++c1, wr += g.A4) {
-                const float2 v = xr[c1 * B];
-                acc0 = cfma(v, wr[0], acc0); acc1 = cfma(v, wr[1], acc1);
-                acc2 = cfma(v, wr[2], acc2); acc3 = cfma(v, wr[3], acc3);
+            switch (g.KA) {
+                case 4: chan_phase1<4>(g, s_x, s_z, twA, twM, k1b, t, c2); break;
+                case 5: chan_phase1<5>(g, s_x, s_z, twA, twM, k1b, t, c2); break;
+                case 6: chan_phase1<6>(g, s_x, s_z, twA, twM, k1b, t, c2); break;
+                case 7: chan_phase1<7>(g, s_x, s_z, twA, twM, k1b, t, c2); break;
+                default: chan_phase1<8>(g, s_x, s_z, twA, twM, k1b, t, c2); break;
             }
-            float2 *zr = s_z + (size_t)t * S + c2 * A + k1b;
-            const float2 *wm = twM + (size_t)k1b * B + c2;
-            zr[0] = cmul(acc0, wm[0]);
-            if (k1b + 1 < A) zr[1] = cmul(acc1, wm[B]);
-            if (k1b + 2 < A) zr[2] = cmul(acc2, wm[2 * B]);
-            if (k1b + 3 < A) zr[3] = cmul(acc3, wm[3 * B]);
         }
     }
     __syncthreads();
 
     // ---- phase 2: B-point DFTs over c2 for every (t, k1); channel-major stores, lanes along t
     {
-        const int items = TF * A, nch = (items + 63) >> 6, nkb = g.B4 >> 2;
-        for (int w = wave; w < nkb * nch; w += kChanThreads / 64) {
-            const int kb = w / nch, k2b = kb * 4;
+        const int items = TF * g.A, nch = (items + 63) >> 6;
+        const bool keep0 = dc_ends != nullptr;
+        for (int w = wave; w < g.nkB * nch; w += nw) {
+            const int kb = w / nch, k2b = kb * g.KB;
             const int it = (w - kb * nch) * 64 + lane;
             const int t = it & tmask, k1 = it >> g.lgTF;
             if (it >= items || t >= nf) continue;
-            const float2 *zr = s_z + (size_t)t * S + k1;
-            float2 acc0 = make_float2(0.f, 0.f), acc1 = acc0, acc2 = acc0, acc3 = acc0;
-            const float2 *wr = twB + k2b;
-            for (int c2 = 0; c2 < B; ++c2, wr += g.B4) {
-                const float2 v = zr[c2 * A];
-                acc0 = cfma(v, wr[0], acc0); acc1 = cfma(v, wr[1], acc1);
-                acc2 = cfma(v, wr[2], acc2); acc3 = cfma(v, wr[3], acc3);
+            switch (g.KB) {
+                case 4: chan_phase2<4>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1); break;
+                case 5: chan_phase2<5>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1); break;
+                case 6: chan_phase2<6>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1); break;
+                case 7: chan_phase2<7>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1); break;
+                default: chan_phase2<8>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1); break;
             }
-            const int k = k1 + A * k2b;
-            float2 *o = out + (int64_t)k * out_stride + f0 + t;
-            if (k == 0 && dc_ends) s_x[t] = acc0;                 // channel 0 of this tile (s_x is free after phase 1)
-            if (active[k]) o[0] = acc0;
-            if (k2b + 1 < B && active[k + A]) o[(int64_t)A * out_stride] = acc1;
-            if (k2b + 2 < B && active[k + 2 * A]) o[(int64_t)2 * A * out_stride] = acc2;
-            if (k2b + 3 < B && active[k + 3 * A]) o[(int64_t)3 * A * out_stride] = acc3;
         }
     }
     if (dc_ends) {
