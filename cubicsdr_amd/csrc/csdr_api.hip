@@ -974,6 +974,23 @@ struct csdr_spec {
     DevBuf<SpecFrameOut> fo;
     DevBuf<SpecScalars> scal;
     int carry_len = 0;
+    // CSDR_SPEC_LINES: fftLastData (the previous FFT input, :399-421) in two copies written alternately, lastDataSize != 0
+    DevBuf<float2> last[2], lines;
+    int last_cur = 0;
+    bool last_primed = false;
+    // peak hold (:247-273): peakHold / peakReset as in the reference; device state allocated when first enabled
+    bool peak_hold = false;
+    int peak_reset = 0;
+    DevBuf<double> peak;                     // fft_result_peak, pair layout like ma / maa
+    DevBuf<float2> maaf;
+    DevBuf<float> peaksum, peak_b, hold_points;
+    DevBuf<SpecPeakScalars> pk;
+    DevBuf<SpecFrameOut> pfo;
+    std::vector<char> hold_valid;            // per frame of the last process: spectrum_hold_points present
+    // hideDC (:578-623) and the frequencies it needs
+    bool hide_dc = false;
+    int64_t center_freq = 0, input_freq = 0;
+    long bandwidth = 0;
 };
 
 extern "C" int csdr_spec_create(csdr_ctx *ctx, csdr_spec **out) {
@@ -997,6 +1014,8 @@ extern "C" void csdr_spec_destroy(csdr_spec *s) {
     s->tw4096.release(); s->tw_hi.release(); s->tw_lo.release(); s->tmp.release(); s->carry.release();
     s->stage_in.release(); s->raw.release(); s->mag.release(); s->ext_w.release(); s->ext.release(); s->pairsum.release(); s->first_b.release(); s->points.release();
     s->ma.release(); s->maa.release(); s->fo.release(); s->scal.release();
+    s->last[0].release(); s->last[1].release(); s->lines.release();
+    s->peak.release(); s->maaf.release(); s->peaksum.release(); s->peak_b.release(); s->hold_points.release(); s->pk.release(); s->pfo.release();
     delete s;
 }
 
@@ -1052,12 +1071,26 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     CSDR_HIP_TRY(hipMemcpy(s->scal.p + 1, &sc, sizeof sc, hipMemcpyHostToDevice));
     s->scal_parity = 0;
     s->carry_len = 0; s->nf_last = 0;
+    s->last_cur = 0; s->last_primed = false;                         // lastDataSize = 0 (:166)
+    s->peak.release(); s->maaf.release(); s->peaksum.release(); s->peak_b.release(); s->hold_points.release();   // sized per fft size
+    if (s->peak_hold) s->peak_reset = 1;                              // fft_result_peak is rebuilt (:261): nothing held until a reset has run
     s->ready = true;
     return CSDR_OK;
 }
 extern "C" int csdr_spec_set_average_rate(csdr_spec *s, float r) { if (!s) return fail(CSDR_EINVAL, "null"); s->avg_rate = r; return CSDR_OK; }
 extern "C" int csdr_spec_set_scale_factor(csdr_spec *s, float f) { if (!s) return fail(CSDR_EINVAL, "null"); s->scale = f; return CSDR_OK; }
 extern "C" int csdr_spec_frames(const csdr_spec *s) { return s ? s->nf_last : 0; }
+extern "C" int csdr_spec_set_peak_hold(csdr_spec *s, int enabled) {      // setPeakHold :115-125
+    if (!s) return fail(CSDR_EINVAL, "null");
+    if (s->peak_hold && enabled) s->peak_reset = 30;                      // PEAK_RESET_COUNT (.h:12)
+    else { s->peak_hold = enabled != 0; s->peak_reset = 1; }
+    return CSDR_OK;
+}
+extern "C" int csdr_spec_get_peak_hold(const csdr_spec *s) { return s && s->peak_hold ? 1 : 0; }
+extern "C" int csdr_spec_set_hide_dc(csdr_spec *s, int enabled) { if (!s) return fail(CSDR_EINVAL, "null"); s->hide_dc = enabled != 0; return CSDR_OK; }
+extern "C" int csdr_spec_set_center_frequency(csdr_spec *s, int64_t f) { if (!s) return fail(CSDR_EINVAL, "null"); s->center_freq = f; return CSDR_OK; }
+extern "C" int csdr_spec_set_bandwidth(csdr_spec *s, int64_t bw) { if (!s) return fail(CSDR_EINVAL, "null"); s->bandwidth = (long)bw; return CSDR_OK; }
+extern "C" int csdr_spec_set_input_frequency(csdr_spec *s, int64_t f) { if (!s) return fail(CSDR_EINVAL, "null"); s->input_freq = f; return CSDR_OK; }
 
 template <int COLS>
 static void launch_radix(csdr_ctx *c, int R, const FrameSrc &fs, int L, unsigned tw_scale, int nseq, const float2 *hi, const float2 *lo, float2 *dst) {
@@ -1097,6 +1130,76 @@ static int spec_run_fft(csdr_spec *s, const FrameSrc &fs, int nf, float *mag, fl
     return CSDR_OK;
 }
 
+// averaging .. display for the frames [f0, f0 + cnt) of the current batch; frames >= pk_from (relative to f0) hold peaks
+static int spec_post_range(csdr_spec *s, const float *mag, int f0, int cnt, int pk_from) {
+    csdr_ctx *c = s->ctx;
+    const SpecGeom &g = s->g;
+    const size_t F = (size_t)g.F;
+    const bool hold = pk_from < cnt;
+    CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_average, dim3(s->n_avg_tiles), dim3(kAvgThreads), kAvgLds, mag + (size_t)f0 * g.N, cnt, g, (double)s->avg_rate,
+                s->ma.p, s->maa.p, s->pairsum.p + f0 * F, s->first_b.p + f0, s->ext_w.p + (size_t)f0 * s->n_avg_tiles,
+                hold ? s->maaf.p + f0 * F : (float2 *)nullptr, hold ? pk_from : cnt);
+    CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_extrema, dim3(cnt), dim3(256), 64, s->ext_w.p + (size_t)f0 * s->n_avg_tiles, s->n_avg_tiles, s->ext.p + f0);
+    const SpecScalars *st_in = s->scal.p + s->scal_parity;
+    if (hold) {
+        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_MISC, spec_peak_track, dim3((g.F + 255) / 256), dim3(256), 0, s->maaf.p + f0 * F, cnt, pk_from, g.F, s->peak.p,
+                    s->peaksum.p + f0 * F, s->peak_b.p + f0);
+        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_MISC, spec_peak_trackers, dim3(1), dim3(64), 0, s->ext.p + f0, cnt, pk_from, st_in, s->pk.p, s->pfo.p + f0);
+    }
+    // display: column blocks per frame sized so that the grid is about one round of resident workgroups
+    const int disp_gx = std::max(1, std::min((g.F / 2 + kDispThreads - 1) / kDispThreads, c->wg_slots(spec_display, kDispThreads, kDispLds) / std::max(1, cnt)));
+    CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_DISPLAY, spec_display, dim3(disp_gx, cnt), dim3(kDispThreads), kDispLds,
+                s->pairsum.p + f0 * F, s->first_b.p + f0, s->ext.p + f0, cnt, g.F, s->scale, st_in, s->scal.p + (s->scal_parity ^ 1), s->fo.p + f0,
+                s->points.p + f0 * 2 * F, hold ? pk_from : cnt, hold ? s->pfo.p + f0 : (const SpecFrameOut *)nullptr,
+                hold ? s->peaksum.p + f0 * F : (const float *)nullptr, hold ? s->peak_b.p + f0 : (const float *)nullptr,
+                hold ? s->hold_points.p + f0 * 2 * F : (float *)nullptr);
+    s->scal_parity ^= 1;
+    CSDR_HIP_TRY(hipGetLastError());
+    return CSDR_OK;
+}
+
+// The batch holds nf frames made from n_inputs process() inputs (input 0 makes no frame when it only primed fftLastData).
+// peakReset counts inputs (:264-273); the reset uses the trackers as they stand before that input's frame.
+static int spec_post_frames(csdr_spec *s, const float *mag, int nf, int n_inputs, bool first_input_has_frame) {
+    csdr_ctx *c = s->ctx;
+    const size_t F = (size_t)s->g.F;
+    const int skip = first_input_has_frame ? 0 : 1;                  // frame of input i is i - skip
+    // walk the inputs: doPeak(i) = peakHold && peakReset == 0 (before the decrement, :247)
+    int reset_input = -1, first_peak_input = n_inputs;
+    {
+        int pr = s->peak_reset;
+        for (int i = 0; i < n_inputs; ++i) {
+            if (s->peak_hold && pr == 0 && first_peak_input == n_inputs) first_peak_input = i;
+            if (pr != 0 && --pr == 0) reset_input = i;
+        }
+        s->peak_reset = pr;
+    }
+    if (s->peak_hold || reset_input >= 0) {
+        const size_t nfF = (size_t)s->max_frames * F;
+        if (int rc = s->peak.reserve(2 * F)) return rc;
+        if (int rc = s->pk.reserve(1)) return rc;
+        if (s->peak_hold) {
+            if (int rc = s->maaf.reserve(nfF)) return rc;
+            if (int rc = s->peaksum.reserve(nfF)) return rc;
+            if (int rc = s->peak_b.reserve(s->max_frames)) return rc;
+            if (int rc = s->hold_points.reserve(2 * nfF)) return rc;
+            if (int rc = s->pfo.reserve(s->max_frames)) return rc;
+        }
+    }
+    s->hold_valid.assign((size_t)std::max(nf, 0), 0);
+    auto frame_of = [&](int input) { return std::min(nf, std::max(0, input - skip)); };
+    for (int f = frame_of(first_peak_input); f < nf; ++f) s->hold_valid[f] = 1;
+    if (reset_input < 0) return nf > 0 ? spec_post_range(s, mag, 0, nf, frame_of(first_peak_input)) : CSDR_OK;
+    // frames of the inputs before the reset, the reset, then the rest (the reset input itself never holds: :247)
+    const int fr = frame_of(reset_input);
+    if (fr > 0) if (int rc = spec_post_range(s, mag, 0, fr, fr)) return rc;
+    CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_MISC, spec_peak_reset, dim3(std::max(1, std::min(256, (int)(2 * F + 255) / 256))), dim3(256), 0,
+                s->scal.p + s->scal_parity, s->peak.p, (int)(2 * F), s->pk.p);
+    CSDR_HIP_TRY(hipGetLastError());
+    if (nf > fr) return spec_post_range(s, mag, fr, nf - fr, frame_of(first_peak_input) - fr);
+    return CSDR_OK;
+}
+
 extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, int n_blocks, int block_len, int mode) {
     if (!s || !s->ready) return fail(CSDR_ESTATE, "spec not set up");
     if (!iq || n_blocks <= 0 || block_len <= 0) return fail(CSDR_EINVAL, "bad block arguments");
@@ -1114,6 +1217,8 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
     } else if ((uintptr_t)iq & 7) return fail(CSDR_EINVAL, "device IQ pointer must be 8-byte aligned");
     FrameSrc fs{nullptr, nullptr, nullptr, 0, 1 << 30};
     int nf = 0;
+    const float2 *lines_x = nullptr;
+    int lines_n = 0;
     if (mode == CSDR_SPEC_FIRST_FRAME) {
         if (block_len < N) return fail(CSDR_EUNSUPPORTED, "block_len %d < internal FFT size %d (overlap priming path :399-421 not built)", block_len, N);
         nf = n_blocks; fs.first = x; fs.rest = x + block_len; fs.stride = block_len;
@@ -1127,9 +1232,46 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
             else fs.first = x;
             fs.rest = x + (N - s->carry_len); fs.stride = N;
         }
+    } else if (mode == CSDR_SPEC_LINES) {
+        // every block is one input of fewer than 2*fftSize samples (FFTDataDistributor lines of fftSize samples): the FFT
+        // input is the previous FFT input shifted left by the line length with the line appended (:410-420); the very first
+        // line only primes fftLastData (zero padded, :401-409)
+        const int len = block_len;
+        if (len >= N) return fail(CSDR_EINVAL, "CSDR_SPEC_LINES takes blocks shorter than the internal FFT size %d", N);
+        for (int k = 0; k < 2; ++k) if (int rc = s->last[k].reserve((size_t)N)) return rc;
+        int nl = n_blocks;
+        if (!s->last_primed) {
+            float2 *L = s->last[s->last_cur].p;
+            CSDR_HIP_TRY(hipMemsetAsync(L + len, 0, (size_t)(N - len) * sizeof(float2), st));
+            CSDR_HIP_TRY(hipMemcpyAsync(L, x, (size_t)len * sizeof(float2), hipMemcpyDeviceToDevice, st));
+            s->last_primed = true;
+            x += len; --nl;
+        }
+        nf = nl;
+        if (nf > s->max_frames) return fail(CSDR_ERANGE, "%d frames exceed max_frames %d", nf, s->max_frames);
+        if (nf > 0) {
+            // V = last ++ lines; frame j = V[(j + 1) len, (j + 1) len + N)
+            const float2 *L = s->last[s->last_cur].p;
+            if (2 * len >= N) {          // only frame 0 straddles the two buffers: read in place
+                fs.first = L + len; fs.split = N - len; fs.first2 = x;
+                fs.rest = x + (2 * len - N); fs.stride = len;
+            } else {                     // several frames straddle: make the tail of `last` and the lines contiguous
+                const size_t need = (size_t)(N - len) + (size_t)nf * len;
+                if (int rc = s->lines.reserve(need)) return rc;
+                CSDR_HIP_TRY(hipMemcpyAsync(s->lines.p, L + len, (size_t)(N - len) * sizeof(float2), hipMemcpyDeviceToDevice, st));
+                CSDR_HIP_TRY(hipMemcpyAsync(s->lines.p + (N - len), x, (size_t)nf * len * sizeof(float2), hipMemcpyDeviceToDevice, st));
+                fs.first = s->lines.p; fs.rest = s->lines.p + len; fs.stride = len;
+            }
+        }
+        lines_x = x; lines_n = nf;
     } else return fail(CSDR_EINVAL, "mode");
     if (nf > s->max_frames) return fail(CSDR_ERANGE, "%d frames exceed max_frames %d", nf, s->max_frames);
     s->nf_last = nf;
+    // process() inputs behind these frames (peakReset counts inputs, :264): a block or a line each; contiguous mode has no
+    // reference input boundaries, every frame counts as one
+    const bool first_input_has_frame = !(mode == CSDR_SPEC_LINES && nf < n_blocks);
+    const int n_inputs = mode == CSDR_SPEC_CONTIGUOUS ? nf : n_blocks;
+    if (nf == 0 && n_inputs > 0) { if (int rc = spec_post_frames(s, nullptr, 0, n_inputs, first_input_has_frame)) return rc; }
     if (nf > 0) {
         // lane FFT fills magnitude copy `mp`; its previous reader was the averaging kernel two batches ago
         const int mp = c->same(LANE_FFT, LANE_AVG) ? 0 : (int)(s->seq & 1);
@@ -1137,22 +1279,28 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
         if (s->avg_pending[mp]) if (int rc = c->wait(s->ev_avg_done[mp], LANE_AVG, LANE_FFT)) return rc;
         if (int rc = spec_run_fft(s, fs, nf, mag, nullptr)) return rc;
         if (int rc = c->signal(s->ev_fft_done[mp], LANE_FFT, LANE_AVG)) return rc;
-        // lane AVG: averaging, extrema, trackers + display points
+        // lane AVG: averaging, extrema, trackers + display points (split where a peak-hold reset falls inside the batch)
         if (int rc = c->wait(s->ev_fft_done[mp], LANE_FFT, LANE_AVG)) return rc;
-        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_average, dim3(s->n_avg_tiles), dim3(kAvgThreads), kAvgLds, mag, nf, g, (double)s->avg_rate,
-                    s->ma.p, s->maa.p, s->pairsum.p, s->first_b.p, s->ext_w.p);
-        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_extrema, dim3(nf), dim3(256), 64, s->ext_w.p, s->n_avg_tiles, s->ext.p);
-        // display: column blocks per frame sized so that the grid is about one round of resident workgroups
-        const int disp_gx = std::max(1, std::min((g.F / 2 + kDispThreads - 1) / kDispThreads, c->wg_slots(spec_display, kDispThreads, kDispLds) / std::max(1, nf)));
-        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_DISPLAY, spec_display, dim3(disp_gx, nf), dim3(kDispThreads), kDispLds,
-                    s->pairsum.p, s->first_b.p, s->ext.p, nf, g.F, s->scale, s->scal.p + s->scal_parity, s->scal.p + (s->scal_parity ^ 1), s->fo.p,
-                    s->points.p);
-        s->scal_parity ^= 1;
-        CSDR_HIP_TRY(hipGetLastError());
+        if (int rc = spec_post_frames(s, mag, nf, n_inputs, first_input_has_frame)) return rc;
         if (int rc = c->signal(s->ev_avg_done[mp], LANE_AVG, LANE_FFT)) return rc;
         s->avg_pending[mp] = true;
         (void)st_y;
         s->seq++;
+    }
+    if (mode == CSDR_SPEC_LINES && lines_n > 0) {
+        // fftLastData = the last FFT input (:417) = V[nf len, nf len + N), written to the other copy (lane FFT: behind the
+        // kernels that read the current one)
+        const int len = block_len;
+        const float2 *L = s->last[s->last_cur].p;
+        float2 *Ln = s->last[s->last_cur ^ 1].p;
+        const int64_t from_x = (int64_t)lines_n * len;             // samples of the lines inside the new fftLastData (if < N)
+        if (from_x >= N) {
+            CSDR_HIP_TRY(hipMemcpyAsync(Ln, lines_x + (from_x - N), (size_t)N * sizeof(float2), hipMemcpyDeviceToDevice, st));
+        } else {
+            CSDR_HIP_TRY(hipMemcpyAsync(Ln, L + from_x, (size_t)(N - from_x) * sizeof(float2), hipMemcpyDeviceToDevice, st));
+            CSDR_HIP_TRY(hipMemcpyAsync(Ln + (N - from_x), lines_x, (size_t)from_x * sizeof(float2), hipMemcpyDeviceToDevice, st));
+        }
+        s->last_cur ^= 1;
     }
     if (mode == CSDR_SPEC_CONTIGUOUS) {
         // new carry = samples after the last whole frame (lane FFT: ordered behind the kernels that read the old carry)
@@ -1168,6 +1316,46 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
     return CSDR_OK;
 }
 
+// DC-spike removal on the finished points (:578-623): the bins within 2 kHz of the input centre are overwritten by their
+// mirror images just outside that span.  A few values on the host copy; integer arithmetic as in the reference.
+static void spec_hide_dc(const csdr_spec *s, float *pts) {
+    const long long centerFreq = s->center_freq, inFreq = s->input_freq;
+    const long bandwidth = s->bandwidth;
+    const long long fftSize = s->g.F;
+    const long long freqMin = centerFreq - (bandwidth / 2), freqMax = centerFreq + (bandwidth / 2);
+    const long long zeroPt = inFreq - freqMin;
+    if (!(freqMin < inFreq && freqMax > inFreq)) return;
+    const int freqRange = (int)(freqMax - freqMin);
+    const int freqStep = freqRange / (int)fftSize;
+    if (freqStep == 0) return;                                       // (the reference would divide by zero)
+    int fftStart = (int)(zeroPt / freqStep) - (2000 / freqStep);
+    int fftEnd = (int)(zeroPt / freqStep) + (2000 / freqStep);
+    if (fftEnd - fftStart < 2) { fftEnd++; fftStart--; }
+    const int numSteps = fftEnd - fftStart;
+    const int halfWay = fftStart + (numSteps / 2);
+    if ((fftEnd + numSteps / 2 + 1 < fftSize) && (fftStart - numSteps / 2 - 1 >= 0) && (fftEnd > fftStart)) {
+        int n = 1;
+        for (int i = fftStart; i < halfWay; i++) { pts[i * 2 + 1] = pts[(fftStart - n) * 2 + 1]; n++; }
+        n = 1;
+        for (int i = halfWay; i < fftEnd; i++) { pts[i * 2 + 1] = pts[(fftEnd + n) * 2 + 1]; n++; }
+    }
+}
+
+extern "C" int csdr_spec_fetch_hold(csdr_spec *s, int frame, float *hold_host, int cap_floats, int *n_floats) {
+    if (!s || !s->ready || !hold_host || !n_floats) return fail(CSDR_EINVAL, "bad argument");
+    if (frame < 0 || frame >= s->nf_last) return fail(CSDR_EINVAL, "frame %d of %d", frame, s->nf_last);
+    const int F = s->g.F;
+    *n_floats = 0;
+    if ((size_t)frame >= s->hold_valid.size() || !s->hold_valid[frame]) return CSDR_OK;     // spectrum_hold_points.resize(0) (:432)
+    if (cap_floats < 2 * F) return fail(CSDR_ERANGE, "need %d floats", 2 * F);
+    hipStream_t st = s->ctx->lanes[LANE_AVG];
+    CSDR_HIP_TRY(hipMemcpyAsync(hold_host, s->hold_points.p + (size_t)frame * 2 * F, (size_t)2 * F * sizeof(float), hipMemcpyDeviceToHost, st));
+    CSDR_HIP_TRY(hipStreamSynchronize(st));
+    if (s->hide_dc) spec_hide_dc(s, hold_host);
+    *n_floats = 2 * F;
+    return CSDR_OK;
+}
+
 extern "C" int csdr_spec_fetch(csdr_spec *s, int frame, float *points_host, int cap_floats, double *fft_ceiling, double *fft_floor) {
     if (!s || !s->ready || !points_host) return fail(CSDR_EINVAL, "bad argument");
     if (frame < 0 || frame >= s->nf_last) return fail(CSDR_EINVAL, "frame %d of %d", frame, s->nf_last);
@@ -1178,6 +1366,7 @@ extern "C" int csdr_spec_fetch(csdr_spec *s, int frame, float *points_host, int 
     CSDR_HIP_TRY(hipMemcpyAsync(points_host, s->points.p + (size_t)frame * 2 * F, (size_t)2 * F * sizeof(float), hipMemcpyDeviceToHost, st));
     CSDR_HIP_TRY(hipMemcpyAsync(&fo, s->fo.p + frame, sizeof fo, hipMemcpyDeviceToHost, st));
     CSDR_HIP_TRY(hipStreamSynchronize(st));
+    if (s->hide_dc) spec_hide_dc(s, points_host);
     if (fft_ceiling) *fft_ceiling = fo.point_ceil / (double)s->scale;     // :626
     if (fft_floor) *fft_floor = fo.point_floor;                            // :627
     return CSDR_OK;

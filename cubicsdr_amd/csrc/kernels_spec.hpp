@@ -355,7 +355,9 @@ __device__ inline void avg_step(AvgState &s, double xa, double xb, double rate) 
 __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restrict__ mag, int nf, SpecGeom g, double rate,
                                                             double *__restrict__ ma, double *__restrict__ maa,
                                                             float *__restrict__ pairsum, float *__restrict__ first_b,
-                                                            float2 *__restrict__ ext_w) {
+                                                            float2 *__restrict__ ext_w,
+                                                            float2 *__restrict__ maaf /* peak hold: both averaged bins of every point, frames >= pk_from */,
+                                                            int pk_from) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     AvgState *s_loc = reinterpret_cast<AvgState *>(smem);               // [kAvgGroups][64] group end states (zero entering state)
     AvgState *s_carry = s_loc + kAvgGroups * kAvgLanes;                  // [64] state after the round
@@ -407,6 +409,7 @@ __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restr
                     avg_step(s, (double)m[i].x, (double)m[i].y, rate);
                     if (valid) {
                         pairsum[(int64_t)f * F + x] = (float)(s.maa_a + s.maa_b);
+                        if (f >= pk_from) maaf[(int64_t)f * F + x] = make_float2((float)s.maa_a, (float)s.maa_b);
                         mx = (float)fmax(s.maa_a, s.maa_b); mn = (float)fmin(s.maa_a, s.maa_b);
                         if (x == 0) first_b[f] = (float)s.maa_b;
                     }
@@ -449,16 +452,68 @@ __global__ __launch_bounds__(256) void spec_extrema(const float2 *__restrict__ e
 // logarithm itself, also when the dynamic range is tiny), their ratio needs no base conversion.
 struct SpecFrameOut { double point_ceil, point_floor; };
 struct SpecScalars { double ceil_ma, ceil_maa, floor_ma, floor_maa; };
+struct SpecPeakScalars { double ceil_peak, floor_peak; };
+
+// ---- peak hold (SpectrumVisualProcessor.cpp:247-273, :506-510, :523-530) --------------------------------------------
+// reset: fft_result_peak[i] = fft_floor_maa, fft_ceil_peak = fft_floor_maa, fft_floor_peak = fft_ceil_maa (:266-272)
+__global__ __launch_bounds__(256) void spec_peak_reset(const SpecScalars *__restrict__ st, double *__restrict__ peak, int n2f,
+                                                       SpecPeakScalars *__restrict__ pk) {
+    const SpecScalars s = *st;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n2f; i += 256 * gridDim.x) peak[i] = s.floor_maa;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { pk->ceil_peak = s.floor_maa; pk->floor_peak = s.ceil_maa; }
+}
+// running maximum of the averaged bins over the frames [pk_from, nf) of a batch, one thread per display point (both of
+// its bins); peaksum[f][x] = peak[2x] + peak[2x+1] after frame f, peak_b[f] = the second bin of point 0 (:546-556)
+__global__ __launch_bounds__(256) void spec_peak_track(const float2 *__restrict__ maaf, int nf, int pk_from, int F,
+                                                       double *__restrict__ peak, float *__restrict__ peaksum, float *__restrict__ peak_b) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= F) return;
+    double pa = peak[x], pb = peak[F + x];
+    for (int f = pk_from; f < nf; ++f) {
+        const float2 v = maaf[(int64_t)f * F + x];
+        if ((double)v.x > pa) pa = (double)v.x;
+        if ((double)v.y > pb) pb = (double)v.y;
+        peaksum[(int64_t)f * F + x] = (float)(pa + pb);
+        if (x == 0) peak_b[f] = (float)pb;
+    }
+    peak[x] = pa; peak[F + x] = pb;
+}
+// the four trackers frame by frame (the reference's statements, :513-521) and their held extremes (:523-530) for the
+// frames [pk_from, nf): pfo[f] = {fft_ceil_peak, fft_floor_peak} after frame f.  One thread: nf short double recurrences.
+__global__ void spec_peak_trackers(const float2 *__restrict__ ext, int nf, int pk_from, const SpecScalars *__restrict__ st_in,
+                                   SpecPeakScalars *__restrict__ pk, SpecFrameOut *__restrict__ pfo) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    SpecScalars s = *st_in;
+    SpecPeakScalars p = *pk;
+    for (int f = 0; f < nf; ++f) {
+        const float2 e = ext[f];
+        float fft_ceil = 0.f, fft_floor = 1.f;
+        if (e.x > fft_ceil) fft_ceil = e.x;
+        if (e.y < fft_floor) fft_floor = e.y;
+        s.ceil_ma = s.ceil_ma + ((double)fft_ceil - s.ceil_ma) * 0.05;
+        s.ceil_maa = s.ceil_maa + (s.ceil_ma - s.ceil_maa) * 0.05;
+        s.floor_ma = s.floor_ma + ((double)fft_floor - s.floor_ma) * 0.05;
+        s.floor_maa = s.floor_maa + (s.floor_ma - s.floor_maa) * 0.05;
+        if (f >= pk_from) {
+            if (s.ceil_maa > p.ceil_peak) p.ceil_peak = s.ceil_maa;
+            if (s.floor_maa < p.floor_peak) p.floor_peak = s.floor_maa;
+            pfo[f].point_ceil = p.ceil_peak; pfo[f].point_floor = p.floor_peak;
+        }
+    }
+    *pk = p;
+}
 constexpr int kDispThreads = 256;
-constexpr size_t kDispLds = (4 * (kDispThreads / 64) + 2) * sizeof(double);
+constexpr size_t kDispLds = (4 * (kDispThreads / 64) + 3) * sizeof(double);
 
 __global__ __launch_bounds__(kDispThreads) void spec_display(const float *__restrict__ pairsum, const float *__restrict__ first_b,
                                                              const float2 *__restrict__ ext, int nf, int F, float sf,
                                                              const SpecScalars *__restrict__ st_in, SpecScalars *__restrict__ st_out,
-                                                             SpecFrameOut *__restrict__ fo, float *__restrict__ points) {
+                                                             SpecFrameOut *__restrict__ fo, float *__restrict__ points,
+                                                             int pk_from, const SpecFrameOut *__restrict__ pfo, const float *__restrict__ peaksum,
+                                                             const float *__restrict__ peak_b, float *__restrict__ hold_points) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *s_sum = reinterpret_cast<double *>(smem);          // reduction scratch [waves][4]
-    double *s_pc = s_sum + 4 * (kDispThreads / 64);            // [2] point_ceil, point_floor of this frame
+    double *s_pc = s_sum + 4 * (kDispThreads / 64);            // [3] point_ceil, point_floor, fft_floor_maa of this frame
     const int f = blockIdx.y, tid = threadIdx.x;
     // trackers after frame f, closed form of the recurrences (a = 0.95, b = 0.05; c_i = float ceiling, d_i = float floor
     // of frame i):   ma_f  = a^(f+1) ma_in + b sum_i a^(f-i) c_i
@@ -490,28 +545,41 @@ __global__ __launch_bounds__(kDispThreads) void spec_display(const float *__rest
         s.ceil_maa = af * s_in.ceil_maa + b * (double)(f + 1) * af * s_in.ceil_ma + b * b * t1;
         s.floor_ma = af * s_in.floor_ma + b * t2;
         s.floor_maa = af * s_in.floor_maa + b * (double)(f + 1) * af * s_in.floor_ma + b * b * t3;
-        s_pc[0] = s.ceil_maa; s_pc[1] = s.floor_maa;
+        // point_ceil / point_floor: the held extremes while peak hold is live (:539-540)
+        const bool hold = f >= pk_from;
+        s_pc[0] = hold ? pfo[f].point_ceil : s.ceil_maa; s_pc[1] = hold ? pfo[f].point_floor : s.floor_maa;
+        s_pc[2] = s.floor_maa;
         if (blockIdx.x == 0) {
-            fo[f].point_ceil = s.ceil_maa; fo[f].point_floor = s.floor_maa;
+            fo[f].point_ceil = s_pc[0]; fo[f].point_floor = s_pc[1];
             if (f == nf - 1) *st_out = s;
         }
     }
     __syncthreads();
-    const double pc = s_pc[0], pf = s_pc[1];
+    const double pc = s_pc[0], pf = s_pc[1], fl = s_pc[2];
+    const bool hold = f >= pk_from;
     const float inv_den = 1.0f / log1pf((float)(pc - pf));          // (pc + 0.25) - (pf - 0.75) = 1 + (pc - pf)
     for (int x0 = 2 * (blockIdx.x * kDispThreads + tid); x0 < F; x0 += 2 * kDispThreads * gridDim.x) {
-    float y[2];
+    float y[2], yh[2] = {0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int x = x0 + u;
-        double acc = 0.0;
-        if (x < F) acc = (x == 0) ? pf + (double)first_b[f]       // idx == 0 is replaced by fft_floor_maa (:546-556)
+        double acc = 0.0, pacc = 0.0;
+        if (x < F) acc = (x == 0) ? fl + (double)first_b[f]       // idx == 0 is replaced by fft_floor_maa (:546-556)
                                   : (double)pairsum[(int64_t)f * F + x];
         y[u] = log1pf((float)(acc / 2.0 - pf)) * inv_den * sf;      // acc / 2 + 0.25 - (pf - 0.75) = 1 + (acc / 2 - pf)
+        if (hold) {
+            if (x < F) pacc = (x == 0) ? fl + (double)peak_b[f] : (double)peaksum[(int64_t)f * F + x];
+            yh[u] = log1pf((float)(pacc / 2.0 - pf)) * inv_den * sf;
+        }
     }
     float *o = points + ((int64_t)f * F + x0) * 2;
     if (x0 + 1 < F) *reinterpret_cast<float4 *>(o) = make_float4((float)x0 / (float)F, y[0], (float)(x0 + 1) / (float)F, y[1]);
     else { o[0] = (float)x0 / (float)F; o[1] = y[0]; }
+    if (hold) {
+        float *h = hold_points + ((int64_t)f * F + x0) * 2;
+        if (x0 + 1 < F) *reinterpret_cast<float4 *>(h) = make_float4((float)x0 / (float)F, yh[0], (float)(x0 + 1) / (float)F, yh[1]);
+        else { h[0] = (float)x0 / (float)F; h[1] = yh[0]; }
+    }
     }
 }
 

@@ -199,11 +199,32 @@ class SpectrumProcessor:
     def set_average_rate(self, r):
         H.check(self._l.csdr_spec_set_average_rate(self.h, float(r)))
 
-    def process(self, iq, n_blocks, block_len, contiguous=False):
+    def set_peak_hold(self, enabled):
+        H.check(self._l.csdr_spec_set_peak_hold(self.h, int(bool(enabled))))
+
+    def set_hide_dc(self, enabled, center_freq=None, bandwidth=None, input_freq=None):
+        H.check(self._l.csdr_spec_set_hide_dc(self.h, int(bool(enabled))))
+        if center_freq is not None:
+            H.check(self._l.csdr_spec_set_center_frequency(self.h, int(center_freq)))
+        if bandwidth is not None:
+            H.check(self._l.csdr_spec_set_bandwidth(self.h, int(bandwidth)))
+        if input_freq is not None:
+            H.check(self._l.csdr_spec_set_input_frequency(self.h, int(input_freq)))
+
+    def fetch_hold(self, frame):
+        """spectrum_hold_points of a frame, or None when it carries none"""
+        pts = np.empty(2 * self.fft_size, np.float32)
+        n = C.c_int()
+        H.check(self._l.csdr_spec_fetch_hold(self.h, int(frame), pts.ctypes.data_as(C.c_void_p), pts.size, C.byref(n)))
+        return pts if n.value else None
+
+    def process(self, iq, n_blocks, block_len, contiguous=False, lines=False):
+        """frames per `mode`: first 2*fftSize samples of every block (default), every non-overlapping frame
+        (contiguous=True), or one overlapped frame per short block (lines=True: FFTDataDistributor's fftSize-sample lines)"""
         p, is_dev, n, keep = _as_iq_arg(iq)
         if n < n_blocks * block_len:
             raise ValueError("iq holds %d samples, need %d" % (n, n_blocks * block_len))
-        mode = H.CSDR_SPEC_CONTIGUOUS if contiguous else H.CSDR_SPEC_FIRST_FRAME
+        mode = H.CSDR_SPEC_LINES if lines else (H.CSDR_SPEC_CONTIGUOUS if contiguous else H.CSDR_SPEC_FIRST_FRAME)
         H.check(self._l.csdr_spec_process(self.h, p, is_dev, int(n_blocks), int(block_len), mode))
         self._keep = keep
         return self._l.csdr_spec_frames(self.h)

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libcsdr_hip.so")
 
 CSDR_POST_SINGLE, CSDR_POST_PFBCH = 0, 1
 CSDR_MODEM_NBFM, CSDR_MODEM_FM, CSDR_MODEM_AM, CSDR_MODEM_USB, CSDR_MODEM_LSB = range(5)
-CSDR_SPEC_FIRST_FRAME, CSDR_SPEC_CONTIGUOUS = 0, 1
+CSDR_SPEC_FIRST_FRAME, CSDR_SPEC_CONTIGUOUS, CSDR_SPEC_LINES = 0, 1, 2
 MODEM_BY_NAME = {"NBFM": 0, "FM": 1, "AM": 2, "USB": 3, "LSB": 4}
 
 
@@ -77,9 +77,16 @@ ABI = {
     "csdr_spec_setup": (_i, [_p, _i, _i]),
     "csdr_spec_set_average_rate": (_i, [_p, _f]),
     "csdr_spec_set_scale_factor": (_i, [_p, _f]),
+    "csdr_spec_set_peak_hold": (_i, [_p, _i]),
+    "csdr_spec_get_peak_hold": (_i, [_p]),
+    "csdr_spec_set_hide_dc": (_i, [_p, _i]),
+    "csdr_spec_set_center_frequency": (_i, [_p, _i64]),
+    "csdr_spec_set_bandwidth": (_i, [_p, _i64]),
+    "csdr_spec_set_input_frequency": (_i, [_p, _i64]),
     "csdr_spec_process": (_i, [_p, _p, _i, _i, _i, _i]),
     "csdr_spec_frames": (_i, [_p]),
     "csdr_spec_fetch": (_i, [_p, _i, _p, _i, C.POINTER(_d), C.POINTER(_d)]),
+    "csdr_spec_fetch_hold": (_i, [_p, _i, _p, _i, C.POINTER(_i)]),
     "csdr_spec_fft_only": (_i, [_p, _p, _p]),
 }
 

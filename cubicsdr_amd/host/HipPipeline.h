@@ -7,7 +7,9 @@
 //       machine (level / floor / ceil / squelch, DemodulatorThread.cpp:142-220) and try_pushes the audio
 //       (:318-328) -- drop-on-full exactly where the reference drops.
 //   SpectrumVisualProcessor : VisualProcessor<DemodulatorThreadIQData, SpectrumVisualData> with the setters of
-//       src/process/SpectrumVisualProcessor.h:29-58 (full-span view).
+//       src/process/SpectrumVisualProcessor.h:29-58 (full-span view, peak hold, DC hiding, short-input overlap rule).
+//   FFTVisualDataThread / SpectrumVisualDataThread : the 10 ms pump threads around it (FFTDataDistributor.h holds the
+//       waterfall line pacing).
 #pragma once
 #include <atomic>
 #include <cmath>
@@ -24,6 +26,7 @@
 #include "VisualProcessor.h"
 
 #define HEARTBEAT_CHECK_PERIOD_MICROS (50 * 1000)
+#include "FFTDataDistributor.h"
 
 inline void csdr_must(int rc, const char *what) {
     if (rc != CSDR_OK) throw std::runtime_error(std::string(what) + ": " + csdr_strerror(rc) + " (" + csdr_last_error() + ")");
@@ -253,6 +256,7 @@ public:
     void setup(unsigned int fftSize_in) {                                            // :140-178
         std::lock_guard<std::mutex> g(busy_run);
         fftSize = fftSize_in;
+        desiredInputSize = (int)(2 * fftSize);                                       // fftSizeInternal, :145,165
         csdr_must(csdr_spec_setup(spec_, (int)fftSize, 1), "csdr_spec_setup");
         csdr_must(csdr_spec_set_average_rate(spec_, fft_average_rate), "csdr_spec_set_average_rate");
         csdr_must(csdr_spec_set_scale_factor(spec_, scaleFactor), "csdr_spec_set_scale_factor");
@@ -263,11 +267,19 @@ public:
     float getFFTAverageRate() { std::lock_guard<std::mutex> g(busy_run); return fft_average_rate; }
     void setScaleFactor(float sf) { std::lock_guard<std::mutex> g(busy_run); scaleFactor = sf; if (fftSize) csdr_spec_set_scale_factor(spec_, sf); }
     float getScaleFactor() { std::lock_guard<std::mutex> g(busy_run); return scaleFactor; }
-    void setCenterFrequency(long long f) { std::lock_guard<std::mutex> g(busy_run); centerFreq = f; }
+    void setCenterFrequency(long long f) { std::lock_guard<std::mutex> g(busy_run); centerFreq = f; csdr_spec_set_center_frequency(spec_, f); }
     long long getCenterFrequency() { std::lock_guard<std::mutex> g(busy_run); return centerFreq; }
-    void setBandwidth(long b) { std::lock_guard<std::mutex> g(busy_run); bandwidth = b; }
+    void setBandwidth(long b) { std::lock_guard<std::mutex> g(busy_run); bandwidth = b; csdr_spec_set_bandwidth(spec_, b); }
     long getBandwidth() { std::lock_guard<std::mutex> g(busy_run); return bandwidth; }
-    int getDesiredInputSize() { std::lock_guard<std::mutex> g(busy_run); return (int)(2 * fftSize); }
+    void setPeakHold(bool on) { std::lock_guard<std::mutex> g(busy_run); csdr_spec_set_peak_hold(spec_, on ? 1 : 0); }       // :115-125
+    bool getPeakHold() { std::lock_guard<std::mutex> g(busy_run); return csdr_spec_get_peak_hold(spec_) != 0; }
+    void setHideDC(bool on) { std::lock_guard<std::mutex> g(busy_run); csdr_spec_set_hide_dc(spec_, on ? 1 : 0); }           // :204-209
+    // the zoomed view (K17, :283-386: NCO shift + msresamp to the view bandwidth + averager history shifts) is a later
+    // tier: the flag is kept, inputs are processed full-span
+    void setView(bool v) { std::lock_guard<std::mutex> g(busy_run); is_view = v; }
+    void setView(bool v, long long centerFreq_in, long bandwidth_in) { setView(v); setCenterFrequency(centerFreq_in); setBandwidth(bandwidth_in); }
+    bool isView() { std::lock_guard<std::mutex> g(busy_run); return is_view; }
+    int getDesiredInputSize() { std::lock_guard<std::mutex> g(busy_run); return desiredInputSize; }
 
 protected:
     void process() override {                                                        // :212-637, full-span branch
@@ -277,14 +289,23 @@ protected:
         { std::lock_guard<std::mutex> g(busy_run); if (fftSizeChanged) { doSetup = true; fftSizeChanged = false; } }
         if (doSetup) setup(newFFTSize);
         DemodulatorThreadIQDataPtr iq;
-        if (!input->pop(iq, HEARTBEAT_CHECK_PERIOD_MICROS) || !iq || iq->data.empty()) return;
+        if (!input->pop(iq, HEARTBEAT_CHECK_PERIOD_MICROS) || !iq) return;
         std::lock_guard<std::mutex> g(busy_run);
-        if (!fftSize || iq->data.size() < 2 * (size_t)fftSize) return;              // short-block overlap path (:399-421) not built
-        csdr_must(csdr_spec_process(spec_, (const float *)iq->data.data(), 0, 1, (int)iq->data.size(), CSDR_SPEC_FIRST_FRAME), "csdr_spec_process");
+        if (!fftSize || iq->data.empty()) return;
+        const size_t N = 2 * (size_t)fftSize;
+        csdr_must(csdr_spec_set_input_frequency(spec_, iq->frequency), "csdr_spec_set_input_frequency");
+        // inputs of at least 2*fftSize samples are transformed directly (:401-404); shorter ones go through the
+        // fftLastData priming / overlap rule (:406-420)
+        const int mode = iq->data.size() >= N ? CSDR_SPEC_FIRST_FRAME : CSDR_SPEC_LINES;
+        csdr_must(csdr_spec_process(spec_, (const float *)iq->data.data(), 0, 1, (int)iq->data.size(), mode), "csdr_spec_process");
+        if (csdr_spec_frames(spec_) < 1) return;                                     // the input only primed fftLastData
         SpectrumVisualDataPtr out = outputBuffers.getBuffer();
         out->spectrum_points.resize(fftSize * 2);
-        out->spectrum_hold_points.resize(0);
         csdr_must(csdr_spec_fetch(spec_, 0, out->spectrum_points.data(), (int)out->spectrum_points.size(), &out->fft_ceiling, &out->fft_floor), "csdr_spec_fetch");
+        out->spectrum_hold_points.resize(fftSize * 2);
+        int nh = 0;
+        csdr_must(csdr_spec_fetch_hold(spec_, 0, out->spectrum_hold_points.data(), (int)out->spectrum_hold_points.size(), &nh), "csdr_spec_fetch_hold");
+        out->spectrum_hold_points.resize((size_t)nh);                                // empty unless peak hold is live (:432)
         out->centerFreq = centerFreq; out->bandwidth = (int)bandwidth;
         distribute(out);
     }
@@ -294,9 +315,65 @@ private:
     csdr_spec *spec_ = nullptr;
     std::mutex busy_run;
     unsigned int fftSize = 0, newFFTSize = 0;
-    bool fftSizeChanged = false;
+    bool fftSizeChanged = false, is_view = false;
+    int desiredInputSize = 0;
     float fft_average_rate = 0.65f, scaleFactor = 1.0f;
     long long centerFreq = 0;
     long bandwidth = 0;
     ReBuffer<SpectrumVisualData> outputBuffers{"SpectrumVisualProcessorBuffers"};
+};
+
+// The two pump threads around the spectrum path (src/process/FFTVisualDataThread.cpp:26-82: distributor -> processor for the
+// waterfall; SpectrumVisualDataThread.cpp:14-25: the processor alone), both ticking every 10 ms.
+class FFTVisualDataThread : public IOThread {
+public:
+    explicit FFTVisualDataThread(csdr_ctx *ctx) : wproc(ctx), linesPerSecond(DEFAULT_WATERFALL_LPS), lpsChanged(true) {}
+    void setLinesPerSecond(int lps) { linesPerSecond.store(lps); lpsChanged.store(true); }
+    int getLinesPerSecond() { return linesPerSecond.load(); }
+    SpectrumVisualProcessor *getProcessor() { return &wproc; }
+    void run() override {
+        auto in = std::static_pointer_cast<DemodulatorThreadInputQueue>(getInputQueue("IQDataInput"));
+        auto out = std::static_pointer_cast<SpectrumVisualDataQueue>(getOutputQueue("FFTDataOutput"));
+        fftQueue->set_max_num_items(100);
+        out->set_max_num_items(100);
+        fftDistrib.setInput(in);
+        fftDistrib.attachOutput(fftQueue);
+        wproc.setInput(fftQueue);
+        wproc.attachOutput(out);
+        wproc.setup(DEFAULT_FFT_SIZE);
+        while (!stopping) {
+            std::this_thread::sleep_for(std::chrono::milliseconds((int)(FFT_DISTRIBUTOR_BUFFER_IN_SECONDS * 1000.0 / 25.0)));
+            const int want = wproc.getDesiredInputSize();
+            fftDistrib.setFFTSize(want ? (unsigned)want : DEFAULT_FFT_SIZE * 2);     // SPECTRUM_VZM
+            if (lpsChanged.load()) { fftDistrib.setLinesPerSecond((unsigned)linesPerSecond.load()); lpsChanged.store(false); }
+            fftDistrib.run();
+            while (!stopping && !wproc.isInputEmpty()) wproc.run();
+        }
+        in->flush();
+        out->flush();
+    }
+    void terminate() override { IOThread::terminate(); fftDistrib.flushQueues(); wproc.flushQueues(); }
+
+protected:
+    FFTDataDistributor fftDistrib;
+    DemodulatorThreadInputQueuePtr fftQueue = std::make_shared<DemodulatorThreadInputQueue>();
+    SpectrumVisualProcessor wproc;
+    std::atomic_int linesPerSecond;
+    std::atomic_bool lpsChanged;
+};
+
+class SpectrumVisualDataThread : public IOThread {
+public:
+    explicit SpectrumVisualDataThread(csdr_ctx *ctx) : sproc(ctx) {}
+    SpectrumVisualProcessor *getProcessor() { return &sproc; }
+    void run() override {
+        while (!stopping) {
+            std::this_thread::sleep_for(std::chrono::milliseconds((int)(FFT_DISTRIBUTOR_BUFFER_IN_SECONDS * 1000.0 / 25.0)));
+            sproc.run();
+        }
+    }
+    void terminate() override { IOThread::terminate(); sproc.flushQueues(); }
+
+protected:
+    SpectrumVisualProcessor sproc;
 };

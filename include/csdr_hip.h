@@ -159,12 +159,26 @@ int  csdr_bank_total_audio(csdr_bank *bank, int64_t *n);
  * floor/ceil EMAs :518-530, display resample + log10 scaling :532-576. */
 #define CSDR_SPEC_FIRST_FRAME 0  /* reference cadence: only the first 2*fftSize samples of each block (:387-397) */
 #define CSDR_SPEC_CONTIGUOUS  1  /* every sample belongs to one non-overlapping 2*fftSize frame */
+#define CSDR_SPEC_LINES       2  /* every block is one input shorter than 2*fftSize (the fftSize-sample lines FFTDataDistributor
+                                  * emits, FFTDataDistributor.cpp:112-131): the first one primes fftLastData, each later one is
+                                  * appended to the previous FFT input shifted left by its length (:399-421) -> one frame each */
 
 int  csdr_spec_create(csdr_ctx *ctx, csdr_spec **out);
 void csdr_spec_destroy(csdr_spec *spec);
 int  csdr_spec_setup(csdr_spec *spec, int fft_size, int max_frames);      /* setup(fftSize_in) */
 int  csdr_spec_set_average_rate(csdr_spec *spec, float rate);             /* setFFTAverageRate, default 0.65 (:36) */
 int  csdr_spec_set_scale_factor(csdr_spec *spec, float sf);               /* setScaleFactor, default 1 */
+/* setPeakHold (:115-125): enabling starts a one-input countdown to the reset of fft_result_peak / fft_ceil_peak /
+ * fft_floor_peak (:264-273), enabling again while enabled restarts it at PEAK_RESET_COUNT = 30 inputs; frames after the
+ * reset carry spectrum_hold_points and are scaled by the held ceiling / floor (:506-510, :523-541). */
+int  csdr_spec_set_peak_hold(csdr_spec *spec, int enabled);
+int  csdr_spec_get_peak_hold(const csdr_spec *spec);
+/* setHideDC (:204-209) and the frequencies its bin arithmetic uses (:578-623): setCenterFrequency, setBandwidth, and
+ * iqData->frequency of the inputs that follow.  Applied to the points as they are fetched. */
+int  csdr_spec_set_hide_dc(csdr_spec *spec, int enabled);
+int  csdr_spec_set_center_frequency(csdr_spec *spec, int64_t center_freq);
+int  csdr_spec_set_bandwidth(csdr_spec *spec, int64_t bandwidth);
+int  csdr_spec_set_input_frequency(csdr_spec *spec, int64_t frequency);
 /* Run the spectrum path over n_blocks x block_len samples; frames are taken per `mode`.  Every frame updates the
  * averagers in order, exactly as one process() call per frame would. */
 int  csdr_spec_process(csdr_spec *spec, const float *iq, int iq_is_dev, int n_blocks, int block_len, int mode);
@@ -172,6 +186,8 @@ int  csdr_spec_frames(const csdr_spec *spec);                             /* fra
 /* SpectrumVisualData of frame `frame` of the last process: spectrum_points[2*fftSize] = (x, y) pairs,
  * fft_ceiling, fft_floor (SpectrumVisualProcessor.h:14-23; :626-627). */
 int  csdr_spec_fetch(csdr_spec *spec, int frame, float *points_host, int cap_floats, double *fft_ceiling, double *fft_floor);
+/* spectrum_hold_points[2*fftSize] of that frame; *n_floats = 0 when the frame carries none (peak hold off or not reset yet) */
+int  csdr_spec_fetch_hold(csdr_spec *spec, int frame, float *hold_host, int cap_floats, int *n_floats);
 /* raw forward FFT of one 2*fftSize frame (K13 alone), for parity tests against fft_execute */
 int  csdr_spec_fft_only(csdr_spec *spec, const float *iq_host, float *out_host);
 

@@ -195,10 +195,95 @@ class RefSpectrum:
         self.rate = float(np.float32(average_rate))                      # float member, :36
         self.sf = float(np.float32(scale))
 
+    def select_input(self, data):
+        """Frame selection of process() for one popped input, full-span view (:387-421): returns the 2*fftSize samples that
+        are transformed, or None when the input only primes fftLastData."""
+        N = self.N
+        if not hasattr(self, "last"):
+            self.last = np.zeros(N, np.complex64)                        # fftLastData
+            self.last_size = 0                                           # lastDataSize, setup :166
+        data = A.as_c64(data)
+        n = min(len(data), N)
+        fin = np.zeros(N, np.complex64)                                  # fftInData: data, zero padded (:388-396)
+        fin[:n] = data[:n]
+        num_written = len(data)
+        if num_written >= N:                                             # :401-404
+            self.last[:] = fin
+            return fin
+        if self.last_size + num_written < N:                             # priming :406-412
+            num_copy = max(N - self.last_size, num_written)
+            self.last[:num_copy] = fin[:num_copy]
+            self.last_size += num_copy
+            return None
+        num_last = N - num_written                                       # :413-419
+        frame = np.concatenate([self.last[self.last_size - num_last:self.last_size], fin[:num_written]])
+        self.last[:] = frame
+        return frame
+
     def fft(self, frame):
         self.x[:] = A.as_c64(frame)
         self.L.fft_execute(self.plan)                                    # :439
         return self.y.copy()
+
+    # ---- peak hold and DC hiding (setPeakHold :115-125, reset :264-273, setHideDC :204-209) -------------------------
+    def set_peak_hold(self, on):
+        if getattr(self, "peak_hold", False) and on:
+            self.peak_reset = 30                                         # PEAK_RESET_COUNT, .h:12
+        else:
+            self.peak_hold = bool(on)
+            self.peak_reset = 1
+
+    def set_hide_dc(self, on, center_freq, bandwidth, input_freq):
+        self.hide_dc, self.center_freq, self.bandwidth, self.input_freq = bool(on), int(center_freq), int(bandwidth), int(input_freq)
+
+    def begin_input(self):
+        """the head of process() for one popped input (:247, :264-273): returns doPeak for this input"""
+        if not hasattr(self, "peak_hold"):
+            self.peak_hold, self.peak_reset = False, 0
+        do_peak = self.peak_hold and self.peak_reset == 0
+        if self.peak_reset != 0:
+            self.peak_reset -= 1
+            if self.peak_reset == 0:
+                self.peak = np.full(self.N, self.floor_maa, np.float64)
+                self.ceil_peak = self.floor_maa
+                self.floor_peak = self.ceil_maa
+        self.do_peak = do_peak
+        return do_peak
+
+    def _hide_dc(self, pts):
+        """:578-623, the reference's integer arithmetic (C division truncates toward zero; operands here are positive)"""
+        F = self.F
+        fmin = self.center_freq - self.bandwidth // 2
+        fmax = self.center_freq + self.bandwidth // 2
+        zero_pt = self.input_freq - fmin
+        if not (fmin < self.input_freq < fmax):
+            return
+        step = int(fmax - fmin) // F
+        start = zero_pt // step - 2000 // step
+        end = zero_pt // step + 2000 // step
+        if end - start < 2:
+            end += 1
+            start -= 1
+        steps = end - start
+        half = start + steps // 2
+        if end + steps // 2 + 1 < F and start - steps // 2 - 1 >= 0 and end > start:
+            n = 1
+            for i in range(start, half):
+                pts[2 * i + 1] = pts[2 * (start - n) + 1]
+                n += 1
+            n = 1
+            for i in range(half, end):
+                pts[2 * i + 1] = pts[2 * (end + n) + 1]
+                n += 1
+
+    def process_input(self, data):
+        """one process() call: returns None (no FFT ran) or (points, fft_ceiling, fft_floor, hold_points or None)"""
+        self.begin_input()
+        frame = self.select_input(data)
+        if frame is None:
+            return None
+        pts, ce, fl = self.process_frame(frame)
+        return pts, ce, fl, self.hold
 
     def process_frame(self, frame):
         """frame: the 2*fftSize samples process() would FFT.  Returns (spectrum_points[2F], fft_ceiling, fft_floor)."""
@@ -214,11 +299,29 @@ class RefSpectrum:
         self.ceil_maa += (self.ceil_ma - self.ceil_maa) * 0.05
         self.floor_ma += (float(fft_floor) - self.floor_ma) * 0.05       # :518-521
         self.floor_maa += (self.floor_ma - self.floor_maa) * 0.05
-        pc, pf = self.ceil_maa, self.floor_maa
+        do_peak = getattr(self, "do_peak", False)
+        if do_peak:                                                      # :506-510, :523-530
+            self.peak = np.maximum(self.peak, self.maa)
+            self.ceil_peak = max(self.ceil_peak, self.ceil_maa)
+            self.floor_peak = min(self.floor_peak, self.floor_maa)
+        pc, pf = (self.ceil_peak, self.floor_peak) if do_peak else (self.ceil_maa, self.floor_maa)   # :539-540
         acc = self.maa[0::2] + self.maa[1::2]                            # visualRatio = 1 -> 2 bins per point :538-560
-        acc[0] = pf + self.maa[1]                                        # idx == 0 is replaced by fft_floor_maa :546-551
-        y = (np.log10(acc / 2.0 + 0.25 - (pf - 0.75)) / np.log10((pc + 0.25) - (pf - 0.75))) * self.sf   # :566
+        acc[0] = self.floor_maa + self.maa[1]                            # idx == 0 is replaced by fft_floor_maa :546-551
+        den = np.log10((pc + 0.25) - (pf - 0.75))
+        y = (np.log10(acc / 2.0 + 0.25 - (pf - 0.75)) / den) * self.sf   # :566
         pts = np.empty(2 * F, np.float32)
         pts[0::2] = (np.arange(F, dtype=np.float32) / np.float32(F))     # :562
         pts[1::2] = y.astype(np.float32)
+        self.hold = None
+        if do_peak:
+            pacc = self.peak[0::2] + self.peak[1::2]
+            pacc[0] = self.floor_maa + self.peak[1]
+            hold = np.empty(2 * F, np.float32)
+            hold[0::2] = pts[0::2]
+            hold[1::2] = ((np.log10(pacc / 2.0 + 0.25 - (pf - 0.75)) / den) * self.sf).astype(np.float32)   # :569
+            self.hold = hold
+        if getattr(self, "hide_dc", False):
+            self._hide_dc(pts)
+            if self.hold is not None:
+                self._hide_dc(self.hold)
         return pts, pc / self.sf, pf                                     # :626-627

@@ -122,6 +122,52 @@ static void test_visual_processor() {
     CHECK(o1->empty() && in->empty());
 }
 
+// FFTDataDistributor scenarios (no GPU): the sample values carry their stream position so that the emitted lines can be
+// identified; output is compared with oracle/fft_distributor.py by tests/test_host_mirror.py.
+struct DistribHarness : FFTDataDistributor {
+    using FFTDataDistributor::process;
+};
+static DemodulatorThreadIQDataPtr make_block(long long freq, long long rate, size_t n, long long &pos) {
+    auto b = std::make_shared<DemodulatorThreadIQData>();
+    b->frequency = freq; b->sampleRate = rate; b->data.resize(n);
+    for (size_t i = 0; i < n; ++i) { b->data[i].real = (float)(pos + (long long)i); b->data[i].imag = 0.f; }
+    pos += (long long)n;
+    return b;
+}
+static int run_distrib() {
+    DistribHarness d;
+    auto in = std::make_shared<DemodulatorThreadInputQueue>();
+    auto out = std::make_shared<DemodulatorThreadInputQueue>();
+    in->set_max_num_items(1000); out->set_max_num_items(100000);
+    d.setInput(in); d.attachOutput(out);
+    long long pos = 0;
+    auto drain = [&](const char *tag) {
+        d.run();
+        DemodulatorThreadIQDataPtr l;
+        while (out->try_pop(l)) std::printf("L %s %lld %zu %lld %lld\n", tag, (long long)l->data[0].real, l->data.size(), l->frequency, l->sampleRate);
+        std::printf("S %s %.12f %zu\n", tag, d.lineRateAccumulator(), d.buffered());
+    };
+    // A: 2.4 MS/s, 40000-sample blocks, 4096-sample lines at 30 lines/s, one block per run()
+    d.setFFTSize(4096); d.setLinesPerSecond(30);
+    for (int b = 0; b < 60; ++b) { in->push(make_block(100000000, 2400000, 40000, pos)); drain("A"); }
+    // B: retune (buffer dropped), faster waterfall, several blocks queued per run()
+    d.setLinesPerSecond(400);
+    for (int b = 0; b < 6; ++b) { for (int k = 0; k < 3; ++k) in->push(make_block(101000000, 2400000, 40000, pos)); drain("B"); }
+    // C: line size change without retune
+    d.setFFTSize(16384);
+    for (int b = 0; b < 8; ++b) { in->push(make_block(101000000, 2400000, 40000, pos)); drain("C"); }
+    // D: low rate -> small buffer; oversized blocks overflow and lose their tail
+    d.setFFTSize(2048); d.setLinesPerSecond(1000);
+    for (int b = 0; b < 5; ++b) { in->push(make_block(101000000, 96000, 40000, pos)); drain("D"); }
+    // E: a full consumer queue loses lines
+    auto small = std::make_shared<DemodulatorThreadInputQueue>();
+    d.removeOutput(out); d.attachOutput(small);
+    in->push(make_block(101000000, 96000, 20000, pos));
+    d.run();
+    std::printf("E %zu\n", small->size());
+    return 0;
+}
+
 static int run_gpu() {
     csdr_ctx *ctx = nullptr;
     csdr_must(csdr_ctx_create(0, nullptr, &ctx), "csdr_ctx_create");
@@ -161,11 +207,15 @@ static int run_gpu() {
             n0 += block;
             CHECK(pipeSDRIQData->push(blk, 2000000));
             while (post.blocksProcessed.load() <= b) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            if (b == 5) { spec.setPeakHold(true); spec.setHideDC(true); }
             spec.run();
             SpectrumVisualDataPtr sv;
             if (spectrumOut->try_pop(sv)) {
                 ++nspec;
                 CHECK(sv->spectrum_points.size() == 4096);
+                // setPeakHold: the first input after the call resets the held arrays (b = 5), later ones carry hold points >= the live ones
+                CHECK(sv->spectrum_hold_points.size() == (b >= 6 ? 4096u : 0u));
+                if (b >= 6) for (int x = 1; x < 2048; x += 97) CHECK(sv->spectrum_hold_points[2 * x + 1] >= sv->spectrum_points[2 * x + 1] - 1e-5f);
                 // carrier at +250 kHz of a 2.4 MHz span -> display point ~ (0.5 + 250/2400) * 2048 = 1237
                 int best = 0; float bv = -1e9f;
                 for (int x = 0; x < 2048; ++x) if (sv->spectrum_points[2 * x + 1] > bv) { bv = sv->spectrum_points[2 * x + 1]; best = x; }
@@ -200,11 +250,53 @@ static int run_gpu() {
         tp.join();
         CHECK(post.isTerminated());
     }
+    {
+        // waterfall pump: IQ blocks -> FFTDataDistributor lines (2 * fftSize samples each, FFTVisualDataThread.cpp:55-61) ->
+        // SpectrumVisualProcessor -> "FFTDataOutput"
+        FFTVisualDataThread wf(ctx);
+        auto iqIn = std::make_shared<DemodulatorThreadInputQueue>();
+        auto fftOut = std::make_shared<SpectrumVisualDataQueue>();
+        iqIn->set_max_num_items(100);
+        wf.setInputQueue("IQDataInput", iqIn);
+        wf.setOutputQueue("FFTDataOutput", fftOut);
+        wf.setLinesPerSecond(200);
+        std::thread tw(&IOThread::threadMain, &wf);
+        const long long fs = 2400000;
+        long long n0 = 0;
+        for (int b = 0; b < 12; ++b) {
+            auto blk = std::make_shared<DemodulatorThreadIQData>();
+            blk->frequency = 100000000; blk->sampleRate = fs; blk->data.resize(40000);
+            for (int i = 0; i < 40000; ++i) {
+                const double ph = 2 * M_PI * 250000.0 * double(n0 + i) / fs;
+                blk->data[i].real = (float)(0.5 * std::cos(ph)); blk->data[i].imag = (float)(0.5 * std::sin(ph));
+            }
+            n0 += 40000;
+            CHECK(iqIn->push(blk, 2000000));
+            std::this_thread::sleep_for(std::chrono::milliseconds(15));
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        int lines = 0;
+        SpectrumVisualDataPtr sv;
+        while (fftOut->try_pop(sv)) {
+            ++lines;
+            CHECK(sv->spectrum_points.size() == 2 * DEFAULT_FFT_SIZE);
+            int best = 0; float bv = -1e9f;
+            for (int x = 0; x < DEFAULT_FFT_SIZE; ++x) if (sv->spectrum_points[2 * x + 1] > bv) { bv = sv->spectrum_points[2 * x + 1]; best = x; }
+            if (lines > 3) CHECK(std::abs(best - 1237) <= 3);
+        }
+        // 0.2 s of samples at 200 lines/s: about 40 lines (4096 samples each, 117 available)
+        std::printf("waterfall lines %d\n", lines);
+        CHECK(lines >= 30 && lines <= 45);
+        wf.terminate();
+        tw.join();
+        CHECK(wf.isTerminated());
+    }
     csdr_ctx_destroy(ctx);
     return g_fail;
 }
 
 int main(int argc, char **argv) {
+    if (argc > 1 && !std::strcmp(argv[1], "distrib")) return run_distrib();
     const bool gpu = argc > 1 && !std::strcmp(argv[1], "gpu");
     if (gpu) { int f = run_gpu(); std::printf(f ? "GPU HOST TEST FAILED (%d)\n" : "gpu host test ok\n", f); return f ? 1 : 0; }
     test_queue();

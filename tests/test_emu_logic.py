@@ -100,6 +100,20 @@ def test_emu_spectrum_contiguous(ctx):
     G.test_spectrum_contiguous_mode(ctx)
 
 
+def test_emu_spectrum_line_cadence(ctx):
+    G.test_spectrum_line_cadence_overlapped_frames(ctx, 1024, 600)
+
+
+@full
+def test_emu_spectrum_line_cadence_half_frame_lines(ctx):
+    G.test_spectrum_line_cadence_overlapped_frames(ctx, 2048, 2048)
+
+
+@full
+def test_emu_spectrum_peak_hold_hide_dc(ctx):
+    G.test_spectrum_peak_hold_and_hide_dc(ctx)
+
+
 @full
 def test_emu_spectrum_many_frames(ctx):
     G.test_spectrum_many_frames_one_batch(ctx)

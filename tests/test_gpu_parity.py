@@ -269,6 +269,75 @@ def test_spectrum_contiguous_mode(ctx):
     sp.close()
 
 
+@pytest.mark.parametrize("F,line", [(2048, 2048), (2048, 3000), (1024, 600), (16384, 16384)])
+def test_spectrum_line_cadence_overlapped_frames(ctx, F, line):
+    """FFTDataDistributor hands the spectrum fftSize-sample lines (FFTDataDistributor.cpp:112-131), shorter than the
+    2*fftSize transform: the first primes fftLastData, every later one is transformed together with the tail of the
+    previous FFT input (SpectrumVisualProcessor.cpp:399-421).  Lines one at a time, then several per call."""
+    from cubicsdr_amd.engine import SpectrumProcessor
+    from oracle.cubicsdr_chain import RefSpectrum
+    nl = 11
+    x = synth_iq(nl * line, 2.4e6, 0, [("NBFM", 300000.0), ("AM", -400000.0)], seed=21)
+    sp = SpectrumProcessor(ctx, F, max_frames=8)
+    ref = RefSpectrum(_backend(), F)
+    want = []
+    for k in range(nl):
+        fr = ref.select_input(x[k * line:(k + 1) * line])
+        want.append(None if fr is None else ref.process_frame(fr))
+    assert want[0] is None and all(w is not None for w in want[1:])
+    k = 0
+    for per_call in (1, 1, 1, 3, 5):
+        nf = sp.process(x[k * line:(k + per_call) * line], per_call, line, lines=True)
+        expect = [w for w in want[k:k + per_call] if w is not None]
+        assert nf == len(expect), (k, nf)
+        for j, (wp, wce, wfl) in enumerate(expect):
+            pts, ce, fl = sp.fetch(j)
+            assert rel_err(pts, wp) < TOL, (k, j)
+            assert abs(ce - wce) <= TOL * abs(wce) and abs(fl - wfl) <= TOL * abs(wce), (k, j)
+        k += per_call
+    assert k == nl
+    sp.close()
+
+
+def test_spectrum_peak_hold_and_hide_dc(ctx):
+    """setPeakHold: one input later the held arrays are reset to the floor tracker, from then on every frame carries
+    spectrum_hold_points and is scaled by the held ceiling / floor; enabling again restarts a 30-input countdown.  The
+    reset falls inside a batch, at its first frame, and between batches.  setHideDC rewrites the bins around the
+    input's centre frequency."""
+    from cubicsdr_amd.engine import SpectrumProcessor
+    from oracle.cubicsdr_chain import RefSpectrum
+    F, block, fs = 2048, 6000, 2400000
+    nb = 60
+    x = synth_iq(nb * block, fs, 0, [("NBFM", 300000.0), ("AM", -500000.0)], seed=31)
+    amp = np.repeat(1.0 + 0.8 * np.sin(np.arange(nb) * 0.7), block).astype(np.float32)      # peaks must actually be held
+    x = (x * amp).astype(np.complex64)
+    sp = SpectrumProcessor(ctx, F, max_frames=16)
+    ref = RefSpectrum(_backend(), F)
+    sp.set_hide_dc(True, center_freq=100000000, bandwidth=fs, input_freq=100000000)
+    ref.set_hide_dc(True, 100000000, fs, 100000000)
+    plan = [(3, None), (4, True), (1, None), (6, None), (5, True), (16, None), (14, None), (6, False), (5, None)]
+    k = 0
+    held = 0
+    for per_call, toggle in plan:
+        if toggle is not None:
+            sp.set_peak_hold(toggle)
+            ref.set_peak_hold(toggle)
+        assert sp.process(x[k * block:(k + per_call) * block], per_call, block) == per_call
+        for j in range(per_call):
+            wp, wce, wfl, whold = ref.process_input(x[(k + j) * block:(k + j + 1) * block])
+            pts, ce, fl = sp.fetch(j)
+            hold = sp.fetch_hold(j)
+            assert rel_err(pts, wp) < TOL, (k, j)
+            assert abs(ce - wce) <= TOL * abs(wce) and abs(fl - wfl) <= TOL * abs(wce), (k, j)
+            assert (hold is None) == (whold is None), (k, j)
+            if hold is not None:
+                assert rel_err(hold, whold) < TOL, (k, j)
+                held += 1
+        k += per_call
+    assert k == nb and held >= 12
+    sp.close()
+
+
 def test_spectrum_many_frames_one_batch(ctx):
     """300 frames in ONE process() call (the averaging kernel splits a batch into 16 frame groups per round of 256
     frames and chains rounds): every frame must equal the frame-at-a-time reference."""

@@ -27,6 +27,54 @@ def test_queue_rebuffer_iothread_visualprocessor_semantics():
     assert "host test ok" in r.stdout
 
 
+def test_fft_data_distributor_line_pacing_matches_oracle():
+    """FFTDataDistributor (waterfall line pacing, K19): the C++ mirror against the statement-by-statement restatement of
+    FFTDataDistributor.cpp:28-144 -- which lines go out (by stream position), the accumulator and the buffered count
+    after every run(), across a retune, a line-size change, buffer overflow and a full consumer queue."""
+    from oracle.fft_distributor import FFTDataDistributorRef
+    _build()
+    r = subprocess.run([EXE, "distrib"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = {}
+    for ln in r.stdout.splitlines():
+        f = ln.split()
+        got.setdefault(f[1] if f[0] in "LS" else "E", []).append(f)
+    ref = FFTDataDistributorRef(4096, 30)
+    pos = 0
+    want = {k: [] for k in "ABCD"}
+
+    def feed(tag, freq, rate, n, blocks_per_run):
+        nonlocal pos
+        for _ in range(blocks_per_run):
+            for first, size, fq, rt in ref.push(list(range(pos, pos + n)), freq, rate):
+                want[tag].append(["L", tag, str(first), str(size), str(fq), str(rt)])
+            pos += n
+        want[tag].append(["S", tag, "%.12f" % ref.accum, str(len(ref.buf))])
+
+    for _ in range(60):
+        feed("A", 100000000, 2400000, 40000, 1)
+    ref.lps = 400
+    for _ in range(6):
+        feed("B", 101000000, 2400000, 40000, 3)
+    ref.fft_size = 16384
+    for _ in range(8):
+        feed("C", 101000000, 2400000, 40000, 1)
+    ref.fft_size = 2048
+    ref.lps = 1000
+    for _ in range(5):
+        feed("D", 101000000, 96000, 40000, 1)
+    for tag in "ABCD":
+        assert len(got[tag]) == len(want[tag]), tag
+        for g, w in zip(got[tag], want[tag]):
+            if g[0] == "S":
+                assert g[3] == w[3] and abs(float(g[2]) - float(w[2])) < 1e-9, (tag, g, w)
+            else:
+                assert g == w, (tag, g, w)
+    n_lines = {t: sum(1 for g in got[t] if g[0] == "L") for t in "ABCD"}
+    assert 28 <= n_lines["A"] <= 31 and n_lines["B"] > 100 and n_lines["D"] > 0, n_lines
+    assert got["E"][0][1] == "1"          # default queue capacity 1: the other lines of that run were dropped
+
+
 @pytest.mark.gpu
 def test_threaded_pipeline_on_gpu():
     """SDRThreadIQData blocks -> SDRPostThread (HIP) -> NBFM audio queue + spectrum queue, through real threads/queues"""
