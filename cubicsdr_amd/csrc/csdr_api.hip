@@ -163,7 +163,8 @@ struct csdr_post {
     csdr_ctx *ctx = nullptr;
     bool configured = false;
     int mode = CSDR_POST_SINGLE, M = 1;
-    int64_t sample_rate = 0, chan_bw = 0, frequency = 0;
+    int64_t sample_rate = 0, chan_bw = 0, chan_rate = 0, frequency = 0;
+    int hop = 1;                             // input samples per output sample of a channel: M, M / 2 (PFBCH2) or 1 (single)
     int max_block_len = 0, max_blocks = 0;
     int64_t chan_stride = 0;                 // samples per channel row in `out` (even: rows stay 16-byte aligned)
     int n_blocks = 0, block_len = 0;         // of the last execute
@@ -179,7 +180,7 @@ struct csdr_post {
     hipEvent_t ev_ready[kPostBufs] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_consumed[kPostBufs][kMaxConsumers] = {};
     int n_consumed[kPostBufs] = {0, 0, 0};
-    DevBuf<float2> out, hist0, hist1, stage_in, twA, twB, twM;
+    DevBuf<float2> out, hist0, hist1, stage_in, twA, twB, twM, post2;
     DevBuf<float> taps;
     DevBuf<int> active;                      // [M] flags
     DevBuf<d2> dc_state, tile_end;           // dc_state[2]: ping-pong carried state
@@ -218,15 +219,15 @@ extern "C" void csdr_post_destroy(csdr_post *p) {
         for (int c = 0; c < csdr_post::kMaxConsumers; ++c) if (p->ev_consumed[k][c]) (void)hipEventDestroy(p->ev_consumed[k][c]);
     }
     p->out.release(); p->hist0.release(); p->hist1.release(); p->stage_in.release();
-    p->twA.release(); p->twB.release(); p->twM.release();
+    p->twA.release(); p->twB.release(); p->twM.release(); p->post2.release();
     p->taps.release(); p->active.release(); p->dc_state.release(); p->tile_end.release();
     delete p;
 }
 
 // geometry of the channelizer kernel for M channels (see kernels_post.hpp)
-static int chan_geometry(int M, ChanGeom &g) {
+static int chan_geometry(int M, int hop, ChanGeom &g) {
     memset(&g, 0, sizeof g);
-    g.M = M;
+    g.M = M; g.hop = hop;
     int B = 1;
     for (int d = 1; (int64_t)d * d <= M; ++d) if (M % d == 0) B = d;     // largest divisor <= sqrt(M)
     g.B = B; g.A = M / B;
@@ -261,15 +262,16 @@ static int chan_geometry(int M, ChanGeom &g) {
 }
 
 typedef void (*chan_kernel_t)(const float2 *, const float2 *, float2 *, const float *, const float2 *, const float2 *, const float2 *,
-                              const int *, ChanGeom, int64_t, float2 *, int64_t, d2 *, double);
+                              const int *, ChanGeom, int64_t, float2 *, int64_t, d2 *, double, const float2 *);
 static chan_kernel_t chan_kernel(const ChanGeom &g) {
-    return g.stage_in ? chan_analyze<1, 1> : g.taps_lds ? chan_analyze<0, 1> : chan_analyze<0, 0>;
+    if (g.hop != g.M) return g.stage_in ? chan_analyze<1, 1, 1> : g.taps_lds ? chan_analyze<0, 1, 1> : chan_analyze<0, 0, 1>;
+    return g.stage_in ? chan_analyze<1, 1, 0> : g.taps_lds ? chan_analyze<0, 1, 0> : chan_analyze<0, 0, 0>;
 }
 
 extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_channels, int mode, int max_block_len, int max_blocks) {
     if (!p) return fail(CSDR_EINVAL, "post is null");
     if (sample_rate <= 0 || num_channels < 1 || max_block_len <= 0 || max_blocks <= 0) return fail(CSDR_EINVAL, "bad sizes");
-    if (mode != CSDR_POST_SINGLE && mode != CSDR_POST_PFBCH) return fail(CSDR_EUNSUPPORTED, "channelizer mode %d (PFBCH2 is a later tier)", mode);
+    if (mode != CSDR_POST_SINGLE && mode != CSDR_POST_PFBCH && mode != CSDR_POST_PFBCH2) return fail(CSDR_EINVAL, "channelizer mode %d", mode);
     if ((mode == CSDR_POST_SINGLE) != (num_channels == 1)) return fail(CSDR_EINVAL, "SINGLE mode <=> num_channels == 1");
     if (max_block_len % num_channels) return fail(CSDR_EINVAL, "max_block_len must be a multiple of num_channels");
     if (num_channels > 1 && (num_channels & 1)) return fail(CSDR_EUNSUPPORTED, "odd numChannels %d (the reference only produces even counts, SoapySDRThread.cpp:676-693)", num_channels);
@@ -280,9 +282,12 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
     for (int k = 0; k < csdr_post::kPostBufs; ++k) p->n_consumed[k] = 0;
     p->mode = mode; p->M = num_channels; p->sample_rate = sample_rate;
     p->chan_bw = sample_rate / num_channels;                       // integer division, SDRPostThread.cpp:408
+    // samples per channel: one per M inputs, or one per M / 2 (firpfbch2, whose channels are handed on at 2 * chanBw, :510)
+    p->hop = mode == CSDR_POST_PFBCH2 ? num_channels / 2 : num_channels;
+    p->chan_rate = mode == CSDR_POST_SINGLE ? sample_rate : (mode == CSDR_POST_PFBCH2 ? 2 * p->chan_bw : p->chan_bw);
     p->max_block_len = max_block_len; p->max_blocks = max_blocks;
     const int M = p->M;
-    p->chan_stride = ((int64_t)max_blocks * (max_block_len / M) + 1) & ~(int64_t)1;
+    p->chan_stride = ((int64_t)max_blocks * (max_block_len / p->hop) + 1) & ~(int64_t)1;
     if (int rc = p->out.reserve((size_t)p->chan_stride * M * csdr_post::kPostBufs)) return rc;
     if (int rc = p->dc_state.reserve(2)) return rc;
     CSDR_HIP_TRY(hipMemsetAsync(p->dc_state.p, 0, 2 * sizeof(d2), st));
@@ -293,11 +298,17 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
     // iirfilt_crcf_create_dc_blocker(0.0005f): b = {1, -1}, a = {1, -1 + alpha}  (float)  ->  v = x - a1 v'
     const float a1 = -1.0f + 0.0005f;
     p->dc_c = -(double)a1;
-    if (mode == CSDR_POST_PFBCH) {
-        if (int rc = chan_geometry(M, p->geom)) return rc;
+    if (mode != CSDR_POST_SINGLE) {
+        if (int rc = chan_geometry(M, p->hop, p->geom)) return rc;
         const ChanGeom &g = p->geom;
         // prototype taps transposed to [n][c]: tapsT[n M + c] multiplies x[(t - n) M + c]
-        std::vector<float> taps = design::channelizer_taps((unsigned)M, 4, 60.0f);
+        std::vector<float> taps = mode == CSDR_POST_PFBCH2 ? design::channelizer2_taps((unsigned)M, 4, 60.0f)      // initPFBCH2 :463
+                                                           : design::channelizer_taps((unsigned)M, 4, 60.0f);      // initPFBCH :406
+        if (mode == CSDR_POST_PFBCH2) {
+            std::vector<float> post = design::channelizer2_post((unsigned)M);
+            if (int rc = p->post2.reserve((size_t)2 * M)) return rc;
+            CSDR_HIP_TRY(hipMemcpy(p->post2.p, post.data(), post.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         std::vector<float> tapsT((size_t)kChanTaps * M);
         for (int c = 0; c < M; c++) for (int n = 0; n < kChanTaps; n++) tapsT[(size_t)n * M + c] = taps[(size_t)c * kChanTaps + n];
         std::vector<float2> twA((size_t)g.A * g.PA, make_float2(0.f, 0.f)), twB((size_t)g.B * g.PB, make_float2(0.f, 0.f)), twM((size_t)g.A * g.B);
@@ -313,7 +324,7 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
         CSDR_HIP_TRY(hipMemcpyAsync(p->twA.p, twA.data(), twA.size() * sizeof(float2), hipMemcpyHostToDevice, st));
         CSDR_HIP_TRY(hipMemcpyAsync(p->twB.p, twB.data(), twB.size() * sizeof(float2), hipMemcpyHostToDevice, st));
         CSDR_HIP_TRY(hipMemcpyAsync(p->twM.p, twM.data(), twM.size() * sizeof(float2), hipMemcpyHostToDevice, st));
-        const size_t H = (size_t)(kChanTaps - 1) * M;
+        const size_t H = (size_t)kChanTaps * M - p->hop;
         if (int rc = p->hist0.reserve(H)) return rc;
         if (int rc = p->hist1.reserve(H)) return rc;
         CSDR_HIP_TRY(hipMemsetAsync(p->hist0.p, 0, H * sizeof(float2), st));
@@ -404,7 +415,7 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
             CSDR_HIP_TRY(hipMemcpy(p->active.p, flags.data(), flags.size() * sizeof(int), hipMemcpyHostToDevice));
             p->active_dirty = false;
         }
-        const int64_t n_frames = n / M;
+        const int64_t n_frames = n / p->hop;
         float2 *hist = p->hist_parity ? p->hist1.p : p->hist0.p, *hist_new = p->hist_parity ? p->hist0.p : p->hist1.p;
         ChanGeom g = p->geom;
         g.fpw = g.TF;                         // frames per workgroup (full tiles measured fastest on MI355X)
@@ -415,7 +426,8 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
         const bool fused_ends = dc0 && g.fpw >= 16;
         const chan_kernel_t kern = chan_kernel(g);
         CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, kern, dim3(ntiles), dim3(g.threads), chan_lds_bytes(g), x, hist, hist_new, p->taps.p,
-                    p->twA.p, p->twB.p, p->twM.p, p->active.p, g, n_frames, out, p->chan_stride, fused_ends ? p->tile_end.p : (d2 *)nullptr, p->dc_c);
+                    p->twA.p, p->twB.p, p->twM.p, p->active.p, g, n_frames, out, p->chan_stride, fused_ends ? p->tile_end.p : (d2 *)nullptr, p->dc_c,
+                    p->mode == CSDR_POST_PFBCH2 ? p->post2.p : (const float2 *)nullptr);
         p->hist_parity ^= 1;
         CSDR_HIP_TRY(hipGetLastError());
         if (dc0) rc = run_dc_blocker(p, out, out, n_frames, fused_ends, g.fpw);
@@ -428,6 +440,7 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
 }
 
 extern "C" int64_t csdr_post_channel_bandwidth(const csdr_post *p) { return p ? (p->M == 1 ? p->sample_rate : p->chan_bw) : 0; }
+extern "C" int64_t csdr_post_channel_rate(const csdr_post *p) { return p ? p->chan_rate : 0; }
 extern "C" int csdr_post_num_channels(const csdr_post *p) { return p ? p->M : 0; }
 extern "C" int64_t csdr_post_channel_center(const csdr_post *p, int i) {
     if (!p || i < 0 || i >= (int)p->centers.size()) return 0;
@@ -448,7 +461,7 @@ extern "C" int csdr_post_read_channel(csdr_post *p, int ch, float *host_out, int
     if (!p || !p->configured || !host_out || !n) return fail(CSDR_EINVAL, "bad argument");
     if (ch == p->M && p->M > 1) ch = p->M / 2;
     if (ch < 0 || ch >= p->M) return fail(CSDR_EINVAL, "channel out of range");
-    const int64_t cnt = (int64_t)p->n_blocks * (p->block_len / p->M);
+    const int64_t cnt = (int64_t)p->n_blocks * (p->block_len / p->hop);
     if (cnt > cap_samples) return fail(CSDR_ERANGE, "need %lld samples", (long long)cnt);
     hipStream_t st = p->ctx->lanes[LANE_POST];
     CSDR_HIP_TRY(hipMemcpyAsync(host_out, post_buf(p, p->cur) + (int64_t)ch * p->chan_stride, (size_t)cnt * sizeof(float2), hipMemcpyDeviceToHost, st));
@@ -613,7 +626,7 @@ extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod
     s.configured = false;
     s.prm = *prm;
     s.prm.bandwidth = modem_check_rate(prm->modem, prm->bandwidth);
-    s.chan_rate = csdr_post_channel_bandwidth(post);
+    s.chan_rate = csdr_post_channel_rate(post);
     const double iq_ratio = (double)s.prm.bandwidth / (double)s.chan_rate;        // DemodulatorWorkerThread.cpp:99-100
     if (iq_ratio > 1.0) return fail(CSDR_EUNSUPPORTED, "bandwidth %d above the channel rate %lld (interpolating IQ resampler)", s.prm.bandwidth, (long long)s.chan_rate);
     s.iq = design::plan_msresamp((float)iq_ratio, 60.0f);
@@ -638,7 +651,7 @@ extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod
     const int hist_len = (s.warm + 63) & ~63;
     if (hist_len > kMixHist) return fail(CSDR_EUNSUPPORTED, "cascade span %d exceeds the carried history", s.warm);
     // capacities for one execute
-    const int64_t max_bc = post->max_block_len / post->M;
+    const int64_t max_bc = post->max_block_len / post->hop;
     const int64_t cap_iq = (int64_t)std::ceil((double)b->max_blocks * (double)max_bc * iq_ratio) + b->max_blocks + 64;
     const int64_t cap_audio = (int64_t)std::ceil((double)cap_iq * au_ratio) + (int64_t)b->max_blocks * (2 << (s.au.interp ? s.au.S : 0)) + 64;
     // one slab per slot
@@ -701,13 +714,13 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     if (!post->configured || post->n_blocks <= 0) return fail(CSDR_ESTATE, "post has no data");
     csdr_ctx *c = b->ctx;
     hipStream_t st = c->lanes[LANE_FE], st_a = c->lanes[LANE_AUDIO];
-    const int NB = post->n_blocks, M = post->M, Bc = post->block_len / M;
+    const int NB = post->n_blocks, M = post->M, Bc = post->block_len / post->hop;
     if (NB > b->max_blocks) return fail(CSDR_ERANGE, "batch of %d blocks exceeds bank capacity %d", NB, b->max_blocks);
     const int bpar = (int)(b->seq & 1);      // which copy of the per-batch device tables this batch uses
     SlotDyn *dyns_d = b->dyns.p + (size_t)bpar * b->max_demods;
     int *lists_d = b->slot_list.p + (size_t)bpar * 3 * b->max_demods;
     BlockPlan *plans_d = b->plans.p + (size_t)bpar * b->max_demods * (b->max_blocks + 1);
-    const int64_t rate = csdr_post_channel_bandwidth(post);
+    const int64_t rate = csdr_post_channel_rate(post);
     // pinned staging set for this batch: wait only for the upload that last used it (kStageRing batches ago)
     const int ring = b->stage_next;
     b->stage_next = (b->stage_next + 1) % kStageRing;

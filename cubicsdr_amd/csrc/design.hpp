@@ -180,6 +180,37 @@ inline std::vector<float> channelizer_taps(unsigned M, unsigned m, float as) {
     return t;
 }
 
+// ---- 2x oversampled polyphase analysis channelizer (firpfbch2_crcf_create_kaiser(ANALYZER, M, m, As)) --------
+// liquid 1.5.0 firpfbch2: prototype Kaiser low-pass of 2 M m + 1 taps with cut-off 1/M (twice the analyzer bandwidth of
+// firpfbch), scaled to sum M; every execute() takes M/2 new samples and applies the first 2 M m taps, an M-point inverse
+// DFT and a 1/M gain, with the branch order rotating by M/2 on alternate calls.  Written in the commutator form of
+// channelizer_taps (pinned against the reference DLL's impulse responses to 1e-7):
+//   X_t[c] = sum_n taps[c][n] x[(t - 1) M/2 + c - n M]
+//   y_t[k] = post[t & 1][k] sum_c X_t[c] exp(-j 2 pi k c / M),   post[p][k] = (p ? (-1)^k : 1) exp(-j 2 pi k / M) / M
+inline std::vector<float> channelizer2_taps(unsigned M, unsigned m, float as) {
+    const unsigned p = 2 * m, hl = 2 * M * m + 1;
+    std::vector<float> h = kaiser_lowpass(hl, 1.0f / (float)M, as);
+    float sum = 0.0f;
+    for (float v : h) sum += v;
+    for (float &v : h) v = v * (float)M / sum;
+    std::vector<float> t((size_t)M * p);
+    for (unsigned c = 0; c < M; ++c)
+        for (unsigned n = 0; n < p; ++n) t[(size_t)c * p + n] = h[(M - 1 - c) + n * M];
+    return t;
+}
+// post[2][M] as (re, im) pairs
+inline std::vector<float> channelizer2_post(unsigned M) {
+    std::vector<float> t((size_t)4 * M);
+    for (unsigned par = 0; par < 2; ++par)
+        for (unsigned k = 0; k < M; ++k) {
+            const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)M;
+            const double s = (par && (k & 1)) ? -1.0 : 1.0;
+            t[2 * ((size_t)par * M + k)] = (float)(s * std::cos(a) / (double)M);
+            t[2 * ((size_t)par * M + k) + 1] = (float)(s * std::sin(a) / (double)M);
+        }
+    return t;
+}
+
 // ---- AM DC-blocking FIR (firfilt_rrrf_create_dc_blocker(m, As) -> liquid_firdes_notch(m, 0, As)) -----------
 inline std::vector<float> dc_notch_taps(unsigned m, float as) {
     const unsigned n = 2 * m + 1;

@@ -204,10 +204,11 @@ struct ChanGeom {
     int taps_lds;             // 1: the [8][M] tap table is staged in LDS
     int stage_in;             // 1: the (TF + 7) M input samples of the tile are staged in LDS (aliasing the Z array)
     int fpw;                  // frames one workgroup processes (<= TF)
+    int hop;                  // input samples between frames: M (firpfbch) or M / 2 (firpfbch2, 2x oversampled)
     int threads;              // workgroup size (whole waves, 256..512): chosen so each phase splits evenly over the waves
 };
 __host__ __device__ inline size_t chan_zin_floats2(const ChanGeom &g) {      // Z array, or the staged input tile if larger
-    const size_t z = (size_t)g.TF * g.S, in = g.stage_in ? (size_t)(g.TF + kChanTaps - 1) * g.M : 0;
+    const size_t z = (size_t)g.TF * g.S, in = g.stage_in ? (size_t)(g.TF - 1) * g.hop + (size_t)kChanTaps * g.M : 0;
     return ((z > in ? z : in) + 1) & ~(size_t)1;
 }
 __host__ __device__ inline size_t chan_lds_bytes(const ChanGeom &g) {
@@ -248,7 +249,8 @@ __device__ __forceinline__ void chan_phase1(const ChanGeom &g, const float2 *s_x
 template <int K>
 __device__ __forceinline__ void chan_phase2(const ChanGeom &g, float2 *s_x, const float2 *s_z, const float2 *__restrict__ twB,
                                             const int *__restrict__ active, float2 *__restrict__ out, int64_t out_stride,
-                                            int64_t f0, bool keep0, int k2b, int t, int k1) {
+                                            int64_t f0, bool keep0, int k2b, int t, int k1,
+                                            const float2 *__restrict__ post /* firpfbch2: [2][M] output factors by frame parity, else null */) {
     const int A = g.A, B = g.B, M = g.M;
     const int k = k1 + A * k2b;
     // consumer flags of the K rows, fetched (index clamped) ahead of the DFT: one latency, not K in a chain
@@ -257,17 +259,22 @@ __device__ __forceinline__ void chan_phase2(const ChanGeom &g, float2 *s_x, cons
     for (int j = 0; j < K; ++j) on[j] = active[min(k + j * A, M - 1)];
     float2 acc[K];
     chan_dft<K>(s_z + (size_t)t * g.S + k1, A, twB + k2b, g.PB, B, acc);
+    if (post) {
+        const float2 *pr = post + (size_t)((f0 + t) & 1) * M;          // every batch holds an even number of frames
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc[j] = cmul(acc[j], pr[min(k + j * A, M - 1)]);
+    }
     float2 *o = out + (int64_t)k * out_stride + f0 + t;
     if (k == 0 && keep0) s_x[t] = acc[0];                 // channel 0 of this tile (s_x is free after phase 1)
 #pragma unroll
     for (int j = 0; j < K; ++j) if (k2b + j < B && on[j]) o[(int64_t)j * A * out_stride] = acc[j];
 }
 
-template <int STAGE_IN, int TAPS_LDS>
+template <int STAGE_IN, int TAPS_LDS, int OS2 /* 1: frames hop by M / 2 and may start at odd sample offsets */>
 __global__ __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
     const float2 *__restrict__ x,        // batch input, n_frames * M samples
-    const float2 *__restrict__ hist,     // 7 * M samples preceding x
-    float2 *__restrict__ hist_new,       // receives the last 7 * M samples of (hist ++ x)
+    const float2 *__restrict__ hist,     // 8 * M - hop samples preceding x
+    float2 *__restrict__ hist_new,       // receives the last 8 * M - hop samples of (hist ++ x)
     const float *__restrict__ tapsT,     // [8][M]  tapsT[n M + c] multiplies x[(t - n) M + c]
     const float2 *__restrict__ twA,      // [A][PA] exp(-j 2 pi k1 c1 / A) at [c1 PA + k1], zero padded
     const float2 *__restrict__ twB,      // [B][PB] exp(-j 2 pi k2 c2 / B) at [c2 PB + k2], zero padded
@@ -275,26 +282,32 @@ __global__ __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
     const int *__restrict__ active,      // [M] 1: store channel row k
     ChanGeom g, int64_t n_frames,
     float2 *__restrict__ out, int64_t out_stride,
-    d2 *__restrict__ dc_ends, double dc_c /* DC blocker of channel 0: end value of this tile's recurrence (zero entering state) */) {
+    d2 *__restrict__ dc_ends, double dc_c /* DC blocker of channel 0: end value of this tile's recurrence (zero entering state) */,
+    const float2 *__restrict__ post) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int M = g.M, TF = g.TF, S = g.S;
+    const int M = g.M, TF = g.TF, S = g.S, hop = g.hop;
     float2 *s_x = reinterpret_cast<float2 *>(smem);
     float2 *s_z = s_x + (size_t)TF * S;                   // also the staged input tile during phase 0
     float *s_taps = reinterpret_cast<float *>(s_z + chan_zin_floats2(g));
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int64_t f0 = (int64_t)blockIdx.x * g.fpw;       // first frame of this tile (g.fpw <= TF frames per workgroup)
     const int nf = (int)min((int64_t)g.fpw, n_frames - f0);
-    const int64_t H = (int64_t)(kChanTaps - 1) * M;
+    const int64_t H = (int64_t)kChanTaps * M - hop;       // samples in front of frame 0's newest hop: 7 M, or 7.5 M when oversampled
 
-    const int64_t base = f0 * M;
+    // frame t of the tile reads x[base + t hop + c - n M], c < M, n < 8 (base = first sample of frame f0's window end row)
+    const int64_t base = f0 * hop - (M - hop);
+    const int64_t Hs = (int64_t)(kChanTaps - 1) * M;      // staged samples in front of `base`
     if (STAGE_IN) {
-        // one memory round trip: every input sample of the tile (7 frames of halo first) is loaded once, 16 bytes per lane
-        float4 *s_in4 = reinterpret_cast<float4 *>(s_z);
-        const int n_in2 = ((nf + kChanTaps - 1) * M) >> 1;
+        // one memory round trip: every input sample of the tile (the halo first) is loaded once, 16 bytes per lane
+        const int n_in2 = ((nf - 1) * hop + kChanTaps * M + 1) >> 1;
         for (int p = tid; p < n_in2; p += nthr) {
-            const int64_t gi = base - H + 2 * (int64_t)p;
+            const int64_t gi = base - Hs + 2 * (int64_t)p;
             const float2 *src = gi >= 0 ? x + gi : hist + (gi + H);
-            s_in4[p] = *reinterpret_cast<const float4 *>(src);
+            if (OS2) {                                    // M / 2 may be odd: 8-byte aligned pairs; the pair may straddle hist | x
+                float2 a = src[0], b2 = (gi + 1 >= 0) ? x[gi + 1] : hist[gi + 1 + H];
+                if (gi + 1 >= n_frames * hop) b2 = make_float2(0.f, 0.f);      // one sample past the batch (odd count): unused
+                s_z[2 * p] = a; s_z[2 * p + 1] = b2;
+            } else reinterpret_cast<float4 *>(s_z)[p] = *reinterpret_cast<const float4 *>(src);
         }
     }
     if (TAPS_LDS) for (int i = tid; i < kChanTaps * M; i += nthr) s_taps[i] = tapsT[i];
@@ -307,23 +320,32 @@ __global__ __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
         const unsigned i = 2u * (unsigned)p;
         const unsigned t = __umulhi(i, g.magicM);
         const unsigned c = i - t * (unsigned)M;
+        const unsigned pos = OS2 ? t * (unsigned)hop + c : i;               // offset of x[.. + t hop + c] from `base`
         float2 a0 = make_float2(0.f, 0.f), a1 = make_float2(0.f, 0.f);
         if (STAGE_IN) {
-            const float2 *sp = s_z + (size_t)(kChanTaps - 1) * M + i;      // x[(f0 + t) M + c] inside the staged tile
+            const float2 *sp = s_z + (size_t)(kChanTaps - 1) * M + pos;    // x[base + t hop + c] inside the staged tile
 #pragma unroll
             for (int n = 0; n < kChanTaps; ++n) {
-                const float4 v = *reinterpret_cast<const float4 *>(sp - n * M);
+                float4 v;
+                if (OS2) { const f4u u = *reinterpret_cast<const f4u *>(sp - n * M); v = make_float4(u.x, u.y, u.z, u.w); }
+                else v = *reinterpret_cast<const float4 *>(sp - n * M);
                 const float2 h = *reinterpret_cast<const float2 *>(tp + n * M + c);
                 a0.x = fmaf(h.x, v.x, a0.x); a0.y = fmaf(h.x, v.y, a0.y);
                 a1.x = fmaf(h.y, v.z, a1.x); a1.y = fmaf(h.y, v.w, a1.y);
             }
         } else {
-            const int64_t gi0 = base + i;
+            const int64_t gi0 = base + pos;
 #pragma unroll
             for (int n = 0; n < kChanTaps; ++n) {
                 const int64_t gi = gi0 - (int64_t)n * M;
-                const float2 *src = gi >= 0 ? x + gi : hist + (gi + H);
-                const float4 v = *reinterpret_cast<const float4 *>(src);
+                float4 v;
+                if (OS2) {                                  // 8-byte aligned pair that may straddle hist | x
+                    const float2 a = gi >= 0 ? x[gi] : hist[gi + H], b2 = gi + 1 >= 0 ? x[gi + 1] : hist[gi + 1 + H];
+                    v = make_float4(a.x, a.y, b2.x, b2.y);
+                } else {
+                    const float2 *src = gi >= 0 ? x + gi : hist + (gi + H);
+                    v = *reinterpret_cast<const float4 *>(src);
+                }
                 const float2 h = *reinterpret_cast<const float2 *>(tp + n * M + c);
                 a0.x = fmaf(h.x, v.x, a0.x); a0.y = fmaf(h.x, v.y, a0.y);
                 a1.x = fmaf(h.y, v.z, a1.x); a1.y = fmaf(h.y, v.w, a1.y);
@@ -334,7 +356,7 @@ __global__ __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
     }
     // the last workgroup also writes the new input history (the launch runs even with no consumers)
     if (blockIdx.x == gridDim.x - 1) {
-        const int64_t n = n_frames * M;
+        const int64_t n = n_frames * hop;
         for (int64_t j = tid; j < H; j += nthr) {
             const int64_t gsrc = n - H + j;
             hist_new[j] = gsrc >= 0 ? x[gsrc] : hist[gsrc + H];
@@ -374,11 +396,11 @@ __global__ __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
             const int t = it & tmask, k1 = it >> g.lgTF;
             if (it >= items || t >= nf) continue;
             switch (g.KB) {
-                case 4: chan_phase2<4>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1); break;
-                case 5: chan_phase2<5>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1); break;
-                case 6: chan_phase2<6>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1); break;
-                case 7: chan_phase2<7>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1); break;
-                default: chan_phase2<8>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1); break;
+                case 4: chan_phase2<4>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1, post); break;
+                case 5: chan_phase2<5>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1, post); break;
+                case 6: chan_phase2<6>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1, post); break;
+                case 7: chan_phase2<7>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1, post); break;
+                default: chan_phase2<8>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1, post); break;
             }
         }
     }

@@ -83,12 +83,14 @@ class Context:
 class SDRPost:
     """SDRPostThread's arithmetic (csdr_post): DC blocker (1 channel) or firpfbch analyzer (M channels)."""
 
-    def __init__(self, ctx, sample_rate, num_channels, max_block_len, max_blocks=1):
+    def __init__(self, ctx, sample_rate, num_channels, max_block_len, max_blocks=1, oversampled=False):
+        """oversampled=True: SDRPostPFBCH2 (firpfbch2, channels at twice the channel spacing)"""
         self._l = H.lib()
         self.ctx = ctx
         self.h = C.c_void_p()
         H.check(self._l.csdr_post_create(ctx.h, C.byref(self.h)))
-        mode = H.CSDR_POST_SINGLE if num_channels == 1 else H.CSDR_POST_PFBCH
+        mode = H.CSDR_POST_SINGLE if num_channels == 1 else (H.CSDR_POST_PFBCH2 if oversampled else H.CSDR_POST_PFBCH)
+        self.hop = 1 if num_channels == 1 else (num_channels // 2 if oversampled else num_channels)
         H.check(self._l.csdr_post_configure(self.h, int(sample_rate), int(num_channels), mode, int(max_block_len), int(max_blocks)))
         self.num_channels = num_channels
         self.sample_rate = sample_rate
@@ -112,6 +114,10 @@ class SDRPost:
     def channel_bandwidth(self):
         return self._l.csdr_post_channel_bandwidth(self.h)
 
+    @property
+    def channel_rate(self):
+        return self._l.csdr_post_channel_rate(self.h)
+
     def channel_center(self, i):
         return self._l.csdr_post_channel_center(self.h, i)
 
@@ -120,7 +126,7 @@ class SDRPost:
 
     def read_channel(self, ch):
         nb, bl = self._last
-        cap = nb * (bl // self.num_channels)
+        cap = nb * (bl // self.hop)
         out = np.empty(cap, np.complex64)
         n = C.c_int()
         H.check(self._l.csdr_post_read_channel(self.h, int(ch), out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))

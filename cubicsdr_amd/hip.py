@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcsdr_hip.so")
 
-CSDR_POST_SINGLE, CSDR_POST_PFBCH = 0, 1
+CSDR_POST_SINGLE, CSDR_POST_PFBCH, CSDR_POST_PFBCH2 = 0, 1, 2
 CSDR_MODEM_NBFM, CSDR_MODEM_FM, CSDR_MODEM_AM, CSDR_MODEM_USB, CSDR_MODEM_LSB = range(5)
 CSDR_SPEC_FIRST_FRAME, CSDR_SPEC_CONTIGUOUS, CSDR_SPEC_LINES = 0, 1, 2
 MODEM_BY_NAME = {"NBFM": 0, "FM": 1, "AM": 2, "USB": 3, "LSB": 4}
@@ -58,6 +58,7 @@ ABI = {
     "csdr_post_execute": (_i, [_p, _p, _i, _i, _i, _i64]),
     "csdr_post_set_active_channels": (_i, [_p, _p, _i]),
     "csdr_post_channel_bandwidth": (_i64, [_p]),
+    "csdr_post_channel_rate": (_i64, [_p]),
     "csdr_post_num_channels": (_i, [_p]),
     "csdr_post_channel_center": (_i64, [_p, _i]),
     "csdr_post_channel_at": (_i, [_p, _i64]),

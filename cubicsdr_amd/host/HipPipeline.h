@@ -156,13 +156,21 @@ public:
     }
     std::atomic<long long> blocksProcessed{0};
 
+    // SDRPostThreadChannelizerType (SDRPostThread.h:9-12, setChannelizerType :142-149): takes effect at the next block,
+    // which rebuilds the channelizer (chanMode != lastChanMode, :418 / :474)
+    enum SDRPostThreadChannelizerType { SDRPostPFBCH = 1, SDRPostPFBCH2 = 2 };
+    void setChannelizerType(SDRPostThreadChannelizerType t) { chanMode.store((int)t); }
+    SDRPostThreadChannelizerType getChannelizerType() { return (SDRPostThreadChannelizerType)chanMode.load(); }
+
 private:
     void processBlock(SDRThreadIQData &in, const DemodulatorThreadInputQueuePtr &iqOut, const DemodulatorThreadInputQueuePtr &iqVisual) {
         const int n = (int)in.data.size();
         const int M = in.numChannels > 1 ? in.numChannels : 1;
-        if (in.sampleRate != sampleRate_ || M != numChannels_ || n > maxBlock_) {      // initPFBCH, :401-414
-            sampleRate_ = in.sampleRate; numChannels_ = M; maxBlock_ = n;
-            csdr_must(csdr_post_configure(post_, sampleRate_, M, M > 1 ? CSDR_POST_PFBCH : CSDR_POST_SINGLE, n, 1), "csdr_post_configure");
+        const int mode = chanMode.load();
+        if (in.sampleRate != sampleRate_ || M != numChannels_ || n > maxBlock_ || mode != lastChanMode_) {      // initPFBCH :401-414, initPFBCH2 :458-470
+            sampleRate_ = in.sampleRate; numChannels_ = M; maxBlock_ = n; lastChanMode_ = mode;
+            const int kind = M > 1 ? (mode == SDRPostPFBCH2 ? CSDR_POST_PFBCH2 : CSDR_POST_PFBCH) : CSDR_POST_SINGLE;
+            csdr_must(csdr_post_configure(post_, sampleRate_, M, kind, n, 1), "csdr_post_configure");
         }
         // full-rate copy to the visual queues first (getFullSampleRateIqData + pushVisualData, :221-245): never blocks
         if (iqOut || iqVisual) {
@@ -173,7 +181,7 @@ private:
         }
         // active set: in range of this block's span (updateActiveDemodulators, :44-98)
         auto demods = mgr_->getDemodulators();
-        const long long chanRate = csdr_post_channel_bandwidth(post_);
+        const long long chanRate = csdr_post_channel_rate(post_);            // chanBw, or 2 * chanBw behind firpfbch2 (:510)
         std::vector<DemodulatorInstancePtr> run;
         for (auto &d : demods) {
             const bool inRange = std::llabs(in.frequency - d->getFrequency()) <= in.sampleRate / 2;
@@ -244,7 +252,8 @@ private:
     csdr_post *post_ = nullptr;
     csdr_bank *bank_ = nullptr;
     long long sampleRate_ = 0;
-    int numChannels_ = 0, maxBlock_ = 0;
+    int numChannels_ = 0, maxBlock_ = 0, lastChanMode_ = 0;
+    std::atomic<int> chanMode{(int)SDRPostPFBCH};                                // ctor :23
     ReBuffer<DemodulatorThreadIQData> visualBuffers_{"SDRPostThreadVisualDataBuffers"};
 };
 

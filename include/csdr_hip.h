@@ -79,6 +79,9 @@ int  csdr_dev_download(csdr_ctx *ctx, void *host, const void *dev, uint64_t byte
  * updateChannels :116-124, getChannelAt :128-139. */
 #define CSDR_POST_SINGLE 0   /* numChannels == 1 : DC-blocked full-rate stream is "channel 0" */
 #define CSDR_POST_PFBCH  1   /* SDRPostPFBCH  (SDRPostThread.h:9-12), critically sampled analyzer */
+#define CSDR_POST_PFBCH2 2   /* SDRPostPFBCH2: initPFBCH2 :458-470 (firpfbch2_crcf_create_kaiser(ANALYZER,M,4,60) :463),
+                              * runPFBCH2 :472-512 (firpfbch2_crcf_execute per M/2 inputs :505-507): every channel comes
+                              * out at 2*chanBw (runDemodChannels(chanBw * 2) :510), channel centres are unchanged */
 
 int  csdr_post_create(csdr_ctx *ctx, csdr_post **out);
 void csdr_post_destroy(csdr_post *post);
@@ -93,6 +96,7 @@ int  csdr_post_execute(csdr_post *post, const float *iq, int iq_is_dev, int n_bl
  * The wrap channel index M is accepted as an alias of M/2. */
 int  csdr_post_set_active_channels(csdr_post *post, const int *channels, int n);
 int64_t csdr_post_channel_bandwidth(const csdr_post *post);                  /* chanBw (:408) */
+int64_t csdr_post_channel_rate(const csdr_post *post);                       /* sampleRate stamped on the channel data (:344): chanBw, 2*chanBw for PFBCH2 */
 int     csdr_post_num_channels(const csdr_post *post);
 int64_t csdr_post_channel_center(const csdr_post *post, int i);              /* chanCenters[i], i in [0, M] (:116-124) */
 int     csdr_post_channel_at(const csdr_post *post, int64_t frequency);      /* getChannelAt (:128-139) */

@@ -21,13 +21,17 @@ def _cptr(a):
 class RefSDRPost:
     """SDRPostThread (src/sdr/SDRPostThread.cpp): runSingleCH :248-299, runPFBCH :416-455, runDemodChannels :303-398."""
 
-    def __init__(self, backend, sample_rate, num_channels):
+    def __init__(self, backend, sample_rate, num_channels, oversampled=False):
         self.L = A.load(backend)
         self.sample_rate = int(sample_rate)
         self.M = int(num_channels)
         self.dc = self.L.iirfilt_crcf_create_dc_blocker(0.0005)          # :29
         self.frequency = 0
-        if self.M > 1:
+        self.oversampled = bool(oversampled) and self.M > 1              # chanMode 2: runPFBCH2 :472-512
+        if self.oversampled:
+            self.chan = self.L.firpfbch2_crcf_create_kaiser(A.LIQUID_ANALYZER, self.M, 4, 60.0)  # :463
+            self.chan_bw = self.sample_rate // self.M                    # :465
+        elif self.M > 1:
             self.chan = self.L.firpfbch_crcf_create_kaiser(A.LIQUID_ANALYZER, self.M, 4, 60.0)   # :406
             self.chan_bw = self.sample_rate // self.M                    # :408 (integer division)
         else:
@@ -64,6 +68,11 @@ class RefSDRPost:
             self.data_out = y
             return
         self.update_channels()
+        if self.oversampled:                                             # :493-507: dataOut holds 2x the input
+            y = np.empty(2 * x.size, np.complex64)
+            self.L.oracle_firpfbch2_block(C.c_void_p(self.chan), self.M, _cptr(x), x.size // (self.M // 2), _cptr(y))
+            self.data_out = y
+            return
         y = np.empty_like(x)
         self.L.oracle_firpfbch_analyzer_block(C.c_void_p(self.chan), self.M, _cptr(x), x.size // self.M, _cptr(y))   # :449-451
         self.data_out = y
@@ -78,7 +87,7 @@ class RefSDRPost:
             y = np.empty_like(d)
             self.L.iirfilt_crcf_execute_block(self.dc, _cptr(d), d.size, _cptr(y))
             d = y
-        return d, self.centers[i], self.chan_bw
+        return d, self.centers[i], (2 * self.chan_bw if self.oversampled else self.chan_bw)   # runDemodChannels(chanBw * 2) :510
 
 
 class RefDemod:

@@ -495,6 +495,62 @@ int firpfbch_crcf_analyzer_execute(void *p, cf32 *x, cf32 *y)
     return 0;
 }
 
+/* ================================================================== firpfbch2 analyzer  liquid v1.5.0 src/multichannel/src/firpfbch2.proto.c (liquid.h firpfbch2 section)
+ * 2x oversampled analysis bank: M channels, M/2 new samples per execute().  Prototype: liquid_firdes_kaiser(2 M m + 1,
+ * fc = 1/M, As) scaled to sum M; branch i filters the samples M apart with the sub-sampled taps h[i + r M], r < 2m; the
+ * branch order rotates by M/2 on alternate calls (the `flag`), then an M-point inverse DFT and a 1/M gain.  Pinned
+ * against the reference DLL (impulse responses and random input, <= 2e-7). */
+typedef struct { unsigned M, m, hl; float *h; cf32 *hist; /* last hl samples, oldest first */ unsigned flag; double *tw_c, *tw_s; } firpfbch2_t;
+
+void *firpfbch2_crcf_create_kaiser(int type, unsigned M, unsigned m, float As)
+{
+    if (type != 0) return NULL; /* analyzer only on this path */
+    firpfbch2_t *q = (firpfbch2_t *)calloc(1, sizeof(*q));
+    unsigned h_len = 2 * M * m + 1;
+    float *h = (float *)malloc(h_len * sizeof(float));
+    liquid_firdes_kaiser(h_len, 1.0f / (float)M, As, 0.0f, h);
+    float sum = 0.0f;
+    for (unsigned i = 0; i < h_len; i++) sum += h[i];
+    for (unsigned i = 0; i < h_len; i++) h[i] = h[i] * (float)M / sum;
+    q->M = M; q->m = m; q->hl = 2 * M * m; q->h = h;
+    q->hist = (cf32 *)calloc(q->hl, sizeof(cf32));
+    q->tw_c = (double *)malloc(M * sizeof(double)); q->tw_s = (double *)malloc(M * sizeof(double));
+    for (unsigned i = 0; i < M; i++) { q->tw_c[i] = cos(2.0 * M_PI * i / M); q->tw_s[i] = sin(2.0 * M_PI * i / M); }
+    return q;
+}
+int firpfbch2_crcf_destroy(void *p)
+{ firpfbch2_t *q = (firpfbch2_t *)p; free(q->h); free(q->hist); free(q->tw_c); free(q->tw_s); free(q); return 0; }
+int firpfbch2_crcf_execute(void *p, cf32 *x, cf32 *y)
+{
+    firpfbch2_t *q = (firpfbch2_t *)p;
+    unsigned M = q->M, M2 = M / 2, hl = q->hl;
+    memmove(q->hist, q->hist + M2, (hl - M2) * sizeof(cf32));
+    memcpy(q->hist + hl - M2, x, M2 * sizeof(cf32));
+    /* branch outputs: U[i] = sum_r h[i + r M] * (sample i + r M back from the newest) */
+    cf32 *U = (cf32 *)alloca(M * sizeof(cf32));
+    for (unsigned i = 0; i < M; i++) {
+        float ar = 0.f, ai = 0.f;
+        for (unsigned r = 0; r < 2 * q->m; r++) {
+            const cf32 v = q->hist[hl - 1 - i - r * M];
+            ar += q->h[i + r * M] * v.re; ai += q->h[i + r * M] * v.im;
+        }
+        U[i].re = ar; U[i].im = ai;
+    }
+    /* inverse DFT over the branches, rotated by M/2 on odd calls: y[k] = (flag ? (-1)^k : 1) / M * sum_i U[i] e^{+j 2 pi k i / M} */
+    for (unsigned k = 0; k < M; k++) {
+        double ar = 0, ai = 0;
+        for (unsigned i = 0; i < M; i++) {
+            unsigned t = (unsigned)(((uint64_t)k * i) % M);
+            ar += U[i].re * q->tw_c[t] - U[i].im * q->tw_s[t];
+            ai += U[i].im * q->tw_c[t] + U[i].re * q->tw_s[t];
+        }
+        double s = (q->flag && (k & 1)) ? -1.0 : 1.0;
+        y[k].re = (float)(s * ar / (double)M); y[k].im = (float)(s * ai / (double)M);
+    }
+    q->flag ^= 1;
+    return 0;
+}
+
 /* ================================================================== iirfilt_crcf  liquid v1.5.0 src/filter/src/iirfilt.proto.c, iirfiltsos.proto.c, iirdes.c */
 typedef struct { int sos; unsigned nsos; float b[3 * 8], a[3 * 8]; cf32 v[3 * 8]; float nb[2], na[2]; cf32 nv[2]; } iirfilt_t;
 
@@ -708,6 +764,9 @@ int fft_execute(void *p)
 /* SDRPostThread.cpp:449-451: one analyzer_execute per M-sample frame */
 int oracle_firpfbch_analyzer_block(void *q, unsigned M, cf32 *x, unsigned nframes, cf32 *y)
 { for (unsigned i = 0; i < nframes; i++) firpfbch_crcf_analyzer_execute(q, x + (size_t)i * M, y + (size_t)i * M); return 0; }
+/* SDRPostThread.cpp:505-507: one firpfbch2 execute per M/2 input samples, M outputs each */
+int oracle_firpfbch2_block(void *q, unsigned M, cf32 *x, unsigned ncalls, cf32 *y)
+{ for (unsigned i = 0; i < ncalls; i++) firpfbch2_crcf_execute(q, x + (size_t)i * (M / 2), y + (size_t)i * M); return 0; }
 /* ModemAM.cpp:41-47 */
 int oracle_am_block(void *dcblock, cf32 *x, unsigned n, float *y)
 { for (unsigned i = 0; i < n; i++) { float I = x[i].re, Q = x[i].im; firfilt_rrrf_push(dcblock, sqrtf(I * I + Q * Q)); firfilt_rrrf_execute(dcblock, &y[i]); } return 0; }

@@ -263,6 +263,9 @@ float sincf(float x) { return sincf_get()(x); }
 /* SDRPostThread.cpp:449-451 */
 int oracle_firpfbch_analyzer_block(obj q, unsigned M, cf32 *x, unsigned nframes, cf32 *y)
 { firpfbch_crcf_analyzer_execute_t f = firpfbch_crcf_analyzer_execute_get(); for (unsigned i = 0; i < nframes; i++) f(q, x + (size_t)i * M, y + (size_t)i * M); return 0; }
+/* SDRPostThread.cpp:505-507 */
+int oracle_firpfbch2_block(obj q, unsigned M, cf32 *x, unsigned ncalls, cf32 *y)
+{ firpfbch2_crcf_execute_t f = firpfbch2_crcf_execute_get(); for (unsigned i = 0; i < ncalls; i++) f(q, x + (size_t)i * (M / 2), y + (size_t)i * M); return 0; }
 /* ModemAM.cpp:41-47 */
 int oracle_am_block(obj dcblock, cf32 *x, unsigned n, float *y)
 { for (unsigned i = 0; i < n; i++) { float I = x[i].re, Q = x[i].im; firfilt_rrrf_push(dcblock, sqrtf(I * I + Q * Q)); firfilt_rrrf_execute(dcblock, &y[i]); } return 0; }

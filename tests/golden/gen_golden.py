@@ -143,5 +143,25 @@ def main():
     print("wrote", out, os.path.getsize(out), "bytes,", len(g), "arrays")
 
 
+def main_b():
+    """second fixture file (later additions keep their own seed so that the first file never changes):
+    tests/golden/liquid_1_5_0_b.npz"""
+    L = A.load("ref")
+    rng = np.random.default_rng(20260923)
+    g = {}
+    # --- 2x oversampled channelizer (SDRPostThread.cpp:463, :505-507): M outputs per M/2 inputs
+    for M in (4, 6, 20, 122):
+        q = L.firpfbch2_crcf_create_kaiser(A.LIQUID_ANALYZER, M, 4, 60.0)
+        nc = 40
+        xin = rnd(rng, (M // 2) * nc); y = np.zeros(M * nc, np.complex64)
+        L.oracle_firpfbch2_block(C.c_void_p(q), M, A.ptr(xin), nc, A.ptr(y))
+        g["firpfbch2_M%d_in" % M] = xin; g["firpfbch2_M%d_out" % M] = y
+    out = os.path.join(ROOT, "tests", "golden", "liquid_1_5_0_b.npz")
+    np.savez_compressed(out, **g)
+    print("wrote", out, os.path.getsize(out), "bytes,", len(g), "arrays")
+
+
 if __name__ == "__main__":
-    main()
+    if "--b-only" not in sys.argv:
+        main()
+    main_b()

@@ -58,6 +58,20 @@ def test_emu_channelizer_batched(ctx):
     G.test_channelizer_batched_equals_blockwise(ctx)
 
 
+def test_emu_channelizer2_m6(ctx):
+    G.test_channelizer2_matches_firpfbch2(ctx, 3000000, 6, 5004)
+
+
+@full
+def test_emu_channelizer2_m20(ctx):
+    G.test_channelizer2_matches_firpfbch2(ctx, 10000000, 20, 16680)
+
+
+@full
+def test_emu_demods_behind_oversampled_channelizer(ctx):
+    G.test_demods_behind_oversampled_channelizer(ctx)
+
+
 def test_emu_dc_blocker(ctx):
     G.test_single_channel_dc_blocker(ctx)
 

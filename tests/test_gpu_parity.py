@@ -50,6 +50,44 @@ def test_channelizer_matches_firpfbch(ctx, fs, M, block):
     post.close()
 
 
+@pytest.mark.parametrize("fs,M,block", [(2400000, 4, 40000), (10000000, 20, 166680), (3000000, 6, 50004), (61440000, 122, 102480),
+                                         (100000000, 1024, 65536)])
+def test_channelizer2_matches_firpfbch2(ctx, fs, M, block):
+    """SDRPostPFBCH2 (runPFBCH2, SDRPostThread.cpp:472-512): firpfbch2 hands out M samples per M/2 inputs, every channel at
+    twice the channel spacing; M/2 odd (6, 122) starts every other frame at an odd sample offset; M = 1024 takes the
+    unstaged kernel variant.  Three blocks one at a time (carried history), then the same three in one batch."""
+    from cubicsdr_amd.engine import SDRPost
+    from oracle.cubicsdr_chain import RefSDRPost
+    center = 100000000
+    x = [synth_iq(block, fs, center, [("NBFM", center + 123456)], seed=41 + b, t0=b * block) for b in range(3)]
+    ref = RefSDRPost(_backend(), fs, M, oversampled=True)
+    post = SDRPost(ctx, fs, M, block, max_blocks=1, oversampled=True)
+    chans = range(M + 1) if M <= 122 else [0, 1, 2, 511, 512, 513, 1023, 1024]
+    want_all = {ch: [] for ch in chans}
+    for b in range(3):
+        ref.run_block(x[b], center)
+        post.execute(x[b], 1, block, center)
+        peak = float(np.max(np.abs(ref.data_out)))              # tolerance relative to the strongest channel of the block
+        for ch in chans:
+            want, fc, rate = ref.channel_data(ch)
+            got = post.read_channel(ch)
+            assert got.size == want.size == 2 * block // M
+            assert post.channel_center(ch) == fc and post.channel_rate == rate == 2 * (fs // M)
+            noise = 4 * np.spacing(np.float32(0.01 * M / 0.0005)) if ch == 0 else 0.0     # DC-blocker state noise (see C4 test)
+            assert np.max(np.abs(got - want)) < TOL * peak + noise, (b, ch)
+            want_all[ch].append(want)
+    assert post.channel_bandwidth == ref.chan_bw
+    post.close()
+    batch = SDRPost(ctx, fs, M, block, max_blocks=3, oversampled=True)
+    batch.execute(np.concatenate(x), 3, block, center)
+    peak = max(float(np.max(np.abs(np.concatenate(want_all[ch])))) for ch in chans)
+    for ch in chans:
+        want = np.concatenate(want_all[ch])
+        noise = 4 * np.spacing(np.float32(0.01 * M / 0.0005)) if ch == 0 else 0.0
+        assert np.max(np.abs(batch.read_channel(ch) - want)) < TOL * peak + noise, ch
+    batch.close()
+
+
 def test_channelizer_batched_equals_blockwise(ctx):
     from cubicsdr_amd.engine import SDRPost
     fs, M, block, center = 2400000, 4, 40000, 100000000
@@ -103,7 +141,7 @@ def test_dc_blocker_large_offset_state_noise(ctx):
 
 
 # ----------------------------------------------------------------------------------------------- demodulators
-def _run_demods(ctx, fs, M, block, kinds, n_blocks, batch, bw=None, seed=3):
+def _run_demods(ctx, fs, M, block, kinds, n_blocks, batch, bw=None, seed=3, oversampled=False):
     """run n_blocks through post+bank in batches of `batch`; return per-demod lists of per-block dicts + oracle's."""
     from cubicsdr_amd.engine import DemodBank, SDRPost
     from oracle.cubicsdr_chain import RefDemod, RefSDRPost
@@ -114,13 +152,13 @@ def _run_demods(ctx, fs, M, block, kinds, n_blocks, batch, bw=None, seed=3):
     demods = list(zip(kinds, freqs))
     x = synth_iq(n_blocks * block, fs, center, demods, seed=seed)
     be = _backend()
-    ref_post = RefSDRPost(be, fs, M)
-    post = SDRPost(ctx, fs, M, block, max_blocks=batch)
+    ref_post = RefSDRPost(be, fs, M, oversampled=oversampled)
+    post = SDRPost(ctx, fs, M, block, max_blocks=batch, oversampled=oversampled)
     bank = DemodBank(ctx, len(kinds), max_blocks=batch)
     refs = []
     for i, (k, f) in enumerate(demods):
         bank.configure(i, post, k, bws[i], f)
-        refs.append(RefDemod(be, k, bws[i], f, ref_post.chan_bw))
+        refs.append(RefDemod(be, k, bws[i], f, ref_post.chan_bw * (2 if oversampled and M > 1 else 1)))
     got = [[] for _ in kinds]
     want = [[] for _ in kinds]
     for b0 in range(0, n_blocks, batch):
@@ -206,6 +244,13 @@ def test_c2_shape_64_nbfm(ctx):
     """BASELINE config 2 shape (64x NBFM, 10 MS/s, M = 20) on 2 blocks; oracle checks 8 of the demods."""
     got, want = _run_demods(ctx, 10000000, 20, 166680, ["NBFM"] * 8, 2, 2)
     print(_compare(got, want, "c2"))
+
+
+def test_demods_behind_oversampled_channelizer(ctx):
+    """chanMode 2: the demodulators see their channel at 2 * chanBw (runDemodChannels(chanBw * 2), :510), so the IQ
+    resampler ratio and cascade depth change; mixed modems over 6 blocks in batches of 2."""
+    got, want = _run_demods(ctx, 2400000, 4, 40000, ["NBFM", "AM", "USB", "FM", "LSB"], 6, 2, seed=23, oversampled=True)
+    print(_compare(got, want, "pfbch2"))
 
 
 def test_single_channel_mode_demod(ctx):

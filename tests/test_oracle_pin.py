@@ -108,6 +108,16 @@ def test_firpfbch(G, P, M):
     assert rel_err(y, G["firpfbch_M%d_out" % M]) < TOL
 
 
+@pytest.mark.parametrize("M", [4, 6, 20, 122])
+def test_firpfbch2(P, M):
+    """2x oversampled analyzer (runPFBCH2): the restatement against the reference binary's outputs"""
+    G2 = np.load(os.path.join(ROOT, "tests", "golden", "liquid_1_5_0_b.npz"))
+    q = P.firpfbch2_crcf_create_kaiser(A.LIQUID_ANALYZER, M, 4, 60.0)
+    xin = np.ascontiguousarray(G2["firpfbch2_M%d_in" % M]); y = np.zeros(2 * xin.size, np.complex64)
+    P.oracle_firpfbch2_block(C.c_void_p(q), M, A.ptr(xin), xin.size // (M // 2), A.ptr(y))
+    assert rel_err(y, G2["firpfbch2_M%d_out" % M]) < TOL
+
+
 def test_filters_and_modems(G, P):
     x = np.ascontiguousarray(G["dcblock_in"]); y = np.zeros_like(x)
     P.iirfilt_crcf_execute_block(P.iirfilt_crcf_create_dc_blocker(0.0005), A.ptr(x), x.size, A.ptr(y))
