@@ -384,10 +384,14 @@ __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restr
         for (int i = 0; i < G; ++i) { aGm1 = aG; aG *= a; }
         const double cG = (double)G * rate * aGm1;
         // 1. local pass from a zero state
+        // (a zero state never needs the NaN repairs of avg_step: plain recurrences)
         AvgState loc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int i = 0; i < kAvgGMax; ++i)
-            if (i < G && fg + i < nfb) avg_step(loc, (double)m[i].x, (double)m[i].y, rate);
+            if (i < G && fg + i < nfb) {
+                loc.maa_a += (loc.ma_a - loc.maa_a) * rate; loc.ma_a += ((double)m[i].x - loc.ma_a) * rate;
+                loc.maa_b += (loc.ma_b - loc.maa_b) * rate; loc.ma_b += ((double)m[i].y - loc.ma_b) * rate;
+            }
         s_loc[grp * kAvgLanes + lane] = loc;
         __syncthreads();
         // 2. entering state of my group
@@ -448,8 +452,21 @@ __global__ __launch_bounds__(256) void spec_extrema(const float2 *__restrict__ e
 // records them and that of the last frame publishes the end state (ping-pong copy).  Then two display points per
 // thread, full-span view (visualRatio = 1: two bins per point), :532-576:
 //     y = log10(acc / 2 + 0.25 - (floor - 0.75)) / log10(ceil + 0.25 - (floor - 0.75)) * scale
-// Both arguments are 1 + u with u formed in double; the logarithms are taken as log1pf(u) (relative error ~1e-7 of the
-// logarithm itself, also when the dynamic range is tiny), their ratio needs no base conversion.
+// Both arguments are 1 + u with u formed in double; the logarithms are taken as log(1 + u) with the rounding of the sum
+// cancelled (log1p_fast: a few float ulps also when the dynamic range is tiny), their ratio needs no base conversion.
+// log(1 + u) for u > -1 from the hardware base-2 logarithm: log(w) u / (w - 1) with w = fl(1 + u) cancels the rounding of
+// the sum (the classic log1p identity), so the relative error stays at a few float ulps however small u is
+__device__ __forceinline__ float log1p_fast(float u) {
+    const float w = 1.0f + u;
+#if defined(__AMDGCN__)
+    const float l = __log2f(w) * 0.69314718055994530942f;             // v_log_f32
+#else
+    const float l = log2f(w) * 0.69314718055994530942f;
+#endif
+    const float d = w - 1.0f;
+    return d == 0.0f ? u : l * (u / d);
+}
+
 struct SpecFrameOut { double point_ceil, point_floor; };
 struct SpecScalars { double ceil_ma, ceil_maa, floor_ma, floor_maa; };
 struct SpecPeakScalars { double ceil_peak, floor_peak; };
@@ -558,6 +575,7 @@ __global__ __launch_bounds__(kDispThreads) void spec_display(const float *__rest
     const double pc = s_pc[0], pf = s_pc[1], fl = s_pc[2];
     const bool hold = f >= pk_from;
     const float inv_den = 1.0f / log1pf((float)(pc - pf));          // (pc + 0.25) - (pf - 0.75) = 1 + (pc - pf)
+    const float inv_F = 1.0f / (float)F;                             // F is a power of two: x * inv_F == x / F exactly
     for (int x0 = 2 * (blockIdx.x * kDispThreads + tid); x0 < F; x0 += 2 * kDispThreads * gridDim.x) {
     float y[2], yh[2] = {0.f, 0.f};
 #pragma unroll
@@ -566,19 +584,19 @@ __global__ __launch_bounds__(kDispThreads) void spec_display(const float *__rest
         double acc = 0.0, pacc = 0.0;
         if (x < F) acc = (x == 0) ? fl + (double)first_b[f]       // idx == 0 is replaced by fft_floor_maa (:546-556)
                                   : (double)pairsum[(int64_t)f * F + x];
-        y[u] = log1pf((float)(acc / 2.0 - pf)) * inv_den * sf;      // acc / 2 + 0.25 - (pf - 0.75) = 1 + (acc / 2 - pf)
+        y[u] = log1p_fast((float)(acc * 0.5 - pf)) * inv_den * sf;  // acc / 2 + 0.25 - (pf - 0.75) = 1 + (acc / 2 - pf)
         if (hold) {
             if (x < F) pacc = (x == 0) ? fl + (double)peak_b[f] : (double)peaksum[(int64_t)f * F + x];
-            yh[u] = log1pf((float)(pacc / 2.0 - pf)) * inv_den * sf;
+            yh[u] = log1p_fast((float)(pacc * 0.5 - pf)) * inv_den * sf;
         }
     }
     float *o = points + ((int64_t)f * F + x0) * 2;
-    if (x0 + 1 < F) *reinterpret_cast<float4 *>(o) = make_float4((float)x0 / (float)F, y[0], (float)(x0 + 1) / (float)F, y[1]);
-    else { o[0] = (float)x0 / (float)F; o[1] = y[0]; }
+    if (x0 + 1 < F) *reinterpret_cast<float4 *>(o) = make_float4((float)x0 * inv_F, y[0], (float)(x0 + 1) * inv_F, y[1]);
+    else { o[0] = (float)x0 * inv_F; o[1] = y[0]; }
     if (hold) {
         float *h = hold_points + ((int64_t)f * F + x0) * 2;
-        if (x0 + 1 < F) *reinterpret_cast<float4 *>(h) = make_float4((float)x0 / (float)F, yh[0], (float)(x0 + 1) / (float)F, yh[1]);
-        else { h[0] = (float)x0 / (float)F; h[1] = yh[0]; }
+        if (x0 + 1 < F) *reinterpret_cast<float4 *>(h) = make_float4((float)x0 * inv_F, yh[0], (float)(x0 + 1) * inv_F, yh[1]);
+        else { h[0] = (float)x0 * inv_F; h[1] = yh[0]; }
     }
     }
 }
