@@ -80,15 +80,19 @@ def algorithmic_bytes_per_sample(kernel, n_demods, m, fft_n):
 def measured_traffic_bytes(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/collect.sh: FETCH_SIZE and WRITE_SIZE in their
     own rocprofv3 runs of this same command; gfx950 reports half of a wide coalesced read stream, MI355X_MICROARCH.md "HBM",
-    so the read side is doubled).  None when no pass is on file for this kernel."""
-    path = os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")
+    so the read side is doubled), per IQ block of the launch.  None when no pass is on file for this kernel."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
     try:
-        t = json.load(open(path))
+        t = json.load(open(files[-1]))                      # the latest committed pass
     except Exception:
         return None
+    blocks = float(t.get("_meta", {}).get("blocks_per_launch", 64))
     for name, v in t.items():
         if name.split("<")[0] in (kernel, kernel + "_s") and "FETCH_SIZE_KiB_avg_per_launch" in v and "WRITE_SIZE_KiB_avg_per_launch" in v:
-            return (2.0 * v["FETCH_SIZE_KiB_avg_per_launch"] + v["WRITE_SIZE_KiB_avg_per_launch"]) * 1024.0
+            return (2.0 * v["FETCH_SIZE_KiB_avg_per_launch"] + v["WRITE_SIZE_KiB_avg_per_launch"]) * 1024.0 / blocks
     return None
 
 
@@ -221,8 +225,8 @@ def main():
         achieved = bps * units / (avg_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": (None if measured_traffic_bytes(dom) is None else measured_traffic_bytes(dom) * NB / 64.0),
-                           "traffic_unit": "bytes per launch (PMC pass at 64 blocks per launch, scaled to this launch size)",
+                           "traffic": (None if measured_traffic_bytes(dom) is None else measured_traffic_bytes(dom) * NB),
+                           "traffic_unit": "bytes per launch (committed PMC pass, per IQ block, times the blocks of this launch)",
                            "avg_launch_ms": avg_ms,
                            "algorithmic_bytes_per_launch": bps * units,
                            "whole_path": {"bytes_per_sample": 54.8, "achieved": 54.8 * value / world * 1e6 / 1e9,

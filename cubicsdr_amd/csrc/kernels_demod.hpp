@@ -937,15 +937,20 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
         const int m = au.m_x[s];
         const int64_t olo = lo[s + 1], ohi = hi[s + 1], ilo = lo[s];
         const int nout = (int)(ohi - olo);
+        float hs[kHbMaxM];                                       // the stage's taps, fetched once (wave-uniform)
+#pragma unroll
+        for (int j = 0; j < kHbMaxM; ++j) hs[j] = au.h_x[s][j];
+        const int qoff = (int)((olo >> 1) - ilo), par0 = (int)(olo & 1);
         for (int i = tid; i < nout; i += kModemThreads) {
-            const int64_t a = olo + i;
-            const int64_t q = a >> 1;
-            const int qi = (int)(q - ilo);
+            const int a = i + par0;                              // output index relative to the even index at or below olo
+            const int qi = qoff + (a >> 1);
             float v;
             if ((a & 1) == 0) v = src[qi - m];
             else {
                 v = 0.f;
-                for (int j = 0; j < m; ++j) v = fmaf(au.h_x[s][j], src[qi - j] + src[qi - (2 * m - 1) + j], v);
+#pragma unroll
+                for (int j = 0; j < kHbMaxM; ++j)
+                    if (j < m) v = fmaf(hs[j], src[qi - j] + src[qi - (2 * m - 1) + j], v);
             }
             dst[i] = v;
         }
@@ -964,11 +969,16 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
             const int nout = (int)(hi[e + 1] - olo);
             const float sc = (e == aS - 1) ? zeta : 1.0f;
             // y[k] = x[2k - 2m + 1] + sum_j h[j] (x[2k - 2j] + x[2k - 4m + 2 + 2j])
+            float hs[kHbMaxM];
+#pragma unroll
+            for (int j = 0; j < kHbMaxM; ++j) hs[j] = au.h_x[e][j];
+            const int xoff = (int)(2 * olo - ilo);
             for (int i = tid; i < nout; i += kModemThreads) {
-                const int64_t k = olo + i;
-                const float *x = in + (2 * k - ilo);
+                const float *x = in + (xoff + 2 * i);
                 float v = x[-2 * m + 1];
-                for (int j = 0; j < m; ++j) v = fmaf(au.h_x[e][j], x[-2 * j] + x[-4 * m + 2 + 2 * j], v);
+#pragma unroll
+                for (int j = 0; j < kHbMaxM; ++j)
+                    if (j < m) v = fmaf(hs[j], x[-2 * j] + x[-4 * m + 2 + 2 * j], v);
                 ping[i] = v * sc;
             }
             __syncthreads();

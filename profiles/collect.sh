@@ -12,11 +12,12 @@ OUT=/tmp/prof_$TAG
 DST=$(pwd)/gpurun_out/prof_$TAG
 mkdir -p $OUT $DST
 REPO=$(pwd)
-BENCH="python $REPO/bench.py --steps 40 --warmup 10 --cpu-seconds 0 --no-profile"
+NB=${2:-128}
+BENCH="python $REPO/bench.py --steps 40 --warmup 10 --cpu-seconds 0 --no-profile --blocks $NB"
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- $BENCH ) > $OUT/stats.log 2>&1
 ( cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o b -- $BENCH ) > $OUT/fetch.log 2>&1
 ( cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o b -- $BENCH ) > $OUT/write.log 2>&1
-python - "$OUT" "$DST" <<'PY'
+python - "$OUT" "$DST" "$NB" <<'PY'
 import csv, glob, json, sys, collections
 out, dst = sys.argv[1], sys.argv[2]
 for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
@@ -34,6 +35,7 @@ for name in ("fetch", "write"):
     for k, v in acc.items():
         traffic[k][name.upper() + "_SIZE_KiB_avg_per_launch"] = sum(v) / len(v)
         traffic[k]["launches_" + name] = len(v)
+traffic["_meta"] = {"blocks_per_launch": int(sys.argv[3]), "command": "bench.py --steps 40 --warmup 10 --cpu-seconds 0 --no-profile --blocks " + sys.argv[3]}
 json.dump(traffic, open(dst + "/pmc_traffic.json", "w"), indent=1, sort_keys=True)
 print(open(dst + "/kernel_stats.csv").read())
 print(json.dumps(traffic, indent=1, sort_keys=True))
