@@ -609,7 +609,8 @@ extern "C" void csdr_bank_destroy(csdr_bank *b) {
     delete b;
 }
 
-static int modem_check_rate(int modem, int bw) {   // Modem*::checkSampleRate (ModemAnalog.cpp:14-19, ModemUSB.cpp:29-37)
+static int modem_check_rate(int modem, int bw, int audio_rate) {   // Modem*::checkSampleRate (ModemAnalog.cpp:14-19, ModemUSB.cpp:29-37, ModemIQ.cpp:31-33)
+    if (modem == CSDR_MODEM_IQ) return audio_rate;
     if (bw < 500) bw = 500;                          // MIN_BANDWIDTH, Modem.h:13
     if ((modem == CSDR_MODEM_USB || modem == CSDR_MODEM_LSB) && (bw % 2)) bw += 1;
     return bw;
@@ -619,13 +620,13 @@ extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod
     if (!b || !prm || !post) return fail(CSDR_EINVAL, "null argument");
     if (slot < 0 || slot >= b->max_demods) return fail(CSDR_EINVAL, "slot out of range");
     if (!post->configured) return fail(CSDR_ESTATE, "post not configured");
-    if (prm->modem < CSDR_MODEM_NBFM || prm->modem > CSDR_MODEM_LSB) return fail(CSDR_EUNSUPPORTED, "modem %d", prm->modem);
+    if (prm->modem < CSDR_MODEM_NBFM || prm->modem > CSDR_MODEM_IQ) return fail(CSDR_EUNSUPPORTED, "modem %d", prm->modem);
     if (prm->bandwidth <= 0 || prm->audio_sample_rate <= 0) return fail(CSDR_EINVAL, "bad rates");
     SlotHost &s = b->slots[slot];
     if (int rc = b->ctx->sync_all()) return rc;
     s.configured = false;
     s.prm = *prm;
-    s.prm.bandwidth = modem_check_rate(prm->modem, prm->bandwidth);
+    s.prm.bandwidth = modem_check_rate(prm->modem, prm->bandwidth, prm->audio_sample_rate);
     s.chan_rate = csdr_post_channel_rate(post);
     const double iq_ratio = (double)s.prm.bandwidth / (double)s.chan_rate;        // DemodulatorWorkerThread.cpp:99-100
     if (iq_ratio > 1.0) return fail(CSDR_EUNSUPPORTED, "bandwidth %d above the channel rate %lld (interpolating IQ resampler)", s.prm.bandwidth, (long long)s.chan_rate);
@@ -653,7 +654,8 @@ extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod
     // capacities for one execute
     const int64_t max_bc = post->max_block_len / post->hop;
     const int64_t cap_iq = (int64_t)std::ceil((double)b->max_blocks * (double)max_bc * iq_ratio) + b->max_blocks + 64;
-    const int64_t cap_audio = (int64_t)std::ceil((double)cap_iq * au_ratio) + (int64_t)b->max_blocks * (2 << (s.au.interp ? s.au.S : 0)) + 64;
+    const int64_t cap_audio = s.prm.modem == CSDR_MODEM_IQ ? 2 * cap_iq + 64      // two floats per IQ sample, no audio resampler
+        : (int64_t)std::ceil((double)cap_iq * au_ratio) + (int64_t)b->max_blocks * (2 << (s.au.interp ? s.au.S : 0)) + 64;
     // one slab per slot
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -765,15 +767,16 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         // per-block plan
         BlockPlan *pl = plans_h + (size_t)si * (NB + 1);
         const int S = (int)s.iq.S, aS = (int)s.au.S;
+        const bool iq_modem = s.prm.modem == CSDR_MODEM_IQ;      // no audio resampler: 2 floats per resampled IQ sample
         const bool au_interp = s.au.interp;
-        const int ash = au_interp ? aS : 0;      // audio samples per arbitrary-stage output = 2^ash
+        const int ash = iq_modem ? 1 : (au_interp ? aS : 0);     // audio samples per arbitrary-stage output = 2^ash
         for (int bb = 0; bb <= NB; ++bb) {
             const int64_t K = ((int64_t)s.buf_idx + (int64_t)bb * Bc) >> S;
             const int64_t J = first_out(K, s.phase, s.iq.step);
             // audio msresamp_rrrf (ModemAnalog.cpp:88): interpolating = arbitrary stage first (input index J);
             // decimating = half-band /2 stages first: the arbitrary stage sees (abuf + J) >> aS chain outputs
             const int64_t Ka = au_interp ? J : (((int64_t)s.abuf + J) >> aS);
-            const int64_t Q = first_out(Ka, s.aphase, s.au.step);
+            const int64_t Q = iq_modem ? J : first_out(Ka, s.aphase, s.au.step);
             pl[bb].j0 = (int)J; pl[bb].q0 = (int)Q;
         }
         const int64_t Jtot = pl[NB].j0, Qtot = pl[NB].q0;
@@ -796,7 +799,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         s.phase = (uint32_t)((int64_t)s.phase + Jtot * (int64_t)s.iq.step - (Ktot << 24));
         s.buf_idx = (uint32_t)(((int64_t)s.buf_idx + (int64_t)NB * Bc) & ((1 << S) - 1));
         if (d.mixdir) s.theta += (uint32_t)((int64_t)NB * Bc) * s.dtheta;
-        {
+        if (!iq_modem) {
             const int64_t Ka_tot = au_interp ? Jtot : (((int64_t)s.abuf + Jtot) >> aS);
             s.aphase = (uint32_t)((int64_t)s.aphase + Qtot * (int64_t)s.au.step - (Ka_tot << 24));
             if (!au_interp) s.abuf = (uint32_t)(((int64_t)s.abuf + Jtot) & ((1 << aS) - 1));
@@ -807,7 +810,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         s.last_J = (int)Jtot; s.last_A = (int)(Qtot << ash);
         s.prev_J = (int)Jtot;
         warm_max = std::max(warm_max, s.warm); max_aS = std::max(max_aS, aS);
-        if (s.prm.modem != CSDR_MODEM_NBFM && s.prm.modem != CSDR_MODEM_FM) ag_list_h[n_ag++] = si;
+        if (s.prm.modem != CSDR_MODEM_NBFM && s.prm.modem != CSDR_MODEM_FM && s.prm.modem != CSDR_MODEM_IQ) ag_list_h[n_ag++] = si;
         slot_list_h[n_run++] = si;
     }
     b->n_run = n_run; b->last_nb = NB;

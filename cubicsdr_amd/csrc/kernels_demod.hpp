@@ -819,6 +819,24 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     const float *arms = arms_all + (size_t)au.arms_idx * kArms * kArmTaps;
     const bool autogain = !(cfg.modem == CSDR_MODEM_NBFM || cfg.modem == CSDR_MODEM_FM);
     const float2 *iq = cfg.iq + (size_t)dyn.hist_parity * ((size_t)kIqHist + cfg.cap_iq) + kIqHist;   // iq[j], j >= -kIqHist
+    if (cfg.modem == CSDR_MODEM_IQ) {
+        // ModemIQ::demodulate (ModemIQ.cpp:41-61): stereo frames (imag, real) of the resampled IQ, no filtering, no gain;
+        // level from the IQ magnitudes like the other non-signal-output modems (DemodulatorThread.cpp:156-162)
+        const int j0 = pl[b].j0, n_iq = pl[b + 1].j0 - j0;
+        float lpk = 0.f;
+        double lsum = 0.0;
+        float2 *ao = reinterpret_cast<float2 *>(cfg.audio) + j0;
+        for (int i = tid; i < n_iq; i += kModemThreads) {
+            const float2 x = iq[j0 + i];
+            ao[i] = make_float2(x.y, x.x);
+            lpk = fmaxf(lpk, fmaxf(fabsf(x.x), fabsf(x.y)));
+            lsum += sqrt((double)x.x * (double)x.x + (double)x.y * (double)x.y);
+        }
+        const float pk = block_max_float(lpk, s_redf);
+        const double sm = block_sum_double(lsum, s_red);
+        if (tid == 0) { cfg.bout[b].audio_peak = pk; cfg.bout[b].level_accum = sm; cfg.bout[b].level_count = n_iq; }
+        return;
+    }
     const float fm_ref = 1.0f / (2.0f * 3.14159265358979323846f * 0.5f);   // freqdem_create(kf = 0.5): 1 / (2 pi kf)
     const float *agc_in = cfg.agc + 4 * dyn.hist_parity;
     const float *dh_in = cfg.dh + (size_t)kDHist * dyn.hist_parity;

@@ -68,6 +68,7 @@ public:
         if (t == "NBFM") return 12500;
         if (t == "AM") return 6000;
         if (t == "USB" || t == "LSB") return 5400;
+        if (t == "I/Q") return 48000;                         // ModemIQ.cpp:35-37
         return 12500;
     }
     static int modemId(const std::string &t) {
@@ -76,6 +77,7 @@ public:
         if (t == "AM") return CSDR_MODEM_AM;
         if (t == "USB") return CSDR_MODEM_USB;
         if (t == "LSB") return CSDR_MODEM_LSB;
+        if (t == "I/Q") return CSDR_MODEM_IQ;
         return -1;
     }
 
@@ -216,7 +218,7 @@ private:
         csdr_must(csdr_bank_fetch_results(bank_, d.slot(), &r, 1, &nb), "csdr_bank_fetch_results");
         if (nb != 1 || r.skipped || r.n_iq == 0) return;
         AudioThreadInputPtr ati = d.outputBuffers_.getBuffer();
-        ati->sampleRate = d.getAudioSampleRate(); ati->inputRate = d.getBandwidth(); ati->channels = 1; ati->frequency = d.getFrequency();
+        ati->sampleRate = d.getAudioSampleRate(); ati->inputRate = d.getBandwidth(); ati->channels = d.getDemodulatorType() == "I/Q" ? 2 : 1; ati->frequency = d.getFrequency();
         ati->data.resize(r.n_audio);
         int got = 0;
         if (r.n_audio) csdr_must(csdr_bank_fetch_audio(bank_, d.slot(), ati->data.data(), r.n_audio, &got), "csdr_bank_fetch_audio");

@@ -115,6 +115,8 @@ int  csdr_post_read_channel(csdr_post *post, int ch, float *host_out, int cap_sa
 #define CSDR_MODEM_AM   2   /* ModemAM.cpp:29-50    |x| -> 51-tap DC notch, auto-gain */
 #define CSDR_MODEM_USB  3   /* ModemUSB.cpp:43-64   fs/4 shift, 6th-order Butterworth, Hilbert, upper sideband */
 #define CSDR_MODEM_LSB  4   /* ModemLSB.cpp         mirror of USB, lower sideband */
+#define CSDR_MODEM_IQ   5   /* ModemIQ.cpp:41-61    stereo pass-through of the resampled IQ (L = imag, R = real); the
+                             * bandwidth is forced to the audio rate (checkSampleRate :31-33); 2 floats per IQ sample */
 
 typedef struct csdr_demod_params {
     int32_t modem;             /* CSDR_MODEM_* (DemodulatorInstance::setDemodulatorType) */

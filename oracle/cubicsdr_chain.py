@@ -102,6 +102,8 @@ class RefDemod:
         bw = max(int(bandwidth), 500)                                    # checkSampleRate, ModemAnalog.cpp:14-19
         if modem in ("USB", "LSB") and bw % 2:
             bw += 1                                                      # ModemUSB.cpp:29-37
+        if modem == "I/Q":
+            bw = int(audio_rate)                                         # ModemIQ.cpp:31-33
         self.bandwidth = bw
         self.chan_rate = int(chan_rate)
         self.nco = L.nco_crcf_create(A.LIQUID_VCO)                       # DemodulatorPreThread.cpp:22
@@ -114,6 +116,8 @@ class RefDemod:
         self.use_signal_output = modem in ("AM", "USB", "LSB")
         if modem in ("NBFM", "FM"):
             self.fm = L.freqdem_create(0.5)                              # ModemNBFM.cpp:7
+        elif modem == "I/Q":
+            pass                                                         # ModemIQ::buildKit: no DSP objects
         elif modem == "AM":
             self.dcb = L.firfilt_rrrf_create_dc_blocker(25, 30.0)        # ModemAM.cpp:9
         else:
@@ -153,6 +157,12 @@ class RefDemod:
         if n == 0:
             return None
         iq = A.as_c64(iq)
+        if self.modem == "I/Q":                                          # ModemIQ.cpp:41-61: stereo (imag, real), 2 channels
+            audio = np.empty(2 * n, np.float32)
+            audio[0::2] = iq.imag
+            audio[1::2] = iq.real
+            accum = float(np.sum(np.sqrt(iq.real.astype(np.float64) ** 2 + iq.imag.astype(np.float64) ** 2)))
+            return dict(audio=audio, level_accum=accum, level_count=n, peak=float(np.max(np.abs(audio))), demod=audio.copy(), channels=2)
         d = np.empty(n, np.float32)
         if self.modem in ("NBFM", "FM"):
             L.freqdem_demodulate_block(self.fm, _cptr(iq), n, _cptr(d))                  # ModemNBFM.cpp:36

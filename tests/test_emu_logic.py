@@ -85,6 +85,10 @@ def test_emu_mixed_modems(ctx):
     G.test_mixed_modems_streaming(ctx)
 
 
+def test_emu_iq_passthrough(ctx):
+    G.test_iq_passthrough_modem(ctx)
+
+
 @full
 def test_emu_wide_fm(ctx):
     G.test_wide_fm_audio_decimation(ctx)

@@ -147,7 +147,7 @@ def _run_demods(ctx, fs, M, block, kinds, n_blocks, batch, bw=None, seed=3, over
     from oracle.cubicsdr_chain import RefDemod, RefSDRPost
     center = 100000000
     freqs = demod_frequencies(center, fs, len(kinds))
-    default_bw = {"NBFM": 12500, "FM": 200000, "AM": 6000, "USB": 5400, "LSB": 5400}
+    default_bw = {"NBFM": 12500, "FM": 200000, "AM": 6000, "USB": 5400, "LSB": 5400, "I/Q": 48000}
     bws = [bw[k] if bw else default_bw[k] for k in kinds] if not isinstance(bw, list) else bw
     demods = list(zip(kinds, freqs))
     x = synth_iq(n_blocks * block, fs, center, demods, seed=seed)
@@ -244,6 +244,14 @@ def test_c2_shape_64_nbfm(ctx):
     """BASELINE config 2 shape (64x NBFM, 10 MS/s, M = 20) on 2 blocks; oracle checks 8 of the demods."""
     got, want = _run_demods(ctx, 10000000, 20, 166680, ["NBFM"] * 8, 2, 2)
     print(_compare(got, want, "c2"))
+
+
+def test_iq_passthrough_modem(ctx):
+    """ModemIQ: the bandwidth is forced to the audio rate, the "audio" is the resampled IQ as stereo frames (imag, real);
+    next to an NBFM demodulator on the same channelizer, 6 blocks in batches of 3."""
+    got, want = _run_demods(ctx, 2400000, 4, 40000, ["I/Q", "NBFM", "I/Q"], 6, 3, seed=29)
+    print(_compare(got, want, "iq"))
+    assert got[0][0]["n_audio"] == 2 * got[0][0]["n_iq"]
 
 
 def test_demods_behind_oversampled_channelizer(ctx):

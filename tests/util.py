@@ -39,5 +39,7 @@ def synth_iq(n, fs, center, demods, seed=0xC0B1C5D2, t0=0, noise=0.05, dc=(0.01,
             x += amp * np.exp(2j * np.pi * (df + 1000.0) * t)
         elif kind == "LSB":
             x += amp * np.exp(2j * np.pi * (df - 1000.0) * t)
+        elif kind == "I/Q":
+            x += amp * np.exp(2j * np.pi * (df + 3000.0) * t)
     x += dc[0] + 1j * dc[1]
     return x.astype(np.complex64)
