@@ -186,6 +186,7 @@ struct csdr_post {
     DevBuf<d2> dc_state, tile_end;           // dc_state[2]: ping-pong carried state
     int hist_parity = 0, dc_parity = 0;
     double dc_c = 0.0;                       // feedback coefficient of the DC blocker recurrence
+    bool raw = false;                        // internal (zoomed spectrum view): SINGLE mode hands the input on unfiltered
 };
 
 static void post_update_channels(csdr_post *p) {   // SDRPostThread::updateChannels, SDRPostThread.cpp:116-124
@@ -405,7 +406,8 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
     p->n_consumed[k] = 0;
     float2 *out = post_buf(p, k);
     int rc = CSDR_OK;
-    if (p->mode == CSDR_POST_SINGLE) rc = run_dc_blocker(p, x, out, n, false, 0);       // runSingleCH :284
+    if (p->mode == CSDR_POST_SINGLE && p->raw) CSDR_HIP_TRY(hipMemcpyAsync(out, x, (size_t)n * sizeof(float2), hipMemcpyDeviceToDevice, st));
+    else if (p->mode == CSDR_POST_SINGLE) rc = run_dc_blocker(p, x, out, n, false, 0);       // runSingleCH :284
     else {
         const int M = p->M;
         if (p->active_dirty) {
@@ -609,18 +611,24 @@ extern "C" void csdr_bank_destroy(csdr_bank *b) {
     delete b;
 }
 
+// internal: NCO + msresamp only, no modem / audio stage (the zoomed spectrum view's shift + resample, SpectrumVisualProcessor.cpp:306-379)
+#define CSDR_MODEM_FRONTEND_ONLY 6
 static int modem_check_rate(int modem, int bw, int audio_rate) {   // Modem*::checkSampleRate (ModemAnalog.cpp:14-19, ModemUSB.cpp:29-37, ModemIQ.cpp:31-33)
-    if (modem == CSDR_MODEM_IQ) return audio_rate;
+    if (modem == CSDR_MODEM_IQ || modem == CSDR_MODEM_FRONTEND_ONLY) return audio_rate;
     if (bw < 500) bw = 500;                          // MIN_BANDWIDTH, Modem.h:13
     if ((modem == CSDR_MODEM_USB || modem == CSDR_MODEM_LSB) && (bw % 2)) bw += 1;
     return bw;
 }
 
+static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *prm, const csdr_post *post);
 extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *prm, const csdr_post *post) {
+    if (prm && (prm->modem < CSDR_MODEM_NBFM || prm->modem > CSDR_MODEM_IQ)) return fail(CSDR_EUNSUPPORTED, "modem %d", prm->modem);
+    return bank_configure_slot(b, slot, prm, post);
+}
+static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *prm, const csdr_post *post) {
     if (!b || !prm || !post) return fail(CSDR_EINVAL, "null argument");
     if (slot < 0 || slot >= b->max_demods) return fail(CSDR_EINVAL, "slot out of range");
     if (!post->configured) return fail(CSDR_ESTATE, "post not configured");
-    if (prm->modem < CSDR_MODEM_NBFM || prm->modem > CSDR_MODEM_IQ) return fail(CSDR_EUNSUPPORTED, "modem %d", prm->modem);
     if (prm->bandwidth <= 0 || prm->audio_sample_rate <= 0) return fail(CSDR_EINVAL, "bad rates");
     SlotHost &s = b->slots[slot];
     if (int rc = b->ctx->sync_all()) return rc;
@@ -654,7 +662,7 @@ extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod
     // capacities for one execute
     const int64_t max_bc = post->max_block_len / post->hop;
     const int64_t cap_iq = (int64_t)std::ceil((double)b->max_blocks * (double)max_bc * iq_ratio) + b->max_blocks + 64;
-    const int64_t cap_audio = s.prm.modem == CSDR_MODEM_IQ ? 2 * cap_iq + 64      // two floats per IQ sample, no audio resampler
+    const int64_t cap_audio = s.prm.modem == CSDR_MODEM_FRONTEND_ONLY ? 64 : s.prm.modem == CSDR_MODEM_IQ ? 2 * cap_iq + 64      // two floats per IQ sample, no audio resampler
         : (int64_t)std::ceil((double)cap_iq * au_ratio) + (int64_t)b->max_blocks * (2 << (s.au.interp ? s.au.S : 0)) + 64;
     // one slab per slot
     size_t off = 0;
@@ -767,7 +775,8 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         // per-block plan
         BlockPlan *pl = plans_h + (size_t)si * (NB + 1);
         const int S = (int)s.iq.S, aS = (int)s.au.S;
-        const bool iq_modem = s.prm.modem == CSDR_MODEM_IQ;      // no audio resampler: 2 floats per resampled IQ sample
+        const bool fe_only = s.prm.modem == CSDR_MODEM_FRONTEND_ONLY;
+        const bool iq_modem = s.prm.modem == CSDR_MODEM_IQ || fe_only;      // no audio resampler: 2 floats per resampled IQ sample
         const bool au_interp = s.au.interp;
         const int ash = iq_modem ? 1 : (au_interp ? aS : 0);     // audio samples per arbitrary-stage output = 2^ash
         for (int bb = 0; bb <= NB; ++bb) {
@@ -780,15 +789,16 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
             pl[bb].j0 = (int)J; pl[bb].q0 = (int)Q;
         }
         const int64_t Jtot = pl[NB].j0, Qtot = pl[NB].q0;
-        if (Jtot > s.cfg.cap_iq - 8 || (Qtot << ash) > s.cfg.cap_audio - 8) return fail(CSDR_ERANGE, "slot %d output exceeds its buffers", si);
+        if (Jtot > s.cfg.cap_iq - 8 || (!fe_only && (Qtot << ash) > s.cfg.cap_audio - 8)) return fail(CSDR_ERANGE, "slot %d output exceeds its buffers", si);
         for (int bb = 0; bb < NB; ++bb) {
             csdr_block_result &r = s.results[bb];
             memset(&r, 0, sizeof r);
             r.n_iq = pl[bb + 1].j0 - pl[bb].j0;
             r.n_audio = (int)(((int64_t)(pl[bb + 1].q0 - pl[bb].q0)) << ash);
             r.audio_offset = (int)(((int64_t)pl[bb].q0) << ash);
-            if (r.n_iq > kModemMaxBlockIq || r.n_audio > kAudioMaxOut) return fail(CSDR_EUNSUPPORTED, "slot %d: %d IQ / %d audio samples per block exceed the per-workgroup limits", si, r.n_iq, r.n_audio);
-            max_n_iq = std::max(max_n_iq, r.n_iq); max_n_audio = std::max(max_n_audio, r.n_audio);
+            if (fe_only) { r.n_audio = 0; r.audio_offset = 0; }
+            else if (r.n_iq > kModemMaxBlockIq || r.n_audio > kAudioMaxOut) return fail(CSDR_EUNSUPPORTED, "slot %d: %d IQ / %d audio samples per block exceed the per-workgroup limits", si, r.n_iq, r.n_audio);
+            if (!fe_only) { max_n_iq = std::max(max_n_iq, r.n_iq); max_n_audio = std::max(max_n_audio, r.n_audio); }
             const int64_t Kb = ((int64_t)s.buf_idx + (int64_t)(bb + 1) * Bc) >> S;
             r.buffer_index = (uint32_t)(((int64_t)s.buf_idx + (int64_t)(bb + 1) * Bc) & ((1 << S) - 1));
             r.resamp_phase = (uint32_t)((int64_t)s.phase + (int64_t)pl[bb + 1].j0 * s.iq.step - (Kb << 24));
@@ -807,10 +817,10 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         s.ssb_theta += (uint32_t)Jtot * (1u << 30);
         s.last_parity = s.hist_parity;
         s.hist_parity ^= 1;
-        s.last_J = (int)Jtot; s.last_A = (int)(Qtot << ash);
+        s.last_J = (int)Jtot; s.last_A = fe_only ? 0 : (int)(Qtot << ash);
         s.prev_J = (int)Jtot;
         warm_max = std::max(warm_max, s.warm); max_aS = std::max(max_aS, aS);
-        if (s.prm.modem != CSDR_MODEM_NBFM && s.prm.modem != CSDR_MODEM_FM && s.prm.modem != CSDR_MODEM_IQ) ag_list_h[n_ag++] = si;
+        if (s.prm.modem != CSDR_MODEM_NBFM && s.prm.modem != CSDR_MODEM_FM && s.prm.modem != CSDR_MODEM_IQ && !fe_only) ag_list_h[n_ag++] = si;
         slot_list_h[n_run++] = si;
     }
     b->n_run = n_run; b->last_nb = NB;
@@ -832,6 +842,9 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
             grp_n[k] = pos - grp_off[k];
         }
     }
+    // the audio stage runs the slots that have one: compact the head of the list (the front-end groups above are copies)
+    int n_audio_run = 0;
+    for (int i = 0; i < n_run; ++i) if (b->slots[slot_list_h[i]].prm.modem != CSDR_MODEM_FRONTEND_ONLY) slot_list_h[n_audio_run++] = slot_list_h[i];
     // lane FE: the channelizer output of this batch must be complete; the tables and the resampled-IQ buffers of this
     // parity were last read by the audio kernels two batches ago
     const int pk = post->cur;
@@ -878,7 +891,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
             CSDR_HIP_TRY(hipFuncSetAttribute(fn[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)want[k]));
             b->lds_attr[k] = want[k];
         }
-    const dim3 grid(n_run, NB);
+    const dim3 grid(std::max(1, n_audio_run), NB);
     const float2 *chan_out = post_buf(post, pk);
     const int *grp_d = lists_d + 2 * (size_t)b->max_demods;
     if (grp_n[0] > 0)
@@ -908,8 +921,9 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     if (n_ag > 0)     // freqdem modems need no block-wide pre-pass: only the auto-gain modems run the modem kernel
         CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, demod_modem, dim3(n_ag, NB), dim3(kModemThreads), modem_lds, b->cfgs.p, dyns_d, lists_d + b->max_demods,
                     plans_d, NB, cap_stream, b->mconsts.p, c->sintab.p);
-    CSDR_LAUNCH(c, LANE_AUDIO, KID_AUDIO, demod_audio_interp, grid, dim3(kModemThreads), audio_lds, b->cfgs.p, dyns_d, lists_d, plans_d, NB,
-                cap_out, cap_win, b->arms.p);
+    if (n_audio_run > 0)
+        CSDR_LAUNCH(c, LANE_AUDIO, KID_AUDIO, demod_audio_interp, grid, dim3(kModemThreads), audio_lds, b->cfgs.p, dyns_d, lists_d, plans_d, NB,
+                    cap_out, cap_win, b->arms.p);
     CSDR_HIP_TRY(hipGetLastError());
     if (int rc = c->signal(b->ev_audio_done[bpar], LANE_AUDIO, LANE_FE)) return rc;
     b->audio_pending[bpar] = true;
@@ -1007,6 +1021,19 @@ struct csdr_spec {
     bool hide_dc = false;
     int64_t center_freq = 0, input_freq = 0;
     long bandwidth = 0;
+    // zoomed view (setView :64-72; process :283-386, :454-492, :532-560)
+    bool is_view = false, last_view = false, have_resampler = false;
+    int64_t input_rate = 0;
+    long last_bandwidth = 0, last_input_bandwidth = 0, shift_frequency = 0, resample_bw = 0;   // ctor :11-15, :30
+    int desired_input_size = 0;
+    csdr_post *vpost = nullptr;              // raw single-channel hand-over of the input block
+    csdr_bank *vbank = nullptr;              // one front-end-only slot: NCO shift + msresamp_crcf
+    int vpost_cap = 0;
+    DevBuf<double> ma2, maa2;                // target of an averager remap (swapped with ma / maa afterwards)
+    DevBuf<int2> vmap;                       // (first bin, bins) per display point for the current visualRatio
+    long vmap_bw = -1, vmap_rbw = -1;
+    DevBuf<float2> peakf;
+    bool view_frame = false;                 // the frames being post-processed belong to the zoomed view
 };
 
 extern "C" int csdr_spec_create(csdr_ctx *ctx, csdr_spec **out) {
@@ -1032,6 +1059,9 @@ extern "C" void csdr_spec_destroy(csdr_spec *s) {
     s->ma.release(); s->maa.release(); s->fo.release(); s->scal.release();
     s->last[0].release(); s->last[1].release(); s->lines.release();
     s->peak.release(); s->maaf.release(); s->peaksum.release(); s->peak_b.release(); s->hold_points.release(); s->pk.release(); s->pfo.release();
+    s->ma2.release(); s->maa2.release(); s->vmap.release(); s->peakf.release();
+    if (s->vbank) csdr_bank_destroy(s->vbank);
+    if (s->vpost) csdr_post_destroy(s->vpost);
     delete s;
 }
 
@@ -1090,6 +1120,7 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     s->last_cur = 0; s->last_primed = false;                         // lastDataSize = 0 (:166)
     s->peak.release(); s->maaf.release(); s->peaksum.release(); s->peak_b.release(); s->hold_points.release();   // sized per fft size
     if (s->peak_hold) s->peak_reset = 1;                              // fft_result_peak is rebuilt (:261): nothing held until a reset has run
+    s->ma2.release(); s->maa2.release(); s->vmap.release(); s->peakf.release(); s->vmap_bw = s->vmap_rbw = -1;
     s->ready = true;
     return CSDR_OK;
 }
@@ -1107,6 +1138,13 @@ extern "C" int csdr_spec_set_hide_dc(csdr_spec *s, int enabled) { if (!s) return
 extern "C" int csdr_spec_set_center_frequency(csdr_spec *s, int64_t f) { if (!s) return fail(CSDR_EINVAL, "null"); s->center_freq = f; return CSDR_OK; }
 extern "C" int csdr_spec_set_bandwidth(csdr_spec *s, int64_t bw) { if (!s) return fail(CSDR_EINVAL, "null"); s->bandwidth = (long)bw; return CSDR_OK; }
 extern "C" int csdr_spec_set_input_frequency(csdr_spec *s, int64_t f) { if (!s) return fail(CSDR_EINVAL, "null"); s->input_freq = f; return CSDR_OK; }
+extern "C" int csdr_spec_set_input_rate(csdr_spec *s, int64_t rate) { if (!s) return fail(CSDR_EINVAL, "null"); s->input_rate = rate; return CSDR_OK; }
+extern "C" int csdr_spec_set_view(csdr_spec *s, int is_view) { if (!s) return fail(CSDR_EINVAL, "null"); s->is_view = is_view != 0; return CSDR_OK; }
+extern "C" int csdr_spec_get_view(const csdr_spec *s) { return s && s->is_view ? 1 : 0; }
+extern "C" int csdr_spec_desired_input_size(const csdr_spec *s) {        // getDesiredInputSize :133-137
+    if (!s || !s->ready) return 0;
+    return s->is_view && s->desired_input_size ? s->desired_input_size : s->g.N;
+}
 
 template <int COLS>
 static void launch_radix(csdr_ctx *c, int R, const FrameSrc &fs, int L, unsigned tw_scale, int nseq, const float2 *hi, const float2 *lo, float2 *dst) {
@@ -1151,15 +1189,16 @@ static int spec_post_range(csdr_spec *s, const float *mag, int f0, int cnt, int 
     csdr_ctx *c = s->ctx;
     const SpecGeom &g = s->g;
     const size_t F = (size_t)g.F;
-    const bool hold = pk_from < cnt;
+    const bool hold = pk_from < cnt, view = s->view_frame;
+    const bool bins = hold || view;                                  // per-bin averaged values are kept (maaf)
     CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_average, dim3(s->n_avg_tiles), dim3(kAvgThreads), kAvgLds, mag + (size_t)f0 * g.N, cnt, g, (double)s->avg_rate,
                 s->ma.p, s->maa.p, s->pairsum.p + f0 * F, s->first_b.p + f0, s->ext_w.p + (size_t)f0 * s->n_avg_tiles,
-                hold ? s->maaf.p + f0 * F : (float2 *)nullptr, hold ? pk_from : cnt);
+                bins ? s->maaf.p + f0 * F : (float2 *)nullptr, view ? 0 : (hold ? pk_from : cnt));
     CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_extrema, dim3(cnt), dim3(256), 64, s->ext_w.p + (size_t)f0 * s->n_avg_tiles, s->n_avg_tiles, s->ext.p + f0);
     const SpecScalars *st_in = s->scal.p + s->scal_parity;
     if (hold) {
         CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_MISC, spec_peak_track, dim3((g.F + 255) / 256), dim3(256), 0, s->maaf.p + f0 * F, cnt, pk_from, g.F, s->peak.p,
-                    s->peaksum.p + f0 * F, s->peak_b.p + f0);
+                    s->peaksum.p + f0 * F, s->peak_b.p + f0, view ? s->peakf.p + f0 * F : (float2 *)nullptr);
         CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_MISC, spec_peak_trackers, dim3(1), dim3(64), 0, s->ext.p + f0, cnt, pk_from, st_in, s->pk.p, s->pfo.p + f0);
     }
     // display: column blocks per frame sized so that the grid is about one round of resident workgroups
@@ -1168,7 +1207,9 @@ static int spec_post_range(csdr_spec *s, const float *mag, int f0, int cnt, int 
                 s->pairsum.p + f0 * F, s->first_b.p + f0, s->ext.p + f0, cnt, g.F, s->scale, st_in, s->scal.p + (s->scal_parity ^ 1), s->fo.p + f0,
                 s->points.p + f0 * 2 * F, hold ? pk_from : cnt, hold ? s->pfo.p + f0 : (const SpecFrameOut *)nullptr,
                 hold ? s->peaksum.p + f0 * F : (const float *)nullptr, hold ? s->peak_b.p + f0 : (const float *)nullptr,
-                hold ? s->hold_points.p + f0 * 2 * F : (float *)nullptr);
+                hold ? s->hold_points.p + f0 * 2 * F : (float *)nullptr,
+                view ? s->vmap.p : (const int2 *)nullptr, view ? s->maaf.p + f0 * F : (const float2 *)nullptr,
+                view && hold ? s->peakf.p + f0 * F : (const float2 *)nullptr);
     s->scal_parity ^= 1;
     CSDR_HIP_TRY(hipGetLastError());
     return CSDR_OK;
@@ -1216,11 +1257,230 @@ static int spec_post_frames(csdr_spec *s, const float *mag, int nf, int n_inputs
     return CSDR_OK;
 }
 
+// ---- inputs shorter than the transform (:399-421).  `nl` inputs of `len` < N samples each at x (device memory).
+// The very first one only primes fftLastData (zero padded, :406-412); every later one is appended to the previous FFT input
+// shifted left by its length (:413-419).  On return x / nl describe the inputs that make frames and fs reads them.
+static int spec_lines_begin(csdr_spec *s, const float2 *&x, int len, int &nl, FrameSrc &fs) {
+    hipStream_t st = s->ctx->lanes[LANE_FFT];
+    const int N = s->g.N;
+    for (int k = 0; k < 2; ++k) if (int rc = s->last[k].reserve((size_t)N)) return rc;
+    if (!s->last_primed && nl > 0) {
+        float2 *L = s->last[s->last_cur].p;
+        CSDR_HIP_TRY(hipMemsetAsync(L + len, 0, (size_t)(N - len) * sizeof(float2), st));
+        if (len) CSDR_HIP_TRY(hipMemcpyAsync(L, x, (size_t)len * sizeof(float2), hipMemcpyDeviceToDevice, st));
+        s->last_primed = true;
+        x += len; --nl;
+    }
+    if (nl > s->max_frames) return fail(CSDR_ERANGE, "%d frames exceed max_frames %d", nl, s->max_frames);
+    if (nl > 0) {
+        // V = last ++ lines; frame j = V[(j + 1) len, (j + 1) len + N)
+        const float2 *L = s->last[s->last_cur].p;
+        if (2 * len >= N) {          // only frame 0 straddles the two buffers: read in place
+            fs.first = L + len; fs.split = N - len; fs.first2 = x;
+            fs.rest = x + (2 * len - N); fs.stride = len;
+        } else {                     // several frames straddle: make the tail of `last` and the lines contiguous
+            const size_t need = (size_t)(N - len) + (size_t)nl * len;
+            if (int rc = s->lines.reserve(need)) return rc;
+            CSDR_HIP_TRY(hipMemcpyAsync(s->lines.p, L + len, (size_t)(N - len) * sizeof(float2), hipMemcpyDeviceToDevice, st));
+            if (len) CSDR_HIP_TRY(hipMemcpyAsync(s->lines.p + (N - len), x, (size_t)nl * len * sizeof(float2), hipMemcpyDeviceToDevice, st));
+            fs.first = s->lines.p; fs.rest = s->lines.p + len; fs.stride = len;
+        }
+    }
+    return CSDR_OK;
+}
+// fftLastData = the last FFT input (:417) = V[nl len, nl len + N), written to the other copy (lane FFT: behind the kernels
+// that read the current one)
+static int spec_lines_end(csdr_spec *s, const float2 *x, int len, int nl) {
+    if (nl <= 0) return CSDR_OK;
+    hipStream_t st = s->ctx->lanes[LANE_FFT];
+    const int N = s->g.N;
+    const float2 *L = s->last[s->last_cur].p;
+    float2 *Ln = s->last[s->last_cur ^ 1].p;
+    const int64_t from_x = (int64_t)nl * len;                    // samples of the inputs inside the new fftLastData (if < N)
+    if (from_x >= N) {
+        CSDR_HIP_TRY(hipMemcpyAsync(Ln, x + (from_x - N), (size_t)N * sizeof(float2), hipMemcpyDeviceToDevice, st));
+    } else {
+        CSDR_HIP_TRY(hipMemcpyAsync(Ln, L + from_x, (size_t)(N - from_x) * sizeof(float2), hipMemcpyDeviceToDevice, st));
+        if (from_x) CSDR_HIP_TRY(hipMemcpyAsync(Ln + (N - from_x), x, (size_t)from_x * sizeof(float2), hipMemcpyDeviceToDevice, st));
+    }
+    s->last_cur ^= 1;
+    return CSDR_OK;
+}
+
+// FFT of nf frames on lane FFT, then `post(mag)` on lane AVG
+template <typename PostFn>
+static int spec_fft_then(csdr_spec *s, const FrameSrc &fs, int nf, PostFn post) {
+    csdr_ctx *c = s->ctx;
+    // lane FFT fills magnitude copy `mp`; its previous reader was the averaging kernel two batches ago
+    const int mp = c->same(LANE_FFT, LANE_AVG) ? 0 : (int)(s->seq & 1);
+    float *mag = s->mag.p + (size_t)mp * s->max_frames * s->g.N;
+    if (s->avg_pending[mp]) if (int rc = c->wait(s->ev_avg_done[mp], LANE_AVG, LANE_FFT)) return rc;
+    if (int rc = spec_run_fft(s, fs, nf, mag, nullptr)) return rc;
+    if (int rc = c->signal(s->ev_fft_done[mp], LANE_FFT, LANE_AVG)) return rc;
+    // lane AVG: averaging, extrema, trackers + display points
+    if (int rc = c->wait(s->ev_fft_done[mp], LANE_FFT, LANE_AVG)) return rc;
+    if (int rc = post(mag)) return rc;
+    if (int rc = c->signal(s->ev_avg_done[mp], LANE_AVG, LANE_FFT)) return rc;
+    s->avg_pending[mp] = true;
+    s->seq++;
+    return CSDR_OK;
+}
+
+// ---- zoomed view: one process() input (:283-386).  The frequency shift and the msresamp run on a private front-end-only
+// demodulator slot (the same NCO + msresamp_crcf kernels the demodulators use); the frame rule, FFT, averaging and display
+// follow with the view's bin walk.
+static int spec_process_view(csdr_spec *s, const float *iq, int iq_is_dev, int block_len) {
+    csdr_ctx *c = s->ctx;
+    const int N = s->g.N, F = s->g.F;
+    const int64_t rate = s->input_rate;
+    s->nf_last = 0;
+    s->hold_valid.clear();
+    // head of process() (:247, :264-273): doPeak is taken before the countdown moves; a reset uses the trackers as they stand
+    const bool do_peak = s->peak_hold && s->peak_reset == 0;
+    if (int rc = s->peak.reserve((size_t)2 * F)) return rc;
+    if (int rc = s->pk.reserve(1)) return rc;
+    if (s->peak_reset != 0 && --s->peak_reset == 0) {
+        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_MISC, spec_peak_reset, dim3(std::max(1, std::min(256, (2 * F + 255) / 256))), dim3(256), 0,
+                    s->scal.p + s->scal_parity, s->peak.p, 2 * F, s->pk.p);
+        CSDR_HIP_TRY(hipGetLastError());
+    }
+    if (!rate) { s->last_view = true; return CSDR_OK; }                        // :286-289
+    // the previous view frame is complete before its buffers are reused (display-rate path: a host wait is affordable)
+    CSDR_HIP_TRY(hipStreamSynchronize(c->lanes[LANE_AVG]));
+    CSDR_HIP_TRY(hipStreamSynchronize(c->lanes[LANE_FFT]));
+    long resampleBw = (long)rate;
+    while (resampleBw / 2 >= (long)s->bandwidth && resampleBw / 2 > 0) resampleBw /= 2;      // SPECTRUM_VZM, :291-293
+    s->resample_bw = resampleBw;
+    const double ratio = (double)resampleBw / (double)rate;                     // :295
+    size_t desired = (size_t)((double)N / ratio);                               // :297
+    s->desired_input_size = (int)desired;                                       // :299
+    if ((size_t)block_len < desired) desired = (size_t)block_len;               // :301-304
+    bool new_resampler = false;
+    long bw_diff = 0;
+    const bool mix = s->center_freq != s->input_freq;                           // :306
+    if (int rc = s->ma2.reserve((size_t)2 * F)) return rc;
+    if (int rc = s->maa2.reserve((size_t)2 * F)) return rc;
+    auto remap = [&](int mode, int n) -> int {
+        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_MISC, spec_avg_remap, dim3(std::max(1, std::min(512, (N + 255) / 256))), dim3(256), 0,
+                    s->ma.p, s->maa.p, s->ma2.p, s->maa2.p, N, mode, n);
+        CSDR_HIP_TRY(hipGetLastError());
+        std::swap(s->ma.p, s->ma2.p); std::swap(s->maa.p, s->maa2.p);
+        return CSDR_OK;
+    };
+    if (mix) {
+        if ((long)(s->center_freq - s->input_freq) != s->shift_frequency || s->last_input_bandwidth != (long)rate) {     // :307
+            if (std::llabs(s->input_freq - s->center_freq) < rate / 2) {        // :308 (the application rate is the input rate)
+                const long last_shift = s->shift_frequency;
+                s->shift_frequency = (long)(s->center_freq - s->input_freq);    // the NCO frequency follows inside the slot (:311)
+                const long freq_diff = s->shift_frequency - last_shift;
+                if (s->last_bandwidth != 0) {                                   // the averagers follow the retune (:316-331)
+                    const double bin_per_hz = double(s->last_bandwidth) / double(N);
+                    const unsigned num_shift = (unsigned)std::floor(double(std::labs(freq_diff)) / bin_per_hz);
+                    if (num_shift < (unsigned)N / 2 && num_shift) if (int rc = remap(freq_diff > 0 ? 0 : 1, (int)num_shift)) return rc;
+                }
+            }
+            s->peak_reset = 30;                                                 // PEAK_RESET_COUNT :335
+        }
+    }
+    // (re)build the resampler (:354-368)
+    if (!s->vpost) { if (int rc = csdr_post_create(c, &s->vpost)) return rc; }
+    if (!s->vbank) { if (int rc = csdr_bank_create(c, 1, 1, &s->vbank)) return rc; }
+    if (!s->have_resampler || resampleBw != s->last_bandwidth || s->last_input_bandwidth != (long)rate) {
+        uint32_t theta = 0;
+        if (s->have_resampler) theta = s->vbank->slots[0].theta;                // freqShifter lives on across resamplers
+        const int cap = std::max(std::max(s->vpost_cap, (int)((double)N / ratio) + 16), block_len);
+        if (int rc = csdr_post_configure(s->vpost, rate, 1, CSDR_POST_SINGLE, cap, 1)) return rc;
+        s->vpost->raw = true;
+        s->vpost_cap = cap;
+        csdr_demod_params prm = {CSDR_MODEM_FRONTEND_ONLY, (int32_t)resampleBw, (int32_t)resampleBw, 0, s->input_freq};
+        if (int rc = bank_configure_slot(s->vbank, 0, &prm, s->vpost)) return rc;   // msresamp_crcf_create(resamplerRatio, 60) :361
+        s->vbank->slots[0].theta = theta;
+        bw_diff = resampleBw - s->last_bandwidth;
+        s->last_bandwidth = resampleBw; s->last_input_bandwidth = (long)rate;
+        s->have_resampler = true;
+        new_resampler = true;
+        s->peak_reset = 30;                                                     // :367
+    } else if (block_len > s->vpost_cap) {
+        return fail(CSDR_ERANGE, "view input of %d samples exceeds the %d the resampler was built for", block_len, s->vpost_cap);
+    }
+    // shift (:341-352) + resample (:379) of the first `desired` samples
+    if (int rc = csdr_bank_set_frequency(s->vbank, 0, mix ? s->input_freq + s->shift_frequency : s->input_freq)) return rc;
+    if (int rc = csdr_post_execute(s->vpost, iq, iq_is_dev, 1, (int)desired, s->input_freq)) return rc;
+    if (int rc = csdr_bank_execute(s->vbank, s->vpost)) return rc;
+    const SlotHost &sl = s->vbank->slots[0];
+    const int nw = sl.last_J;                                                   // num_written
+    const float2 *xr = sl.cfg.iq + (size_t)sl.last_parity * ((size_t)kIqHist + sl.cfg.cap_iq) + kIqHist;
+    // the spectrum lanes read what the front-end lane wrote
+    CSDR_HIP_TRY(hipStreamSynchronize(c->lanes[LANE_FE]));
+    // frame rule (:399-421)
+    if (int rc = c->lane_begin(LANE_FFT)) return rc;
+    FrameSrc fs{nullptr, nullptr, nullptr, 0, 1 << 30};
+    int nf = 0;
+    const float2 *lx = xr;
+    int nl = 1;
+    if (nw >= N) { fs.first = xr; nf = 1; }
+    else { if (int rc = spec_lines_begin(s, lx, nw, nl, fs)) return rc; nf = nl; }
+    s->nf_last = nf;
+    if (nf > 0) {
+        // bins per display point for visualRatio = bandwidth / resampleBw (:532-560), walked with the reference's accumulator
+        if (s->vmap_bw != s->bandwidth || s->vmap_rbw != resampleBw) {
+            if (int rc = s->vmap.reserve((size_t)F)) return rc;
+            std::vector<int2> vm((size_t)F);
+            const double visualRatio = double(s->bandwidth) / double(resampleBw);
+            const double visualStart = (double(N) / 2.0) - (double(N) * (visualRatio / 2.0));
+            double visualAccum = 0, i = 0;
+            for (int x = 0; x < F; ++x) {
+                visualAccum += visualRatio * 2.0;
+                int first = 0, cnt = 0;
+                while (visualAccum >= 1.0) {
+                    const unsigned idx = (unsigned)std::round(visualStart + i);
+                    if (!cnt) first = (int)idx;
+                    ++cnt; visualAccum -= 1.0; i += 1.0;
+                }
+                vm[x] = make_int2(first, cnt);
+            }
+            CSDR_HIP_TRY(hipMemcpy(s->vmap.p, vm.data(), vm.size() * sizeof(int2), hipMemcpyHostToDevice));
+            s->vmap_bw = s->bandwidth; s->vmap_rbw = resampleBw;
+        }
+        const size_t nfF = (size_t)s->max_frames * F;
+        if (int rc = s->maaf.reserve(nfF)) return rc;
+        if (do_peak) {
+            if (int rc = s->peaksum.reserve(nfF)) return rc;
+            if (int rc = s->peak_b.reserve(s->max_frames)) return rc;
+            if (int rc = s->hold_points.reserve(2 * nfF)) return rc;
+            if (int rc = s->pfo.reserve(s->max_frames)) return rc;
+            if (int rc = s->peakf.reserve(nfF)) return rc;
+        }
+        const bool rescale = new_resampler && s->last_view;                     // :454
+        int rc = spec_fft_then(s, fs, 1, [&](float *mag) -> int {
+            if (rescale) if (int r2 = remap(bw_diff < 0 ? 2 : 3, 0)) return r2;  // :455-491
+            s->view_frame = true;
+            const int r3 = spec_post_range(s, mag, 0, 1, do_peak ? 0 : 1);
+            s->view_frame = false;
+            return r3;
+        });
+        if (rc) return rc;
+        s->hold_valid.assign(1, do_peak ? 1 : 0);
+        hipStream_t st = c->lanes[LANE_FFT];
+        if (nw >= N) {                                                           // memcpy(fftLastData, fftInput) :404
+            for (int k = 0; k < 2; ++k) if (int r4 = s->last[k].reserve((size_t)N)) return r4;
+            CSDR_HIP_TRY(hipMemcpyAsync(s->last[s->last_cur ^ 1].p, xr, (size_t)N * sizeof(float2), hipMemcpyDeviceToDevice, st));
+            s->last_cur ^= 1;
+        } else if (int r5 = spec_lines_end(s, lx, nw, nl)) return r5;
+    }
+    s->last_view = true;                                                         // :631
+    return CSDR_OK;
+}
+
 extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, int n_blocks, int block_len, int mode) {
     if (!s || !s->ready) return fail(CSDR_ESTATE, "spec not set up");
     if (!iq || n_blocks <= 0 || block_len <= 0) return fail(CSDR_EINVAL, "bad block arguments");
+    if (s->is_view) {
+        if (n_blocks != 1) return fail(CSDR_EINVAL, "the zoomed view takes one process() input per call");
+        return spec_process_view(s, iq, iq_is_dev, block_len);
+    }
     csdr_ctx *c = s->ctx;
-    hipStream_t st = c->lanes[LANE_FFT], st_y = c->lanes[LANE_AVG];
+    hipStream_t st = c->lanes[LANE_FFT];
     const SpecGeom &g = s->g;
     const int N = g.N;
     const int64_t n = (int64_t)n_blocks * block_len;
@@ -1236,7 +1496,7 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
     const float2 *lines_x = nullptr;
     int lines_n = 0;
     if (mode == CSDR_SPEC_FIRST_FRAME) {
-        if (block_len < N) return fail(CSDR_EUNSUPPORTED, "block_len %d < internal FFT size %d (overlap priming path :399-421 not built)", block_len, N);
+        if (block_len < N) return fail(CSDR_EINVAL, "block_len %d < internal FFT size %d: use CSDR_SPEC_LINES for short inputs", block_len, N);
         nf = n_blocks; fs.first = x; fs.rest = x + block_len; fs.stride = block_len;
     } else if (mode == CSDR_SPEC_CONTIGUOUS) {
         const int64_t total = s->carry_len + n;
@@ -1249,37 +1509,11 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
             fs.rest = x + (N - s->carry_len); fs.stride = N;
         }
     } else if (mode == CSDR_SPEC_LINES) {
-        // every block is one input of fewer than 2*fftSize samples (FFTDataDistributor lines of fftSize samples): the FFT
-        // input is the previous FFT input shifted left by the line length with the line appended (:410-420); the very first
-        // line only primes fftLastData (zero padded, :401-409)
-        const int len = block_len;
-        if (len >= N) return fail(CSDR_EINVAL, "CSDR_SPEC_LINES takes blocks shorter than the internal FFT size %d", N);
-        for (int k = 0; k < 2; ++k) if (int rc = s->last[k].reserve((size_t)N)) return rc;
-        int nl = n_blocks;
-        if (!s->last_primed) {
-            float2 *L = s->last[s->last_cur].p;
-            CSDR_HIP_TRY(hipMemsetAsync(L + len, 0, (size_t)(N - len) * sizeof(float2), st));
-            CSDR_HIP_TRY(hipMemcpyAsync(L, x, (size_t)len * sizeof(float2), hipMemcpyDeviceToDevice, st));
-            s->last_primed = true;
-            x += len; --nl;
-        }
-        nf = nl;
-        if (nf > s->max_frames) return fail(CSDR_ERANGE, "%d frames exceed max_frames %d", nf, s->max_frames);
-        if (nf > 0) {
-            // V = last ++ lines; frame j = V[(j + 1) len, (j + 1) len + N)
-            const float2 *L = s->last[s->last_cur].p;
-            if (2 * len >= N) {          // only frame 0 straddles the two buffers: read in place
-                fs.first = L + len; fs.split = N - len; fs.first2 = x;
-                fs.rest = x + (2 * len - N); fs.stride = len;
-            } else {                     // several frames straddle: make the tail of `last` and the lines contiguous
-                const size_t need = (size_t)(N - len) + (size_t)nf * len;
-                if (int rc = s->lines.reserve(need)) return rc;
-                CSDR_HIP_TRY(hipMemcpyAsync(s->lines.p, L + len, (size_t)(N - len) * sizeof(float2), hipMemcpyDeviceToDevice, st));
-                CSDR_HIP_TRY(hipMemcpyAsync(s->lines.p + (N - len), x, (size_t)nf * len * sizeof(float2), hipMemcpyDeviceToDevice, st));
-                fs.first = s->lines.p; fs.rest = s->lines.p + len; fs.stride = len;
-            }
-        }
-        lines_x = x; lines_n = nf;
+        // every block is one input of fewer than 2*fftSize samples (e.g. FFTDataDistributor lines of fftSize samples)
+        if (block_len >= N) return fail(CSDR_EINVAL, "CSDR_SPEC_LINES takes blocks shorter than the internal FFT size %d", N);
+        lines_x = x; lines_n = n_blocks;
+        if (int rc = spec_lines_begin(s, lines_x, block_len, lines_n, fs)) return rc;
+        nf = lines_n;
     } else return fail(CSDR_EINVAL, "mode");
     if (nf > s->max_frames) return fail(CSDR_ERANGE, "%d frames exceed max_frames %d", nf, s->max_frames);
     s->nf_last = nf;
@@ -1288,36 +1522,9 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
     const bool first_input_has_frame = !(mode == CSDR_SPEC_LINES && nf < n_blocks);
     const int n_inputs = mode == CSDR_SPEC_CONTIGUOUS ? nf : n_blocks;
     if (nf == 0 && n_inputs > 0) { if (int rc = spec_post_frames(s, nullptr, 0, n_inputs, first_input_has_frame)) return rc; }
-    if (nf > 0) {
-        // lane FFT fills magnitude copy `mp`; its previous reader was the averaging kernel two batches ago
-        const int mp = c->same(LANE_FFT, LANE_AVG) ? 0 : (int)(s->seq & 1);
-        float *mag = s->mag.p + (size_t)mp * s->max_frames * N;
-        if (s->avg_pending[mp]) if (int rc = c->wait(s->ev_avg_done[mp], LANE_AVG, LANE_FFT)) return rc;
-        if (int rc = spec_run_fft(s, fs, nf, mag, nullptr)) return rc;
-        if (int rc = c->signal(s->ev_fft_done[mp], LANE_FFT, LANE_AVG)) return rc;
-        // lane AVG: averaging, extrema, trackers + display points (split where a peak-hold reset falls inside the batch)
-        if (int rc = c->wait(s->ev_fft_done[mp], LANE_FFT, LANE_AVG)) return rc;
-        if (int rc = spec_post_frames(s, mag, nf, n_inputs, first_input_has_frame)) return rc;
-        if (int rc = c->signal(s->ev_avg_done[mp], LANE_AVG, LANE_FFT)) return rc;
-        s->avg_pending[mp] = true;
-        (void)st_y;
-        s->seq++;
-    }
-    if (mode == CSDR_SPEC_LINES && lines_n > 0) {
-        // fftLastData = the last FFT input (:417) = V[nf len, nf len + N), written to the other copy (lane FFT: behind the
-        // kernels that read the current one)
-        const int len = block_len;
-        const float2 *L = s->last[s->last_cur].p;
-        float2 *Ln = s->last[s->last_cur ^ 1].p;
-        const int64_t from_x = (int64_t)lines_n * len;             // samples of the lines inside the new fftLastData (if < N)
-        if (from_x >= N) {
-            CSDR_HIP_TRY(hipMemcpyAsync(Ln, lines_x + (from_x - N), (size_t)N * sizeof(float2), hipMemcpyDeviceToDevice, st));
-        } else {
-            CSDR_HIP_TRY(hipMemcpyAsync(Ln, L + from_x, (size_t)(N - from_x) * sizeof(float2), hipMemcpyDeviceToDevice, st));
-            CSDR_HIP_TRY(hipMemcpyAsync(Ln + (N - from_x), lines_x, (size_t)from_x * sizeof(float2), hipMemcpyDeviceToDevice, st));
-        }
-        s->last_cur ^= 1;
-    }
+    if (nf > 0)
+        if (int rc = spec_fft_then(s, fs, nf, [&](float *mag) { return spec_post_frames(s, mag, nf, n_inputs, first_input_has_frame); })) return rc;
+    if (mode == CSDR_SPEC_LINES) if (int rc = spec_lines_end(s, lines_x, block_len, lines_n)) return rc;
     if (mode == CSDR_SPEC_CONTIGUOUS) {
         // new carry = samples after the last whole frame (lane FFT: ordered behind the kernels that read the old carry)
         const int64_t total = s->carry_len + n;
@@ -1329,6 +1536,7 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
         }
         s->carry_len = rem;
     }
+    s->last_view = false;                                                        // :631
     return CSDR_OK;
 }
 

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restr
                                                             double *__restrict__ ma, double *__restrict__ maa,
                                                             float *__restrict__ pairsum, float *__restrict__ first_b,
                                                             float2 *__restrict__ ext_w,
-                                                            float2 *__restrict__ maaf /* peak hold: both averaged bins of every point, frames >= pk_from */,
+                                                            float2 *__restrict__ maaf /* peak hold / zoomed view: both averaged bins of every point, frames >= pk_from */,
                                                             int pk_from) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     AvgState *s_loc = reinterpret_cast<AvgState *>(smem);               // [kAvgGroups][64] group end states (zero entering state)
@@ -482,7 +482,8 @@ __global__ __launch_bounds__(256) void spec_peak_reset(const SpecScalars *__rest
 // running maximum of the averaged bins over the frames [pk_from, nf) of a batch, one thread per display point (both of
 // its bins); peaksum[f][x] = peak[2x] + peak[2x+1] after frame f, peak_b[f] = the second bin of point 0 (:546-556)
 __global__ __launch_bounds__(256) void spec_peak_track(const float2 *__restrict__ maaf, int nf, int pk_from, int F,
-                                                       double *__restrict__ peak, float *__restrict__ peaksum, float *__restrict__ peak_b) {
+                                                       double *__restrict__ peak, float *__restrict__ peaksum, float *__restrict__ peak_b,
+                                                       float2 *__restrict__ peakf /* zoomed view: both held bins per frame, else null */) {
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= F) return;
     double pa = peak[x], pb = peak[F + x];
@@ -491,10 +492,30 @@ __global__ __launch_bounds__(256) void spec_peak_track(const float2 *__restrict_
         if ((double)v.x > pa) pa = (double)v.x;
         if ((double)v.y > pb) pb = (double)v.y;
         peaksum[(int64_t)f * F + x] = (float)(pa + pb);
+        if (peakf) peakf[(int64_t)f * F + x] = make_float2((float)pa, (float)pb);
         if (x == 0) peak_b[f] = (float)pb;
     }
     peak[x] = pa; peak[F + x] = pb;
 }
+// zoomed view: the averagers follow a retune or a zoom step (SpectrumVisualProcessor.cpp:316-331, :454-492).  Display-order
+// bin i lives at [(i & 1) F + (i >> 1)] (pair layout).  mode 0/1: memmove left / right by n bins (the vacated end keeps its
+// old values); 2: zoom in, dst[i] = src[N/4 + i/2]; 3: zoom out, dst[i] = src[(i - N/4) 2] inside the middle half, else 0.
+__global__ __launch_bounds__(256) void spec_avg_remap(const double *__restrict__ ma, const double *__restrict__ maa,
+                                                      double *__restrict__ ma_o, double *__restrict__ maa_o, int N, int mode, int n) {
+    const int F = N >> 1;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += 256 * gridDim.x) {
+        int src = i;
+        bool zero = false;
+        if (mode == 0) src = i < N - n ? i + n : i;
+        else if (mode == 1) src = i >= n ? i - n : i;
+        else if (mode == 2) src = N / 4 + i / 2;
+        else { zero = i < N / 4 || i >= N - N / 4; src = zero ? 0 : (i - N / 4) * 2; }
+        const int so = (src & 1) * F + (src >> 1), dn = (i & 1) * F + (i >> 1);
+        ma_o[dn] = zero ? 0.0 : ma[so];
+        maa_o[dn] = zero ? 0.0 : maa[so];
+    }
+}
+
 // the four trackers frame by frame (the reference's statements, :513-521) and their held extremes (:523-530) for the
 // frames [pk_from, nf): pfo[f] = {fft_ceil_peak, fft_floor_peak} after frame f.  One thread: nf short double recurrences.
 __global__ void spec_peak_trackers(const float2 *__restrict__ ext, int nf, int pk_from, const SpecScalars *__restrict__ st_in,
@@ -527,7 +548,9 @@ __global__ __launch_bounds__(kDispThreads) void spec_display(const float *__rest
                                                              const SpecScalars *__restrict__ st_in, SpecScalars *__restrict__ st_out,
                                                              SpecFrameOut *__restrict__ fo, float *__restrict__ points,
                                                              int pk_from, const SpecFrameOut *__restrict__ pfo, const float *__restrict__ peaksum,
-                                                             const float *__restrict__ peak_b, float *__restrict__ hold_points) {
+                                                             const float *__restrict__ peak_b, float *__restrict__ hold_points,
+                                                             const int2 *__restrict__ vmap /* zoomed view: (first bin, bins) per point, else null */,
+                                                             const float2 *__restrict__ maaf, const float2 *__restrict__ peakf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *s_sum = reinterpret_cast<double *>(smem);          // reduction scratch [waves][4]
     double *s_pc = s_sum + 4 * (kDispThreads / 64);            // [3] point_ceil, point_floor, fft_floor_maa of this frame
@@ -581,14 +604,30 @@ __global__ __launch_bounds__(kDispThreads) void spec_display(const float *__rest
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int x = x0 + u;
-        double acc = 0.0, pacc = 0.0;
-        if (x < F) acc = (x == 0) ? fl + (double)first_b[f]       // idx == 0 is replaced by fft_floor_maa (:546-556)
-                                  : (double)pairsum[(int64_t)f * F + x];
-        y[u] = log1p_fast((float)(acc * 0.5 - pf)) * inv_den * sf;  // acc / 2 + 0.25 - (pf - 0.75) = 1 + (acc / 2 - pf)
-        if (hold) {
-            if (x < F) pacc = (x == 0) ? fl + (double)peak_b[f] : (double)peaksum[(int64_t)f * F + x];
-            yh[u] = log1p_fast((float)(pacc * 0.5 - pf)) * inv_den * sf;
+        double acc = 0.0, pacc = 0.0, inv_n = 0.5;
+        if (vmap) {
+            // zoomed view (:532-560): visualRatio = bandwidth / resampleBw in (0.5, 1] -> one or two bins per point, walked on
+            // the host with the reference's double accumulator; bins outside (0, N) read as fft_floor_maa
+            if (x < F) {
+                const int2 m = vmap[x];
+                const float *row = reinterpret_cast<const float *>(maaf + (int64_t)f * F);
+                const float *prow = hold ? reinterpret_cast<const float *>(peakf + (int64_t)f * F) : nullptr;
+                const int N = 2 * F;
+                for (int k = 0; k < m.y; ++k) {
+                    const int idx = m.x + k;
+                    const bool in = idx > 0 && idx < N;
+                    acc += in ? (double)row[idx] : fl;
+                    if (hold) pacc += in ? (double)prow[idx] : fl;
+                }
+                inv_n = 1.0 / (double)max(m.y, 1);
+            }
+        } else {
+            if (x < F) acc = (x == 0) ? fl + (double)first_b[f]   // idx == 0 is replaced by fft_floor_maa (:546-556)
+                                      : (double)pairsum[(int64_t)f * F + x];
+            if (hold && x < F) pacc = (x == 0) ? fl + (double)peak_b[f] : (double)peaksum[(int64_t)f * F + x];
         }
+        y[u] = log1p_fast((float)(acc * inv_n - pf)) * inv_den * sf;  // acc / n + 0.25 - (pf - 0.75) = 1 + (acc / n - pf)
+        if (hold) yh[u] = log1p_fast((float)(pacc * inv_n - pf)) * inv_den * sf;
     }
     float *o = points + ((int64_t)f * F + x0) * 2;
     if (x0 + 1 < F) *reinterpret_cast<float4 *>(o) = make_float4((float)x0 * inv_F, y[0], (float)(x0 + 1) * inv_F, y[1]);

@@ -217,6 +217,26 @@ class SpectrumProcessor:
         if input_freq is not None:
             H.check(self._l.csdr_spec_set_input_frequency(self.h, int(input_freq)))
 
+    def set_view(self, on, center_freq=None, bandwidth=None):
+        H.check(self._l.csdr_spec_set_view(self.h, int(bool(on))))
+        if center_freq is not None:
+            H.check(self._l.csdr_spec_set_center_frequency(self.h, int(center_freq)))
+        if bandwidth is not None:
+            H.check(self._l.csdr_spec_set_bandwidth(self.h, int(bandwidth)))
+
+    def process_view_input(self, iq, frequency, sample_rate):
+        """one process() input in zoomed-view mode; returns the number of frames it produced (0 or 1)"""
+        H.check(self._l.csdr_spec_set_input_frequency(self.h, int(frequency)))
+        H.check(self._l.csdr_spec_set_input_rate(self.h, int(sample_rate)))
+        p, is_dev, n, keep = _as_iq_arg(iq)
+        H.check(self._l.csdr_spec_process(self.h, p, is_dev, 1, int(n), H.CSDR_SPEC_FIRST_FRAME))
+        self._keep = keep
+        return self._l.csdr_spec_frames(self.h)
+
+    @property
+    def desired_input_size(self):
+        return self._l.csdr_spec_desired_input_size(self.h)
+
     def fetch_hold(self, frame):
         """spectrum_hold_points of a frame, or None when it carries none"""
         pts = np.empty(2 * self.fft_size, np.float32)

@@ -84,6 +84,10 @@ ABI = {
     "csdr_spec_set_center_frequency": (_i, [_p, _i64]),
     "csdr_spec_set_bandwidth": (_i, [_p, _i64]),
     "csdr_spec_set_input_frequency": (_i, [_p, _i64]),
+    "csdr_spec_set_view": (_i, [_p, _i]),
+    "csdr_spec_get_view": (_i, [_p]),
+    "csdr_spec_set_input_rate": (_i, [_p, _i64]),
+    "csdr_spec_desired_input_size": (_i, [_p]),
     "csdr_spec_process": (_i, [_p, _p, _i, _i, _i, _i]),
     "csdr_spec_frames": (_i, [_p]),
     "csdr_spec_fetch": (_i, [_p, _i, _p, _i, C.POINTER(_d), C.POINTER(_d)]),

@@ -267,7 +267,6 @@ public:
     void setup(unsigned int fftSize_in) {                                            // :140-178
         std::lock_guard<std::mutex> g(busy_run);
         fftSize = fftSize_in;
-        desiredInputSize = (int)(2 * fftSize);                                       // fftSizeInternal, :145,165
         csdr_must(csdr_spec_setup(spec_, (int)fftSize, 1), "csdr_spec_setup");
         csdr_must(csdr_spec_set_average_rate(spec_, fft_average_rate), "csdr_spec_set_average_rate");
         csdr_must(csdr_spec_set_scale_factor(spec_, scaleFactor), "csdr_spec_set_scale_factor");
@@ -285,12 +284,11 @@ public:
     void setPeakHold(bool on) { std::lock_guard<std::mutex> g(busy_run); csdr_spec_set_peak_hold(spec_, on ? 1 : 0); }       // :115-125
     bool getPeakHold() { std::lock_guard<std::mutex> g(busy_run); return csdr_spec_get_peak_hold(spec_) != 0; }
     void setHideDC(bool on) { std::lock_guard<std::mutex> g(busy_run); csdr_spec_set_hide_dc(spec_, on ? 1 : 0); }           // :204-209
-    // the zoomed view (K17, :283-386: NCO shift + msresamp to the view bandwidth + averager history shifts) is a later
-    // tier: the flag is kept, inputs are processed full-span
-    void setView(bool v) { std::lock_guard<std::mutex> g(busy_run); is_view = v; }
+    // zoomed view (K17, :64-72): shift + resample to the view bandwidth, averager retune / zoom steps, fractional bins per point
+    void setView(bool v) { std::lock_guard<std::mutex> g(busy_run); is_view = v; csdr_spec_set_view(spec_, v ? 1 : 0); }
     void setView(bool v, long long centerFreq_in, long bandwidth_in) { setView(v); setCenterFrequency(centerFreq_in); setBandwidth(bandwidth_in); }
     bool isView() { std::lock_guard<std::mutex> g(busy_run); return is_view; }
-    int getDesiredInputSize() { std::lock_guard<std::mutex> g(busy_run); return desiredInputSize; }
+    int getDesiredInputSize() { std::lock_guard<std::mutex> g(busy_run); return fftSize ? csdr_spec_desired_input_size(spec_) : 0; }
 
 protected:
     void process() override {                                                        // :212-637, full-span branch
@@ -305,6 +303,7 @@ protected:
         if (!fftSize || iq->data.empty()) return;
         const size_t N = 2 * (size_t)fftSize;
         csdr_must(csdr_spec_set_input_frequency(spec_, iq->frequency), "csdr_spec_set_input_frequency");
+        csdr_must(csdr_spec_set_input_rate(spec_, iq->sampleRate), "csdr_spec_set_input_rate");
         // inputs of at least 2*fftSize samples are transformed directly (:401-404); shorter ones go through the
         // fftLastData priming / overlap rule (:406-420)
         const int mode = iq->data.size() >= N ? CSDR_SPEC_FIRST_FRAME : CSDR_SPEC_LINES;
@@ -327,7 +326,6 @@ private:
     std::mutex busy_run;
     unsigned int fftSize = 0, newFFTSize = 0;
     bool fftSizeChanged = false, is_view = false;
-    int desiredInputSize = 0;
     float fft_average_rate = 0.65f, scaleFactor = 1.0f;
     long long centerFreq = 0;
     long bandwidth = 0;

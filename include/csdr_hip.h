@@ -185,6 +185,17 @@ int  csdr_spec_set_hide_dc(csdr_spec *spec, int enabled);
 int  csdr_spec_set_center_frequency(csdr_spec *spec, int64_t center_freq);
 int  csdr_spec_set_bandwidth(csdr_spec *spec, int64_t bandwidth);
 int  csdr_spec_set_input_frequency(csdr_spec *spec, int64_t frequency);
+/* Zoomed view: setView(bView[, centerFreq, bandwidth]) :64-72 with setCenterFrequency / setBandwidth above.  While set, every
+ * csdr_spec_process call is ONE process() input (n_blocks == 1; `mode` is ignored) taken through :283-386: the sample rate
+ * is halved while half of it still covers `bandwidth`, the first fftSizeInternal / ratio samples are shifted by
+ * centerFreq - input frequency (nco_crcf) and resampled (msresamp_crcf_create(ratio, 60)), the averagers follow retunes and
+ * zoom steps (:316-331, :454-492), and the display walks bandwidth / resampleBw bins per point (:532-560).
+ * csdr_spec_set_input_rate gives iqData->sampleRate of the inputs that follow (it also stands in for the application
+ * sample rate of the range test :308). */
+int  csdr_spec_set_view(csdr_spec *spec, int is_view);
+int  csdr_spec_get_view(const csdr_spec *spec);
+int  csdr_spec_set_input_rate(csdr_spec *spec, int64_t sample_rate);
+int  csdr_spec_desired_input_size(const csdr_spec *spec);                 /* getDesiredInputSize :133-137 */
 /* Run the spectrum path over n_blocks x block_len samples; frames are taken per `mode`.  Every frame updates the
  * averagers in order, exactly as one process() call per frame would. */
 int  csdr_spec_process(csdr_spec *spec, const float *iq, int iq_is_dev, int n_blocks, int block_len, int mode);

@@ -295,14 +295,139 @@ class RefSpectrum:
                 pts[2 * i + 1] = pts[2 * (end + n) + 1]
                 n += 1
 
-    def process_input(self, data):
-        """one process() call: returns None (no FFT ran) or (points, fft_ceiling, fft_floor, hold_points or None)"""
+    def process_input(self, data, frequency=None, sample_rate=None):
+        """one process() call: returns None (no FFT ran) or (points, fft_ceiling, fft_floor, hold_points or None).
+        With set_view(True, ...) the input goes through the zoomed-view branch (:283-386) first."""
         self.begin_input()
+        if getattr(self, "is_view", False):
+            data = self._view_input(A.as_c64(data), int(frequency), int(sample_rate))
+            if data is None:
+                self.last_view = True
+                return None
         frame = self.select_input(data)
         if frame is None:
+            self.last_view = getattr(self, "is_view", False)
             return None
         pts, ce, fl = self.process_frame(frame)
+        self.last_view = getattr(self, "is_view", False)                 # :631
         return pts, ce, fl, self.hold
+
+    # ---- zoomed view (setView :64-72, process :283-386, :454-492, :532-560) -------------------------------------------
+    def set_view(self, on, center_freq=None, bandwidth=None):
+        self.is_view = bool(on)
+        if center_freq is not None:
+            self.center_freq = int(center_freq)
+        if bandwidth is not None:
+            self.bandwidth = int(bandwidth)
+        if not hasattr(self, "last_bandwidth"):
+            self.last_bandwidth = 0                                      # ctor :11-15
+            self.last_input_bandwidth = 0
+            self.shift_frequency = 0                                     # ctor :30
+            self.resampler = None
+            self.shifter = self.L.nco_crcf_create(A.LIQUID_NCO)          # ctor :29
+            self.last_view = False
+            self.new_resampler = False
+            self.bw_diff = 0
+            self.desired_input_size = 0
+        if not hasattr(self, "peak_hold"):
+            self.peak_hold, self.peak_reset = False, 0
+
+    def _view_input(self, x, frequency, sample_rate):
+        """:283-386: returns the resampler output (num_written samples) of this input"""
+        L, N = self.L, self.N
+        self.input_freq = frequency
+        if not sample_rate:
+            return None                                                  # :286-289
+        resample_bw = sample_rate
+        while resample_bw // 2 >= self.bandwidth:                        # SPECTRUM_VZM, :291-293 (long division)
+            resample_bw //= 2
+        self.resample_bw = resample_bw
+        ratio = float(resample_bw) / float(sample_rate)                  # :295
+        desired = int(N / ratio)                                         # :297 size_t <- double
+        self.desired_input_size = desired                                # :299
+        if x.size < desired:
+            desired = x.size                                             # :301-304
+        self.new_resampler = False
+        self.bw_diff = 0
+        if self.center_freq != frequency:                                # :306
+            if (self.center_freq - frequency) != self.shift_frequency or self.last_input_bandwidth != sample_rate:   # :307
+                if abs(frequency - self.center_freq) < (sample_rate // 2):          # :308 (app rate == input rate here)
+                    last_shift = self.shift_frequency
+                    self.shift_frequency = self.center_freq - frequency
+                    L.nco_crcf_set_frequency(self.shifter, float(np.float32((2.0 * math.pi) * (float(abs(self.shift_frequency)) / float(sample_rate)))))   # :311
+                    freq_diff = self.shift_frequency - last_shift        # :314
+                    if self.last_bandwidth != 0:                         # :316
+                        bin_per_hz = float(self.last_bandwidth) / float(N)
+                        num_shift = int(math.floor(float(abs(freq_diff)) / bin_per_hz))
+                        if num_shift < N // 2 and num_shift:             # :321
+                            if freq_diff > 0:                            # memmove left :323-324
+                                self.ma[:N - num_shift] = self.ma[num_shift:].copy()
+                                self.maa[:N - num_shift] = self.maa[num_shift:].copy()
+                            else:                                        # memmove right :328-329
+                                self.ma[num_shift:] = self.ma[:N - num_shift].copy()
+                                self.maa[num_shift:] = self.maa[:N - num_shift].copy()
+                self.peak_reset = 30                                     # :335 (inside the outer if, whatever the range test said)
+            xin = np.ascontiguousarray(x[:desired])
+            y = np.empty(desired, np.complex64)
+            if self.shift_frequency < 0:                                 # :345-349
+                L.nco_crcf_mix_block_up(self.shifter, _cptr(xin), _cptr(y), desired)
+            else:
+                L.nco_crcf_mix_block_down(self.shifter, _cptr(xin), _cptr(y), desired)
+            shifted = y
+        else:
+            shifted = np.ascontiguousarray(x[:desired])                  # :351
+        if self.resampler is None or resample_bw != self.last_bandwidth or self.last_input_bandwidth != sample_rate:   # :354
+            self.resampler = L.msresamp_crcf_create(float(np.float32(ratio)), 60.0)   # :361 (destroying the old one)
+            self.bw_diff = resample_bw - self.last_bandwidth
+            self.last_bandwidth = resample_bw
+            self.last_input_bandwidth = sample_rate
+            self.new_resampler = True
+            self.peak_reset = 30                                         # :367
+        out = np.empty(int(math.ceil(float(desired) * ratio)) + 512, np.complex64)   # :370
+        nw = C.c_uint()
+        L.msresamp_crcf_execute(self.resampler, _cptr(shifted), desired, _cptr(out), C.byref(nw))   # :379
+        return out[:nw.value].copy()
+
+    def _rescale_averagers(self):
+        """newResampler && lastView (:454-492): the averaged spectrum is stretched / squeezed about its centre"""
+        N = self.N
+        i = np.arange(N)
+        if self.bw_diff < 0:
+            src = N // 4 + i // 2
+            self.ma = self.ma[src].copy()
+            self.maa = self.maa[src].copy()
+        else:
+            inside = (i >= N // 4) & (i < N - N // 4)
+            src = np.where(inside, (i - N // 4) * 2, 0)
+            self.ma = np.where(inside, self.ma[src], 0.0)
+            self.maa = np.where(inside, self.maa[src], 0.0)
+
+    def _view_map(self):
+        """the bin walk of :532-560 for visualRatio = bandwidth / resampleBw: for every visited bin its index, whether it is
+        inside (0, N), and the display point that owns it; plus the bins per point.  The double accumulator is stepped
+        exactly as the reference does."""
+        N, F = self.N, self.F
+        key = (self.bandwidth, self.resample_bw)
+        if getattr(self, "_vm_key", None) == key:
+            return self._vm
+        ratio = float(self.bandwidth) / float(self.resample_bw)          # :532
+        start = (float(N) / 2.0) - (float(N) * (ratio / 2.0))            # :533
+        accum = 0.0
+        i = 0.0
+        idx, owner, cnt = [], [], np.zeros(F, np.int64)
+        for x in range(F):
+            accum += ratio * 2.0                                         # SPECTRUM_VZM :541
+            while accum >= 1.0:
+                v = start + i
+                idx.append(int(math.floor(v + 0.5)) if v >= 0 else -int(math.floor(-v + 0.5)))   # C round(): half away from zero
+                owner.append(x)
+                cnt[x] += 1
+                accum -= 1.0
+                i += 1.0
+        idx = np.array(idx, np.int64)
+        valid = (idx > 0) & (idx < N)                                    # unsigned idx: negative wraps to huge -> invalid
+        self._vm_key, self._vm = key, (idx, valid, np.array(owner, np.int64), cnt)
+        return self._vm
 
     def process_frame(self, frame):
         """frame: the 2*fftSize samples process() would FFT.  Returns (spectrum_points[2F], fft_ceiling, fft_floor)."""
@@ -310,6 +435,8 @@ class RefSpectrum:
         Y = self.fft(frame)
         mag = np.sqrt((Y.real * Y.real + Y.imag * Y.imag).astype(np.float32)).astype(np.float32)   # float sqrt :443-448
         res = np.concatenate([mag[N // 2:], mag[:N // 2]]).astype(np.float64)                       # :450-451
+        if getattr(self, "is_view", False) and self.new_resampler and self.last_view:
+            self._rescale_averagers()
         self.maa += (self.ma - self.maa) * self.rate                     # :494-497
         self.ma += (res - self.ma) * self.rate
         fft_ceil = np.float32(max(0.0, self.maa.max()))                  # float locals :436, :499-504
@@ -324,20 +451,34 @@ class RefSpectrum:
             self.ceil_peak = max(self.ceil_peak, self.ceil_maa)
             self.floor_peak = min(self.floor_peak, self.floor_maa)
         pc, pf = (self.ceil_peak, self.floor_peak) if do_peak else (self.ceil_maa, self.floor_maa)   # :539-540
-        acc = self.maa[0::2] + self.maa[1::2]                            # visualRatio = 1 -> 2 bins per point :538-560
-        acc[0] = self.floor_maa + self.maa[1]                            # idx == 0 is replaced by fft_floor_maa :546-551
+        view_map = None
+        if getattr(self, "is_view", False):
+            view_map = self._view_map()
+            idx, valid, owner, cnt = view_map
+            vals = np.where(valid, self.maa[np.clip(idx, 0, N - 1)], self.floor_maa)
+            acc = np.bincount(owner, weights=vals, minlength=F)
+            acc_n = cnt.astype(np.float64)
+        else:
+            acc = self.maa[0::2] + self.maa[1::2]                        # visualRatio = 1 -> 2 bins per point :538-560
+            acc[0] = self.floor_maa + self.maa[1]                        # idx == 0 is replaced by fft_floor_maa :546-551
+            acc_n = 2.0
         den = np.log10((pc + 0.25) - (pf - 0.75))
-        y = (np.log10(acc / 2.0 + 0.25 - (pf - 0.75)) / den) * self.sf   # :566
+        y = (np.log10(acc / acc_n + 0.25 - (pf - 0.75)) / den) * self.sf   # :566
         pts = np.empty(2 * F, np.float32)
         pts[0::2] = (np.arange(F, dtype=np.float32) / np.float32(F))     # :562
         pts[1::2] = y.astype(np.float32)
         self.hold = None
         if do_peak:
-            pacc = self.peak[0::2] + self.peak[1::2]
-            pacc[0] = self.floor_maa + self.peak[1]
+            if view_map is not None:
+                idx, valid, owner, cnt = view_map
+                pvals = np.where(valid, self.peak[np.clip(idx, 0, N - 1)], self.floor_maa)
+                pacc = np.bincount(owner, weights=pvals, minlength=F)
+            else:
+                pacc = self.peak[0::2] + self.peak[1::2]
+                pacc[0] = self.floor_maa + self.peak[1]
             hold = np.empty(2 * F, np.float32)
             hold[0::2] = pts[0::2]
-            hold[1::2] = ((np.log10(pacc / 2.0 + 0.25 - (pf - 0.75)) / den) * self.sf).astype(np.float32)   # :569
+            hold[1::2] = ((np.log10(pacc / acc_n + 0.25 - (pf - 0.75)) / den) * self.sf).astype(np.float32)   # :569
             self.hold = hold
         if getattr(self, "hide_dc", False):
             self._hide_dc(pts)

@@ -132,6 +132,10 @@ def test_emu_spectrum_peak_hold_hide_dc(ctx):
     G.test_spectrum_peak_hold_and_hide_dc(ctx)
 
 
+def test_emu_spectrum_zoomed_view(ctx):
+    G.test_spectrum_zoomed_view(ctx)
+
+
 @full
 def test_emu_spectrum_many_frames(ctx):
     G.test_spectrum_many_frames_one_batch(ctx)

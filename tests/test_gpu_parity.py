@@ -391,6 +391,58 @@ def test_spectrum_peak_hold_and_hide_dc(ctx):
     sp.close()
 
 
+def test_spectrum_zoomed_view(ctx):
+    """setView: the input is shifted to the view centre and resampled to the smallest rate/2^k that still covers the view
+    bandwidth, then transformed; the display walks bandwidth / resampleBw bins per point.  The scenario retunes the view
+    (the averagers shift), zooms in and out (they are stretched / squeezed, the resampler is rebuilt while the NCO phase
+    lives on), centres the view on the input (no mixing), holds peaks across a reset, and feeds inputs shorter than the
+    resampler needs (overlap rule)."""
+    from cubicsdr_amd.engine import SpectrumProcessor
+    from oracle.cubicsdr_chain import RefSpectrum
+    F, fs, center = 512, 2400000, 100000000
+    block = 40000
+    steps = [  # (view centre, view bandwidth, samples of the block handed over, peak-hold toggle)
+        (center + 200000, 500000, block, None), (center + 200000, 500000, block, None), (center + 200000, 500000, block, True),
+        (center + 200000, 500000, block, None), (center + 230000, 500000, block, None), (center + 230000, 500000, block, None),
+        (center + 150000, 500000, block, None), (center + 150000, 250000, block, None), (center + 150000, 250000, block, None),
+        (center + 150000, 250000, 7000, None), (center + 150000, 250000, 7000, None), (center + 150000, 250000, block, None),
+        (center + 150000, 900000, block, None), (center + 150000, 900000, block, None), (center, 900000, block, None),
+        (center, 900000, block, None), (center - 300000, 140000, block, None), (center - 300000, 140000, block, None),
+    ]
+    steps += [(center - 300000, 140000, block, None)] * 34          # long enough for the 30-input peak countdown to end
+    x = synth_iq(len(steps) * block, fs, center, [("NBFM", center + 200000.0), ("AM", center + 100000.0), ("NBFM", center - 310000.0)], seed=51)
+    sp = SpectrumProcessor(ctx, F, max_frames=1)
+    ref = RefSpectrum(_backend(), F)
+    ref.set_hide_dc(True, 0, 0, 0)
+    sp.set_hide_dc(True)
+    frames = held = 0
+    for k, (vc, vbw, n, toggle) in enumerate(steps):
+        if toggle is not None:
+            sp.set_peak_hold(toggle)
+            ref.set_peak_hold(toggle)
+        sp.set_view(True, vc, vbw)
+        ref.set_view(True, vc, vbw)
+        xin = x[k * block:k * block + n]
+        want = ref.process_input(xin, center, fs)
+        nf = sp.process_view_input(xin, center, fs)
+        assert sp.desired_input_size == ref.desired_input_size, k
+        assert nf == (0 if want is None else 1), k
+        if want is None:
+            continue
+        wp, wce, wfl, whold = want
+        pts, ce, fl = sp.fetch(0)
+        hold = sp.fetch_hold(0)
+        assert rel_err(pts, wp) < TOL, (k, rel_err(pts, wp))
+        assert abs(ce - wce) <= TOL * abs(wce) and abs(fl - wfl) <= TOL * abs(wce), k
+        assert (hold is None) == (whold is None), k
+        if hold is not None:
+            assert rel_err(hold, whold) < TOL, k
+            held += 1
+        frames += 1
+    assert frames >= len(steps) - 3 and held >= 3, (frames, held)
+    sp.close()
+
+
 def test_spectrum_many_frames_one_batch(ctx):
     """300 frames in ONE process() call (the averaging kernel splits a batch into 16 frame groups per round of 256
     frames and chains rounds): every frame must equal the frame-at-a-time reference."""
