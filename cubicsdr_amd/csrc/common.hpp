@@ -143,6 +143,8 @@ struct csdr_ctx {
     csdr::DevBuf<float> sintab;  // 1024-entry sine table of the reference's NCO
     // per-kernel profile: event pairs recorded around launches while enabled
     bool prof_on = false;
+    int prof_period = 1;                     // bracket every prof_period-th launch of each kernel
+    unsigned prof_seen[KID_COUNT] = {0};
     struct ProfRec { int id; hipEvent_t a, b; };
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> prof_pool;
@@ -200,7 +202,9 @@ struct csdr_ctx {
 // bracket one kernel launch with events when profiling is on
 struct ProfScope {
     csdr_ctx *c; int id; hipStream_t st; hipEvent_t a = nullptr;
-    ProfScope(csdr_ctx *c_, int id_, hipStream_t st_) : c(c_), id(id_), st(st_) { if (c->prof_on) { a = c->prof_event(); (void)hipEventRecord(a, st); } }
+    ProfScope(csdr_ctx *c_, int id_, hipStream_t st_) : c(c_), id(id_), st(st_) {
+        if (c->prof_on && (c->prof_seen[id]++ % (unsigned)c->prof_period) == 0) { a = c->prof_event(); (void)hipEventRecord(a, st); }
+    }
     ~ProfScope() { if (a) { hipEvent_t b = c->prof_event(); (void)hipEventRecord(b, st); c->prof_pending.push_back({id, a, b}); } }
 };
 #define CSDR_LAUNCH(ctx_, lane_, kid_, kern_, grid_, block_, lds_, ...) \

@@ -126,7 +126,8 @@ extern "C" int csdr_ctx_profile_enable(csdr_ctx *c, int on) {
     if (!c) return fail(CSDR_EINVAL, "ctx is null");
     if (int rc = prof_drain(c)) return rc;
     c->prof_on = on != 0;
-    if (on) for (int i = 0; i < KID_COUNT; i++) { c->prof_ms[i] = 0.0; c->prof_n[i] = 0; }
+    c->prof_period = on > 1 ? on : 1;
+    if (on) for (int i = 0; i < KID_COUNT; i++) { c->prof_ms[i] = 0.0; c->prof_n[i] = 0; c->prof_seen[i] = 0; }
     return CSDR_OK;
 }
 extern "C" int csdr_ctx_profile_num_kernels(void) { return KID_COUNT; }
@@ -480,7 +481,7 @@ struct SlotHost {
     design::MsresampPlan iq, au;
     int64_t chan_rate = 0;
     // integer state mirrored on the host (closed-form bookkeeping)
-    uint32_t theta = 0, dtheta = 0, buf_idx = 0, phase = 0, aphase = 0, abuf = 0, ssb_theta = 0;
+    uint32_t theta = 0, dtheta = 0, buf_idx = 0, phase = 0, aphase = 0, abuf = 0, ssb_theta = 0, cw_dtheta = 0;
     long long shift_frequency = 0;
     bool shift_valid = false;
     int hist_parity = 0, last_parity = 0;
@@ -589,6 +590,8 @@ extern "C" int csdr_bank_create(csdr_ctx *ctx, int max_demods, int max_blocks, c
     for (int q = 0; q < 3; q++) for (int i = 0; i < 3; i++) { mc.sos_b[q][i] = sos[q].b[i]; mc.sos_a[q][i] = sos[q].a[i]; }
     std::vector<float> hq = design::hilbert_taps(kHilbM, 90.0f);
     for (int i = 0; i < 2 * kHilbM; i++) mc.hilb[i] = hq[i];
+    std::vector<float> hq60 = design::hilbert_taps(kHilbM, 60.0f);           // ModemCW.cpp:23
+    for (int i = 0; i < 2 * kHilbM; i++) mc.hilb60[i] = hq60[i];
     CSDR_HIP_TRY(hipMemcpy(b->mconsts.p, &mc, sizeof mc, hipMemcpyHostToDevice));
     *out = b.release();
     return CSDR_OK;
@@ -612,7 +615,7 @@ extern "C" void csdr_bank_destroy(csdr_bank *b) {
 }
 
 // internal: NCO + msresamp only, no modem / audio stage (the zoomed spectrum view's shift + resample, SpectrumVisualProcessor.cpp:306-379)
-#define CSDR_MODEM_FRONTEND_ONLY 6
+#define CSDR_MODEM_FRONTEND_ONLY 100
 static int modem_check_rate(int modem, int bw, int audio_rate) {   // Modem*::checkSampleRate (ModemAnalog.cpp:14-19, ModemUSB.cpp:29-37, ModemIQ.cpp:31-33)
     if (modem == CSDR_MODEM_IQ || modem == CSDR_MODEM_FRONTEND_ONLY) return audio_rate;
     if (bw < 500) bw = 500;                          // MIN_BANDWIDTH, Modem.h:13
@@ -622,7 +625,7 @@ static int modem_check_rate(int modem, int bw, int audio_rate) {   // Modem*::ch
 
 static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *prm, const csdr_post *post);
 extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *prm, const csdr_post *post) {
-    if (prm && (prm->modem < CSDR_MODEM_NBFM || prm->modem > CSDR_MODEM_IQ)) return fail(CSDR_EUNSUPPORTED, "modem %d", prm->modem);
+    if (prm && (prm->modem < CSDR_MODEM_NBFM || prm->modem > CSDR_MODEM_CW)) return fail(CSDR_EUNSUPPORTED, "modem %d", prm->modem);
     return bank_configure_slot(b, slot, prm, post);
 }
 static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *prm, const csdr_post *post) {
@@ -697,6 +700,8 @@ static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *
     s.shift_valid = false; s.shift_frequency = 0;
     // ModemUSB/LSB ctor: nco_crcf_set_frequency(ssbShift, 2 pi 0.25) -> the oscillator advances 2^30 per sample
     s.ssb_theta = 0;
+    // ModemCW: mLO runs at the audio rate, nco_crcf_set_frequency(mLO, 2 pi mBeepFrequency / audioSampleRate) every block (:171)
+    s.cw_dtheta = s.prm.modem == CSDR_MODEM_CW ? design::nco_phase_word(2.0f * (float)M_PI * 650.0f / (float)s.prm.audio_sample_rate) : 0;
     s.configured = true; s.active = true;
     s.results.clear(); s.last_J = 0; s.last_A = 0;
     return CSDR_OK;
@@ -738,7 +743,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     SlotDyn *dyns_h = b->dyns_h[ring].p;
     int *slot_list_h = b->slot_list_h[ring].p;
     BlockPlan *plans_h = b->plans_h[ring].p;
-    int n_run = 0, n_ag = 0, max_n_iq = 0, max_n_audio = 0, warm_max = 0, max_aS = 0;
+    int n_run = 0, n_ag = 0, max_n_iq = 0, max_n_audio = 0, warm_max = 0, max_aS = 0, max_cw_audio = 0;
     int *ag_list_h = slot_list_h + b->max_demods;
     for (int si = 0; si < b->max_demods; ++si) {
         SlotHost &s = b->slots[si];
@@ -770,7 +775,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         memset(&d, 0, sizeof d);
         d.active = 1; d.chan = data_ch; d.theta0 = s.theta; d.dtheta = s.dtheta;
         d.mixdir = shift == 0 ? 0 : (shift < 0 ? +1 : -1);          // :186-191: shift < 0 -> mix up
-        d.buf0 = s.buf_idx; d.phase0 = s.phase; d.aphase0 = s.aphase; d.abuf0 = s.abuf; d.ssb_theta0 = s.ssb_theta; d.hist_parity = s.hist_parity;
+        d.buf0 = s.buf_idx; d.phase0 = s.phase; d.aphase0 = s.aphase; d.abuf0 = s.abuf; d.ssb_theta0 = s.ssb_theta; d.cw_dtheta = s.cw_dtheta; d.hist_parity = s.hist_parity;
         d.prev_j = s.prev_J;
         // per-block plan
         BlockPlan *pl = plans_h + (size_t)si * (NB + 1);
@@ -790,6 +795,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         }
         const int64_t Jtot = pl[NB].j0, Qtot = pl[NB].q0;
         if (Jtot > s.cfg.cap_iq - 8 || (!fe_only && (Qtot << ash) > s.cfg.cap_audio - 8)) return fail(CSDR_ERANGE, "slot %d output exceeds its buffers", si);
+        int max_blk_audio = 0;
         for (int bb = 0; bb < NB; ++bb) {
             csdr_block_result &r = s.results[bb];
             memset(&r, 0, sizeof r);
@@ -799,6 +805,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
             if (fe_only) { r.n_audio = 0; r.audio_offset = 0; }
             else if (r.n_iq > kModemMaxBlockIq || r.n_audio > kAudioMaxOut) return fail(CSDR_EUNSUPPORTED, "slot %d: %d IQ / %d audio samples per block exceed the per-workgroup limits", si, r.n_iq, r.n_audio);
             if (!fe_only) { max_n_iq = std::max(max_n_iq, r.n_iq); max_n_audio = std::max(max_n_audio, r.n_audio); }
+            max_blk_audio = std::max(max_blk_audio, r.n_audio);
             const int64_t Kb = ((int64_t)s.buf_idx + (int64_t)(bb + 1) * Bc) >> S;
             r.buffer_index = (uint32_t)(((int64_t)s.buf_idx + (int64_t)(bb + 1) * Bc) & ((1 << S) - 1));
             r.resamp_phase = (uint32_t)((int64_t)s.phase + (int64_t)pl[bb + 1].j0 * s.iq.step - (Kb << 24));
@@ -814,7 +821,8 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
             s.aphase = (uint32_t)((int64_t)s.aphase + Qtot * (int64_t)s.au.step - (Ka_tot << 24));
             if (!au_interp) s.abuf = (uint32_t)(((int64_t)s.abuf + Jtot) & ((1 << aS) - 1));
         }
-        s.ssb_theta += (uint32_t)Jtot * (1u << 30);
+        if (s.prm.modem == CSDR_MODEM_CW) { s.ssb_theta += (uint32_t)(Qtot << ash) * s.cw_dtheta; max_cw_audio = std::max(max_cw_audio, max_blk_audio); }
+        else s.ssb_theta += (uint32_t)Jtot * (1u << 30);
         s.last_parity = s.hist_parity;
         s.hist_parity ^= 1;
         s.last_J = (int)Jtot; s.last_A = fe_only ? 0 : (int)(Qtot << ash);
@@ -878,7 +886,9 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     size_t fe_lds = 0;
     for (int i = 0; i < grp_n[0]; ++i) fe_lds = std::max(fe_lds, fe_lds_bytes((int)b->slots[grp_h[grp_off[0] + i]].iq.S));
     const int cap_stream = (max_n_iq + kSsbWarm + 64 + 3) & ~3;
-    const size_t modem_lds = (size_t)2 * cap_stream * sizeof(float) + 64;
+    // CW blocks run the complex audio interpolator in LDS: IQ window + two stage arrays of (block audio + Hilbert reach)
+    const int cap_cw = max_cw_audio ? ((max_cw_audio + 4 * kHilbM + 64 + 3) & ~3) : 0;
+    const size_t modem_lds = std::max((size_t)2 * cap_stream * sizeof(float), ((size_t)kCwIqWin + 2 * (size_t)cap_cw) * sizeof(float2)) + 64;
     // LDS of the audio kernel: two ping-pong arrays (stage outputs) and the staged demodulator window (decimating
     // cascades reach back up to kDHist samples and their first stage outputs half the window)
     const int cap_win = (max_n_iq + kDHist + 64 + 3) & ~3;
@@ -920,7 +930,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     if (int rc = c->wait(b->ev_fe_done[bpar], LANE_FE, LANE_AUDIO)) return rc;
     if (n_ag > 0)     // freqdem modems need no block-wide pre-pass: only the auto-gain modems run the modem kernel
         CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, demod_modem, dim3(n_ag, NB), dim3(kModemThreads), modem_lds, b->cfgs.p, dyns_d, lists_d + b->max_demods,
-                    plans_d, NB, cap_stream, b->mconsts.p, c->sintab.p);
+                    plans_d, NB, cap_stream, b->mconsts.p, c->sintab.p, b->arms.p, cap_cw);
     if (n_audio_run > 0)
         CSDR_LAUNCH(c, LANE_AUDIO, KID_AUDIO, demod_audio_interp, grid, dim3(kModemThreads), audio_lds, b->cfgs.p, dyns_d, lists_d, plans_d, NB,
                     cap_out, cap_win, b->arms.p);

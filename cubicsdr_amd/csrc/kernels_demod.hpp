@@ -65,7 +65,8 @@ struct SlotDyn {                  // per batch
     uint32_t phase0;              // arbitrary resampler phase at batch start
     uint32_t aphase0;             // audio arbitrary resampler phase at batch start
     uint32_t abuf0;               // audio msresamp buffer_index (decimating audio path)
-    uint32_t ssb_theta0;          // SSB fs/4 oscillator phase word at batch start
+    uint32_t ssb_theta0;          // modem oscillator phase word at batch start: SSB fs/4 shifter (IQ rate), CW beep oscillator (audio rate)
+    uint32_t cw_dtheta;           // CW beep oscillator increment per audio sample
     int32_t hist_parity;
     int32_t prev_j;               // resampled-IQ samples the previous batch produced (its tail is this batch's history)
 };
@@ -654,13 +655,15 @@ constexpr int kModemThreads = 256;
 constexpr int kModemMaxBlockIq = 4096;     // resampled samples of one block handled by one workgroup (LDS bound)
 constexpr int kAmTaps = 51;
 constexpr int kSsbWarm = 192;              // IIR warm-up span; |pole|^192 ~ 1e-22
-constexpr int kHilbM = 5;                  // firhilbf_create(5, 90): 21-tap half-band, 10 odd taps
+constexpr int kHilbM = 5;                  // firhilbf_create(5, As): 21-tap half-band, 10 odd taps
+constexpr int kCwIqWin = 512;              // resampled-IQ samples one CW block can reach (interpolation by >= 2: far fewer)
 // dynamic LDS: two float streams of `cap_stream` samples (max block + warm-up, multiple of 4) + 64 bytes of reduction scratch
 
 struct ModemConsts {
     float am_taps[kAmTaps];                // h[i] multiplies |x|[j - i]
     float sos_b[3][3], sos_a[3][3];        // Butterworth sections, execution order
-    float hilb[2 * kHilbM];                // hq[(n-1)/2] for odd delay n
+    float hilb[2 * kHilbM];                // hq[(n-1)/2] for odd delay n   (firhilbf_create(5, 90), ModemUSB.cpp:11)
+    float hilb60[2 * kHilbM];              // the same for firhilbf_create(5, 60)          (ModemCW.cpp:23)
 };
 
 __device__ inline double block_sum_double(double v, double *lds) {
@@ -686,11 +689,12 @@ __device__ inline float block_max_float(float v, float *lds) {
 
 __global__ __launch_bounds__(kModemThreads) void demod_modem(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
-    const BlockPlan *__restrict__ plans, int NB, int cap_stream, const ModemConsts *__restrict__ mc, const float *__restrict__ sintab) {
+    const BlockPlan *__restrict__ plans, int NB, int cap_stream, const ModemConsts *__restrict__ mc, const float *__restrict__ sintab,
+    const float *__restrict__ arms_all, int cap_cw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_a = reinterpret_cast<float *>(smem);              // AM: |x| ; SSB: real part stream
     float *s_b = s_a + cap_stream;                             // SSB: imag part stream
-    double *s_red = reinterpret_cast<double *>(s_b + cap_stream);
+    double *s_red = reinterpret_cast<double *>(s_b + cap_stream);   // (CW carves the same memory differently, see below)
     float *s_redf = reinterpret_cast<float *>(s_red + 4);
 
     const int slot = slot_list[blockIdx.x], b = blockIdx.y, tid = threadIdx.x;
@@ -718,6 +722,87 @@ __global__ __launch_bounds__(kModemThreads) void demod_modem(
             for (int t = 0; t < kAmTaps; ++t) acc = fmaf(mc->am_taps[t], s_a[i + halo - t], acc);
             d[j0 + i] = acc;
             lmax = fmaxf(lmax, acc);
+        }
+    } else if (cfg.modem == CSDR_MODEM_CW) {
+        // ModemCW::demodulate (ModemCW.cpp:155-198) up to the gain: msresamp_cccf interpolation of the IQ stream to the audio
+        // rate (arbitrary stage, then x2 half-band stages: the structure of the real audio interpolator, on complex samples),
+        // mix up by the beep oscillator, upper-sideband output of the c2r Hilbert transform.  The block's outputs [A0, A1)
+        // and the 4m samples the Hilbert window reaches back are recomputed from the resampled-IQ stream (history included).
+        const ResampCfg &au = cfg.rs_au;
+        const int aS = au.S, H = 4 * kHilbM;
+        const int64_t A0 = (int64_t)pl[b].q0 << aS, A1 = (int64_t)pl[b + 1].q0 << aS;
+        const int n_audio = (int)(A1 - A0);
+        float2 *s_iq = reinterpret_cast<float2 *>(smem);          // staged IQ window [kCwIqWin]
+        float2 *w0 = s_iq + kCwIqWin, *w1 = w0 + cap_cw;          // ping-pong stage arrays
+        s_red = reinterpret_cast<double *>(w1 + cap_cw);
+        s_redf = reinterpret_cast<float *>(s_red + 4);
+        const float *arms = arms_all + (size_t)au.arms_idx * kArms * kArmTaps;
+        int64_t lo[kMaxHb + 1], hi[kMaxHb + 1];
+        lo[aS] = A0 - H; hi[aS] = A1;
+        for (int st = aS - 1; st >= 0; --st) { lo[st] = (lo[st + 1] >> 1) - (2 * au.m_x[st] - 1); hi[st] = (hi[st + 1] + 1) >> 1; }
+        const int nv = (int)(hi[0] - lo[0]);
+        const int64_t jlo = (((int64_t)dyn.aphase0 + lo[0] * (int64_t)au.step) >> 24) - (kArmTaps - 1);
+        const int64_t jhi = nv > 0 ? (((int64_t)dyn.aphase0 + (hi[0] - 1) * (int64_t)au.step) >> 24) + 1 : jlo;
+        const int nwin = (int)(jhi - jlo);
+        for (int i = tid; i < nwin; i += kModemThreads) {
+            const int64_t j = jlo + i;
+            s_iq[i] = j >= -(int64_t)kIqHist ? iq[j] : make_float2(0.f, 0.f);
+        }
+        __syncthreads();
+        // arbitrary stage: v[q], q in [lo[0], hi[0])
+        for (int i = tid; i < nv; i += kModemThreads) {
+            const int64_t P = (int64_t)dyn.aphase0 + (lo[0] + i) * (int64_t)au.step;
+            const float *h = arms + (int)((P & 0xFFFFFF) >> 16) * kArmTaps;
+            const float2 *z = s_iq + ((P >> 24) - (kArmTaps - 1) - jlo);
+            float ar = 0.f, ai = 0.f;
+#pragma unroll
+            for (int t = 0; t < kArmTaps; ++t) { ar = fmaf(h[t], z[t].x, ar); ai = fmaf(h[t], z[t].y, ai); }
+            w0[i] = make_float2(ar, ai);
+        }
+        __syncthreads();
+        // x2 stages: w'[2q] = w[q - m], w'[2q + 1] = sum_j h1[j] (w[q - j] + w[q - (2m - 1) + j])
+        float2 *src = w0, *dst = w1;
+        for (int st = 0; st < aS; ++st) {
+            const int m = au.m_x[st];
+            const int64_t olo = lo[st + 1], ilo = lo[st];
+            const int nout = (int)(hi[st + 1] - olo);
+            const int qoff = (int)((olo >> 1) - ilo), par0 = (int)(olo & 1);
+            for (int i = tid; i < nout; i += kModemThreads) {
+                const int a = i + par0, qi = qoff + (a >> 1);
+                float2 v;
+                if ((a & 1) == 0) v = src[qi - m];
+                else {
+                    v = make_float2(0.f, 0.f);
+                    for (int j = 0; j < m; ++j) {
+                        const float hj = au.h_x[st][j];
+                        const float2 p = src[qi - j], q2 = src[qi - (2 * m - 1) + j];
+                        v.x = fmaf(hj, p.x + q2.x, v.x); v.y = fmaf(hj, p.y + q2.y, v.y);
+                    }
+                }
+                dst[i] = v;
+            }
+            __syncthreads();
+            float2 *t = src; src = dst; dst = t;
+        }
+        // beep oscillator (mix up, then step: audio sample a uses theta0 + a dtheta), in place; src[i] is audio sample A0 - H + i
+        for (int i = tid; i < n_audio + H; i += kModemThreads) {
+            const int64_t a = A0 - H + i;
+            float sn, cs;
+            nco_sincos(sintab, dyn.ssb_theta0 + (uint32_t)a * dyn.cw_dtheta, sn, cs);
+            const float2 v = src[i];
+            src[i] = make_float2(v.x * cs - v.y * sn, v.y * cs + v.x * sn);
+        }
+        __syncthreads();
+        // Hilbert c2r, upper sideband: yi - yq (as in the SSB path, taps of firhilbf_create(5, 60))
+        for (int i = tid; i < n_audio; i += kModemThreads) {
+            const int k = i + H;
+            const float yi = src[k - 2 * kHilbM].x;
+            float yq = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2 * kHilbM; ++t) yq = fmaf(mc->hilb60[t], src[k - (2 * t + 1)].y, yq);
+            const float v = yi - yq;
+            cfg.audio[A0 + i] = v;                                // unscaled: demod_audio_interp applies the block gain
+            lmax = fmaxf(lmax, v);                                // signed maximum from 0 (:184-190)
         }
     } else {  // USB / LSB
         const bool usb = (cfg.modem == CSDR_MODEM_USB);
@@ -819,6 +904,36 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     const float *arms = arms_all + (size_t)au.arms_idx * kArms * kArmTaps;
     const bool autogain = !(cfg.modem == CSDR_MODEM_NBFM || cfg.modem == CSDR_MODEM_FM);
     const float2 *iq = cfg.iq + (size_t)dyn.hist_parity * ((size_t)kIqHist + cfg.cap_iq) + kIqHist;   // iq[j], j >= -kIqHist
+    if (cfg.modem == CSDR_MODEM_CW) {
+        // ModemCW.cpp:181-203: the auto-gain of block b from the maxima of the blocks before it (recurrence replayed from the
+        // batch-entering state), gain in dB and back as the reference does, applied to the unscaled audio demod_modem wrote
+        const float *agc_in = cfg.agc + 4 * dyn.hist_parity;
+        float ceil_ = agc_in[0], ma = agc_in[1], maa = agc_in[2];
+        for (int bb = 0; bb <= b; ++bb) {
+            ma = ma + (ceil_ - ma) * 0.025f;
+            maa = maa + (ma - maa) * 0.025f;
+            ceil_ = cfg.blockmax[bb];
+        }
+        const float gain_db = 10.0f * log10f(0.5f / maa);
+        const float g = powf(10.0f, gain_db / 10.0f);
+        const int aS = cfg.rs_au.S;
+        const int a0 = pl[b].q0 << aS, n_audio = (pl[b + 1].q0 << aS) - a0;
+        float lpk = 0.f;
+        double lsum = 0.0;
+        for (int i = tid; i < n_audio; i += kModemThreads) {
+            const float v = cfg.audio[a0 + i] * g;
+            cfg.audio[a0 + i] = v;
+            lpk = fmaxf(lpk, fabsf(v));
+            lsum += (double)fabsf(v);
+        }
+        const float pk = block_max_float(lpk, s_redf);
+        const double sm = block_sum_double(lsum, s_red);
+        if (tid == 0) {
+            cfg.bout[b].audio_peak = pk; cfg.bout[b].level_accum = sm; cfg.bout[b].level_count = n_audio;
+            if (b == NB - 1) { float *agc_out = cfg.agc + 4 * (dyn.hist_parity ^ 1); agc_out[0] = ceil_; agc_out[1] = ma; agc_out[2] = maa; }
+        }
+        return;
+    }
     if (cfg.modem == CSDR_MODEM_IQ) {
         // ModemIQ::demodulate (ModemIQ.cpp:41-61): stereo frames (imag, real) of the resampled IQ, no filtering, no gain;
         // level from the IQ magnitudes like the other non-signal-output modems (DemodulatorThread.cpp:156-162)

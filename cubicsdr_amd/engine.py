@@ -56,7 +56,8 @@ class Context:
         return ms.value
 
     def profile_enable(self, on=True):
-        H.check(self._l.csdr_ctx_profile_enable(self.h, int(bool(on))))
+        """True / 1: time every launch; an integer P > 1: every P-th launch of each kernel; False: off"""
+        H.check(self._l.csdr_ctx_profile_enable(self.h, int(on)))
 
     def profile(self):
         """-> {kernel name: (total_ms, launches)} accumulated since profile_enable(True)"""

@@ -69,6 +69,7 @@ public:
         if (t == "AM") return 6000;
         if (t == "USB" || t == "LSB") return 5400;
         if (t == "I/Q") return 48000;                         // ModemIQ.cpp:35-37
+        if (t == "CW") return 500;                            // ModemCW.cpp:107-109 (MIN_BANDWIDTH)
         return 12500;
     }
     static int modemId(const std::string &t) {
@@ -78,6 +79,7 @@ public:
         if (t == "USB") return CSDR_MODEM_USB;
         if (t == "LSB") return CSDR_MODEM_LSB;
         if (t == "I/Q") return CSDR_MODEM_IQ;
+        if (t == "CW") return CSDR_MODEM_CW;
         return -1;
     }
 

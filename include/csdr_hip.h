@@ -60,8 +60,9 @@ void *csdr_ctx_stream(csdr_ctx *ctx);              /* the boundary hipStream_t *
  * stream on both sides, so the bracket covers exactly the work enqueued between the two calls; returns milliseconds. */
 int  csdr_ctx_timer_start(csdr_ctx *ctx);
 int  csdr_ctx_timer_stop(csdr_ctx *ctx, float *ms);
-/* Optional per-kernel profile: while enabled every kernel launch of this ctx is bracketed by HIP events on the
- * stream it is launched on; fetch returns the accumulated device time and launch count of kernel `id`. */
+/* Optional per-kernel profile: while enabled (on = 1) every kernel launch of this ctx -- or, with on = P > 1, every P-th
+ * launch of each kernel -- is bracketed by HIP events on the stream it is launched on; fetch returns the accumulated
+ * device time and the number of bracketed launches of kernel `id`. */
 int  csdr_ctx_profile_enable(csdr_ctx *ctx, int on);
 int  csdr_ctx_profile_num_kernels(void);
 const char *csdr_ctx_profile_kernel_name(int id);
@@ -115,6 +116,8 @@ int  csdr_post_read_channel(csdr_post *post, int ch, float *host_out, int cap_sa
 #define CSDR_MODEM_AM   2   /* ModemAM.cpp:29-50    |x| -> 51-tap DC notch, auto-gain */
 #define CSDR_MODEM_USB  3   /* ModemUSB.cpp:43-64   fs/4 shift, 6th-order Butterworth, Hilbert, upper sideband */
 #define CSDR_MODEM_LSB  4   /* ModemLSB.cpp         mirror of USB, lower sideband */
+#define CSDR_MODEM_CW   6   /* ModemCW.cpp:155-209  msresamp_cccf interpolation to the audio rate, 650 Hz beep oscillator, c2r Hilbert
+                             * (upper sideband), auto-gain in dB; bandwidth floor 500 Hz (:100-104) */
 #define CSDR_MODEM_IQ   5   /* ModemIQ.cpp:41-61    stereo pass-through of the resampled IQ (L = imag, R = real); the
                              * bandwidth is forced to the audio rate (checkSampleRate :31-33); 2 floats per IQ sample */
 

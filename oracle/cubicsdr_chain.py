@@ -104,6 +104,7 @@ class RefDemod:
             bw += 1                                                      # ModemUSB.cpp:29-37
         if modem == "I/Q":
             bw = int(audio_rate)                                         # ModemIQ.cpp:31-33
+        self.cw_offset = 650.0                                           # mBeepFrequency, ModemCW.cpp:17
         self.bandwidth = bw
         self.chan_rate = int(chan_rate)
         self.nco = L.nco_crcf_create(A.LIQUID_VCO)                       # DemodulatorPreThread.cpp:22
@@ -118,6 +119,12 @@ class RefDemod:
             self.fm = L.freqdem_create(0.5)                              # ModemNBFM.cpp:7
         elif modem == "I/Q":
             pass                                                         # ModemIQ::buildKit: no DSP objects
+        elif modem == "CW":
+            self.cw_lo = L.nco_crcf_create(A.LIQUID_NCO)                 # ModemCW.cpp:22
+            self.cw_hilb = L.firhilbf_create(5, 60.0)                    # :23
+            self.cw_resamp = L.msresamp_cccf_create(float(np.float32(self.au_ratio)), 60.0)   # buildKit :124
+            self.cw_gain = np.float32(15.0)                              # mGain :18 (overwritten while mAutoGain is on)
+            self.use_signal_output = True                                # :24
         elif modem == "AM":
             self.dcb = L.firfilt_rrrf_create_dc_blocker(25, 30.0)        # ModemAM.cpp:9
         else:
@@ -163,6 +170,24 @@ class RefDemod:
             audio[1::2] = iq.real
             accum = float(np.sum(np.sqrt(iq.real.astype(np.float64) ** 2 + iq.imag.astype(np.float64) ** 2)))
             return dict(audio=audio, level_accum=accum, level_count=n, peak=float(np.max(np.abs(audio))), demod=audio.copy(), channels=2)
+        if self.modem == "CW":                                           # ModemCW::demodulate :155-209
+            f32 = np.float32
+            cx = np.empty(int(math.ceil(n * self.au_ratio)) + 512, np.complex64)      # initOutputBuffers :140
+            nw = C.c_uint()
+            L.msresamp_cccf_execute(self.cw_resamp, _cptr(iq), n, _cptr(cx), C.byref(nw))   # :163
+            m = nw.value
+            L.nco_crcf_set_frequency(self.cw_lo, float(f32(f32(2.0) * f32(math.pi) * f32(self.cw_offset) / f32(self.audio_rate))))   # :171
+            d = np.empty(m, np.float32)
+            L.oracle_cw_block(C.c_void_p(self.cw_lo), C.c_void_p(self.cw_hilb), _cptr(np.ascontiguousarray(cx[:m])), m, _cptr(d))   # :174-178
+            demod_unscaled = d.copy()
+            self.ceil_ma = f32(self.ceil_ma + f32(f32(self.ceil - self.ceil_ma) * f32(0.025)))            # :182-183
+            self.ceil_maa = f32(self.ceil_maa + f32(f32(self.ceil_ma - self.ceil_maa) * f32(0.025)))
+            self.ceil = f32(max(0.0, float(d.max()))) if m else f32(0)                                    # :184-190 (signed maximum from 0)
+            self.cw_gain = f32(f32(10.0) * f32(np.log10(f32(f32(0.5) / self.ceil_maa))))                  # :192
+            audio = (d * f32(np.power(f32(10.0), f32(self.cw_gain / f32(10.0))))).astype(np.float32)     # :196-198
+            accum = float(np.sum(np.abs(audio.astype(np.float64))))
+            peak = float(np.max(np.abs(audio))) if m else 0.0
+            return dict(audio=audio, level_accum=accum, level_count=m, peak=peak, demod=demod_unscaled)
         d = np.empty(n, np.float32)
         if self.modem in ("NBFM", "FM"):
             L.freqdem_demodulate_block(self.fm, _cptr(iq), n, _cptr(d))                  # ModemNBFM.cpp:36

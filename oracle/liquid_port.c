@@ -423,6 +423,12 @@ int msresamp_crcf_execute(void *p, cf32 *x, unsigned nx, cf32 *y, unsigned *ny_o
     *ny_out = ny;
     return 0;
 }
+/* msresamp_cccf: the complex-coefficient instance.  Its prototype filters are the same real designs (centre frequency 0)
+ * stored as complex numbers with zero imaginary part, so the arithmetic is that of msresamp_crcf. */
+void *msresamp_cccf_create(float r, float As) { return msresamp_crcf_create(r, As); }
+int msresamp_cccf_destroy(void *p) { return msresamp_crcf_destroy(p); }
+int msresamp_cccf_execute(void *p, cf32 *x, unsigned nx, cf32 *y, unsigned *ny_out) { return msresamp_crcf_execute(p, x, nx, y, ny_out); }
+
 int msresamp_rrrf_execute(void *p, float *x, unsigned nx, float *y, unsigned *ny_out)
 {
     msresamp_t *q = (msresamp_t *)p;
@@ -771,6 +777,17 @@ int oracle_firpfbch2_block(void *q, unsigned M, cf32 *x, unsigned ncalls, cf32 *
 int oracle_am_block(void *dcblock, cf32 *x, unsigned n, float *y)
 { for (unsigned i = 0; i < n; i++) { float I = x[i].re, Q = x[i].im; firfilt_rrrf_push(dcblock, sqrtf(I * I + Q * Q)); firfilt_rrrf_execute(dcblock, &y[i]); } return 0; }
 /* ModemUSB.cpp:54-61 (usb=1) / ModemLSB.cpp (usb=0) */
+/* ModemCW.cpp:175-180: mix up by the beep-frequency oscillator, step it, keep the upper-sideband output of the c2r Hilbert transform */
+int oracle_cw_block(void *nco, void *hilb, cf32 *in, unsigned n, float *out)
+{
+    for (unsigned i = 0; i < n; i++) {
+        cf32 sig; float lsb;
+        nco_crcf_mix_up(nco, in[i], &sig);
+        nco_crcf_step(nco);
+        firhilbf_c2r_execute(hilb, sig, &lsb, &out[i]);
+    }
+    return 0;
+}
 int oracle_ssb_block(void *nco, void *iir, void *hilb, int usb, cf32 *in, unsigned n, float *out)
 {
     for (unsigned i = 0; i < n; i++) {

@@ -108,6 +108,14 @@ float msresamp_crcf_get_delay(obj q) { return msresamp_crcf_get_delay_get()(q); 
 FN(int, msresamp_crcf_execute, obj, cf32 *, unsigned, cf32 *, unsigned *)
 int msresamp_crcf_execute(obj q, cf32 *x, unsigned nx, cf32 *y, unsigned *ny) { return msresamp_crcf_execute_get()(q, x, nx, y, ny); }
 
+/* msresamp_cccf (ModemCW.cpp:124,163: complex interpolation of the IQ stream to the audio rate) */
+FN(obj, msresamp_cccf_create, float, float)
+obj msresamp_cccf_create(float r, float as) { return msresamp_cccf_create_get()(r, as); }
+FN(int, msresamp_cccf_destroy, obj)
+int msresamp_cccf_destroy(obj q) { return msresamp_cccf_destroy_get()(q); }
+FN(int, msresamp_cccf_execute, obj, cf32 *, unsigned, cf32 *, unsigned *)
+int msresamp_cccf_execute(obj q, cf32 *x, unsigned nx, cf32 *y, unsigned *ny) { return msresamp_cccf_execute_get()(q, x, nx, y, ny); }
+
 FN(obj, msresamp_rrrf_create, float, float)
 obj msresamp_rrrf_create(float r, float as) { return msresamp_rrrf_create_get()(r, as); }
 FN(int, msresamp_rrrf_destroy, obj)
@@ -270,6 +278,17 @@ int oracle_firpfbch2_block(obj q, unsigned M, cf32 *x, unsigned ncalls, cf32 *y)
 int oracle_am_block(obj dcblock, cf32 *x, unsigned n, float *y)
 { for (unsigned i = 0; i < n; i++) { float I = x[i].re, Q = x[i].im; firfilt_rrrf_push(dcblock, sqrtf(I * I + Q * Q)); firfilt_rrrf_execute(dcblock, &y[i]); } return 0; }
 /* ModemUSB.cpp:54-61 (usb=1) / ModemLSB.cpp (usb=0) */
+/* ModemCW.cpp:175-180: mix up by the beep-frequency oscillator, step it, keep the upper-sideband output of the c2r Hilbert transform */
+int oracle_cw_block(obj nco, obj hilb, cf32 *in, unsigned n, float *out)
+{
+    for (unsigned i = 0; i < n; i++) {
+        cf32 sig; float lsb;
+        nco_crcf_mix_up(nco, in[i], &sig);
+        nco_crcf_step(nco);
+        firhilbf_c2r_execute(hilb, sig, &lsb, &out[i]);
+    }
+    return 0;
+}
 int oracle_ssb_block(obj nco, obj iir, obj hilb, int usb, cf32 *in, unsigned n, float *out)
 {
     for (unsigned i = 0; i < n; i++) {

@@ -85,6 +85,11 @@ def test_emu_mixed_modems(ctx):
     G.test_mixed_modems_streaming(ctx)
 
 
+@full
+def test_emu_cw(ctx):
+    G.test_cw_modem(ctx)
+
+
 def test_emu_iq_passthrough(ctx):
     G.test_iq_passthrough_modem(ctx)
 
@@ -144,3 +149,7 @@ def test_emu_spectrum_many_frames(ctx):
 @full
 def test_emu_retune_skip_inactive(ctx):
     G.test_retune_skip_and_inactive(ctx)
+
+
+def test_emu_error_codes(ctx):
+    G.test_error_codes_and_edge_inputs(ctx)

@@ -147,7 +147,7 @@ def _run_demods(ctx, fs, M, block, kinds, n_blocks, batch, bw=None, seed=3, over
     from oracle.cubicsdr_chain import RefDemod, RefSDRPost
     center = 100000000
     freqs = demod_frequencies(center, fs, len(kinds))
-    default_bw = {"NBFM": 12500, "FM": 200000, "AM": 6000, "USB": 5400, "LSB": 5400, "I/Q": 48000}
+    default_bw = {"NBFM": 12500, "FM": 200000, "AM": 6000, "USB": 5400, "LSB": 5400, "I/Q": 48000, "CW": 500}
     bws = [bw[k] if bw else default_bw[k] for k in kinds] if not isinstance(bw, list) else bw
     demods = list(zip(kinds, freqs))
     x = synth_iq(n_blocks * block, fs, center, demods, seed=seed)
@@ -252,6 +252,18 @@ def test_iq_passthrough_modem(ctx):
     got, want = _run_demods(ctx, 2400000, 4, 40000, ["I/Q", "NBFM", "I/Q"], 6, 3, seed=29)
     print(_compare(got, want, "iq"))
     assert got[0][0]["n_audio"] == 2 * got[0][0]["n_iq"]
+
+
+def test_cw_modem(ctx):
+    """ModemCW: 500 Hz of IQ interpolated x96 to the audio rate (msresamp_cccf: arbitrary stage + six x2 stages), 650 Hz beep
+    oscillator, c2r Hilbert, auto-gain through dB.  14 blocks so that the keyed carrier is well through the 500 S/s filters;
+    batches of 7 exercise the gain replay and the oscillator / resampler phases across batches."""
+    # (a 32 kS/s channel: from the 600 kS/s channels of the other tests 500 Hz would take a ten-stage IQ cascade, which the
+    #  front-end does not carry history for)
+    got, want = _run_demods(ctx, 128000, 4, 2132, ["CW", "NBFM", "CW"], 14, 7, seed=33)
+    w = _compare(got, want, "cw")
+    print(w)
+    assert max(g["peak"] for g in got[0]) > 0.05          # the tone actually came through
 
 
 def test_demods_behind_oversampled_channelizer(ctx):
@@ -652,3 +664,77 @@ def test_retune_skip_and_inactive(ctx):
             assert rel_err(bank.iq(i), riq) < TOL, (b, i)
             assert rel_err(bank.audio(i), want["audio"]) < TOL, (b, i)
     post.close(); bank.close()
+
+
+# ----------------------------------------------------------------------------------------------- error behaviour
+def test_error_codes_and_edge_inputs(ctx):
+    """The ABI never throws and never falls back: bad arguments, state errors, capacity overruns and not-built features come
+    back as negative codes with a message; nothing is half-applied (a following valid call still gives reference results)."""
+    import ctypes as C
+    import cubicsdr_amd.hip as H
+    from cubicsdr_amd.engine import DemodBank, SDRPost, SpectrumProcessor
+    from oracle.cubicsdr_chain import RefSpectrum
+    L = H.lib()
+    EINVAL, ESTATE, ERANGE, EUNSUP = -1, -4, -5, -6
+    assert L.csdr_strerror(0) == b"ok" or L.csdr_strerror(0)
+    post = C.c_void_p()
+    assert L.csdr_post_create(ctx.h, C.byref(post)) == 0
+    buf = np.zeros(64, np.complex64)
+    assert L.csdr_post_execute(post, buf.ctypes.data_as(C.c_void_p), 0, 1, 40, 0) == ESTATE          # not configured
+    assert L.csdr_post_configure(post, 2400000, 5, H.CSDR_POST_PFBCH, 40000, 1) in (EINVAL, EUNSUP)     # odd channel count
+    assert L.csdr_post_configure(post, 2400000, 4, H.CSDR_POST_SINGLE, 40000, 1) == EINVAL             # SINGLE <=> one channel
+    assert L.csdr_post_configure(post, 2400000, 4, 7, 40000, 1) == EINVAL                              # unknown mode
+    assert L.csdr_post_configure(post, 2400000, 4, H.CSDR_POST_PFBCH, 40002, 1) == EINVAL              # block not a multiple of M
+    assert L.csdr_post_configure(post, 2400000, 4, H.CSDR_POST_PFBCH, 40000, 2) == 0
+    x = synth_iq(3 * 40000, 2400000, 0, [("NBFM", 300000.0)], seed=61)
+    assert L.csdr_post_execute(post, x.ctypes.data_as(C.c_void_p), 0, 3, 40000, 0) == ERANGE           # more blocks than configured
+    assert L.csdr_post_execute(post, x.ctypes.data_as(C.c_void_p), 0, 1, 40002, 0) == ERANGE           # block longer than configured
+    assert L.csdr_post_execute(post, x.ctypes.data_as(C.c_void_p), 0, 1, 39998, 0) == EINVAL           # not a multiple of M
+    assert L.csdr_post_execute(post, None, 0, 1, 40000, 0) == EINVAL
+    assert b"" != L.csdr_last_error()
+    n = C.c_int()
+    out = np.zeros(8, np.complex64)
+    assert L.csdr_post_execute(post, x.ctypes.data_as(C.c_void_p), 0, 2, 40000, 0) == 0
+    assert L.csdr_post_read_channel(post, 0, out.ctypes.data_as(C.c_void_p), 8, C.byref(n)) == ERANGE  # needs 20000 samples
+    assert L.csdr_post_read_channel(post, 9, out.ctypes.data_as(C.c_void_p), 8, C.byref(n)) == EINVAL
+    # bank: slot range, unknown modem, bandwidth above the channel rate (the reference would interpolate: not built)
+    bank = C.c_void_p()
+    assert L.csdr_bank_create(ctx.h, 2, 2, C.byref(bank)) == 0
+    prm = H.DemodParams(H.CSDR_MODEM_NBFM, 12500, 48000, 0, 300000)
+    assert L.csdr_bank_configure_slot(bank, 5, C.byref(prm), post) == EINVAL
+    bad = H.DemodParams(17, 12500, 48000, 0, 300000)
+    assert L.csdr_bank_configure_slot(bank, 0, C.byref(bad), post) == EUNSUP
+    wide = H.DemodParams(H.CSDR_MODEM_FM, 900000, 48000, 0, 300000)
+    assert L.csdr_bank_configure_slot(bank, 0, C.byref(wide), post) == EUNSUP
+    assert L.csdr_bank_configure_slot(bank, 0, C.byref(prm), post) == 0
+    res = (H.BlockResult * 1)()
+    assert L.csdr_bank_execute(bank, post) == 0
+    assert L.csdr_bank_fetch_results(bank, 0, res, 1, C.byref(n)) == ERANGE                            # two blocks, room for one
+    # a demodulator outside the span: routed nowhere, no blocks (updateActiveDemodulators would have parked it)
+    assert L.csdr_bank_set_frequency(bank, 0, 50000000) == 0
+    assert L.csdr_bank_execute(bank, post) == 0
+    res2 = (H.BlockResult * 2)()
+    assert L.csdr_bank_fetch_results(bank, 0, res2, 2, C.byref(n)) == 0 and (n.value == 0 or all(r.skipped for r in res2[:n.value]))
+    L.csdr_bank_destroy(bank)
+    L.csdr_post_destroy(post)
+    # spectrum: sizes, modes, capacity; a rejected call leaves the averagers untouched
+    spec = C.c_void_p()
+    assert L.csdr_spec_create(ctx.h, C.byref(spec)) == 0
+    assert L.csdr_spec_process(spec, x.ctypes.data_as(C.c_void_p), 0, 1, 4096, 0) == ESTATE
+    assert L.csdr_spec_setup(spec, 1000, 4) == EUNSUP                                                  # not a power of two
+    assert L.csdr_spec_setup(spec, 512, 0) == EINVAL
+    assert L.csdr_spec_setup(spec, 512, 4) == 0
+    assert L.csdr_spec_process(spec, x.ctypes.data_as(C.c_void_p), 0, 1, 4096, 9) == EINVAL            # unknown mode
+    assert L.csdr_spec_process(spec, x.ctypes.data_as(C.c_void_p), 0, 1, 600, H.CSDR_SPEC_FIRST_FRAME) == EINVAL   # short input needs LINES
+    assert L.csdr_spec_process(spec, x.ctypes.data_as(C.c_void_p), 0, 1, 2000, H.CSDR_SPEC_LINES) == EINVAL        # long input is not a line
+    assert L.csdr_spec_process(spec, x.ctypes.data_as(C.c_void_p), 0, 9, 1024, H.CSDR_SPEC_CONTIGUOUS) == ERANGE   # 9 frames > max_frames
+    pts = np.zeros(1024, np.float32)
+    ce, fl = C.c_double(), C.c_double()
+    assert L.csdr_spec_fetch(spec, 0, pts.ctypes.data_as(C.c_void_p), 1024, C.byref(ce), C.byref(fl)) == EINVAL   # no frame yet
+    assert L.csdr_spec_process(spec, x.ctypes.data_as(C.c_void_p), 0, 1, 1024, H.CSDR_SPEC_FIRST_FRAME) == 0
+    assert L.csdr_spec_fetch(spec, 0, pts.ctypes.data_as(C.c_void_p), 100, C.byref(ce), C.byref(fl)) == ERANGE
+    assert L.csdr_spec_fetch(spec, 0, pts.ctypes.data_as(C.c_void_p), 1024, C.byref(ce), C.byref(fl)) == 0
+    ref = RefSpectrum(_backend(), 512)
+    wp, wce, wfl = ref.process_frame(x[:1024])
+    assert rel_err(pts, wp) < TOL and abs(ce.value - wce) <= TOL * abs(wce)
+    L.csdr_spec_destroy(spec)
