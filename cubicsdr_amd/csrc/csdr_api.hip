@@ -644,7 +644,7 @@ static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *
     s.iq = design::plan_msresamp((float)iq_ratio, 60.0f);
     const double au_ratio = double(s.prm.audio_sample_rate) / double(s.prm.bandwidth);   // ModemAnalog.cpp:29-30
     s.au = design::plan_msresamp((float)au_ratio, 60.0f);
-    if (s.iq.S > 8 || s.au.S > kMaxHb) return fail(CSDR_EUNSUPPORTED, "resampling ratio needs %u half-band stages", s.iq.S);
+    if (s.iq.S > kMaxHb || s.au.S > kMaxHb) return fail(CSDR_EUNSUPPORTED, "resampling ratio needs %u half-band stages", s.iq.S);
     if (!s.au.interp) {      // decimating audio resampler: its cascade must fit the carried demodulator-output history
         int64_t lo = -(int64_t)(kArmTaps - 1);
         for (int e = (int)s.au.S - 1; e >= 0; --e) lo = 2 * lo - (4 * (int)s.au.m[s.au.S - 1 - e] - 2);

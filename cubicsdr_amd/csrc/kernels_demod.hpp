@@ -22,7 +22,7 @@ constexpr int kMaxHb = 10;        // half-band stages supported per resampler
 constexpr int kHbMaxM = 10;       // largest half-band m (taps: 2m on the filtered branch)
 constexpr int kArmTaps = 14;      // arbitrary resampler: 2 * 7 taps per arm
 constexpr int kArms = 256;
-constexpr int kMixHist = 16384;   // upper bound of the mixed-input history kept per slot (cascade span; S <= 8)
+constexpr int kMixHist = 65536;   // upper bound of the mixed-input history kept per slot (cascade span; S <= 10)
 constexpr int kIqHist = 256;      // resampled-IQ history kept per slot
 constexpr int kDHist = 256;       // scaled demodulator-output history kept per slot (>= span of a decimating audio cascade)
 constexpr int kFeThreads = 256;

@@ -266,6 +266,13 @@ def test_cw_modem(ctx):
     assert max(g["peak"] for g in got[0]) > 0.05          # the tone actually came through
 
 
+def test_cw_from_a_wide_channel_ten_stage_cascade(ctx):
+    """500 Hz CW straight from a 600 kS/s channel: the IQ msresamp_crcf runs TEN half-band stages (span ~46 000 inputs, more
+    than a block: the carried mixed-input history and the warm-up re-derivation are exercised at their deepest)."""
+    got, want = _run_demods(ctx, 2400000, 4, 40000, ["CW", "NBFM"], 12, 4, seed=35)
+    print(_compare(got, want, "cw10"))
+
+
 def test_demods_behind_oversampled_channelizer(ctx):
     """chanMode 2: the demodulators see their channel at 2 * chanBw (runDemodChannels(chanBw * 2), :510), so the IQ
     resampler ratio and cascade depth change; mixed modems over 6 blocks in batches of 2."""
