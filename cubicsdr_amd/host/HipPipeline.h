@@ -121,9 +121,17 @@ public:
             if (*it == d) { used_.erase(d->slot()); demods_.erase(it); break; }
     }
     int capacity() const { return max_; }
+    // the selected ("current") modem: its channel is what SDRPostThread taps for the demodulator spectrum view
+    // (DemodulatorMgr.cpp:207-250, :285-290; runDemodChannels :304, :334, :383-387)
+    void setActiveDemodulator(const DemodulatorInstancePtr &d, bool temporary = true) {
+        std::lock_guard<std::recursive_mutex> g(mu_);
+        if (!temporary) currentModem_ = d;
+    }
+    DemodulatorInstancePtr getCurrentModem() { std::lock_guard<std::recursive_mutex> g(mu_); return currentModem_; }
 
 private:
     std::recursive_mutex mu_;
+    DemodulatorInstancePtr currentModem_;
     std::vector<DemodulatorInstancePtr> demods_;
     std::map<int, bool> used_;
     int max_;
@@ -208,6 +216,23 @@ private:
         if (run.empty()) return;                                                     // :436 "if (!runDemods.empty())"
         csdr_must(csdr_post_execute(post_, (const float *)in.data.data(), 0, 1, n, in.frequency), "csdr_post_execute");
         csdr_must(csdr_bank_execute(bank_, post_), "csdr_bank_execute");
+        // the active demodulator's channel also feeds the demodulator spectrum (:289-291 single channel; :334, :383-387)
+        auto iqActive = std::static_pointer_cast<DemodulatorThreadInputQueue>(getOutputQueue("IQActiveDemodVisualDataOutput"));
+        DemodulatorInstancePtr cur = mgr_->getCurrentModem();
+        if (iqActive && cur && cur->isActive()) {
+            const int ch = csdr_post_channel_at(post_, cur->getFrequency());
+            if (ch >= 0) {
+                DemodulatorThreadIQDataPtr tap = visualBuffers_.getBuffer();
+                const int cnt = n / std::max(1, (int)(in.sampleRate / std::max(1LL, (long long)csdr_post_channel_rate(post_)))) + 8;
+                tap->data.resize((size_t)cnt);
+                int got = 0;
+                csdr_must(csdr_post_read_channel(post_, ch, (float *)tap->data.data(), cnt, &got), "csdr_post_read_channel");
+                tap->data.resize((size_t)got);
+                tap->frequency = M > 1 ? csdr_post_channel_center(post_, ch) : in.frequency;
+                tap->sampleRate = csdr_post_channel_rate(post_);
+                iqActive->try_push(tap);                                              // never blocks (:386)
+            }
+        }
         for (auto &d : run) finishDemod(*d);
     }
 

@@ -191,6 +191,17 @@ static int run_gpu() {
         auto d = mgr.newThread();
         d->setDemodulatorType("NBFM");
         d->setFrequency(center + 250000);
+        // demodulator spectrum (CubicSDR.cpp:373-381): the selected modem's channel -> a second processor in view mode
+        mgr.setActiveDemodulator(d, false);
+        SpectrumVisualProcessor demodSpec(ctx);
+        auto pipeDemodIQVisualData = std::make_shared<DemodulatorThreadInputQueue>();
+        auto demodSpectrumOut = std::make_shared<SpectrumVisualDataQueue>();
+        post.setOutputQueue("IQActiveDemodVisualDataOutput", pipeDemodIQVisualData);
+        demodSpec.setInput(pipeDemodIQVisualData);
+        demodSpec.attachOutput(demodSpectrumOut);
+        demodSpec.setup(1024);                                                       // DEFAULT_DMOD_FFT_SIZE
+        demodSpec.setView(true, center + 250000, 300000);
+        int ndemodspec = 0;
         std::thread tp(&IOThread::threadMain, &post);
         // FM carrier at +250 kHz, 1 kHz tone, 2.5 kHz deviation; 12 blocks = 0.2 s
         const double dev = 2500.0, ft = 1000.0, amp = 0.5;
@@ -208,6 +219,16 @@ static int run_gpu() {
             CHECK(pipeSDRIQData->push(blk, 2000000));
             while (post.blocksProcessed.load() <= b) std::this_thread::sleep_for(std::chrono::milliseconds(1));
             if (b == 5) { spec.setPeakHold(true); spec.setHideDC(true); }
+            demodSpec.run();
+            SpectrumVisualDataPtr dv;
+            if (demodSpectrumOut->try_pop(dv)) {
+                ++ndemodspec;
+                CHECK(dv->spectrum_points.size() == 2048);
+                // channel 0 is centred on `center`; the view is centred on the carrier (+250 kHz): it peaks mid-display
+                int best = 0; float bv = -1e9f;
+                for (int x = 0; x < 1024; ++x) if (dv->spectrum_points[2 * x + 1] > bv) { bv = dv->spectrum_points[2 * x + 1]; best = x; }
+                if (b >= 3) CHECK(std::abs(best - 512) <= 4);
+            }
             spec.run();
             SpectrumVisualDataPtr sv;
             if (spectrumOut->try_pop(sv)) {
@@ -223,6 +244,8 @@ static int run_gpu() {
             }
         }
         CHECK(nspec >= 10);
+        std::printf("demodulator-view spectra %d\n", ndemodspec);
+        CHECK(ndemodspec >= 9);
         // audio: ~800 samples per block at 48 kHz; after the filters settle the output is a 1 kHz tone of amplitude
         // dev / (kf * fs_demod) = 2500 / (0.5 * 12500) = 0.4
         auto aq = d->getAudioOutputQueue();
