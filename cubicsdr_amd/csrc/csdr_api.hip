@@ -244,8 +244,7 @@ static int chan_geometry(int M, int hop, ChanGeom &g) {
     g.fpw = 0;   // set per launch
     // frames per workgroup: the largest power of two <= 64 whose two row arrays fit the LDS budget
     const size_t budget = (M <= 512) ? 64 * 1024 : 72 * 1024;
-    static const int tf_cap = getenv("CSDR_CHAN_TF") ? atoi(getenv("CSDR_CHAN_TF")) : 64;    // experiment knob
-    for (int tf = std::max(1, std::min(128, tf_cap)); tf >= 1; tf >>= 1) {
+    for (int tf = 64; tf >= 1; tf >>= 1) {
         g.TF = tf;
         g.lgTF = 0; while ((1 << g.lgTF) < tf) ++g.lgTF;
         const int q = 32 / std::min(tf, 32);              // row stride = q * odd: lanes along t hit distinct banks
@@ -258,8 +257,6 @@ static int chan_geometry(int M, int hop, ChanGeom &g) {
     // workgroup size: four waves, one per SIMD (five waves balance M = 20 better on paper -- 10 FIR wave-iterations, 4 + 5 DFT
     // wave-items -- but measured 20 % slower on MI355X: the fifth wave doubles up on one SIMD)
     g.threads = 256;
-    static const int thr_env = getenv("CSDR_CHAN_THREADS") ? atoi(getenv("CSDR_CHAN_THREADS")) : 0;    // experiment knob
-    if (thr_env >= 64 && thr_env <= 64 * kChanMaxWaves && thr_env % 64 == 0) g.threads = thr_env;
     return CSDR_OK;
 }
 
@@ -875,8 +872,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     const int fe_slots = c->wg_slots(demod_frontend_s<5, 2048>, kFeThreads, fes_lds_bytes<5, 2048>());
     int P = (int)std::max<int64_t>(1, std::min<int64_t>(total / std::max<int64_t>(4096, 4 * (int64_t)warm_max), 4096));
     {
-        static const int p_env = getenv("CSDR_FE_P") ? atoi(getenv("CSDR_FE_P")) : 0;      // experiment knob
-        const int per_slot = p_env > 0 ? p_env : fe_slots / std::max(1, n_run) - 1;        // one extra workgroup per slot carries the histories
+        const int per_slot = fe_slots / std::max(1, n_run) - 1;                            // one extra workgroup per slot carries the histories
         if (per_slot >= 1) P = std::min(P, per_slot);
         else {                                                           // more slots than resident workgroups: whole rounds
             const int rounds = (n_run * 2 + fe_slots - 1) / fe_slots;
@@ -911,10 +907,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     if (grp_n[S_] > 0)                                                                                                                  \
         CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, (demod_frontend_s<S_, CH_>), dim3(P + 1, grp_n[S_]), dim3(kFeThreads), (fes_lds_bytes<S_, CH_>()), \
                     b->cfgs.p, dyns_d, grp_d + grp_off[S_], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p)
-    static const int fe_chunk = getenv("CSDR_FE_CHUNK") ? atoi(getenv("CSDR_FE_CHUNK")) : 2048;   // experiment knob
-    if (fe_chunk == 1024) { CSDR_FE_S(3, 1024); CSDR_FE_S(4, 1024); CSDR_FE_S(5, 1024); }
-    else { CSDR_FE_S(3, 2048); CSDR_FE_S(4, 2048); CSDR_FE_S(5, 2048); }
-    CSDR_FE_S(6, 2048);
+    CSDR_FE_S(3, 2048); CSDR_FE_S(4, 2048); CSDR_FE_S(5, 2048); CSDR_FE_S(6, 2048);
 #undef CSDR_FE_S
     CSDR_HIP_TRY(hipGetLastError());
     // the front-end was the only reader of the channelizer buffer: hand it back to the post object's rotation
