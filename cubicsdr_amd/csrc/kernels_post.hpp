@@ -304,8 +304,9 @@ __global__ __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
             const int64_t gi = base - Hs + 2 * (int64_t)p;
             const float2 *src = gi >= 0 ? x + gi : hist + (gi + H);
             if (OS2) {                                    // M / 2 may be odd: 8-byte aligned pairs; the pair may straddle hist | x
-                float2 a = src[0], b2 = (gi + 1 >= 0) ? x[gi + 1] : hist[gi + 1 + H];
-                if (gi + 1 >= n_frames * hop) b2 = make_float2(0.f, 0.f);      // one sample past the batch (odd count): unused
+                const float2 a = src[0];
+                float2 b2 = make_float2(0.f, 0.f);                              // one sample past the batch (odd count): never read, never used
+                if (gi + 1 < n_frames * hop) b2 = (gi + 1 >= 0) ? x[gi + 1] : hist[gi + 1 + H];
                 s_z[2 * p] = a; s_z[2 * p + 1] = b2;
             } else reinterpret_cast<float4 *>(s_z)[p] = *reinterpret_cast<const float4 *>(src);
         }
