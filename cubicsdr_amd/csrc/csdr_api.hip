@@ -622,7 +622,7 @@ static int modem_check_rate(int modem, int bw, int audio_rate) {   // Modem*::ch
 
 static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *prm, const csdr_post *post);
 extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *prm, const csdr_post *post) {
-    if (prm && (prm->modem < CSDR_MODEM_NBFM || prm->modem > CSDR_MODEM_CW)) return fail(CSDR_EUNSUPPORTED, "modem %d", prm->modem);
+    if (prm && (prm->modem < CSDR_MODEM_NBFM || prm->modem > CSDR_MODEM_DSB)) return fail(CSDR_EUNSUPPORTED, "modem %d", prm->modem);
     return bank_configure_slot(b, slot, prm, post);
 }
 static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *prm, const csdr_post *post) {
@@ -673,6 +673,7 @@ static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *
     const size_t o_dh = carve(2 * kDHist * sizeof(float));
     const size_t o_au = carve(cap_audio * sizeof(float));
     const size_t o_agc = carve(8 * sizeof(float));
+    const size_t o_pll = carve(2 * sizeof(uint32_t));
     const size_t o_bm = carve(b->max_blocks * sizeof(float));
     const size_t o_bo = carve(b->max_blocks * sizeof(BlockOut));
     if (s.slab) { (void)hipFree(s.slab); s.slab = nullptr; }
@@ -686,7 +687,7 @@ static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *
     c.modem = s.prm.modem;
     c.hist_len = hist_len;
     c.mixhist = (float2 *)(base + o_mix); c.iq = (float2 *)(base + o_iq); c.d = (float *)(base + o_d); c.dh = (float *)(base + o_dh);
-    c.audio = (float *)(base + o_au); c.agc = (float *)(base + o_agc);
+    c.audio = (float *)(base + o_au); c.agc = (float *)(base + o_agc); c.pll = (uint32_t *)(base + o_pll);   // slab is zeroed: nco_crcf_reset
     c.blockmax = (float *)(base + o_bm); c.bout = (BlockOut *)(base + o_bo);
     c.cap_iq = (int)cap_iq; c.cap_audio = (int)cap_audio;
     const float agc0[8] = {1.0f, 1.0f, 1.0f, 0.f, 1.0f, 1.0f, 1.0f, 0.f};   // ModemAnalog::ModemAnalog(): aOutputCeil(1), MA(1), MAA(1)
@@ -884,7 +885,8 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     const int cap_stream = (max_n_iq + kSsbWarm + 64 + 3) & ~3;
     // CW blocks run the complex audio interpolator in LDS: IQ window + two stage arrays of (block audio + Hilbert reach)
     const int cap_cw = max_cw_audio ? ((max_cw_audio + 4 * kHilbM + 64 + 3) & ~3) : 0;
-    const size_t modem_lds = std::max((size_t)2 * cap_stream * sizeof(float), ((size_t)kCwIqWin + 2 * (size_t)cap_cw) * sizeof(float2)) + 64;
+    const size_t dsb_lds = 1024 * sizeof(float) + (size_t)kModemMaxBlockIq * sizeof(float2);   // DSB: sine table + one block of IQ
+    const size_t modem_lds = std::max(std::max((size_t)2 * cap_stream * sizeof(float), ((size_t)kCwIqWin + 2 * (size_t)cap_cw) * sizeof(float2)), dsb_lds) + 64;
     // LDS of the audio kernel: two ping-pong arrays (stage outputs) and the staged demodulator window (decimating
     // cascades reach back up to kDHist samples and their first stage outputs half the window)
     const int cap_win = (max_n_iq + kDHist + 64 + 3) & ~3;

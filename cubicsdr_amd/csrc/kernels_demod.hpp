@@ -51,6 +51,7 @@ struct SlotCfg {                  // static per configuration, lives in HBM
     float *dh;                    // [2][kDHist]  scaled demodulator-output history, ping-pong
     float *audio;                 // [cap_audio]
     float *agc;                   // [2][4] aOutputCeil, aOutputCeilMA, aOutputCeilMAA (ModemAnalog.h), ping-pong
+    uint32_t *pll;                // [2] DSB Costas loop: oscillator phase word, frequency word (carried across batches)
     float *blockmax;              // [max_blocks]
     struct BlockOut *bout;        // [max_blocks]
     int32_t cap_iq, cap_audio;
@@ -78,6 +79,14 @@ struct BlockOut {
     int32_t level_count;
     float audio_peak;
 };
+
+// phase word of an angle in radians, as nco_crcf_set_frequency / pll_step quantise it (liquid 1.5.0; host twin: design::nco_phase_word)
+__device__ inline uint32_t nco_phase_word_dev(float theta) {
+    float p = (float)((double)theta * 0.159154943091895);
+    p -= truncf(p);
+    if (p < 0.0f) p += 1.0f;
+    return (uint32_t)(long long)(p * 4294967296.0f);
+}
 
 // --- NCO: 1024-entry table, no interpolation (liquid 1.5.0 nco_crcf, both NCO and VCO types) -----------------
 __device__ inline void nco_sincos(const float *tab, uint32_t theta, float &s, float &c) {
@@ -723,6 +732,45 @@ __global__ __launch_bounds__(kModemThreads) void demod_modem(
             d[j0 + i] = acc;
             lmax = fmaxf(lmax, acc);
         }
+    } else if (cfg.modem == CSDR_MODEM_DSB) {
+        // ModemDSB::demodulate -> ampmodem_demodulate, DSB with suppressed carrier (liquid 1.5.0 ampmodem_demod_dsb_pll_costas):
+        //   v = x e^{-j theta};  e = Re v > 0 ? Im v : -Im v;  dtheta += W(alpha e);  theta += W(beta e);  theta += dtheta;
+        //   y = Re v / mod_index          (alpha = 0.001, beta = sqrt(0.001), W = the oscillator's phase-word quantisation)
+        // Every sample's phase depends on the previous one: ONE thread walks the whole batch of this demodulator (the
+        // workgroup of block 0; the table and each block's samples are staged in LDS by all of its threads).
+        if (b != 0) return;
+        float *s_tab = reinterpret_cast<float *>(smem);                        // 1024-entry sine table
+        float2 *s_x = reinterpret_cast<float2 *>(s_tab + 1024);                // one block of resampled IQ (<= kModemMaxBlockIq)
+        for (int i = tid; i < 1024; i += kModemThreads) s_tab[i] = sintab[i];
+        uint32_t th = cfg.pll[0], dth = cfg.pll[1];
+        const float alpha = 0.001f, beta = sqrtf(0.001f);                      // nco_crcf_pll_set_bandwidth(0.001)
+        for (int bb = 0; bb < NB; ++bb) {
+            const int jb = pl[bb].j0, nb = pl[bb + 1].j0 - jb;
+            __syncthreads();
+            for (int i = tid; i < nb; i += kModemThreads) s_x[i] = iq[jb + i];
+            __syncthreads();
+            if (tid == 0) {
+                float mx = 0.0f;
+                for (int i = 0; i < nb; ++i) {
+                    const float2 x = s_x[i];
+                    const unsigned idx = (th + (1u << 21)) >> 22;
+                    const float sn = s_tab[idx & 1023], cs = s_tab[(idx + 256) & 1023];
+                    const float vr = __fadd_rn(__fmul_rn(x.x, cs), __fmul_rn(x.y, sn));       // mix down, the reference's operation order
+                    const float vi = __fsub_rn(__fmul_rn(x.y, cs), __fmul_rn(x.x, sn));
+                    const float e = vr > 0.0f ? vi : -vi;
+                    dth += nco_phase_word_dev(alpha * e);
+                    th += nco_phase_word_dev(beta * e);
+                    th += dth;
+                    const float y = vr / 0.5f;
+                    d[jb + i] = y;
+                    mx = fmaxf(mx, y);
+                }
+                cfg.blockmax[bb] = mx;
+                cfg.bout[bb].level_accum = 0.0; cfg.bout[bb].level_count = 0; cfg.bout[bb].audio_peak = 0.f;
+            }
+        }
+        if (tid == 0) { cfg.pll[0] = th; cfg.pll[1] = dth; }
+        return;
     } else if (cfg.modem == CSDR_MODEM_CW) {
         // ModemCW::demodulate (ModemCW.cpp:155-198) up to the gain: msresamp_cccf interpolation of the IQ stream to the audio
         // rate (arbitrary stage, then x2 half-band stages: the structure of the real audio interpolator, on complex samples),

@@ -70,6 +70,7 @@ public:
         if (t == "USB" || t == "LSB") return 5400;
         if (t == "I/Q") return 48000;                         // ModemIQ.cpp:35-37
         if (t == "CW") return 500;                            // ModemCW.cpp:107-109 (MIN_BANDWIDTH)
+        if (t == "DSB") return 5400;                          // ModemDSB.cpp:25-27
         return 12500;
     }
     static int modemId(const std::string &t) {
@@ -80,6 +81,7 @@ public:
         if (t == "LSB") return CSDR_MODEM_LSB;
         if (t == "I/Q") return CSDR_MODEM_IQ;
         if (t == "CW") return CSDR_MODEM_CW;
+        if (t == "DSB") return CSDR_MODEM_DSB;
         return -1;
     }
 

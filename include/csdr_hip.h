@@ -118,6 +118,8 @@ int  csdr_post_read_channel(csdr_post *post, int ch, float *host_out, int cap_sa
 #define CSDR_MODEM_LSB  4   /* ModemLSB.cpp         mirror of USB, lower sideband */
 #define CSDR_MODEM_CW   6   /* ModemCW.cpp:155-209  msresamp_cccf interpolation to the audio rate, 650 Hz beep oscillator, c2r Hilbert
                              * (upper sideband), auto-gain in dB; bandwidth floor 500 Hz (:100-104) */
+#define CSDR_MODEM_DSB  7   /* ModemDSB.cpp:38-53   ampmodem(0.5, DSB, suppressed carrier): Costas loop around the table oscillator
+                             * (a per-sample feedback loop: one thread per demodulator walks the batch), auto-gain */
 #define CSDR_MODEM_IQ   5   /* ModemIQ.cpp:41-61    stereo pass-through of the resampled IQ (L = imag, R = real); the
                              * bandwidth is forced to the audio rate (checkSampleRate :31-33); 2 floats per IQ sample */
 

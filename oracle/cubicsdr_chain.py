@@ -114,7 +114,7 @@ class RefDemod:
         self.au_ratio = float(audio_rate) / float(bw)                    # ModemAnalog.cpp:29
         self.au = L.msresamp_rrrf_create(self.au_ratio, 60.0)            # :30
         self.ceil, self.ceil_ma, self.ceil_maa = 1.0, 1.0, 1.0           # ModemAnalog ctor
-        self.use_signal_output = modem in ("AM", "USB", "LSB")
+        self.use_signal_output = modem in ("AM", "USB", "LSB", "DSB")
         if modem in ("NBFM", "FM"):
             self.fm = L.freqdem_create(0.5)                              # ModemNBFM.cpp:7
         elif modem == "I/Q":
@@ -125,6 +125,8 @@ class RefDemod:
             self.cw_resamp = L.msresamp_cccf_create(float(np.float32(self.au_ratio)), 60.0)   # buildKit :124
             self.cw_gain = np.float32(15.0)                              # mGain :18 (overwritten while mAutoGain is on)
             self.use_signal_output = True                                # :24
+        elif modem == "DSB":
+            self.dsb = L.ampmodem_create(0.5, 0, 1)                      # ModemDSB.cpp:6 (LIQUID_AMPMODEM_DSB = 0, suppressed carrier)
         elif modem == "AM":
             self.dcb = L.firfilt_rrrf_create_dc_blocker(25, 30.0)        # ModemAM.cpp:9
         else:
@@ -192,6 +194,9 @@ class RefDemod:
         if self.modem in ("NBFM", "FM"):
             L.freqdem_demodulate_block(self.fm, _cptr(iq), n, _cptr(d))                  # ModemNBFM.cpp:36
             autogain = False
+        elif self.modem == "DSB":
+            L.oracle_dsb_block(C.c_void_p(self.dsb), _cptr(iq), n, _cptr(d))             # ModemDSB.cpp:49-51
+            autogain = True
         elif self.modem == "AM":
             L.oracle_am_block(C.c_void_p(self.dcb), _cptr(iq), n, _cptr(d))              # ModemAM.cpp:41-47
             autogain = True

@@ -45,6 +45,8 @@ _SIGS = {
     "msresamp_crcf_print": (c_i, [c_p]),
     "msresamp_crcf_get_delay": (c_f, [c_p]),
     "msresamp_crcf_execute": (c_i, [c_p, c_p, c_u, c_p, c_p]),
+    "ampmodem_create": (c_p, [c_f, c_i, c_i]),
+    "ampmodem_destroy": (c_i, [c_p]),
     "msresamp_cccf_create": (c_p, [c_f, c_f]),
     "msresamp_cccf_destroy": (c_i, [c_p]),
     "msresamp_cccf_execute": (c_i, [c_p, c_p, c_u, c_p, c_p]),

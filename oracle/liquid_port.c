@@ -124,7 +124,7 @@ static float dot_rrrf(const float *h, const float *x, unsigned n)
 
 /* ================================================================== nco_crcf  (liquid v1.5.0 src/nco/src/nco.proto.c; liquid.h nco section)
  * Both LIQUID_NCO and LIQUID_VCO use a 1024-entry sine table without interpolation in this version. */
-typedef struct { int type; float sintab[1024]; uint32_t theta, d_theta; } nco_t;
+typedef struct { int type; float sintab[1024]; uint32_t theta, d_theta; float alpha, beta; } nco_t;
 
 static uint32_t nco_constrain(float theta)
 {
@@ -164,6 +164,11 @@ int nco_crcf_mix_block_up(void *p, cf32 *x, cf32 *y, unsigned n)
 { for (unsigned i = 0; i < n; i++) { nco_crcf_mix_up(p, x[i], &y[i]); nco_crcf_step(p); } return 0; }
 int nco_crcf_mix_block_down(void *p, cf32 *x, cf32 *y, unsigned n)
 { for (unsigned i = 0; i < n; i++) { nco_crcf_mix_down(p, x[i], &y[i]); nco_crcf_step(p); } return 0; }
+/* phase-locked loop of the oscillator (liquid v1.5.0 nco.proto.c): bandwidth -> alpha = bw, beta = sqrt(bw); a step moves the
+ * frequency word by alpha dphi and the phase word by beta dphi, each quantised like set_frequency / set_phase */
+int nco_crcf_pll_set_bandwidth(void *p, float bw) { nco_t *q = (nco_t *)p; q->alpha = bw; q->beta = sqrtf(bw); return 0; }
+int nco_crcf_pll_step(void *p, float dphi)
+{ nco_t *q = (nco_t *)p; q->d_theta += nco_constrain(q->alpha * dphi); q->theta += nco_constrain(q->beta * dphi); return 0; }
 /* test hook: raw phase words */
 void port_nco_get_state(void *p, uint32_t *theta, uint32_t *dtheta) { *theta = ((nco_t *)p)->theta; *dtheta = ((nco_t *)p)->d_theta; }
 
@@ -770,6 +775,36 @@ int fft_execute(void *p)
 /* SDRPostThread.cpp:449-451: one analyzer_execute per M-sample frame */
 int oracle_firpfbch_analyzer_block(void *q, unsigned M, cf32 *x, unsigned nframes, cf32 *y)
 { for (unsigned i = 0; i < nframes; i++) firpfbch_crcf_analyzer_execute(q, x + (size_t)i * M, y + (size_t)i * M); return 0; }
+/* ================================================================== ampmodem, DSB with suppressed carrier  liquid v1.5.0 src/modem/src/ampmodem.c
+ * (ampmodem_create(0.5, LIQUID_AMPMODEM_DSB, 1), ModemDSB.cpp:6).  The demodulator is a Costas loop around the table
+ * oscillator: mix down, phase error = Im(v) signed by Re(v), pll step (bandwidth 0.001), oscillator step, output Re(v) /
+ * mod_index.  (The object also builds a DC blocker, a Hilbert transformer, a low-pass and a delay line: the other modes'.) */
+typedef struct { float mod_index; void *mixer; } ampmodem_t;
+void *ampmodem_create(float mod_index, int type, int suppressed)
+{
+    if (type != 0 || !suppressed) return NULL;   /* only the mode CubicSDR instantiates */
+    ampmodem_t *q = (ampmodem_t *)calloc(1, sizeof(*q));
+    q->mod_index = mod_index;
+    q->mixer = nco_crcf_create(0);
+    nco_crcf_pll_set_bandwidth(q->mixer, 0.001f);
+    nco_crcf_reset(q->mixer);
+    return q;
+}
+int ampmodem_destroy(void *p) { ampmodem_t *q = (ampmodem_t *)p; nco_crcf_destroy(q->mixer); free(q); return 0; }
+int ampmodem_demodulate(void *p, cf32 x, float *y)
+{
+    ampmodem_t *q = (ampmodem_t *)p;
+    cf32 v;
+    nco_crcf_mix_down(q->mixer, x, &v);
+    float phase_error = v.re > 0.0f ? v.im : -v.im;
+    nco_crcf_pll_step(q->mixer, phase_error);
+    nco_crcf_step(q->mixer);
+    *y = v.re / q->mod_index;
+    return 0;
+}
+int oracle_dsb_block(void *q, cf32 *in, unsigned n, float *out)
+{ for (unsigned i = 0; i < n; i++) ampmodem_demodulate(q, in[i], &out[i]); return 0; }
+
 /* SDRPostThread.cpp:505-507: one firpfbch2 execute per M/2 input samples, M outputs each */
 int oracle_firpfbch2_block(void *q, unsigned M, cf32 *x, unsigned ncalls, cf32 *y)
 { for (unsigned i = 0; i < ncalls; i++) firpfbch2_crcf_execute(q, x + (size_t)i * (M / 2), y + (size_t)i * M); return 0; }

@@ -271,6 +271,15 @@ float sincf(float x) { return sincf_get()(x); }
 /* SDRPostThread.cpp:449-451 */
 int oracle_firpfbch_analyzer_block(obj q, unsigned M, cf32 *x, unsigned nframes, cf32 *y)
 { firpfbch_crcf_analyzer_execute_t f = firpfbch_crcf_analyzer_execute_get(); for (unsigned i = 0; i < nframes; i++) f(q, x + (size_t)i * M, y + (size_t)i * M); return 0; }
+/* ampmodem (ModemDSB.cpp:6,49-51): cf32 by value is an 8-byte integer-register aggregate in the MS ABI */
+FN(obj, ampmodem_create, float, int, int)
+obj ampmodem_create(float mod_index, int type, int suppressed) { return ampmodem_create_get()(mod_index, type, suppressed); }
+FN(int, ampmodem_destroy, obj)
+int ampmodem_destroy(obj q) { return ampmodem_destroy_get()(q); }
+FN(int, ampmodem_demodulate, obj, uint64_t, float *)
+int oracle_dsb_block(obj q, cf32 *in, unsigned n, float *out)
+{ ampmodem_demodulate_t f = ampmodem_demodulate_get(); for (unsigned i = 0; i < n; i++) { uint64_t v; memcpy(&v, &in[i], 8); f(q, v, &out[i]); } return 0; }
+
 /* SDRPostThread.cpp:505-507 */
 int oracle_firpfbch2_block(obj q, unsigned M, cf32 *x, unsigned ncalls, cf32 *y)
 { firpfbch2_crcf_execute_t f = firpfbch2_crcf_execute_get(); for (unsigned i = 0; i < ncalls; i++) f(q, x + (size_t)i * (M / 2), y + (size_t)i * M); return 0; }

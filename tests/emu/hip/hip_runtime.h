@@ -124,6 +124,9 @@ static inline T __shfl(T v, int src, int width = 64) {
 // device math the kernels use beyond <cmath>
 using std::max;
 using std::min;
+static inline float __fmul_rn(float a, float b) { return a * b; }      // (the emulation is built with -ffp-contract=off)
+static inline float __fadd_rn(float a, float b) { return a + b; }
+static inline float __fsub_rn(float a, float b) { return a - b; }
 static inline long long min(long long a, long long b) { return a < b ? a : b; }
 static inline long long max(long long a, long long b) { return a > b ? a : b; }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }

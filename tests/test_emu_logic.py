@@ -86,6 +86,11 @@ def test_emu_mixed_modems(ctx):
 
 
 @full
+def test_emu_dsb(ctx):
+    G.test_dsb_modem_costas_loop(ctx)
+
+
+@full
 def test_emu_cw_ten_stage(ctx):
     G.test_cw_from_a_wide_channel_ten_stage_cascade(ctx)
 

@@ -39,6 +39,8 @@ def synth_iq(n, fs, center, demods, seed=0xC0B1C5D2, t0=0, noise=0.05, dc=(0.01,
             x += amp * np.exp(2j * np.pi * (df + 1000.0) * t)
         elif kind == "LSB":
             x += amp * np.exp(2j * np.pi * (df - 1000.0) * t)
+        elif kind == "DSB":
+            x += amp * np.sin(2 * np.pi * 700.0 * t) * np.exp(1j * (0.4 + 2 * np.pi * (df + 35.0) * t))   # suppressed carrier, 35 Hz off tune
         elif kind == "CW":
             x += amp * np.exp(2j * np.pi * (df + 60.0) * t) * (np.floor(t * 40.0) % 2 == 0)    # keyed carrier, 20 Hz dots
         elif kind == "I/Q":
