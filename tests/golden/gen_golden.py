@@ -156,6 +156,28 @@ def main_b():
         xin = rnd(rng, (M // 2) * nc); y = np.zeros(M * nc, np.complex64)
         L.oracle_firpfbch2_block(C.c_void_p(q), M, A.ptr(xin), nc, A.ptr(y))
         g["firpfbch2_M%d_in" % M] = xin; g["firpfbch2_M%d_out" % M] = y
+    # --- ampmodem DSB, suppressed carrier (ModemDSB.cpp:6,49-51): Costas loop pulling in a carrier 0.002 cycles/sample off
+    n = 3000
+    t = np.arange(n)
+    xin = ((np.sin(2 * np.pi * t * 0.01) * np.exp(1j * (0.3 + 2 * np.pi * 0.002 * t))) * 0.4).astype(np.complex64) + rnd(rng, n) * np.float32(0.05)
+    q = L.ampmodem_create(0.5, 0, 1); y = np.zeros(n, np.float32)
+    L.oracle_dsb_block(C.c_void_p(q), A.ptr(xin), n, A.ptr(y))
+    g["ampmodem_dsb_in"] = xin; g["ampmodem_dsb_out"] = y
+    # --- msresamp_cccf interpolation (ModemCW.cpp:124,163): 500 S/s -> 48 kS/s, six blocks of ten samples
+    xin = rnd(rng, 60)
+    q = L.msresamp_cccf_create(float(np.float32(48000 / 500)), 60.0)
+    outs, cnts = [], []
+    for b in range(6):
+        xb = np.ascontiguousarray(xin[b * 10:(b + 1) * 10]); y = np.zeros(10 * 96 + 600, np.complex64); ny = C.c_uint()
+        L.msresamp_cccf_execute(q, A.ptr(xb), 10, A.ptr(y), C.byref(ny))
+        outs.append(y[:ny.value].copy()); cnts.append(ny.value)
+    g["msresamp_cccf_in"] = xin; g["msresamp_cccf_out"] = np.concatenate(outs); g["msresamp_cccf_counts"] = np.array(cnts, np.int64)
+    # --- the CW chain on those samples: beep oscillator + c2r Hilbert (ModemCW.cpp:171-178)
+    lo = L.nco_crcf_create(A.LIQUID_NCO); hb = L.firhilbf_create(5, 60.0)
+    L.nco_crcf_set_frequency(lo, float(np.float32(np.float32(2.0) * np.float32(np.pi) * np.float32(650.0) / np.float32(48000))))
+    cw_in = np.ascontiguousarray(g["msresamp_cccf_out"]); cw = np.zeros(cw_in.size, np.float32)
+    L.oracle_cw_block(C.c_void_p(lo), C.c_void_p(hb), A.ptr(cw_in), cw_in.size, A.ptr(cw))
+    g["cw_chain_out"] = cw
     out = os.path.join(ROOT, "tests", "golden", "liquid_1_5_0_b.npz")
     np.savez_compressed(out, **g)
     print("wrote", out, os.path.getsize(out), "bytes,", len(g), "arrays")

@@ -118,6 +118,31 @@ def test_firpfbch2(P, M):
     assert rel_err(y, G2["firpfbch2_M%d_out" % M]) < TOL
 
 
+def test_dsb_costas_loop_and_cw_chain(P):
+    """ampmodem DSB (suppressed carrier) -- whole loop trajectory -- and the CW chain (msresamp_cccf interpolation, beep
+    oscillator, c2r Hilbert): the restatements against the reference binary's outputs"""
+    G2 = np.load(os.path.join(ROOT, "tests", "golden", "liquid_1_5_0_b.npz"))
+    xin = np.ascontiguousarray(G2["ampmodem_dsb_in"]); y = np.zeros(xin.size, np.float32)
+    q = P.ampmodem_create(0.5, 0, 1)
+    P.oracle_dsb_block(C.c_void_p(q), A.ptr(xin), xin.size, A.ptr(y))
+    assert rel_err(y, G2["ampmodem_dsb_out"]) < TOL
+    xin = np.ascontiguousarray(G2["msresamp_cccf_in"])
+    q = P.msresamp_cccf_create(float(np.float32(48000 / 500)), 60.0)
+    outs, cnts = [], []
+    for b in range(6):
+        xb = np.ascontiguousarray(xin[b * 10:(b + 1) * 10]); yb = np.zeros(10 * 96 + 600, np.complex64); ny = C.c_uint()
+        P.msresamp_cccf_execute(q, A.ptr(xb), 10, A.ptr(yb), C.byref(ny))
+        outs.append(yb[:ny.value].copy()); cnts.append(ny.value)
+    assert cnts == list(G2["msresamp_cccf_counts"])
+    up = np.concatenate(outs)
+    assert rel_err(up, G2["msresamp_cccf_out"]) < TOL
+    lo = P.nco_crcf_create(A.LIQUID_NCO); hb = P.firhilbf_create(5, 60.0)
+    P.nco_crcf_set_frequency(lo, float(np.float32(np.float32(2.0) * np.float32(np.pi) * np.float32(650.0) / np.float32(48000))))
+    cw_in = np.ascontiguousarray(G2["msresamp_cccf_out"]); cw = np.zeros(cw_in.size, np.float32)
+    P.oracle_cw_block(C.c_void_p(lo), C.c_void_p(hb), A.ptr(cw_in), cw_in.size, A.ptr(cw))
+    assert rel_err(cw, G2["cw_chain_out"]) < TOL
+
+
 def test_filters_and_modems(G, P):
     x = np.ascontiguousarray(G["dcblock_in"]); y = np.zeros_like(x)
     P.iirfilt_crcf_execute_block(P.iirfilt_crcf_create_dc_blocker(0.0005), A.ptr(x), x.size, A.ptr(y))
