@@ -958,6 +958,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
         const float *agc_in = cfg.agc + 4 * dyn.hist_parity;
         float ceil_ = agc_in[0], ma = agc_in[1], maa = agc_in[2];
         for (int bb = 0; bb <= b; ++bb) {
+            if (pl[bb + 1].j0 == pl[bb].j0) continue;          // a block without samples never reaches demodulate(): no state change
             ma = ma + (ceil_ - ma) * 0.025f;
             maa = maa + (ma - maa) * 0.025f;
             ceil_ = cfg.blockmax[bb];
@@ -1008,6 +1009,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     float g_cur = 1.0f, g_prev = 1.0f, ceil_ = agc_in[0], ma = agc_in[1], maa = agc_in[2];
     if (autogain) {
         for (int bb = 0; bb <= b; ++bb) {
+            if (pl[bb + 1].j0 == pl[bb].j0) continue;          // a block without samples never reaches demodulate() (ModemAM.cpp:33-36): no state change
             ma = ma + (ceil_ - ma) * 0.025f;
             maa = maa + (ma - maa) * 0.025f;
             ceil_ = cfg.blockmax[bb];
@@ -1042,6 +1044,8 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     // 0. stage the scaled demodulator samples [jlo, jhi) the cascade touches
     const int nwin = (int)(jhi - jlo);
     const int jb0 = pl[b].j0, jbp = b > 0 ? pl[b - 1].j0 : 0;
+    // g_cur / g_prev are the gains of blocks b and b - 1 only when both hold samples (empty blocks do not step the gain)
+    const bool fast_gain = pl[b + 1].j0 > jb0 && (b == 0 || jb0 > jbp);
     if (!autogain) {
         // NBFM / FM (ModemNBFM.cpp:36, ModemFM.cpp:36): m[j] = atan2f(Im(x_j conj x_{j-1}), Re(..)) / (2 pi kf), gain 1.
         // Formed here from the resampled IQ stream (history included: x_{-1} of a fresh demodulator is 0 -> m = 0).
@@ -1059,14 +1063,14 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
         const int64_t j = jlo + i;
         float x;
         if (j < 0) x = j >= -(int64_t)kDHist ? dh_in[kDHist + j] : 0.f;
-        else if (j >= jb0) x = cfg.d[j] * g_cur;
-        else if (j >= jbp) x = cfg.d[j] * g_prev;
+        else if (fast_gain && j >= jb0) x = cfg.d[j] * g_cur;
+        else if (fast_gain && j >= jbp) x = cfg.d[j] * g_prev;
         else {
-            // more than one block back (tiny blocks): replay the gain of that block
-            int bb = b - 1;
+            // more than one block back, or empty blocks nearby (tiny blocks): replay the gain of the block that holds j
+            int bb = b;
             while (bb > 0 && j < pl[bb].j0) --bb;
             float c2 = agc_in[0], m2 = agc_in[1], mm2 = agc_in[2], gg = 1.0f;
-            for (int q = 0; q <= bb; ++q) { m2 = m2 + (c2 - m2) * 0.025f; mm2 = mm2 + (m2 - mm2) * 0.025f; c2 = cfg.blockmax[q]; gg = 0.5f / mm2; }
+            for (int q = 0; q <= bb; ++q) { if (pl[q + 1].j0 == pl[q].j0) continue; m2 = m2 + (c2 - m2) * 0.025f; mm2 = mm2 + (m2 - mm2) * 0.025f; c2 = cfg.blockmax[q]; gg = 0.5f / mm2; }
             x = cfg.d[j] * gg;
         }
         s_d[i] = x;
@@ -1215,13 +1219,13 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
             const int j = J - kDHist + tid;
             float dv;
             if (j < 0) dv = dh_in[kDHist + j];
-            else if (j >= jb0) dv = cfg.d[j] * g_cur;
-            else if (j >= jbp) dv = cfg.d[j] * g_prev;
+            else if (fast_gain && j >= jb0) dv = cfg.d[j] * g_cur;
+            else if (fast_gain && j >= jbp) dv = cfg.d[j] * g_prev;
             else {
-                int bb = b - 1;
+                int bb = b;
                 while (bb > 0 && j < pl[bb].j0) --bb;
                 float c2 = agc_in[0], m2 = agc_in[1], mm2 = agc_in[2], gg = 1.0f;
-                for (int q = 0; q <= bb; ++q) { m2 = m2 + (c2 - m2) * 0.025f; mm2 = mm2 + (m2 - mm2) * 0.025f; c2 = cfg.blockmax[q]; gg = 0.5f / mm2; }
+                for (int q = 0; q <= bb; ++q) { if (pl[q + 1].j0 == pl[q].j0) continue; m2 = m2 + (c2 - m2) * 0.025f; mm2 = mm2 + (m2 - mm2) * 0.025f; c2 = cfg.blockmax[q]; gg = 0.5f / mm2; }
                 dv = cfg.d[j] * gg;
             }
             (cfg.dh + (size_t)kDHist * (dyn.hist_parity ^ 1))[tid] = dv;

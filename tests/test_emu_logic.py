@@ -86,6 +86,11 @@ def test_emu_mixed_modems(ctx):
 
 
 @full
+def test_emu_tiny_blocks(ctx):
+    G.test_tiny_blocks_ragged_outputs(ctx)
+
+
+@full
 def test_emu_dsb(ctx):
     G.test_dsb_modem_costas_loop(ctx)
 

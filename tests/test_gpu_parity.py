@@ -190,6 +190,8 @@ def _run_demods(ctx, fs, M, block, kinds, n_blocks, batch, bw=None, seed=3, over
                     continue
                 gpu_iq = got[i][b0 + k]["iq"] if i in modem_on_gpu_iq else None
                 out = rd.demodulate(gpu_iq if gpu_iq is not None and gpu_iq.size == riq.size else riq)
+                if out is None:       # no samples in this block: demodulate() returns at once, no audio item, no state change
+                    out = dict(audio=np.zeros(0, np.float32), level_accum=0.0, level_count=0, peak=0.0)
                 out["iq"] = riq
                 want[i].append(out)
     post.close(); bank.close()
@@ -209,8 +211,12 @@ def _compare(got, want, label):
             assert g["n_audio"] == w["audio"].size, (label, i, b, g["n_audio"], w["audio"].size)
             assert g["level_count"] == w["level_count"], (label, i, b)
         e_iq, e_au = rel_err(gi, wi), rel_err(ga, wa)
-        lv = max(abs(g["level_accum"] - w["level_accum"]) / max(abs(w["level_accum"]), 1e-30) for g, w in zip(got[i], want[i]))
-        pk = max(abs(g["peak"] - w["peak"]) / max(abs(w["peak"]), 1e-30) for g, w in zip(got[i], want[i]))
+        # per-block level sums and peaks, relative to the block's own value -- but not below 5 % of the stream's peak per
+        # sample (a block of one or two quiet samples has no scale of its own)
+        gpk = float(np.max(np.abs(wa))) if wa.size else 1.0
+        lv = max([abs(g["level_accum"] - w["level_accum"]) / max(abs(w["level_accum"]), 0.05 * gpk * max(w["level_count"], 1), 1e-30)
+                  for g, w in zip(got[i], want[i]) if w["audio"].size] + [0.0])
+        pk = max([abs(g["peak"] - w["peak"]) / max(abs(w["peak"]), 0.05 * gpk, 1e-30) for g, w in zip(got[i], want[i]) if w["audio"].size] + [0.0])
         worst[i] = (e_iq, e_au, lv, pk)
         assert e_iq < TOL, (label, i, "iq", e_iq)
         assert e_au < TOL, (label, i, "audio", e_au)
@@ -299,6 +305,15 @@ def test_demods_behind_oversampled_channelizer(ctx):
     resampler ratio and cascade depth change; mixed modems over 6 blocks in batches of 2."""
     got, want = _run_demods(ctx, 2400000, 4, 40000, ["NBFM", "AM", "USB", "FM", "LSB"], 6, 2, seed=23, oversampled=True)
     print(_compare(got, want, "pfbch2"))
+
+
+def test_tiny_blocks_ragged_outputs(ctx):
+    """Blocks far shorter than the filters: 400 input samples = 100 channel samples -> two or three resampled IQ samples and
+    a handful of audio samples per block, some blocks of the narrow modems produce none at all.  Every cascade reaches
+    back over many blocks (the auto-gain of the block a history sample belongs to is replayed), counts stay exact."""
+    got, want = _run_demods(ctx, 2400000, 4, 400, ["NBFM", "AM", "USB", "I/Q"], 60, 15, seed=43)
+    print(_compare(got, want, "tiny"))
+    assert min(g["n_audio"] for g in got[1]) <= 1 or min(g["n_iq"] for g in got[1]) <= 1
 
 
 def test_single_channel_mode_demod(ctx):
