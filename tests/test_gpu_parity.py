@@ -28,7 +28,7 @@ def ctx():
 
 
 # ----------------------------------------------------------------------------------------------- SDRPostThread
-@pytest.mark.parametrize("fs,M,block", [(2400000, 4, 40000), (10000000, 20, 166680), (3000000, 6, 50004)])
+@pytest.mark.parametrize("fs,M,block", [(2400000, 4, 40000), (10000000, 20, 166680), (3000000, 6, 50004), (1000000, 2, 16668)])
 def test_channelizer_matches_firpfbch(ctx, fs, M, block):
     from cubicsdr_amd.engine import SDRPost
     from oracle.cubicsdr_chain import RefSDRPost
@@ -51,7 +51,7 @@ def test_channelizer_matches_firpfbch(ctx, fs, M, block):
 
 
 @pytest.mark.parametrize("fs,M,block", [(2400000, 4, 40000), (10000000, 20, 166680), (3000000, 6, 50004), (61440000, 122, 102480),
-                                         (100000000, 1024, 65536)])
+                                         (100000000, 1024, 65536), (1000000, 2, 16668)])
 def test_channelizer2_matches_firpfbch2(ctx, fs, M, block):
     """SDRPostPFBCH2 (runPFBCH2, SDRPostThread.cpp:472-512): firpfbch2 hands out M samples per M/2 inputs, every channel at
     twice the channel spacing; M/2 odd (6, 122) starts every other frame at an odd sample offset; M = 1024 takes the
