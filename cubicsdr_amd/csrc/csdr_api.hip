@@ -900,6 +900,9 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
             b->lds_attr[k] = want[k];
         }
     const dim3 grid(std::max(1, n_audio_run), NB);
+    // one wave per (demodulator, block): the block's few hundred samples pass through five barrier-separated stages, and a
+    // single wave crosses a barrier without waiting for anyone (measured 30 us against 41 us with four waves, 64 x 64 blocks)
+    const int audio_threads = 64;
     const float2 *chan_out = post_buf(post, pk);
     const int *grp_d = lists_d + 2 * (size_t)b->max_demods;
     if (grp_n[0] > 0)
@@ -927,7 +930,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, demod_modem, dim3(n_ag, NB), dim3(kModemThreads), modem_lds, b->cfgs.p, dyns_d, lists_d + b->max_demods,
                     plans_d, NB, cap_stream, b->mconsts.p, c->sintab.p, b->arms.p, cap_cw);
     if (n_audio_run > 0)
-        CSDR_LAUNCH(c, LANE_AUDIO, KID_AUDIO, demod_audio_interp, grid, dim3(kModemThreads), audio_lds, b->cfgs.p, dyns_d, lists_d, plans_d, NB,
+        CSDR_LAUNCH(c, LANE_AUDIO, KID_AUDIO, demod_audio_interp, grid, dim3(audio_threads), audio_lds, b->cfgs.p, dyns_d, lists_d, plans_d, NB,
                     cap_out, cap_win, b->arms.p);
     CSDR_HIP_TRY(hipGetLastError());
     if (int rc = c->signal(b->ev_audio_done[bpar], LANE_AUDIO, LANE_FE)) return rc;

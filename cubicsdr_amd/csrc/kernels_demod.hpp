@@ -938,6 +938,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     float *s_redf = reinterpret_cast<float *>(s_red + 4);
 
     const int slot = slot_list[blockIdx.x], b = blockIdx.y, tid = threadIdx.x;
+    const int nthr = blockDim.x;                               // 64 .. kModemThreads (host: csdr_bank_execute)
     const SlotCfg &cfg = cfgs[slot];
     const SlotDyn dyn = dyns[slot];
     const BlockPlan *pl = plans + (size_t)slot * (NB + 1);
@@ -969,7 +970,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
         const int a0 = pl[b].q0 << aS, n_audio = (pl[b + 1].q0 << aS) - a0;
         float lpk = 0.f;
         double lsum = 0.0;
-        for (int i = tid; i < n_audio; i += kModemThreads) {
+        for (int i = tid; i < n_audio; i += nthr) {
             const float v = cfg.audio[a0 + i] * g;
             cfg.audio[a0 + i] = v;
             lpk = fmaxf(lpk, fabsf(v));
@@ -990,7 +991,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
         float lpk = 0.f;
         double lsum = 0.0;
         float2 *ao = reinterpret_cast<float2 *>(cfg.audio) + j0;
-        for (int i = tid; i < n_iq; i += kModemThreads) {
+        for (int i = tid; i < n_iq; i += nthr) {
             const float2 x = iq[j0 + i];
             ao[i] = make_float2(x.y, x.x);
             lpk = fmaxf(lpk, fmaxf(fabsf(x.x), fabsf(x.y)));
@@ -1049,7 +1050,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     if (!autogain) {
         // NBFM / FM (ModemNBFM.cpp:36, ModemFM.cpp:36): m[j] = atan2f(Im(x_j conj x_{j-1}), Re(..)) / (2 pi kf), gain 1.
         // Formed here from the resampled IQ stream (history included: x_{-1} of a fresh demodulator is 0 -> m = 0).
-        for (int i = tid; i < nwin; i += kModemThreads) {
+        for (int i = tid; i < nwin; i += nthr) {
             const int64_t j = jlo + i;
             float x = 0.f;
             if (j >= -(int64_t)(kIqHist - 1)) {
@@ -1059,7 +1060,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
             s_d[i] = x;
         }
     } else
-    for (int i = tid; i < nwin; i += kModemThreads) {
+    for (int i = tid; i < nwin; i += nthr) {
         const int64_t j = jlo + i;
         float x;
         if (j < 0) x = j >= -(int64_t)kDHist ? dh_in[kDHist + j] : 0.f;
@@ -1082,7 +1083,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     if (interp) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const int i = tid + r * kModemThreads;
+        const int i = tid + r * nthr;
         if (i < nv) {
             const int64_t P = (int64_t)dyn.aphase0 + (lo[0] + i) * (int64_t)au.step;
             zoff[r] = (int)((P >> 24) - (kArmTaps - 1) - jlo);
@@ -1095,7 +1096,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     // 1. arbitrary stage: v[q] for q in [lo[0], hi[0]) into s_w0
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const int i = tid + r * kModemThreads;
+        const int i = tid + r * nthr;
         if (i < nv) {
             const float *z = s_d + zoff[r];
             float acc = 0.f;
@@ -1104,7 +1105,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
             s_w0[i] = acc;
         }
     }
-    for (int i = tid + 2 * kModemThreads; i < nv; i += kModemThreads) {
+    for (int i = tid + 2 * nthr; i < nv; i += nthr) {
         const int64_t q = lo[0] + i;
         const int64_t P = (int64_t)dyn.aphase0 + q * (int64_t)au.step;
         const int64_t jq = P >> 24;
@@ -1126,7 +1127,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
 #pragma unroll
         for (int j = 0; j < kHbMaxM; ++j) hs[j] = au.h_x[s][j];
         const int qoff = (int)((olo >> 1) - ilo), par0 = (int)(olo & 1);
-        for (int i = tid; i < nout; i += kModemThreads) {
+        for (int i = tid; i < nout; i += nthr) {
             const int a = i + par0;                              // output index relative to the even index at or below olo
             const int qi = qoff + (a >> 1);
             float v;
@@ -1158,7 +1159,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
 #pragma unroll
             for (int j = 0; j < kHbMaxM; ++j) hs[j] = au.h_x[e][j];
             const int xoff = (int)(2 * olo - ilo);
-            for (int i = tid; i < nout; i += kModemThreads) {
+            for (int i = tid; i < nout; i += nthr) {
                 const float *x = in + (xoff + 2 * i);
                 float v = x[-2 * m + 1];
 #pragma unroll
@@ -1171,7 +1172,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
             float *t = ping; ping = pong; pong = t;
         }
         // arbitrary stage on the chain output Z = in[k - lo[aS]]
-        for (int i = tid; i < n_audio; i += kModemThreads) {
+        for (int i = tid; i < n_audio; i += nthr) {
             const int64_t P = (int64_t)dyn.aphase0 + (Q0 + i) * (int64_t)au.step;
             const int64_t kq = P >> 24;
             const float *h = arms + (int)((P & 0xFFFFFF) >> 16) * kArmTaps;
@@ -1189,7 +1190,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     float lpk = 0.f;
     double lsum = 0.0;
     const int aoff = (int)A0;
-    for (int i = tid; i < n_audio; i += kModemThreads) {
+    for (int i = tid; i < n_audio; i += nthr) {
         const float v = src[i];
         cfg.audio[aoff + i] = v;
         lpk = fmaxf(lpk, fabsf(v));
@@ -1197,7 +1198,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     }
     const int n_iq = pl[b + 1].j0 - jb0;
     if (!autogain)
-        for (int i = tid; i < n_iq; i += kModemThreads) {
+        for (int i = tid; i < n_iq; i += nthr) {
             const float2 x = iq[jb0 + i];
             lsum += sqrt((double)x.x * (double)x.x + (double)x.y * (double)x.y);
         }
@@ -1215,8 +1216,8 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
             agc_out[0] = ceil_; agc_out[1] = ma; agc_out[2] = maa;
         }
         const int J = pl[NB].j0;
-        if (tid < kDHist) {
-            const int j = J - kDHist + tid;
+        for (int td = tid; td < kDHist; td += nthr) {
+            const int j = J - kDHist + td;
             float dv;
             if (j < 0) dv = dh_in[kDHist + j];
             else if (fast_gain && j >= jb0) dv = cfg.d[j] * g_cur;
@@ -1228,7 +1229,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
                 for (int q = 0; q <= bb; ++q) { if (pl[q + 1].j0 == pl[q].j0) continue; m2 = m2 + (c2 - m2) * 0.025f; mm2 = mm2 + (m2 - mm2) * 0.025f; c2 = cfg.blockmax[q]; gg = 0.5f / mm2; }
                 dv = cfg.d[j] * gg;
             }
-            (cfg.dh + (size_t)kDHist * (dyn.hist_parity ^ 1))[tid] = dv;
+            (cfg.dh + (size_t)kDHist * (dyn.hist_parity ^ 1))[td] = dv;
         }
     }
 }
