@@ -927,7 +927,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     // lane AUDIO: modem + audio kernels of this batch
     if (int rc = c->wait(b->ev_fe_done[bpar], LANE_FE, LANE_AUDIO)) return rc;
     if (n_ag > 0)     // freqdem modems need no block-wide pre-pass: only the auto-gain modems run the modem kernel
-        CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, demod_modem, dim3(n_ag, NB), dim3(kModemThreads), modem_lds, b->cfgs.p, dyns_d, lists_d + b->max_demods,
+        CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, demod_modem, dim3(n_ag, NB), dim3(audio_threads) /* one wave per block, like the audio kernel */, modem_lds, b->cfgs.p, dyns_d, lists_d + b->max_demods,
                     plans_d, NB, cap_stream, b->mconsts.p, c->sintab.p, b->arms.p, cap_cw);
     if (n_audio_run > 0)
         CSDR_LAUNCH(c, LANE_AUDIO, KID_AUDIO, demod_audio_interp, grid, dim3(audio_threads), audio_lds, b->cfgs.p, dyns_d, lists_d, plans_d, NB,

@@ -707,6 +707,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_modem(
     float *s_redf = reinterpret_cast<float *>(s_red + 4);
 
     const int slot = slot_list[blockIdx.x], b = blockIdx.y, tid = threadIdx.x;
+    const int nthr = blockDim.x;
     const SlotCfg &cfg = cfgs[slot];
     const SlotDyn dyn = dyns[slot];
     const BlockPlan *pl = plans + (size_t)slot * (NB + 1);
@@ -721,12 +722,12 @@ __global__ __launch_bounds__(kModemThreads) void demod_modem(
         return;                                 // freqdem needs no block-wide maximum: done inside demod_audio_interp
     } else if (cfg.modem == CSDR_MODEM_AM) {
         const int halo = kAmTaps - 1;
-        for (int i = tid; i < n + halo; i += kModemThreads) {
+        for (int i = tid; i < n + halo; i += nthr) {
             const float2 x = iq[j0 - halo + i];
             s_a[i] = sqrtf(x.x * x.x + x.y * x.y);
         }
         __syncthreads();
-        for (int i = tid; i < n; i += kModemThreads) {
+        for (int i = tid; i < n; i += nthr) {
             float acc = 0.f;
             for (int t = 0; t < kAmTaps; ++t) acc = fmaf(mc->am_taps[t], s_a[i + halo - t], acc);
             d[j0 + i] = acc;
@@ -741,13 +742,13 @@ __global__ __launch_bounds__(kModemThreads) void demod_modem(
         if (b != 0) return;
         float *s_tab = reinterpret_cast<float *>(smem);                        // 1024-entry sine table
         float2 *s_x = reinterpret_cast<float2 *>(s_tab + 1024);                // one block of resampled IQ (<= kModemMaxBlockIq)
-        for (int i = tid; i < 1024; i += kModemThreads) s_tab[i] = sintab[i];
+        for (int i = tid; i < 1024; i += nthr) s_tab[i] = sintab[i];
         uint32_t th = cfg.pll[0], dth = cfg.pll[1];
         const float alpha = 0.001f, beta = sqrtf(0.001f);                      // nco_crcf_pll_set_bandwidth(0.001)
         for (int bb = 0; bb < NB; ++bb) {
             const int jb = pl[bb].j0, nb = pl[bb + 1].j0 - jb;
             __syncthreads();
-            for (int i = tid; i < nb; i += kModemThreads) s_x[i] = iq[jb + i];
+            for (int i = tid; i < nb; i += nthr) s_x[i] = iq[jb + i];
             __syncthreads();
             if (tid == 0) {
                 float mx = 0.0f;
@@ -792,13 +793,13 @@ __global__ __launch_bounds__(kModemThreads) void demod_modem(
         const int64_t jlo = (((int64_t)dyn.aphase0 + lo[0] * (int64_t)au.step) >> 24) - (kArmTaps - 1);
         const int64_t jhi = nv > 0 ? (((int64_t)dyn.aphase0 + (hi[0] - 1) * (int64_t)au.step) >> 24) + 1 : jlo;
         const int nwin = (int)(jhi - jlo);
-        for (int i = tid; i < nwin; i += kModemThreads) {
+        for (int i = tid; i < nwin; i += nthr) {
             const int64_t j = jlo + i;
             s_iq[i] = j >= -(int64_t)kIqHist ? iq[j] : make_float2(0.f, 0.f);
         }
         __syncthreads();
         // arbitrary stage: v[q], q in [lo[0], hi[0])
-        for (int i = tid; i < nv; i += kModemThreads) {
+        for (int i = tid; i < nv; i += nthr) {
             const int64_t P = (int64_t)dyn.aphase0 + (lo[0] + i) * (int64_t)au.step;
             const float *h = arms + (int)((P & 0xFFFFFF) >> 16) * kArmTaps;
             const float2 *z = s_iq + ((P >> 24) - (kArmTaps - 1) - jlo);
@@ -815,7 +816,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_modem(
             const int64_t olo = lo[st + 1], ilo = lo[st];
             const int nout = (int)(hi[st + 1] - olo);
             const int qoff = (int)((olo >> 1) - ilo), par0 = (int)(olo & 1);
-            for (int i = tid; i < nout; i += kModemThreads) {
+            for (int i = tid; i < nout; i += nthr) {
                 const int a = i + par0, qi = qoff + (a >> 1);
                 float2 v;
                 if ((a & 1) == 0) v = src[qi - m];
@@ -833,7 +834,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_modem(
             float2 *t = src; src = dst; dst = t;
         }
         // beep oscillator (mix up, then step: audio sample a uses theta0 + a dtheta), in place; src[i] is audio sample A0 - H + i
-        for (int i = tid; i < n_audio + H; i += kModemThreads) {
+        for (int i = tid; i < n_audio + H; i += nthr) {
             const int64_t a = A0 - H + i;
             float sn, cs;
             nco_sincos(sintab, dyn.ssb_theta0 + (uint32_t)a * dyn.cw_dtheta, sn, cs);
@@ -842,7 +843,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_modem(
         }
         __syncthreads();
         // Hilbert c2r, upper sideband: yi - yq (as in the SSB path, taps of firhilbf_create(5, 60))
-        for (int i = tid; i < n_audio; i += kModemThreads) {
+        for (int i = tid; i < n_audio; i += nthr) {
             const int k = i + H;
             const float yi = src[k - 2 * kHilbM].x;
             float yq = 0.f;
@@ -858,7 +859,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_modem(
         const int pre = kSsbWarm + hh;             // samples before j0 that are processed
         const int tot = n + pre;
         // 1. shift by fs/4 (oscillator is stepped BEFORE use: theta_j = theta0 + (j+1) * 2^30)
-        for (int i = tid; i < tot; i += kModemThreads) {
+        for (int i = tid; i < tot; i += nthr) {
             const int j = j0 - pre + i;
             const float2 x = iq[j];
             float s, c;
@@ -885,7 +886,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_modem(
         }
         __syncthreads();
         // 3. shift back (same oscillator phase), in place
-        for (int i = tid; i < tot; i += kModemThreads) {
+        for (int i = tid; i < tot; i += nthr) {
             const int j = j0 - pre + i;
             float s, c;
             nco_sincos(sintab, dyn.ssb_theta0 + (uint32_t)(j + 1) * (1u << 30), s, c);
@@ -895,7 +896,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_modem(
         }
         __syncthreads();
         // 4. Hilbert c2r: yi = re[k - 2m], yq = sum_{n odd} hq[(n-1)/2] im[k - n]; lower = yi + yq, upper = yi - yq
-        for (int i = tid; i < n; i += kModemThreads) {
+        for (int i = tid; i < n; i += nthr) {
             const int k = i + pre;
             const float yi = s_a[k - 2 * kHilbM];
             float yq = 0.f;
