@@ -105,6 +105,7 @@ def test_emu_cw(ctx):
     G.test_cw_modem(ctx)
 
 
+@full
 def test_emu_iq_passthrough(ctx):
     G.test_iq_passthrough_modem(ctx)
 
