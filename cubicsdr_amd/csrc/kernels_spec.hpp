@@ -362,11 +362,31 @@ __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restr
     AvgState *s_loc = reinterpret_cast<AvgState *>(smem);               // [kAvgGroups][64] group end states (zero entering state)
     AvgState *s_carry = s_loc + kAvgGroups * kAvgLanes;                  // [64] state after the round
     const int F = g.F, lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int x = blockIdx.x * kAvgLanes + lane;
-    const bool valid = x < F;
+    // The magnitudes lie in the row order of the last FFT pass: bin k1 + Ra (k2 + Rb k3) at [(k1 Rb + k2) 4096 + k3].  A tile
+    // of 64 display points therefore takes its lanes ALONG k3 (two k1 pairs x 32 consecutive k3: whole 128-byte runs of four
+    // rows per load) instead of 64 consecutive points, which would touch 16 bytes in each of Ra rows.
+    int x;
+    bool valid;
+    int64_t t, db;
+    if (g.Ra == 1) {
+        x = blockIdx.x * kAvgLanes + lane;
+        valid = x < F;
+        t = spec_pair_offset(g, valid ? x : 0, db);
+    } else {
+        const int pk1 = g.Ra >= 4 ? 2 : 1, pk3 = kAvgLanes / pk1;
+        const int nk3b = 4096 / pk3, nk1g = (g.Ra / 2) / pk1;
+        // neighbouring workgroups take the k1 groups of one k3 block: together they write whole lines of the display-order outputs
+        int tile = blockIdx.x;
+        const int k1g = tile % nk1g; tile /= nk1g;
+        const int k3b = tile % nk3b, k2 = tile / nk3b;
+        const int k1 = 2 * (k1g * pk1 + lane / pk3), k3 = k3b * pk3 + lane % pk3;
+        const int ka = k1 + g.Ra * (k2 + g.Rb * k3);
+        x = ((ka - g.N / 2) & (g.N - 1)) >> 1;
+        valid = true;
+        t = ((int64_t)k1 * g.Rb + k2) * 4096 + k3;
+        db = (int64_t)g.Rb * 4096;
+    }
     const int xs = valid ? x : 0;
-    int64_t db;
-    const int64_t t = spec_pair_offset(g, xs, db);
     const int64_t NN = g.N;
     const int ntiles = gridDim.x;
     const double a = 1.0 - rate;
