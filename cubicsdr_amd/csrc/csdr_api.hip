@@ -1199,7 +1199,9 @@ static int spec_post_range(csdr_spec *s, const float *mag, int f0, int cnt, int 
     const size_t F = (size_t)g.F;
     const bool hold = pk_from < cnt, view = s->view_frame;
     const bool bins = hold || view;                                  // per-bin averaged values are kept (maaf)
-    CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_average, dim3(s->n_avg_tiles), dim3(kAvgThreads), kAvgLds, mag + (size_t)f0 * g.N, cnt, g, (double)s->avg_rate,
+    // frame groups per workgroup: up to 16 frames each, so a short batch does not pay the set-up of sixteen groups
+    const int avg_groups = std::max(1, std::min(kAvgGroups, (cnt + kAvgGMax - 1) / kAvgGMax));
+    CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_average, dim3(s->n_avg_tiles), dim3(kAvgLanes * avg_groups), kAvgLds, mag + (size_t)f0 * g.N, cnt, g, (double)s->avg_rate,
                 s->ma.p, s->maa.p, s->pairsum.p + f0 * F, s->first_b.p + f0, s->ext_w.p + (size_t)f0 * s->n_avg_tiles,
                 bins ? s->maaf.p + f0 * F : (float2 *)nullptr, view ? 0 : (hold ? pk_from : cnt));
     CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_extrema, dim3(cnt), dim3(256), 64, s->ext_w.p + (size_t)f0 * s->n_avg_tiles, s->n_avg_tiles, s->ext.p + f0);

@@ -359,8 +359,9 @@ __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restr
                                                             float2 *__restrict__ maaf /* peak hold / zoomed view: both averaged bins of every point, frames >= pk_from */,
                                                             int pk_from) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    AvgState *s_loc = reinterpret_cast<AvgState *>(smem);               // [kAvgGroups][64] group end states (zero entering state)
-    AvgState *s_carry = s_loc + kAvgGroups * kAvgLanes;                  // [64] state after the round
+    const int ng = blockDim.x >> 6;                                      // frame groups in this launch (1 .. kAvgGroups: few frames, few groups)
+    AvgState *s_loc = reinterpret_cast<AvgState *>(smem);               // [ng][64] group end states (zero entering state)
+    AvgState *s_carry = s_loc + ng * kAvgLanes;                          // [64] state after the round
     const int F = g.F, lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     // The magnitudes lie in the row order of the last FFT pass: bin k1 + Ra (k2 + Rb k3) at [(k1 Rb + k2) 4096 + k3].  A tile
     // of 64 display points therefore takes its lanes ALONG k3 (two k1 pairs x 32 consecutive k3: whole 128-byte runs of four
@@ -391,9 +392,9 @@ __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restr
     const int ntiles = gridDim.x;
     const double a = 1.0 - rate;
     AvgState s0 = {ma[xs], maa[xs], ma[F + xs], maa[F + xs]};            // state entering the batch
-    for (int fb = 0; fb < nf; fb += kAvgGroups * kAvgGMax) {
-        const int nfb = min(kAvgGroups * kAvgGMax, nf - fb);
-        const int G = (nfb + kAvgGroups - 1) / kAvgGroups;               // frames per group (block-uniform)
+    for (int fb = 0; fb < nf; fb += ng * kAvgGMax) {
+        const int nfb = min(ng * kAvgGMax, nf - fb);
+        const int G = (nfb + ng - 1) / ng;                               // frames per group (block-uniform)
         const int fg = grp * G;                                           // first frame of my group inside the round
         float2 m[kAvgGMax];
 #pragma unroll
