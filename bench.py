@@ -178,14 +178,18 @@ def main():
     NB = args.blocks
     ring = make_ring(torch, device, NB, seed=0xC0B1C5D2 + rank)
     torch.cuda.synchronize()
-    ctx = Context(local_rank)        # one HIP stream per pipeline stage inside (include/csdr_hip.h "Streams")
-    post = SDRPost(ctx, FS, M, BLOCK, max_blocks=NB)
-    bank = DemodBank(ctx, N_DEMODS, max_blocks=NB)
-    for i, f in enumerate(demod_frequencies(CENTER, FS, N_DEMODS)):
-        kind = kinds[i % len(kinds)]
-        bank.configure(i, post, kind, {"NBFM": NBFM_BW, "AM": 6000, "USB": 5400}[kind], f, AUDIO_RATE)
     n_frames_max = (NB * BLOCK) // (2 * FFT_SIZE) + 2
-    spec = SpectrumProcessor(ctx, FFT_SIZE, max_frames=n_frames_max)
+
+    def make_pipeline():
+        c = Context(local_rank)        # one HIP stream per pipeline stage inside (include/csdr_hip.h "Streams")
+        p = SDRPost(c, FS, M, BLOCK, max_blocks=NB)
+        b = DemodBank(c, N_DEMODS, max_blocks=NB)
+        for i, f in enumerate(demod_frequencies(CENTER, FS, N_DEMODS)):
+            kind = kinds[i % len(kinds)]
+            b.configure(i, p, kind, {"NBFM": NBFM_BW, "AM": 6000, "USB": 5400}[kind], f, AUDIO_RATE)
+        return c, p, b, SpectrumProcessor(c, FFT_SIZE, max_frames=n_frames_max)
+
+    ctx, post, bank, spec = make_pipeline()
 
     def step():
         post.execute(ring, NB, BLOCK, CENTER)
@@ -248,6 +252,26 @@ def main():
                                           "frac": bytes_per_sample * value / world * 1e6 / 1e9 / HBM_PEAK_GBS},
                            "profile_sampling": "HIP events around every %d-th launch of each kernel inside the timed region" % PROFILE_PERIOD,
                            "kernels_ms_per_step": {k: v[0] * PROFILE_PERIOD / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}
+    spec.close(); bank.close(); post.close(); ctx.close()
+    if prof and rank == 0:
+        # The live durations above include whatever the other stream's kernels took from the GPU at that moment (the two chains
+        # overlap by design), so they move with the phase between the chains.  For a kernel-quality figure the same batch is run
+        # once more, untimed, on ONE stream: every kernel alone on the device.
+        os.environ["CSDR_STREAMS"] = "1"
+        ctx1, post1, bank1, spec1 = make_pipeline()
+        os.environ.pop("CSDR_STREAMS", None)
+        for it in range(13):
+            if it == 3:
+                ctx1.synchronize(); ctx1.profile_enable(1)
+            post1.execute(ring, NB, BLOCK, CENTER); bank1.execute(post1); spec1.process(ring, NB, BLOCK, contiguous=True)
+        ctx1.synchronize()
+        solo = {k: v[0] / v[1] for k, v in ctx1.profile().items()}
+        dom = out["roofline"]["kernel"]
+        alg = out["roofline"]["algorithmic_bytes_per_launch"]
+        out["roofline"]["solo"] = {"note": "same batch, one stream, nothing else on the GPU; 10 launches", "avg_launch_ms": solo[dom],
+                                   "achieved": alg / (solo[dom] * 1e-3) / 1e9, "frac": alg / (solo[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "kernels_ms_per_launch": {k: v for k, v in sorted(solo.items(), key=lambda kv: -kv[1])}}
+        spec1.close(); bank1.close(); post1.close(); ctx1.close()
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         try:
             out["cpu_baseline"] = cpu_baseline(ring.cpu().numpy().view("complex64").reshape(-1), args.cpu_seconds)
@@ -255,7 +279,6 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "MS/s", "cores": 0, "kind": "unavailable", "sample": repr(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    spec.close(); bank.close(); post.close(); ctx.close()
     if dist:
         dist.destroy_process_group()
 
