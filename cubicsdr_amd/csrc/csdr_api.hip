@@ -238,6 +238,11 @@ static int chan_geometry(int M, int hop, ChanGeom &g) {
     auto passes = [](int n, int &K, int &nk, int &pitch) { nk = (n + 7) / 8; K = std::max(4, (n + nk - 1) / nk); pitch = nk * K; };
     passes(g.A, g.KA, g.nkA, g.PA);
     passes(g.B, g.KB, g.nkB, g.PB);
+    g.oddA = (g.A >= 3 && (g.A & 1)) ? 1 : 0;
+    if (g.oddA) {            // conjugate-pair form of phase 1: (A - 1) / 2 output pairs, up to four per pass
+        const int H = (g.A - 1) / 2;
+        g.nkA = (H + 3) / 4; g.KA = (H + g.nkA - 1) / g.nkA; g.PA = g.nkA * g.KA;
+    }
     g.magicM = (unsigned)((1ull << 32) / (unsigned)M) + 1u;
     g.taps_lds = (M <= 512) ? 1 : 0;
     g.stage_in = (M <= 256) ? 1 : 0;
@@ -263,8 +268,12 @@ static int chan_geometry(int M, int hop, ChanGeom &g) {
 typedef void (*chan_kernel_t)(const float2 *, const float2 *, float2 *, const float *, const float2 *, const float2 *, const float2 *,
                               const int *, ChanGeom, int64_t, float2 *, int64_t, d2 *, double, const float2 *);
 static chan_kernel_t chan_kernel(const ChanGeom &g) {
-    if (g.hop != g.M) return g.stage_in ? chan_analyze<1, 1, 1> : g.taps_lds ? chan_analyze<0, 1, 1> : chan_analyze<0, 0, 1>;
-    return g.stage_in ? chan_analyze<1, 1, 0> : g.taps_lds ? chan_analyze<0, 1, 0> : chan_analyze<0, 0, 0>;
+    if (g.oddA) {
+        if (g.hop != g.M) return g.stage_in ? chan_analyze<1, 1, 1, 1> : g.taps_lds ? chan_analyze<0, 1, 1, 1> : chan_analyze<0, 0, 1, 1>;
+        return g.stage_in ? chan_analyze<1, 1, 0, 1> : g.taps_lds ? chan_analyze<0, 1, 0, 1> : chan_analyze<0, 0, 0, 1>;
+    }
+    if (g.hop != g.M) return g.stage_in ? chan_analyze<1, 1, 1, 0> : g.taps_lds ? chan_analyze<0, 1, 1, 0> : chan_analyze<0, 0, 1, 0>;
+    return g.stage_in ? chan_analyze<1, 1, 0, 0> : g.taps_lds ? chan_analyze<0, 1, 0, 0> : chan_analyze<0, 0, 0, 0>;
 }
 
 extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_channels, int mode, int max_block_len, int max_blocks) {
@@ -312,6 +321,13 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
         for (int c = 0; c < M; c++) for (int n = 0; n < kChanTaps; n++) tapsT[(size_t)n * M + c] = taps[(size_t)c * kChanTaps + n];
         std::vector<float2> twA((size_t)g.A * g.PA, make_float2(0.f, 0.f)), twB((size_t)g.B * g.PB, make_float2(0.f, 0.f)), twM((size_t)g.A * g.B);
         auto W = [](int64_t num, int den) { const double a = -2.0 * M_PI * (double)(num % den) / (double)den; return make_float2((float)std::cos(a), (float)std::sin(a)); };
+        if (g.oddA) {        // (cos, sin)(2 pi kp c / A) at [(c - 1) PA + kp - 1], c, kp = 1 .. (A - 1) / 2
+            const int H = (g.A - 1) / 2;
+            for (int c = 1; c <= H; c++) for (int kp = 1; kp <= H; kp++) {
+                const double a = 2.0 * M_PI * (double)(((int64_t)c * kp) % g.A) / (double)g.A;
+                twA[(size_t)(c - 1) * g.PA + kp - 1] = make_float2((float)std::cos(a), (float)std::sin(a));
+            }
+        } else
         for (int c1 = 0; c1 < g.A; c1++) for (int k1 = 0; k1 < g.A; k1++) twA[(size_t)c1 * g.PA + k1] = W((int64_t)c1 * k1, g.A);
         for (int c2 = 0; c2 < g.B; c2++) for (int k2 = 0; k2 < g.B; k2++) twB[(size_t)c2 * g.PB + k2] = W((int64_t)c2 * k2, g.B);
         for (int k1 = 0; k1 < g.A; k1++) for (int c2 = 0; c2 < g.B; c2++) twM[(size_t)k1 * g.B + c2] = W((int64_t)k1 * c2, M);

@@ -205,6 +205,7 @@ struct ChanGeom {
     int stage_in;             // 1: the (TF + 7) M input samples of the tile are staged in LDS (aliasing the Z array)
     int fpw;                  // frames one workgroup processes (<= TF)
     int hop;                  // input samples between frames: M (firpfbch) or M / 2 (firpfbch2, 2x oversampled)
+    int oddA;                 // 1: A is odd (>= 3) and phase 1 uses the conjugate-pair form: KA / nkA / PA then count output PAIRS (k, A - k)
     int threads;              // workgroup size (whole waves, 256..512): chosen so each phase splits evenly over the waves
 };
 __host__ __device__ inline size_t chan_zin_floats2(const ChanGeom &g) {      // Z array, or the staged input tile if larger
@@ -245,6 +246,50 @@ __device__ __forceinline__ void chan_phase1(const ChanGeom &g, const float2 *s_x
     for (int j = 0; j < K; ++j) if (k1b + j < A) zr[j] = cmul(acc[j], m[j]);
 }
 
+// phase 1 when A is odd: outputs k and A - k share their products.  With s_c = x_c + x_{A-c}, d_c = x_c - x_{A-c} (c = 1 .. H,
+// H = (A - 1) / 2):  P_k = x_0 + sum_c s_c cos(2 pi k c / A),  Q_k = sum_c d_c sin(2 pi k c / A),  X_k = P_k - j Q_k,
+// X_{A-k} = P_k + j Q_k -- a quarter of the multiplies of the direct form (M = 20: A = 5; M = 122: A = 61).
+// `cs` holds (cos, sin) of pair kp = 1 .. H and term c at [(c - 1) pitch + kp - 1], wave-uniform; KP pairs per pass.
+template <int KP>
+__device__ __forceinline__ void chan_phase1_odd(const ChanGeom &g, const float2 *s_x, float2 *s_z, const float2 *__restrict__ cs,
+                                                const float2 *__restrict__ twM, int kpb, int t, int c2) {
+    const int A = g.A, B = g.B, H = (A - 1) >> 1;
+    const float2 *xr = s_x + (size_t)t * g.S + c2;
+    float2 mk[KP], mn[KP];                                    // W_M factors of outputs k and A - k, fetched ahead
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        const int k = min(kpb + 1 + j, H);
+        mk[j] = twM[(size_t)k * B + c2]; mn[j] = twM[(size_t)(A - k) * B + c2];
+    }
+    const float2 m0 = twM[c2];                                // k = 0 (row 0 of W_M is all ones, kept for uniformity)
+    const float2 x0 = xr[0];
+    float2 P[KP], Q[KP], sum0 = x0;
+#pragma unroll
+    for (int j = 0; j < KP; ++j) { P[j] = x0; Q[j] = make_float2(0.f, 0.f); }
+    const float2 *w = cs + kpb;
+    for (int c = 1; c <= H; ++c, w += g.PA) {
+        const float2 a = xr[c * B], b = xr[(A - c) * B];
+        const float2 sc = make_float2(a.x + b.x, a.y + b.y), dc = make_float2(a.x - b.x, a.y - b.y);
+        sum0.x += sc.x; sum0.y += sc.y;
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            const float2 e = w[j];
+            P[j].x = fmaf(sc.x, e.x, P[j].x); P[j].y = fmaf(sc.y, e.x, P[j].y);
+            Q[j].x = fmaf(dc.x, e.y, Q[j].x); Q[j].y = fmaf(dc.y, e.y, Q[j].y);
+        }
+    }
+    float2 *zr = s_z + (size_t)t * g.S + c2 * A;
+    if (kpb == 0) zr[0] = cmul(sum0, m0);
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        const int k = kpb + 1 + j;
+        if (k <= H) {
+            zr[k] = cmul(make_float2(P[j].x + Q[j].y, P[j].y - Q[j].x), mk[j]);          // P - jQ
+            zr[A - k] = cmul(make_float2(P[j].x - Q[j].y, P[j].y + Q[j].x), mn[j]);      // P + jQ
+        }
+    }
+}
+
 // phase 2 for one wave item: B-point DFTs over c2 (K of the k2 outputs) for 64 (t, k1) pairs; channel-major stores
 template <int K>
 __device__ __forceinline__ void chan_phase2(const ChanGeom &g, float2 *s_x, const float2 *s_z, const float2 *__restrict__ twB,
@@ -270,7 +315,8 @@ __device__ __forceinline__ void chan_phase2(const ChanGeom &g, float2 *s_x, cons
     for (int j = 0; j < K; ++j) if (k2b + j < B && on[j]) o[(int64_t)j * A * out_stride] = acc[j];
 }
 
-template <int STAGE_IN, int TAPS_LDS, int OS2 /* 1: frames hop by M / 2 and may start at odd sample offsets */>
+template <int STAGE_IN, int TAPS_LDS, int OS2 /* 1: frames hop by M / 2 and may start at odd sample offsets */,
+          int ODDA /* 1: phase 1 in the conjugate-pair form (its own variant: the registers it needs would cost the others occupancy) */>
 __global__ __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
     const float2 *__restrict__ x,        // batch input, n_frames * M samples
     const float2 *__restrict__ hist,     // 8 * M - hop samples preceding x
@@ -376,6 +422,15 @@ __global__ __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
             const int it = (w - kb * nch) * 64 + lane;
             const int t = it & tmask, c2 = it >> g.lgTF;
             if (it >= items || t >= nf) continue;
+            if (ODDA) {                                         // k1b counts output pairs here
+                switch (g.KA) {
+                    case 1: chan_phase1_odd<1>(g, s_x, s_z, twA, twM, k1b, t, c2); break;
+                    case 2: chan_phase1_odd<2>(g, s_x, s_z, twA, twM, k1b, t, c2); break;
+                    case 3: chan_phase1_odd<3>(g, s_x, s_z, twA, twM, k1b, t, c2); break;
+                    default: chan_phase1_odd<4>(g, s_x, s_z, twA, twM, k1b, t, c2); break;
+                }
+                continue;
+            }
             switch (g.KA) {
                 case 4: chan_phase1<4>(g, s_x, s_z, twA, twM, k1b, t, c2); break;
                 case 5: chan_phase1<5>(g, s_x, s_z, twA, twM, k1b, t, c2); break;
@@ -397,11 +452,11 @@ __global__ __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
             const int t = it & tmask, k1 = it >> g.lgTF;
             if (it >= items || t >= nf) continue;
             switch (g.KB) {
-                case 4: chan_phase2<4>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1, post); break;
-                case 5: chan_phase2<5>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1, post); break;
-                case 6: chan_phase2<6>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1, post); break;
-                case 7: chan_phase2<7>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1, post); break;
-                default: chan_phase2<8>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1, post); break;
+                case 4: chan_phase2<4>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1, OS2 ? post : nullptr); break;
+                case 5: chan_phase2<5>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1, OS2 ? post : nullptr); break;
+                case 6: chan_phase2<6>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1, OS2 ? post : nullptr); break;
+                case 7: chan_phase2<7>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1, OS2 ? post : nullptr); break;
+                default: chan_phase2<8>(g, s_x, s_z, twB, active, out, out_stride, f0, keep0, k2b, t, k1, OS2 ? post : nullptr); break;
             }
         }
     }
