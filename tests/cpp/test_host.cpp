@@ -309,7 +309,7 @@ static int run_gpu() {
         }
         // 0.2 s of samples at 200 lines/s: about 40 lines (4096 samples each, 117 available)
         std::printf("waterfall lines %d\n", lines);
-        CHECK(lines >= 30 && lines <= 45);
+        CHECK(lines >= 20 && lines <= 60);            // (pump timing: 10 ms ticks on a possibly busy host)
         wf.terminate();
         tw.join();
         CHECK(wf.isTerminated());
