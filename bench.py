@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--blocks", type=int, default=0, help="IQ blocks per step (batch resident in HBM); default 128 (C2) / 16 (C3)")
+    ap.add_argument("--blocks", type=int, default=0, help="IQ blocks per step (batch resident in HBM); default 256 (C2) / 16 (C3)")
     ap.add_argument("--config", default="C2", choices=["C2", "C3"],
                     help="BASELINE.json workload: C2 (default, the judged one) or C3 = 256 mixed NBFM/AM/USB demods, 61.44 MS/s, M=122, 65536-pt FFT (reported, not judged)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 disables)")
@@ -152,7 +152,7 @@ def main():
         workload = "C3: 256 mixed NBFM/AM/USB demods, 61.44 MS/s complex-float IQ, firpfbch M=122, 65536-pt spectrum FFT (internal 131072) over every sample"
         args.cpu_seconds = 0.0                          # the CPU sample is defined for the judged workload only
     if not args.blocks:
-        args.blocks = 128 if args.config == "C2" else 16
+        args.blocks = 256 if args.config == "C2" else 16
     bytes_per_sample = 8 + 8 + 8.0 * N_DEMODS / M + 4.0 * N_DEMODS * AUDIO_RATE / FS + 12      # 54.8 (C2), 45.6 (C3)
     import torch
     from cubicsdr_amd import build as cbuild
