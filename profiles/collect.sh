@@ -12,7 +12,7 @@ OUT=/tmp/prof_$TAG
 DST=$(pwd)/gpurun_out/prof_$TAG
 mkdir -p $OUT $DST
 REPO=$(pwd)
-NB=${2:-128}
+NB=${2:-256}
 BENCH="python $REPO/bench.py --steps 40 --warmup 10 --cpu-seconds 0 --no-profile --blocks $NB"
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- $BENCH ) > $OUT/stats.log 2>&1
 ( cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o b -- $BENCH ) > $OUT/fetch.log 2>&1
