@@ -886,7 +886,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     const int64_t total = (int64_t)NB * Bc;
     // ranges per slot: as many as make the grid ONE round of resident workgroups (each range re-runs `warm` inputs, so
     // fewer, longer ranges waste less), but never shorter than 4 warm-up spans and never fewer than one
-    const int fe_slots = c->wg_slots(demod_frontend_s<5, 2048>, kFeThreads, fes_lds_bytes<5, 2048>());
+    const int fe_slots = c->wg_slots(demod_frontend_s<5, 2048, true>, kFeThreads + 64, fes_lds_bytes<5, 2048>());
     int P = (int)std::max<int64_t>(1, std::min<int64_t>(total / std::max<int64_t>(4096, 4 * (int64_t)warm_max), 4096));
     {
         const int per_slot = fe_slots / std::max(1, n_run) - 1;                            // one extra workgroup per slot carries the histories
@@ -928,7 +928,10 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     if (grp_n[S_] > 0)                                                                                                                  \
         CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, (demod_frontend_s<S_, CH_>), dim3(P + 1, grp_n[S_]), dim3(kFeThreads), (fes_lds_bytes<S_, CH_>()), \
                     b->cfgs.p, dyns_d, grp_d + grp_off[S_], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p)
-    CSDR_FE_S(3, 2048); CSDR_FE_S(4, 2048); CSDR_FE_S(5, 2048); CSDR_FE_S(6, 2048);
+    CSDR_FE_S(3, 2048); CSDR_FE_S(4, 2048); CSDR_FE_S(6, 2048);
+    if (grp_n[5] > 0)            // depth 5 (NBFM from ~500 kS/s channels): a fifth wave runs the one-wave tail one chunk behind
+        CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, (demod_frontend_s<5, 2048, true>), dim3(P + 1, grp_n[5]), dim3(kFeThreads + 64), (fes_lds_bytes<5, 2048>()),
+                    b->cfgs.p, dyns_d, grp_d + grp_off[5], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
 #undef CSDR_FE_S
     CSDR_HIP_TRY(hipGetLastError());
     // the front-end was the only reader of the channelizer buffer: hand it back to the post object's rotation

@@ -416,11 +416,11 @@ __host__ __device__ constexpr int fes_offo(int e) { return fes_off<CH>(e) + (fes
 // CNT outputs of stage `E` (compile-time), two per thread
 template <int M, int CNT>
 __device__ inline void fes_stage_pairs(const float2 *__restrict__ Ein, const float2 *__restrict__ Oin, const float *__restrict__ h,
-                                       float2 *__restrict__ outE, float2 *__restrict__ outO) {
+                                       float2 *__restrict__ outE, float2 *__restrict__ outO, int tx /* thread index inside the group that runs the stage */) {
     constexpr int NP = CNT / 2;
 #pragma unroll
     for (int t0 = 0; t0 < NP; t0 += kFeThreads) {
-        const int t = t0 + (int)threadIdx.x;
+        const int t = t0 + tx;
         if (NP >= kFeThreads || t < NP) {
             float2 ev[2 * M + 2];                               // ev[i] = E[2t - 2M + i]
             float4 e4[M + 1], o4;                               // both windows are 16-byte aligned (fes_offo)
@@ -442,9 +442,9 @@ __device__ inline void fes_stage_pairs(const float2 *__restrict__ Ein, const flo
 // last stage (m = 10, CNT <= 256 outputs, one per thread) -> Z, scaled by 2^-S
 template <int CNT>
 __device__ inline void fes_stage_last(const float2 *__restrict__ Ein, const float2 *__restrict__ Oin, const float *__restrict__ h, float zeta,
-                                      float2 *__restrict__ outZ) {
+                                      float2 *__restrict__ outZ, int tx) {
     constexpr int M = 10;
-    const int k = threadIdx.x;
+    const int k = tx;
     if (k < CNT) {
         const float2 d = Oin[k - M];
         float ar = d.x, ai = d.y;
@@ -461,7 +461,7 @@ __device__ inline void fes_stage_last(const float2 *__restrict__ Ein, const floa
 template <int CNT>
 __device__ inline void fes_carry_tail(float2 *__restrict__ LE, float2 *__restrict__ LO, int off, int offo) {
     const int c = (int)threadIdx.x - (kFeThreads - 2 * kFeTail);
-    if (c >= 0) {
+    if (c >= 0 && c < 2 * kFeTail) {
         float2 *arr = c < kFeTail ? LE + off : LO + offo;
         const int k = c < kFeTail ? c : c - kFeTail;
         arr[k] = arr[CNT + k];
@@ -480,36 +480,42 @@ __host__ __device__ constexpr int fes_blk() {
 }
 template <int S, int CH, int E, int END, bool WAVE>
 struct FesStages {
-    static __device__ inline void run(float2 *LE, float2 *LO, float2 *LZ, const float *hb, float zeta) {
+    static __device__ inline void run(float2 *LE, float2 *LO, float2 *LZ, const float *hb, float zeta, int tx) {
         constexpr int CNT = CH >> (E + 1);                       // outputs of stage E
         constexpr int M = fes_m(S, E);
         const float2 *Ein = LE + fes_off<CH>(E) + kFeTail, *Oin = LO + fes_offo<S, CH>(E) + kFeTail;
-        if constexpr (E == S - 1) fes_stage_last<CNT>(Ein, Oin, hb + E * kHbMaxM, zeta, LZ + kFeZTail);
-        else fes_stage_pairs<M, CNT>(Ein, Oin, hb + E * kHbMaxM, LE + fes_off<CH>(E + 1) + kFeTail, LO + fes_offo<S, CH>(E + 1) + kFeTail);
+        if constexpr (E == S - 1) fes_stage_last<CNT>(Ein, Oin, hb + E * kHbMaxM, zeta, LZ + kFeZTail, tx);
+        else fes_stage_pairs<M, CNT>(Ein, Oin, hb + E * kHbMaxM, LE + fes_off<CH>(E + 1) + kFeTail, LO + fes_offo<S, CH>(E + 1) + kFeTail, tx);
         if constexpr (!WAVE) {
             // the tail of the PREVIOUS stage's input region is free to move now (its consumer finished at the last barrier)
             if constexpr (E >= 1) fes_carry_tail<(CH >> E)>(LE, LO, fes_off<CH>(E - 1), fes_offo<S, CH>(E - 1));
             __syncthreads();
         } else {
-            // wave 0 alone: its own stage input is free once every lane has read it
+            // one wave alone: its own stage input is free once every lane has read it
             wave_sync();
-            const int c = (int)threadIdx.x;
+            const int c = tx;
             if (c < 2 * kFeTail) {
                 float2 *arr = c < kFeTail ? LE + fes_off<CH>(E) : LO + fes_offo<S, CH>(E);
                 const int k = c < kFeTail ? c : c - kFeTail;
                 arr[k] = arr[(CH >> (E + 1)) + k];
             }
         }
-        FesStages<S, CH, E + 1, END, WAVE>::run(LE, LO, LZ, hb, zeta);
+        FesStages<S, CH, E + 1, END, WAVE>::run(LE, LO, LZ, hb, zeta, tx);
     }
 };
 template <int S, int CH, int END, bool WAVE>
 struct FesStages<S, CH, END, END, WAVE> {
-    static __device__ inline void run(float2 *, float2 *, float2 *, const float *, float) {}
+    static __device__ inline void run(float2 *, float2 *, float2 *, const float *, float, int) {}
 };
 
-template <int S, int CH>
-__global__ __launch_bounds__(kFeThreads, 4) void demod_frontend_s(
+// TW (S = 5 only): a FIFTH wave owns the one-wave tail (stages S-2, S-1 and the arbitrary resampler).  It works one chunk behind
+// the four worker waves, one piece per barrier interval, so the workers never wait for the tail at the head of the next chunk:
+//   workers      mix k | B1 | stage 0 | B2 | stage 1 | B3 | stage 2 (writes the tail's input of chunk k) | B4
+//   tail wave    stage S-2 of chunk k-1 (+ its carry) | B1 | Z tail, stage S-1 | B2 | resampler | B3 | - | B4
+// The tail's input region is read before B1 of chunk k and rewritten only after B3 of chunk k; everything else it touches
+// is its own.  After the last chunk it runs once more without barriers.
+template <int S, int CH, bool TW = false>
+__global__ __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? 5 : 4) void demod_frontend_s(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
     const float2 *__restrict__ chan_base, int64_t chan_stride, int64_t total /* batch samples per channel */,
     const float *__restrict__ arms_all, const float *__restrict__ sintab) {
@@ -578,6 +584,98 @@ __global__ __launch_bounds__(kFeThreads, 4) void demod_frontend_s(
     u_lo = u_stop - ((u_stop - u_lo + CH - 1) / CH) * CH;        // ... and a whole number of chunks before u_stop
     const float zeta = 1.0f / (float)(1 << S);
 
+    if constexpr (TW) {
+        constexpr int BLK = fes_blk<S, CH>();
+        static_assert(S - BLK == 2 && BLK >= 1, "the tail wave schedule is laid out for two tail stages");
+        const bool tailw = tid >= kFeThreads;
+        const int ltid = tid - kFeThreads;
+        const int nch = (int)((u_stop - u_lo) / CH);
+        float4 pf[NPF];
+        if (!tailw) {
+            const int64_t rel0 = u_lo - (int64_t)dyn.buf0;
+            const bool inside = rel0 >= 0 && rel0 + CH <= total;
+#pragma unroll
+            for (int q = 0; q < NPF; ++q) pf[q] = fe_fetch_pair(chan, hist, hist_len, rel0 + 2 * (tid + q * kFeThreads), total, inside);
+        }
+        __syncthreads();
+        if (!tailw) {
+            for (int k = 0; k < nch; ++k) {
+                const int64_t uc = u_lo + (int64_t)k * CH;
+                const int64_t rel0 = uc - (int64_t)dyn.buf0;
+                const bool do_mix = dyn.mixdir != 0;
+                const uint32_t th0 = dyn.theta0 + (uint32_t)rel0 * dyn.dtheta;
+#pragma unroll
+                for (int q = 0; q < NPF; ++q) {
+                    const int p = tid + q * kFeThreads;
+                    float2 a = make_float2(pf[q].x, pf[q].y), b = make_float2(pf[q].z, pf[q].w);
+                    if (do_mix) {
+                        const uint32_t tha = th0 + (uint32_t)(2 * p) * dyn.dtheta, thb = tha + dyn.dtheta;
+                        const uint32_t ia = (tha + (1u << 21)) >> 22, ib = (thb + (1u << 21)) >> 22;
+                        const float sa = tab[ia] * sgn, ca = tab[ia + 256], sb = tab[ib] * sgn, cb = tab[ib + 256];
+                        if (rel0 + 2 * p >= 0) a = make_float2(fmaf(a.x, ca, -(a.y * sa)), fmaf(a.y, ca, a.x * sa));
+                        if (rel0 + 2 * p + 1 >= 0) b = make_float2(fmaf(b.x, cb, -(b.y * sb)), fmaf(b.y, cb, b.x * sb));
+                    }
+                    LE[kFeTail + p] = a; LO[fes_offo<S, CH>(0) + kFeTail + p] = b;
+                }
+                if (k + 1 < nch) {
+                    const int64_t reln = rel0 + CH;
+                    const bool inside = reln >= 0 && reln + CH <= total;
+#pragma unroll
+                    for (int q = 0; q < NPF; ++q) pf[q] = fe_fetch_pair(chan, hist, hist_len, reln + 2 * (tid + q * kFeThreads), total, inside);
+                }
+                __syncthreads();                                                        // B1
+                FesStages<S, CH, 0, BLK, false>::run(LE, LO, LZ, hb, zeta, tid);        // B2 .. B(BLK+1)
+                fes_carry_tail<(CH >> BLK)>(LE, LO, fes_off<CH>(BLK - 1), fes_offo<S, CH>(BLK - 1));
+            }
+        } else {
+            for (int k = 0; k <= nch; ++k) {
+                const bool have = k >= 1, bar = k < nch;          // chunk k - 1 has a tail to run; the workers are at chunk k
+                const int64_t uc = u_lo + (int64_t)(k - 1) * CH;
+                const int64_t kz0 = uc >> S;
+                int64_t jmine = 0, jhi = 0;
+                int kj = 0;
+                float2 hv[kArmTaps / 2];
+                if (have) {
+                    const int64_t ja = resamp_first_out(kz0, dyn.phase0, step), jb = resamp_first_out(kz0 + CZ, dyn.phase0, step);
+                    const int64_t jlo = ja < j0 ? j0 : ja;
+                    jhi = jb > j1 ? j1 : jb;
+                    jmine = jlo + ltid;                           // CZ <= 64 chain outputs, rate < 1: at most one per lane
+                    if (jmine < jhi) {
+                        const int64_t Pj = (int64_t)dyn.phase0 + jmine * (int64_t)step;
+                        kj = (int)((Pj >> 24) - kz0);
+                        const float2 *h2 = reinterpret_cast<const float2 *>(arms + (int)((Pj & 0xFFFFFF) >> 16) * kArmTaps);
+#pragma unroll
+                        for (int t = 0; t < kArmTaps / 2; ++t) hv[t] = h2[t];
+                    }
+                    FesStages<S, CH, BLK, BLK + 1, true>::run(LE, LO, LZ, hb, zeta, ltid);      // stage S-2 and the carry of its input
+                }
+                if (bar) __syncthreads();                                                       // B1
+                if (have) {
+                    if (k >= 2 && ltid < kFeZTail) LZ[ltid] = LZ[CZ + ltid];                    // Z tail of the chunk before
+                    wave_sync();
+                    FesStages<S, CH, BLK + 1, S, true>::run(LE, LO, LZ, hb, zeta, ltid);        // stage S-1 -> Z
+                }
+                if (bar) __syncthreads();                                                       // B2
+                if (have) {
+                    wave_sync();
+                    if (jmine < jhi) {
+                        const float2 *z = LZ + kFeZTail + kj - (kArmTaps - 1);
+                        float ar = 0.f, ai = 0.f;
+#pragma unroll
+                        for (int t = 0; t < kArmTaps / 2; ++t) {
+                            ar = fmaf(hv[t].x, z[2 * t].x, ar); ai = fmaf(hv[t].x, z[2 * t].y, ai);
+                            ar = fmaf(hv[t].y, z[2 * t + 1].x, ar); ai = fmaf(hv[t].y, z[2 * t + 1].y, ai);
+                        }
+                        iq_cur[kIqHist + jmine] = make_float2(ar, ai);
+                    }
+                    wave_sync();
+                }
+                if (bar) { for (int q = 2; q <= BLK; ++q) __syncthreads(); }                    // B3 .. B(BLK+1)
+            }
+        }
+        return;
+    }
+
     float4 pf[NPF];
     {
         const int64_t rel0 = u_lo - (int64_t)dyn.buf0;
@@ -635,11 +733,11 @@ __global__ __launch_bounds__(kFeThreads, 4) void demod_frontend_s(
         // the previous chunk's resampler is done (barrier above): its Z tail may move to the front now
         if (uc > u_lo && tid >= kFeThreads - kFeZTail) { const int k = tid - (kFeThreads - kFeZTail); LZ[k] = LZ[CZ + k]; }
         constexpr int BLK = fes_blk<S, CH>();
-        FesStages<S, CH, 0, BLK, false>::run(LE, LO, LZ, hb, zeta);
+        FesStages<S, CH, 0, BLK, false>::run(LE, LO, LZ, hb, zeta, tid);
         // tail of the last block-wide stage's input region (threads 208 .. 255)
         if constexpr (BLK >= 1) fes_carry_tail<(CH >> BLK)>(LE, LO, fes_off<CH>(BLK - 1), fes_offo<S, CH>(BLK - 1));
         if (BLK < S && tid >= 64) continue;                      // waves 1..3 go on to the next chunk
-        FesStages<S, CH, BLK, S, true>::run(LE, LO, LZ, hb, zeta);
+        FesStages<S, CH, BLK, S, true>::run(LE, LO, LZ, hb, zeta, tid);
         // ---- the arbitrary resampler on Z
         if (jmine < jhi) {
             const float2 *z = LZ + kFeZTail + kj - (kArmTaps - 1);
