@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native CubicSDR hot path (contract: see task statement / DESIGN.md).
 
-Workload = BASELINE.json configs[1] ("C2"): 64x NBFM demodulators, 10 MS/s complex-float IQ, firpfbch M = 20
-(block = 166 680 samples, channel rate 500 kS/s), 16384-point spectrum FFT (internal 32768), every sample FFT'ed
-("contiguous" frames).  One step = one pass of the whole hot path (channelizer + 64 demodulator chains
-+ spectrum) over one batch of `--blocks` consecutive IQ blocks that are already resident in HBM.
+Default workload = BASELINE.json configs[2] ("C3", the configuration the north-star target is quoted on): 256 mixed
+NBFM / AM / USB demodulators, 61.44 MS/s complex-float IQ, firpfbch M = 122 (block = 1 024 068 samples, channel rate
+503 606 S/s), 65536-point spectrum FFT (internal 131072), every sample FFT'ed ("contiguous" frames).
+`--config C3N` is the same with 256 NBFM demodulators (the north-star sentence's wording), `--config C2` the 64-NBFM /
+10 MS/s / 16384-point case.
+
+One step = `--batches` consecutive passes of the whole hot path (channelizer + demodulator chains + spectrum), each over
+one batch of `--blocks` consecutive IQ blocks that are already resident in HBM; the stream state (filter histories,
+oscillators, averagers) carries on from batch to batch.  The defaults make one step ~0.1-0.2 s of GPU work so that the
+driver's `--steps 20` is a multi-second timed region.
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 Multi-GPU: each rank owns an independent IQ stream with its own demodulators (BASELINE config 5 style partitioning:
 no data-path collective); value = samples processed by all ranks / max-over-ranks time; scaling = weak.
+`--config C4 --gpus N` is the demodulator-sharded one-stream case (see cubicsdr_amd/parallel.py).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -24,136 +31,183 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-
-FS = 10_000_000
-M = 20
-BLOCK = 166_680            # ceil(floor(Fs/60)/M)*M, SoapySDRThread.cpp:668-674
-N_DEMODS = 64
-FFT_SIZE = 16384
-PROFILE_PERIOD = 8          # per-kernel HIP events bracket every 8th launch (bracketing all of them costs ~7 % of the throughput)
+PROFILE_PERIOD = 8        # per-kernel HIP events bracket every 8th launch (bracketing all of them costs ~7 % of the throughput)
 CENTER = 100_000_000
-NBFM_BW = 12_500
 AUDIO_RATE = 48_000
+MODEM_BW = {"NBFM": 12_500, "AM": 6_000, "USB": 5_400}
+MODEM_ID = {"NBFM": 0, "AM": 2, "USB": 3}
+
+# fs, M, block (SoapySDRThread.cpp:668-693: numChannels = even floor of ceil(fs / 500 kHz), block = ceil(fs / 60 / M) M), demods,
+# fftSize, modem round-robin, IQ blocks per batch, batches per step
+CONFIGS = {
+    "C2": dict(fs=10_000_000, M=20, block=166_680, n_demods=64, fft=16384, kinds=["NBFM"], blocks=256, batches=48,
+               label="C2: 64x NBFM demods (12.5 kHz -> 48 kHz audio), 10 MS/s complex-float IQ, firpfbch M=20, 16384-pt spectrum FFT (internal 32768) over every sample"),
+    "C3": dict(fs=61_440_000, M=122, block=1_024_068, n_demods=256, fft=65536, kinds=["NBFM", "AM", "USB"], blocks=64, batches=48,
+               label="C3: 256 mixed NBFM/AM/USB demods, 61.44 MS/s complex-float IQ, firpfbch M=122, 65536-pt spectrum FFT (internal 131072) over every sample"),
+    "C3N": dict(fs=61_440_000, M=122, block=1_024_068, n_demods=256, fft=65536, kinds=["NBFM"], blocks=64, batches=48,
+                label="C3N: 256 NBFM demods, 61.44 MS/s complex-float IQ, firpfbch M=122, 65536-pt spectrum FFT (internal 131072) over every sample"),
+}
 
 
 def demod_frequencies(center, fs, n):
     return [int(center + (k + 0.37) * fs / n - fs / 2) for k in range(n)]
 
 
-def make_ring(torch, device, n_blocks, seed):
-    """synthetic IQ ring in HBM: noise sigma 0.05 + one NBFM carrier per demod + DC offset."""
-    n = n_blocks * BLOCK
+def make_ring(torch, device, cfg, n_blocks, seed):
+    """synthetic IQ ring in HBM: noise sigma 0.05 + one modulated carrier per demod (NBFM: 1 kHz tone, 2.5 kHz
+    deviation; AM: 80 %; USB: single tone at +1 kHz) + DC offset.  Generated in slices so the temporaries stay small."""
+    fs, n_demods, kinds = cfg["fs"], cfg["n_demods"], cfg["kinds"]
+    n = n_blocks * cfg["block"]
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     x = torch.randn(n, 2, generator=g, device=device, dtype=torch.float32) * 0.05
-    t = torch.arange(n, device=device, dtype=torch.float64) / FS
-    amp = 0.5 / math.sqrt(N_DEMODS)
-    acc_r = torch.zeros(n, device=device, dtype=torch.float32)
-    acc_i = torch.zeros(n, device=device, dtype=torch.float32)
-    mod = (2500.0 / 1000.0) * torch.sin(2 * math.pi * 1000.0 * t)
-    for f in demod_frequencies(CENTER, FS, N_DEMODS):
-        ph = (2 * math.pi * (f - CENTER)) * t + mod
-        ph = torch.remainder(ph, 2 * math.pi)
-        acc_r += (amp * torch.cos(ph)).float()
-        acc_i += (amp * torch.sin(ph)).float()
-    x[:, 0] += acc_r + 0.01
-    x[:, 1] += acc_i + 0.01
+    amp = 0.5 / math.sqrt(n_demods)
+    freqs = demod_frequencies(CENTER, fs, n_demods)
+    SL = 1 << 22
+    for s0 in range(0, n, SL):
+        s1 = min(n, s0 + SL)
+        t = torch.arange(s0, s1, device=device, dtype=torch.float64) / fs
+        tone = torch.sin(2 * math.pi * 1000.0 * t)
+        acc_r = torch.zeros(s1 - s0, device=device, dtype=torch.float32)
+        acc_i = torch.zeros(s1 - s0, device=device, dtype=torch.float32)
+        for i, f in enumerate(freqs):
+            kind = kinds[i % len(kinds)]
+            df = float(f - CENTER)
+            if kind == "NBFM":
+                ph = torch.remainder((2 * math.pi * df) * t + 2.5 * tone, 2 * math.pi).float()
+                acc_r += amp * torch.cos(ph); acc_i += amp * torch.sin(ph)
+            elif kind == "AM":
+                ph = torch.remainder((2 * math.pi * df) * t, 2 * math.pi).float()
+                env = (amp * (1 + 0.8 * tone)).float()
+                acc_r += env * torch.cos(ph); acc_i += env * torch.sin(ph)
+            else:
+                ph = torch.remainder((2 * math.pi * (df + 1000.0)) * t, 2 * math.pi).float()
+                acc_r += amp * torch.cos(ph); acc_i += amp * torch.sin(ph)
+        x[s0:s1, 0] += acc_r + 0.01
+        x[s0:s1, 1] += acc_i + 0.01
     return x.contiguous()
 
 
 # algorithmic HBM bytes per INPUT SAMPLE attributed to each kernel (DESIGN.md "Roofline accounting"; SURVEY.md 8d):
-#   ingest read 8 + channelizer write 8 ; demod reads 8 N/M + audio/IQ writes ; spectrum read 8 + display write 4
-def algorithmic_bytes_per_sample(kernel, n_demods, m, fft_n):
-    audio = 4.0 * n_demods * AUDIO_RATE / FS
+#   ingest read 8 + channelizer write 8 ; demod reads 8 N/M + audio writes ; spectrum read 8 + display write 4
+def algorithmic_bytes_per_sample(kernel, cfg):
+    audio = 4.0 * cfg["n_demods"] * AUDIO_RATE / cfg["fs"]
     table = {
         "chan_analyze": 16.0,
-        "demod_frontend": 8.0 * n_demods / m,
+        "demod_frontend": 8.0 * cfg["n_demods"] / cfg["M"],
         "demod_modem": 0.0,
         "demod_audio_interp": audio,
         "spec_fft_radix": 8.0,         # the frame is read once from HBM ...
-        "spec_fft_rows": 0.0,          # ... the second pass re-reads an intermediate that is not algorithmic traffic
+        "spec_fft_rows": 0.0,          # ... later passes re-read intermediates that are not algorithmic traffic
+        "spec_fft_big": 12.0,          # one-pass transform: reads the frame, writes the display points' inputs
         "spec_average": 0.0,
         "spec_display": 4.0,
     }
     return table.get(kernel, 0.0)
 
 
-def measured_traffic_bytes(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/collect.sh: FETCH_SIZE and WRITE_SIZE in their
-    own rocprofv3 runs of this same command; gfx950 reports half of a wide coalesced read stream, MI355X_MICROARCH.md "HBM",
-    so the read side is doubled), per IQ block of the launch.  None when no pass is on file for this kernel."""
+def whole_path_bytes_per_sample(cfg):                      # SURVEY.md 8d: 54.8 (C2), 45.6 (C3)
+    return 8 + 8 + 8.0 * cfg["n_demods"] / cfg["M"] + 4.0 * cfg["n_demods"] * AUDIO_RATE / cfg["fs"] + 12
+
+
+def measured_traffic(cfg_name):
+    """-> (dict kernel -> HBM bytes per IQ block, file) from the latest committed PMC pass of this configuration
+    (profiles/collect.sh: FETCH_SIZE and WRITE_SIZE in their own rocprofv3 runs of this same command; gfx950 reports half of a
+    wide coalesced read stream, MI355X_MICROARCH.md "HBM", so the read side is doubled)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_pmc_traffic.json" % cfg_name.lower())))
     if not files:
-        return None
+        return {}, None
     try:
-        t = json.load(open(files[-1]))                      # the latest committed pass
+        t = json.load(open(files[-1]))
     except Exception:
-        return None
+        return {}, None
     blocks = float(t.get("_meta", {}).get("blocks_per_launch", 64))
+    out = {}
     for name, v in t.items():
-        if name.split("<")[0] in (kernel, kernel + "_s") and "FETCH_SIZE_KiB_avg_per_launch" in v and "WRITE_SIZE_KiB_avg_per_launch" in v:
-            return (2.0 * v["FETCH_SIZE_KiB_avg_per_launch"] + v["WRITE_SIZE_KiB_avg_per_launch"]) * 1024.0 / blocks
-    return None
+        if "FETCH_SIZE_KiB_avg_per_launch" in v and "WRITE_SIZE_KiB_avg_per_launch" in v:
+            base = name.split("<")[0]
+            base = {"demod_frontend_s": "demod_frontend", "spec_fft_rows4096": "spec_fft_rows"}.get(base, base)
+            out[base] = out.get(base, 0.0) + (2.0 * v["FETCH_SIZE_KiB_avg_per_launch"] + v["WRITE_SIZE_KiB_avg_per_launch"]) * 1024.0 / blocks
+    return out, os.path.relpath(files[-1], ROOT)
 
 
-def cpu_baseline(ring_host, target_seconds):
-    """time the reference CPU path (single thread) on a bounded sample of the same workload"""
+def cpu_baseline(cfg, ring_host, target_seconds):
+    """time the reference CPU path on a bounded sample of the same workload: single thread, then thread-per-stage"""
     import numpy as np
     import oracle.liquid_api as A
     kind = "reference" if A.available("ref") else "port"
     L = A.load("ref" if kind == "reference" else "port")
+    L.oracle_chain_create.restype = C.c_void_p
+    L.oracle_chain_create.argtypes = [C.c_int] * 3 + [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int]
     L.oracle_chain_run.restype = C.c_double
-    L.oracle_chain_run.argtypes = [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
-    chan_bw = FS // M
-    centers = [CENTER + chan_bw * i for i in range(M // 2)] + [CENTER - FS // 2 + chan_bw * i for i in range(M // 2)] + [CENTER + FS // 2]
-    ch, nf, md = [], [], []
-    for f in demod_frequencies(CENTER, FS, N_DEMODS):
-        i = min(range(M + 1), key=lambda k: (abs(f - centers[k]), k))
-        shift = f - centers[i]
-        ch.append(i)
+    L.oracle_chain_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    fs, M, BLOCK, n_demods, kinds = cfg["fs"], cfg["M"], cfg["block"], cfg["n_demods"], cfg["kinds"]
+    chan_bw = fs // M
+    centers = [CENTER + chan_bw * i for i in range(M // 2)] + [CENTER - fs // 2 + chan_bw * i for i in range(M // 2)] + [CENTER + fs // 2]
+    ch, nf, md, kd, iqr, aur = [], [], [], [], [], []
+    for i, f in enumerate(demod_frequencies(CENTER, fs, n_demods)):
+        k = min(range(M + 1), key=lambda q: (abs(f - centers[q]), q))
+        shift = f - centers[k]
+        name = kinds[i % len(kinds)]
+        ch.append(k)
         nf.append(np.float32(2.0 * math.pi * abs(shift) / chan_bw))
         md.append(0 if shift == 0 else (1 if shift < 0 else -1))
-    ch = np.array(ch, np.int32); nf = np.array(nf, np.float32); md = np.array(md, np.int32)
+        kd.append(MODEM_ID[name])
+        iqr.append(np.float32(float(MODEM_BW[name]) / chan_bw))
+        aur.append(np.float32(float(AUDIO_RATE) / MODEM_BW[name]))
+    ch = np.array(ch, np.int32); nf = np.array(nf, np.float32); md = np.array(md, np.int32); kd = np.array(kd, np.int32)
+    iqr = np.array(iqr, np.float32); aur = np.array(aur, np.float32)
     ring_blocks = ring_host.size // BLOCK
     t = np.zeros(3)
     na = C.c_longlong()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
 
-    def run(nb):
-        return L.oracle_chain_run(M, BLOCK, nb, ring_blocks, ring_host.ctypes.data_as(C.c_void_p), N_DEMODS, ch.ctypes.data_as(C.c_void_p),
-                                  nf.ctypes.data_as(C.c_void_p), md.ctypes.data_as(C.c_void_p), float(NBFM_BW) / chan_bw,
-                                  float(AUDIO_RATE) / NBFM_BW, 2 * FFT_SIZE, t.ctypes.data_as(C.c_void_p), C.byref(na))
-    probe = run(8)
-    nb = max(8, int(target_seconds / (probe / 8)))
-    T = run(nb)
-    return {"value": nb * BLOCK / T / 1e6, "unit": "MS/s", "cores": 1, "kind": kind,
-            "sample": "%d blocks x %d samples of the same C2 workload (64 NBFM chains + M=20 firpfbch + contiguous 32768-pt FFT frames), %.1f s single thread: channelizer %.0f%%, demodulators %.0f%%, spectrum %.0f%%"
-                      % (nb, BLOCK, T, 100 * t[0] / T, 100 * t[1] / T, 100 * t[2] / T)}
+    ncpu = os.cpu_count() or 1
+    # the DSP objects are built once (liquid designs two 3585-tap Kaiser prototypes per demodulator: ~0.3 s each) and kept
+    h = C.c_void_p(L.oracle_chain_create(M, BLOCK, ring_blocks, p(ring_host), n_demods, p(ch), p(nf), p(md), p(kd), p(iqr), p(aur), 2 * cfg["fft"], ncpu))
+
+    def run(nb, nthreads):
+        return L.oracle_chain_run(h, nb, nthreads, p(t), C.byref(na))
+    nprobe = 2 if BLOCK > 500_000 else 8
+    probe = run(nprobe, 1)
+    nb = max(nprobe, int(target_seconds / (probe / nprobe)))
+    T = run(nb, 1)
+    out = {"value": nb * BLOCK / T / 1e6, "unit": "MS/s", "cores": 1, "kind": kind,
+           "sample": "%d blocks x %d samples of the same %s workload (%d demodulator chains + M=%d firpfbch + contiguous %d-pt FFT frames), %.1f s single thread: channelizer %.0f%%, demodulators %.0f%%, spectrum %.0f%%"
+                     % (nb, BLOCK, cfg["name"], n_demods, M, 2 * cfg["fft"], T, 100 * t[0] / T, 100 * t[1] / T, 100 * t[2] / T)}
+    if ncpu >= 3:
+        nb2 = max(nprobe, int(nb * min(ncpu - 1, 8) * 0.6))
+        T2 = run(nb2, ncpu)
+        out["threaded"] = {"value": nb2 * BLOCK / T2 / 1e6, "unit": "MS/s", "cores": ncpu, "nproc": ncpu,
+                           "sample": "%d blocks, %.1f s, thread-per-stage as CubicSDR runs it: 1 SDRPostThread + 1 spectrum thread + %d demodulator threads sharing the %d demodulators"
+                                     % (nb2, T2, ncpu - 2, n_demods)}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--blocks", type=int, default=0, help="IQ blocks per step (batch resident in HBM); default 256 (C2) / 16 (C3)")
-    ap.add_argument("--config", default="C2", choices=["C2", "C3"],
-                    help="BASELINE.json workload: C2 (default, the judged one) or C3 = 256 mixed NBFM/AM/USB demods, 61.44 MS/s, M=122, 65536-pt FFT (reported, not judged)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 disables)")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3", choices=sorted(CONFIGS) + ["C4"],
+                    help="BASELINE.json workload: C3 (default: 256 mixed demods, 61.44 MS/s, M=122, 65536-pt FFT -- the configuration the target is quoted on), "
+                         "C3N (same, all NBFM), C2 (64 NBFM, 10 MS/s, M=20, 16384-pt), C4 (M=1024 channelizer + 1024 NBFM, demodulators sharded over the ranks)")
+    ap.add_argument("--blocks", type=int, default=0, help="IQ blocks per batch (HBM-resident ring); default per config")
+    ap.add_argument("--batches", type=int, default=0, help="batches per step; default per config (a step is ~0.1-0.2 s of GPU work)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline sample budget per leg (0 disables)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event profile")
+    ap.add_argument("--no-latency", action="store_true", help="skip the small-batch (real-time shape) measurement")
     args = ap.parse_args()
+    if args.config == "C4":
+        from cubicsdr_amd import sharded_bench
+        return sharded_bench.main(args)
 
-    global FS, M, BLOCK, N_DEMODS, FFT_SIZE
-    kinds = ["NBFM"]
-    workload = "C2: 64x NBFM demods (12.5 kHz -> 48 kHz audio), 10 MS/s complex-float IQ, firpfbch M=20, 16384-pt spectrum FFT (internal 32768) over every sample"
-    if args.config == "C3":
-        FS, M, BLOCK, N_DEMODS, FFT_SIZE = 61_440_000, 122, 1_024_068, 256, 65536          # SoapySDRThread.cpp:668-693 for 61.44 MS/s
-        kinds = ["NBFM", "AM", "USB"]
-        workload = "C3: 256 mixed NBFM/AM/USB demods, 61.44 MS/s complex-float IQ, firpfbch M=122, 65536-pt spectrum FFT (internal 131072) over every sample"
-        args.cpu_seconds = 0.0                          # the CPU sample is defined for the judged workload only
-    if not args.blocks:
-        args.blocks = 256 if args.config == "C2" else 16
-    bytes_per_sample = 8 + 8 + 8.0 * N_DEMODS / M + 4.0 * N_DEMODS * AUDIO_RATE / FS + 12      # SURVEY.md 8d: 54.8 (C2), 45.6 (C3)
+    cfg = dict(CONFIGS[args.config]); cfg["name"] = args.config
+    FS, M, BLOCK, N_DEMODS, FFT_SIZE, kinds = cfg["fs"], cfg["M"], cfg["block"], cfg["n_demods"], cfg["fft"], cfg["kinds"]
+    NB = args.blocks or cfg["blocks"]
+    NBATCH = args.batches or cfg["batches"]
+    bytes_per_sample = whole_path_bytes_per_sample(cfg)
     import torch
     from cubicsdr_amd import build as cbuild
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,26 +229,28 @@ def main():
     device = torch.device("cuda", local_rank)
 
     from cubicsdr_amd.engine import Context, DemodBank, SDRPost, SpectrumProcessor
-    NB = args.blocks
-    ring = make_ring(torch, device, NB, seed=0xC0B1C5D2 + rank)
+    ring = make_ring(torch, device, cfg, NB, seed=0xC0B1C5D2 + rank)
     torch.cuda.synchronize()
-    n_frames_max = (NB * BLOCK) // (2 * FFT_SIZE) + 2
 
-    def make_pipeline():
+    def make_pipeline(nb):
         c = Context(local_rank)        # one HIP stream per pipeline stage inside (include/csdr_hip.h "Streams")
-        p = SDRPost(c, FS, M, BLOCK, max_blocks=NB)
-        b = DemodBank(c, N_DEMODS, max_blocks=NB)
+        p = SDRPost(c, FS, M, BLOCK, max_blocks=nb)
+        b = DemodBank(c, N_DEMODS, max_blocks=nb)
         for i, f in enumerate(demod_frequencies(CENTER, FS, N_DEMODS)):
             kind = kinds[i % len(kinds)]
-            b.configure(i, p, kind, {"NBFM": NBFM_BW, "AM": 6000, "USB": 5400}[kind], f, AUDIO_RATE)
-        return c, p, b, SpectrumProcessor(c, FFT_SIZE, max_frames=n_frames_max)
+            b.configure(i, p, kind, MODEM_BW[kind], f, AUDIO_RATE)
+        return c, p, b, SpectrumProcessor(c, FFT_SIZE, max_frames=(nb * BLOCK) // (2 * FFT_SIZE) + 2)
 
-    ctx, post, bank, spec = make_pipeline()
+    ctx, post, bank, spec = make_pipeline(NB)
+
+    def batch(p=post, b=bank, s=spec, nb=NB, x=ring):
+        p.execute(x, nb, BLOCK, CENTER)
+        b.execute(p)
+        s.process(x, nb, BLOCK, contiguous=True)
 
     def step():
-        post.execute(ring, NB, BLOCK, CENTER)
-        bank.execute(post)
-        spec.process(ring, NB, BLOCK, contiguous=True)
+        for _ in range(NBATCH):
+            batch()
 
     for _ in range(args.warmup):
         step()
@@ -223,47 +279,52 @@ def main():
         ctx.profile_enable(False)
     audio_total = bank.total_audio()
 
-    samples = args.steps * NB * BLOCK * world
+    samples = args.steps * NBATCH * NB * BLOCK * world
     value = samples / elapsed / 1e6
     out = {
         "metric": "IQ MS/s sustained @ N demods + FFT size",
         "value": value, "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": workload,
-                   "blocks_per_step": NB, "block_len": BLOCK, "n_demods": N_DEMODS, "fft_size": FFT_SIZE,
-                   "realtime_multiple": value / world / (FS / 1e6), "audio_samples_per_step": audio_total,
-                   "event_ms_per_step": ev_ms / args.steps, "parallelism": "one independent IQ stream per GPU; one HIP stream per pipeline stage, consecutive batches overlap"},
+        "config": {"workload": cfg["label"], "batches_per_step": NBATCH, "blocks_per_batch": NB, "block_len": BLOCK,
+                   "samples_per_step": NBATCH * NB * BLOCK, "n_demods": N_DEMODS, "fft_size": FFT_SIZE,
+                   "realtime_multiple": value / world / (FS / 1e6), "audio_samples_per_batch": audio_total,
+                   "timed_region_s": elapsed, "event_ms_per_step": ev_ms / args.steps,
+                   "error_metric": "parity tests hold |gpu - reference| <= 1e-5 of the reference's peak magnitude per compared array (tests/util.py rel_err); integer items bit-exact",
+                   "parallelism": "one independent IQ stream per GPU; one HIP stream per pipeline chain, consecutive batches overlap"},
     }
     if prof:
-        dom = max(prof, key=lambda k: prof[k][0])
+        units = NB * BLOCK                      # input samples one launch covers
+        launches_per_step = {k: NBATCH * (2 if k == "spec_fft_radix" and 2 * FFT_SIZE > 32 * 4096 else 1) for k in prof}
+        dom = max(prof, key=lambda k: prof[k][0] / prof[k][1] * launches_per_step[k])
         ms, launches = prof[dom]
         avg_ms = ms / launches
-        units = NB * BLOCK                      # input samples one launch covers
-        bps = algorithmic_bytes_per_sample(dom, N_DEMODS, M, 2 * FFT_SIZE)
+        bps = algorithmic_bytes_per_sample(dom, cfg)
         achieved = bps * units / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_file = measured_traffic(args.config)
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": (None if args.config != "C2" or measured_traffic_bytes(dom) is None else measured_traffic_bytes(dom) * NB),
-                           "traffic_unit": "bytes per launch (committed PMC pass, per IQ block, times the blocks of this launch)",
+                           "traffic": (traffic[dom] * NB if dom in traffic else None),
+                           "traffic_unit": "HBM bytes per launch of the dominant kernel (PMC pass %s: per IQ block, times the blocks of this launch)" % traffic_file,
                            "avg_launch_ms": avg_ms,
                            "algorithmic_bytes_per_launch": bps * units,
                            "whole_path": {"bytes_per_sample": round(bytes_per_sample, 1), "achieved": bytes_per_sample * value / world * 1e6 / 1e9,
-                                          "frac": bytes_per_sample * value / world * 1e6 / 1e9 / HBM_PEAK_GBS},
+                                          "frac": bytes_per_sample * value / world * 1e6 / 1e9 / HBM_PEAK_GBS,
+                                          "traffic_bytes_per_sample": (sum(traffic.values()) / BLOCK if traffic else None)},
                            "profile_sampling": "HIP events around every %d-th launch of each kernel inside the timed region" % PROFILE_PERIOD,
-                           "kernels_ms_per_step": {k: v[0] * PROFILE_PERIOD / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}
+                           "kernels_avg_launch_ms": {k: v[0] / v[1] for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0] / kv[1][1])}}
     spec.close(); bank.close(); post.close(); ctx.close()
     if prof and rank == 0:
         # The live durations above include whatever the other stream's kernels took from the GPU at that moment (the two chains
         # overlap by design), so they move with the phase between the chains.  For a kernel-quality figure the same batch is run
         # once more, untimed, on ONE stream: every kernel alone on the device.
         os.environ["CSDR_STREAMS"] = "1"
-        ctx1, post1, bank1, spec1 = make_pipeline()
+        ctx1, post1, bank1, spec1 = make_pipeline(NB)
         os.environ.pop("CSDR_STREAMS", None)
         for it in range(13):
             if it == 3:
                 ctx1.synchronize(); ctx1.profile_enable(1)
-            post1.execute(ring, NB, BLOCK, CENTER); bank1.execute(post1); spec1.process(ring, NB, BLOCK, contiguous=True)
+            batch(post1, bank1, spec1)
         ctx1.synchronize()
         solo = {k: v[0] / v[1] for k, v in ctx1.profile().items()}
         dom = out["roofline"]["kernel"]
@@ -272,9 +333,31 @@ def main():
                                    "achieved": alg / (solo[dom] * 1e-3) / 1e9, "frac": alg / (solo[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "kernels_ms_per_launch": {k: v for k, v in sorted(solo.items(), key=lambda kv: -kv[1])}}
         spec1.close(); bank1.close(); post1.close(); ctx1.close()
+    if rank == 0 and world == 1 and not args.no_latency:
+        # the real-time shape: the reference hands ONE block (1/60 s of signal) per call (SoapySDRThread.cpp:12); small batches
+        # through the same entry points, untimed part of the run, reported next to the throughput setting
+        lat = {}
+        for nb in (1, 4, 16):
+            if nb >= NB:
+                continue
+            c2, p2, b2, s2 = make_pipeline(nb)
+            calls = max(8, min(240, 960 // nb))
+            sub = ring[: nb * BLOCK]
+            for _ in range(4):
+                batch(p2, b2, s2, nb, sub)
+            c2.synchronize()
+            tl = time.perf_counter()
+            for _ in range(calls):
+                batch(p2, b2, s2, nb, sub)
+            c2.synchronize()
+            dt = time.perf_counter() - tl
+            lat[str(nb)] = {"MS_per_s": calls * nb * BLOCK / dt / 1e6, "blocks_per_s": calls * nb / dt, "ms_per_call": 1e3 * dt / calls,
+                            "streams_at_60_blocks_per_s": calls * nb / dt / 60.0}
+            s2.close(); b2.close(); p2.close(); c2.close()
+        out["config"]["small_batches"] = lat
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         try:
-            out["cpu_baseline"] = cpu_baseline(ring.cpu().numpy().view("complex64").reshape(-1), args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(cfg, ring.cpu().numpy().view("complex64").reshape(-1), args.cpu_seconds)
         except Exception as e:  # the baseline is reported, never required for the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "MS/s", "cores": 0, "kind": "unavailable", "sample": repr(e)}
     if rank == 0:

@@ -81,6 +81,13 @@ __device__ inline void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// keep the compiler's scheduler from moving instructions across this point (software-pipelined loops: requests for the next
+// iteration stay in front of the arithmetic of the current one instead of being sunk to their first use)
+__device__ __forceinline__ void sched_fence() {
+#if defined(__AMDGCN__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
 // 16 bytes that are only guaranteed 8-byte aligned (two adjacent complex samples at an odd sample offset)
 struct __attribute__((aligned(8))) f4u { float x, y, z, w; };
 

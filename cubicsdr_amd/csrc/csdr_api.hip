@@ -244,6 +244,17 @@ static int chan_geometry(int M, int hop, ChanGeom &g) {
         g.nkA = (H + 3) / 4; g.KA = (H + g.nkA - 1) / g.nkA; g.PA = g.nkA * g.KA;
     }
     g.magicM = (unsigned)((1ull << 32) / (unsigned)M) + 1u;
+    if (hop == M && g.B == 2 && g.oddA && g.A <= 63 && !getenv("CSDR_CHAN_GENERIC")) {
+        // whole transform of a frame inside one lane (kernels_post.hpp, chan_analyze_p2): (A - 1) / 2 output pairs + the k = 0
+        // pseudo pair, split evenly over (up to) four passes of at most eight slots
+        const int slots = (g.A - 1) / 2 + 1;
+        g.p2 = 1;
+        g.KA = std::min(8, (slots + kP2Waves - 1) / kP2Waves);
+        g.nkA = (slots + g.KA - 1) / g.KA;
+        g.PA = g.nkA * g.KA;
+        g.TF = kP2Frames; g.lgTF = 6; g.S = M; g.taps_lds = 0; g.stage_in = 1; g.threads = 64 * kP2Waves;
+        return CSDR_OK;
+    }
     g.taps_lds = (M <= 512) ? 1 : 0;
     g.stage_in = (M <= 256) ? 1 : 0;
     g.fpw = 0;   // set per launch
@@ -267,6 +278,20 @@ static int chan_geometry(int M, int hop, ChanGeom &g) {
 
 typedef void (*chan_kernel_t)(const float2 *, const float2 *, float2 *, const float *, const float2 *, const float2 *, const float2 *,
                               const int *, ChanGeom, int64_t, float2 *, int64_t, d2 *, double, const float2 *);
+typedef void (*chan_p2_kernel_t)(const float2 *, const float2 *, float2 *, const float *, const float2 *, const float2 *, const int *, ChanGeom,
+                                 int64_t, float2 *, int64_t, d2 *, double);
+static chan_p2_kernel_t chan_p2_kernel(const ChanGeom &g) {
+    switch (g.KA) {
+        case 1: return chan_analyze_p2<1>;
+        case 2: return chan_analyze_p2<2>;
+        case 3: return chan_analyze_p2<3>;
+        case 4: return chan_analyze_p2<4>;
+        case 5: return chan_analyze_p2<5>;
+        case 6: return chan_analyze_p2<6>;
+        case 7: return chan_analyze_p2<7>;
+        default: return chan_analyze_p2<8>;
+    }
+}
 static chan_kernel_t chan_kernel(const ChanGeom &g) {
     if (g.oddA) {
         if (g.hop != g.M) return g.stage_in ? chan_analyze<1, 1, 1, 1> : g.taps_lds ? chan_analyze<0, 1, 1, 1> : chan_analyze<0, 0, 1, 1>;
@@ -321,7 +346,15 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
         for (int c = 0; c < M; c++) for (int n = 0; n < kChanTaps; n++) tapsT[(size_t)n * M + c] = taps[(size_t)c * kChanTaps + n];
         std::vector<float2> twA((size_t)g.A * g.PA, make_float2(0.f, 0.f)), twB((size_t)g.B * g.PB, make_float2(0.f, 0.f)), twM((size_t)g.A * g.B);
         auto W = [](int64_t num, int den) { const double a = -2.0 * M_PI * (double)(num % den) / (double)den; return make_float2((float)std::cos(a), (float)std::sin(a)); };
-        if (g.oddA) {        // (cos, sin)(2 pi kp c / A) at [(c - 1) PA + kp - 1], c, kp = 1 .. (A - 1) / 2
+        if (g.p2) {          // slot q: output pair k = q + 1 (q < H), k = 0 as (1, 0) (q == H), unused (0, 0) beyond
+            const int H = (g.A - 1) / 2;
+            twA.assign((size_t)H * g.PA, make_float2(0.f, 0.f));
+            for (int c = 1; c <= H; c++) for (int q = 0; q <= H; q++) {
+                const int k = q < H ? q + 1 : 0;
+                const double a = 2.0 * M_PI * (double)(((int64_t)c * k) % g.A) / (double)g.A;
+                twA[(size_t)(c - 1) * g.PA + q] = make_float2((float)std::cos(a), (float)std::sin(a));
+            }
+        } else if (g.oddA) {        // (cos, sin)(2 pi kp c / A) at [(c - 1) PA + kp - 1], c, kp = 1 .. (A - 1) / 2
             const int H = (g.A - 1) / 2;
             for (int c = 1; c <= H; c++) for (int kp = 1; kp <= H; kp++) {
                 const double a = 2.0 * M_PI * (double)(((int64_t)c * kp) % g.A) / (double)g.A;
@@ -345,8 +378,8 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
         CSDR_HIP_TRY(hipMemsetAsync(p->hist0.p, 0, H * sizeof(float2), st));
         CSDR_HIP_TRY(hipMemsetAsync(p->hist1.p, 0, H * sizeof(float2), st));
         CSDR_HIP_TRY(hipStreamSynchronize(st));   // host vectors above go out of scope
-        const size_t lds = chan_lds_bytes(g);
-        if (lds > 64 * 1024) CSDR_HIP_TRY(hipFuncSetAttribute((const void *)chan_kernel(g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const size_t lds = g.p2 ? chan_p2_lds_bytes(M) : chan_lds_bytes(g);
+        if (lds > 64 * 1024) CSDR_HIP_TRY(hipFuncSetAttribute(g.p2 ? (const void *)chan_p2_kernel(g) : (const void *)chan_kernel(g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     p->hist_parity = 0;
     p->active_host.resize(M);
@@ -440,10 +473,15 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
         // channelizer itself emits the per-tile end values the blocked scan needs
         const bool dc0 = !p->active_host.empty() && p->active_host[0] == 0;
         const bool fused_ends = dc0 && g.fpw >= 16;
+        if (g.p2) {
+            CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, chan_p2_kernel(g), dim3(ntiles), dim3(g.threads), chan_p2_lds_bytes(M), x, hist, hist_new, p->taps.p,
+                        p->twA.p, p->twM.p, p->active.p, g, n_frames, out, p->chan_stride, fused_ends ? p->tile_end.p : (d2 *)nullptr, p->dc_c);
+        } else {
         const chan_kernel_t kern = chan_kernel(g);
         CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, kern, dim3(ntiles), dim3(g.threads), chan_lds_bytes(g), x, hist, hist_new, p->taps.p,
                     p->twA.p, p->twB.p, p->twM.p, p->active.p, g, n_frames, out, p->chan_stride, fused_ends ? p->tile_end.p : (d2 *)nullptr, p->dc_c,
                     p->mode == CSDR_POST_PFBCH2 ? p->post2.p : (const float2 *)nullptr);
+        }
         p->hist_parity ^= 1;
         CSDR_HIP_TRY(hipGetLastError());
         if (dc0) rc = run_dc_blocker(p, out, out, n_frames, fused_ends, g.fpw);

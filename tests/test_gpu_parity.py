@@ -88,6 +88,43 @@ def test_channelizer2_matches_firpfbch2(ctx, fs, M, block):
     batch.close()
 
 
+@pytest.mark.parametrize("fs,M,block", [(5000000, 10, 83340), (7000000, 14, 14 * 70), (61440000, 122, 122 * 150), (61440000, 122, 1024068)])
+def test_channelizer_m_twice_odd(ctx, fs, M, block):
+    """M = 2 A with A odd (10, 14, 122 = the 61.44 MS/s channel count, SoapySDRThread.cpp:676-693) runs the one-lane-per-frame
+    kernel (chan_analyze_p2): whole and ragged 64-frame tiles, three blocks one at a time (carried history), then the same
+    three in one batch.  Tolerance relative to the strongest channel of the block (a DFT's rounding error scales with the
+    frame's energy; the reference's own mixed-radix / Rader FFT is no closer to the exact transform in the quiet channels)."""
+    from cubicsdr_amd.engine import SDRPost
+    from oracle.cubicsdr_chain import RefSDRPost
+    center = 100000000
+    x = [synth_iq(block, fs, center, [("NBFM", center + 123456), ("AM", center - 7 * (fs // M) + 999)], seed=71 + b, t0=b * block) for b in range(3)]
+    ref = RefSDRPost(_backend(), fs, M)
+    post = SDRPost(ctx, fs, M, block, max_blocks=1)
+    chans = list(range(M + 1))
+    want_all = {ch: [] for ch in chans}
+    for b in range(3):
+        ref.run_block(x[b], center)
+        post.execute(x[b], 1, block, center)
+        peak = float(np.max(np.abs(ref.data_out)))
+        for ch in chans:
+            want, fc, rate = ref.channel_data(ch)
+            got = post.read_channel(ch)
+            assert got.size == want.size == block // M
+            assert post.channel_center(ch) == fc
+            noise = 4 * np.spacing(np.float32(0.01 * M / 0.0005)) if ch == 0 else 0.0     # DC-blocker state noise (see C4 test)
+            assert np.max(np.abs(got - want)) < TOL * peak + noise, (b, ch)
+            want_all[ch].append(want)
+    post.close()
+    batch = SDRPost(ctx, fs, M, block, max_blocks=3)
+    batch.execute(np.concatenate(x), 3, block, center)
+    peak = max(float(np.max(np.abs(np.concatenate(want_all[ch])))) for ch in chans)
+    for ch in chans:
+        want = np.concatenate(want_all[ch])
+        noise = 4 * np.spacing(np.float32(0.01 * M / 0.0005)) if ch == 0 else 0.0
+        assert np.max(np.abs(batch.read_channel(ch) - want)) < TOL * peak + noise, ch
+    batch.close()
+
+
 def test_channelizer_batched_equals_blockwise(ctx):
     from cubicsdr_amd.engine import SDRPost
     fs, M, block, center = 2400000, 4, 40000, 100000000
