@@ -88,6 +88,32 @@ __device__ __forceinline__ void sched_fence() {
     __builtin_amdgcn_sched_barrier(0);
 #endif
 }
+// workgroup barrier that orders LDS traffic only: global loads / stores already issued stay in flight across it (__syncthreads
+// also waits for every outstanding global access of the wave -- vmcnt(0) -- which exposes the full store latency at each barrier)
+__device__ __forceinline__ void lds_barrier() {
+#if defined(__AMDGCN__)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#else
+    __syncthreads();
+#endif
+}
+// make a value opaque to the optimiser at this point: address arithmetic derived from it is redone where it is used instead of
+// being hoisted out of an enclosing loop and kept (or spilled) across it
+__device__ __forceinline__ void opaque(int &v) {
+#if defined(__AMDGCN__)
+    asm volatile("" : "+v"(v));
+#endif
+}
+// value of the neighbouring lane (lane ^ 1): a DPP quad permute on the device, no LDS traffic
+__device__ __forceinline__ float lane_xor1(float v) {
+#if defined(__AMDGCN__)
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+#else
+    return __shfl_xor(v, 1, 64);
+#endif
+}
 // 16 bytes that are only guaranteed 8-byte aligned (two adjacent complex samples at an odd sample offset)
 struct __attribute__((aligned(8))) f4u { float x, y, z, w; };
 

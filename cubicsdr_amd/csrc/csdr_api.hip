@@ -252,7 +252,7 @@ static int chan_geometry(int M, int hop, ChanGeom &g) {
         g.KA = std::min(8, (slots + kP2Waves - 1) / kP2Waves);
         g.nkA = (slots + g.KA - 1) / g.KA;
         g.PA = g.nkA * g.KA;
-        g.TF = kP2Frames; g.lgTF = 6; g.S = M; g.taps_lds = 0; g.stage_in = 1; g.threads = 64 * kP2Waves;
+        g.TF = kP2Frames; g.lgTF = 6; g.S = M; g.taps_lds = 0; g.stage_in = 1; g.threads = kP2Threads;
         return CSDR_OK;
     }
     g.taps_lds = (M <= 512) ? 1 : 0;
@@ -281,16 +281,12 @@ typedef void (*chan_kernel_t)(const float2 *, const float2 *, float2 *, const fl
 typedef void (*chan_p2_kernel_t)(const float2 *, const float2 *, float2 *, const float *, const float2 *, const float2 *, const int *, ChanGeom,
                                  int64_t, float2 *, int64_t, d2 *, double);
 static chan_p2_kernel_t chan_p2_kernel(const ChanGeom &g) {
+#define CSDR_P2_CASE(K_) case K_: return chan_analyze_p2<K_>
     switch (g.KA) {
-        case 1: return chan_analyze_p2<1>;
-        case 2: return chan_analyze_p2<2>;
-        case 3: return chan_analyze_p2<3>;
-        case 4: return chan_analyze_p2<4>;
-        case 5: return chan_analyze_p2<5>;
-        case 6: return chan_analyze_p2<6>;
-        case 7: return chan_analyze_p2<7>;
+        CSDR_P2_CASE(1); CSDR_P2_CASE(2); CSDR_P2_CASE(3); CSDR_P2_CASE(4); CSDR_P2_CASE(5); CSDR_P2_CASE(6); CSDR_P2_CASE(7);
         default: return chan_analyze_p2<8>;
     }
+#undef CSDR_P2_CASE
 }
 static chan_kernel_t chan_kernel(const ChanGeom &g) {
     if (g.oddA) {
@@ -474,7 +470,10 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
         const bool dc0 = !p->active_host.empty() && p->active_host[0] == 0;
         const bool fused_ends = dc0 && g.fpw >= 16;
         if (g.p2) {
-            CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, chan_p2_kernel(g), dim3(ntiles), dim3(g.threads), chan_p2_lds_bytes(M), x, hist, hist_new, p->taps.p,
+            // persistent workgroups: as many as are resident at once, each walks over tiles blockIdx.x, + gridDim.x, ...
+            const chan_p2_kernel_t k2 = chan_p2_kernel(g);
+            const int wgs = std::min(ntiles, c->wg_slots(k2, g.threads, chan_p2_lds_bytes(M)));
+            CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, k2, dim3(wgs), dim3(g.threads), chan_p2_lds_bytes(M), x, hist, hist_new, p->taps.p,
                         p->twA.p, p->twM.p, p->active.p, g, n_frames, out, p->chan_stride, fused_ends ? p->tile_end.p : (d2 *)nullptr, p->dc_c);
         } else {
         const chan_kernel_t kern = chan_kernel(g);

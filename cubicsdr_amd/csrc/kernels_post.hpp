@@ -480,26 +480,85 @@ __global__ __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
 // ------------------------------------------------------------------------------------------------------------
 // K2 + K4 for M = 2 A with A odd (M = 6, 10, 14, 22, ... 122 = the 61.44 MS/s case, A <= 63): the Cooley-Tukey split has B = 2,
 // so the B-point pass is one butterfly and the whole transform of a frame stays inside one lane.
-// A workgroup (four waves) owns 64 consecutive frames; LDS holds ONE array of (64 + 7) rows of M samples:
-//  stage    the tile's input rows, 16-byte coalesced loads (one HBM round trip, all loads in flight at once)
-//  FIR      lane = column pair (c1; c2 = 0, 1 = one float4), wave = 16 consecutive frames walked in ascending order with
+// Persistent workgroups of eight waves (two per CU) walk over tiles of 64 consecutive frames; LDS holds ONE array of
+// (64 + 7) rows of M samples:
+//  prefetch the tile's input rows are requested as 16-byte coalesced loads into registers while the PREVIOUS tile's DFT runs
+//           (the two workgroups of a CU otherwise stay in lockstep -- loading together, computing together -- and the phases
+//           add up: measured 0.17 + 0.15 + 0.08 ms for load + FIR, DFT, stores against 0.34 ms in total), then committed to LDS
+//  FIR      lane = column pair (c1; c2 = 0, 1 = one float4), wave = 8 consecutive frames walked in ascending order with
 //           the eight rows of the window in REGISTERS: one ds_read_b128 + one ds_write_b128 per frame instead of eight
 //           reads (the taps live in registers too).  X[t] overwrites row t in place: a row is last needed by the frame
 //           that replaces it; the seven rows a wave needs from its upper neighbour's range are fetched before that
 //           neighbour starts writing (one barrier).
 //  DFT      lane = frame t, wave = KP of the (A - 1) / 2 conjugate output pairs (k, A - k) for BOTH c2 at once
 //           (4 KP accumulators): per term c one ds_read_b128 pair x_c, x_{A-c} (row stride 4 A dwords: conflict-free for
-//           odd A), the (cos, sin) rows are wave-uniform scalar loads; then the radix-2 butterfly with W_M^k in registers
-//           and four channel-major stores of 512 contiguous bytes per wave.  k = 0 rides along as a pseudo pair with
-//           (cos, sin) = (1, 0).  No Z array, no third phase: two barriers per tile after staging.
+//           odd A), the (cos, sin) rows are wave-uniform scalar loads, both requested one term ahead; then the radix-2
+//           butterfly with W_M^k and four channel-major stores of 512 contiguous bytes per wave (scalar row base + lane
+//           offset).  k = 0 rides along as a pseudo pair with (cos, sin) = (1, 0).  No Z array, no third phase.
+// (v_pk_fma_f32 issues every ~5 clk per SIMD with >= 2 waves resident on it, 13 clk with one: measured, scratch/ubench.)
 // ------------------------------------------------------------------------------------------------------------
-constexpr int kP2Frames = 64;          // frames per workgroup
-constexpr int kP2Waves = 4;
-constexpr int kP2Range = kP2Frames / kP2Waves;     // frames one wave filters
+constexpr int kP2Frames = 64;          // frames per tile
+constexpr int kP2Waves = 8;
+constexpr int kP2Threads = 64 * kP2Waves;
+constexpr int kP2MaxA = 63;
+constexpr int kP2Pre = ((kP2Frames + kChanTaps - 1) * kP2MaxA + kP2Threads - 1) / kP2Threads;     // float4 registers per thread holding a tile's input
 __host__ __device__ inline size_t chan_p2_lds_bytes(int M) { return (size_t)(kP2Frames + kChanTaps - 1) * M * sizeof(float2); }
 
+// store to a wave-uniform row base plus a 32-bit per-lane byte offset (scalar-base addressing: no 64-bit address arithmetic per lane)
+__device__ __forceinline__ void store_row(float2 *row_base, unsigned byte_off, float2 v) {
+    *reinterpret_cast<float2 *>(reinterpret_cast<char *>(row_base) + byte_off) = v;
+}
+// one term of the conjugate-pair sums for KP slots and both c2: s = x_c + x_{A-c}, d = x_c - x_{A-c}; e = (cos, sin) rows
 template <int KP>
-__global__ __launch_bounds__(64 * kP2Waves) void chan_analyze_p2(
+__device__ __forceinline__ void chan_p2_term(const float4 a, const float4 b, const float2 (&e)[KP], float2 (&P0)[KP], float2 (&Q0)[KP],
+                                             float2 (&P1)[KP], float2 (&Q1)[KP]) {
+    const float4 s = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    const float4 d = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        P0[j].x = fmaf(s.x, e[j].x, P0[j].x); P0[j].y = fmaf(s.y, e[j].x, P0[j].y);
+        P1[j].x = fmaf(s.z, e[j].x, P1[j].x); P1[j].y = fmaf(s.w, e[j].x, P1[j].y);
+        Q0[j].x = fmaf(d.x, e[j].y, Q0[j].x); Q0[j].y = fmaf(d.y, e[j].y, Q0[j].y);
+        Q1[j].x = fmaf(d.z, e[j].y, Q1[j].x); Q1[j].y = fmaf(d.w, e[j].y, Q1[j].y);
+    }
+}
+
+// request the input of `tile` (rows f0 - 7 .. f0 + nf - 1 as one flat run of float4) into registers.  Every element of `pre`
+// is assigned (zero where there is nothing to load) so that the registers are dead between a commit and the next request.
+template <bool FIRST /* the tile may reach back into the carried history (tile 0 only) */>
+__device__ __forceinline__ void chan_p2_request(const float2 *__restrict__ x, const float2 *__restrict__ hist, int M, int64_t n_frames, int64_t tile,
+                                                bool valid, float4 (&pre)[kP2Pre]) {
+    const int tid = threadIdx.x;
+    const int64_t f0 = tile * kP2Frames, Hs = (int64_t)(kChanTaps - 1) * M;
+    const int nf = (int)min((int64_t)kP2Frames, n_frames - f0);
+    const int n_in2 = valid ? ((nf - 1) * M + kChanTaps * M) >> 1 : 0;
+    const int64_t gbase = f0 * M - Hs;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!FIRST) {                                             // one wave-uniform base, 32-bit lane offsets
+        const float4 *src4 = reinterpret_cast<const float4 *>(x + gbase);
+#pragma unroll
+        for (int i = 0; i < kP2Pre; ++i) {
+            const unsigned p = tid + i * kP2Threads;
+            float4 v = z4;
+            if (p < (unsigned)n_in2) v = src4[p];
+            pre[i] = v;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kP2Pre; ++i) {
+            const int p = tid + i * kP2Threads;
+            float4 v = z4;
+            if (p < n_in2) {
+                const int64_t gi = gbase + 2 * (int64_t)p;
+                v = *reinterpret_cast<const float4 *>(gi >= 0 ? x + gi : hist + (gi + Hs));
+            }
+            pre[i] = v;
+        }
+    }
+}
+
+template <int KP>
+__global__ __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
     const float2 *__restrict__ x, const float2 *__restrict__ hist, float2 *__restrict__ hist_new,
     const float *__restrict__ tapsT,      // [8][M]
     const float2 *__restrict__ cs,        // [(A-1)/2][PA]: (cos, sin)(2 pi k(q) c / A) at [(c - 1) PA + q]; slot q: k = q + 1 (q < H), k = 0 (q == H), else (0, 0)
@@ -509,138 +568,143 @@ __global__ __launch_bounds__(64 * kP2Waves) void chan_analyze_p2(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *rows = reinterpret_cast<float4 *>(smem);          // row r (input row f0 + r - 7, later X[r]) at rows + r A
     const int M = g.M, A = g.A, H = (A - 1) >> 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
-    const int64_t f0 = (int64_t)blockIdx.x * kP2Frames;
-    const int nf = (int)min((int64_t)kP2Frames, n_frames - f0);
-    const int64_t Hs = (int64_t)(kChanTaps - 1) * M;          // samples in front of frame f0's own row = carried history length
-    {
-        const int n_in2 = ((nf - 1) * M + kChanTaps * M) >> 1;
-        const int64_t gbase = f0 * M - Hs;
-        for (int p = tid; p < n_in2; p += 64 * kP2Waves) {
-            const int64_t gi = gbase + 2 * (int64_t)p;
-            const float2 *src = gi >= 0 ? x + gi : hist + (gi + Hs);
-            rows[p] = *reinterpret_cast<const float4 *>(src);
-        }
-    }
-    const bool col = lane < A;
-    float2 h[kChanTaps];
-#pragma unroll
-    for (int n = 0; n < kChanTaps; ++n) h[n] = col ? *reinterpret_cast<const float2 *>(tapsT + n * M + 2 * lane) : make_float2(0.f, 0.f);
-    // the last workgroup also writes the new input history (the launch runs even with no consumers)
-    if (blockIdx.x == gridDim.x - 1) {
+    const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = wave_uniform(tid0 >> 6);
+    const int64_t n_tiles = (n_frames + kP2Frames - 1) / kP2Frames;
+    const int64_t Hs = (int64_t)(kChanTaps - 1) * M;          // samples in front of a tile's own first row = carried history length
+    // the workgroup that finishes last in program order is unknown: the new input history is written by workgroup 0 up front
+    // (it only reads x / hist, which nobody writes during this launch)
+    if (blockIdx.x == 0) {
         const int64_t n = n_frames * M;
-        for (int64_t j = tid; j < Hs; j += 64 * kP2Waves) {
+        for (int64_t j = tid0; j < Hs; j += kP2Threads) {
             const int64_t gsrc = n - Hs + j;
             hist_new[j] = gsrc >= 0 ? x[gsrc] : hist[gsrc + Hs];
         }
     }
-    __syncthreads();
-    // ---- FIR: frames [ta, ta + 16) of this wave, window rows t .. t + 7 in registers
-    {
-        const int ta = wave * kP2Range;
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 halo[kChanTaps - 1];
+    float4 pre[kP2Pre];
+    int64_t tile = blockIdx.x;
+    if (tile == 0) chan_p2_request<true>(x, hist, M, n_frames, tile, true, pre);
+    else chan_p2_request<false>(x, hist, M, n_frames, tile, tile < n_tiles, pre);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int64_t f0 = tile * kP2Frames;
+        const int nf = (int)min((int64_t)kP2Frames, n_frames - f0);
+        int lane = lane0, tid = tid0;                         // per-tile copies: their address arithmetic is not worth carrying across tiles
+        opaque(lane); opaque(tid);
+        {   // commit the prefetched rows
+            const int n_in2 = ((nf - 1) * M + kChanTaps * M) >> 1;
 #pragma unroll
-        for (int j = 0; j < kChanTaps - 1; ++j) halo[j] = col ? rows[(ta + kP2Range + j) * A + lane] : z4;
-        __syncthreads();                                      // every wave holds its upper halo: rows may now be overwritten
-        float4 w[kChanTaps];
+            for (int i = 0; i < kP2Pre; ++i) { const int p = tid + i * kP2Threads; if (p < n_in2) rows[p] = pre[i]; }
+        }
+        const bool col = lane < A;
+        float2 h[kChanTaps];
 #pragma unroll
-        for (int j = 0; j < kChanTaps; ++j) w[j] = col ? rows[(ta + j) * A + lane] : z4;
+        for (int n = 0; n < kChanTaps; ++n) h[n] = col ? *reinterpret_cast<const float2 *>(tapsT + n * M + 2 * lane) : make_float2(0.f, 0.f);
+        lds_barrier();
+        // ---- FIR: frames [ta, ta + 8) of this wave, window rows t .. t + 7 in registers
+        {
+            constexpr int kRange = kP2Frames / kP2Waves;
+            static_assert(kRange == kChanTaps, "the window of a range is exactly its own rows; everything after comes from the halo");
+            const int ta = wave * kRange;
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 halo[kChanTaps - 1], w[kChanTaps];
 #pragma unroll
-        for (int i = 0; i < kP2Range; ++i) {
-            float4 acc = z4;
+            for (int j = 0; j < kChanTaps - 1; ++j) halo[j] = col ? rows[(ta + kRange + j) * A + lane] : z4;
 #pragma unroll
-            for (int n = 0; n < kChanTaps; ++n) {             // tap n multiplies input row t - n = window row 7 - n
-                const float4 v = w[kChanTaps - 1 - n];
-                acc.x = fmaf(h[n].x, v.x, acc.x); acc.y = fmaf(h[n].x, v.y, acc.y);
-                acc.z = fmaf(h[n].y, v.z, acc.z); acc.w = fmaf(h[n].y, v.w, acc.w);
-            }
-            if (col) rows[(ta + i) * A + lane] = acc;
+            for (int j = 0; j < kChanTaps; ++j) w[j] = col ? rows[(ta + j) * A + lane] : z4;
+            lds_barrier();                                  // every wave holds its rows and its upper halo: rows may now be overwritten
 #pragma unroll
-            for (int j = 0; j < kChanTaps - 1; ++j) w[j] = w[j + 1];
-            if (i + 1 < kP2Range) {
-                const int r = i + kChanTaps;                  // next row of the window, relative to ta
-                w[kChanTaps - 1] = r < kP2Range ? (col ? rows[(ta + r) * A + lane] : z4) : halo[r - kP2Range];
+            for (int i = 0; i < kRange; ++i) {
+                float4 acc = z4;
+#pragma unroll
+                for (int n = 0; n < kChanTaps; ++n) {         // tap n multiplies input row t - n = window row 7 - n
+                    const float4 v = w[kChanTaps - 1 - n];
+                    acc.x = fmaf(h[n].x, v.x, acc.x); acc.y = fmaf(h[n].x, v.y, acc.y);
+                    acc.z = fmaf(h[n].y, v.z, acc.z); acc.w = fmaf(h[n].y, v.w, acc.w);
+                }
+                if (col) rows[(ta + i) * A + lane] = acc;
+#pragma unroll
+                for (int j = 0; j < kChanTaps - 1; ++j) w[j] = w[j + 1];
+                if (i + 1 < kRange) w[kChanTaps - 1] = halo[i];
+                sched_fence();                                // frame after frame: interleaving all eight costs ~100 registers
             }
         }
-    }
-    __syncthreads();
-    // ---- DFT: lane = frame t; wave = pass of KP output-pair slots
-    const int t = lane;
-    const float4 *row = rows + t * A;
-    const bool tv = t < nf;
-    for (int p = wave; p < g.nkA; p += kP2Waves) {
-        const int q0 = p * KP;
-        const float4 x0 = row[0];
-        float2 P0[KP], Q0[KP], P1[KP], Q1[KP];
-#pragma unroll
-        for (int j = 0; j < KP; ++j) {
-            P0[j] = make_float2(x0.x, x0.y); P1[j] = make_float2(x0.z, x0.w);
-            Q0[j] = make_float2(0.f, 0.f); Q1[j] = make_float2(0.f, 0.f);
-        }
-        // software pipeline: the rows and the (cos, sin) row of term c + 1 are requested before term c is accumulated
-        const float2 *w = cs + q0;
-        float4 a = row[1], b = row[A - 1];
-        float2 e[KP];
-#pragma unroll
-        for (int j = 0; j < KP; ++j) e[j] = w[j];
-        for (int c = 1; c <= H; ++c) {
-            const float4 s = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-            const float4 d = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
-            float2 en[KP];
-            w += g.PA;
-            if (c < H) {
-                a = row[c + 1]; b = row[A - c - 1];
-#pragma unroll
-                for (int j = 0; j < KP; ++j) en[j] = w[j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < KP; ++j) en[j] = e[j];
-            }
-            sched_fence();
+        lds_barrier();
+        // the next tile's input is on its way while this one is transformed
+        chan_p2_request<false>(x, hist, M, n_frames, tile + gridDim.x, tile + gridDim.x < n_tiles, pre);
+        // ---- DFT: lane = frame t; wave = pass of KP output-pair slots
+        const int t = lane;
+        const float4 *row = rows + t * A;
+        const bool tv = t < nf;
+        for (int p = wave; p < g.nkA; p += kP2Waves) {
+            const int q0 = p * KP;
+            const float4 x0 = row[0];
+            float2 P0[KP], Q0[KP], P1[KP], Q1[KP];
 #pragma unroll
             for (int j = 0; j < KP; ++j) {
-                P0[j].x = fmaf(s.x, e[j].x, P0[j].x); P0[j].y = fmaf(s.y, e[j].x, P0[j].y);
-                P1[j].x = fmaf(s.z, e[j].x, P1[j].x); P1[j].y = fmaf(s.w, e[j].x, P1[j].y);
-                Q0[j].x = fmaf(d.x, e[j].y, Q0[j].x); Q0[j].y = fmaf(d.y, e[j].y, Q0[j].y);
-                Q1[j].x = fmaf(d.z, e[j].y, Q1[j].x); Q1[j].y = fmaf(d.w, e[j].y, Q1[j].y);
+                P0[j] = make_float2(x0.x, x0.y); P1[j] = make_float2(x0.z, x0.w);
+                Q0[j] = make_float2(0.f, 0.f); Q1[j] = make_float2(0.f, 0.f);
             }
-            sched_fence();
+            // software pipeline, two terms per trip with two register sets (no copies): the rows and the (cos, sin) row of the
+            // next term are requested before the current one is accumulated
+            const float2 *w = cs + q0;
+            float4 a = row[1], b = row[A - 1], a2 = a, b2 = b;
+            float2 eA[KP], eB[KP];
 #pragma unroll
-            for (int j = 0; j < KP; ++j) e[j] = en[j];
-        }
-        float2 *o = out + f0 + t;
+            for (int j = 0; j < KP; ++j) { eA[j] = w[j]; eB[j] = eA[j]; }
+            int c = 1;
+            for (; c + 1 <= H; c += 2) {
+                w += g.PA;
+                a2 = row[c + 1]; b2 = row[A - c - 1];
 #pragma unroll
-        for (int j = 0; j < KP; ++j) {
-            const int q = q0 + j;                               // wave-uniform
-            if (q < H) {
-                const int k = q + 1, kn = A - k;
-                const float2 wk = twM[2 * k + 1], wn = twM[2 * kn + 1];
-                const int on0 = active[k], on1 = active[k + A], on2 = active[kn], on3 = active[kn + A];
-                const float2 z0k = make_float2(P0[j].x + Q0[j].y, P0[j].y - Q0[j].x), z0n = make_float2(P0[j].x - Q0[j].y, P0[j].y + Q0[j].x);
-                const float2 u = cmul(make_float2(P1[j].x + Q1[j].y, P1[j].y - Q1[j].x), wk);
-                const float2 v = cmul(make_float2(P1[j].x - Q1[j].y, P1[j].y + Q1[j].x), wn);
-                if (tv) {
-                    if (on0) o[(int64_t)k * out_stride] = make_float2(z0k.x + u.x, z0k.y + u.y);
-                    if (on1) o[(int64_t)(k + A) * out_stride] = make_float2(z0k.x - u.x, z0k.y - u.y);
-                    if (on2) o[(int64_t)kn * out_stride] = make_float2(z0n.x + v.x, z0n.y + v.y);
-                    if (on3) o[(int64_t)(kn + A) * out_stride] = make_float2(z0n.x - v.x, z0n.y - v.y);
+                for (int j = 0; j < KP; ++j) eB[j] = w[j];
+                sched_fence();
+                chan_p2_term<KP>(a, b, eA, P0, Q0, P1, Q1);
+                sched_fence();
+                w += g.PA;
+                if (c + 2 <= H) {
+                    a = row[c + 2]; b = row[A - c - 2];
+#pragma unroll
+                    for (int j = 0; j < KP; ++j) eA[j] = w[j];
                 }
-            } else if (q == H) {                                // k = 0: P = sum of the column, Q = 0
-                const float2 y0 = make_float2(P0[j].x + P1[j].x, P0[j].y + P1[j].y);
-                if (tv) {
-                    if (active[0]) o[0] = y0;
-                    if (active[A]) o[(int64_t)A * out_stride] = make_float2(P0[j].x - P1[j].x, P0[j].y - P1[j].y);
-                }
-                if (dc_ends) {
-                    // v_end = sum_t c^(nf-1-t) y0[t]: the DC blocker's state after this tile if it entered with zero (iirfilt, :375)
-                    const double wgt = tv ? dc_pow(dc_c, nf - 1 - t) : 0.0;
-                    double vx = tv ? wgt * (double)y0.x : 0.0, vy = tv ? wgt * (double)y0.y : 0.0;      // rows past the last frame hold no data
-                    for (int s2 = 32; s2 > 0; s2 >>= 1) { vx += __shfl_down(vx, s2, 64); vy += __shfl_down(vy, s2, 64); }
-                    if (lane == 0) dc_ends[blockIdx.x] = d2{vx, vy};
+                sched_fence();
+                chan_p2_term<KP>(a2, b2, eB, P0, Q0, P1, Q1);
+                sched_fence();
+            }
+            if (c <= H) chan_p2_term<KP>(a, b, eA, P0, Q0, P1, Q1);        // H odd: the last term
+            float2 *ob = out + f0;                                  // wave-uniform row bases + a 32-bit lane offset: scalar-base stores
+            const unsigned tb = (unsigned)t * (unsigned)sizeof(float2);   // byte offset of this lane inside a channel row
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                const int q = q0 + j;                               // wave-uniform
+                if (q < H) {
+                    const int k = q + 1, kn = A - k;
+                    const float2 wk = twM[2 * k + 1], wn = twM[2 * kn + 1];
+                    const int on0 = active[k], on1 = active[k + A], on2 = active[kn], on3 = active[kn + A];
+                    const float2 z0k = make_float2(P0[j].x + Q0[j].y, P0[j].y - Q0[j].x), z0n = make_float2(P0[j].x - Q0[j].y, P0[j].y + Q0[j].x);
+                    const float2 u = cmul(make_float2(P1[j].x + Q1[j].y, P1[j].y - Q1[j].x), wk);
+                    const float2 v = cmul(make_float2(P1[j].x - Q1[j].y, P1[j].y + Q1[j].x), wn);
+                    if (tv) {
+                        if (on0) store_row(ob + (int64_t)k * out_stride, tb, make_float2(z0k.x + u.x, z0k.y + u.y));
+                        if (on1) store_row(ob + (int64_t)(k + A) * out_stride, tb, make_float2(z0k.x - u.x, z0k.y - u.y));
+                        if (on2) store_row(ob + (int64_t)kn * out_stride, tb, make_float2(z0n.x + v.x, z0n.y + v.y));
+                        if (on3) store_row(ob + (int64_t)(kn + A) * out_stride, tb, make_float2(z0n.x - v.x, z0n.y - v.y));
+                    }
+                } else if (q == H) {                                // k = 0: P = sum of the column, Q = 0
+                    const float2 y0 = make_float2(P0[j].x + P1[j].x, P0[j].y + P1[j].y);
+                    if (tv) {
+                        if (active[0]) store_row(ob, tb, y0);
+                        if (active[A]) store_row(ob + (int64_t)A * out_stride, tb, make_float2(P0[j].x - P1[j].x, P0[j].y - P1[j].y));
+                    }
+                    if (dc_ends) {
+                        // v_end = sum_t c^(nf-1-t) y0[t]: the DC blocker's state after this tile if it entered with zero (iirfilt, :375)
+                        const double wgt = tv ? dc_pow(dc_c, nf - 1 - t) : 0.0;
+                        double vx = tv ? wgt * (double)y0.x : 0.0, vy = tv ? wgt * (double)y0.y : 0.0;      // rows past the last frame hold no data
+                        for (int s2 = 32; s2 > 0; s2 >>= 1) { vx += __shfl_down(vx, s2, 64); vy += __shfl_down(vy, s2, 64); }
+                        if (lane == 0) dc_ends[tile] = d2{vx, vy};
+                    }
                 }
             }
         }
+        lds_barrier();                                      // the rows are free for the next tile
     }
 }
 
