@@ -642,6 +642,8 @@ extern "C" int csdr_bank_create(csdr_ctx *ctx, int max_demods, int max_blocks, c
     for (int i = 0; i < 2 * kHilbM; i++) mc.hilb[i] = hq[i];
     std::vector<float> hq60 = design::hilbert_taps(kHilbM, 60.0f);           // ModemCW.cpp:23
     for (int i = 0; i < 2 * kHilbM; i++) mc.hilb60[i] = hq60[i];
+    std::vector<float> g = design::sos_impulse_response(sos, kSsbFir);
+    for (int i = 0; i < kSsbFir; i++) mc.ssb_fir[i] = g[i];
     CSDR_HIP_TRY(hipMemcpy(b->mconsts.p, &mc, sizeof mc, hipMemcpyHostToDevice));
     *out = b.release();
     return CSDR_OK;
@@ -921,25 +923,32 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     // Slots whose cascade has the reference's standard shape (m = 3..3, 5, 10; 3 <= S <= 6) run the specialised kernel,
     // one launch per depth S; anything else runs the generic one.
     const int64_t total = (int64_t)NB * Bc;
-    // ranges per slot: as many as make the grid ONE round of resident workgroups (each range re-runs `warm` inputs, so
-    // fewer, longer ranges waste less), but never shorter than 4 warm-up spans and never fewer than one
+    // ranges per slot, PER LAUNCH (the slots are grouped by cascade depth, one launch per group on the same stream): as many as
+    // make that launch's grid ONE round of resident workgroups (each range re-runs `warm` inputs, so fewer, longer ranges
+    // waste less), but never shorter than 4 warm-up spans and never fewer than one
     const int fe_slots = c->wg_slots(demod_frontend_s<5, 2048, true>, kFeThreads + 64, fes_lds_bytes<5, 2048>());
-    int P = (int)std::max<int64_t>(1, std::min<int64_t>(total / std::max<int64_t>(4096, 4 * (int64_t)warm_max), 4096));
-    {
-        const int per_slot = fe_slots / std::max(1, n_run) - 1;                            // one extra workgroup per slot carries the histories
+    auto ranges_for = [&](int n_slots) {
+        int P = (int)std::max<int64_t>(1, std::min<int64_t>(total / std::max<int64_t>(4096, 4 * (int64_t)warm_max), 4096));
+        const int per_slot = fe_slots / std::max(1, n_slots) - 1;                          // one extra workgroup per slot carries the histories
         if (per_slot >= 1) P = std::min(P, per_slot);
         else {                                                           // more slots than resident workgroups: whole rounds
-            const int rounds = (n_run * 2 + fe_slots - 1) / fe_slots;
-            P = std::max(1, std::min(P, rounds * fe_slots / std::max(1, n_run) - 1));
+            const int rounds = (n_slots * 2 + fe_slots - 1) / fe_slots;
+            P = std::max(1, std::min(P, rounds * fe_slots / std::max(1, n_slots) - 1));
         }
-    }
+        return P;
+    };
     size_t fe_lds = 0;
     for (int i = 0; i < grp_n[0]; ++i) fe_lds = std::max(fe_lds, fe_lds_bytes((int)b->slots[grp_h[grp_off[0] + i]].iq.S));
     const int cap_stream = (max_n_iq + kSsbWarm + 64 + 3) & ~3;
     // CW blocks run the complex audio interpolator in LDS: IQ window + two stage arrays of (block audio + Hilbert reach)
     const int cap_cw = max_cw_audio ? ((max_cw_audio + 4 * kHilbM + 64 + 3) & ~3) : 0;
-    const size_t dsb_lds = 1024 * sizeof(float) + (size_t)kModemMaxBlockIq * sizeof(float2);   // DSB: sine table + one block of IQ
-    const size_t modem_lds = std::max(std::max((size_t)2 * cap_stream * sizeof(float), ((size_t)kCwIqWin + 2 * (size_t)cap_cw) * sizeof(float2)), dsb_lds) + 64;
+    // LDS of the modem kernel, sized by the modems that actually run (a DSB slot stages the sine table and one block of IQ, a CW
+    // slot the complex interpolator's arrays; AM / SSB need four float streams): an oversized request costs resident waves
+    bool any_dsb = false;
+    for (int i = 0; i < n_ag; ++i) any_dsb = any_dsb || b->slots[ag_list_h[i]].prm.modem == CSDR_MODEM_DSB;
+    const size_t dsb_lds = any_dsb ? 1024 * sizeof(float) + (size_t)kModemMaxBlockIq * sizeof(float2) : 0;
+    const size_t cw_lds = cap_cw ? ((size_t)kCwIqWin + 2 * (size_t)cap_cw) * sizeof(float2) : 0;
+    const size_t modem_lds = std::max(std::max((size_t)4 * cap_stream * sizeof(float), cw_lds), dsb_lds) + 64;
     // LDS of the audio kernel: two ping-pong arrays (stage outputs) and the staged demodulator window (decimating
     // cascades reach back up to kDHist samples and their first stage outputs half the window)
     const int cap_win = (max_n_iq + kDHist + 64 + 3) & ~3;
@@ -959,15 +968,15 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     const float2 *chan_out = post_buf(post, pk);
     const int *grp_d = lists_d + 2 * (size_t)b->max_demods;
     if (grp_n[0] > 0)
-        CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, demod_frontend, dim3(P, grp_n[0]), dim3(kFeThreads), fe_lds, b->cfgs.p, dyns_d, grp_d + grp_off[0],
+        CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, demod_frontend, dim3(ranges_for(grp_n[0]), grp_n[0]), dim3(kFeThreads), fe_lds, b->cfgs.p, dyns_d, grp_d + grp_off[0],
                     chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
 #define CSDR_FE_S(S_, CH_)                                                                                                              \
     if (grp_n[S_] > 0)                                                                                                                  \
-        CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, (demod_frontend_s<S_, CH_>), dim3(P + 1, grp_n[S_]), dim3(kFeThreads), (fes_lds_bytes<S_, CH_>()), \
+        CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, (demod_frontend_s<S_, CH_>), dim3(ranges_for(grp_n[S_]) + 1, grp_n[S_]), dim3(kFeThreads), (fes_lds_bytes<S_, CH_>()), \
                     b->cfgs.p, dyns_d, grp_d + grp_off[S_], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p)
     CSDR_FE_S(3, 2048); CSDR_FE_S(4, 2048); CSDR_FE_S(6, 2048);
     if (grp_n[5] > 0)            // depth 5 (NBFM from ~500 kS/s channels): a fifth wave runs the one-wave tail one chunk behind
-        CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, (demod_frontend_s<5, 2048, true>), dim3(P + 1, grp_n[5]), dim3(kFeThreads + 64), (fes_lds_bytes<5, 2048>()),
+        CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, (demod_frontend_s<5, 2048, true>), dim3(ranges_for(grp_n[5]) + 1, grp_n[5]), dim3(kFeThreads + 64), (fes_lds_bytes<5, 2048>()),
                     b->cfgs.p, dyns_d, grp_d + grp_off[5], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
 #undef CSDR_FE_S
     CSDR_HIP_TRY(hipGetLastError());

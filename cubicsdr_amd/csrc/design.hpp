@@ -260,6 +260,24 @@ inline std::vector<Sos> butter_lowpass_sos(unsigned order, float fc) {
     return out;
 }
 
+// impulse response of a cascade of second-order sections (direct form II, as iirfilt_crcf_execute runs them), n samples, in
+// double: the SSB low-pass has poles of radius <= 0.77, so its response is below 1e-14 of the peak after 128 samples and the
+// recursive filter IS (to far below float32 resolution) the FIR filter with these taps -- which runs in parallel
+inline std::vector<float> sos_impulse_response(const std::vector<Sos> &sos, unsigned n) {
+    std::vector<double> v1(sos.size(), 0.0), v2(sos.size(), 0.0);
+    std::vector<float> g(n);
+    for (unsigned i = 0; i < n; ++i) {
+        double t = i == 0 ? 1.0 : 0.0;
+        for (size_t q = 0; q < sos.size(); ++q) {
+            const double v0 = t - (double)sos[q].a[1] * v1[q] - (double)sos[q].a[2] * v2[q];
+            t = (double)sos[q].b[0] * v0 + (double)sos[q].b[1] * v1[q] + (double)sos[q].b[2] * v2[q];
+            v2[q] = v1[q]; v1[q] = v0;
+        }
+        g[i] = (float)t;
+    }
+    return g;
+}
+
 // ---- SSB: Hilbert transformer taps (firhilbf_create(m, As)); h[n] for odd delays n = 1, 3, .., 4m-1 ---------
 // y_q[k] = sum_{n odd} hq[(n-1)/2] * imag(x[k - n]),  y_i[k] = real(x[k - 2m])
 inline std::vector<float> hilbert_taps(unsigned m, float as) {

@@ -761,7 +761,8 @@ __global__ __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? 5 : 4) void demod_
 constexpr int kModemThreads = 256;
 constexpr int kModemMaxBlockIq = 4096;     // resampled samples of one block handled by one workgroup (LDS bound)
 constexpr int kAmTaps = 51;
-constexpr int kSsbWarm = 192;              // IIR warm-up span; |pole|^192 ~ 1e-22
+constexpr int kSsbFir = 128;               // taps of the SSB low-pass run as an FIR filter (pole radius <= 0.77: 0.77^128 ~ 3e-15)
+constexpr int kSsbWarm = kSsbFir - 1;      // samples the filter reaches back
 constexpr int kHilbM = 5;                  // firhilbf_create(5, As): 21-tap half-band, 10 odd taps
 constexpr int kCwIqWin = 512;              // resampled-IQ samples one CW block can reach (interpolation by >= 2: far fewer)
 // dynamic LDS: two float streams of `cap_stream` samples (max block + warm-up, multiple of 4) + 64 bytes of reduction scratch
@@ -771,6 +772,7 @@ struct ModemConsts {
     float sos_b[3][3], sos_a[3][3];        // Butterworth sections, execution order
     float hilb[2 * kHilbM];                // hq[(n-1)/2] for odd delay n   (firhilbf_create(5, 90), ModemUSB.cpp:11)
     float hilb60[2 * kHilbM];              // the same for firhilbf_create(5, 60)          (ModemCW.cpp:23)
+    float ssb_fir[kSsbFir];                // impulse response of the three sections (iirfilt_crcf_create_lowpass(6, 0.25), ModemUSB.cpp:8)
 };
 
 __device__ inline double block_sum_double(double v, double *lds) {
@@ -800,8 +802,8 @@ __global__ __launch_bounds__(kModemThreads) void demod_modem(
     const float *__restrict__ arms_all, int cap_cw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_a = reinterpret_cast<float *>(smem);              // AM: |x| ; SSB: real part stream
-    float *s_b = s_a + cap_stream;                             // SSB: imag part stream
-    double *s_red = reinterpret_cast<double *>(s_b + cap_stream);   // (CW carves the same memory differently, see below)
+    float *s_b = s_a + cap_stream;                             // SSB: imag part stream (two more streams follow: the filtered pair)
+    double *s_red = reinterpret_cast<double *>(s_b + 3 * cap_stream);   // (CW carves the same memory differently, see below)
     float *s_redf = reinterpret_cast<float *>(s_red + 4);
 
     const int slot = slot_list[blockIdx.x], b = blockIdx.y, tid = threadIdx.x;
@@ -967,24 +969,22 @@ __global__ __launch_bounds__(kModemThreads) void demod_modem(
             s_a[i] = v.x; s_b[i] = v.y;
         }
         __syncthreads();
-        // 2. three direct-form-II biquads, real coefficients: real and imaginary streams are independent (lanes 0, 1)
-        if (tid < 2) {
-            float *st = tid ? s_b : s_a;
-            float v1[3] = {0.f, 0.f, 0.f}, v2[3] = {0.f, 0.f, 0.f};
-            for (int i = 0; i < tot; ++i) {
-                float t = st[i];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const float v0 = t - mc->sos_a[q][1] * v1[q] - mc->sos_a[q][2] * v2[q];
-                    t = mc->sos_b[q][0] * v0 + mc->sos_b[q][1] * v1[q] + mc->sos_b[q][2] * v2[q];
-                    v2[q] = v1[q]; v1[q] = v0;
-                }
-                st[i] = t;
+        // 2. the three Butterworth sections (iirfilt_crcf_execute, ModemUSB.cpp:57) as their 128-tap impulse response: every
+        //    output is an independent dot product (the recursion ran 300 dependent steps on two lanes), real taps on both streams
+        float *s_c = s_b + cap_stream, *s_d = s_c + cap_stream;
+        for (int i = kSsbWarm + tid; i < tot; i += nthr) {
+            float ar = 0.f, ai = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < kSsbFir; ++k) {
+                const float gk = mc->ssb_fir[k];
+                ar = fmaf(gk, s_a[i - k], ar); ai = fmaf(gk, s_b[i - k], ai);
             }
+            s_c[i] = ar; s_d[i] = ai;
         }
         __syncthreads();
+        s_a = s_c; s_b = s_d;
         // 3. shift back (same oscillator phase), in place
-        for (int i = tid; i < tot; i += nthr) {
+        for (int i = kSsbWarm + tid; i < tot; i += nthr) {
             const int j = j0 - pre + i;
             float s, c;
             nco_sincos(sintab, dyn.ssb_theta0 + (uint32_t)(j + 1) * (1u << 30), s, c);
