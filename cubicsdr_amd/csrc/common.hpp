@@ -114,6 +114,41 @@ __device__ __forceinline__ float lane_xor1(float v) {
     return __shfl_xor(v, 1, 64);
 #endif
 }
+// maximum / minimum over the 64 lanes of the wave, valid in lane 63: six DPP steps on the vector ALU (quad permutes, row mirrors,
+// row broadcasts), no LDS crossbar traffic (__shfl_down goes through ds_bpermute: an LDS-pipe round trip per step)
+#if defined(__AMDGCN__)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_max_to_lane63(float v) {
+    v = fmaxf(v, dpp_f<0xB1, 0xF>(v));      // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_f<0x4E, 0xF>(v));      // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_f<0x141, 0xF>(v));     // row_half_mirror
+    v = fmaxf(v, dpp_f<0x140, 0xF>(v));     // row_mirror: every lane of a row holds the row's maximum
+    v = fmaxf(v, dpp_f<0x142, 0xA>(v));     // row_bcast:15 into rows 1 and 3
+    v = fmaxf(v, dpp_f<0x143, 0xC>(v));     // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ float wave_min_to_lane63(float v) {
+    v = fminf(v, dpp_f<0xB1, 0xF>(v));
+    v = fminf(v, dpp_f<0x4E, 0xF>(v));
+    v = fminf(v, dpp_f<0x141, 0xF>(v));
+    v = fminf(v, dpp_f<0x140, 0xF>(v));
+    v = fminf(v, dpp_f<0x142, 0xA>(v));
+    v = fminf(v, dpp_f<0x143, 0xC>(v));
+    return v;
+}
+#else
+__device__ __forceinline__ float wave_max_to_lane63(float v) {
+    for (int o = 1; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min_to_lane63(float v) {
+    for (int o = 1; o < 64; o <<= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+#endif
 // 16 bytes that are only guaranteed 8-byte aligned (two adjacent complex samples at an odd sample offset)
 struct __attribute__((aligned(8))) f4u { float x, y, z, w; };
 

@@ -1279,7 +1279,7 @@ static int spec_post_range(csdr_spec *s, const float *mag, int f0, int cnt, int 
     // display: column blocks per frame sized so that the grid is about one round of resident workgroups
     const int disp_gx = std::max(1, std::min((g.F / 2 + kDispThreads - 1) / kDispThreads, c->wg_slots(spec_display, kDispThreads, kDispLds) / std::max(1, cnt)));
     CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_DISPLAY, spec_display, dim3(disp_gx, cnt), dim3(kDispThreads), kDispLds,
-                s->pairsum.p + f0 * F, s->first_b.p + f0, s->ext.p + f0, cnt, g.F, s->scale, st_in, s->scal.p + (s->scal_parity ^ 1), s->fo.p + f0,
+                s->pairsum.p + f0 * F, s->first_b.p + f0, s->ext.p + f0, cnt, g, s->scale, st_in, s->scal.p + (s->scal_parity ^ 1), s->fo.p + f0,
                 s->points.p + f0 * 2 * F, hold ? pk_from : cnt, hold ? s->pfo.p + f0 : (const SpecFrameOut *)nullptr,
                 hold ? s->peaksum.p + f0 * F : (const float *)nullptr, hold ? s->peak_b.p + f0 : (const float *)nullptr,
                 hold ? s->hold_points.p + f0 * 2 * F : (float *)nullptr,

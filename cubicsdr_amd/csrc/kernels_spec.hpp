@@ -335,6 +335,16 @@ __device__ inline int64_t spec_pair_offset(const SpecGeom &g, int x, int64_t &db
     db = (int64_t)g.Rb * 4096;                                        // bin ka + 1 lives in row (k1 + 1) Rb + k2
     return ((int64_t)k1 * g.Rb + k2) * 4096 + k3;
 }
+// index of display point x in the PAIR order of the last FFT pass (pair row ((k1 / 2) Rb + k2), position k3): the averaging kernel
+// reads the magnitudes and writes the averaged pair sums in this order (whole 256-byte runs per wave; display-order stores were
+// 8 bytes per 64: measured 4.2 x the bytes as 32-byte partial writes); the display kernel permutes on its read side
+__device__ inline int64_t spec_pair_index(const SpecGeom &g, int x) {
+    const int ka = (2 * x + g.N / 2) & (g.N - 1);
+    if (g.Ra == 1) return ka >> 1;
+    const int k1 = ka & (g.Ra - 1), rest = ka >> g.lgRa;
+    const int k2 = rest & (g.Rb - 1), k3 = rest >> g.lgRb;
+    return ((int64_t)(k1 >> 1) * g.Rb + k2) * 4096 + k3;
+}
 __device__ inline float2 spec_load_pair(const float *__restrict__ mag, int64_t off, int64_t db) {
     if (db == 1) return *reinterpret_cast<const float2 *>(mag + off);   // ka is even: 8-byte aligned
     return make_float2(mag[off], mag[off + db]);
@@ -363,29 +373,26 @@ __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restr
     AvgState *s_loc = reinterpret_cast<AvgState *>(smem);               // [ng][64] group end states (zero entering state)
     AvgState *s_carry = s_loc + ng * kAvgLanes;                          // [64] state after the round
     const int F = g.F, lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    // The magnitudes lie in the row order of the last FFT pass: bin k1 + Ra (k2 + Rb k3) at [(k1 Rb + k2) 4096 + k3].  A tile
-    // of 64 display points therefore takes its lanes ALONG k3 (two k1 pairs x 32 consecutive k3: whole 128-byte runs of four
-    // rows per load) instead of 64 consecutive points, which would touch 16 bytes in each of Ra rows.
+    // The magnitudes lie in the row order of the last FFT pass: bin k1 + Ra (k2 + Rb k3) at [(k1 Rb + k2) 4096 + k3].  A tile is
+    // 64 consecutive k3 of ONE row pair (k1 even, k1 + 1): two 256-byte runs per load, and the averaged pair sums are written in
+    // the same pair order (one 256-byte run per store); the display kernel does the permutation to display order on its read side.
     int x;
     bool valid;
-    int64_t t, db;
+    int64_t t, db, pt;
     if (g.Ra == 1) {
         x = blockIdx.x * kAvgLanes + lane;
         valid = x < F;
         t = spec_pair_offset(g, valid ? x : 0, db);
+        pt = t >> 1;
     } else {
-        const int pk1 = g.Ra >= 4 ? 2 : 1, pk3 = kAvgLanes / pk1;
-        const int nk3b = 4096 / pk3, nk1g = (g.Ra / 2) / pk1;
-        // neighbouring workgroups take the k1 groups of one k3 block: together they write whole lines of the display-order outputs
-        int tile = blockIdx.x;
-        const int k1g = tile % nk1g; tile /= nk1g;
-        const int k3b = tile % nk3b, k2 = tile / nk3b;
-        const int k1 = 2 * (k1g * pk1 + lane / pk3), k3 = k3b * pk3 + lane % pk3;
+        const int prow = blockIdx.x >> 6, k3 = ((blockIdx.x & 63) << 6) + lane;      // 4096 / 64 = 64 tiles per row pair
+        const int k1 = 2 * (prow >> g.lgRb), k2 = prow & (g.Rb - 1);
         const int ka = k1 + g.Ra * (k2 + g.Rb * k3);
         x = ((ka - g.N / 2) & (g.N - 1)) >> 1;
         valid = true;
         t = ((int64_t)k1 * g.Rb + k2) * 4096 + k3;
         db = (int64_t)g.Rb * 4096;
+        pt = (int64_t)prow * 4096 + k3;
     }
     const int xs = valid ? x : 0;
     const int64_t NN = g.N;
@@ -433,14 +440,14 @@ __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restr
                 if (fv) {
                     avg_step(s, (double)m[i].x, (double)m[i].y, rate);
                     if (valid) {
-                        pairsum[(int64_t)f * F + x] = (float)(s.maa_a + s.maa_b);
+                        pairsum[(int64_t)f * F + pt] = (float)(s.maa_a + s.maa_b);
                         if (f >= pk_from) maaf[(int64_t)f * F + x] = make_float2((float)s.maa_a, (float)s.maa_b);
                         mx = (float)fmax(s.maa_a, s.maa_b); mn = (float)fmin(s.maa_a, s.maa_b);
                         if (x == 0) first_b[f] = (float)s.maa_b;
                     }
                 }
-                for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_down(mx, o, 64)); mn = fminf(mn, __shfl_down(mn, o, 64)); }
-                if (lane == 0 && fv) ext_w[(int64_t)f * ntiles + blockIdx.x] = make_float2(mx, mn);
+                mx = wave_max_to_lane63(mx); mn = wave_min_to_lane63(mn);
+                if (lane == 63 && fv) ext_w[(int64_t)f * ntiles + blockIdx.x] = make_float2(mx, mn);
             }
         }
         // 4. the group that holds the last frame of the round publishes the state entering the next round
@@ -562,10 +569,11 @@ __global__ void spec_peak_trackers(const float2 *__restrict__ ext, int nf, int p
     *pk = p;
 }
 constexpr int kDispThreads = 256;
-constexpr size_t kDispLds = (4 * (kDispThreads / 64) + 3) * sizeof(double);
+constexpr int kDispTile = 2 * kDispThreads;   // display points per tile
+constexpr size_t kDispLds = (4 * (kDispThreads / 64) + 4) * sizeof(double) + 2 * kDispTile * sizeof(float);
 
-__global__ __launch_bounds__(kDispThreads) void spec_display(const float *__restrict__ pairsum, const float *__restrict__ first_b,
-                                                             const float2 *__restrict__ ext, int nf, int F, float sf,
+__global__ __launch_bounds__(kDispThreads) void spec_display(const float *__restrict__ pairsum /* pair order: spec_pair_index */, const float *__restrict__ first_b,
+                                                             const float2 *__restrict__ ext, int nf, SpecGeom g, float sf,
                                                              const SpecScalars *__restrict__ st_in, SpecScalars *__restrict__ st_out,
                                                              SpecFrameOut *__restrict__ fo, float *__restrict__ points,
                                                              int pk_from, const SpecFrameOut *__restrict__ pfo, const float *__restrict__ peaksum,
@@ -575,7 +583,7 @@ __global__ __launch_bounds__(kDispThreads) void spec_display(const float *__rest
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *s_sum = reinterpret_cast<double *>(smem);          // reduction scratch [waves][4]
     double *s_pc = s_sum + 4 * (kDispThreads / 64);            // [3] point_ceil, point_floor, fft_floor_maa of this frame
-    const int f = blockIdx.y, tid = threadIdx.x;
+    const int f = blockIdx.y, tid = threadIdx.x, F = g.F;
     // trackers after frame f, closed form of the recurrences (a = 0.95, b = 0.05; c_i = float ceiling, d_i = float floor
     // of frame i):   ma_f  = a^(f+1) ma_in + b sum_i a^(f-i) c_i
     //                maa_f = a^(f+1) maa_in + b (f+1) a^(f+1) ma_in + b^2 sum_i (f-i+1) a^(f-i) c_i      (maa uses the NEW ma)
@@ -620,6 +628,45 @@ __global__ __launch_bounds__(kDispThreads) void spec_display(const float *__rest
     const bool hold = f >= pk_from;
     const float inv_den = 1.0f / log1pf((float)(pc - pf));          // (pc + 0.25) - (pf - 0.75) = 1 + (pc - pf)
     const float inv_F = 1.0f / (float)F;                             // F is a power of two: x * inv_F == x / F exactly
+    // Full-span view of a multi-pass transform: the pair sums lie in PAIR order (spec_pair_index).  A tile of kDispTile
+    // consecutive display points = nk3 consecutive k3 of every row pair: the threads read it row by row (runs of nk3 floats),
+    // form y, drop it at its display position in LDS and write the tile out as whole 16-byte (x, y, x, y) groups.
+    const int npairs = g.Ra == 1 ? 1 : (g.Ra >> 1) * g.Rb;           // row pairs = display points per k3
+    if (!vmap && g.Ra > 1 && npairs <= kDispTile && F >= kDispTile) {
+        float *s_y = reinterpret_cast<float *>(s_pc + 4);            // [2][kDispTile]: y, held y
+        const int nk3 = kDispTile / npairs, lg_nk3 = 31 - __clz(nk3), lg_half = g.lgRa - 1;
+        for (int tile = blockIdx.x; tile < F / kDispTile; tile += gridDim.x) {
+            const int k3base = tile * nk3;
+            const int x0 = (npairs * k3base - (g.N >> 2)) & (F - 1);       // display point of (row pair 0, k3base); tiles do not wrap
+#pragma unroll
+            for (int u = 0; u < kDispTile / kDispThreads; ++u) {
+                const int i = tid + u * kDispThreads;
+                const int prow = i >> lg_nk3, k3i = i & (nk3 - 1);
+                const int k1h = prow >> g.lgRb, k2 = prow & (g.Rb - 1);
+                const int pos = k3i * npairs + k1h + (k2 << lg_half);      // position inside the tile, display order
+                const int x = x0 + pos;
+                const double acc = (x == 0) ? fl + (double)first_b[f]       // idx == 0 is replaced by fft_floor_maa (:546-556)
+                                            : (double)pairsum[(int64_t)f * F + (int64_t)prow * 4096 + k3base + k3i];
+                s_y[pos] = log1p_fast((float)(acc * 0.5 - pf)) * inv_den * sf;
+                if (hold) {
+                    const double pacc = (x == 0) ? fl + (double)peak_b[f] : (double)peaksum[(int64_t)f * F + x];
+                    s_y[kDispTile + pos] = log1p_fast((float)(pacc * 0.5 - pf)) * inv_den * sf;
+                }
+            }
+            __syncthreads();
+            {
+                const int j = 2 * tid, xo = x0 + j;
+                const float2 yy = *reinterpret_cast<const float2 *>(s_y + j);
+                *reinterpret_cast<float4 *>(points + ((int64_t)f * F + xo) * 2) = make_float4((float)xo * inv_F, yy.x, (float)(xo + 1) * inv_F, yy.y);
+                if (hold) {
+                    const float2 yh = *reinterpret_cast<const float2 *>(s_y + kDispTile + j);
+                    *reinterpret_cast<float4 *>(hold_points + ((int64_t)f * F + xo) * 2) = make_float4((float)xo * inv_F, yh.x, (float)(xo + 1) * inv_F, yh.y);
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     for (int x0 = 2 * (blockIdx.x * kDispThreads + tid); x0 < F; x0 += 2 * kDispThreads * gridDim.x) {
     float y[2], yh[2] = {0.f, 0.f};
 #pragma unroll
@@ -644,7 +691,7 @@ __global__ __launch_bounds__(kDispThreads) void spec_display(const float *__rest
             }
         } else {
             if (x < F) acc = (x == 0) ? fl + (double)first_b[f]   // idx == 0 is replaced by fft_floor_maa (:546-556)
-                                      : (double)pairsum[(int64_t)f * F + x];
+                                      : (double)pairsum[(int64_t)f * F + spec_pair_index(g, x)];
             if (hold && x < F) pacc = (x == 0) ? fl + (double)peak_b[f] : (double)peaksum[(int64_t)f * F + x];
         }
         y[u] = log1p_fast((float)(acc * inv_n - pf)) * inv_den * sf;  // acc / n + 0.25 - (pf - 0.75) = 1 + (acc / n - pf)

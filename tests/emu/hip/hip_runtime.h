@@ -129,6 +129,7 @@ static inline float __fadd_rn(float a, float b) { return a + b; }
 static inline float __fsub_rn(float a, float b) { return a - b; }
 static inline long long min(long long a, long long b) { return a < b ? a : b; }
 static inline long long max(long long a, long long b) { return a > b ? a : b; }
+static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 static inline float __fdividef(float a, float b) { return a / b; }
