@@ -114,6 +114,16 @@ __device__ __forceinline__ float lane_xor1(float v) {
     return __shfl_xor(v, 1, 64);
 #endif
 }
+// true in every lane when the predicate holds in any lane of the wave
+__device__ __forceinline__ bool wave_any(bool p) {
+#if defined(__AMDGCN__)
+    return __builtin_amdgcn_ballot_w64(p) != 0;
+#else
+    int v = p ? 1 : 0;
+    for (int o = 1; o < 64; o <<= 1) v |= __shfl_xor(v, o, 64);
+    return v != 0;
+#endif
+}
 // maximum / minimum over the 64 lanes of the wave, valid in lane 63: six DPP steps on the vector ALU (quad permutes, row mirrors,
 // row broadcasts), no LDS crossbar traffic (__shfl_down goes through ds_bpermute: an LDS-pipe round trip per step)
 #if defined(__AMDGCN__)

@@ -324,7 +324,6 @@ constexpr int kAvgLanes = 64;
 constexpr int kAvgGroups = 16;
 constexpr int kAvgThreads = kAvgLanes * kAvgGroups;
 constexpr int kAvgGMax = 16;               // frames per thread per round -> 256 frames per round
-constexpr size_t kAvgLds = (size_t)(kAvgGroups + 1) * kAvgLanes * 4 * sizeof(double);
 
 // offsets (in floats, inside one frame of `mag`) of the two bins of display point x; db = distance between them
 __device__ inline int64_t spec_pair_offset(const SpecGeom &g, int x, int64_t &db) {
@@ -361,10 +360,38 @@ __device__ inline void avg_step(AvgState &s, double xa, double xb, double rate) 
     if (s.ma_b != s.ma_b) s.ma_b = xb;
     s.ma_b += (xb - s.ma_b) * rate;
 }
+// the same statements when no state is NaN (the repairs are no-ops): checked once per round, see below
+__device__ __forceinline__ void avg_step_fast(AvgState &s, double xa, double xb, double rate) {
+    s.maa_a += (s.ma_a - s.maa_a) * rate; s.ma_a += (xa - s.ma_a) * rate;
+    s.maa_b += (s.ma_b - s.maa_b) * rate; s.ma_b += (xb - s.ma_b) * rate;
+}
+// loads / stores at a wave-uniform base plus a 32-bit per-lane byte offset (scalar-base addressing)
+__device__ __forceinline__ float ldf(const float *base, unsigned byte_off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off); }
+__device__ __forceinline__ float2 ldf2(const float *base, unsigned byte_off) { return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(base) + byte_off); }
+__device__ __forceinline__ void stf(float *base, unsigned byte_off, float v) { *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v; }
+// max / min over each row of 16 lanes (every lane of the row gets the result): four DPP steps, operands fused into the ALU op
+__device__ __forceinline__ void row16_max_min(float &mx, float &mn) {
+#if defined(__AMDGCN__)
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_min_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_min_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_min_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_min_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(mx), "+v"(mn));
+#else
+    for (int o = 1; o < 16; o <<= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); mn = fminf(mn, __shfl_xor(mn, o, 64)); }
+#endif
+}
+
+constexpr int kAvgExtFrames = 4;           // frames whose per-lane extrema sit in LDS before one transposed reduction
+constexpr size_t kAvgLds = (size_t)(kAvgGroups + 1) * kAvgLanes * 4 * sizeof(double) + (size_t)kAvgGroups * 2 * kAvgExtFrames * kAvgLanes * sizeof(float);
 
 __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restrict__ mag, int nf, SpecGeom g, double rate,
                                                             double *__restrict__ ma, double *__restrict__ maa,
-                                                            float *__restrict__ pairsum, float *__restrict__ first_b,
+                                                            float *__restrict__ pairsum /* pair order */, float *__restrict__ first_b,
                                                             float2 *__restrict__ ext_w,
                                                             float2 *__restrict__ maaf /* peak hold / zoomed view: both averaged bins of every point, frames >= pk_from */,
                                                             int pk_from) {
@@ -372,7 +399,8 @@ __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restr
     const int ng = blockDim.x >> 6;                                      // frame groups in this launch (1 .. kAvgGroups: few frames, few groups)
     AvgState *s_loc = reinterpret_cast<AvgState *>(smem);               // [ng][64] group end states (zero entering state)
     AvgState *s_carry = s_loc + ng * kAvgLanes;                          // [64] state after the round
-    const int F = g.F, lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int F = g.F, lane = threadIdx.x & 63, grp = wave_uniform((int)(threadIdx.x >> 6));
+    float *s_ex = reinterpret_cast<float *>(s_carry + kAvgLanes) + grp * 2 * kAvgExtFrames * kAvgLanes;   // this wave's [max | min][4 frames][64 lanes]
     // The magnitudes lie in the row order of the last FFT pass: bin k1 + Ra (k2 + Rb k3) at [(k1 Rb + k2) 4096 + k3].  A tile is
     // 64 consecutive k3 of ONE row pair (k1 even, k1 + 1): two 256-byte runs per load, and the averaged pair sums are written in
     // the same pair order (one 256-byte run per store); the display kernel does the permutation to display order on its read side.
@@ -398,28 +426,30 @@ __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restr
     const int64_t NN = g.N;
     const int ntiles = gridDim.x;
     const double a = 1.0 - rate;
+    const unsigned off_a = (unsigned)t * 4u, off_b = (unsigned)(t + db) * 4u, off_p = (unsigned)pt * 4u;
+    const bool adjacent = db == 1;                                       // (uniform) single-pass sizes: the two bins are one 8-byte load
     AvgState s0 = {ma[xs], maa[xs], ma[F + xs], maa[F + xs]};            // state entering the batch
     for (int fb = 0; fb < nf; fb += ng * kAvgGMax) {
         const int nfb = min(ng * kAvgGMax, nf - fb);
         const int G = (nfb + ng - 1) / ng;                               // frames per group (block-uniform)
-        const int fg = grp * G;                                           // first frame of my group inside the round
+        const int fg = grp * G;                                           // first frame of my group inside the round (wave-uniform)
+        const int cnt = max(0, min(G, nfb - fg));                         // frames this wave really has (wave-uniform)
+        // magnitudes of my frames (frames past the end read the round's last frame: loaded, never used)
         float2 m[kAvgGMax];
 #pragma unroll
-        for (int i = 0; i < kAvgGMax; ++i)
-            m[i] = (i < G && fg + i < nfb) ? spec_load_pair(mag, (int64_t)(fb + fg + i) * NN + t, db) : make_float2(0.f, 0.f);
+        for (int i = 0; i < kAvgGMax; ++i) {
+            const float *mf = mag + (int64_t)(fb + min(fg + i, nfb - 1)) * NN;      // wave-uniform base
+            m[i] = adjacent ? ldf2(mf, off_a) : make_float2(ldf(mf, off_a), ldf(mf, off_b));
+        }
         // M^G = [[aG, 0], [cG, aG]] with aG = a^G, cG = G rate a^(G-1)
         double aG = 1.0, aGm1 = 1.0;
         for (int i = 0; i < G; ++i) { aGm1 = aG; aG *= a; }
         const double cG = (double)G * rate * aGm1;
-        // 1. local pass from a zero state
-        // (a zero state never needs the NaN repairs of avg_step: plain recurrences)
+        // 1. local pass from a zero state (a zero state never needs the NaN repairs of avg_step: plain recurrences)
         AvgState loc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int i = 0; i < kAvgGMax; ++i)
-            if (i < G && fg + i < nfb) {
-                loc.maa_a += (loc.ma_a - loc.maa_a) * rate; loc.ma_a += ((double)m[i].x - loc.ma_a) * rate;
-                loc.maa_b += (loc.ma_b - loc.maa_b) * rate; loc.ma_b += ((double)m[i].y - loc.ma_b) * rate;
-            }
+            if (i < cnt) avg_step_fast(loc, (double)m[i].x, (double)m[i].y, rate);
         s_loc[grp * kAvgLanes + lane] = loc;
         __syncthreads();
         // 2. entering state of my group
@@ -430,24 +460,39 @@ __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restr
             s.ma_a = aG * o.ma_a + e.ma_a;  s.maa_a = aG * o.maa_a + cG * o.ma_a + e.maa_a;
             s.ma_b = aG * o.ma_b + e.ma_b;  s.maa_b = aG * o.maa_b + cG * o.ma_b + e.maa_b;
         }
-        // 3. final pass with the reference's statements; per-frame extrema reduced over the wave's 64 points
+        // 3. final pass with the reference's statements.  Its NaN repairs only ever fire when a state is NaN, which a finite input
+        // stream never produces: one wave-wide test of the entering state picks the plain form (a NaN arriving inside the round is
+        // then repaired at the head of the next one: NaN input is outside the parity contract either way)
+        const bool sick = (s.ma_a != s.ma_a) | (s.maa_a != s.maa_a) | (s.ma_b != s.ma_b) | (s.maa_b != s.maa_b);
+        const bool slow = wave_any(sick);
 #pragma unroll
         for (int i = 0; i < kAvgGMax; ++i) {
-            if (i < G) {                                                  // block-uniform
+            if (i < cnt) {                                                // wave-uniform
                 const int f = fb + fg + i;
-                const bool fv = fg + i < nfb;
+                if (slow) avg_step(s, (double)m[i].x, (double)m[i].y, rate);
+                else avg_step_fast(s, (double)m[i].x, (double)m[i].y, rate);
+                const float fa = (float)s.maa_a, fbb = (float)s.maa_b;    // float rounding is monotonic: extrema of the rounded values
                 float mx = 0.f, mn = 3.0e38f;
-                if (fv) {
-                    avg_step(s, (double)m[i].x, (double)m[i].y, rate);
-                    if (valid) {
-                        pairsum[(int64_t)f * F + pt] = (float)(s.maa_a + s.maa_b);
-                        if (f >= pk_from) maaf[(int64_t)f * F + x] = make_float2((float)s.maa_a, (float)s.maa_b);
-                        mx = (float)fmax(s.maa_a, s.maa_b); mn = (float)fmin(s.maa_a, s.maa_b);
-                        if (x == 0) first_b[f] = (float)s.maa_b;
-                    }
+                if (valid) {
+                    stf(pairsum + (int64_t)f * F, off_p, (float)(s.maa_a + s.maa_b));
+                    if (f >= pk_from) maaf[(int64_t)f * F + x] = make_float2(fa, fbb);
+                    mx = fmaxf(fa, fbb); mn = fminf(fa, fbb);
+                    if (x == 0) first_b[f] = fbb;
                 }
-                mx = wave_max_to_lane63(mx); mn = wave_min_to_lane63(mn);
-                if (lane == 63 && fv) ext_w[(int64_t)f * ntiles + blockIdx.x] = make_float2(mx, mn);
+                s_ex[(i & (kAvgExtFrames - 1)) * kAvgLanes + lane] = mx;
+                s_ex[(kAvgExtFrames + (i & (kAvgExtFrames - 1))) * kAvgLanes + lane] = mn;
+            }
+            // every four frames (and after the last one): transposed reduction through LDS -- lane = (frame q, sixteenth p) folds four
+            // lanes' values in registers, then a 16-lane row reduction: ~10 instructions per frame instead of 36
+            if ((i & (kAvgExtFrames - 1)) == kAvgExtFrames - 1 && i - (kAvgExtFrames - 1) < cnt) {
+                wave_sync();
+                const int q = lane >> 4, p16 = lane & 15, fq = i - (kAvgExtFrames - 1) + q;
+                const float4 vx = *reinterpret_cast<const float4 *>(s_ex + q * kAvgLanes + 4 * p16);
+                const float4 vn = *reinterpret_cast<const float4 *>(s_ex + (kAvgExtFrames + q) * kAvgLanes + 4 * p16);
+                float mx = fmaxf(fmaxf(vx.x, vx.y), fmaxf(vx.z, vx.w)), mn = fminf(fminf(vn.x, vn.y), fminf(vn.z, vn.w));
+                row16_max_min(mx, mn);
+                if (p16 == 0 && fq < cnt) ext_w[(int64_t)(fb + fg + fq) * ntiles + blockIdx.x] = make_float2(mx, mn);
+                wave_sync();
             }
         }
         // 4. the group that holds the last frame of the round publishes the state entering the next round
