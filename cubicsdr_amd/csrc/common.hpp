@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -216,7 +217,8 @@ struct csdr_ctx {
     hipStream_t phys[LANE_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};    // streams this ctx created
     int n_phys = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr; // timing
-    hipEvent_t ev_in = nullptr;              // fork: boundary stream -> lane
+    hipEvent_t ev_in[LANE_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // fork: boundary stream -> lane (one per lane: stage threads fork concurrently)
+    std::mutex prof_mu;                      // the profile bookkeeping is shared by the stage threads
     hipEvent_t ev_lane[LANE_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // join: lane -> boundary stream
     csdr::DevBuf<float> sintab;  // 1024-entry sine table of the reference's NCO
     // per-kernel profile: event pairs recorded around launches while enabled
@@ -228,7 +230,7 @@ struct csdr_ctx {
     std::vector<hipEvent_t> prof_pool;
     double prof_ms[KID_COUNT] = {0};
     long long prof_n[KID_COUNT] = {0};
-    hipEvent_t prof_event() {
+    hipEvent_t prof_event() {                // (callers hold prof_mu)
         if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
         hipEvent_t e = nullptr;
         (void)hipEventCreate(&e);
@@ -237,8 +239,8 @@ struct csdr_ctx {
     // work the caller enqueued on the boundary stream (e.g. the producer of a device IQ buffer) precedes this lane's next work
     int lane_begin(int lane) {
         if (own_stream) return CSDR_OK;      // nobody else can enqueue on a stream we created
-        CSDR_HIP_TRY(hipEventRecord(ev_in, stream));
-        CSDR_HIP_TRY(hipStreamWaitEvent(lanes[lane], ev_in, 0));
+        CSDR_HIP_TRY(hipEventRecord(ev_in[lane], stream));
+        CSDR_HIP_TRY(hipStreamWaitEvent(lanes[lane], ev_in[lane], 0));
         return CSDR_OK;
     }
     // everything enqueued on the lanes so far precedes whatever is enqueued on the boundary stream next
@@ -277,13 +279,29 @@ struct csdr_ctx {
     }
 };
 
+// Every entry point of the C ABI that touches HIP runs on the device of its context, whichever host thread calls it (the
+// reference's pipeline calls from one IOThread per stage).  hipSetDevice is per host thread; the last device this thread
+// selected is remembered so that the common case costs one comparison.
+struct DeviceScope {
+    explicit DeviceScope(const csdr_ctx *c) {
+        static thread_local int current = -1;
+        if (c && current != c->device) { if (hipSetDevice(c->device) == hipSuccess) current = c->device; }
+    }
+};
+
 // bracket one kernel launch with events when profiling is on
 struct ProfScope {
     csdr_ctx *c; int id; hipStream_t st; hipEvent_t a = nullptr;
     ProfScope(csdr_ctx *c_, int id_, hipStream_t st_) : c(c_), id(id_), st(st_) {
-        if (c->prof_on && (c->prof_seen[id]++ % (unsigned)c->prof_period) == 0) { a = c->prof_event(); (void)hipEventRecord(a, st); }
+        if (!c->prof_on) return;
+        std::lock_guard<std::mutex> lk(c->prof_mu);
+        if ((c->prof_seen[id]++ % (unsigned)c->prof_period) == 0) { a = c->prof_event(); (void)hipEventRecord(a, st); }
     }
-    ~ProfScope() { if (a) { hipEvent_t b = c->prof_event(); (void)hipEventRecord(b, st); c->prof_pending.push_back({id, a, b}); } }
+    ~ProfScope() {
+        if (!a) return;
+        std::lock_guard<std::mutex> lk(c->prof_mu);
+        hipEvent_t b = c->prof_event(); (void)hipEventRecord(b, st); c->prof_pending.push_back({id, a, b});
+    }
 };
 #define CSDR_LAUNCH(ctx_, lane_, kid_, kern_, grid_, block_, lds_, ...) \
     do { ProfScope ps__((ctx_), (kid_), (ctx_)->lanes[lane_]); hipLaunchKernelGGL(kern_, grid_, block_, lds_, (ctx_)->lanes[lane_], __VA_ARGS__); } while (0)

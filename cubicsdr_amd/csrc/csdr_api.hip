@@ -58,7 +58,7 @@ extern "C" int csdr_ctx_create(int device, void *hip_stream, csdr_ctx **out) {
     for (int l = 0; l < LANE_COUNT; ++l) c->lanes[l] = c->phys[kMap[want][l]];
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
     else { c->stream = c->phys[0]; c->own_stream = true; }      // a private boundary stream is just the first stage stream
-    CSDR_HIP_TRY(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+    for (int l = 0; l < LANE_COUNT; ++l) CSDR_HIP_TRY(hipEventCreateWithFlags(&c->ev_in[l], hipEventDisableTiming));
     CSDR_HIP_TRY(hipEventCreate(&c->ev0));
     CSDR_HIP_TRY(hipEventCreate(&c->ev1));
     std::vector<float> tab = design::nco_sine_table();
@@ -68,6 +68,7 @@ extern "C" int csdr_ctx_create(int device, void *hip_stream, csdr_ctx **out) {
     return CSDR_OK;
 }
 extern "C" void csdr_ctx_destroy(csdr_ctx *c) {
+    DeviceScope dev__(c);
     if (!c) return;
     (void)c->sync_all();
     c->sintab.release();
@@ -75,7 +76,7 @@ extern "C" void csdr_ctx_destroy(csdr_ctx *c) {
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+    for (int l = 0; l < LANE_COUNT; ++l) if (c->ev_in[l]) (void)hipEventDestroy(c->ev_in[l]);
     for (int l = 0; l < c->n_phys; ++l) {
         if (c->ev_lane[l]) (void)hipEventDestroy(c->ev_lane[l]);
         if (c->phys[l]) (void)hipStreamDestroy(c->phys[l]);
@@ -83,15 +84,18 @@ extern "C" void csdr_ctx_destroy(csdr_ctx *c) {
     delete c;
 }
 extern "C" int csdr_ctx_synchronize(csdr_ctx *c) {
+    DeviceScope dev__(c);
     if (!c) return fail(CSDR_EINVAL, "ctx is null");
     return c->sync_all();
 }
 extern "C" int csdr_ctx_join(csdr_ctx *c) {
+    DeviceScope dev__(c);
     if (!c) return fail(CSDR_EINVAL, "ctx is null");
     return c->join();
 }
 extern "C" void *csdr_ctx_stream(csdr_ctx *c) { return c ? (void *)c->stream : nullptr; }
 extern "C" int csdr_ctx_timer_start(csdr_ctx *c) {
+    DeviceScope dev__(c);
     if (!c) return fail(CSDR_EINVAL, "ctx is null");
     if (int rc = c->join()) return rc;
     CSDR_HIP_TRY(hipEventRecord(c->ev0, c->stream));
@@ -100,6 +104,7 @@ extern "C" int csdr_ctx_timer_start(csdr_ctx *c) {
     return CSDR_OK;
 }
 extern "C" int csdr_ctx_timer_stop(csdr_ctx *c, float *ms) {
+    DeviceScope dev__(c);
     if (!c || !ms) return fail(CSDR_EINVAL, "null argument");
     if (int rc = c->join()) return rc;
     CSDR_HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -114,6 +119,7 @@ static const char *kKernelNames[KID_COUNT] = {
     "spec_fft_radix", "spec_fft_rows", "spec_average", "spec_extrema", "spec_display", "spec_misc"};
 static int prof_drain(csdr_ctx *c) {
     if (int rc = c->sync_all()) return rc;
+    std::lock_guard<std::mutex> lk(c->prof_mu);
     for (auto &r : c->prof_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->prof_ms[r.id] += ms; c->prof_n[r.id] += 1; }
@@ -123,6 +129,7 @@ static int prof_drain(csdr_ctx *c) {
     return CSDR_OK;
 }
 extern "C" int csdr_ctx_profile_enable(csdr_ctx *c, int on) {
+    DeviceScope dev__(c);
     if (!c) return fail(CSDR_EINVAL, "ctx is null");
     if (int rc = prof_drain(c)) return rc;
     c->prof_on = on != 0;
@@ -133,6 +140,7 @@ extern "C" int csdr_ctx_profile_enable(csdr_ctx *c, int on) {
 extern "C" int csdr_ctx_profile_num_kernels(void) { return KID_COUNT; }
 extern "C" const char *csdr_ctx_profile_kernel_name(int id) { return (id >= 0 && id < KID_COUNT) ? kKernelNames[id] : ""; }
 extern "C" int csdr_ctx_profile_fetch(csdr_ctx *c, int id, double *total_ms, int64_t *launches) {
+    DeviceScope dev__(c);
     if (!c || id < 0 || id >= KID_COUNT || !total_ms || !launches) return fail(CSDR_EINVAL, "bad argument");
     if (int rc = prof_drain(c)) return rc;
     *total_ms = c->prof_ms[id]; *launches = c->prof_n[id];
@@ -140,18 +148,22 @@ extern "C" int csdr_ctx_profile_fetch(csdr_ctx *c, int id, double *total_ms, int
 }
 
 extern "C" int csdr_dev_alloc(csdr_ctx *c, uint64_t bytes, void **dev) {
+    DeviceScope dev__(c);
     if (!c || !dev) return fail(CSDR_EINVAL, "null argument");
     if (hipMalloc(dev, bytes) != hipSuccess) return fail(CSDR_ENOMEM, "hipMalloc(%llu) failed", (unsigned long long)bytes);
     return CSDR_OK;
 }
-extern "C" int csdr_dev_free(csdr_ctx *c, void *dev) { (void)c; if (dev) CSDR_HIP_TRY(hipFree(dev)); return CSDR_OK; }
+extern "C" int csdr_dev_free(csdr_ctx *c, void *dev) {
+    DeviceScope dev__(c); (void)c; if (dev) CSDR_HIP_TRY(hipFree(dev)); return CSDR_OK; }
 extern "C" int csdr_dev_upload(csdr_ctx *c, void *dev, const void *host, uint64_t bytes) {
+    DeviceScope dev__(c);
     if (!c) return fail(CSDR_EINVAL, "ctx is null");
     CSDR_HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
     CSDR_HIP_TRY(hipStreamSynchronize(c->stream));
     return CSDR_OK;
 }
 extern "C" int csdr_dev_download(csdr_ctx *c, void *host, const void *dev, uint64_t bytes) {
+    DeviceScope dev__(c);
     if (!c) return fail(CSDR_EINVAL, "ctx is null");
     if (int rc = c->sync_all()) return rc;
     CSDR_HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -203,6 +215,7 @@ static void post_update_channels(csdr_post *p) {   // SDRPostThread::updateChann
 }
 
 extern "C" int csdr_post_create(csdr_ctx *ctx, csdr_post **out) {
+    DeviceScope dev__(ctx);
     if (!ctx || !out) return fail(CSDR_EINVAL, "null argument");
     std::unique_ptr<csdr_post> p(new csdr_post());
     p->ctx = ctx;
@@ -214,6 +227,7 @@ extern "C" int csdr_post_create(csdr_ctx *ctx, csdr_post **out) {
     return CSDR_OK;
 }
 extern "C" void csdr_post_destroy(csdr_post *p) {
+    DeviceScope dev__(p ? p->ctx : nullptr);
     if (!p) return;
     (void)p->ctx->sync_all();
     for (int k = 0; k < csdr_post::kPostBufs; ++k) {
@@ -298,6 +312,7 @@ static chan_kernel_t chan_kernel(const ChanGeom &g) {
 }
 
 extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_channels, int mode, int max_block_len, int max_blocks) {
+    DeviceScope dev__(p ? p->ctx : nullptr);
     if (!p) return fail(CSDR_EINVAL, "post is null");
     if (sample_rate <= 0 || num_channels < 1 || max_block_len <= 0 || max_blocks <= 0) return fail(CSDR_EINVAL, "bad sizes");
     if (mode != CSDR_POST_SINGLE && mode != CSDR_POST_PFBCH && mode != CSDR_POST_PFBCH2) return fail(CSDR_EINVAL, "channelizer mode %d", mode);
@@ -425,6 +440,7 @@ static int run_dc_blocker(csdr_post *p, const float2 *x, float2 *y, int64_t n, b
 static float2 *post_buf(const csdr_post *p, int k) { return p->out.p + (size_t)k * p->chan_stride * p->M; }
 
 extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, int n_blocks, int block_len, int64_t frequency) {
+    DeviceScope dev__(p ? p->ctx : nullptr);
     if (!p || !p->configured) return fail(CSDR_ESTATE, "post not configured");
     if (!iq || n_blocks <= 0 || block_len <= 0) return fail(CSDR_EINVAL, "bad block arguments");
     if (n_blocks > p->max_blocks || block_len > p->max_block_len) return fail(CSDR_ERANGE, "batch %d x %d exceeds configured %d x %d", n_blocks, block_len, p->max_blocks, p->max_block_len);
@@ -511,6 +527,7 @@ extern "C" int csdr_post_channel_at(const csdr_post *p, int64_t frequency_in) { 
     return chan;
 }
 extern "C" int csdr_post_read_channel(csdr_post *p, int ch, float *host_out, int cap_samples, int *n) {
+    DeviceScope dev__(p ? p->ctx : nullptr);
     if (!p || !p->configured || !host_out || !n) return fail(CSDR_EINVAL, "bad argument");
     if (ch == p->M && p->M > 1) ch = p->M / 2;
     if (ch < 0 || ch >= p->M) return fail(CSDR_EINVAL, "channel out of range");
@@ -610,6 +627,7 @@ static void fill_resamp_cfg(ResampCfg &rc, const design::MsresampPlan &p, int ar
 }
 
 extern "C" int csdr_bank_create(csdr_ctx *ctx, int max_demods, int max_blocks, csdr_bank **out) {
+    DeviceScope dev__(ctx);
     if (!ctx || !out || max_demods <= 0 || max_blocks <= 0) return fail(CSDR_EINVAL, "bad argument");
     std::unique_ptr<csdr_bank> b(new csdr_bank());
     b->ctx = ctx; b->max_demods = max_demods; b->max_blocks = max_blocks;
@@ -650,6 +668,7 @@ extern "C" int csdr_bank_create(csdr_ctx *ctx, int max_demods, int max_blocks, c
 }
 
 extern "C" void csdr_bank_destroy(csdr_bank *b) {
+    DeviceScope dev__(b ? b->ctx : nullptr);
     if (!b) return;
     (void)b->ctx->sync_all();
     for (int k = 0; k < 2; ++k) {
@@ -677,6 +696,7 @@ static int modem_check_rate(int modem, int bw, int audio_rate) {   // Modem*::ch
 
 static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *prm, const csdr_post *post);
 extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *prm, const csdr_post *post) {
+    DeviceScope dev__(b ? b->ctx : nullptr);
     if (prm && (prm->modem < CSDR_MODEM_NBFM || prm->modem > CSDR_MODEM_DSB)) return fail(CSDR_EUNSUPPORTED, "modem %d", prm->modem);
     return bank_configure_slot(b, slot, prm, post);
 }
@@ -731,6 +751,7 @@ static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *
     const size_t o_pll = carve(2 * sizeof(uint32_t));
     const size_t o_bm = carve(b->max_blocks * sizeof(float));
     const size_t o_bo = carve(b->max_blocks * sizeof(BlockOut));
+    const size_t o_sc = carve(kScopeMax * sizeof(float)), o_scn = carve(sizeof(int32_t));
     if (s.slab) { (void)hipFree(s.slab); s.slab = nullptr; }
     if (hipMalloc(&s.slab, off) != hipSuccess) return fail(CSDR_ENOMEM, "slot slab of %zu bytes", off);
     CSDR_HIP_TRY(hipMemset(s.slab, 0, off));
@@ -744,6 +765,7 @@ static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *
     c.mixhist = (float2 *)(base + o_mix); c.iq = (float2 *)(base + o_iq); c.d = (float *)(base + o_d); c.dh = (float *)(base + o_dh);
     c.audio = (float *)(base + o_au); c.agc = (float *)(base + o_agc); c.pll = (uint32_t *)(base + o_pll);   // slab is zeroed: nco_crcf_reset
     c.blockmax = (float *)(base + o_bm); c.bout = (BlockOut *)(base + o_bo);
+    c.scope = (float *)(base + o_sc); c.scope_n = (int32_t *)(base + o_scn);
     c.cap_iq = (int)cap_iq; c.cap_audio = (int)cap_audio;
     const float agc0[8] = {1.0f, 1.0f, 1.0f, 0.f, 1.0f, 1.0f, 1.0f, 0.f};   // ModemAnalog::ModemAnalog(): aOutputCeil(1), MA(1), MAA(1)
     CSDR_HIP_TRY(hipMemcpy(c.agc, agc0, sizeof agc0, hipMemcpyHostToDevice));
@@ -778,6 +800,7 @@ static inline int64_t first_out(int64_t K, uint32_t phase0, uint32_t step) {
 }
 
 extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
+    DeviceScope dev__(b ? b->ctx : nullptr);
     if (!b || !post) return fail(CSDR_EINVAL, "null argument");
     if (!post->configured || post->n_blocks <= 0) return fail(CSDR_ESTATE, "post has no data");
     csdr_ctx *c = b->ctx;
@@ -798,18 +821,39 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     BlockPlan *plans_h = b->plans_h[ring].p;
     int n_run = 0, n_ag = 0, max_n_iq = 0, max_n_audio = 0, warm_max = 0, max_aS = 0, max_cw_audio = 0;
     int *ag_list_h = slot_list_h + b->max_demods;
+    // The per-slot walk below validates AND advances the host-side integer state (oscillator phases, resampler phases, buffer
+    // parities).  A rejected batch must leave every slot as it was -- no kernel runs for it -- so the state is snapshotted and
+    // put back on any error return of the walk.
+    struct Snap { uint32_t theta, dtheta, buf_idx, phase, aphase, abuf, ssb_theta; long long shift_frequency; bool shift_valid; int hist_parity, last_parity, prev_J; };
+    std::vector<Snap> snap((size_t)b->max_demods);
+    for (int si = 0; si < b->max_demods; ++si) {
+        const SlotHost &s = b->slots[si];
+        snap[si] = Snap{s.theta, s.dtheta, s.buf_idx, s.phase, s.aphase, s.abuf, s.ssb_theta, s.shift_frequency, s.shift_valid, s.hist_parity, s.last_parity, s.prev_J};
+    }
+    const int ring_before = ring;
+    auto reject = [&](int rc) {
+        for (int si = 0; si < b->max_demods; ++si) {
+            SlotHost &s = b->slots[si];
+            const Snap &q = snap[si];
+            s.theta = q.theta; s.dtheta = q.dtheta; s.buf_idx = q.buf_idx; s.phase = q.phase; s.aphase = q.aphase; s.abuf = q.abuf; s.ssb_theta = q.ssb_theta;
+            s.shift_frequency = q.shift_frequency; s.shift_valid = q.shift_valid; s.hist_parity = q.hist_parity; s.last_parity = q.last_parity; s.prev_J = q.prev_J;
+            s.results.clear(); s.last_J = 0; s.last_A = 0;
+        }
+        b->stage_next = ring_before;
+        return rc;
+    };
     for (int si = 0; si < b->max_demods; ++si) {
         SlotHost &s = b->slots[si];
         s.results.clear(); s.last_J = 0; s.last_A = 0;
         if (!s.configured || !s.active) continue;
-        if (s.chan_rate != rate) return fail(CSDR_ESTATE, "slot %d was built for channel rate %lld, post now runs %lld: reconfigure", si, (long long)s.chan_rate, (long long)rate);
+        if (s.chan_rate != rate) return reject(fail(CSDR_ESTATE, "slot %d was built for channel rate %lld, post now runs %lld: reconfigure", si, (long long)s.chan_rate, (long long)rate));
         // channel routing: runDemodChannels, SDRPostThread.cpp:317-323 (nearest centre; M == wrap channel = M/2)
         int ch = csdr_post_channel_at(post, s.prm.frequency);
         if (ch < 0) continue;
         const int64_t centre = (M == 1) ? post->frequency : post->centers[ch];
         const int data_ch = (M > 1 && ch == M) ? M / 2 : ch;
         if (M > 1 && !std::binary_search(post->active_host.begin(), post->active_host.end(), data_ch))
-            return fail(CSDR_ESTATE, "slot %d needs channel %d which the channelizer was told not to produce", si, data_ch);
+            return reject(fail(CSDR_ESTATE, "slot %d needs channel %d which the channelizer was told not to produce", si, data_ch));
         // DemodulatorPreThread.cpp:154-165
         const long long shift = (long long)s.prm.frequency - (long long)centre;
         const int bound = (int)((double)(rate / 2) * 1.5);
@@ -847,7 +891,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
             pl[bb].j0 = (int)J; pl[bb].q0 = (int)Q;
         }
         const int64_t Jtot = pl[NB].j0, Qtot = pl[NB].q0;
-        if (Jtot > s.cfg.cap_iq - 8 || (!fe_only && (Qtot << ash) > s.cfg.cap_audio - 8)) return fail(CSDR_ERANGE, "slot %d output exceeds its buffers", si);
+        if (Jtot > s.cfg.cap_iq - 8 || (!fe_only && (Qtot << ash) > s.cfg.cap_audio - 8)) return reject(fail(CSDR_ERANGE, "slot %d output exceeds its buffers", si));
         int max_blk_audio = 0;
         for (int bb = 0; bb < NB; ++bb) {
             csdr_block_result &r = s.results[bb];
@@ -856,7 +900,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
             r.n_audio = (int)(((int64_t)(pl[bb + 1].q0 - pl[bb].q0)) << ash);
             r.audio_offset = (int)(((int64_t)pl[bb].q0) << ash);
             if (fe_only) { r.n_audio = 0; r.audio_offset = 0; }
-            else if (r.n_iq > kModemMaxBlockIq || r.n_audio > kAudioMaxOut) return fail(CSDR_EUNSUPPORTED, "slot %d: %d IQ / %d audio samples per block exceed the per-workgroup limits", si, r.n_iq, r.n_audio);
+            else if (r.n_iq > kModemMaxBlockIq || r.n_audio > kAudioMaxOut) return reject(fail(CSDR_EUNSUPPORTED, "slot %d: %d IQ / %d audio samples per block exceed the per-workgroup limits", si, r.n_iq, r.n_audio));
             if (!fe_only) { max_n_iq = std::max(max_n_iq, r.n_iq); max_n_audio = std::max(max_n_audio, r.n_audio); }
             max_blk_audio = std::max(max_blk_audio, r.n_audio);
             const int64_t Kb = ((int64_t)s.buf_idx + (int64_t)(bb + 1) * Bc) >> S;
@@ -1006,6 +1050,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
 }
 
 extern "C" int csdr_bank_fetch_results(csdr_bank *b, int slot, csdr_block_result *out, int cap_blocks, int *n_blocks) {
+    DeviceScope dev__(b ? b->ctx : nullptr);
     if (!b || !out || !n_blocks || slot < 0 || slot >= b->max_demods) return fail(CSDR_EINVAL, "bad argument");
     SlotHost &s = b->slots[slot];
     const int nb = (int)s.results.size();
@@ -1026,6 +1071,7 @@ extern "C" int csdr_bank_fetch_results(csdr_bank *b, int slot, csdr_block_result
     return CSDR_OK;
 }
 extern "C" int csdr_bank_fetch_audio(csdr_bank *b, int slot, float *host_out, int cap_samples, int *n) {
+    DeviceScope dev__(b ? b->ctx : nullptr);
     if (!b || !host_out || !n || slot < 0 || slot >= b->max_demods) return fail(CSDR_EINVAL, "bad argument");
     SlotHost &s = b->slots[slot];
     if (s.last_A > cap_samples) return fail(CSDR_ERANGE, "need room for %d samples", s.last_A);
@@ -1038,6 +1084,7 @@ extern "C" int csdr_bank_fetch_audio(csdr_bank *b, int slot, float *host_out, in
     return CSDR_OK;
 }
 extern "C" int csdr_bank_fetch_iq(csdr_bank *b, int slot, float *host_out, int cap_samples, int *n) {
+    DeviceScope dev__(b ? b->ctx : nullptr);
     if (!b || !host_out || !n || slot < 0 || slot >= b->max_demods) return fail(CSDR_EINVAL, "bad argument");
     SlotHost &s = b->slots[slot];
     if (s.last_J > cap_samples) return fail(CSDR_ERANGE, "need room for %d samples", s.last_J);
@@ -1048,6 +1095,26 @@ extern "C" int csdr_bank_fetch_iq(csdr_bank *b, int slot, float *host_out, int c
         CSDR_HIP_TRY(hipMemcpyAsync(host_out, cur, (size_t)s.last_J * sizeof(float2), hipMemcpyDeviceToHost, st));
         CSDR_HIP_TRY(hipStreamSynchronize(st));
     }
+    return CSDR_OK;
+}
+// ModemAnalog::getDemodOutputData of the last block of the last batch: the scaled demodulator output before the audio resampler,
+// at most DEMOD_VIS_SIZE samples (the scope tap of DemodulatorThread.cpp:293-305 reads it when the audio is decimated)
+extern "C" int csdr_bank_fetch_demod_output(csdr_bank *b, int slot, float *host_out, int cap_samples, int *n) {
+    DeviceScope dev__(b ? b->ctx : nullptr);
+    if (!b || !host_out || !n || slot < 0 || slot >= b->max_demods) return fail(CSDR_EINVAL, "bad argument");
+    SlotHost &s = b->slots[slot];
+    *n = 0;
+    if (!s.configured || s.last_A == 0 || s.prm.modem == CSDR_MODEM_IQ || s.prm.modem == CSDR_MODEM_CW) return CSDR_OK;     // (those modems keep no demodOutputData)
+    hipStream_t st = b->ctx->lanes[LANE_AUDIO];
+    int32_t cnt = 0;
+    CSDR_HIP_TRY(hipMemcpyAsync(&cnt, s.cfg.scope_n, sizeof cnt, hipMemcpyDeviceToHost, st));
+    CSDR_HIP_TRY(hipStreamSynchronize(st));
+    cnt = std::min<int32_t>(cnt, cap_samples);
+    if (cnt > 0) {
+        CSDR_HIP_TRY(hipMemcpyAsync(host_out, s.cfg.scope, (size_t)cnt * sizeof(float), hipMemcpyDeviceToHost, st));
+        CSDR_HIP_TRY(hipStreamSynchronize(st));
+    }
+    *n = cnt;
     return CSDR_OK;
 }
 extern "C" int csdr_bank_total_audio(csdr_bank *b, int64_t *n) {
@@ -1110,6 +1177,7 @@ struct csdr_spec {
 };
 
 extern "C" int csdr_spec_create(csdr_ctx *ctx, csdr_spec **out) {
+    DeviceScope dev__(ctx);
     if (!ctx || !out) return fail(CSDR_EINVAL, "null argument");
     std::unique_ptr<csdr_spec> s(new csdr_spec());
     s->ctx = ctx;
@@ -1121,6 +1189,7 @@ extern "C" int csdr_spec_create(csdr_ctx *ctx, csdr_spec **out) {
     return CSDR_OK;
 }
 extern "C" void csdr_spec_destroy(csdr_spec *s) {
+    DeviceScope dev__(s ? s->ctx : nullptr);
     if (!s) return;
     (void)s->ctx->sync_all();
     for (int k = 0; k < 2; ++k) {
@@ -1141,6 +1210,7 @@ extern "C" void csdr_spec_destroy(csdr_spec *s) {
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
+    DeviceScope dev__(s ? s->ctx : nullptr);
     if (!s) return fail(CSDR_EINVAL, "spec is null");
     if (fft_size < 2 || (fft_size & (fft_size - 1))) return fail(CSDR_EUNSUPPORTED, "fft_size %d: only powers of two are built", fft_size);
     if (max_frames <= 0) return fail(CSDR_EINVAL, "max_frames");
@@ -1548,6 +1618,7 @@ static int spec_process_view(csdr_spec *s, const float *iq, int iq_is_dev, int b
 }
 
 extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, int n_blocks, int block_len, int mode) {
+    DeviceScope dev__(s ? s->ctx : nullptr);
     if (!s || !s->ready) return fail(CSDR_ESTATE, "spec not set up");
     if (!iq || n_blocks <= 0 || block_len <= 0) return fail(CSDR_EINVAL, "bad block arguments");
     if (s->is_view) {
@@ -1641,6 +1712,7 @@ static void spec_hide_dc(const csdr_spec *s, float *pts) {
 }
 
 extern "C" int csdr_spec_fetch_hold(csdr_spec *s, int frame, float *hold_host, int cap_floats, int *n_floats) {
+    DeviceScope dev__(s ? s->ctx : nullptr);
     if (!s || !s->ready || !hold_host || !n_floats) return fail(CSDR_EINVAL, "bad argument");
     if (frame < 0 || frame >= s->nf_last) return fail(CSDR_EINVAL, "frame %d of %d", frame, s->nf_last);
     const int F = s->g.F;
@@ -1656,6 +1728,7 @@ extern "C" int csdr_spec_fetch_hold(csdr_spec *s, int frame, float *hold_host, i
 }
 
 extern "C" int csdr_spec_fetch(csdr_spec *s, int frame, float *points_host, int cap_floats, double *fft_ceiling, double *fft_floor) {
+    DeviceScope dev__(s ? s->ctx : nullptr);
     if (!s || !s->ready || !points_host) return fail(CSDR_EINVAL, "bad argument");
     if (frame < 0 || frame >= s->nf_last) return fail(CSDR_EINVAL, "frame %d of %d", frame, s->nf_last);
     const int F = s->g.F;
@@ -1672,6 +1745,7 @@ extern "C" int csdr_spec_fetch(csdr_spec *s, int frame, float *points_host, int 
 }
 
 extern "C" int csdr_spec_fft_only(csdr_spec *s, const float *iq_host, float *out_host) {
+    DeviceScope dev__(s ? s->ctx : nullptr);
     if (!s || !s->ready || !iq_host || !out_host) return fail(CSDR_EINVAL, "bad argument");
     hipStream_t st = s->ctx->lanes[LANE_FFT];
     const int N = s->g.N;

@@ -25,6 +25,7 @@ constexpr int kArms = 256;
 constexpr int kMixHist = 65536;   // upper bound of the mixed-input history kept per slot (cascade span; S <= 10)
 constexpr int kIqHist = 256;      // resampled-IQ history kept per slot
 constexpr int kDHist = 256;       // scaled demodulator-output history kept per slot (>= span of a decimating audio cascade)
+constexpr int kScopeMax = 2048;   // DEMOD_VIS_SIZE (DemodulatorThread.h:15)
 constexpr int kFeThreads = 256;
 constexpr int kFeChunk = 2048;    // input samples one inner iteration of the front-end stages through LDS
 constexpr int kFePairs = kFeChunk / 2 / kFeThreads;   // 16-byte loads per thread per chunk
@@ -54,6 +55,8 @@ struct SlotCfg {                  // static per configuration, lives in HBM
     uint32_t *pll;                // [2] DSB Costas loop: oscillator phase word, frequency word (carried across batches)
     float *blockmax;              // [max_blocks]
     struct BlockOut *bout;        // [max_blocks]
+    float *scope;                 // [kScopeMax] scaled demodulator output of the LAST block of the batch (ModemAnalog::getDemodOutputData: the scope tap)
+    int32_t *scope_n;             // how many of them
     int32_t cap_iq, cap_audio;
 };
 
@@ -1174,6 +1177,14 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
             x = cfg.d[j] * gg;
         }
         s_d[i] = x;
+    }
+    // the last block's own scaled samples are the scope tap (DemodulatorThread.cpp:293-305); they lie inside the staged window
+    if (b == NB - 1) {
+        const int n_own = pl[b + 1].j0 - jb0;
+        const int ns = max(0, min(min(n_own, kScopeMax), (int)(jhi - (int64_t)jb0)));
+        __syncthreads();
+        for (int i = tid; i < ns; i += nthr) cfg.scope[i] = s_d[(int)((int64_t)jb0 - jlo) + i];
+        if (tid == 0) *cfg.scope_n = ns;
     }
     // the filter arms of this thread's first two arbitrary-stage outputs travel while the staging above lands
     float2 hv[2][kArmTaps / 2];

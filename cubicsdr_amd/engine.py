@@ -181,6 +181,13 @@ class DemodBank:
         H.check(self._l.csdr_bank_fetch_iq(self.h, int(slot), out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
         return out[:n.value].copy()
 
+    def demod_output(self, slot, cap=2048):
+        """scaled demodulator output of the last block (ModemAnalog::getDemodOutputData), at most 2048 samples"""
+        out = np.empty(cap, np.float32)
+        n = C.c_int()
+        H.check(self._l.csdr_bank_fetch_demod_output(self.h, int(slot), out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        return out[:n.value].copy()
+
     def total_audio(self):
         n = C.c_int64()
         H.check(self._l.csdr_bank_total_audio(self.h, C.byref(n)))

@@ -12,9 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcsdr_hip.so")
 
 CSDR_POST_SINGLE, CSDR_POST_PFBCH, CSDR_POST_PFBCH2 = 0, 1, 2
-CSDR_MODEM_NBFM, CSDR_MODEM_FM, CSDR_MODEM_AM, CSDR_MODEM_USB, CSDR_MODEM_LSB, CSDR_MODEM_IQ, CSDR_MODEM_CW, CSDR_MODEM_DSB = range(8)
+CSDR_MODEM_NBFM, CSDR_MODEM_FM, CSDR_MODEM_AM, CSDR_MODEM_USB, CSDR_MODEM_LSB, CSDR_MODEM_IQ, CSDR_MODEM_CW, CSDR_MODEM_DSB, CSDR_MODEM_FMS = range(9)
 CSDR_SPEC_FIRST_FRAME, CSDR_SPEC_CONTIGUOUS, CSDR_SPEC_LINES = 0, 1, 2
-MODEM_BY_NAME = {"NBFM": 0, "FM": 1, "AM": 2, "USB": 3, "LSB": 4, "I/Q": 5, "IQ": 5, "CW": 6, "DSB": 7}
+MODEM_BY_NAME = {"NBFM": 0, "FM": 1, "AM": 2, "USB": 3, "LSB": 4, "I/Q": 5, "IQ": 5, "CW": 6, "DSB": 7, "FMS": 8}
 
 
 class DemodParams(C.Structure):
@@ -72,6 +72,7 @@ ABI = {
     "csdr_bank_fetch_results": (_i, [_p, _i, C.POINTER(BlockResult), _i, C.POINTER(_i)]),
     "csdr_bank_fetch_audio": (_i, [_p, _i, _p, _i, C.POINTER(_i)]),
     "csdr_bank_fetch_iq": (_i, [_p, _i, _p, _i, C.POINTER(_i)]),
+    "csdr_bank_fetch_demod_output": (_i, [_p, _i, _p, _i, C.POINTER(_i)]),
     "csdr_bank_total_audio": (_i, [_p, C.POINTER(_i64)]),
     "csdr_spec_create": (_i, [_p, _pp]),
     "csdr_spec_destroy": (None, [_p]),

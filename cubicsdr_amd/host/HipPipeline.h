@@ -23,9 +23,11 @@
 #include "../../include/csdr_hip.h"
 #include "DataTypes.h"
 #include "IOThread.h"
+#include "Modem.h"
 #include "VisualProcessor.h"
 
 #define HEARTBEAT_CHECK_PERIOD_MICROS (50 * 1000)
+#define DEMOD_VIS_SIZE 2048                      // DemodulatorThread.h:15
 #include "FFTDataDistributor.h"
 
 inline void csdr_must(int rc, const char *what) {
@@ -34,21 +36,48 @@ inline void csdr_must(int rc, const char *what) {
 
 class DemodulatorMgr;
 
+typedef ThreadBlockingQueue<AudioThreadInputPtr> DemodulatorThreadOutputQueue;           // DemodDefs.h: the scope ("audio visual") queue
+typedef std::shared_ptr<DemodulatorThreadOutputQueue> DemodulatorThreadOutputQueuePtr;
+
 class DemodulatorInstance {
 public:
     DemodulatorInstance(DemodulatorMgr *mgr, int slot) : mgr_(mgr), slot_(slot) {
         audioQueue_ = std::make_shared<AudioThreadInputQueue>();
         audioQueue_->set_max_num_items(100);
+        pipeIQInputData_ = std::make_shared<DemodulatorThreadInputQueue>();                 // DemodulatorInstance.cpp:54-56
+        pipeIQInputData_->set_max_num_items(100);
+        setDemodulatorType("NBFM");
     }
+    // --- lifecycle (DemodulatorInstance.cpp:111-196): the reference starts a pre-demod, a demod and an audio thread per instance;
+    // here the arithmetic of all instances runs inside SDRPostThread's csdr_bank_execute, so run() only marks the instance live
+    void run() { terminated_.store(false); active_.store(true); }
+    void terminate() { active_.store(false); terminated_.store(true); if (pipeIQInputData_) pipeIQInputData_->flush(); audioQueue_->flush(); }
+    bool isTerminated() { return terminated_.load(); }
+    std::string getLabel() { std::lock_guard<std::mutex> g(mu_); return label_; }
+    void setLabel(std::string l) { std::lock_guard<std::mutex> g(mu_); label_ = std::move(l); }
     // --- configuration (applied at the next block, like the atomics of DemodulatorPreThread.cpp:293-336)
-    void setDemodulatorType(const std::string &t) { std::lock_guard<std::mutex> g(mu_); type_ = t; bandwidth_ = defaultBandwidth(t); dirty_ = true; }
+    void setDemodulatorType(const std::string &t) {                                          // DemodulatorInstance.cpp:318-333
+        std::unique_ptr<Modem> m(Modem::makeModem(t));
+        if (!m) return;                                                                      // unknown type: keep the current modem
+        std::lock_guard<std::mutex> g(mu_);
+        type_ = t; bandwidth_ = Modem::getModemDefaultSampleRate(t); modem_ = std::move(m); dirty_ = true;
+        auto it = lastModemSettings_.find(t);
+        if (it != lastModemSettings_.end()) modem_->writeSettings(it->second);
+    }
     std::string getDemodulatorType() { std::lock_guard<std::mutex> g(mu_); return type_; }
-    void setBandwidth(int bw) { std::lock_guard<std::mutex> g(mu_); bandwidth_ = bw; dirty_ = true; }
+    std::string getModemType() { std::lock_guard<std::mutex> g(mu_); return modem_ ? modem_->getType() : ""; }
+    bool isModemInitialized() { std::lock_guard<std::mutex> g(mu_); return modem_ != nullptr; }
+    void setBandwidth(int bw) {                                                              // through the modem's checkSampleRate (DemodulatorPreThread.cpp:98-104)
+        std::lock_guard<std::mutex> g(mu_);
+        bandwidth_ = modem_ ? modem_->checkSampleRate(bw, audioRate_) : bw; dirty_ = true;
+    }
     int getBandwidth() { std::lock_guard<std::mutex> g(mu_); return bandwidth_; }
     void setFrequency(long long f) { frequency_.store(f); }
     long long getFrequency() { return frequency_.load(); }
     void setAudioSampleRate(int r) { std::lock_guard<std::mutex> g(mu_); audioRate_ = r; dirty_ = true; }
     int getAudioSampleRate() { std::lock_guard<std::mutex> g(mu_); return audioRate_; }
+    void setGain(float g) { gain_.store(g < 0.005f ? 0.005f : (g > 40.0f ? 40.0f : g)); }   // AudioThread::setGain clamps (AudioThread.cpp:523-531)
+    float getGain() { return gain_.load(); }
     void setActive(bool a) { active_.store(a); }
     bool isActive() { return active_.load(); }
     void setSquelchEnabled(bool e) { squelchEnabled_.store(e); }
@@ -61,44 +90,44 @@ public:
     float getSignalFloor() { return signalFloor_.load(); }
     float getSignalCeil() { return signalCeil_.load(); }
     AudioThreadInputQueuePtr getAudioOutputQueue() { return audioQueue_; }   // "AudioDataOutput" (DemodulatorThread.cpp:80)
+    // the block hand-over pipe of the reference (DemodulatorInstance.cpp:447-449).  SDRPostThread does not push blocks through it
+    // (the channelizer output stays on the device); it exists so that code holding the pipe keeps linking, and is flushed on terminate
+    DemodulatorThreadInputQueuePtr getIQInputDataPipe() { return pipeIQInputData_; }
+    // the audio-scope queue (DemodulatorInstance.cpp:103-105 -> DemodulatorThread::setOutputQueue("AudioVisualOutput"))
+    void setVisualOutputQueue(const DemodulatorThreadOutputQueuePtr &q) { std::lock_guard<std::mutex> g(mu_); audioVisQueue_ = q; }
+    // modem settings (DemodulatorInstance.cpp:451-498)
+    ModemArgInfoList getModemArgs() { std::lock_guard<std::mutex> g(mu_); return modem_ ? modem_->getSettings() : ModemArgInfoList(); }
+    std::string readModemSetting(const std::string &setting) { std::lock_guard<std::mutex> g(mu_); return modem_ ? modem_->readSetting(setting) : ""; }
+    ModemSettings readModemSettings() { std::lock_guard<std::mutex> g(mu_); return modem_ ? modem_->readSettings() : ModemSettings(); }
+    void writeModemSetting(const std::string &setting, std::string value) {
+        std::lock_guard<std::mutex> g(mu_);
+        if (!modem_) return;
+        modem_->writeSetting(setting, value);
+        lastModemSettings_[type_][setting] = value;
+        if (modem_->shouldRebuildKit()) { dirty_ = true; modem_->clearRebuildKit(); }
+    }
+    void writeModemSettings(ModemSettings settings) { for (auto &kv : settings) writeModemSetting(kv.first, kv.second); }
+    ModemSettings getLastModemSettings(const std::string &demodType) { std::lock_guard<std::mutex> g(mu_); return lastModemSettings_[demodType]; }
     int slot() const { return slot_; }
-
-    static int defaultBandwidth(const std::string &t) {      // factory table, CubicSDR.cpp:305-313
-        if (t == "FM") return 200000;
-        if (t == "NBFM") return 12500;
-        if (t == "AM") return 6000;
-        if (t == "USB" || t == "LSB") return 5400;
-        if (t == "I/Q") return 48000;                         // ModemIQ.cpp:35-37
-        if (t == "CW") return 500;                            // ModemCW.cpp:107-109 (MIN_BANDWIDTH)
-        if (t == "DSB") return 5400;                          // ModemDSB.cpp:25-27
-        return 12500;
-    }
-    static int modemId(const std::string &t) {
-        if (t == "NBFM") return CSDR_MODEM_NBFM;
-        if (t == "FM") return CSDR_MODEM_FM;
-        if (t == "AM") return CSDR_MODEM_AM;
-        if (t == "USB") return CSDR_MODEM_USB;
-        if (t == "LSB") return CSDR_MODEM_LSB;
-        if (t == "I/Q") return CSDR_MODEM_IQ;
-        if (t == "CW") return CSDR_MODEM_CW;
-        if (t == "DSB") return CSDR_MODEM_DSB;
-        return -1;
-    }
 
 private:
     friend class SDRPostThread;
     DemodulatorMgr *mgr_;
     int slot_;
     std::mutex mu_;
-    std::string type_ = "NBFM";
+    std::string type_ = "NBFM", label_;
+    std::unique_ptr<Modem> modem_;
+    std::map<std::string, ModemSettings> lastModemSettings_;
     int bandwidth_ = 12500, audioRate_ = 48000;
     bool dirty_ = true;                       // needs csdr_bank_configure_slot
     long long builtRate_ = 0;
     std::atomic<long long> frequency_{0};
-    std::atomic_bool active_{false}, squelchEnabled_{false}, muted_{false};
-    std::atomic<float> squelchLevel_{-100.0f}, signalLevel_{-100.0f}, signalFloor_{-30.0f}, signalCeil_{30.0f};
+    std::atomic_bool active_{false}, terminated_{false}, squelchEnabled_{false}, muted_{false};
+    std::atomic<float> squelchLevel_{-100.0f}, signalLevel_{-100.0f}, signalFloor_{-30.0f}, signalCeil_{30.0f}, gain_{1.0f};
     bool squelchBreak_ = false;
     AudioThreadInputQueuePtr audioQueue_;
+    DemodulatorThreadInputQueuePtr pipeIQInputData_;
+    DemodulatorThreadOutputQueuePtr audioVisQueue_;
     ReBuffer<AudioThreadInput> outputBuffers_{"DemodulatorThreadBuffers"};
 };
 typedef std::shared_ptr<DemodulatorInstance> DemodulatorInstancePtr;
@@ -178,19 +207,37 @@ public:
 
 private:
     void processBlock(SDRThreadIQData &in, const DemodulatorThreadInputQueuePtr &iqOut, const DemodulatorThreadInputQueuePtr &iqVisual) {
-        const int n = (int)in.data.size();
         const int M = in.numChannels > 1 ? in.numChannels : 1;
+        // whole frames only (the reference's channelizer loop steps by numChannels, :449; SoapySDRThread hands out multiples, :668-674)
+        const int n = ((int)in.data.size() / M) * M;
+        if (n <= 0) return;
         const int mode = chanMode.load();
         if (in.sampleRate != sampleRate_ || M != numChannels_ || n > maxBlock_ || mode != lastChanMode_) {      // initPFBCH :401-414, initPFBCH2 :458-470
-            sampleRate_ = in.sampleRate; numChannels_ = M; maxBlock_ = n; lastChanMode_ = mode;
+            // room for blocks up to twice the nominal 1/60 s (a longer one re-initialises, which also rebuilds every demodulator:
+            // their buffers are sized from the block length)
+            const long long nominal = ((in.sampleRate / 30 + M - 1) / M) * M;
+            sampleRate_ = in.sampleRate; numChannels_ = M; lastChanMode_ = mode;
+            maxBlock_ = (int)std::max<long long>(n, std::min<long long>(nominal, 1LL << 26));
             const int kind = M > 1 ? (mode == SDRPostPFBCH2 ? CSDR_POST_PFBCH2 : CSDR_POST_PFBCH) : CSDR_POST_SINGLE;
-            csdr_must(csdr_post_configure(post_, sampleRate_, M, kind, n, 1), "csdr_post_configure");
+            csdr_must(csdr_post_configure(post_, sampleRate_, M, kind, maxBlock_, 1), "csdr_post_configure");
+            for (auto &d : mgr_->getDemodulators()) { std::lock_guard<std::mutex> g(d->mu_); d->dirty_ = true; }
         }
-        // full-rate copy to the visual queues first (getFullSampleRateIqData + pushVisualData, :221-245): never blocks
-        if (iqOut || iqVisual) {
+        if (M == 1) {
+            // runSingleCH (:248-299): the DC blocker runs on EVERY block; the DC-corrected data is what the main spectrum, the
+            // waterfall and (when a demodulator is active) the demodulator spectrum see
+            csdr_must(csdr_post_execute(post_, (const float *)in.data.data(), 0, 1, n, in.frequency), "csdr_post_execute");
+            singleOut_ = visualBuffers_.getBuffer();
+            singleOut_->frequency = in.frequency; singleOut_->sampleRate = in.sampleRate;
+            singleOut_->data.resize((size_t)n);
+            int got = 0;
+            csdr_must(csdr_post_read_channel(post_, 0, (float *)singleOut_->data.data(), n, &got), "csdr_post_read_channel");
+            singleOut_->data.resize((size_t)got);
+            if (iqOut) { iqOut->try_push(singleOut_); if (iqVisual) iqVisual->try_push(singleOut_); }       // pushVisualData :233-245
+        } else if (iqOut) {
+            // full-rate copy to the visual queues first (getFullSampleRateIqData + pushVisualData, :221-245): never blocks
             DemodulatorThreadIQDataPtr vis = visualBuffers_.getBuffer();
             vis->frequency = in.frequency; vis->sampleRate = in.sampleRate; vis->data = in.data;
-            if (iqOut) iqOut->try_push(vis);
+            iqOut->try_push(vis);
             if (iqVisual) iqVisual->try_push(vis);
         }
         // active set: in range of this block's span (updateActiveDemodulators, :44-98)
@@ -205,7 +252,7 @@ private:
             {
                 std::lock_guard<std::mutex> g(d->mu_);
                 rebuild = d->dirty_ || d->builtRate_ != chanRate;
-                p.modem = DemodulatorInstance::modemId(d->type_); p.bandwidth = d->bandwidth_; p.audio_sample_rate = d->audioRate_;
+                p.modem = d->modem_ ? d->modem_->csdrModemId() : -1; p.bandwidth = d->bandwidth_; p.audio_sample_rate = d->audioRate_;
                 p.frequency = d->getFrequency();
                 if (rebuild && inRange) { d->dirty_ = false; d->builtRate_ = chanRate; }
             }
@@ -216,12 +263,14 @@ private:
             run.push_back(d);
         }
         if (run.empty()) return;                                                     // :436 "if (!runDemods.empty())"
-        csdr_must(csdr_post_execute(post_, (const float *)in.data.data(), 0, 1, n, in.frequency), "csdr_post_execute");
-        csdr_must(csdr_bank_execute(bank_, post_), "csdr_bank_execute");
-        // the active demodulator's channel also feeds the demodulator spectrum (:289-291 single channel; :334, :383-387)
         auto iqActive = std::static_pointer_cast<DemodulatorThreadInputQueue>(getOutputQueue("IQActiveDemodVisualDataOutput"));
+        if (M == 1) {
+            if (iqActive) iqActive->try_push(singleOut_);                            // :289-292
+        } else csdr_must(csdr_post_execute(post_, (const float *)in.data.data(), 0, 1, n, in.frequency), "csdr_post_execute");
+        csdr_must(csdr_bank_execute(bank_, post_), "csdr_bank_execute");
+        // the active demodulator's channel also feeds the demodulator spectrum (:334, :383-387)
         DemodulatorInstancePtr cur = mgr_->getCurrentModem();
-        if (iqActive && cur && cur->isActive()) {
+        if (M > 1 && iqActive && cur && cur->isActive()) {
             const int ch = csdr_post_channel_at(post_, cur->getFrequency());
             if (ch >= 0) {
                 DemodulatorThreadIQDataPtr tap = visualBuffers_.getBuffer();
@@ -230,7 +279,7 @@ private:
                 int got = 0;
                 csdr_must(csdr_post_read_channel(post_, ch, (float *)tap->data.data(), cnt, &got), "csdr_post_read_channel");
                 tap->data.resize((size_t)got);
-                tap->frequency = M > 1 ? csdr_post_channel_center(post_, ch) : in.frequency;
+                tap->frequency = csdr_post_channel_center(post_, ch);
                 tap->sampleRate = csdr_post_channel_rate(post_);
                 iqActive->try_push(tap);                                              // never blocks (:386)
             }
@@ -275,6 +324,47 @@ private:
         }
         ati->peak = r.audio_peak;
         ati->is_squelch_active = squelched;
+        // the audio scope tap (:240-316): only when the scope queue is bound and empty
+        DemodulatorThreadOutputQueuePtr vis;
+        { std::lock_guard<std::mutex> g(d.mu_); vis = d.audioVisQueue_; }
+        if (!squelched && vis && vis->empty()) {
+            AudioThreadInputPtr ati_vis = std::make_shared<AudioThreadInput>();
+            ati_vis->sampleRate = d.getBandwidth(); ati_vis->inputRate = d.getBandwidth();       // inp->sampleRate
+            size_t num_vis = DEMOD_VIS_SIZE;
+            if (ati->channels == 2) {                                                             // :269-291
+                ati_vis->channels = 2;
+                int stereoSize = (int)ati->data.size();
+                if (stereoSize > DEMOD_VIS_SIZE * 2) stereoSize = DEMOD_VIS_SIZE * 2;
+                ati_vis->data.resize((size_t)stereoSize);
+                if (d.getDemodulatorType() == "I/Q") {
+                    // inputData = the resampled IQ of the block; the I/Q modem's audio is (imag, real) of it (ModemIQ.cpp:41-61)
+                    for (int i = 0; i < stereoSize / 2; i++) {
+                        ati_vis->data[i] = ati->data[2 * i + 1] * 0.75f;
+                        ati_vis->data[i + stereoSize / 2] = ati->data[2 * i] * 0.75f;
+                    }
+                } else {
+                    ati_vis->inputRate = d.getAudioSampleRate(); ati_vis->sampleRate = 36000;
+                    for (int i = 0; i < stereoSize / 2; i++) { ati_vis->data[i] = ati->data[i * 2]; ati_vis->data[i + stereoSize / 2] = ati->data[i * 2 + 1]; }
+                }
+                ati_vis->type = 1;
+            } else {                                                                              // :292-312
+                const size_t numAudioWritten = ati->data.size();
+                ati_vis->channels = 1;
+                std::vector<float> demodOut((size_t)DEMOD_VIS_SIZE);
+                int nd = 0;
+                const bool haveDemodOut = csdr_bank_fetch_demod_output(bank_, d.slot(), demodOut.data(), DEMOD_VIS_SIZE, &nd) == CSDR_OK && nd > 0;
+                if (numAudioWritten > (size_t)r.n_iq || !haveDemodOut) {
+                    ati_vis->inputRate = d.getAudioSampleRate();
+                    if (num_vis > numAudioWritten) num_vis = numAudioWritten;
+                    ati_vis->data.assign(ati->data.begin(), ati->data.begin() + (long)num_vis);
+                } else {
+                    if (num_vis > (size_t)nd) num_vis = (size_t)nd;
+                    ati_vis->data.assign(demodOut.begin(), demodOut.begin() + (long)num_vis);
+                }
+                ati_vis->type = 0;
+            }
+            (void)vis->try_push(ati_vis);                                                         // non-blocking (:314)
+        }
         if (!squelched && !d.muted_) (void)d.audioQueue_->try_push(ati);            // never blocks (:322)
     }
 
@@ -286,6 +376,7 @@ private:
     int numChannels_ = 0, maxBlock_ = 0, lastChanMode_ = 0;
     std::atomic<int> chanMode{(int)SDRPostPFBCH};                                // ctor :23
     ReBuffer<DemodulatorThreadIQData> visualBuffers_{"SDRPostThreadVisualDataBuffers"};
+    DemodulatorThreadIQDataPtr singleOut_;                                        // single-channel mode: the DC-corrected block
 };
 
 class SpectrumVisualProcessor : public VisualProcessor<DemodulatorThreadIQData, SpectrumVisualData> {

@@ -1,0 +1,149 @@
+// Modem.h -- the reference's modem plug-in surface (src/modules/modem/Modem.h:127-166, Modem.cpp:42-101) over the HIP library.
+//
+// In the reference a Modem object owns the demodulator arithmetic (demodulate()) and its kit; here that arithmetic runs on the
+// GPU inside csdr_bank_execute, so a Modem is the host-side DESCRIPTOR of one demodulator type: its name / type, its default
+// and admissible sample rates (checkSampleRate) and the CSDR_MODEM_* id the bank slot is configured with.  The registry
+// (addModemFactory / makeModem / getFactories / getModemDefaultSampleRate) and the settings calls keep the reference's
+// signatures, so DemodulatorInstance and the GUI's modem menus bind unchanged.  demodulate() is not a host path and says so.
+#pragma once
+#include <atomic>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/csdr_hip.h"
+#include "DataTypes.h"
+
+#define MIN_BANDWIDTH 500                      // Modem.h:13
+
+class ModemKit {                                // Modem.h:15-24
+public:
+    ModemKit() : sampleRate(0), audioSampleRate(0) {}
+    virtual ~ModemKit() = default;
+    long long sampleRate;
+    int audioSampleRate;
+};
+class ModemIQData {                             // Modem.h:26-37
+public:
+    std::vector<liquid_float_complex_t> data;
+    long long sampleRate = 0;
+    virtual ~ModemIQData() = default;
+};
+struct ModemArgInfo { std::string key, value, name, description, units; };   // the analog modems publish no settings but FM-stereo's de-emphasis
+typedef std::vector<ModemArgInfo> ModemArgInfoList;
+typedef std::map<std::string, std::string> ModemSettings;
+
+class ModemBase {};
+typedef ModemBase *(*ModemFactoryFn)();
+typedef std::map<std::string, ModemFactoryFn> ModemFactoryList;
+typedef std::map<std::string, int> DefaultRatesList;
+
+class Modem : public ModemBase {
+public:
+    static void addModemFactory(ModemFactoryFn factoryFunc, std::string modemName, int defaultRate) {     // Modem.cpp:42-45
+        factories()[modemName] = factoryFunc; defaultRates()[modemName] = defaultRate;
+    }
+    static ModemFactoryList getFactories() { registerBuiltins(); return factories(); }
+    static Modem *makeModem(std::string modemName) {                                                      // Modem.cpp:51-57
+        registerBuiltins();
+        auto it = factories().find(modemName);
+        return it == factories().end() ? nullptr : (Modem *)it->second();
+    }
+    static int getModemDefaultSampleRate(std::string modemName) {                                         // Modem.cpp:59-65
+        registerBuiltins();
+        auto it = defaultRates().find(modemName);
+        return it == defaultRates().end() ? 0 : it->second;
+    }
+
+    virtual std::string getType() = 0;
+    virtual std::string getName() = 0;
+    Modem() { useSignalOutput(false); }
+    virtual ~Modem() = default;
+
+    virtual ModemArgInfoList getSettings() { return ModemArgInfoList(); }
+    virtual int getDefaultSampleRate() { return 200000; }
+    virtual void writeSetting(std::string, std::string) {}
+    virtual void writeSettings(ModemSettings settings) { for (auto &kv : settings) writeSetting(kv.first, kv.second); }
+    virtual std::string readSetting(std::string) { return ""; }
+    virtual ModemSettings readSettings() {
+        ModemSettings rs;
+        for (auto &a : getSettings()) rs[a.key] = readSetting(a.key);
+        return rs;
+    }
+    virtual int checkSampleRate(long long sampleRate, int audioSampleRate) = 0;
+    virtual ModemKit *buildKit(long long sampleRate, int audioSampleRate) {          // the rates the bank slot is built with
+        ModemKit *kit = new ModemKit; kit->sampleRate = sampleRate; kit->audioSampleRate = audioSampleRate; return kit;
+    }
+    virtual void disposeKit(ModemKit *kit) { delete kit; }
+    // the arithmetic of Modem*::demodulate runs on the GPU (csdr_bank_execute); calling the host entry is a wiring error
+    virtual void demodulate(ModemKit *, ModemIQData *, AudioThreadInput *) {
+        throw std::logic_error("Modem::demodulate: demodulation runs on the device (csdr_bank_execute); there is no host path");
+    }
+    bool shouldRebuildKit() { return refreshKit.load(); }
+    void rebuildKit() { refreshKit.store(true); }
+    void clearRebuildKit() { refreshKit.store(false); }
+    bool useSignalOutput() { return _useSignalOutput.load(); }
+    void useSignalOutput(bool useOutput) { _useSignalOutput.store(useOutput); }
+
+    // the CSDR_MODEM_* id of this modem in include/csdr_hip.h
+    virtual int csdrModemId() = 0;
+
+    static void registerBuiltins();
+
+private:
+    static ModemFactoryList &factories() { static ModemFactoryList f; return f; }
+    static DefaultRatesList &defaultRates() { static DefaultRatesList r; return r; }
+    std::atomic_bool refreshKit{false}, _useSignalOutput{false};
+};
+
+// one descriptor class for the analog modems of the reference (src/modules/modem/analog/*.cpp)
+template <int ID>
+class ModemHip : public Modem {
+public:
+    static ModemBase *factory() { return new ModemHip<ID>(); }
+    ModemHip() {
+        // useSignalOutput(true): ModemAM.cpp:8, ModemUSB.cpp:12, ModemLSB.cpp:12, ModemDSB.cpp:7, ModemCW.cpp:24
+        useSignalOutput(ID == CSDR_MODEM_AM || ID == CSDR_MODEM_USB || ID == CSDR_MODEM_LSB || ID == CSDR_MODEM_DSB || ID == CSDR_MODEM_CW);
+    }
+    std::string getType() override { return "analog"; }
+    std::string getName() override {
+        switch (ID) {
+            case CSDR_MODEM_NBFM: return "NBFM"; case CSDR_MODEM_FM: return "FM"; case CSDR_MODEM_AM: return "AM";
+            case CSDR_MODEM_USB: return "USB"; case CSDR_MODEM_LSB: return "LSB"; case CSDR_MODEM_IQ: return "I/Q";
+            case CSDR_MODEM_CW: return "CW"; case CSDR_MODEM_DSB: return "DSB"; case CSDR_MODEM_FMS: return "FMS";
+        }
+        return "";
+    }
+    int getDefaultSampleRate() override {
+        switch (ID) {
+            case CSDR_MODEM_NBFM: return 12500; case CSDR_MODEM_FM: case CSDR_MODEM_FMS: return 200000; case CSDR_MODEM_AM: return 6000;
+            case CSDR_MODEM_USB: case CSDR_MODEM_LSB: case CSDR_MODEM_DSB: return 5400; case CSDR_MODEM_IQ: return 48000;
+            case CSDR_MODEM_CW: return MIN_BANDWIDTH;
+        }
+        return 200000;
+    }
+    int checkSampleRate(long long sampleRate, int audioSampleRate) override {
+        if (ID == CSDR_MODEM_IQ) return audioSampleRate;                                   // ModemIQ.cpp:31-33
+        if (ID == CSDR_MODEM_FMS) { if (sampleRate < 100000) return 100000; if (sampleRate < 1500) return 1500; return (int)sampleRate; }   // ModemFMStereo.cpp:41-49
+        if (sampleRate < MIN_BANDWIDTH) return MIN_BANDWIDTH;                              // ModemAnalog.cpp:14-19
+        if ((ID == CSDR_MODEM_USB || ID == CSDR_MODEM_LSB) && (sampleRate % 2)) return (int)sampleRate + 1;   // ModemUSB.cpp:29-37
+        return (int)sampleRate;
+    }
+    int csdrModemId() override { return ID; }
+};
+
+inline void Modem::registerBuiltins() {                                                   // CubicSDR.cpp:305-313
+    static bool done = false;
+    if (done) return;
+    done = true;
+    addModemFactory(ModemHip<CSDR_MODEM_FM>::factory, "FM", 200000);
+    addModemFactory(ModemHip<CSDR_MODEM_NBFM>::factory, "NBFM", 12500);
+    addModemFactory(ModemHip<CSDR_MODEM_FMS>::factory, "FMS", 200000);
+    addModemFactory(ModemHip<CSDR_MODEM_AM>::factory, "AM", 6000);
+    addModemFactory(ModemHip<CSDR_MODEM_CW>::factory, "CW", 500);
+    addModemFactory(ModemHip<CSDR_MODEM_LSB>::factory, "LSB", 5400);
+    addModemFactory(ModemHip<CSDR_MODEM_USB>::factory, "USB", 5400);
+    addModemFactory(ModemHip<CSDR_MODEM_DSB>::factory, "DSB", 5400);
+    addModemFactory(ModemHip<CSDR_MODEM_IQ>::factory, "I/Q", 48000);
+}

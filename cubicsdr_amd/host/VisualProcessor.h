@@ -63,3 +63,52 @@ protected:
     std::vector<VisualOutputQueueTypePtr> outputs;
     std::mutex busy_update;
 };
+
+// 1-to-n dispatchers without processing (reference VisualProcessor.h:164-224): they drain the input while at least one
+// output has room and stop at the first item that would find every output full (that item is consumed, as in the reference).
+#include <string>
+#include <typeinfo>
+
+#include "IOThread.h"
+
+// every output receives the SAME instance (pointer re-dispatch)
+template <typename OutputDataType>
+class VisualDataDistributor : public VisualProcessor<OutputDataType, OutputDataType> {
+    typedef VisualProcessor<OutputDataType, OutputDataType> Base;
+
+protected:
+    void process() override {
+        typename Base::OutputDataTypePtr inp;
+        typename Base::VisualInputQueueTypePtr in;
+        { std::lock_guard<std::mutex> g(Base::busy_update); in = Base::input; }
+        while (in && in->try_pop(inp)) {
+            if (!Base::isAnyOutputEmpty()) return;         // do not distribute when all outputs are full
+            if (inp) Base::distribute(inp);
+        }
+    }
+};
+
+// every item is deep-copied once into a pooled buffer, and that copy goes to all outputs
+template <typename OutputDataType>
+class VisualDataReDistributor : public VisualProcessor<OutputDataType, OutputDataType> {
+    typedef VisualProcessor<OutputDataType, OutputDataType> Base;
+
+public:
+    VisualDataReDistributor() : buffers(std::string(typeid(*this).name())) {}
+
+protected:
+    ReBuffer<OutputDataType> buffers;
+    void process() override {
+        typename Base::OutputDataTypePtr inp;
+        typename Base::VisualInputQueueTypePtr in;
+        { std::lock_guard<std::mutex> g(Base::busy_update); in = Base::input; }
+        while (in && in->try_pop(inp)) {
+            if (!Base::isAnyOutputEmpty()) return;
+            if (inp) {
+                typename Base::OutputDataTypePtr outp = buffers.getBuffer();
+                (*outp) = (*inp);
+                Base::distribute(outp);
+            }
+        }
+    }
+};

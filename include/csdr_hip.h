@@ -123,6 +123,8 @@ int  csdr_post_read_channel(csdr_post *post, int ch, float *host_out, int cap_sa
 #define CSDR_MODEM_IQ   5   /* ModemIQ.cpp:41-61    stereo pass-through of the resampled IQ (L = imag, R = real); the
                              * bandwidth is forced to the audio rate (checkSampleRate :31-33); 2 floats per IQ sample */
 
+#define CSDR_MODEM_FMS  8   /* ModemFMStereo.cpp:178-287  FM stereo: pilot band-pass + PLL, L-R down-mix, two audio resamplers, de-emphasis */
+
 typedef struct csdr_demod_params {
     int32_t modem;             /* CSDR_MODEM_* (DemodulatorInstance::setDemodulatorType) */
     int32_t bandwidth;         /* Hz, modem input rate after checkSampleRate() (setBandwidth) */
@@ -161,6 +163,10 @@ int  csdr_bank_execute(csdr_bank *bank, const csdr_post *post);
 int  csdr_bank_fetch_results(csdr_bank *bank, int slot, csdr_block_result *out, int cap_blocks, int *n_blocks);
 int  csdr_bank_fetch_audio(csdr_bank *bank, int slot, float *host_out, int cap_samples, int *n);
 int  csdr_bank_fetch_iq(csdr_bank *bank, int slot, float *host_out, int cap_samples, int *n);   /* resampled IQ */
+/* ModemAnalog::getDemodOutputData() of the LAST block of the last execute (ModemAnalog.cpp:95-97): the gain-scaled demodulator
+ * output in front of the audio resampler, at most DEMOD_VIS_SIZE = 2048 samples (DemodulatorThread.h:15) -- what the scope tap
+ * hands to the audio scope when the audio is decimated (DemodulatorThread.cpp:293-305).  *n = 0 for the I/Q and CW modems. */
+int  csdr_bank_fetch_demod_output(csdr_bank *bank, int slot, float *host_out, int cap_samples, int *n);
 /* device-side total of audio samples produced by the last execute over all slots (bench sanity) */
 int  csdr_bank_total_audio(csdr_bank *bank, int64_t *n);
 

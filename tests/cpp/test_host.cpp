@@ -10,6 +10,7 @@
 #include <thread>
 
 #include "../../cubicsdr_amd/host/HipPipeline.h"
+#include "../../cubicsdr_amd/host/ScopeVisualProcessor.h"
 
 static int g_fail = 0;
 #define CHECK(cond) do { if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); ++g_fail; } } while (0)
@@ -122,6 +123,71 @@ static void test_visual_processor() {
     CHECK(o1->empty() && in->empty());
 }
 
+// VisualDataDistributor shares the instance, VisualDataReDistributor hands out one pooled deep copy (VisualProcessor.h:164-224)
+static void test_distributors() {
+    VisualDataDistributor<Item> dist;
+    auto in = std::make_shared<VisualDataDistributor<Item>::VisualInputQueueType>();
+    auto o1 = std::make_shared<VisualDataDistributor<Item>::VisualOutputQueueType>(), o2 = std::make_shared<VisualDataDistributor<Item>::VisualOutputQueueType>();
+    in->set_max_num_items(8); o1->set_max_num_items(2); o2->set_max_num_items(4);
+    dist.setInput(in); dist.attachOutput(o1); dist.attachOutput(o2);
+    auto a = std::make_shared<Item>(Item{7});
+    in->push(a); in->push(std::make_shared<Item>(Item{8}));
+    dist.run();
+    ItemPtr x, y;
+    CHECK(o1->size() == 2 && o2->size() == 2);
+    CHECK(o1->try_pop(x) && o2->try_pop(y) && x == a && y == a);            // the same instance on both outputs
+    struct Re : VisualDataReDistributor<Item> {} re;
+    auto rin = std::make_shared<VisualDataReDistributor<Item>::VisualInputQueueType>();
+    auto r1 = std::make_shared<VisualDataReDistributor<Item>::VisualOutputQueueType>();
+    rin->set_max_num_items(4); r1->set_max_num_items(4);
+    re.setInput(rin); re.attachOutput(r1);
+    auto b = std::make_shared<Item>(Item{9});
+    rin->push(b);
+    re.run();
+    CHECK(r1->try_pop(x) && x != b && x->v == 9);                            // a copy, not the instance
+    // all outputs full: the popped item is dropped and the drain stops (as in the reference)
+    auto f1 = std::make_shared<VisualDataDistributor<Item>::VisualOutputQueueType>();
+    VisualDataDistributor<Item> d2;
+    d2.setInput(in); d2.attachOutput(f1);
+    f1->push(std::make_shared<Item>(Item{1}));                               // capacity 1: full
+    in->flush(); in->push(std::make_shared<Item>(Item{2})); in->push(std::make_shared<Item>(Item{3}));
+    d2.run();
+    CHECK(f1->size() == 1 && in->size() == 1);
+}
+
+// the Modem registry / descriptor surface (Modem.h:127-166) and the DemodulatorInstance calls that go through it
+static void test_modem_shim() {
+    CHECK(Modem::getFactories().size() == 9);
+    CHECK(Modem::getModemDefaultSampleRate("NBFM") == 12500 && Modem::getModemDefaultSampleRate("FM") == 200000 && Modem::getModemDefaultSampleRate("I/Q") == 48000);
+    CHECK(Modem::makeModem("nope") == nullptr && Modem::getModemDefaultSampleRate("nope") == 0);
+    std::unique_ptr<Modem> usb(Modem::makeModem("USB")), iq(Modem::makeModem("I/Q")), nb(Modem::makeModem("NBFM")), cw(Modem::makeModem("CW"));
+    CHECK(usb && usb->getName() == "USB" && usb->getType() == "analog" && usb->csdrModemId() == CSDR_MODEM_USB && usb->useSignalOutput());
+    CHECK(usb->checkSampleRate(5401, 48000) == 5402 && usb->checkSampleRate(100, 48000) == MIN_BANDWIDTH);      // ModemUSB.cpp:29-37
+    CHECK(iq->checkSampleRate(12345, 44100) == 44100 && !nb->useSignalOutput() && cw->getDefaultSampleRate() == MIN_BANDWIDTH);
+    ModemKit *kit = nb->buildKit(12500, 48000);
+    CHECK(kit->sampleRate == 12500 && kit->audioSampleRate == 48000);
+    nb->disposeKit(kit);
+    bool threw = false;
+    try { nb->demodulate(nullptr, nullptr, nullptr); } catch (const std::logic_error &) { threw = true; }
+    CHECK(threw);                                                             // no host demodulation path exists
+    DemodulatorMgr mgr(4);
+    auto d = mgr.newThread();
+    CHECK(d->getDemodulatorType() == "NBFM" && d->getBandwidth() == 12500 && d->isModemInitialized() && d->getModemType() == "analog");
+    d->setDemodulatorType("USB");
+    CHECK(d->getBandwidth() == 5400);
+    d->setBandwidth(5401);
+    CHECK(d->getBandwidth() == 5402);
+    d->setDemodulatorType("bogus");
+    CHECK(d->getDemodulatorType() == "USB");
+    d->setGain(100.f);
+    CHECK(d->getGain() == 40.0f);
+    CHECK(d->getIQInputDataPipe() != nullptr && d->getModemArgs().empty() && d->readModemSetting("x").empty());
+    d->run();
+    CHECK(!d->isTerminated() && d->isActive());
+    d->terminate();
+    CHECK(d->isTerminated() && !d->isActive());
+}
+
 // FFTDataDistributor scenarios (no GPU): the sample values carry their stream position so that the emitted lines can be
 // identified; output is compared with oracle/fft_distributor.py by tests/test_host_mirror.py.
 struct DistribHarness : FFTDataDistributor {
@@ -202,6 +268,17 @@ static int run_gpu() {
         demodSpec.setup(1024);                                                       // DEFAULT_DMOD_FFT_SIZE
         demodSpec.setView(true, center + 250000, 300000);
         int ndemodspec = 0;
+        // audio scope: DemodulatorInstance::setVisualOutputQueue -> the <= 2048-sample tap -> ScopeVisualProcessor (CubicSDR.cpp:383-394)
+        auto pipeAudioVisualData = std::make_shared<DemodulatorThreadOutputQueue>();
+        pipeAudioVisualData->set_max_num_items(1);
+        d->setVisualOutputQueue(pipeAudioVisualData);
+        ScopeVisualProcessor scope(ctx);
+        auto scopeOut = std::make_shared<ScopeRenderDataQueue>();
+        scopeOut->set_max_num_items(4);
+        scope.setInput(pipeAudioVisualData);
+        scope.attachOutput(scopeOut);
+        scope.setup(DEFAULT_SCOPE_FFT_SIZE);
+        int nscope = 0, nscopespec = 0;
         std::thread tp(&IOThread::threadMain, &post);
         // FM carrier at +250 kHz, 1 kHz tone, 2.5 kHz deviation; 12 blocks = 0.2 s
         const double dev = 2500.0, ft = 1000.0, amp = 0.5;
@@ -229,6 +306,25 @@ static int run_gpu() {
                 for (int x = 0; x < 1024; ++x) if (dv->spectrum_points[2 * x + 1] > bv) { bv = dv->spectrum_points[2 * x + 1]; best = x; }
                 if (b >= 3) CHECK(std::abs(best - 512) <= 4);
             }
+            scope.run();
+            ScopeRenderDataPtr rd;
+            while (scopeOut->try_pop(rd)) {
+                if (!rd->spectrum) {
+                    ++nscope;
+                    // NBFM: 800 audio samples > 208 IQ samples -> the tap carries the audio (:295-300), clipped to maxScopeSamples
+                    CHECK(rd->mode == ScopePanel::SCOPE_MODE_Y && rd->channels == 1 && rd->inputRate == 48000 && rd->waveform_points.size() >= 2 * 790);
+                } else {
+                    ++nscopespec;
+                    CHECK(rd->fft_size == DEFAULT_SCOPE_FFT_SIZE / 2);
+                    // sampleRate (12500, the bandwidth) != inputRate (48000): outSize = floor(512 * 12500 / 48000) = 133
+                    CHECK(rd->waveform_points.size() == 2 * 133);
+                    if (b >= 6) {   // the 1 kHz tone at 48 kHz sits in bin 1000 / 48000 * 1024 = 21 of the 1024-point transform
+                        int best = 0; float bv = -1e9f;
+                        for (int x = 1; x < 133; ++x) if (rd->waveform_points[2 * x + 1] > bv) { bv = rd->waveform_points[2 * x + 1]; best = x; }
+                        CHECK(std::abs(best - 21) <= 1);
+                    }
+                }
+            }
             spec.run();
             SpectrumVisualDataPtr sv;
             if (spectrumOut->try_pop(sv)) {
@@ -244,6 +340,8 @@ static int run_gpu() {
             }
         }
         CHECK(nspec >= 10);
+        std::printf("scope frames %d, scope spectra %d\n", nscope, nscopespec);
+        CHECK(nscope >= 9 && nscopespec >= 9);
         std::printf("demodulator-view spectra %d\n", ndemodspec);
         CHECK(ndemodspec >= 9);
         // audio: ~800 samples per block at 48 kHz; after the filters settle the output is a 1 kHz tone of amplitude
@@ -314,6 +412,35 @@ static int run_gpu() {
         tw.join();
         CHECK(wf.isTerminated());
     }
+    {
+        // single-channel mode (numChannels = 1, runSingleCH :248-299): the DC blocker runs on every block and the DC-corrected data is
+        // what the visual queues receive -- with or without an active demodulator
+        DemodulatorMgr mgr(2);
+        SDRPostThread post(ctx, &mgr);
+        auto in = std::make_shared<SDRThreadIQDataQueue>();
+        auto vis = std::make_shared<DemodulatorThreadInputQueue>();
+        in->set_max_num_items(10); vis->set_max_num_items(10);
+        post.setInputQueue("IQDataInput", in);
+        post.setOutputQueue("IQDataOutput", vis);
+        std::thread tp(&IOThread::threadMain, &post);
+        for (int b = 0; b < 3; ++b) {
+            auto blk = std::make_shared<SDRThreadIQData>();
+            blk->frequency = 50000000; blk->sampleRate = 480000; blk->numChannels = 1;
+            blk->data.assign(8000, liquid_float_complex_t{0.25f, -0.125f});                 // pure DC
+            const long long before = post.blocksProcessed.load();
+            CHECK(in->push(blk, 2000000));
+            while (post.blocksProcessed.load() == before) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        DemodulatorThreadIQDataPtr o;
+        int nv = 0;
+        float last = 1.f;
+        while (vis->try_pop(o)) { ++nv; CHECK(o->data.size() == 8000 && o->sampleRate == 480000); last = std::fabs(o->data.back().real); }
+        // y[n] = DC (1 - 0.0005)^n: after 24000 samples the offset has decayed to 0.25 e^-12 ~ 1.5e-6
+        std::printf("single-channel blocks on the visual queue %d, residual DC %.3g\n", nv, last);
+        CHECK(nv == 3 && last < 1e-4f);
+        post.terminate();
+        tp.join();
+    }
     csdr_ctx_destroy(ctx);
     return g_fail;
 }
@@ -326,6 +453,8 @@ int main(int argc, char **argv) {
     test_rebuffer();
     test_iothread();
     test_visual_processor();
+    test_distributors();
+    test_modem_shim();
     std::printf(g_fail ? "HOST TEST FAILED (%d)\n" : "host test ok\n", g_fail);
     return g_fail ? 1 : 0;
 }
