@@ -22,6 +22,7 @@
 
 #include "../../include/csdr_hip.h"
 #include "DataTypes.h"
+#include "DemodLevel.h"
 #include "IOThread.h"
 #include "Modem.h"
 #include "VisualProcessor.h"
@@ -287,8 +288,6 @@ private:
         for (auto &d : run) finishDemod(*d);
     }
 
-    static double linearToDb(double linear) { if (linear <= 1e-20) linear = 1e-20; return 20.0 * std::log10(linear); }   // DemodulatorThread.cpp:59-67
-
     // DemodulatorThread::run after demodulate(): :142-233, :318-328
     void finishDemod(DemodulatorInstance &d) {
         csdr_block_result r;
@@ -301,27 +300,10 @@ private:
         int got = 0;
         if (r.n_audio) csdr_must(csdr_bank_fetch_audio(bank_, d.slot(), ati->data.data(), r.n_audio, &got), "csdr_bank_fetch_audio");
         const double sampleTime = double(r.n_iq) / double(d.getBandwidth());
-        double currentSignalLevel = 0;
-        if (!ati->data.empty()) {
-            currentSignalLevel = linearToDb(r.level_accum / double(r.level_count));
-            float sf = d.signalFloor_, sc = d.signalCeil_, sl = d.squelchLevel_;
-            if (currentSignalLevel > sc) sc = (float)currentSignalLevel;
-            if (currentSignalLevel < sf) sf = (float)currentSignalLevel;
-            if (sl + 1.0f > sc) sc = sl + 1.0f;
-            if ((sf + 2.0f) > sc) sc = sf + 2.0f;
-            sc -= (sc - (currentSignalLevel + 2.0f)) * sampleTime * 0.05f;
-            sf += ((currentSignalLevel - 5.0f) - sf) * sampleTime * 0.15f;
-            d.signalFloor_ = sf; d.signalCeil_ = sc;
-        }
-        float lvl = d.signalLevel_;
-        if (currentSignalLevel > lvl) lvl = lvl + (currentSignalLevel - lvl) * 0.5;
-        else lvl = lvl + (currentSignalLevel - lvl) * 0.05 * sampleTime * 30.0;
-        d.signalLevel_ = lvl;
-        const bool squelched = d.squelchEnabled_ && (lvl < d.squelchLevel_);
-        if (d.squelchEnabled_) {
-            if (!squelched && !d.squelchBreak_) d.squelchBreak_ = true;
-            else if (squelched && d.squelchBreak_) d.squelchBreak_ = false;
-        }
+        DemodLevelState st;
+        st.signalLevel = d.signalLevel_; st.signalFloor = d.signalFloor_; st.signalCeil = d.signalCeil_; st.squelchBreak = d.squelchBreak_;
+        const bool squelched = demodLevelStep(st, !ati->data.empty(), r.level_accum, r.level_count, sampleTime, d.squelchEnabled_, d.squelchLevel_);
+        d.signalLevel_ = st.signalLevel; d.signalFloor_ = st.signalFloor; d.signalCeil_ = st.signalCeil; d.squelchBreak_ = st.squelchBreak;
         ati->peak = r.audio_peak;
         ati->is_squelch_active = squelched;
         // the audio scope tap (:240-316): only when the scope queue is bound and empty

@@ -227,6 +227,51 @@ class RefDemod:
         return dict(audio=audio, level_accum=accum, level_count=cnt, peak=peak, demod=demod_unscaled)
 
 
+class RefLevelSquelch:
+    """DemodulatorThread::run's level / floor / ceil / squelch bookkeeping (src/demod/DemodulatorThread.cpp:142-220), one step per
+    block, in the reference's types: float32 trackers, double currentSignalLevel (TEST INFRASTRUCTURE: pins cubicsdr_amd/host/DemodLevel.h)."""
+
+    def __init__(self):
+        f32 = np.float32
+        self.level, self.floor, self.ceil = f32(-100.0), f32(-30.0), f32(30.0)     # ctor :20-27
+        self.squelch_break = False
+
+    @staticmethod
+    def linear_to_db(x):                                                    # :59-67
+        return 20.0 * math.log10(max(x, 1e-20))
+
+    def step(self, have_level, accum, count, sample_time, squelch_enabled, squelch_level):
+        f32 = np.float32
+        cur = 0.0
+        if have_level:
+            cur = self.linear_to_db(accum / float(count))                   # :152 / :162
+            sf, sc, sl = f32(self.floor), f32(self.ceil), f32(squelch_level)
+            if cur > float(sc):
+                sc = f32(cur)
+            if cur < float(sf):
+                sf = f32(cur)
+            if float(f32(sl + f32(1.0))) > float(sc):
+                sc = f32(sl + f32(1.0))
+            if float(f32(sf + f32(2.0))) > float(sc):
+                sc = f32(sf + f32(2.0))
+            sc = f32(float(sc) - (float(sc) - (cur + 2.0)) * sample_time * float(f32(0.05)))       # double arithmetic, stored as float
+            sf = f32(float(sf) + ((cur - 5.0) - float(sf)) * sample_time * float(f32(0.15)))
+            self.floor, self.ceil = sf, sc
+        lvl = float(self.level)
+        if cur > lvl:
+            lvl = lvl + (cur - lvl) * 0.5
+        else:
+            lvl = lvl + (cur - lvl) * 0.05 * sample_time * 30.0
+        self.level = f32(lvl)
+        squelched = bool(squelch_enabled) and float(self.level) < float(f32(squelch_level))
+        if squelch_enabled:
+            if not squelched and not self.squelch_break:
+                self.squelch_break = True
+            elif squelched and self.squelch_break:
+                self.squelch_break = False
+        return squelched
+
+
 class RefSpectrum:
     """SpectrumVisualProcessor::process, full-span view (src/process/SpectrumVisualProcessor.cpp:387-576, 626-627)."""
 

@@ -234,6 +234,27 @@ static int run_distrib() {
     return 0;
 }
 
+// the level / squelch state machine on a deterministic sequence of block sums (no GPU): printed for the oracle comparison
+static int run_level() {
+    DemodLevelState st;
+    unsigned lcg = 12345u;
+    auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (double)(lcg >> 8) / 16777216.0; };
+    for (int b = 0; b < 400; ++b) {
+        // quiet / loud stretches, empty blocks, the squelch switched on in the middle third with a moving threshold
+        const bool have = (b % 17) != 5;
+        const int count = 208 + (b % 3);
+        const double amp = (b / 50) % 2 ? 0.2 + 0.05 * rnd() : 0.002 + 0.001 * rnd();
+        const double accum = amp * count;
+        const double sampleTime = (double)count / 12500.0;
+        const bool sq = b >= 130 && b < 330;
+        const float sl = b < 230 ? -35.0f : -12.0f;
+        const bool squelched = demodLevelStep(st, have, accum, count, sampleTime, sq, sl);
+        std::printf("%d %d %.17g %d %.17g %d %.9g %d %.9g %.9g %.9g %d\n", b, have ? 1 : 0, accum, count, sampleTime, sq ? 1 : 0, (double)sl,
+                    squelched ? 1 : 0, (double)st.signalLevel, (double)st.signalFloor, (double)st.signalCeil, st.squelchBreak ? 1 : 0);
+    }
+    return 0;
+}
+
 static int run_gpu() {
     csdr_ctx *ctx = nullptr;
     csdr_must(csdr_ctx_create(0, nullptr, &ctx), "csdr_ctx_create");
@@ -247,6 +268,10 @@ static int run_gpu() {
         auto spectrumOut = std::make_shared<SpectrumVisualDataQueue>();
         post.setInputQueue("IQDataInput", pipeSDRIQData);
         post.setOutputQueue("IQVisualDataOutput", pipeIQVisualData);
+        // pushVisualData (SDRPostThread.cpp:233-245) feeds the spectrum queue only when the waterfall queue is bound too
+        auto pipeWaterfallIQVisualData = std::make_shared<DemodulatorThreadInputQueue>();      // CubicSDR.cpp:346-348
+        pipeWaterfallIQVisualData->set_max_num_items(1000);
+        post.setOutputQueue("IQDataOutput", pipeWaterfallIQVisualData);
         spec.setInput(pipeIQVisualData);
         spec.attachOutput(spectrumOut);
         spec.setup(2048);
@@ -447,6 +472,7 @@ static int run_gpu() {
 
 int main(int argc, char **argv) {
     if (argc > 1 && !std::strcmp(argv[1], "distrib")) return run_distrib();
+    if (argc > 1 && !std::strcmp(argv[1], "level")) return run_level();
     const bool gpu = argc > 1 && !std::strcmp(argv[1], "gpu");
     if (gpu) { int f = run_gpu(); std::printf(f ? "GPU HOST TEST FAILED (%d)\n" : "gpu host test ok\n", f); return f ? 1 : 0; }
     test_queue();

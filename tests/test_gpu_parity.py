@@ -7,7 +7,7 @@ half-band buffer fill) bit-exact; float32 samples within 1e-5 of the reference's
 import numpy as np
 import pytest
 
-from tests.util import demod_frequencies, rel_err, synth_iq
+from tests.util import demod_frequencies, rel_err, synth_iq, synth_iq_fast
 
 pytestmark = pytest.mark.gpu
 
@@ -178,31 +178,19 @@ def test_dc_blocker_large_offset_state_noise(ctx):
 
 
 # ----------------------------------------------------------------------------------------------- demodulators
-def _run_demods(ctx, fs, M, block, kinds, n_blocks, batch, bw=None, seed=3, oversampled=False, modem_on_gpu_iq=()):
-    """modem_on_gpu_iq: slots whose reference MODEM is fed the GPU's resampled IQ of each block (the reference front-end still
-    runs and its IQ is compared): isolates a modem whose arithmetic amplifies the 1e-6 front-end differences."""
+def _gpu_demods(ctx, x, fs, M, block, demods, bws, n_blocks, batch, oversampled=False):
+    """the HIP path over n_blocks blocks of x in batches of `batch`: per demodulator the list of per-block results"""
     from cubicsdr_amd.engine import DemodBank, SDRPost
-    from oracle.cubicsdr_chain import RefDemod, RefSDRPost
     center = 100000000
-    freqs = demod_frequencies(center, fs, len(kinds))
-    default_bw = {"NBFM": 12500, "FM": 200000, "AM": 6000, "USB": 5400, "LSB": 5400, "I/Q": 48000, "CW": 500, "DSB": 5400}
-    bws = [bw[k] if bw else default_bw[k] for k in kinds] if not isinstance(bw, list) else bw
-    demods = list(zip(kinds, freqs))
-    x = synth_iq(n_blocks * block, fs, center, demods, seed=seed)
-    be = _backend()
-    ref_post = RefSDRPost(be, fs, M, oversampled=oversampled)
     post = SDRPost(ctx, fs, M, block, max_blocks=batch, oversampled=oversampled)
-    bank = DemodBank(ctx, len(kinds), max_blocks=batch)
-    refs = []
+    bank = DemodBank(ctx, len(demods), max_blocks=batch)
     for i, (k, f) in enumerate(demods):
         bank.configure(i, post, k, bws[i], f)
-        refs.append(RefDemod(be, k, bws[i], f, ref_post.chan_bw * (2 if oversampled and M > 1 else 1)))
-    got = [[] for _ in kinds]
-    want = [[] for _ in kinds]
+    got = [[] for _ in demods]
     for b0 in range(0, n_blocks, batch):
         post.execute(x[b0 * block:(b0 + batch) * block], batch, block, center)
         bank.execute(post)
-        for i in range(len(kinds)):
+        for i in range(len(demods)):
             res = bank.results(i)
             audio = bank.audio(i)
             iq = bank.iq(i)
@@ -210,32 +198,91 @@ def _run_demods(ctx, fs, M, block, kinds, n_blocks, batch, bw=None, seed=3, over
             for r in res:
                 got[i].append(dict(n_iq=r.n_iq, n_audio=r.n_audio, audio=audio[r.audio_offset:r.audio_offset + r.n_audio],
                                    iq=iq[o:o + r.n_iq], level_accum=r.level_accum, level_count=r.level_count, peak=r.audio_peak,
-                                   skipped=r.skipped))
+                                   skipped=r.skipped, nco_theta=r.nco_theta, resamp_phase=r.resamp_phase, buffer_index=r.buffer_index))
                 o += r.n_iq
-        for k in range(batch):
-            xb = x[(b0 + k) * block:(b0 + k + 1) * block]
-            ref_post.run_block(xb, center)
-            chan_cache = {}       # one buffer per channel per block, shared by its demods (SDRPostThread.cpp:341-396)
-            for i, rd in enumerate(refs):
-                ch = ref_post.channel_at(rd.frequency)
-                if ch not in chan_cache:
-                    chan_cache[ch] = ref_post.channel_data(ch)
-                data, fc, rate = chan_cache[ch]
-                riq = rd.pre(data, fc, rate)
-                if riq is None:
-                    want[i].append(None)
-                    continue
-                gpu_iq = got[i][b0 + k]["iq"] if i in modem_on_gpu_iq else None
-                out = rd.demodulate(gpu_iq if gpu_iq is not None and gpu_iq.size == riq.size else riq)
-                if out is None:       # no samples in this block: demodulate() returns at once, no audio item, no state change
-                    out = dict(audio=np.zeros(0, np.float32), level_accum=0.0, level_count=0, peak=0.0)
-                out["iq"] = riq
-                want[i].append(out)
     post.close(); bank.close()
+    return got
+
+
+def _ref_demods(x, fs, M, block, demods, bws, n_blocks, oversampled=False, modem_iq=None):
+    """the reference path block by block.  modem_iq: {slot: list of per-block IQ arrays} fed to that slot's MODEM instead of the
+    reference front-end's own IQ (which is still produced and compared)."""
+    from oracle.cubicsdr_chain import RefDemod, RefSDRPost
+    center = 100000000
+    be = _backend()
+    ref_post = RefSDRPost(be, fs, M, oversampled=oversampled)
+    refs = [RefDemod(be, k, bws[i], f, ref_post.chan_bw * (2 if oversampled and M > 1 else 1)) for i, (k, f) in enumerate(demods)]
+    want = [[] for _ in demods]
+    _ref_demods.last_channels = [None] * len(demods)          # the channel each demodulator was routed to (for the callers that ask)
+    for b in range(n_blocks):
+        ref_post.run_block(x[b * block:(b + 1) * block], center)
+        chan_cache = {}       # one buffer per channel per block, shared by its demods (SDRPostThread.cpp:341-396)
+        for i, rd in enumerate(refs):
+            ch = ref_post.channel_at(rd.frequency)
+            _ref_demods.last_channels[i] = ch
+            if ch not in chan_cache:
+                chan_cache[ch] = ref_post.channel_data(ch)
+            data, fc, rate = chan_cache[ch]
+            riq = rd.pre(data, fc, rate)
+            if riq is None:
+                want[i].append(None)
+                continue
+            gpu_iq = modem_iq[i][b] if modem_iq and i in modem_iq else None
+            out = rd.demodulate(gpu_iq if gpu_iq is not None and gpu_iq.size == riq.size else riq)
+            if out is None:       # no samples in this block: demodulate() returns at once, no audio item, no state change
+                out = dict(audio=np.zeros(0, np.float32), level_accum=0.0, level_count=0, peak=0.0)
+            out["iq"] = riq
+            want[i].append(out)
+    return want
+
+
+_DEFAULT_BW = {"NBFM": 12500, "FM": 200000, "AM": 6000, "USB": 5400, "LSB": 5400, "I/Q": 48000, "CW": 500, "DSB": 5400}
+
+
+def _run_demods(ctx, fs, M, block, kinds, n_blocks, batch, bw=None, seed=3, oversampled=False, modem_on_gpu_iq=()):
+    """modem_on_gpu_iq: slots whose reference MODEM is fed the GPU's resampled IQ of each block (the reference front-end still
+    runs and its IQ is compared): isolates a modem whose arithmetic amplifies the 1e-6 front-end differences."""
+    center = 100000000
+    freqs = demod_frequencies(center, fs, len(kinds))
+    bws = [bw[k] if bw else _DEFAULT_BW[k] for k in kinds] if not isinstance(bw, list) else bw
+    demods = list(zip(kinds, freqs))
+    x = synth_iq(n_blocks * block, fs, center, demods, seed=seed)
+    got = _gpu_demods(ctx, x, fs, M, block, demods, bws, n_blocks, batch, oversampled)
+    want = _ref_demods(x, fs, M, block, demods, bws, n_blocks, oversampled,
+                       modem_iq={i: [g["iq"] for g in got[i]] for i in modem_on_gpu_iq})
     return got, want
 
 
-def _compare(got, want, label):
+def _full_config(ctx, fs, M, block, kinds, n_blocks, seed):
+    """every demodulator of a BASELINE configuration over n_blocks consecutive blocks: one oracle run, the HIP path once as ONE
+    batch and once block at a time; both must match the oracle (counts and phase words exact, samples within TOL) and each
+    other bit for bit.  Returns the worst errors."""
+    center = 100000000
+    freqs = demod_frequencies(center, fs, len(kinds))
+    demods = list(zip(kinds, freqs))
+    bws = [_DEFAULT_BW[k] for k in kinds]
+    x = synth_iq_fast(n_blocks * block, fs, center, demods, seed=seed)
+    want = _ref_demods(x, fs, M, block, demods, bws, n_blocks)
+    # Demodulators routed to channel 0 sit behind the reference's float32 DC blocker (SDRPostThread.cpp:375), whose state
+    # v ~ DC M / 0.0005 carries ~ulp(v) of rounding noise per sample that no evaluation order reproduces (the GPU evaluates the
+    # recurrence to fp64 accuracy: test_dc_blocker_large_offset_state_noise).  They get that noise floor as an absolute allowance.
+    dc_floor = float(4 * np.spacing(np.float32(0.01 * M / 0.0005))) if M > 1 else 0.0
+    floors = {i: dc_floor for i, ch in enumerate(_ref_demods.last_channels) if ch == 0 and M >= 100}
+    batched = _gpu_demods(ctx, x, fs, M, block, demods, bws, n_blocks, n_blocks)
+    worst = _compare(batched, want, "batched", floors)
+    single = _gpu_demods(ctx, x, fs, M, block, demods, bws, n_blocks, 1)
+    _compare(single, want, "blockwise", floors)
+    for i in range(len(kinds)):
+        for a, b in zip(batched[i], single[i]):
+            assert (a["n_iq"], a["n_audio"], a["nco_theta"], a["resamp_phase"], a["buffer_index"]) == (b["n_iq"], b["n_audio"], b["nco_theta"], b["resamp_phase"], b["buffer_index"]), i
+            assert np.array_equal(a["audio"], b["audio"]) and np.array_equal(a["iq"], b["iq"]), i
+    return dict(iq=max(w[0] for w in worst.values()), audio=max(w[1] for w in worst.values()),
+                level=max(w[2] for w in worst.values()), peak=max(w[3] for w in worst.values()))
+
+
+def _compare(got, want, label, floors=None):
+    """floors: {slot: absolute noise floor of that slot's channel samples} (channel 0 behind a wide channelizer, see _full_config):
+    the slot's IQ may differ by that much on top of TOL, its audio / level / peak by the phase noise that implies."""
     worst = {}
     for i in range(len(got)):
         assert len(got[i]) == len(want[i])
@@ -255,9 +302,15 @@ def _compare(got, want, label):
                   for g, w in zip(got[i], want[i]) if w["audio"].size] + [0.0])
         pk = max([abs(g["peak"] - w["peak"]) / max(abs(w["peak"]), 0.05 * gpk, 1e-30) for g, w in zip(got[i], want[i]) if w["audio"].size] + [0.0])
         worst[i] = (e_iq, e_au, lv, pk)
-        assert e_iq < TOL, (label, i, "iq", e_iq)
-        assert e_au < TOL, (label, i, "audio", e_au)
-        assert lv < TOL and pk < TOL, (label, i, lv, pk)
+        tol_iq = tol_au = TOL
+        if floors and i in floors and wi.size:
+            tol_iq = TOL + floors[i] / float(np.max(np.abs(wi)))
+            tol_au = TOL + 2.0 * floors[i] / float(np.median(np.abs(wi)))      # two noisy samples per discriminator / envelope output
+            worst[i] = (0.0, 0.0, 0.0, 0.0)                                  # reported separately: not part of the configuration's worst case
+            print("slot %d on channel 0: iq %.3g audio %.3g (allowances %.3g / %.3g)" % (i, e_iq, e_au, tol_iq, tol_au))
+        assert e_iq < tol_iq, (label, i, "iq", e_iq)
+        assert e_au < tol_au, (label, i, "audio", e_au)
+        assert lv < tol_au and pk < tol_au, (label, i, lv, pk)
     return worst
 
 
@@ -286,9 +339,9 @@ def test_batched_equals_reference(ctx):
 
 
 def test_c2_shape_64_nbfm(ctx):
-    """BASELINE config 2 shape (64x NBFM, 10 MS/s, M = 20) on 2 blocks; oracle checks 8 of the demods."""
-    got, want = _run_demods(ctx, 10000000, 20, 166680, ["NBFM"] * 8, 2, 2)
-    print(_compare(got, want, "c2"))
+    """BASELINE config 2 (64x NBFM, 10 MS/s, M = 20, block 166 680): ALL 64 demodulators over 3 consecutive blocks against the
+    oracle, as one 3-block batch and block at a time."""
+    print("c2 worst errors", _full_config(ctx, 10000000, 20, 166680, ["NBFM"] * 64, 3, seed=23))
 
 
 def test_iq_passthrough_modem(ctx):
@@ -603,10 +656,14 @@ def test_pipelined_batches_equal_synchronised_batches(ctx):
 
 # ----------------------------------------------------------------------------------------------- BASELINE config shapes
 def test_c3_shape_mixed_m122(ctx):
-    """BASELINE config 3 shape: 61.44 MS/s, M = 122 (channel rate 503606 by integer division), block 1 024 068, mixed
-    NBFM / AM / USB demodulators (24 of the 256 are checked against the oracle), 2 blocks in one batch."""
-    got, want = _run_demods(ctx, 61440000, 122, 1024068, ["NBFM", "AM", "USB"] * 8, 2, 2, seed=41)
-    print(_compare(got, want, "c3"))
+    """BASELINE config 3 (the headline): 61.44 MS/s, M = 122 (channel rate 503606 by integer division), block 1 024 068, ALL 256
+    mixed NBFM / AM / USB demodulators over 3 consecutive blocks against the oracle, as one batch and block at a time."""
+    print("c3 worst errors", _full_config(ctx, 61440000, 122, 1024068, ["NBFM", "AM", "USB"] * 85 + ["NBFM"], 3, seed=41))
+
+
+def test_c3n_shape_all_nbfm_m122(ctx):
+    """the north-star wording of config 3: 256 NBFM demodulators behind the M = 122 channelizer, 3 blocks, every demodulator."""
+    print("c3n worst errors", _full_config(ctx, 61440000, 122, 1024068, ["NBFM"] * 256, 3, seed=43))
 
 
 def test_c4_shape_m1024_channelizer_and_nbfm(ctx):
@@ -632,8 +689,8 @@ def test_c4_shape_m1024_channelizer_and_nbfm(ctx):
         else:
             assert rel_err(got, want) < TOL, ch
     post.close()
-    got, want = _run_demods(ctx, fs, M, block, ["NBFM"] * 4, 2, 1, seed=52)
-    print(_compare(got, want, "c4"))
+    # one NBFM demodulator on each of 32 different channels (evenly spread over the 1024), 3 blocks, batched and block at a time
+    print("c4 worst errors", _full_config(ctx, fs, M, block, ["NBFM"] * 32, 3, seed=52))
 
 
 def test_c5_shape_m200_and_1m_point_spectrum(ctx):
@@ -665,6 +722,48 @@ def test_c5_shape_m200_and_1m_point_spectrum(ctx):
     assert rel_err(pts, wp) < TOL
     assert abs(ce - wce) <= TOL * abs(wce) and abs(fl - wfl) <= TOL * abs(wce)
     sp.close()
+    # the demodulators of this configuration too: 24 mixed ones behind the M = 200 channelizer (500 kS/s channels), 3 blocks
+    print("c5 worst errors", _full_config(ctx, fs, M, block, ["NBFM", "AM", "USB"] * 8, 3, seed=62))
+
+
+def test_active_channel_subset_matches_all_channels(ctx):
+    """csdr_post_set_active_channels (the channels with consumers, SDRPostThread.cpp:336-339; what a demodulator-sharded rank
+    produces): the rows of the active channels equal the all-channels run bit for bit, the other rows are not written, and a
+    demodulator routed to an inactive channel is refused."""
+    from cubicsdr_amd.engine import DemodBank, SDRPost
+    from cubicsdr_amd.hip import CsdrError
+    for fs, M, block in ((10000000, 20, 166680), (61440000, 122, 122 * 300)):
+        center = 100000000
+        x = synth_iq(2 * block, fs, center, [("NBFM", center + 1234567)], seed=81)
+        full = SDRPost(ctx, fs, M, block, max_blocks=1)
+        part = SDRPost(ctx, fs, M, block, max_blocks=1)
+        active = sorted({0, 3, M // 2, M - 1, 7 % M})
+        part.set_active_channels(active)
+        sentinel = None
+        for b in range(2):
+            full.execute(x[b * block:(b + 1) * block], 1, block, center)
+            part.execute(x[b * block:(b + 1) * block], 1, block, center)
+            for ch in range(M):
+                if ch in active:
+                    assert np.array_equal(part.read_channel(ch), full.read_channel(ch)), (M, b, ch)
+            rows = {ch: part.read_channel(ch) for ch in range(M) if ch not in active}
+            if sentinel is None:
+                sentinel = rows                                   # whatever the buffer held: it must not change any more
+            else:
+                for ch, r in rows.items():
+                    assert np.array_equal(r, sentinel[ch], equal_nan=True), (M, ch)
+        # a demodulator on an inactive channel: refused, and nothing else disturbed
+        bank = DemodBank(ctx, 2, max_blocks=1)
+        f_inactive = part.channel_center(1) + 1000
+        bank.configure(0, part, "NBFM", 12500, f_inactive)
+        with pytest.raises(CsdrError):
+            bank.execute(part)
+        bank.set_frequency(0, part.channel_center(3) + 1000)
+        bank.execute(part)
+        assert bank.results(0)[0].n_iq > 0
+        part.set_active_channels(None)                             # back to every channel
+        part.execute(x[:block], 1, block, center)
+        bank.close(); full.close(); part.close()
 
 
 def test_c2_full_size_batching_invariance(ctx):

@@ -75,6 +75,34 @@ def test_fft_data_distributor_line_pacing_matches_oracle():
     assert got["E"][0][1] == "1"          # default queue capacity 1: the other lines of that run were dropped
 
 
+def test_level_squelch_state_machine_matches_oracle():
+    """DemodulatorThread's level / floor / ceil / squelch bookkeeping (DemodulatorThread.cpp:142-220): the C++ mirror
+    (cubicsdr_amd/host/DemodLevel.h) against the statement-by-statement restatement in oracle/cubicsdr_chain.py over 400 blocks
+    with quiet and loud stretches, empty blocks and the squelch switched on and moved: squelch decisions and the squelch-break
+    flag exact, the float trackers to one float32 ulp."""
+    import numpy as np
+    from oracle.cubicsdr_chain import RefLevelSquelch
+    _build()
+    r = subprocess.run([EXE, "level"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = RefLevelSquelch()
+    n = 0
+    flips = 0
+    last = None
+    for ln in r.stdout.splitlines():
+        f = ln.split()
+        have, accum, count, st, sq, sl = int(f[1]), float(f[2]), int(f[3]), float(f[4]), int(f[5]), float(f[6])
+        squelched = ref.step(bool(have), accum, count, st, bool(sq), sl)
+        assert squelched == bool(int(f[7])), ln
+        assert ref.squelch_break == bool(int(f[11])), ln
+        for got, want in ((float(f[8]), ref.level), (float(f[9]), ref.floor), (float(f[10]), ref.ceil)):
+            assert abs(got - float(want)) <= float(np.spacing(np.float32(abs(float(want))))), (ln, got, want)
+        flips += last is not None and squelched != last
+        last = squelched
+        n += 1
+    assert n == 400 and flips >= 2            # the sequence really opens and closes the squelch
+
+
 @pytest.mark.gpu
 def test_threaded_pipeline_on_gpu():
     """SDRThreadIQData blocks -> SDRPostThread (HIP) -> NBFM audio queue + spectrum queue, through real threads/queues"""

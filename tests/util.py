@@ -47,3 +47,45 @@ def synth_iq(n, fs, center, demods, seed=0xC0B1C5D2, t0=0, noise=0.05, dc=(0.01,
             x += amp * np.exp(2j * np.pi * (df + 3000.0) * t)
     x += dc[0] + 1j * dc[1]
     return x.astype(np.complex64)
+
+
+def synth_iq_fast(n, fs, center, demods, seed=0xC0B1C5D2, noise=0.05, dc=(0.01, 0.01)):
+    """the same signal model as synth_iq for the NBFM / AM / USB carriers of the BASELINE configurations, formed on the GPU when
+    one is present (hundreds of carriers over millions of samples), numpy otherwise; returns a host complex64 array"""
+    try:
+        import torch
+        use = torch.cuda.is_available()
+    except Exception:
+        use = False
+    if not use:
+        return synth_iq(n, fs, center, demods, seed=seed, noise=noise, dc=dc)
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed))
+    x = torch.randn(n, 2, generator=g, device=dev, dtype=torch.float32) * noise
+    amp = 0.5 / math.sqrt(max(len(demods), 1))
+    SL = 1 << 21
+    for s0 in range(0, n, SL):
+        s1 = min(n, s0 + SL)
+        t = torch.arange(s0, s1, device=dev, dtype=torch.float64) / fs
+        tone = torch.sin(2 * math.pi * 1000.0 * t)
+        ar = torch.zeros(s1 - s0, device=dev, dtype=torch.float64)
+        ai = torch.zeros(s1 - s0, device=dev, dtype=torch.float64)
+        for kind, f in demods:
+            df = float(f - center)
+            if kind in ("NBFM", "FM"):
+                ph = (2 * math.pi * df) * t + ((2500.0 if kind == "NBFM" else 50000.0) / 1000.0) * tone
+                ar += amp * torch.cos(ph); ai += amp * torch.sin(ph)
+            elif kind == "AM":
+                ph = (2 * math.pi * df) * t
+                env = amp * (1 + 0.8 * tone)
+                ar += env * torch.cos(ph); ai += env * torch.sin(ph)
+            elif kind == "USB":
+                ph = (2 * math.pi * (df + 1000.0)) * t
+                ar += amp * torch.cos(ph); ai += amp * torch.sin(ph)
+            else:
+                raise ValueError(kind)
+        x[s0:s1, 0] += (ar + dc[0]).float()
+        x[s0:s1, 1] += (ai + dc[1]).float()
+    return x.cpu().numpy().view(np.complex64).reshape(-1).copy()
