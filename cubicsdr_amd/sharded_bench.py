@@ -1,0 +1,74 @@
+"""bench.py --config C4: BASELINE config 4 -- ONE 100 MS/s IQ stream, firpfbch M = 1024, one NBFM demodulator per channel, the
+demodulators sharded over the ranks (cubicsdr_amd.parallel.ShardedStream): rank 0 owns the HBM-resident ring, every batch is
+broadcast (RCCL over xGMI), every rank channelizes for its own channels and runs its own slots.  scaling = "strong": the value is
+the one stream's MS/s (total work fixed as N grows).  The time-slab scatter + all-to-all variant (SURVEY.md 8e option 2) is not
+built; with the broadcast variant the redundant polyphase front bounds the speed-up (multi-GPU)."""
+import json
+import os
+import time
+
+FS, M, BLOCK, CENTER = 100_000_000, 1024, 1_667_072, 400_000_000        # BASELINE config 4 names M = 1024; block = ceil(fs / 60 / M) M (SoapySDRThread.cpp:668-674)
+NBFM_BW, AUDIO = 12_500, 48_000
+
+
+def main(args):
+    import torch
+    from cubicsdr_amd import build as cbuild
+    from cubicsdr_amd.parallel import ShardedStream, channel_centers
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank == 0:
+        cbuild.build(verbose=False)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.barrier()
+    NB = args.blocks or 16
+    NBATCH = args.batches or 24
+    cc = channel_centers(CENTER, FS, M)
+    demods = [("NBFM", NBFM_BW, cc[ch] + 3700) for ch in range(M)]          # one per channel, 3.7 kHz off the channel centre (forces the NCO)
+    g = torch.Generator(device=device); g.manual_seed(0xC0B1C5D2)
+    ring = torch.randn(NB * BLOCK, 2, generator=g, device=device, dtype=torch.float32) * 0.05 + 0.01
+    st = ShardedStream(local_rank, rank, world, FS, M, BLOCK, demods, CENTER, NB)
+
+    def step():
+        for _ in range(NBATCH):
+            st.step(ring, NB, src=0)
+
+    for _ in range(args.warmup):
+        step()
+    st.synchronize(); torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    st.synchronize(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        dist.barrier()
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    samples = args.steps * NBATCH * NB * BLOCK                                   # ONE stream: not multiplied by the world size
+    value = samples / elapsed / 1e6
+    bytes_per_sample = 8 + 8 + 8.0 * 1.0 + 4.0 * M * AUDIO / FS                  # SURVEY.md 8d, C4 (no FFT): 26.0
+    out = {"metric": "IQ MS/s sustained @ N demods + FFT size", "value": value, "unit": "MS/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "C4: 1024-channel firpfbch + 1024x NBFM (one per channel), 100 MS/s IQ, demodulators sharded over the ranks, IQ batches broadcast from rank 0 (RCCL)",
+                      "batches_per_step": NBATCH, "blocks_per_batch": NB, "block_len": BLOCK, "n_demods": M, "demods_on_rank0": len(st.plan.demods),
+                      "channels_on_rank0": len(st.plan.active_channels), "realtime_multiple": value / (FS / 1e6), "timed_region_s": elapsed,
+                      "parallelism": "dp over demodulators (one IQ stream): broadcast + per-rank channel subset + per-rank bank"},
+           "roofline": {"bound": "hbm", "whole_path": {"bytes_per_sample": round(bytes_per_sample, 1), "achieved": bytes_per_sample * value * 1e6 / 1e9,
+                                                       "frac": bytes_per_sample * value * 1e6 / 1e9 / 8000.0 / world}}}
+    st.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()

@@ -766,6 +766,42 @@ def test_active_channel_subset_matches_all_channels(ctx):
         bank.close(); full.close(); part.close()
 
 
+def test_sharded_stream_equals_unsharded(ctx):
+    """BASELINE config 4 partitioning on one GPU: two "virtual ranks" (two contexts, disjoint demodulator shards, each
+    channelizing only the channels its own demodulators sit on) reproduce the unsharded audio of every demodulator bit for bit,
+    and the host-side routing used for planning equals the library's."""
+    from cubicsdr_amd.engine import DemodBank, SDRPost
+    from cubicsdr_amd.parallel import ShardedStream, channel_at, data_channel
+    fs, M, block, center, nb = 100000000, 1024, 1667072, 400000000, 2
+    nd = 48
+    freqs = demod_frequencies(center, fs, nd)
+    demods = [("NBFM", 12500, f) for f in freqs]
+    x = synth_iq_fast(nb * block, fs, center, [("NBFM", f) for f in freqs[:8]], seed=91)
+    post = SDRPost(ctx, fs, M, block, max_blocks=nb)
+    bank = DemodBank(ctx, nd, max_blocks=nb)
+    for i, (k, bw, f) in enumerate(demods):
+        bank.configure(i, post, k, bw, f)
+        assert channel_at(f, center, fs, M) == post.channel_at(f)
+    post.execute(x, nb, block, center)
+    bank.execute(post)
+    whole = [bank.audio(i) for i in range(nd)]
+    counts = [[(r.n_iq, r.n_audio, r.nco_theta, r.resamp_phase) for r in bank.results(i)] for i in range(nd)]
+    bank.close(); post.close()
+    import torch
+    xd = torch.from_numpy(x.view(np.float32).reshape(-1, 2)).cuda()
+    ranks = [ShardedStream(0, r, 2, fs, M, block, demods, center, nb, group=False) for r in range(2)]
+    assert sorted(ranks[0].plan.demods + ranks[1].plan.demods) == list(range(nd))
+    assert not (set(ranks[0].plan.active_channels) & set(ranks[1].plan.active_channels))
+    assert all(len(r.plan.active_channels) < M // 8 for r in ranks)            # each rank computes a small subset of the 1024 rows
+    for r in ranks:
+        r.step(xd, nb)
+    for r in ranks:
+        for i in r.plan.demods:
+            assert np.array_equal(r.audio(i), whole[i]), i
+            assert [(q.n_iq, q.n_audio, q.nco_theta, q.resamp_phase) for q in r.results(i)] == counts[i], i
+        r.close()
+
+
 def test_c2_full_size_batching_invariance(ctx):
     """Size-independent property at the full C2 size: 64 NBFM demodulators, 16 blocks -- the audio, the resampled IQ and
     the per-block counts of one 16-block batch equal, bit for bit, those of 16 one-block batches."""

@@ -71,3 +71,28 @@ def test_contiguous_shards_cover_everything():
         assert got == list(range(n))
         sizes = [len(shard_demods(n, w, r)) for r in range(w)]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_channel_routing_twin_and_stream_plan():
+    """the host twin of getChannelAt / updateChannels (SDRPostThread.cpp:116-139) that ShardedStream plans with: every channel
+    centre routes to itself, the upper band edge to entry M (row M / 2), ties go to the first entry; and the plans of all ranks
+    partition the demodulators of BASELINE config 4 (1024 channels, one demodulator each) with disjoint channel sets."""
+    from cubicsdr_amd import parallel as P
+    fs, M, center = 100000000, 1024, 400000000
+    cc = P.channel_centers(center, fs, M)
+    assert len(cc) == M + 1 and cc[0] == center and cc[M] == center + fs // 2 and cc[M // 2] == center - fs // 2
+    for ch in (0, 1, 17, 511, 512, 513, 1023):
+        assert P.channel_at(cc[ch], center, fs, M) == ch
+        assert P.channel_at(cc[ch] + 1000, center, fs, M) == ch
+    assert P.channel_at(center + fs // 2, center, fs, M) == M and P.data_channel(M, M) == M // 2
+    assert P.channel_at(center + 3 * fs, center, fs, M) == -1
+    assert P.channel_at(123, 456, 2400000, 1) == 0
+    channels = [P.data_channel(P.channel_at(cc[ch] + 3700, center, fs, M), M) for ch in range(M)]
+    for world in (2, 4, 8):
+        plans = [P.plan(M, channels, world, r) for r in range(world)]
+        assert sorted(i for p in plans for i in p.demods) == list(range(M))
+        seen = set()
+        for p in plans:
+            assert not (seen & set(p.active_channels))
+            seen |= set(p.active_channels)
+            assert abs(len(p.demods) - M // world) <= 1
