@@ -40,11 +40,11 @@ MODEM_ID = {"NBFM": 0, "AM": 2, "USB": 3}
 # fs, M, block (SoapySDRThread.cpp:668-693: numChannels = even floor of ceil(fs / 500 kHz), block = ceil(fs / 60 / M) M), demods,
 # fftSize, modem round-robin, IQ blocks per batch, batches per step
 CONFIGS = {
-    "C2": dict(fs=10_000_000, M=20, block=166_680, n_demods=64, fft=16384, kinds=["NBFM"], blocks=256, batches=48,
+    "C2": dict(fs=10_000_000, M=20, block=166_680, n_demods=64, fft=16384, kinds=["NBFM"], blocks=256, batches=128,
                label="C2: 64x NBFM demods (12.5 kHz -> 48 kHz audio), 10 MS/s complex-float IQ, firpfbch M=20, 16384-pt spectrum FFT (internal 32768) over every sample"),
-    "C3": dict(fs=61_440_000, M=122, block=1_024_068, n_demods=256, fft=65536, kinds=["NBFM", "AM", "USB"], blocks=64, batches=48,
+    "C3": dict(fs=61_440_000, M=122, block=1_024_068, n_demods=256, fft=65536, kinds=["NBFM", "AM", "USB"], blocks=128, batches=48,
                label="C3: 256 mixed NBFM/AM/USB demods, 61.44 MS/s complex-float IQ, firpfbch M=122, 65536-pt spectrum FFT (internal 131072) over every sample"),
-    "C3N": dict(fs=61_440_000, M=122, block=1_024_068, n_demods=256, fft=65536, kinds=["NBFM"], blocks=64, batches=48,
+    "C3N": dict(fs=61_440_000, M=122, block=1_024_068, n_demods=256, fft=65536, kinds=["NBFM"], blocks=128, batches=48,
                 label="C3N: 256 NBFM demods, 61.44 MS/s complex-float IQ, firpfbch M=122, 65536-pt spectrum FFT (internal 131072) over every sample"),
 }
 

@@ -749,7 +749,7 @@ static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *
     const size_t o_au = carve(cap_audio * sizeof(float));
     const size_t o_agc = carve(8 * sizeof(float));
     const size_t o_pll = carve(2 * sizeof(uint32_t));
-    const size_t o_bm = carve(b->max_blocks * sizeof(float));
+    const size_t o_bm = carve(b->max_blocks * sizeof(float)), o_bma = carve(b->max_blocks * sizeof(float));
     const size_t o_bo = carve(b->max_blocks * sizeof(BlockOut));
     const size_t o_sc = carve(kScopeMax * sizeof(float)), o_scn = carve(sizeof(int32_t));
     if (s.slab) { (void)hipFree(s.slab); s.slab = nullptr; }
@@ -764,7 +764,7 @@ static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *
     c.hist_len = hist_len;
     c.mixhist = (float2 *)(base + o_mix); c.iq = (float2 *)(base + o_iq); c.d = (float *)(base + o_d); c.dh = (float *)(base + o_dh);
     c.audio = (float *)(base + o_au); c.agc = (float *)(base + o_agc); c.pll = (uint32_t *)(base + o_pll);   // slab is zeroed: nco_crcf_reset
-    c.blockmax = (float *)(base + o_bm); c.bout = (BlockOut *)(base + o_bo);
+    c.blockmax = (float *)(base + o_bm); c.blockmaa = (float *)(base + o_bma); c.bout = (BlockOut *)(base + o_bo);
     c.scope = (float *)(base + o_sc); c.scope_n = (int32_t *)(base + o_scn);
     c.cap_iq = (int)cap_iq; c.cap_audio = (int)cap_audio;
     const float agc0[8] = {1.0f, 1.0f, 1.0f, 0.f, 1.0f, 1.0f, 1.0f, 0.f};   // ModemAnalog::ModemAnalog(): aOutputCeil(1), MA(1), MAA(1)
@@ -990,14 +990,38 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     // slot the complex interpolator's arrays; AM / SSB need four float streams): an oversized request costs resident waves
     bool any_dsb = false;
     for (int i = 0; i < n_ag; ++i) any_dsb = any_dsb || b->slots[ag_list_h[i]].prm.modem == CSDR_MODEM_DSB;
-    const size_t dsb_lds = any_dsb ? 1024 * sizeof(float) + (size_t)kModemMaxBlockIq * sizeof(float2) : 0;
+    const size_t dsb_lds = any_dsb ? 1024 * sizeof(float) + (size_t)(max_n_iq + 64) * sizeof(float2) : 0;
     const size_t cw_lds = cap_cw ? ((size_t)kCwIqWin + 2 * (size_t)cap_cw) * sizeof(float2) : 0;
     const size_t modem_lds = std::max(std::max((size_t)4 * cap_stream * sizeof(float), cw_lds), dsb_lds) + 64;
     // LDS of the audio kernel: two ping-pong arrays (stage outputs) and the staged demodulator window (decimating
     // cascades reach back up to kDHist samples and their first stage outputs half the window)
-    const int cap_win = (max_n_iq + kDHist + 64 + 3) & ~3;
+    // samples in front of a block its audio cascade reaches back to (the backward range propagation of demod_audio_interp, taken
+    // at A0 = 0): the staged window is the block's own samples plus this much history -- sized per configuration, not by the
+    // largest history the slots could carry
+    int hist_need = 2 * kArmTaps;
+    for (int i = 0; i < n_run; ++i) {
+        const SlotHost &s = b->slots[slot_list_h[i]];
+        if (s.prm.modem == CSDR_MODEM_FRONTEND_ONLY || s.prm.modem == CSDR_MODEM_IQ) continue;
+        const int aS = (int)s.au.S;
+        int64_t lo = 0, need;
+        if (s.au.interp) {
+            for (int st = aS - 1; st >= 0; --st) lo = (lo >> 1) - (2 * (int)s.au.m[st] - 1);        // execution order = design order
+            need = ((-lo * (int64_t)s.au.step) >> 24) + kArmTaps + 8;
+        } else {
+            lo = -(int64_t)(kArmTaps - 1);
+            for (int e = aS - 1; e >= 0; --e) lo = 2 * lo - (4 * (int)s.au.m[aS - 1 - e] - 2);
+            need = -lo + (1 << aS) + 8;
+        }
+        hist_need = std::max<int>(hist_need, (int)need);
+    }
+    const int cap_win = (max_n_iq + std::min(hist_need, kDHist) + 64 + 3) & ~3;
     const int cap_out = (std::max(max_n_audio + 32 * max_aS + 64, cap_win / 2 + 64) + 3) & ~3;
     const size_t audio_lds = (size_t)(2 * cap_out + cap_win) * sizeof(float) + 64;
+    // a block is staged whole in LDS by the modem and audio kernels: that, not a fixed sample count, is what bounds the samples
+    // per block and demodulator (a full-width 500 kS/s channel demodulated at its own rate is ~8400 samples per 1/60 s block)
+    constexpr size_t kLdsPerWorkgroup = 160 * 1024;
+    if (modem_lds > kLdsPerWorkgroup || audio_lds > kLdsPerWorkgroup)
+        return reject(fail(CSDR_EUNSUPPORTED, "%d IQ / %d audio samples per block need %zu / %zu bytes of LDS (limit %zu)", max_n_iq, max_n_audio, modem_lds, audio_lds, kLdsPerWorkgroup));
     const size_t want[3] = {fe_lds, modem_lds, audio_lds};     // (the specialised front-end kernels stay below 64 KB)
     const void *fn[3] = {(const void *)demod_frontend, (const void *)demod_modem, (const void *)demod_audio_interp};
     for (int k = 0; k < 3; ++k)
@@ -1038,6 +1062,8 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     if (n_ag > 0)     // freqdem modems need no block-wide pre-pass: only the auto-gain modems run the modem kernel
         CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, demod_modem, dim3(n_ag, NB), dim3(audio_threads) /* one wave per block, like the audio kernel */, modem_lds, b->cfgs.p, dyns_d, lists_d + b->max_demods,
                     plans_d, NB, cap_stream, b->mconsts.p, c->sintab.p, b->arms.p, cap_cw);
+    if (n_ag > 0)     // the auto-gain recurrence over the blocks, once per demodulator
+        CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, demod_gain_scan, dim3(n_ag), dim3(64), (size_t)NB * sizeof(float), b->cfgs.p, dyns_d, lists_d + b->max_demods, plans_d, NB);
     if (n_audio_run > 0)
         CSDR_LAUNCH(c, LANE_AUDIO, KID_AUDIO, demod_audio_interp, grid, dim3(audio_threads), audio_lds, b->cfgs.p, dyns_d, lists_d, plans_d, NB,
                     cap_out, cap_win, b->arms.p);

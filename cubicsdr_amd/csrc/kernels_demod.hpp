@@ -23,8 +23,8 @@ constexpr int kHbMaxM = 10;       // largest half-band m (taps: 2m on the filter
 constexpr int kArmTaps = 14;      // arbitrary resampler: 2 * 7 taps per arm
 constexpr int kArms = 256;
 constexpr int kMixHist = 65536;   // upper bound of the mixed-input history kept per slot (cascade span; S <= 10)
-constexpr int kIqHist = 256;      // resampled-IQ history kept per slot
-constexpr int kDHist = 256;       // scaled demodulator-output history kept per slot (>= span of a decimating audio cascade)
+constexpr int kIqHist = 1024;     // resampled-IQ history kept per slot (modem warm-ups; the discriminator in front of a decimating audio cascade)
+constexpr int kDHist = 1024;      // scaled demodulator-output history kept per slot (>= span of a decimating audio cascade: 302 samples at 400 kHz -> 48 kHz)
 constexpr int kScopeMax = 2048;   // DEMOD_VIS_SIZE (DemodulatorThread.h:15)
 constexpr int kFeThreads = 256;
 constexpr int kFeChunk = 2048;    // input samples one inner iteration of the front-end stages through LDS
@@ -54,6 +54,7 @@ struct SlotCfg {                  // static per configuration, lives in HBM
     float *agc;                   // [2][4] aOutputCeil, aOutputCeilMA, aOutputCeilMAA (ModemAnalog.h), ping-pong
     uint32_t *pll;                // [2] DSB Costas loop: oscillator phase word, frequency word (carried across batches)
     float *blockmax;              // [max_blocks]
+    float *blockmaa;              // [max_blocks] aOutputCeilMAA in force for each block (demod_gain_scan)
     struct BlockOut *bout;        // [max_blocks]
     float *scope;                 // [kScopeMax] scaled demodulator output of the LAST block of the batch (ModemAnalog::getDemodOutputData: the scope tap)
     int32_t *scope_n;             // how many of them
@@ -217,10 +218,10 @@ __global__ __launch_bounds__(kFeThreads, 4) void demod_frontend(
     const float *__restrict__ arms = arms_all + (size_t)cfg.rs_iq.arms_idx * kArms * kArmTaps;
     const size_t iq_stride = (size_t)kIqHist + cfg.cap_iq;
     float2 *__restrict__ iq_cur = cfg.iq + (size_t)dyn.hist_parity * iq_stride;
-    if (part == 0 && tid < kIqHist) {
+    if (part == 0) {
         // resampled-IQ history of this batch = the last kIqHist samples of (previous history ++ previous batch)
         const float2 *iq_prev = cfg.iq + (size_t)(dyn.hist_parity ^ 1) * iq_stride;
-        iq_cur[tid] = iq_prev[dyn.prev_j + tid];
+        for (int i = tid; i < kIqHist; i += kFeThreads) iq_cur[i] = iq_prev[dyn.prev_j + i];
     }
 
     const int alen = fe_arr_len(S);
@@ -550,9 +551,9 @@ __global__ __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? 5 : 4) void demod_
 
     if (part == P) {
         // ---- carried streams of this demodulator (one workgroup): resampled-IQ history and mixed-input history
-        if (tid < kIqHist) {
+        {
             const float2 *iq_prev = cfg.iq + (size_t)(dyn.hist_parity ^ 1) * iq_stride;
-            iq_cur[tid] = iq_prev[dyn.prev_j + tid];             // last kIqHist samples of (previous history ++ previous batch)
+            for (int i = tid; i < kIqHist; i += (int)blockDim.x) iq_cur[i] = iq_prev[dyn.prev_j + i];   // last kIqHist samples of (previous history ++ previous batch)
         }
         __syncthreads();
         float2 *hnew = cfg.mixhist + (size_t)(dyn.hist_parity ^ 1) * hist_len;
@@ -762,7 +763,7 @@ __global__ __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? 5 : 4) void demod_
 //   USB/LSB : fs/4 shift, 3 biquads, shift back, Hilbert c2r, keep upper/lower    (ModemUSB.cpp:54-61)
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kModemThreads = 256;
-constexpr int kModemMaxBlockIq = 4096;     // resampled samples of one block handled by one workgroup (LDS bound)
+constexpr int kModemMaxBlockIq = 16384;    // resampled samples of one block one workgroup may have to stage (the real bound is the LDS its kernels need: csdr_bank_execute)
 constexpr int kAmTaps = 51;
 constexpr int kSsbFir = 128;               // taps of the SSB low-pass run as an FIR filter (pole radius <= 0.77: 0.77^128 ~ 3e-15)
 constexpr int kSsbWarm = kSsbFir - 1;      // samples the filter reaches back
@@ -1019,6 +1020,37 @@ __global__ __launch_bounds__(kModemThreads) void demod_modem(
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// D2a': the auto-gain recurrence over the blocks of the batch (ModemAnalog.cpp:70-77, ModemCW.cpp:181-190), once per demodulator:
+//     MA += (ceil - MA) 0.025;  MAA += (MA - MAA) 0.025;  ceil = max of the block           (blocks without samples change nothing)
+// blockmaa[b] = MAA in force for block b; the end state goes to the other parity copy.  (Every audio workgroup used to replay the
+// recurrence up to its own block: quadratic in the blocks per batch.)   grid = auto-gain slots, 64 threads
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void demod_gain_scan(const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
+                                                      const BlockPlan *__restrict__ plans, int NB) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_max = reinterpret_cast<float *>(smem);             // [NB] block maxima (one coalesced read instead of NB dependent ones)
+    const int slot = slot_list[blockIdx.x], tid = threadIdx.x;
+    const SlotCfg &cfg = cfgs[slot];
+    const SlotDyn dyn = dyns[slot];
+    const BlockPlan *pl = plans + (size_t)slot * (NB + 1);
+    for (int i = tid; i < NB; i += 64) s_max[i] = cfg.blockmax[i];
+    __syncthreads();
+    if (tid != 0) return;
+    const float *agc_in = cfg.agc + 4 * dyn.hist_parity;
+    float ceil_ = agc_in[0], ma = agc_in[1], maa = agc_in[2];
+    for (int bb = 0; bb < NB; ++bb) {
+        if (pl[bb + 1].j0 != pl[bb].j0) {                       // a block without samples never reaches demodulate() (ModemAM.cpp:33-36)
+            ma = ma + (ceil_ - ma) * 0.025f;
+            maa = maa + (ma - maa) * 0.025f;
+            ceil_ = s_max[bb];
+        }
+        cfg.blockmaa[bb] = maa;
+    }
+    float *agc_out = cfg.agc + 4 * (dyn.hist_parity ^ 1);
+    agc_out[0] = ceil_; agc_out[1] = ma; agc_out[2] = maa;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // D2b: auto-gain (ModemAnalog.cpp:70-86) + msresamp_rrrf to the audio rate (interpolating form: arbitrary stage then
 // x2 stages), audio peak and (for useSignalOutput modems) the audio-based level sum.   grid = (slot, block)
 // The gain of block b depends on the maxima of the blocks before it: every workgroup replays that short recurrence
@@ -1026,7 +1058,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_modem(
 // workgroup of the last block also carries the stream tails (resampled IQ, scaled demodulator output) to the
 // history regions for the next batch.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int kAudioMaxOut = 4096;         // audio samples of one block handled by one workgroup
+constexpr int kAudioMaxOut = 16384;        // audio samples of one block handled by one workgroup (likewise bounded by the LDS request)
 // dynamic LDS: two ping-pong arrays of `cap_out` floats, `cap_win` staged demodulator samples, 64 bytes of scratch
 
 __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
@@ -1058,14 +1090,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     if (cfg.modem == CSDR_MODEM_CW) {
         // ModemCW.cpp:181-203: the auto-gain of block b from the maxima of the blocks before it (recurrence replayed from the
         // batch-entering state), gain in dB and back as the reference does, applied to the unscaled audio demod_modem wrote
-        const float *agc_in = cfg.agc + 4 * dyn.hist_parity;
-        float ceil_ = agc_in[0], ma = agc_in[1], maa = agc_in[2];
-        for (int bb = 0; bb <= b; ++bb) {
-            if (pl[bb + 1].j0 == pl[bb].j0) continue;          // a block without samples never reaches demodulate(): no state change
-            ma = ma + (ceil_ - ma) * 0.025f;
-            maa = maa + (ma - maa) * 0.025f;
-            ceil_ = cfg.blockmax[bb];
-        }
+        const float maa = cfg.blockmaa[b];                       // demod_gain_scan
         const float gain_db = 10.0f * log10f(0.5f / maa);
         const float g = powf(10.0f, gain_db / 10.0f);
         const int aS = cfg.rs_au.S;
@@ -1082,7 +1107,6 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
         const double sm = block_sum_double(lsum, s_red);
         if (tid == 0) {
             cfg.bout[b].audio_peak = pk; cfg.bout[b].level_accum = sm; cfg.bout[b].level_count = n_audio;
-            if (b == NB - 1) { float *agc_out = cfg.agc + 4 * (dyn.hist_parity ^ 1); agc_out[0] = ceil_; agc_out[1] = ma; agc_out[2] = maa; }
         }
         return;
     }
@@ -1105,20 +1129,13 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
         return;
     }
     const float fm_ref = 1.0f / (2.0f * 3.14159265358979323846f * 0.5f);   // freqdem_create(kf = 0.5): 1 / (2 pi kf)
-    const float *agc_in = cfg.agc + 4 * dyn.hist_parity;
     const float *dh_in = cfg.dh + (size_t)kDHist * dyn.hist_parity;
 
     // gains of block b (g_cur) and of the block before it (g_prev); block -1 means "previous batch" (already scaled)
-    float g_cur = 1.0f, g_prev = 1.0f, ceil_ = agc_in[0], ma = agc_in[1], maa = agc_in[2];
-    if (autogain) {
-        for (int bb = 0; bb <= b; ++bb) {
-            if (pl[bb + 1].j0 == pl[bb].j0) continue;          // a block without samples never reaches demodulate() (ModemAM.cpp:33-36): no state change
-            ma = ma + (ceil_ - ma) * 0.025f;
-            maa = maa + (ma - maa) * 0.025f;
-            ceil_ = cfg.blockmax[bb];
-            g_prev = g_cur;
-            g_cur = 0.5f / maa;
-        }
+    float g_cur = 1.0f, g_prev = 1.0f;
+    if (autogain) {                                              // MAA per block from demod_gain_scan
+        g_cur = 0.5f / cfg.blockmaa[b];
+        if (b > 0) g_prev = 0.5f / cfg.blockmaa[b - 1];
     }
 
     // backward range propagation.
@@ -1172,9 +1189,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
             // more than one block back, or empty blocks nearby (tiny blocks): replay the gain of the block that holds j
             int bb = b;
             while (bb > 0 && j < pl[bb].j0) --bb;
-            float c2 = agc_in[0], m2 = agc_in[1], mm2 = agc_in[2], gg = 1.0f;
-            for (int q = 0; q <= bb; ++q) { if (pl[q + 1].j0 == pl[q].j0) continue; m2 = m2 + (c2 - m2) * 0.025f; mm2 = mm2 + (m2 - mm2) * 0.025f; c2 = cfg.blockmax[q]; gg = 0.5f / mm2; }
-            x = cfg.d[j] * gg;
+            x = cfg.d[j] * (0.5f / cfg.blockmaa[bb]);              // block bb holds sample j, so it stepped the gain
         }
         s_d[i] = x;
     }
@@ -1321,10 +1336,6 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     }
     // 4. last block of an auto-gain modem: publish the gain state and the scaled demodulator tail (other parity)
     if (b == NB - 1 && autogain) {
-        if (tid == 0) {
-            float *agc_out = cfg.agc + 4 * (dyn.hist_parity ^ 1);
-            agc_out[0] = ceil_; agc_out[1] = ma; agc_out[2] = maa;
-        }
         const int J = pl[NB].j0;
         for (int td = tid; td < kDHist; td += nthr) {
             const int j = J - kDHist + td;
@@ -1335,9 +1346,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
             else {
                 int bb = b;
                 while (bb > 0 && j < pl[bb].j0) --bb;
-                float c2 = agc_in[0], m2 = agc_in[1], mm2 = agc_in[2], gg = 1.0f;
-                for (int q = 0; q <= bb; ++q) { if (pl[q + 1].j0 == pl[q].j0) continue; m2 = m2 + (c2 - m2) * 0.025f; mm2 = mm2 + (m2 - mm2) * 0.025f; c2 = cfg.blockmax[q]; gg = 0.5f / mm2; }
-                dv = cfg.d[j] * gg;
+                dv = cfg.d[j] * (0.5f / cfg.blockmaa[bb]);
             }
             (cfg.dh + (size_t)kDHist * (dyn.hist_parity ^ 1))[td] = dv;
         }

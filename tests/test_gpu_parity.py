@@ -332,6 +332,14 @@ def test_wide_fm_audio_decimation(ctx):
     print(_compare(got, want, "fm"))
 
 
+def test_wide_demodulators_many_samples_per_block(ctx):
+    """more than 4096 resampled samples per block and demodulator (the former per-workgroup wall): FM at 400 kHz and AM at
+    300 kHz on 600 kS/s channels (6667 / 5000 samples per 1/60 s block), next to an NBFM demodulator, 4 blocks in batches of 2."""
+    got, want = _run_demods(ctx, 2400000, 4, 40000, ["FM", "NBFM", "AM"], 4, 2, bw=[400000, 12500, 300000], seed=19)
+    assert got[0][0]["n_iq"] > 6000 and got[2][0]["n_iq"] > 4900
+    print(_compare(got, want, "wide"))
+
+
 def test_batched_equals_reference(ctx):
     """6 blocks in two batches of 3: results must equal the block-at-a-time reference (counts exact)."""
     got, want = _run_demods(ctx, 2400000, 4, 40000, ["NBFM", "AM", "USB"], 6, 3)
@@ -781,8 +789,9 @@ def test_sharded_stream_equals_unsharded(ctx):
     bank = DemodBank(ctx, nd, max_blocks=nb)
     for i, (k, bw, f) in enumerate(demods):
         bank.configure(i, post, k, bw, f)
-        assert channel_at(f, center, fs, M) == post.channel_at(f)
     post.execute(x, nb, block, center)
+    for k, bw, f in demods:                                      # (the library knows the stream's centre frequency from the first block on)
+        assert channel_at(f, center, fs, M) == post.channel_at(f)
     bank.execute(post)
     whole = [bank.audio(i) for i in range(nd)]
     counts = [[(r.n_iq, r.n_audio, r.nco_theta, r.resamp_phase) for r in bank.results(i)] for i in range(nd)]
