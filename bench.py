@@ -198,6 +198,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline sample budget per leg (0 disables)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event profile")
     ap.add_argument("--no-latency", action="store_true", help="skip the small-batch (real-time shape) measurement")
+    ap.add_argument("--ring", default="signal", choices=["signal", "noise"],
+                    help="signal: noise + one modulated carrier per demodulator + DC (default, SURVEY.md 8d); noise: the noise and DC only "
+                         "(counter-collection passes: rocprofv3 --pmc does not survive the thousands of small torch launches of the synthesis)")
     args = ap.parse_args()
     if args.config == "C4":
         from cubicsdr_amd import sharded_bench
@@ -229,7 +232,11 @@ def main():
     device = torch.device("cuda", local_rank)
 
     from cubicsdr_amd.engine import Context, DemodBank, SDRPost, SpectrumProcessor
-    ring = make_ring(torch, device, cfg, NB, seed=0xC0B1C5D2 + rank)
+    if args.ring == "noise":
+        g0 = torch.Generator(device=device); g0.manual_seed(0xC0B1C5D2 + rank)
+        ring = torch.randn(NB * BLOCK, 2, generator=g0, device=device, dtype=torch.float32) * 0.05 + 0.01
+    else:
+        ring = make_ring(torch, device, cfg, NB, seed=0xC0B1C5D2 + rank)
     torch.cuda.synchronize()
 
     def make_pipeline(nb):
