@@ -171,6 +171,19 @@ extern "C" int csdr_dev_download(csdr_ctx *c, void *host, const void *dev, uint6
     return CSDR_OK;
 }
 
+extern "C" int csdr_host_register(csdr_ctx *c, void *host, uint64_t bytes) {
+    DeviceScope dev__(c);
+    if (!c || !host || !bytes) return fail(CSDR_EINVAL, "bad argument");
+    CSDR_HIP_TRY(hipHostRegister(host, bytes, hipHostRegisterDefault));
+    return CSDR_OK;
+}
+extern "C" int csdr_host_unregister(csdr_ctx *c, void *host) {
+    DeviceScope dev__(c);
+    if (!c || !host) return fail(CSDR_EINVAL, "bad argument");
+    CSDR_HIP_TRY(hipHostUnregister(host));
+    return CSDR_OK;
+}
+
 // =================================================================================================== SDRPostThread
 struct csdr_post {
     csdr_ctx *ctx = nullptr;

@@ -52,6 +52,8 @@ ABI = {
     "csdr_dev_free": (_i, [_p, _p]),
     "csdr_dev_upload": (_i, [_p, _p, _p, C.c_uint64]),
     "csdr_dev_download": (_i, [_p, _p, _p, C.c_uint64]),
+    "csdr_host_register": (_i, [_p, _p, C.c_uint64]),
+    "csdr_host_unregister": (_i, [_p, _p]),
     "csdr_post_create": (_i, [_p, _pp]),
     "csdr_post_destroy": (None, [_p]),
     "csdr_post_configure": (_i, [_p, _i64, _i, _i, _i, _i]),

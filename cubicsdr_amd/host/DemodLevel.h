@@ -2,7 +2,7 @@
 // (reference src/demod/DemodulatorThread.cpp:142-220, linearToDb :59-67), one step per demodulated block.  The sums it starts
 // from (level_accum / level_count) come from the device (csdr_block_result); everything here is a few scalar operations per
 // block in the reference's own types (float trackers, double level), so it stays on the host and is pinned by
-// tests/test_host_mirror.py::test_level_squelch_state_machine_matches_oracle against oracle/cubicsdr_chain.py::RefLevelSquelch.
+// tests/test_host_mirror.py::test_level_squelch_state_machine_matches_oracle against the checker's statement-by-statement restatement.
 #pragma once
 #include <cmath>
 

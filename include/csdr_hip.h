@@ -72,6 +72,10 @@ int  csdr_dev_alloc(csdr_ctx *ctx, uint64_t bytes, void **dev);
 int  csdr_dev_free(csdr_ctx *ctx, void *dev);
 int  csdr_dev_upload(csdr_ctx *ctx, void *dev, const void *host, uint64_t bytes);
 int  csdr_dev_download(csdr_ctx *ctx, void *host, const void *dev, uint64_t bytes);
+/* Page-lock a caller-owned host buffer (e.g. the pooled SDRThreadIQData blocks, SoapySDRThread.cpp:221-225) so that the
+ * host-to-device copies of csdr_post_execute / csdr_spec_process read it by DMA; unregister before freeing it. */
+int  csdr_host_register(csdr_ctx *ctx, void *host, uint64_t bytes);
+int  csdr_host_unregister(csdr_ctx *ctx, void *host);
 
 /* ------------------------------------------------------------------ SDRPostThread (src/sdr/SDRPostThread.cpp)
  * replaces: iirfilt_crcf_create_dc_blocker :29, runSingleCH :248-299 (iirfilt_crcf_execute_block :284),
@@ -90,7 +94,10 @@ void csdr_post_destroy(csdr_post *post);
 int  csdr_post_configure(csdr_post *post, int64_t sample_rate, int num_channels, int mode,
                          int max_block_len, int max_blocks);
 /* Process n_blocks x block_len input samples (block_len % num_channels == 0).  `iq` is device memory when
- * iq_is_dev != 0, else host memory that is staged through a pinned buffer.  Output stays in HBM, channel-major. */
+ * iq_is_dev != 0, else host memory that is copied to a device staging buffer with hipMemcpyAsync on the stage's stream: from
+ * pageable memory the runtime stages the copy before the call returns; from page-locked memory (csdr_host_register) it is a
+ * DMA that may still be in flight, so the buffer must stay unchanged until the next synchronising call on this object
+ * (csdr_post_read_channel, csdr_bank_fetch_*, csdr_ctx_synchronize).  Output stays in HBM, channel-major. */
 int  csdr_post_execute(csdr_post *post, const float *iq, int iq_is_dev, int n_blocks, int block_len,
                        int64_t frequency);
 /* Optional: produce only these channels (the reference skips channels without consumers, :336-339).  NULL = all.

@@ -10,6 +10,7 @@
 #include <thread>
 
 #include "../../cubicsdr_amd/host/HipPipeline.h"
+#include "../../cubicsdr_amd/host/Adapters.h"
 #include "../../cubicsdr_amd/host/ScopeVisualProcessor.h"
 
 static int g_fail = 0;
@@ -186,6 +187,114 @@ static void test_modem_shim() {
     CHECK(!d->isTerminated() && d->isActive());
     d->terminate();
     CHECK(d->isTerminated() && !d->isActive());
+}
+
+// SDRThread::readStream block semantics (SoapySDRThread.cpp:195-402): MTU chunks, overflow carry, IQ swap, full-queue discard
+struct RampSource : IQStreamSource {
+    long long pos = 0; int chunk; int fail_at = -1; int calls = 0;
+    explicit RampSource(int c) : chunk(c) {}
+    int readStream(float *buff, int maxElems) override {
+        if (++calls == fail_at) return -1;
+        const int n = std::min(chunk, maxElems);
+        for (int i = 0; i < n; ++i) { buff[2 * i] = (float)(pos + i); buff[2 * i + 1] = -(float)(pos + i); }
+        pos += n;
+        return n;
+    }
+};
+static void test_block_assembler() {
+    CHECK(SDRBlockAssembler::getOptimalChannelCount(2400000) == 4 && SDRBlockAssembler::getOptimalChannelCount(500000) == 1);
+    CHECK(SDRBlockAssembler::getOptimalChannelCount(10000000) == 20 && SDRBlockAssembler::getOptimalChannelCount(61440000) == 122);
+    CHECK(SDRBlockAssembler::getOptimalChannelCount(100000000) == 200 && SDRBlockAssembler::getOptimalChannelCount(600000) == 2);
+    CHECK(SDRBlockAssembler::getOptimalElementCount(10000000, 60, 20) == 166680 && SDRBlockAssembler::getOptimalElementCount(61440000, 60, 122) == 1024068);
+    SDRBlockAssembler a;                          // no ctx: plain pageable buffers
+    a.setSampleRate(2400000);
+    a.setFrequency(100000000);
+    CHECK(a.getNumChannels() == 4 && a.getNumElems() == 40000);
+    a.setMTU(16384);                              // 40000 = 2 x 16384 + 7232: every block ends inside a read
+    RampSource dev(16384);
+    auto q = std::make_shared<SDRThreadIQDataQueue>();
+    q->set_max_num_items(8);
+    std::atomic_bool stopping{false};
+    long long expect = 0;
+    for (int b = 0; b < 5; ++b) {
+        CHECK(a.readStream(dev, q, stopping) > 0);
+        SDRThreadIQDataPtr blk;
+        CHECK(q->try_pop(blk) && blk->data.size() == 40000 && blk->numChannels == 4 && blk->sampleRate == 2400000 && blk->frequency == 100000000);
+        bool ok = true;
+        for (int i = 0; i < 40000; ++i) ok = ok && blk->data[i].real == (float)(expect + i) && blk->data[i].imag == -(float)(expect + i);
+        CHECK(ok);                                // the stream is continuous across blocks: nothing lost, nothing repeated
+        expect += 40000;
+        CHECK(a.pendingOverflow() == (int)(dev.pos - expect));
+    }
+    a.setIQSwap(true);
+    CHECK(a.readStream(dev, q, stopping) > 0);
+    SDRThreadIQDataPtr blk;
+    CHECK(q->try_pop(blk));
+    // samples carried over from before the swap keep their orientation; fresh ones are swapped (the reference swaps at copy time)
+    CHECK(blk->data[39999].imag == (float)(expect + 39999) && blk->data[39999].real == -(float)(expect + 39999));
+    expect += 40000;
+    a.setIQSwap(false);
+    // full consumer queue: the block is discarded, the code is 0, the overflow bookkeeping stays consistent
+    auto q1 = std::make_shared<SDRThreadIQDataQueue>();
+    q1->push(std::make_shared<SDRThreadIQData>());
+    CHECK(a.readStream(dev, q1, stopping) == 0 && q1->size() == 1);
+    // a stream error ends the block early: what was read so far is posted
+    dev.fail_at = dev.calls + 2;
+    const int code = a.readStream(dev, q, stopping);
+    CHECK(code < 0 && q->try_pop(blk) && blk->data.size() < 40000 && !blk->data.empty());
+}
+
+// the RtAudio callback's mixing (AudioThread.cpp:88-240) and the WAV writer (AudioFileWAV.cpp:63-170)
+static void test_audio_egress() {
+    AudioMixer mix(48000);
+    auto s1 = std::make_shared<AudioMixSource>(), s2 = std::make_shared<AudioMixSource>();
+    s1->inputQueue = std::make_shared<AudioThreadInputQueue>(); s2->inputQueue = std::make_shared<AudioThreadInputQueue>();
+    s1->inputQueue->set_max_num_items(8); s2->inputQueue->set_max_num_items(8);
+    s2->gain = 0.5f;
+    mix.bindThread(s1); mix.bindThread(s2);
+    auto mk = [](int ch, int rate, int n, float v, float peak) { auto a = std::make_shared<AudioThreadInput>(); a->channels = ch; a->sampleRate = rate; a->data.assign((size_t)n, v); a->peak = peak; return a; };
+    for (int k = 0; k < 3; ++k) s1->inputQueue->push(mk(1, 48000, 100, 0.25f, 0.25f));        // mono
+    for (int k = 0; k < 3; ++k) s2->inputQueue->push(mk(2, 48000, 200, 0.5f, 0.5f));          // stereo, gain 0.5
+    std::vector<float> out(2 * 64);
+    mix.callback(out.data(), 64);                 // the first call only latches each source's first block (:131-139)
+    CHECK(out[0] == 0.f && out[127] == 0.f);
+    mix.callback(out.data(), 64);
+    CHECK(std::fabs(out[0] - 0.5f) < 1e-6f && std::fabs(out[127] - 0.5f) < 1e-6f);             // 0.25 + 0.5 * 0.5 on both channels
+    mix.callback(out.data(), 64);                 // crosses the first mono block (100 samples) into the second one
+    CHECK(std::fabs(out[2 * 40] - 0.5f) < 1e-6f);
+    // a loud source: the sum of the peaks exceeds 1 -> the buffer is scaled by 1 / peak
+    auto s3 = std::make_shared<AudioMixSource>();
+    s3->inputQueue = std::make_shared<AudioThreadInputQueue>(); s3->inputQueue->set_max_num_items(8);
+    for (int k = 0; k < 4; ++k) s3->inputQueue->push(mk(1, 48000, 64, 2.0f, 2.0f));
+    AudioMixer loud(48000);
+    loud.bindThread(s3);
+    loud.callback(out.data(), 64); loud.callback(out.data(), 64);
+    CHECK(std::fabs(out[10] - 1.0f) < 1e-6f);
+    // blocks at another sample rate are skipped (:141-158)
+    auto s4 = std::make_shared<AudioMixSource>();
+    s4->inputQueue = std::make_shared<AudioThreadInputQueue>(); s4->inputQueue->set_max_num_items(8);
+    s4->inputQueue->push(mk(1, 44100, 64, 0.3f, 0.3f)); s4->inputQueue->push(mk(1, 44100, 64, 0.3f, 0.3f)); s4->inputQueue->push(mk(1, 48000, 64, 0.1f, 0.1f)); s4->inputQueue->push(mk(1, 48000, 64, 0.1f, 0.1f));
+    AudioMixer m4(48000);
+    m4.bindThread(s4);
+    m4.callback(out.data(), 32); m4.callback(out.data(), 32);
+    CHECK(std::fabs(out[0] - 0.1f) < 1e-6f);
+    // WAV: header fields, 16-bit payload with the anti-clipping scale, sizes patched on close, roll-over at the size limit
+    {
+        const std::string base = "/tmp/csdr_test_wav";
+        AudioSinkWAV w(base, 44 + 300);           // tiny limit; the reference counts the file size from the data chunk header (36): 154 samples fit
+        auto a = mk(1, 48000, 200, 0.5f, 0.5f);
+        w.writeToFile(a);
+        w.closeFile();
+        std::ifstream f0(base + ".wav", std::ios::binary), f1(base + "_001.wav", std::ios::binary);
+        std::vector<unsigned char> b0((std::istreambuf_iterator<char>(f0)), std::istreambuf_iterator<char>()), b1((std::istreambuf_iterator<char>(f1)), std::istreambuf_iterator<char>());
+        auto u32 = [](const std::vector<unsigned char> &b, size_t o) { return (unsigned)b[o] | ((unsigned)b[o + 1] << 8) | ((unsigned)b[o + 2] << 16) | ((unsigned)b[o + 3] << 24); };
+        CHECK(b0.size() == 44 + 308 && b1.size() == 44 + 92);
+        CHECK(std::memcmp(b0.data(), "RIFF", 4) == 0 && std::memcmp(b0.data() + 8, "WAVEfmt ", 8) == 0 && std::memcmp(b0.data() + 36, "data", 4) == 0);
+        CHECK(u32(b0, 4) == b0.size() - 8 && u32(b0, 40) == 308 && u32(b0, 24) == 48000 && b0[22] == 1 && b0[34] == 16);
+        const short v = (short)(b0[44] | (b0[45] << 8));
+        CHECK(v == (short)int(0.5f * 32767.0f));
+        std::remove((base + ".wav").c_str()); std::remove((base + "_001.wav").c_str());
+    }
 }
 
 // FFTDataDistributor scenarios (no GPU): the sample values carry their stream position so that the emitted lines can be
@@ -481,6 +590,8 @@ int main(int argc, char **argv) {
     test_visual_processor();
     test_distributors();
     test_modem_shim();
+    test_block_assembler();
+    test_audio_egress();
     std::printf(g_fail ? "HOST TEST FAILED (%d)\n" : "host test ok\n", g_fail);
     return g_fail ? 1 : 0;
 }
