@@ -725,8 +725,7 @@ static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *
     s.prm.bandwidth = modem_check_rate(prm->modem, prm->bandwidth, prm->audio_sample_rate);
     s.chan_rate = csdr_post_channel_rate(post);
     const double iq_ratio = (double)s.prm.bandwidth / (double)s.chan_rate;        // DemodulatorWorkerThread.cpp:99-100
-    if (iq_ratio > 1.0) return fail(CSDR_EUNSUPPORTED, "bandwidth %d above the channel rate %lld (interpolating IQ resampler)", s.prm.bandwidth, (long long)s.chan_rate);
-    s.iq = design::plan_msresamp((float)iq_ratio, 60.0f);
+    s.iq = design::plan_msresamp((float)iq_ratio, 60.0f);        // bandwidth above the channel rate: the interpolating form (:97-101 creates it for any ratio)
     const double au_ratio = double(s.prm.audio_sample_rate) / double(s.prm.bandwidth);   // ModemAnalog.cpp:29-30
     s.au = design::plan_msresamp((float)au_ratio, 60.0f);
     if (s.iq.S > kMaxHb || s.au.S > kMaxHb) return fail(CSDR_EUNSUPPORTED, "resampling ratio needs %u half-band stages", s.iq.S);
@@ -739,7 +738,12 @@ static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *
     if (int rc = bank_arm_bank(b, s.iq, &ia)) return rc;
     if (int rc = bank_arm_bank(b, s.au, &aa)) return rc;
     // cascade span: input samples before an output that can influence it (front-end warm-up, carried history)
-    {
+    if (s.iq.interp) {
+        // interpolating: the first outputs of a batch reach back (arm length + the half-band windows, in input samples)
+        int64_t lo = 0;
+        for (int st = (int)s.iq.S - 1; st >= 0; --st) lo = (lo >> 1) - (2 * (int)s.iq.m[st] - 1);
+        s.warm = (int)(((-lo) * (int64_t)s.iq.step) >> 24) + kArmTaps + 8;
+    } else {
         const int S = (int)s.iq.S;
         int64_t lo = -(int64_t)(kArmTaps - 1);
         for (int e = S - 1; e >= 0; --e) lo = 2 * lo - (4 * (int)s.iq.m[S - 1 - e] - 2);
@@ -894,9 +898,10 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         const bool iq_modem = s.prm.modem == CSDR_MODEM_IQ || fe_only;      // no audio resampler: 2 floats per resampled IQ sample
         const bool au_interp = s.au.interp;
         const int ash = iq_modem ? 1 : (au_interp ? aS : 0);     // audio samples per arbitrary-stage output = 2^ash
+        const bool iq_interp = s.iq.interp;      // arbitrary stage first: it consumes the channel samples directly, each output fans out to 2^S
         for (int bb = 0; bb <= NB; ++bb) {
-            const int64_t K = ((int64_t)s.buf_idx + (int64_t)bb * Bc) >> S;
-            const int64_t J = first_out(K, s.phase, s.iq.step);
+            const int64_t K = iq_interp ? (int64_t)bb * Bc : (((int64_t)s.buf_idx + (int64_t)bb * Bc) >> S);
+            const int64_t J = iq_interp ? (first_out(K, s.phase, s.iq.step) << S) : first_out(K, s.phase, s.iq.step);
             // audio msresamp_rrrf (ModemAnalog.cpp:88): interpolating = arbitrary stage first (input index J);
             // decimating = half-band /2 stages first: the arbitrary stage sees (abuf + J) >> aS chain outputs
             const int64_t Ka = au_interp ? J : (((int64_t)s.abuf + J) >> aS);
@@ -916,15 +921,15 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
             else if (r.n_iq > kModemMaxBlockIq || r.n_audio > kAudioMaxOut) return reject(fail(CSDR_EUNSUPPORTED, "slot %d: %d IQ / %d audio samples per block exceed the per-workgroup limits", si, r.n_iq, r.n_audio));
             if (!fe_only) { max_n_iq = std::max(max_n_iq, r.n_iq); max_n_audio = std::max(max_n_audio, r.n_audio); }
             max_blk_audio = std::max(max_blk_audio, r.n_audio);
-            const int64_t Kb = ((int64_t)s.buf_idx + (int64_t)(bb + 1) * Bc) >> S;
-            r.buffer_index = (uint32_t)(((int64_t)s.buf_idx + (int64_t)(bb + 1) * Bc) & ((1 << S) - 1));
-            r.resamp_phase = (uint32_t)((int64_t)s.phase + (int64_t)pl[bb + 1].j0 * s.iq.step - (Kb << 24));
+            const int64_t Kb = iq_interp ? (int64_t)(bb + 1) * Bc : (((int64_t)s.buf_idx + (int64_t)(bb + 1) * Bc) >> S);
+            r.buffer_index = iq_interp ? 0u : (uint32_t)(((int64_t)s.buf_idx + (int64_t)(bb + 1) * Bc) & ((1 << S) - 1));
+            r.resamp_phase = (uint32_t)((int64_t)s.phase + (int64_t)(iq_interp ? pl[bb + 1].j0 >> S : pl[bb + 1].j0) * s.iq.step - (Kb << 24));
             r.nco_theta = d.mixdir ? (uint32_t)(s.theta + (uint32_t)((int64_t)(bb + 1) * Bc) * s.dtheta) : s.theta;
         }
         // advance host-side integer state
-        const int64_t Ktot = ((int64_t)s.buf_idx + (int64_t)NB * Bc) >> S;
-        s.phase = (uint32_t)((int64_t)s.phase + Jtot * (int64_t)s.iq.step - (Ktot << 24));
-        s.buf_idx = (uint32_t)(((int64_t)s.buf_idx + (int64_t)NB * Bc) & ((1 << S) - 1));
+        const int64_t Ktot = iq_interp ? (int64_t)NB * Bc : (((int64_t)s.buf_idx + (int64_t)NB * Bc) >> S);
+        s.phase = (uint32_t)((int64_t)s.phase + (iq_interp ? Jtot >> S : Jtot) * (int64_t)s.iq.step - (Ktot << 24));
+        if (!iq_interp) s.buf_idx = (uint32_t)(((int64_t)s.buf_idx + (int64_t)NB * Bc) & ((1 << S) - 1));
         if (d.mixdir) s.theta += (uint32_t)((int64_t)NB * Bc) * s.dtheta;
         if (!iq_modem) {
             const int64_t Ka_tot = au_interp ? Jtot : (((int64_t)s.abuf + Jtot) >> aS);
@@ -949,12 +954,13 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     {
         auto klass = [&](const SlotHost &s) {
             const int S = (int)s.iq.S;
+            if (s.iq.interp) return 7;
             if (S < 3 || S > 6) return 0;
             for (int e = 0; e < S; ++e) if ((int)s.iq.m[S - 1 - e] != fes_m(S, e)) return 0;
             return S;
         };
         int pos = 0;
-        for (int k = 0; k < 7; ++k) {
+        for (int k = 0; k < 8; ++k) {
             grp_off[k] = pos;
             for (int i = 0; i < n_run; ++i) if (klass(b->slots[slot_list_h[i]]) == k) grp_h[pos++] = slot_list_h[i];
             grp_n[k] = pos - grp_off[k];
@@ -1056,6 +1062,13 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, (demod_frontend_s<S_, CH_>), dim3(ranges_for(grp_n[S_]) + 1, grp_n[S_]), dim3(kFeThreads), (fes_lds_bytes<S_, CH_>()), \
                     b->cfgs.p, dyns_d, grp_d + grp_off[S_], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p)
     CSDR_FE_S(3, 2048); CSDR_FE_S(4, 2048); CSDR_FE_S(6, 2048);
+    if (grp_n[7] > 0) {          // interpolating IQ resamplers: chunks of output samples
+        int64_t jmax = 0;
+        for (int i = 0; i < grp_n[7]; ++i) jmax = std::max<int64_t>(jmax, b->slots[grp_h[grp_off[7] + i]].last_J);
+        const int nchunks = (int)((jmax + kFiChunk - 1) / kFiChunk);
+        CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, demod_frontend_interp, dim3(nchunks + 1, grp_n[7]), dim3(kFeThreads), kFiLds, b->cfgs.p, dyns_d, grp_d + grp_off[7],
+                    chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
+    }
     if (grp_n[5] > 0)            // depth 5 (NBFM from ~500 kS/s channels): a fifth wave runs the one-wave tail one chunk behind
         CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, (demod_frontend_s<5, 2048, true>), dim3(ranges_for(grp_n[5]) + 1, grp_n[5]), dim3(kFeThreads + 64), (fes_lds_bytes<5, 2048>()),
                     b->cfgs.p, dyns_d, grp_d + grp_off[5], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);

@@ -757,6 +757,106 @@ __global__ __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? 5 : 4) void demod_
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// D1i: NCO shift + INTERPOLATING msresamp_crcf (demodulator bandwidth above the channel rate: DemodulatorWorkerThread.cpp:97-101
+// creates the resampler for any ratio): arbitrary polyphase stage first (1 < rate_arb <= 2: one or two outputs per input), then
+// S x2 half-band stages -- the structure of the audio interpolator, on complex samples.
+// grid = (chunks + 1, slots): a workgroup owns a chunk of kFiChunk consecutive OUTPUT samples of the batch, propagates the range
+// back through the stages (closed-form indices, no carried window), stages the mixed inputs it needs in LDS and runs the cascade
+// through two ping-pong arrays; the extra workgroup carries the histories (resampled IQ, mixed input).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kFiChunk = 2048;
+constexpr int kFiArr = kFiChunk + 256;        // LDS array length (outputs of a stage + half-band reach)
+constexpr size_t kFiLds = (size_t)3 * kFiArr * sizeof(float2);
+
+__global__ __launch_bounds__(kFeThreads) void demod_frontend_interp(
+    const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
+    const float2 *__restrict__ chan_base, int64_t chan_stride, int64_t total /* batch samples per channel */,
+    const float *__restrict__ arms_all, const float *__restrict__ sintab) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *s_in = reinterpret_cast<float2 *>(smem), *w0 = s_in + kFiArr, *w1 = w0 + kFiArr;
+    const int slot = slot_list[blockIdx.y], tid = threadIdx.x;
+    const SlotCfg &cfg = cfgs[slot];
+    const SlotDyn dyn = dyns[slot];
+    const ResampCfg &rs = cfg.rs_iq;
+    const int S = rs.S, hist_len = cfg.hist_len;
+    const uint32_t step = rs.step;
+    const float2 *__restrict__ chan = chan_base + (int64_t)dyn.chan * chan_stride;
+    const float2 *__restrict__ hist = cfg.mixhist + (size_t)dyn.hist_parity * hist_len;
+    const size_t iq_stride = (size_t)kIqHist + cfg.cap_iq;
+    float2 *__restrict__ iq_cur = cfg.iq + (size_t)dyn.hist_parity * iq_stride;
+    const float *__restrict__ arms = arms_all + (size_t)rs.arms_idx * kArms * kArmTaps;
+    if (blockIdx.x == gridDim.x - 1) {
+        // ---- carried streams: resampled-IQ history and mixed-input history (other parity)
+        const float2 *iq_prev = cfg.iq + (size_t)(dyn.hist_parity ^ 1) * iq_stride;
+        for (int i = tid; i < kIqHist; i += kFeThreads) iq_cur[i] = iq_prev[dyn.prev_j + i];
+        float2 *hnew = cfg.mixhist + (size_t)(dyn.hist_parity ^ 1) * hist_len;
+        for (int i = tid; i < hist_len; i += kFeThreads) {
+            const int64_t rel = total - hist_len + i;
+            float2 v = make_float2(0.f, 0.f);
+            if (rel >= 0) v = fe_mix(chan[rel], rel, dyn, sintab);
+            else if (rel >= -(int64_t)hist_len) v = hist[hist_len + rel];
+            hnew[i] = v;
+        }
+        return;
+    }
+    const int64_t Jtot = resamp_first_out(total, dyn.phase0, step) << S;      // resampled samples of the batch
+    const int64_t A0 = (int64_t)blockIdx.x * kFiChunk, A1 = min(Jtot, A0 + kFiChunk);
+    if (A0 >= A1) return;
+    // backward range propagation: lo[s] / hi[s] = input range of x2 stage s (s = 0: arbitrary-stage outputs)
+    int64_t lo[kMaxHb + 1], hi[kMaxHb + 1];
+    lo[S] = A0; hi[S] = A1;
+    for (int st = S - 1; st >= 0; --st) { lo[st] = (lo[st + 1] >> 1) - (2 * rs.m_x[st] - 1); hi[st] = (hi[st + 1] + 1) >> 1; }
+    const int nv = (int)(hi[0] - lo[0]);
+    const int64_t jlo = (((int64_t)dyn.phase0 + lo[0] * (int64_t)step) >> 24) - (kArmTaps - 1);
+    const int64_t jhi = (((int64_t)dyn.phase0 + (hi[0] - 1) * (int64_t)step) >> 24) + 1;
+    const int nwin = (int)(jhi - jlo);
+    for (int i = tid; i < nwin; i += kFeThreads) {
+        const int64_t rel = jlo + i;                                           // batch-relative input index
+        float2 v = make_float2(0.f, 0.f);
+        if (rel >= 0) { if (rel < total) v = fe_mix(chan[rel], rel, dyn, sintab); }
+        else if (rel >= -(int64_t)hist_len) v = hist[hist_len + rel];          // history samples are stored mixed
+        s_in[i] = v;
+    }
+    __syncthreads();
+    // arbitrary stage: v[q], q in [lo[0], hi[0])  (outputs with q < 0 belong to the previous batch: recomputed from its history)
+    for (int i = tid; i < nv; i += kFeThreads) {
+        const int64_t P = (int64_t)dyn.phase0 + (lo[0] + i) * (int64_t)step;
+        const float *h = arms + (int)((P & 0xFFFFFF) >> 16) * kArmTaps;
+        const float2 *z = s_in + ((P >> 24) - (kArmTaps - 1) - jlo);
+        float ar = 0.f, ai = 0.f;
+#pragma unroll
+        for (int t = 0; t < kArmTaps; ++t) { ar = fmaf(h[t], z[t].x, ar); ai = fmaf(h[t], z[t].y, ai); }
+        w0[i] = make_float2(ar, ai);
+    }
+    __syncthreads();
+    // x2 stages: w'[2q] = w[q - m], w'[2q + 1] = sum_j h1[j] (w[q - j] + w[q - (2m - 1) + j])
+    float2 *src = w0, *dst = w1;
+    for (int st = 0; st < S; ++st) {
+        const int m = rs.m_x[st];
+        const int64_t olo = lo[st + 1], ilo = lo[st];
+        const int nout = (int)(hi[st + 1] - olo);
+        const int qoff = (int)((olo >> 1) - ilo), par0 = (int)(olo & 1);
+        for (int i = tid; i < nout; i += kFeThreads) {
+            const int a = i + par0, qi = qoff + (a >> 1);
+            float2 v;
+            if ((a & 1) == 0) v = src[qi - m];
+            else {
+                v = make_float2(0.f, 0.f);
+                for (int j = 0; j < m; ++j) {
+                    const float hj = rs.h_x[st][j];
+                    const float2 p = src[qi - j], q2 = src[qi - (2 * m - 1) + j];
+                    v.x = fmaf(hj, p.x + q2.x, v.x); v.y = fmaf(hj, p.y + q2.y, v.y);
+                }
+            }
+            dst[i] = v;
+        }
+        __syncthreads();
+        float2 *t = src; src = dst; dst = t;
+    }
+    for (int i = tid; i < (int)(A1 - A0); i += kFeThreads) iq_cur[kIqHist + A0 + i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // D2a: modem core of the auto-gain modems -> unscaled demodulator output d[j] for the block and the block maximum
 // (auto-gain input).   grid = (auto-gain slot, block), 256 threads
 //   AM      : d = FIR51(|x|)                                                     (ModemAM.cpp:41-47)

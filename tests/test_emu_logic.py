@@ -169,3 +169,9 @@ def test_emu_retune_skip_inactive(ctx):
 
 def test_emu_error_codes(ctx):
     G.test_error_codes_and_edge_inputs(ctx)
+
+
+@full
+def test_emu_interpolating_iq_resampler(ctx):
+    got, want = G._run_demods(ctx, 2400000, 4, 4000, ["FM", "NBFM"], 4, 2, bw=[800000, 12500], seed=21)
+    print(G._compare(got, want, "interp"))

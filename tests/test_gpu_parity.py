@@ -340,6 +340,15 @@ def test_wide_demodulators_many_samples_per_block(ctx):
     print(_compare(got, want, "wide"))
 
 
+def test_bandwidth_above_channel_rate_interpolating_iq_resampler(ctx):
+    """demodulator bandwidths above the channel rate (msresamp_crcf with rate > 1, DemodulatorWorkerThread.cpp:97-101): FM at
+    800 kHz (rate 1.33: arbitrary stage only) and 1.5 MHz (rate 2.5: arbitrary stage + one x2 half-band) on 600 kS/s channels,
+    next to an NBFM demodulator; 4 blocks in batches of 2 (block boundaries inside output chunks, history across batches)."""
+    got, want = _run_demods(ctx, 2400000, 4, 20000, ["FM", "NBFM", "FM"], 4, 2, bw=[800000, 12500, 1500000], seed=21)
+    assert got[0][0]["n_iq"] > 6000 and got[2][0]["n_iq"] > 12000
+    print(_compare(got, want, "interp"))
+
+
 def test_batched_equals_reference(ctx):
     """6 blocks in two batches of 3: results must equal the block-at-a-time reference (counts exact)."""
     got, want = _run_demods(ctx, 2400000, 4, 40000, ["NBFM", "AM", "USB"], 6, 3)
