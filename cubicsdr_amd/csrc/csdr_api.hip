@@ -836,7 +836,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     SlotDyn *dyns_h = b->dyns_h[ring].p;
     int *slot_list_h = b->slot_list_h[ring].p;
     BlockPlan *plans_h = b->plans_h[ring].p;
-    int n_run = 0, n_ag = 0, max_n_iq = 0, max_n_audio = 0, warm_max = 0, max_aS = 0, max_cw_audio = 0;
+    int n_run = 0, n_ag = 0, max_n_iq = 0, max_n_iq_ag = 0, max_n_audio = 0, warm_max = 0, max_aS = 0, max_cw_audio = 0;
     int *ag_list_h = slot_list_h + b->max_demods;
     // The per-slot walk below validates AND advances the host-side integer state (oscillator phases, resampler phases, buffer
     // parities).  A rejected batch must leave every slot as it was -- no kernel runs for it -- so the state is snapshotted and
@@ -943,7 +943,10 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         s.last_J = (int)Jtot; s.last_A = fe_only ? 0 : (int)(Qtot << ash);
         s.prev_J = (int)Jtot;
         warm_max = std::max(warm_max, s.warm); max_aS = std::max(max_aS, aS);
-        if (s.prm.modem != CSDR_MODEM_NBFM && s.prm.modem != CSDR_MODEM_FM && s.prm.modem != CSDR_MODEM_IQ && !fe_only) ag_list_h[n_ag++] = si;
+        if (s.prm.modem != CSDR_MODEM_NBFM && s.prm.modem != CSDR_MODEM_FM && s.prm.modem != CSDR_MODEM_IQ && !fe_only) {
+            ag_list_h[n_ag++] = si;
+            for (int bb = 0; bb < NB; ++bb) max_n_iq_ag = std::max(max_n_iq_ag, s.results[bb].n_iq);      // what the modem kernel stages per block
+        }
         slot_list_h[n_run++] = si;
     }
     b->n_run = n_run; b->last_nb = NB;
@@ -1002,14 +1005,14 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     };
     size_t fe_lds = 0;
     for (int i = 0; i < grp_n[0]; ++i) fe_lds = std::max(fe_lds, fe_lds_bytes((int)b->slots[grp_h[grp_off[0] + i]].iq.S));
-    const int cap_stream = (max_n_iq + kSsbWarm + 64 + 3) & ~3;
+    const int cap_stream = (max_n_iq_ag + kSsbWarm + 64 + 3) & ~3;
     // CW blocks run the complex audio interpolator in LDS: IQ window + two stage arrays of (block audio + Hilbert reach)
     const int cap_cw = max_cw_audio ? ((max_cw_audio + 4 * kHilbM + 64 + 3) & ~3) : 0;
     // LDS of the modem kernel, sized by the modems that actually run (a DSB slot stages the sine table and one block of IQ, a CW
     // slot the complex interpolator's arrays; AM / SSB need four float streams): an oversized request costs resident waves
     bool any_dsb = false;
     for (int i = 0; i < n_ag; ++i) any_dsb = any_dsb || b->slots[ag_list_h[i]].prm.modem == CSDR_MODEM_DSB;
-    const size_t dsb_lds = any_dsb ? 1024 * sizeof(float) + (size_t)(max_n_iq + 64) * sizeof(float2) : 0;
+    const size_t dsb_lds = any_dsb ? 1024 * sizeof(float) + (size_t)(max_n_iq_ag + 64) * sizeof(float2) : 0;
     const size_t cw_lds = cap_cw ? ((size_t)kCwIqWin + 2 * (size_t)cap_cw) * sizeof(float2) : 0;
     const size_t modem_lds = std::max(std::max((size_t)4 * cap_stream * sizeof(float), cw_lds), dsb_lds) + 64;
     // LDS of the audio kernel: two ping-pong arrays (stage outputs) and the staged demodulator window (decimating
