@@ -1064,7 +1064,14 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     if (grp_n[S_] > 0)                                                                                                                  \
         CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, (demod_frontend_s<S_, CH_>), dim3(ranges_for(grp_n[S_]) + 1, grp_n[S_]), dim3(kFeThreads), (fes_lds_bytes<S_, CH_>()), \
                     b->cfgs.p, dyns_d, grp_d + grp_off[S_], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p)
-    CSDR_FE_S(3, 2048); CSDR_FE_S(4, 2048); CSDR_FE_S(6, 2048);
+    CSDR_FE_S(3, 2048); CSDR_FE_S(4, 2048);
+    if (grp_n[6] > 0) {          // depth 6 (AM / SSB from ~500 kS/s channels): tail wave with three tail stages (CSDR_FE_TW6=0: without)
+        static const bool tw6 = !(getenv("CSDR_FE_TW6") && atoi(getenv("CSDR_FE_TW6")) == 0);
+        if (tw6)
+            CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, (demod_frontend_s<6, 2048, true>), dim3(ranges_for(grp_n[6]) + 1, grp_n[6]), dim3(kFeThreads + 64), (fes_lds_bytes<6, 2048>()),
+                        b->cfgs.p, dyns_d, grp_d + grp_off[6], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
+        else CSDR_FE_S(6, 2048);
+    }
     if (grp_n[7] > 0) {          // interpolating IQ resamplers: chunks of output samples
         int64_t jmax = 0;
         for (int i = 0; i < grp_n[7]; ++i) jmax = std::max<int64_t>(jmax, b->slots[grp_h[grp_off[7] + i]].last_J);

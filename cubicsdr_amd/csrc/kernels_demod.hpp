@@ -512,7 +512,7 @@ struct FesStages<S, CH, END, END, WAVE> {
     static __device__ inline void run(float2 *, float2 *, float2 *, const float *, float, int) {}
 };
 
-// TW (S = 5 only): a FIFTH wave owns the one-wave tail (stages S-2, S-1 and the arbitrary resampler).  It works one chunk behind
+// TW (S = 5, 6): a FIFTH wave owns the one-wave tail (the last two -- depth 6: three -- stages and the arbitrary resampler).  It works one chunk behind
 // the four worker waves, one piece per barrier interval, so the workers never wait for the tail at the head of the next chunk:
 //   workers      mix k | B1 | stage 0 | B2 | stage 1 | B3 | stage 2 (writes the tail's input of chunk k) | B4
 //   tail wave    stage S-2 of chunk k-1 (+ its carry) | B1 | Z tail, stage S-1 | B2 | resampler | B3 | - | B4
@@ -590,7 +590,8 @@ __global__ __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? 5 : 4) void demod_
 
     if constexpr (TW) {
         constexpr int BLK = fes_blk<S, CH>();
-        static_assert(S - BLK == 2 && BLK >= 1, "the tail wave schedule is laid out for two tail stages");
+        constexpr int NT = S - BLK;                               // tail stages: 2 (depth 5) or 3 (depth 6)
+        static_assert((NT == 2 || NT == 3) && BLK >= 1 && NT + 1 <= BLK + 1, "the tail wave schedule needs one barrier interval per tail piece");
         const bool tailw = tid >= kFeThreads;
         const int ltid = tid - kFeThreads;
         const int nch = (int)((u_stop - u_lo) / CH);
@@ -654,12 +655,16 @@ __global__ __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? 5 : 4) void demod_
                     FesStages<S, CH, BLK, BLK + 1, true>::run(LE, LO, LZ, hb, zeta, ltid);      // stage S-2 and the carry of its input
                 }
                 if (bar) __syncthreads();                                                       // B1
+                if constexpr (NT == 3) {
+                    if (have) { wave_sync(); FesStages<S, CH, BLK + 1, BLK + 2, true>::run(LE, LO, LZ, hb, zeta, ltid); }   // middle tail stage
+                    if (bar) __syncthreads();                                                   // B2
+                }
                 if (have) {
                     if (k >= 2 && ltid < kFeZTail) LZ[ltid] = LZ[CZ + ltid];                    // Z tail of the chunk before
                     wave_sync();
-                    FesStages<S, CH, BLK + 1, S, true>::run(LE, LO, LZ, hb, zeta, ltid);        // stage S-1 -> Z
+                    FesStages<S, CH, S - 1, S, true>::run(LE, LO, LZ, hb, zeta, ltid);          // stage S-1 -> Z
                 }
-                if (bar) __syncthreads();                                                       // B2
+                if (bar) __syncthreads();                                                       // B2 (B3 with three tail stages)
                 if (have) {
                     wave_sync();
                     if (jmine < jhi) {
@@ -674,7 +679,7 @@ __global__ __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? 5 : 4) void demod_
                     }
                     wave_sync();
                 }
-                if (bar) { for (int q = 2; q <= BLK; ++q) __syncthreads(); }                    // B3 .. B(BLK+1)
+                if (bar) { for (int q = NT; q <= BLK; ++q) __syncthreads(); }                   // the workers' remaining barriers of this chunk
             }
         }
         return;
