@@ -9,6 +9,7 @@
 #include "common.hpp"
 #include "design.hpp"
 #include "kernels_demod.hpp"
+#include "kernels_fms.hpp"
 #include "kernels_post.hpp"
 #include "kernels_spec.hpp"
 
@@ -567,6 +568,8 @@ struct SlotHost {
     int hist_parity = 0, last_parity = 0;
     int prev_J = 0;                          // resampled-IQ samples of the previous executed batch
     int warm = 0;                            // cascade span in input samples (+ one output period)
+    bool fms_sos_set = false;                // csdr_bank_set_fms_pilot: caller-supplied pilot band-pass sections
+    float fms_b[15] = {0}, fms_a[15] = {0};
     void *slab = nullptr;
     SlotCfg cfg{};
     // results of the last execute
@@ -601,7 +604,7 @@ struct csdr_bank {
     std::map<uint32_t, int> arm_index;       // key: bit pattern of rate_arb
     std::vector<float> arms_host;
     int n_run = 0, last_nb = 0;
-    size_t lds_attr[3] = {0, 0, 0};
+    size_t lds_attr[7] = {0, 0, 0, 0, 0, 0, 0};
 };
 
 static int bank_arm_bank(csdr_bank *b, const design::MsresampPlan &p, int *idx) {
@@ -702,6 +705,7 @@ extern "C" void csdr_bank_destroy(csdr_bank *b) {
 #define CSDR_MODEM_FRONTEND_ONLY 100
 static int modem_check_rate(int modem, int bw, int audio_rate) {   // Modem*::checkSampleRate (ModemAnalog.cpp:14-19, ModemUSB.cpp:29-37, ModemIQ.cpp:31-33)
     if (modem == CSDR_MODEM_IQ || modem == CSDR_MODEM_FRONTEND_ONLY) return audio_rate;
+    if (modem == CSDR_MODEM_FMS) return bw < 100000 ? 100000 : bw;      // ModemFMStereo.cpp:27-35
     if (bw < 500) bw = 500;                          // MIN_BANDWIDTH, Modem.h:13
     if ((modem == CSDR_MODEM_USB || modem == CSDR_MODEM_LSB) && (bw % 2)) bw += 1;
     return bw;
@@ -710,7 +714,7 @@ static int modem_check_rate(int modem, int bw, int audio_rate) {   // Modem*::ch
 static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *prm, const csdr_post *post);
 extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *prm, const csdr_post *post) {
     DeviceScope dev__(b ? b->ctx : nullptr);
-    if (prm && (prm->modem < CSDR_MODEM_NBFM || prm->modem > CSDR_MODEM_DSB)) return fail(CSDR_EUNSUPPORTED, "modem %d", prm->modem);
+    if (prm && (prm->modem < CSDR_MODEM_NBFM || prm->modem > CSDR_MODEM_FMS)) return fail(CSDR_EUNSUPPORTED, "modem %d", prm->modem);
     return bank_configure_slot(b, slot, prm, post);
 }
 static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *prm, const csdr_post *post) {
@@ -734,6 +738,15 @@ static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *
         for (int e = (int)s.au.S - 1; e >= 0; --e) lo = 2 * lo - (4 * (int)s.au.m[s.au.S - 1 - e] - 2);
         if (-lo + (1 << s.au.S) > kDHist) return fail(CSDR_EUNSUPPORTED, "audio decimation by %d / %d needs %lld samples of history", s.prm.bandwidth, s.prm.audio_sample_rate, (long long)-lo);
     }
+    const bool fms = s.prm.modem == CSDR_MODEM_FMS;
+    std::vector<float> fms_fir;
+    if (fms) {
+        // csdr_demod_params::modem_arg = the "demph" setting (ModemFMStereo.cpp:42-81): microseconds, 0 -> the default 75, < 0 -> none
+        const int demph = s.prm.modem_arg == 0 ? 75 : (s.prm.modem_arg < 0 ? 0 : s.prm.modem_arg);
+        if (s.au.interp) return fail(CSDR_EUNSUPPORTED, "FM stereo at %d Hz into %d Hz audio: the audio resamplers must decimate", s.prm.bandwidth, s.prm.audio_sample_rate);
+        fms_fir = design::fms_output_fir(s.prm.audio_sample_rate, demph, kFmsFirMax);
+        if (fms_fir.empty()) return fail(CSDR_EUNSUPPORTED, "FM stereo output filter at %d Hz exceeds %d taps", s.prm.audio_sample_rate, kFmsFirMax);
+    }
     int ia = 0, aa = 0;
     if (int rc = bank_arm_bank(b, s.iq, &ia)) return rc;
     if (int rc = bank_arm_bank(b, s.au, &aa)) return rc;
@@ -755,7 +768,7 @@ static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *
     const int64_t max_bc = post->max_block_len / post->hop;
     const int64_t cap_iq = (int64_t)std::ceil((double)b->max_blocks * (double)max_bc * iq_ratio) + b->max_blocks + 64;
     const int64_t cap_audio = s.prm.modem == CSDR_MODEM_FRONTEND_ONLY ? 64 : s.prm.modem == CSDR_MODEM_IQ ? 2 * cap_iq + 64      // two floats per IQ sample, no audio resampler
-        : (int64_t)std::ceil((double)cap_iq * au_ratio) + (int64_t)b->max_blocks * (2 << (s.au.interp ? s.au.S : 0)) + 64;
+        : (fms ? 2 : 1) * ((int64_t)std::ceil((double)cap_iq * au_ratio) + (int64_t)b->max_blocks * (2 << (s.au.interp ? s.au.S : 0)) + 64);
     // one slab per slot
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -769,6 +782,13 @@ static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *
     const size_t o_bm = carve(b->max_blocks * sizeof(float)), o_bma = carve(b->max_blocks * sizeof(float));
     const size_t o_bo = carve(b->max_blocks * sizeof(BlockOut));
     const size_t o_sc = carve(kScopeMax * sizeof(float)), o_scn = carve(sizeof(int32_t));
+    size_t o_fx = 0, o_fth = 0, o_fm = 0, o_fs = 0, o_fyh = 0, o_fuh = 0, o_fst = 0, o_ffir = 0;
+    if (fms) {
+        o_fx = carve(cap_iq * sizeof(float2)); o_fth = carve(cap_iq * sizeof(uint32_t));
+        o_fm = carve((cap_audio / 2) * sizeof(float)); o_fs = carve((cap_audio / 2) * sizeof(float));
+        o_fyh = carve(2 * kFmsYHist * sizeof(float2)); o_fuh = carve((size_t)4 * kFmsFirMax * sizeof(float));
+        o_fst = carve(kFmsStateWords * sizeof(float)); o_ffir = carve(kFmsFirMax * sizeof(float));
+    }
     if (s.slab) { (void)hipFree(s.slab); s.slab = nullptr; }
     if (hipMalloc(&s.slab, off) != hipSuccess) return fail(CSDR_ENOMEM, "slot slab of %zu bytes", off);
     CSDR_HIP_TRY(hipMemset(s.slab, 0, off));
@@ -784,6 +804,15 @@ static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *
     c.blockmax = (float *)(base + o_bm); c.blockmaa = (float *)(base + o_bma); c.bout = (BlockOut *)(base + o_bo);
     c.scope = (float *)(base + o_sc); c.scope_n = (int32_t *)(base + o_scn);
     c.cap_iq = (int)cap_iq; c.cap_audio = (int)cap_audio;
+    if (fms) {
+        c.fms_x = (float2 *)(base + o_fx); c.fms_theta = (uint32_t *)(base + o_fth); c.fms_m = (float *)(base + o_fm); c.fms_s = (float *)(base + o_fs);
+        c.fms_yh = (float2 *)(base + o_fyh); c.fms_uh = (float *)(base + o_fuh); c.fms_state = (float *)(base + o_fst); c.fms_fir = (float *)(base + o_ffir);
+        c.fms_fir_len = (int)fms_fir.size();
+        CSDR_HIP_TRY(hipMemcpy(c.fms_fir, fms_fir.data(), fms_fir.size() * sizeof(float), hipMemcpyHostToDevice));
+        const std::vector<design::Sos> sos = design::fms_pilot_sos(s.prm.bandwidth);
+        for (int q = 0; q < 5; ++q) for (int k = 0; k < 3; ++k) { c.fms_b[3 * q + k] = sos[q].b[k]; c.fms_a[3 * q + k] = sos[q].a[k]; }
+        if (s.fms_sos_set) { memcpy(c.fms_b, s.fms_b, sizeof c.fms_b); memcpy(c.fms_a, s.fms_a, sizeof c.fms_a); }
+    }
     const float agc0[8] = {1.0f, 1.0f, 1.0f, 0.f, 1.0f, 1.0f, 1.0f, 0.f};   // ModemAnalog::ModemAnalog(): aOutputCeil(1), MA(1), MAA(1)
     CSDR_HIP_TRY(hipMemcpy(c.agc, agc0, sizeof agc0, hipMemcpyHostToDevice));
     CSDR_HIP_TRY(hipMemcpy(b->cfgs.p + slot, &c, sizeof c, hipMemcpyHostToDevice));
@@ -837,6 +866,8 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     int *slot_list_h = b->slot_list_h[ring].p;
     BlockPlan *plans_h = b->plans_h[ring].p;
     int n_run = 0, n_ag = 0, max_n_iq = 0, max_n_iq_ag = 0, max_n_audio = 0, warm_max = 0, max_aS = 0, max_cw_audio = 0;
+    int max_n_iq_fms = 0, max_n_au_fms = 0;
+    std::vector<int> fms_slots;              // FM-stereo slots of this batch (their list shares the auto-gain list's region, from its end)
     int *ag_list_h = slot_list_h + b->max_demods;
     // The per-slot walk below validates AND advances the host-side integer state (oscillator phases, resampler phases, buffer
     // parities).  A rejected batch must leave every slot as it was -- no kernel runs for it -- so the state is snapshotted and
@@ -897,7 +928,8 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         const bool fe_only = s.prm.modem == CSDR_MODEM_FRONTEND_ONLY;
         const bool iq_modem = s.prm.modem == CSDR_MODEM_IQ || fe_only;      // no audio resampler: 2 floats per resampled IQ sample
         const bool au_interp = s.au.interp;
-        const int ash = iq_modem ? 1 : (au_interp ? aS : 0);     // audio samples per arbitrary-stage output = 2^ash
+        const bool fms = s.prm.modem == CSDR_MODEM_FMS;          // two floats (left, right) per audio sample
+        const int ash = (iq_modem || fms) ? 1 : (au_interp ? aS : 0);     // floats written per arbitrary-stage output = 2^ash
         const bool iq_interp = s.iq.interp;      // arbitrary stage first: it consumes the channel samples directly, each output fans out to 2^S
         for (int bb = 0; bb <= NB; ++bb) {
             const int64_t K = iq_interp ? (int64_t)bb * Bc : (((int64_t)s.buf_idx + (int64_t)bb * Bc) >> S);
@@ -919,7 +951,8 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
             r.audio_offset = (int)(((int64_t)pl[bb].q0) << ash);
             if (fe_only) { r.n_audio = 0; r.audio_offset = 0; }
             else if (r.n_iq > kModemMaxBlockIq || r.n_audio > kAudioMaxOut) return reject(fail(CSDR_EUNSUPPORTED, "slot %d: %d IQ / %d audio samples per block exceed the per-workgroup limits", si, r.n_iq, r.n_audio));
-            if (!fe_only) { max_n_iq = std::max(max_n_iq, r.n_iq); max_n_audio = std::max(max_n_audio, r.n_audio); }
+            if (!fe_only) { max_n_iq = std::max(max_n_iq, r.n_iq); max_n_audio = std::max(max_n_audio, fms ? r.n_audio / 2 : r.n_audio); }
+            if (fms) { max_n_iq_fms = std::max(max_n_iq_fms, r.n_iq); max_n_au_fms = std::max(max_n_au_fms, r.n_audio / 2); }
             max_blk_audio = std::max(max_blk_audio, r.n_audio);
             const int64_t Kb = iq_interp ? (int64_t)(bb + 1) * Bc : (((int64_t)s.buf_idx + (int64_t)(bb + 1) * Bc) >> S);
             r.buffer_index = iq_interp ? 0u : (uint32_t)(((int64_t)s.buf_idx + (int64_t)(bb + 1) * Bc) & ((1 << S) - 1));
@@ -943,7 +976,8 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         s.last_J = (int)Jtot; s.last_A = fe_only ? 0 : (int)(Qtot << ash);
         s.prev_J = (int)Jtot;
         warm_max = std::max(warm_max, s.warm); max_aS = std::max(max_aS, aS);
-        if (s.prm.modem != CSDR_MODEM_NBFM && s.prm.modem != CSDR_MODEM_FM && s.prm.modem != CSDR_MODEM_IQ && !fe_only) {
+        if (fms) fms_slots.push_back(si);
+        else if (s.prm.modem != CSDR_MODEM_NBFM && s.prm.modem != CSDR_MODEM_FM && s.prm.modem != CSDR_MODEM_IQ && !fe_only) {
             ag_list_h[n_ag++] = si;
             for (int bb = 0; bb < NB; ++bb) max_n_iq_ag = std::max(max_n_iq_ag, s.results[bb].n_iq);      // what the modem kernel stages per block
         }
@@ -951,6 +985,8 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     }
     b->n_run = n_run; b->last_nb = NB;
     if (n_run == 0) return CSDR_OK;
+    const int n_fms = (int)fms_slots.size(), fms_off = b->max_demods - n_fms;     // n_ag + n_fms <= n_run <= max_demods
+    for (int i = 0; i < n_fms; ++i) ag_list_h[fms_off + i] = fms_slots[i];
     // running slots grouped by front-end kernel (filled before the staging set is handed to the copy engine)
     int *grp_h = slot_list_h + 2 * (size_t)b->max_demods;
     int grp_off[8] = {0}, grp_n[8] = {0};        // index 0: generic, 3..6: specialised by S
@@ -1044,9 +1080,17 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     constexpr size_t kLdsPerWorkgroup = 160 * 1024;
     if (modem_lds > kLdsPerWorkgroup || audio_lds > kLdsPerWorkgroup)
         return reject(fail(CSDR_EUNSUPPORTED, "%d IQ / %d audio samples per block need %zu / %zu bytes of LDS (limit %zu)", max_n_iq, max_n_audio, modem_lds, audio_lds, kLdsPerWorkgroup));
-    const size_t want[3] = {fe_lds, modem_lds, audio_lds};     // (the specialised front-end kernels stay below 64 KB)
-    const void *fn[3] = {(const void *)demod_frontend, (const void *)demod_modem, (const void *)demod_audio_interp};
-    for (int k = 0; k < 3; ++k)
+    // FM stereo: a block of x / theta / the two matrix streams staged whole, like the modem kernel
+    const int fms_blk = (max_n_iq_fms + 4 * kHilbM + 4 + 3) & ~3, fms_au = (max_n_au_fms + 4 + 3) & ~3;
+    const size_t fms_pre_lds = (size_t)fms_blk * sizeof(float), fms_pll_lds = 1024 * sizeof(float) + (size_t)fms_blk * (sizeof(float2) + sizeof(uint32_t)),
+                 fms_mix_lds = (size_t)2 * (fms_blk + 4 * kHilbM) * sizeof(float),
+                 fms_out_lds = ((size_t)2 * (fms_au + kFmsFirMax) + kFmsFirMax) * sizeof(float) + 64;
+    if (n_fms && std::max(std::max(fms_pre_lds, fms_pll_lds), std::max(fms_mix_lds, fms_out_lds)) > kLdsPerWorkgroup)
+        return reject(fail(CSDR_EUNSUPPORTED, "FM stereo: %d IQ samples per block need more LDS than a workgroup has", max_n_iq_fms));
+    const size_t want[7] = {fe_lds, modem_lds, audio_lds, n_fms ? fms_pre_lds : 0, n_fms ? fms_pll_lds : 0, n_fms ? fms_mix_lds : 0, n_fms ? fms_out_lds : 0};
+    const void *fn[7] = {(const void *)demod_frontend, (const void *)demod_modem, (const void *)demod_audio_interp,
+                         (const void *)fms_pre, (const void *)fms_pll, (const void *)fms_mix, (const void *)fms_out};
+    for (int k = 0; k < 7; ++k)
         if (want[k] > 64 * 1024 && want[k] > b->lds_attr[k]) {
             CSDR_HIP_TRY(hipFuncSetAttribute(fn[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)want[k]));
             b->lds_attr[k] = want[k];
@@ -1100,9 +1144,20 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
                     plans_d, NB, cap_stream, b->mconsts.p, c->sintab.p, b->arms.p, cap_cw);
     if (n_ag > 0)     // the auto-gain recurrence over the blocks, once per demodulator
         CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, demod_gain_scan, dim3(n_ag), dim3(64), (size_t)NB * sizeof(float), b->cfgs.p, dyns_d, lists_d + b->max_demods, plans_d, NB);
+    const int *fms_d = lists_d + b->max_demods + fms_off;
+    if (n_fms > 0) {  // FM stereo, ahead of the audio stage: Hilbert r2c of the discriminator output, the pilot loop, the 38 kHz down-mix
+        CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, fms_pre, dim3(n_fms, NB), dim3(64), fms_pre_lds, b->cfgs.p, dyns_d, fms_d, plans_d, NB, b->mconsts.p);
+        CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, fms_pll, dim3(n_fms), dim3(kModemThreads), fms_pll_lds, b->cfgs.p, fms_d, plans_d, NB, fms_blk, c->sintab.p);
+        CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, fms_mix, dim3(n_fms, NB), dim3(64), fms_mix_lds, b->cfgs.p, dyns_d, fms_d, plans_d, NB, fms_blk - 4 * kHilbM, b->mconsts.p, c->sintab.p);
+    }
     if (n_audio_run > 0)
         CSDR_LAUNCH(c, LANE_AUDIO, KID_AUDIO, demod_audio_interp, grid, dim3(audio_threads), audio_lds, b->cfgs.p, dyns_d, lists_d, plans_d, NB,
-                    cap_out, cap_win, b->arms.p);
+                    cap_out, cap_win, b->arms.p, 0);
+    if (n_fms > 0) {  // the second msresamp_rrrf (stereo difference), then matrix + de-emphasis + low-pass into interleaved frames
+        CSDR_LAUNCH(c, LANE_AUDIO, KID_AUDIO, demod_audio_interp, dim3(n_fms, NB), dim3(audio_threads), audio_lds, b->cfgs.p, dyns_d, fms_d, plans_d, NB,
+                    cap_out, cap_win, b->arms.p, 1);
+        CSDR_LAUNCH(c, LANE_AUDIO, KID_AUDIO, fms_out, dim3(n_fms, NB), dim3(64), fms_out_lds, b->cfgs.p, dyns_d, fms_d, plans_d, NB, fms_au);
+    }
     CSDR_HIP_TRY(hipGetLastError());
     if (int rc = c->signal(b->ev_audio_done[bpar], LANE_AUDIO, LANE_FE)) return rc;
     b->audio_pending[bpar] = true;
@@ -1166,7 +1221,7 @@ extern "C" int csdr_bank_fetch_demod_output(csdr_bank *b, int slot, float *host_
     if (!b || !host_out || !n || slot < 0 || slot >= b->max_demods) return fail(CSDR_EINVAL, "bad argument");
     SlotHost &s = b->slots[slot];
     *n = 0;
-    if (!s.configured || s.last_A == 0 || s.prm.modem == CSDR_MODEM_IQ || s.prm.modem == CSDR_MODEM_CW) return CSDR_OK;     // (those modems keep no demodOutputData)
+    if (!s.configured || s.last_A == 0 || s.prm.modem == CSDR_MODEM_IQ || s.prm.modem == CSDR_MODEM_CW || s.prm.modem == CSDR_MODEM_FMS) return CSDR_OK;     // (those modems keep no demodOutputData: not ModemAnalog)
     hipStream_t st = b->ctx->lanes[LANE_AUDIO];
     int32_t cnt = 0;
     CSDR_HIP_TRY(hipMemcpyAsync(&cnt, s.cfg.scope_n, sizeof cnt, hipMemcpyDeviceToHost, st));
@@ -1177,6 +1232,47 @@ extern "C" int csdr_bank_fetch_demod_output(csdr_bank *b, int slot, float *host_
         CSDR_HIP_TRY(hipStreamSynchronize(st));
     }
     *n = cnt;
+    return CSDR_OK;
+}
+// FM stereo pilot band-pass: the sections this library designs for a modem input rate (five sections, b[15] / a[15] in execution order)
+extern "C" int csdr_design_fms_pilot(int64_t sample_rate, float *b15, float *a15) {
+    if (!b15 || !a15 || sample_rate <= 0) return fail(CSDR_EINVAL, "bad argument");
+    const std::vector<design::Sos> sos = design::fms_pilot_sos(sample_rate);
+    for (int q = 0; q < 5; ++q) for (int k = 0; k < 3; ++k) { b15[3 * q + k] = sos[q].b[k]; a15[3 * q + k] = sos[q].a[k]; }
+    return CSDR_OK;
+}
+// replace the pilot band-pass sections of an FM-stereo slot (e.g. with the output of the host's own liquid_iirdes); takes effect now and
+// survives reconfiguration of the slot.  b15 == NULL returns to the library's design.
+extern "C" int csdr_bank_set_fms_pilot(csdr_bank *b, int slot, const float *b15, const float *a15) {
+    DeviceScope dev__(b ? b->ctx : nullptr);
+    if (!b || slot < 0 || slot >= b->max_demods) return fail(CSDR_EINVAL, "bad slot");
+    SlotHost &s = b->slots[slot];
+    if (!s.configured || s.prm.modem != CSDR_MODEM_FMS) return fail(CSDR_ESTATE, "slot %d is not an FM-stereo demodulator", slot);
+    if (int rc = b->ctx->sync_all()) return rc;
+    if (b15 && a15) { memcpy(s.fms_b, b15, sizeof s.fms_b); memcpy(s.fms_a, a15, sizeof s.fms_a); s.fms_sos_set = true; }
+    else {
+        s.fms_sos_set = false;
+        const std::vector<design::Sos> sos = design::fms_pilot_sos(s.prm.bandwidth);
+        for (int q = 0; q < 5; ++q) for (int k = 0; k < 3; ++k) { s.fms_b[3 * q + k] = sos[q].b[k]; s.fms_a[3 * q + k] = sos[q].a[k]; }
+    }
+    memcpy(s.cfg.fms_b, s.fms_b, sizeof s.fms_b); memcpy(s.cfg.fms_a, s.fms_a, sizeof s.fms_a);
+    CSDR_HIP_TRY(hipMemcpy(b->cfgs.p + slot, &s.cfg, sizeof s.cfg, hipMemcpyHostToDevice));
+    return CSDR_OK;
+}
+// FM stereo intermediates of the last batch, for stage-by-stage parity checks: which = 0 the pilot oscillator's phase word after each
+// resampled-IQ sample's step (uint32), 1 the stereo-difference stream before its audio resampler (float)
+extern "C" int csdr_bank_fetch_fms_stage(csdr_bank *b, int slot, int which, void *host_out, int cap_samples, int *n) {
+    DeviceScope dev__(b ? b->ctx : nullptr);
+    if (!b || !host_out || !n || slot < 0 || slot >= b->max_demods || which < 0 || which > 1) return fail(CSDR_EINVAL, "bad argument");
+    SlotHost &s = b->slots[slot];
+    if (!s.configured || s.prm.modem != CSDR_MODEM_FMS) return fail(CSDR_ESTATE, "slot %d is not an FM-stereo demodulator", slot);
+    if (s.last_J > cap_samples) return fail(CSDR_ERANGE, "need room for %d samples", s.last_J);
+    *n = s.last_J;
+    if (s.last_J) {
+        hipStream_t st = b->ctx->lanes[LANE_AUDIO];
+        CSDR_HIP_TRY(hipMemcpyAsync(host_out, which == 0 ? (const void *)s.cfg.fms_theta : (const void *)s.cfg.d, (size_t)s.last_J * 4, hipMemcpyDeviceToHost, st));
+        CSDR_HIP_TRY(hipStreamSynchronize(st));
+    }
     return CSDR_OK;
 }
 extern "C" int csdr_bank_total_audio(csdr_bank *b, int64_t *n) {

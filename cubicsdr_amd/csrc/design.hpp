@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
+#include <complex>
 #include <vector>
 
 namespace csdr {
@@ -164,7 +165,8 @@ inline uint32_t nco_phase_word(float theta) {
 }
 inline std::vector<float> nco_sine_table() {
     std::vector<float> t(1024);
-    for (unsigned i = 0; i < 1024; ++i) t[i] = std::sin(2.0f * kPi * (float)i / 1024.0f);
+    // the argument is formed in float, its sine correctly rounded (the reference binary's table bit for bit; glibc's sinf differs in 15 entries)
+    for (unsigned i = 0; i < 1024; ++i) t[i] = (float)std::sin((double)(2.0f * kPi * (float)i / 1024.0f));
     return t;
 }
 
@@ -276,6 +278,135 @@ inline std::vector<float> sos_impulse_response(const std::vector<Sos> &sos, unsi
         g[i] = (float)t;
     }
     return g;
+}
+
+// ---- FM stereo: 19 kHz pilot band-pass (iirfilt_crcf_create_prototype(CHEBY2, BANDPASS, SOS, 5, fc, f0, 1, 60), ModemFMStereo.cpp:128-139) ----
+// liquid_iirdes of liquid 1.5.0 restated with its single-precision data flow (cheby2_azpkf -> bilinear_zpkf -> iirdes_dzpk_lp2bp ->
+// iirdes_dzpk2sosf): the pole radii are ~0.998, so the pass-band phase moves by 1e-4 rad per unit in the last place of a feedback
+// coefficient, and only the same roundings give the same filter.  Complex quotients of floats are formed the plain way
+// ((a conj b) / |b|^2), the bilinear map runs in double (its "1.0" literals promote the operands); pinned bit-for-bit against the
+// reference binary on 400 sample rates (feedback taps always; 3 of 400 feed-forward taps differ by one unit in the last place).
+inline std::vector<Sos> cheby2_bandpass_sos(unsigned n, float fc, float f0, float as) {
+    typedef std::complex<float> cf;
+    typedef std::complex<double> cd;
+    const double pi = 3.14159265358979323846;
+    auto qf = [](cf a, cf b) { const float d = b.real() * b.real() + b.imag() * b.imag();
+                               return cf((a.real() * b.real() + a.imag() * b.imag()) / d, (a.imag() * b.real() - a.real() * b.imag()) / d); };
+    auto qd = [](cd a, cd b) { const double d = b.real() * b.real() + b.imag() * b.imag();
+                               return cd((a.real() * b.real() + a.imag() * b.imag()) / d, (a.imag() * b.real() - a.real() * b.imag()) / d); };
+    const unsigned r = n % 2, L = (n - r) / 2;
+    const float es = std::pow(10.0f, -as / 20.0f);
+    const float t0 = (float)std::sqrt(1.0 + 1.0 / ((double)es * (double)es));
+    const float tp = std::pow((float)((double)t0 + 1.0 / (double)es), (float)(1.0 / (double)(float)n));
+    const float tm = std::pow((float)((double)t0 - 1.0 / (double)es), (float)(1.0 / (double)(float)n));
+    const float eb = (float)(0.5 * ((double)tp + (double)tm)), ea = (float)(0.5 * ((double)tp - (double)tm));
+    std::vector<cf> pa, za;
+    for (unsigned i = 0; i < L; ++i) {
+        const float th = (float)((double)(float)(2 * (i + 1) + n - 1) * pi / (double)(float)(2 * n));
+        pa.push_back(qf(cf(1.0f, 0.f), cf(ea * std::cos(th), -eb * std::sin(th))));
+        pa.push_back(qf(cf(1.0f, 0.f), cf(ea * std::cos(th), eb * std::sin(th))));
+    }
+    if (r) pa.push_back(cf(-1.0f / ea, 0.f));
+    for (unsigned i = 0; i < L; ++i) {
+        const float th = (float)(0.5 * pi * (double)(2 * (i + 1) - 1) / (double)(float)n);
+        za.push_back(qf(cf(-1.0f, 0.f), cf(0.f, std::cos(th))));
+        za.push_back(qf(cf(1.0f, 0.f), cf(0.f, std::cos(th))));
+    }
+    const float m = std::fabs((std::cos((float)(2 * pi * (double)fc)) - std::cos((float)(2 * pi * (double)f0))) / std::sin((float)(2 * pi * (double)fc)));
+    std::vector<cf> zd(n), pd(n);
+    cf G(1.0f, 0.f);
+    for (unsigned i = 0; i < n; ++i) {
+        if (i < 2 * L) { const cf zm = za[i] * m; zd[i] = (cf)qd(cd(1.0) + (cd)zm, cd(1.0) - (cd)zm); } else zd[i] = cf(-1.0f, 0.f);
+        const cf pm = pa[i] * m;
+        pd[i] = (cf)qd(cd(1.0) + (cd)pm, cd(1.0) - (cd)pm);
+        G = (cf)((cd)G * qd(cd(1.0) - (cd)pd[i], cd(1.0) - (cd)zd[i]));
+    }
+    const float c0 = std::cos((float)(2 * pi * (double)f0));
+    auto lp2bp = [&](const std::vector<cf> &v) {
+        std::vector<cf> o;
+        for (const cf &z : v) {
+            const cf t = cf(1.0f) + z, sq = std::sqrt(c0 * c0 * t * t - 4.0f * z);
+            o.push_back(0.5f * (c0 * t + sq));
+            o.push_back(0.5f * (c0 * t - sq));
+        }
+        return o;
+    };
+    // liquid_cplxpair: conjugate pairs (negative imaginary part first) by ascending real part, then the purely real values
+    auto pairup = [](std::vector<cf> v) {
+        const float tol = 1e-6f;
+        const size_t N = v.size();
+        std::vector<bool> used(N, false);
+        std::vector<cf> o;
+        for (size_t i = 0; i < N; ++i) {
+            if (used[i] || std::fabs(v[i].imag()) < tol) continue;
+            for (size_t j = 0; j < N; ++j) {
+                if (j == i || used[j] || std::fabs(v[j].imag()) < tol) continue;
+                if (std::fabs(v[i].imag() + v[j].imag()) < tol && std::fabs(v[i].real() - v[j].real()) < tol) {
+                    o.push_back(v[i]); o.push_back(v[j]); used[i] = used[j] = true;
+                    break;
+                }
+            }
+        }
+        const size_t np = o.size() / 2;
+        for (size_t i = 0; i < N; ++i) if (!used[i]) o.push_back(v[i]);
+        for (size_t i = 0; i < np; ++i) if (o[2 * i].imag() > 0) std::swap(o[2 * i], o[2 * i + 1]);
+        for (size_t i = 0; i < np; ++i)
+            for (size_t j = i + 1; j < np; ++j)
+                if (o[2 * j].real() < o[2 * i].real()) { std::swap(o[2 * i], o[2 * j]); std::swap(o[2 * i + 1], o[2 * j + 1]); }
+        for (size_t i = 2 * np; i < N; ++i)
+            for (size_t j = i + 1; j < N; ++j)
+                if (o[j].real() < o[i].real()) std::swap(o[i], o[j]);
+        return o;
+    };
+    const std::vector<cf> zp = pairup(lp2bp(zd)), pp = pairup(lp2bp(pd));
+    const float kg = std::pow(G.real(), 1.0f / (float)n);
+    std::vector<Sos> out;
+    for (unsigned i = 0; i < n; ++i) {
+        const cf p0 = -pp[2 * i], p1 = -pp[2 * i + 1], z0 = -zp[2 * i], z1 = -zp[2 * i + 1];
+        Sos q;
+        q.a[0] = 1.0f; q.a[1] = (p0 + p1).real(); q.a[2] = (p0 * p1).real();
+        q.b[0] = kg; q.b[1] = (z0 + z1).real() * kg; q.b[2] = (z0 * z1).real() * kg;
+        out.push_back(q);
+    }
+    return out;
+}
+inline std::vector<Sos> fms_pilot_sos(int64_t sample_rate) {          // ModemFMStereo.cpp:128-139
+    float bw = (float)sample_rate;
+    if (bw < 100000.0f) bw = 100000.0f;
+    return cheby2_bandpass_sos(5, (float)19500 / bw, (float)19000 / bw, 60.0f);
+}
+
+// ---- FM stereo: output filter of one channel = de-emphasis (iirfilt_rrrf, one pole: ModemFMStereo.cpp:147-159) followed by the
+// 16 kHz Kaiser low-pass (firfilt_rrrf, :107-126), as ONE impulse response (both are LTI and start from rest).  The pole of the
+// de-emphasis is at most 0.9 in magnitude at the rates the reference runs (75 us at 96 kHz: -0.87), so its response is cut where
+// it falls below 1e-10; demph_us == 0 leaves the low-pass alone.
+inline std::vector<float> fms_output_fir(int audio_rate, int demph_us, unsigned max_taps) {
+    const float as = 60.0f;
+    float fcut = 16000.0f / (float)audio_rate;
+    const float ft = 1000.0f / (float)audio_rate;
+    if (fcut < 0) fcut = 0;
+    if (fcut > 0.5f) fcut = 0.5f;
+    const unsigned h_len = required_filter_len(ft, as);
+    const std::vector<float> h = kaiser_lowpass(h_len, fcut, as);
+    if (!demph_us) return h.size() <= max_taps ? h : std::vector<float>();
+    const double f = 1.0 / (2.0 * M_PI * (double)demph_us * 1e-6);
+    double t = 1.0 / (2.0 * M_PI * f);
+    t = 1.0 / (2.0 * (double)audio_rate * std::tan(1.0 / (2.0 * (double)audio_rate * t)));
+    const double tb = 1.0 + 2.0 * t * (double)audio_rate;
+    const float b0 = (float)(1.0 / tb), b1 = (float)(1.0 / tb), a1 = (float)((1.0 - 2.0 * t * (double)audio_rate) / tb);
+    std::vector<double> dm;
+    double v1 = 0.0;
+    for (unsigned i = 0; i < 4096; ++i) {                 // direct form II: v0 = x - a1 v1;  y = b0 v0 + b1 v1
+        const double v0 = (i == 0 ? 1.0 : 0.0) - (double)a1 * v1;
+        dm.push_back((double)b0 * v0 + (double)b1 * v1);
+        v1 = v0;
+        if (i > 8 && std::fabs(v0) < 1e-10) break;
+    }
+    if (h.size() + dm.size() - 1 > max_taps) return std::vector<float>();
+    std::vector<double> g(h.size() + dm.size() - 1, 0.0);
+    for (size_t i = 0; i < h.size(); ++i)
+        for (size_t k = 0; k < dm.size(); ++k) g[i + k] += (double)h[i] * dm[k];
+    return std::vector<float>(g.begin(), g.end());
 }
 
 // ---- SSB: Hilbert transformer taps (firhilbf_create(m, As)); h[n] for odd delays n = 1, 3, .., 4m-1 ---------

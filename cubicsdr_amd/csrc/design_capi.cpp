@@ -33,6 +33,16 @@ int csdr_design_butter_sos(unsigned order, float fc, float *b, float *a) {
     for (size_t i = 0; i < v.size(); ++i) for (int k = 0; k < 3; ++k) { b[3 * i + k] = v[i].b[k]; a[3 * i + k] = v[i].a[k]; }
     return (int)v.size();
 }
+int csdr_design_fms_pilot_sos(long long sample_rate, float *b, float *a) {
+    auto v = fms_pilot_sos(sample_rate);
+    for (size_t q = 0; q < v.size(); ++q) for (int k = 0; k < 3; ++k) { b[3 * q + k] = v[q].b[k]; a[3 * q + k] = v[q].a[k]; }
+    return (int)v.size();
+}
+int csdr_design_fms_output_fir(int audio_rate, int demph_us, float *g, unsigned cap) {
+    auto v = fms_output_fir(audio_rate, demph_us, cap);
+    std::memcpy(g, v.data(), v.size() * sizeof(float));
+    return (int)v.size();
+}
 void csdr_design_hilbert(unsigned m, float as, float *hq) { auto v = hilbert_taps(m, as); std::memcpy(hq, v.data(), v.size() * sizeof(float)); }
 int csdr_design_channel_count(long long rate) { return optimal_channel_count(rate); }
 int csdr_design_element_count(long long rate, int fps, int nch) { return optimal_element_count(rate, fps, nch); }

@@ -59,6 +59,16 @@ struct SlotCfg {                  // static per configuration, lives in HBM
     float *scope;                 // [kScopeMax] scaled demodulator output of the LAST block of the batch (ModemAnalog::getDemodOutputData: the scope tap)
     int32_t *scope_n;             // how many of them
     int32_t cap_iq, cap_audio;
+    // FM stereo (ModemFMStereo.cpp), allocated for CSDR_MODEM_FMS slots only (kernels_fms.hpp)
+    float2 *fms_x;                // [cap_iq]  r2c Hilbert output of the batch
+    uint32_t *fms_theta;          // [cap_iq]  pilot oscillator phase word after each sample's step
+    float *fms_m, *fms_s;         // [cap_audio / 2]  mono / stereo-difference audio of the batch
+    float2 *fms_yh;               // [2][kFmsYHist]  down-mixed samples in front of the batch (c2r window), ping-pong
+    float *fms_uh;                // [2][2][kFmsFirMax]  matrix outputs in front of the batch (left | right), ping-pong
+    float *fms_state;             // [kFmsStateWords]  pilot filter state + oscillator phase / frequency words (carried in place)
+    float *fms_fir;               // [fms_fir_len]  de-emphasis * 16 kHz low-pass of one output channel
+    int32_t fms_fir_len;
+    float fms_b[15], fms_a[15];   // pilot band-pass sections, execution order
 };
 
 struct SlotDyn {                  // per batch
@@ -1168,7 +1178,7 @@ constexpr int kAudioMaxOut = 16384;        // audio samples of one block handled
 
 __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
-    const BlockPlan *__restrict__ plans, int NB, int cap_out, int cap_win, const float *__restrict__ arms_all) {
+    const BlockPlan *__restrict__ plans, int NB, int cap_out, int cap_win, const float *__restrict__ arms_all, int pass) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_w0 = reinterpret_cast<float *>(smem);
     float *s_w1 = s_w0 + cap_out;
@@ -1190,7 +1200,10 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     const int64_t A0 = interp ? (Q0 << aS) : Q0, A1 = interp ? (Q1 << aS) : Q1;
     const int n_audio = (int)(A1 - A0);
     const float *arms = arms_all + (size_t)au.arms_idx * kArms * kArmTaps;
-    const bool autogain = !(cfg.modem == CSDR_MODEM_NBFM || cfg.modem == CSDR_MODEM_FM);
+    // FM stereo runs this kernel twice (ModemFMStereo.cpp:189,236: two msresamp_rrrf of the same ratio, so the same integer
+    // bookkeeping): pass 0 is the FM path into fms_m, pass 1 resamples the stereo-difference stream fms_mix left in cfg.d into fms_s
+    const bool fms = cfg.modem == CSDR_MODEM_FMS, plain = fms && pass == 1;
+    const bool autogain = !(cfg.modem == CSDR_MODEM_NBFM || cfg.modem == CSDR_MODEM_FM || fms);
     const float2 *iq = cfg.iq + (size_t)dyn.hist_parity * ((size_t)kIqHist + cfg.cap_iq) + kIqHist;   // iq[j], j >= -kIqHist
     if (cfg.modem == CSDR_MODEM_CW) {
         // ModemCW.cpp:181-203: the auto-gain of block b from the maxima of the blocks before it (recurrence replayed from the
@@ -1271,7 +1284,12 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     const int jb0 = pl[b].j0, jbp = b > 0 ? pl[b - 1].j0 : 0;
     // g_cur / g_prev are the gains of blocks b and b - 1 only when both hold samples (empty blocks do not step the gain)
     const bool fast_gain = pl[b + 1].j0 > jb0 && (b == 0 || jb0 > jbp);
-    if (!autogain) {
+    if (plain) {
+        for (int i = tid; i < nwin; i += nthr) {
+            const int64_t j = jlo + i;
+            s_d[i] = j < 0 ? (j >= -(int64_t)kDHist ? dh_in[kDHist + j] : 0.f) : cfg.d[j];
+        }
+    } else if (!autogain) {
         // NBFM / FM (ModemNBFM.cpp:36, ModemFM.cpp:36): m[j] = atan2f(Im(x_j conj x_{j-1}), Re(..)) / (2 pi kf), gain 1.
         // Formed here from the resampled IQ stream (history included: x_{-1} of a fresh demodulator is 0 -> m = 0).
         for (int i = tid; i < nwin; i += nthr) {
@@ -1299,7 +1317,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
         s_d[i] = x;
     }
     // the last block's own scaled samples are the scope tap (DemodulatorThread.cpp:293-305); they lie inside the staged window
-    if (b == NB - 1) {
+    if (b == NB - 1 && !fms) {
         const int n_own = pl[b + 1].j0 - jb0;
         const int ns = max(0, min(min(n_own, kScopeMax), (int)(jhi - (int64_t)jb0)));
         __syncthreads();
@@ -1420,32 +1438,34 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     float lpk = 0.f;
     double lsum = 0.0;
     const int aoff = (int)A0;
+    float *aout = fms ? (pass ? cfg.fms_s : cfg.fms_m) : cfg.audio;
     for (int i = tid; i < n_audio; i += nthr) {
         const float v = src[i];
-        cfg.audio[aoff + i] = v;
+        aout[aoff + i] = v;
         lpk = fmaxf(lpk, fabsf(v));
         if (autogain) lsum += (double)fabsf(v);
     }
     const int n_iq = pl[b + 1].j0 - jb0;
-    if (!autogain)
+    if (!autogain && !plain)
         for (int i = tid; i < n_iq; i += nthr) {
             const float2 x = iq[jb0 + i];
             lsum += sqrt((double)x.x * (double)x.x + (double)x.y * (double)x.y);
         }
     const float pk = block_max_float(lpk, s_redf);
     const double sm = block_sum_double(lsum, s_red);
-    if (tid == 0) {
+    if (tid == 0 && !plain) {                                    // (FM stereo: fms_out sets the peak of the finished stereo frames)
         cfg.bout[b].audio_peak = pk;
         cfg.bout[b].level_accum = sm;
         cfg.bout[b].level_count = autogain ? n_audio : n_iq;
     }
     // 4. last block of an auto-gain modem: publish the gain state and the scaled demodulator tail (other parity)
-    if (b == NB - 1 && autogain) {
+    if (b == NB - 1 && (autogain || plain)) {
         const int J = pl[NB].j0;
         for (int td = tid; td < kDHist; td += nthr) {
             const int j = J - kDHist + td;
             float dv;
             if (j < 0) dv = dh_in[kDHist + j];
+            else if (plain) dv = cfg.d[j];
             else if (fast_gain && j >= jb0) dv = cfg.d[j] * g_cur;
             else if (fast_gain && j >= jbp) dv = cfg.d[j] * g_prev;
             else {

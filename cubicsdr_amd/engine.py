@@ -149,9 +149,10 @@ class DemodBank:
         self.max_blocks = max_blocks
         H.check(self._l.csdr_bank_create(ctx.h, int(max_demods), int(max_blocks), C.byref(self.h)))
 
-    def configure(self, slot, post, modem, bandwidth, frequency, audio_sample_rate=48000):
+    def configure(self, slot, post, modem, bandwidth, frequency, audio_sample_rate=48000, modem_arg=0):
+        """modem_arg: FM stereo de-emphasis in microseconds (0: the reference's default 75, negative: none)"""
         m = H.MODEM_BY_NAME[modem] if isinstance(modem, str) else int(modem)
-        p = H.DemodParams(m, int(bandwidth), int(audio_sample_rate), 0, int(frequency))
+        p = H.DemodParams(m, int(bandwidth), int(audio_sample_rate), int(modem_arg), int(frequency))
         H.check(self._l.csdr_bank_configure_slot(self.h, int(slot), C.byref(p), post.h))
 
     def set_frequency(self, slot, f):
@@ -186,6 +187,22 @@ class DemodBank:
         out = np.empty(cap, np.float32)
         n = C.c_int()
         H.check(self._l.csdr_bank_fetch_demod_output(self.h, int(slot), out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def set_fms_pilot(self, slot, b15=None, a15=None):
+        """replace (or, with None, restore) the pilot band-pass sections of an FM-stereo slot"""
+        if b15 is None:
+            H.check(self._l.csdr_bank_set_fms_pilot(self.h, int(slot), None, None))
+            return
+        b = np.ascontiguousarray(b15, dtype=np.float32); a = np.ascontiguousarray(a15, dtype=np.float32)
+        assert b.size == 15 and a.size == 15
+        H.check(self._l.csdr_bank_set_fms_pilot(self.h, int(slot), b.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p)))
+
+    def fms_stage(self, slot, which, cap=1 << 22):
+        """FM stereo intermediates of the last batch: which = 0 pilot oscillator phase words (uint32), 1 stereo-difference stream (float32)"""
+        out = np.empty(cap, dtype=np.uint32 if which == 0 else np.float32)
+        n = C.c_int(0)
+        H.check(self._l.csdr_bank_fetch_fms_stage(self.h, int(slot), int(which), out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
         return out[:n.value].copy()
 
     def total_audio(self):

@@ -19,7 +19,7 @@ MODEM_BY_NAME = {"NBFM": 0, "FM": 1, "AM": 2, "USB": 3, "LSB": 4, "I/Q": 5, "IQ"
 
 class DemodParams(C.Structure):
     _fields_ = [("modem", C.c_int32), ("bandwidth", C.c_int32), ("audio_sample_rate", C.c_int32),
-                ("reserved", C.c_int32), ("frequency", C.c_int64)]
+                ("modem_arg", C.c_int32), ("frequency", C.c_int64)]
 
 
 class BlockResult(C.Structure):
@@ -75,6 +75,9 @@ ABI = {
     "csdr_bank_fetch_audio": (_i, [_p, _i, _p, _i, C.POINTER(_i)]),
     "csdr_bank_fetch_iq": (_i, [_p, _i, _p, _i, C.POINTER(_i)]),
     "csdr_bank_fetch_demod_output": (_i, [_p, _i, _p, _i, C.POINTER(_i)]),
+    "csdr_design_fms_pilot": (_i, [_i64, _p, _p]),
+    "csdr_bank_set_fms_pilot": (_i, [_p, _i, _p, _p]),
+    "csdr_bank_fetch_fms_stage": (_i, [_p, _i, _i, _p, _i, C.POINTER(_i)]),
     "csdr_bank_total_audio": (_i, [_p, C.POINTER(_i64)]),
     "csdr_spec_create": (_i, [_p, _pp]),
     "csdr_spec_destroy": (None, [_p]),

@@ -254,6 +254,7 @@ private:
                 std::lock_guard<std::mutex> g(d->mu_);
                 rebuild = d->dirty_ || d->builtRate_ != chanRate;
                 p.modem = d->modem_ ? d->modem_->csdrModemId() : -1; p.bandwidth = d->bandwidth_; p.audio_sample_rate = d->audioRate_;
+                p.modem_arg = d->modem_ ? d->modem_->csdrModemArg() : 0;
                 p.frequency = d->getFrequency();
                 if (rebuild && inRange) { d->dirty_ = false; d->builtRate_ = chanRate; }
             }
@@ -295,7 +296,7 @@ private:
         csdr_must(csdr_bank_fetch_results(bank_, d.slot(), &r, 1, &nb), "csdr_bank_fetch_results");
         if (nb != 1 || r.skipped || r.n_iq == 0) return;
         AudioThreadInputPtr ati = d.outputBuffers_.getBuffer();
-        ati->sampleRate = d.getAudioSampleRate(); ati->inputRate = d.getBandwidth(); ati->channels = d.getDemodulatorType() == "I/Q" ? 2 : 1; ati->frequency = d.getFrequency();
+        ati->sampleRate = d.getAudioSampleRate(); ati->inputRate = d.getBandwidth(); ati->channels = (d.getDemodulatorType() == "I/Q" || d.getDemodulatorType() == "FMS") ? 2 : 1; ati->frequency = d.getFrequency();
         ati->data.resize(r.n_audio);
         int got = 0;
         if (r.n_audio) csdr_must(csdr_bank_fetch_audio(bank_, d.slot(), ati->data.data(), r.n_audio, &got), "csdr_bank_fetch_audio");

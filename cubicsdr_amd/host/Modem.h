@@ -30,7 +30,10 @@ public:
     long long sampleRate = 0;
     virtual ~ModemIQData() = default;
 };
-struct ModemArgInfo { std::string key, value, name, description, units; };   // the analog modems publish no settings but FM-stereo's de-emphasis
+struct ModemArgInfo {                                                         // ModemArgInfo of Modem.h:22-60, the fields FM stereo's setting uses
+    std::string key, value, name, description, units;
+    std::vector<std::string> options, optionNames;
+};   // the analog modems publish no settings but FM-stereo's de-emphasis
 typedef std::vector<ModemArgInfo> ModemArgInfoList;
 typedef std::map<std::string, std::string> ModemSettings;
 
@@ -88,6 +91,7 @@ public:
 
     // the CSDR_MODEM_* id of this modem in include/csdr_hip.h
     virtual int csdrModemId() = 0;
+    virtual int csdrModemArg() { return 0; }
 
     static void registerBuiltins();
 
@@ -131,6 +135,27 @@ public:
         return (int)sampleRate;
     }
     int csdrModemId() override { return ID; }
+    // FM stereo's one setting, "demph" (ModemFMStereo.cpp:42-89): de-emphasis in microseconds, "0" = none; a write asks for a rebuild
+    ModemArgInfoList getSettings() override {
+        ModemArgInfoList args;
+        if (ID != CSDR_MODEM_FMS) return args;
+        ModemArgInfo a;
+        a.key = "demph"; a.name = "De-emphasis"; a.value = std::to_string(demph_);
+        a.description = "FM Stereo De-Emphasis, typically 75us in US/Canada, 50us elsewhere.";
+        a.optionNames = {"None", "10us", "25us", "32us", "50us", "75us"};
+        a.options = {"0", "10", "25", "32", "50", "75"};
+        args.push_back(a);
+        return args;
+    }
+    void writeSetting(std::string setting, std::string value) override {
+        if (ID == CSDR_MODEM_FMS && setting == "demph") { demph_ = std::stoi(value); rebuildKit(); }
+    }
+    std::string readSetting(std::string setting) override { return (ID == CSDR_MODEM_FMS && setting == "demph") ? std::to_string(demph_) : ""; }
+    // csdr_demod_params::modem_arg for this modem: FM stereo's de-emphasis (0 there means "the default", so "None" travels as -1)
+    int csdrModemArg() override { return ID == CSDR_MODEM_FMS ? (demph_ ? demph_ : -1) : 0; }
+
+private:
+    int demph_ = 75;                                                          // ModemFMStereo::ModemFMStereo()
 };
 
 inline void Modem::registerBuiltins() {                                                   // CubicSDR.cpp:305-313

@@ -136,7 +136,7 @@ typedef struct csdr_demod_params {
     int32_t modem;             /* CSDR_MODEM_* (DemodulatorInstance::setDemodulatorType) */
     int32_t bandwidth;         /* Hz, modem input rate after checkSampleRate() (setBandwidth) */
     int32_t audio_sample_rate; /* Hz (setAudioSampleRate; 48000 in the reference, DemodulatorInstance.cpp:345) */
-    int32_t reserved;
+    int32_t modem_arg;         /* FM stereo: de-emphasis in microseconds ("demph", ModemFMStereo.cpp:42-81; 0 = the default 75, < 0 = none); else 0 */
     int64_t frequency;         /* Hz, demodulator centre (setFrequency) */
 } csdr_demod_params;
 
@@ -174,6 +174,15 @@ int  csdr_bank_fetch_iq(csdr_bank *bank, int slot, float *host_out, int cap_samp
  * output in front of the audio resampler, at most DEMOD_VIS_SIZE = 2048 samples (DemodulatorThread.h:15) -- what the scope tap
  * hands to the audio scope when the audio is decimated (DemodulatorThread.cpp:293-305).  *n = 0 for the I/Q and CW modems. */
 int  csdr_bank_fetch_demod_output(csdr_bank *bank, int slot, float *host_out, int cap_samples, int *n);
+/* FM stereo (CSDR_MODEM_FMS).  The 19 kHz pilot band-pass is iirfilt_crcf_create_prototype(CHEBY2, BANDPASS, SOS, 5, 19500/fs, 19000/fs, 1, 60)
+ * (ModemFMStereo.cpp:128-139): csdr_design_fms_pilot returns the five sections the library designs for a modem input rate
+ * (b15 / a15: three taps per section, execution order); csdr_bank_set_fms_pilot replaces a slot's sections (NULL: back to the design) --
+ * e.g. with the host liquid's own liquid_iirdes output, whose last-place roundings depend on its libm;
+ * csdr_bank_fetch_fms_stage returns intermediates of the last batch for stage-by-stage checks (which = 0: pilot oscillator phase
+ * words, uint32 per resampled-IQ sample; 1: the stereo-difference stream before its audio resampler, float). */
+int  csdr_design_fms_pilot(int64_t sample_rate, float *b15, float *a15);
+int  csdr_bank_set_fms_pilot(csdr_bank *bank, int slot, const float *b15, const float *a15);
+int  csdr_bank_fetch_fms_stage(csdr_bank *bank, int slot, int which, void *host_out, int cap_samples, int *n);
 /* device-side total of audio samples produced by the last execute over all slots (bench sanity) */
 int  csdr_bank_total_audio(csdr_bank *bank, int64_t *n);
 

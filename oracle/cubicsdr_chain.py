@@ -94,7 +94,9 @@ class RefDemod:
     """DemodulatorPreThread::run (src/demod/DemodulatorPreThread.cpp:154-220) + DemodulatorThread::run
     (src/demod/DemodulatorThread.cpp:119-233) + the analog modems (src/modules/modem/)."""
 
-    def __init__(self, backend, modem, bandwidth, frequency, chan_rate, audio_rate=48000):
+    def __init__(self, backend, modem, bandwidth, frequency, chan_rate, audio_rate=48000, demph=75, pilot_sos=None):
+        """demph / pilot_sos: FM stereo only -- the "demph" setting (microseconds, 0 = none) and, when given, (b15, a15) second-order
+        sections to build the pilot band-pass from (iirfilt_crcf_create_sos) instead of the reference's own design call"""
         L = self.L = A.load(backend)
         self.modem = modem
         self.frequency = int(frequency)
@@ -104,6 +106,8 @@ class RefDemod:
             bw += 1                                                      # ModemUSB.cpp:29-37
         if modem == "I/Q":
             bw = int(audio_rate)                                         # ModemIQ.cpp:31-33
+        if modem == "FMS":
+            bw = max(int(bandwidth), 100000)                             # ModemFMStereo.cpp:27-35
         self.cw_offset = 650.0                                           # mBeepFrequency, ModemCW.cpp:17
         self.bandwidth = bw
         self.chan_rate = int(chan_rate)
@@ -119,6 +123,43 @@ class RefDemod:
             self.fm = L.freqdem_create(0.5)                              # ModemNBFM.cpp:7
         elif modem == "I/Q":
             pass                                                         # ModemIQ::buildKit: no DSP objects
+        elif modem == "FMS":                                             # ModemFMStereo::buildKit, ModemFMStereo.cpp:91-162
+            f32 = np.float32
+            self.fm = L.freqdem_create(0.5)                              # :7
+            self.au2 = L.msresamp_rrrf_create(self.au_ratio, 60.0)       # stereoResampler :103
+            fcut = float(f32(16000.0) / f32(audio_rate))                 # :106
+            ft = float(f32(1000.0) / f32(audio_rate))                    # :108
+            fcut = min(max(fcut, 0.0), 0.5)
+            h_len = L.estimate_req_filter_len(ft, 60.0)                  # :120
+            h = np.zeros(h_len, np.float32)
+            L.liquid_firdes_kaiser(h_len, fcut, 60.0, 0.0, A.ptr(h))     # :122
+            self.fir_l = L.firfilt_rrrf_create(A.ptr(h), h_len)          # :124-125
+            self.fir_r = L.firfilt_rrrf_create(A.ptr(h), h_len)
+            bwf = f32(max(float(f32(bw)), 100000.0))                     # :128-131
+            f0 = float(f32(19000) / bwf)
+            fc = float(f32(19500) / bwf)
+            if pilot_sos is None:
+                self.pilot = L.iirfilt_crcf_create_prototype(A.LIQUID_IIRDES_CHEBY2, A.LIQUID_IIRDES_BANDPASS, A.LIQUID_IIRDES_SOS,
+                                                             5, fc, f0, 1.0, 60.0)     # :138
+            else:
+                b15 = A.as_f32(pilot_sos[0]).copy(); a15 = A.as_f32(pilot_sos[1]).copy()
+                self.pilot = L.iirfilt_crcf_create_sos(A.ptr(b15), A.ptr(a15), 5)
+            self.r2c = L.firhilbf_create(5, 60.0)                        # :140-141
+            self.c2r = L.firhilbf_create(5, 60.0)
+            self.pll = L.nco_crcf_create(A.LIQUID_VCO)                   # :143-145
+            L.nco_crcf_reset(self.pll)
+            L.nco_crcf_pll_set_bandwidth(self.pll, 0.25)
+            self.demph = int(demph)
+            self.dem_l = self.dem_r = None
+            if self.demph:                                               # :149-158
+                f = 1.0 / (2.0 * math.pi * float(self.demph) * 1e-6)
+                t = 1.0 / (2.0 * math.pi * f)
+                t = 1.0 / (2.0 * float(audio_rate) * math.tan(1.0 / (2.0 * float(audio_rate) * t)))
+                tb = 1.0 + 2.0 * t * float(audio_rate)
+                bd = np.array([1.0 / tb, 1.0 / tb], np.float32)
+                ad = np.array([1.0, (1.0 - 2.0 * t * float(audio_rate)) / tb], np.float32)
+                self.dem_l = L.iirfilt_rrrf_create(A.ptr(bd), 2, A.ptr(ad), 2)
+                self.dem_r = L.iirfilt_rrrf_create(A.ptr(bd), 2, A.ptr(ad), 2)
         elif modem == "CW":
             self.cw_lo = L.nco_crcf_create(A.LIQUID_NCO)                 # ModemCW.cpp:22
             self.cw_hilb = L.firhilbf_create(5, 60.0)                    # :23
@@ -172,6 +213,28 @@ class RefDemod:
             audio[1::2] = iq.real
             accum = float(np.sum(np.sqrt(iq.real.astype(np.float64) ** 2 + iq.imag.astype(np.float64) ** 2)))
             return dict(audio=audio, level_accum=accum, level_count=n, peak=float(np.max(np.abs(audio))), demod=audio.copy(), channels=2)
+        if self.modem == "FMS":                                          # ModemFMStereo::demodulate, ModemFMStereo.cpp:163-289
+            d = np.empty(n, np.float32)
+            L.freqdem_demodulate_block(self.fm, _cptr(iq), n, _cptr(d))                  # :178
+            cap = int(math.ceil(n * self.au_ratio)) + 512                               # :176
+            mono = np.empty(cap, np.float32)
+            nw = C.c_uint()
+            L.msresamp_rrrf_execute(self.au, _cptr(d), n, _cptr(mono), C.byref(nw))      # :189
+            st = np.empty(n, np.float32)
+            th = np.empty(n, np.uint32)
+            L.oracle_fms_pilot_block(C.c_void_p(self.r2c), C.c_void_p(self.pilot), C.c_void_p(self.pll), C.c_void_p(self.c2r),
+                                     _cptr(d), n, _cptr(st), _cptr(th))                  # :198-226
+            ster = np.empty(cap, np.float32)
+            nw2 = C.c_uint()
+            L.msresamp_rrrf_execute(self.au2, _cptr(st), n, _cptr(ster), C.byref(nw2))   # :236
+            m = nw2.value                                                                # numAudioWritten of the SECOND call sizes the output (:238-262)
+            audio = np.empty(2 * m, np.float32)
+            L.oracle_fms_matrix_block(C.c_void_p(self.dem_l) if self.dem_l else None, C.c_void_p(self.dem_r) if self.dem_r else None,
+                                      C.c_void_p(self.fir_l), C.c_void_p(self.fir_r), _cptr(mono), _cptr(ster), m, _cptr(audio))   # :263-287
+            accum = float(np.sum(np.sqrt(iq.real.astype(np.float64) ** 2 + iq.imag.astype(np.float64) ** 2)))
+            peak = float(np.max(np.abs(audio))) if m else 0.0
+            return dict(audio=audio, level_accum=accum, level_count=n, peak=peak, demod=d.copy(), channels=2,
+                        fms_stereo=st.copy(), fms_theta=th.copy(), fms_mono_audio=mono[:m].copy(), fms_stereo_audio=ster[:m].copy())
         if self.modem == "CW":                                           # ModemCW::demodulate :155-209
             f32 = np.float32
             cx = np.empty(int(math.ceil(n * self.au_ratio)) + 512, np.complex64)      # initOutputBuffers :140

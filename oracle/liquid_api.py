@@ -106,6 +106,18 @@ _SIGS = {
     "firhilbf_destroy": (c_i, [c_p]),
     "firhilbf_print": (c_i, [c_p]),
     "firhilbf_c2r_execute": (c_i, [c_p, cf32, c_p, c_p]),
+    "firhilbf_r2c_execute": (c_i, [c_p, c_f, c_p]),
+    "iirfilt_crcf_create_prototype": (c_p, [c_i, c_i, c_i, c_u, c_f, c_f, c_f, c_f]),
+    "liquid_iirdes": (c_i, [c_i, c_i, c_i, c_u, c_f, c_f, c_f, c_f, c_p, c_p]),
+    "iirfilt_crcf_create_sos": (c_p, [c_p, c_p, c_u]),
+    "nco_crcf_pll_set_bandwidth": (c_i, [c_p, c_f]),
+    "nco_crcf_pll_step": (c_i, [c_p, c_f]),
+    "iirfilt_rrrf_create": (c_p, [c_p, c_u, c_p, c_u]),
+    "iirfilt_rrrf_destroy": (c_i, [c_p]),
+    "iirfilt_rrrf_execute": (c_i, [c_p, c_f, c_p]),
+    "firfilt_rrrf_create": (c_p, [c_p, c_u]),
+    "oracle_fms_pilot_block": (c_i, [c_p, c_p, c_p, c_p, c_p, c_u, c_p, c_p]),
+    "oracle_fms_matrix_block": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_u, c_p]),
     "estimate_req_filter_len": (c_u, [c_f, c_f]),
     "kaiser_beta_As": (c_f, [c_f]),
     "liquid_firdes_kaiser": (c_i, [c_u, c_f, c_f, c_f, c_p]),
@@ -116,6 +128,7 @@ _SIGS = {
 }
 
 LIQUID_NCO, LIQUID_VCO = 0, 1
+LIQUID_IIRDES_CHEBY2, LIQUID_IIRDES_BANDPASS, LIQUID_IIRDES_SOS = 2, 2, 0
 LIQUID_ANALYZER, LIQUID_SYNTHESIZER = 0, 1
 LIQUID_RESAMP_INTERP, LIQUID_RESAMP_DECIM = 0, 1
 LIQUID_FFT_FORWARD, LIQUID_FFT_BACKWARD = 1, -1

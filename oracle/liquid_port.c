@@ -138,7 +138,7 @@ void *nco_crcf_create(int type)
 {
     nco_t *q = (nco_t *)calloc(1, sizeof(nco_t));
     q->type = type;
-    for (unsigned i = 0; i < 1024; i++) q->sintab[i] = sinf(2.0f * (float)M_PI * (float)i / 1024.0f);
+    for (unsigned i = 0; i < 1024; i++) q->sintab[i] = (float)sin((double)(2.0f * (float)M_PI * (float)i / 1024.0f));   /* float argument, correctly rounded sine: the reference binary's table bit for bit */
     return q;
 }
 int nco_crcf_destroy(void *q) { free(q); return 0; }

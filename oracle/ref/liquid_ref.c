@@ -311,6 +311,66 @@ int oracle_ssb_block(obj nco, obj iir, obj hilb, int usb, cf32 *in, unsigned n, 
     }
     return 0;
 }
+static inline void ref_peek_u32(const void *p, unsigned off, unsigned *dst) { memcpy(dst, (const char *)p + off, 4); }
+
+/* ---- FM stereo (ModemFMStereo.cpp:113-152 kit, :163-289 demodulate) ---- */
+FN(int, firhilbf_r2c_execute, obj, float, cf32 *)
+int firhilbf_r2c_execute(obj q, float x, cf32 *y) { return firhilbf_r2c_execute_get()(q, x, y); }
+FN(obj, iirfilt_crcf_create_prototype, int, int, int, unsigned, float, float, float, float)
+obj iirfilt_crcf_create_prototype(int ft, int bt, int fmt, unsigned order, float fc, float f0, float ap, float as)
+{ return iirfilt_crcf_create_prototype_get()(ft, bt, fmt, order, fc, f0, ap, as); }
+FN(int, nco_crcf_pll_set_bandwidth, obj, float)
+int nco_crcf_pll_set_bandwidth(obj q, float bw) { return nco_crcf_pll_set_bandwidth_get()(q, bw); }
+FN(int, nco_crcf_pll_step, obj, float)
+int nco_crcf_pll_step(obj q, float dphi) { return nco_crcf_pll_step_get()(q, dphi); }
+FN(obj, iirfilt_rrrf_create, float *, unsigned, float *, unsigned)
+obj iirfilt_rrrf_create(float *b, unsigned nb, float *a, unsigned na) { return iirfilt_rrrf_create_get()(b, nb, a, na); }
+FN(int, iirfilt_rrrf_destroy, obj)
+int iirfilt_rrrf_destroy(obj q) { return iirfilt_rrrf_destroy_get()(q); }
+FN(int, iirfilt_rrrf_execute, obj, float, float *)
+int iirfilt_rrrf_execute(obj q, float x, float *y) { return iirfilt_rrrf_execute_get()(q, x, y); }
+FN(obj, firfilt_rrrf_create, float *, unsigned)
+obj firfilt_rrrf_create(float *h, unsigned n) { return firfilt_rrrf_create_get()(h, n); }
+FN(int, liquid_iirdes, int, int, int, unsigned, float, float, float, float, float *, float *)
+int liquid_iirdes(int ft, int bt, int fmt, unsigned n, float fc, float f0, float ap, float as, float *b, float *a)
+{ return liquid_iirdes_get()(ft, bt, fmt, n, fc, f0, ap, as, b, a); }
+FN(obj, iirfilt_crcf_create_sos, float *, float *, unsigned)
+obj iirfilt_crcf_create_sos(float *b, float *a, unsigned nsos) { return iirfilt_crcf_create_sos_get()(b, a, nsos); }
+/* the per-sample pilot loop of ModemFMStereo.cpp:198-226; theta_out (optional) records the oscillator phase word after each step */
+int oracle_fms_pilot_block(obj r2c, obj bp, obj pll, obj c2r, float *d, unsigned n, float *stereo, unsigned *theta_out)
+{
+    for (unsigned i = 0; i < n; i++) {
+        cf32 x, v, w, u, y; float usb;
+        firhilbf_r2c_execute(r2c, d[i], &x);
+        iirfilt_crcf_execute(bp, x, &v);
+        nco_crcf_cexpf(pll, &w);
+        w.im = -w.im;
+        u.re = v.re * w.re - v.im * w.im;
+        u.im = v.re * w.im + v.im * w.re;
+        float pe = atan2f(u.im, u.re);
+        nco_crcf_pll_step(pll, pe);
+        nco_crcf_step(pll);
+        if (theta_out) ref_peek_u32(pll, 0x1004, &theta_out[i]);
+        nco_crcf_mix_down(pll, x, &y);
+        nco_crcf_mix_down(pll, y, &x);
+        firhilbf_c2r_execute(c2r, x, &stereo[i], &usb);
+    }
+    return 0;
+}
+/* ModemFMStereo.cpp:263-288: matrix, de-emphasis (dl/dr NULL when demph == 0), 16 kHz low-pass, interleave */
+int oracle_fms_matrix_block(obj dl, obj dr, obj fl, obj fr, float *mono, float *st, unsigned n, float *out)
+{
+    for (unsigned i = 0; i < n; i++) {
+        float l, r, ld = 0.568f * (mono[i] - st[i]), rd = 0.568f * (mono[i] + st[i]);
+        if (dl) { float a = ld, b = rd; iirfilt_rrrf_execute(dl, a, &ld); iirfilt_rrrf_execute(dr, b, &rd); }
+        firfilt_rrrf_push(fl, ld); firfilt_rrrf_execute(fl, &l);
+        firfilt_rrrf_push(fr, rd); firfilt_rrrf_execute(fr, &r);
+        out[2 * i] = l; out[2 * i + 1] = r;
+    }
+    return 0;
+}
 /* raw object peek for pinning integer state (nco theta/d_theta at +0x1004/+0x1008) */
 void ref_peek(const void *p, unsigned off, void *dst, unsigned n) { memcpy(dst, (const char *)p + off, n); }
+/* and poke: set the oscillator phase word per sample when a stage is checked against given phases (tests/test_gpu_parity.py, FM stereo) */
+void ref_poke(void *p, unsigned off, const void *src, unsigned n) { memcpy((char *)p + off, src, n); }
 #include "../chain_bench.inc"

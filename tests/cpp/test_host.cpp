@@ -171,6 +171,16 @@ static void test_modem_shim() {
     bool threw = false;
     try { nb->demodulate(nullptr, nullptr, nullptr); } catch (const std::logic_error &) { threw = true; }
     CHECK(threw);                                                             // no host demodulation path exists
+    // FM stereo: rate rule and the "demph" setting (ModemFMStereo.cpp:27-89)
+    std::unique_ptr<Modem> fms(Modem::makeModem("FMS"));
+    CHECK(fms && fms->csdrModemId() == CSDR_MODEM_FMS && fms->getDefaultSampleRate() == 200000 && !fms->useSignalOutput());
+    CHECK(fms->checkSampleRate(50000, 48000) == 100000 && fms->checkSampleRate(250000, 48000) == 250000);
+    CHECK(fms->getSettings().size() == 1 && fms->getSettings()[0].key == "demph" && fms->getSettings()[0].options.size() == 6);
+    CHECK(fms->readSetting("demph") == "75" && fms->csdrModemArg() == 75 && !fms->shouldRebuildKit());
+    fms->writeSetting("demph", "50");
+    CHECK(fms->readSetting("demph") == "50" && fms->csdrModemArg() == 50 && fms->shouldRebuildKit());
+    fms->writeSetting("demph", "0");
+    CHECK(fms->csdrModemArg() == -1 && fms->readSettings()["demph"] == "0" && nb->getSettings().empty() && nb->csdrModemArg() == 0);
     DemodulatorMgr mgr(4);
     auto d = mgr.newThread();
     CHECK(d->getDemodulatorType() == "NBFM" && d->getBandwidth() == 12500 && d->isModemInitialized() && d->getModemType() == "analog");

@@ -175,3 +175,7 @@ def test_emu_error_codes(ctx):
 def test_emu_interpolating_iq_resampler(ctx):
     got, want = G._run_demods(ctx, 2400000, 4, 4000, ["FM", "NBFM"], 4, 2, bw=[800000, 12500], seed=21)
     print(G._compare(got, want, "interp"))
+
+
+def test_emu_fm_stereo(ctx):
+    print(G._fms_case(ctx, 2400000, 4, 20000, 4, 2))

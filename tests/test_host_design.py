@@ -138,7 +138,7 @@ def test_nco_word_and_table(D, O):
             d = np.zeros(2, np.uint32); R.ref_peek(C.c_void_p(q), 0x1004, A.ptr(d), 8)
             assert int(d[1]) == D.csdr_design_nco_word(C.c_float(float(np.float32(f))))          # bit-exact word
             tab = np.zeros(1024, np.float32); R.ref_peek(C.c_void_p(q), 4, A.ptr(tab), 4096)
-            assert np.max(np.abs(tab - t)) <= 6e-8                                                # the reference's own table
+            assert np.array_equal(tab, t)                                                         # the reference's own table, bit for bit
 
 
 @pytest.mark.parametrize("M", [4, 20, 122, 200])
@@ -185,6 +185,52 @@ def test_modem_filter_designs(D, O):
     re = np.concatenate([np.zeros(32), x.real[:200].astype(np.float64)]); im = np.concatenate([np.zeros(32), x.imag[:200].astype(np.float64)])
     mine = [re[32 + k - 10] - sum(hq[t] * im[32 + k - (2 * t + 1)] for t in range(10)) for k in range(200)]
     assert rel_err(np.array(mine, np.float32), np.array(got_up, np.float32)) < 5e-6
+
+
+def test_fm_stereo_designs(D):
+    """ModemFMStereo::buildKit (ModemFMStereo.cpp:91-162): the 19 kHz pilot band-pass sections against liquid_iirdes of the reference
+    binary -- feedback taps bit for bit (pole radii ~0.998: the pass-band phase moves 1e-4 rad per unit in the last place), feed-forward
+    taps within one unit in the last place -- and the one-FIR form of de-emphasis + low-pass against the reference's two filters."""
+    if not A.available("ref"):
+        pytest.skip("needs the reference liquid binary")
+    R = A.load("ref")
+    rng = np.random.default_rng(7)
+    rates = [100000, 120000, 150000, 192000, 200000, 240000, 250000, 384000, 400000, 500000, 1000000] + [int(v) for v in rng.integers(100000, 1500000, 60)]
+    for fs in rates:
+        f32 = np.float32
+        bwf = f32(max(float(f32(fs)), 100000.0))
+        f0, fc = float(f32(19000) / bwf), float(f32(19500) / bwf)
+        wb = np.zeros(15, np.float32); wa = np.zeros(15, np.float32)
+        R.liquid_iirdes(A.LIQUID_IIRDES_CHEBY2, A.LIQUID_IIRDES_BANDPASS, A.LIQUID_IIRDES_SOS, 5, fc, f0, 1.0, 60.0, A.ptr(wb), A.ptr(wa))
+        b = np.zeros(15, np.float32); a = np.zeros(15, np.float32)
+        assert D.csdr_design_fms_pilot_sos(C.c_longlong(fs), A.ptr(b), A.ptr(a)) == 5
+        assert np.array_equal(a, wa), fs
+        ulps = np.abs(b.view(np.int32).astype(np.int64) - wb.view(np.int32).astype(np.int64))
+        assert ulps[np.abs(wb) > 1e-6].max() <= 1 and np.max(np.abs(b - wb)) < 2e-8, fs
+    # output filter: impulse + noise through the reference's iirfilt_rrrf + firfilt_rrrf, against one convolution with the product's taps
+    for rate, demph in [(48000, 75), (48000, 50), (44100, 75), (48000, 0), (96000, 75), (48000, 10)]:
+        g = np.zeros(1024, np.float32)
+        L = D.csdr_design_fms_output_fir(rate, demph, A.ptr(g), 1024)
+        assert 0 < L <= 1024
+        fcut, ft = float(np.float32(16000.0) / np.float32(rate)), float(np.float32(1000.0) / np.float32(rate))
+        h_len = R.estimate_req_filter_len(ft, 60.0)
+        h = np.zeros(h_len, np.float32); R.liquid_firdes_kaiser(h_len, min(fcut, 0.5), 60.0, 0.0, A.ptr(h))
+        fir = R.firfilt_rrrf_create(A.ptr(h), h_len)
+        dem = None
+        if demph:
+            f = 1.0 / (2.0 * np.pi * demph * 1e-6); t = 1.0 / (2.0 * np.pi * f)
+            t = 1.0 / (2.0 * rate * np.tan(1.0 / (2.0 * rate * t))); tb = 1.0 + 2.0 * t * rate
+            bd = np.array([1.0 / tb, 1.0 / tb], np.float32); ad = np.array([1.0, (1.0 - 2.0 * t * rate) / tb], np.float32)
+            dem = R.iirfilt_rrrf_create(A.ptr(bd), 2, A.ptr(ad), 2)
+        x = (rng.standard_normal(3000) * 0.3).astype(np.float32); x[0] = 1.0
+        y = np.zeros_like(x); tmp = C.c_float(); out = C.c_float()
+        for i in range(x.size):
+            v = float(x[i])
+            if dem:
+                R.iirfilt_rrrf_execute(C.c_void_p(dem), v, C.byref(tmp)); v = tmp.value
+            R.firfilt_rrrf_push(C.c_void_p(fir), v); R.firfilt_rrrf_execute(C.c_void_p(fir), C.byref(out)); y[i] = out.value
+        mine = np.convolve(x.astype(np.float64), g[:L].astype(np.float64))[:x.size]
+        assert rel_err(mine.astype(np.float32), y) < 2e-6, (rate, demph)
 
 
 def test_block_and_channel_sizing_rules(D):

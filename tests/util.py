@@ -45,6 +45,12 @@ def synth_iq(n, fs, center, demods, seed=0xC0B1C5D2, t0=0, noise=0.05, dc=(0.01,
             x += amp * np.exp(2j * np.pi * (df + 60.0) * t) * (np.floor(t * 40.0) % 2 == 0)    # keyed carrier, 20 Hz dots
         elif kind == "I/Q":
             x += amp * np.exp(2j * np.pi * (df + 3000.0) * t)
+        elif kind == "FMS":
+            # FM broadcast multiplex: (L + R) + 19 kHz pilot + (L - R) on the suppressed 38 kHz subcarrier, 75 kHz deviation
+            Ls = 0.8 * np.sin(2 * np.pi * 1000.0 * t) + 0.3 * np.sin(2 * np.pi * 3300.0 * t)
+            Rs = 0.9 * np.sin(2 * np.pi * 700.0 * t + 1.0)
+            mpx = 0.45 * (Ls + Rs) + 0.1 * np.sin(2 * np.pi * 19000.0 * t) + 0.45 * (Ls - Rs) * np.sin(2 * np.pi * 38000.0 * t)
+            x += amp * np.exp(1j * (2 * np.pi * df * t + 2 * np.pi * 75000.0 * np.cumsum(mpx) / fs))
     x += dc[0] + 1j * dc[1]
     return x.astype(np.complex64)
 
