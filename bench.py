@@ -196,6 +196,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=0, help="IQ blocks per batch (HBM-resident ring); default per config")
     ap.add_argument("--batches", type=int, default=0, help="batches per step; default per config (a step is ~0.1-0.2 s of GPU work)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline sample budget per leg (0 disables)")
+    ap.add_argument("--shard", default="broadcast", choices=["broadcast", "slab"],
+                    help="--config C4 only: how the ONE stream is spread over the GPUs (broadcast + channel subsets, or time slabs + all-to-all)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event profile")
     ap.add_argument("--no-latency", action="store_true", help="skip the small-batch (real-time shape) measurement")
     ap.add_argument("--ring", default="signal", choices=["signal", "noise"],

@@ -214,6 +214,9 @@ struct csdr_post {
     int hist_parity = 0, dc_parity = 0;
     double dc_c = 0.0;                       // feedback coefficient of the DC blocker recurrence
     bool raw = false;                        // internal (zoomed spectrum view): SINGLE mode hands the input on unfiltered
+    bool dc_enabled = true;                  // csdr_post_set_dc_blocker: a time-slab producer leaves channel 0 to the rank that owns it
+    int import_k = -1;                       // buffer being assembled by csdr_post_import_begin .. commit
+    std::map<std::vector<int>, int *> rowlists;   // device copies of the channel lists export / import calls name (a handful, reused every batch)
 };
 
 static void post_update_channels(csdr_post *p) {   // SDRPostThread::updateChannels, SDRPostThread.cpp:116-124
@@ -251,6 +254,8 @@ extern "C" void csdr_post_destroy(csdr_post *p) {
     p->out.release(); p->hist0.release(); p->hist1.release(); p->stage_in.release();
     p->twA.release(); p->twB.release(); p->twM.release(); p->post2.release();
     p->taps.release(); p->active.release(); p->dc_state.release(); p->tile_end.release();
+    for (auto &kv : p->rowlists) (void)hipFree(kv.second);
+    p->rowlists.clear();
     delete p;
 }
 
@@ -497,7 +502,7 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
         const int ntiles = (int)((n_frames + g.fpw - 1) / g.fpw);
         // channel 0 carries the DC spike: it is blocked after de-interleave (:364-375); when the tile size allows, the
         // channelizer itself emits the per-tile end values the blocked scan needs
-        const bool dc0 = !p->active_host.empty() && p->active_host[0] == 0;
+        const bool dc0 = p->dc_enabled && !p->active_host.empty() && p->active_host[0] == 0;
         const bool fused_ends = dc0 && g.fpw >= 16;
         if (g.p2) {
             // persistent workgroups: as many as are resident at once, each walks over tiles blockIdx.x, + gridDim.x, ...
@@ -551,6 +556,116 @@ extern "C" int csdr_post_read_channel(csdr_post *p, int ch, float *host_out, int
     CSDR_HIP_TRY(hipMemcpyAsync(host_out, post_buf(p, p->cur) + (int64_t)ch * p->chan_stride, (size_t)cnt * sizeof(float2), hipMemcpyDeviceToHost, st));
     CSDR_HIP_TRY(hipStreamSynchronize(st));
     *n = (int)cnt;
+    return CSDR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Time-slab sharding of ONE stream over several GPUs (SURVEY 8e option 2; host side: cubicsdr_amd/parallel.py SlabStream).
+// A producer rank runs the channelizer over ITS blocks of the batch for all channels -- csdr_post_set_history gives it the input
+// samples in front of its slab, csdr_post_set_dc_blocker(0) leaves channel 0 unfiltered -- and csdr_post_export_rows packs the
+// rows each peer owns for the all-to-all.  The owner assembles its channels' rows from every peer's frames into a second post
+// object (import_begin / import_rows / import_commit: commit runs the carried DC blocker over channel 0 when it owns it), which
+// its demodulator bank then reads exactly like an executed one.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace csdr {
+__global__ __launch_bounds__(256) void rows_copy(const float2 *__restrict__ src, int64_t src_stride, const int *__restrict__ src_rows,
+                                                 float2 *__restrict__ dst, int64_t dst_stride, const int *__restrict__ dst_rows, int64_t n_frames) {
+    const int r = blockIdx.y;
+    const float2 *s = src + (int64_t)(src_rows ? src_rows[r] : r) * src_stride;
+    float2 *d = dst + (int64_t)(dst_rows ? dst_rows[r] : r) * dst_stride;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_frames; i += (int64_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+}  // namespace csdr
+static int post_row_list(csdr_post *p, const int *channels, int n, const int **dev_list) {
+    if (n <= 0 || n > p->M) return fail(CSDR_EINVAL, "bad channel count");
+    for (int i = 0; i < n; ++i) if (channels[i] < 0 || channels[i] >= p->M) return fail(CSDR_EINVAL, "channel %d out of range", channels[i]);
+    std::vector<int> key(channels, channels + n);
+    auto it = p->rowlists.find(key);
+    if (it == p->rowlists.end()) {
+        if (p->rowlists.size() >= 64) return fail(CSDR_ERANGE, "too many distinct channel lists");
+        int *d = nullptr;
+        if (hipMalloc((void **)&d, (size_t)n * sizeof(int)) != hipSuccess) return fail(CSDR_ENOMEM, "channel list");
+        CSDR_HIP_TRY(hipMemcpy(d, channels, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        it = p->rowlists.emplace(std::move(key), d).first;
+    }
+    *dev_list = it->second;
+    return CSDR_OK;
+}
+extern "C" int csdr_post_set_history(csdr_post *p, const float *dev_tail, int64_t n_samples) {
+    DeviceScope dev__(p ? p->ctx : nullptr);
+    if (!p || !p->configured || p->mode == CSDR_POST_SINGLE) return fail(CSDR_ESTATE, "post is not a configured channelizer");
+    if (!dev_tail || n_samples < 0) return fail(CSDR_EINVAL, "bad argument");
+    const int64_t H = (int64_t)kChanTaps * p->M - p->hop;
+    hipStream_t st = p->ctx->lanes[LANE_POST];
+    if (int rc = p->ctx->lane_begin(LANE_POST)) return rc;
+    float2 *hist = p->hist_parity ? p->hist1.p : p->hist0.p;                 // what the next execute reads in front of its input
+    const int64_t take = std::min(H, n_samples);
+    if (take < H) CSDR_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)(H - take) * sizeof(float2), st));
+    if (take) CSDR_HIP_TRY(hipMemcpyAsync(hist + (H - take), (const float2 *)dev_tail + (n_samples - take), (size_t)take * sizeof(float2), hipMemcpyDeviceToDevice, st));
+    return CSDR_OK;
+}
+extern "C" int csdr_post_history_length(const csdr_post *p) { return (p && p->configured && p->mode != CSDR_POST_SINGLE) ? kChanTaps * p->M - p->hop : 0; }
+extern "C" int csdr_post_set_dc_blocker(csdr_post *p, int enabled) {
+    if (!p) return fail(CSDR_EINVAL, "null argument");
+    p->dc_enabled = enabled != 0;
+    return CSDR_OK;
+}
+extern "C" int csdr_post_export_rows(csdr_post *p, const int *channels, int n, float *dst_dev, int64_t dst_stride) {
+    DeviceScope dev__(p ? p->ctx : nullptr);
+    if (!p || !p->configured || p->n_blocks <= 0) return fail(CSDR_ESTATE, "post has no data");
+    if (!channels || !dst_dev) return fail(CSDR_EINVAL, "null argument");
+    const int64_t nf = (int64_t)p->n_blocks * (p->block_len / p->hop);
+    if (dst_stride < nf) return fail(CSDR_EINVAL, "destination stride %lld below %lld frames", (long long)dst_stride, (long long)nf);
+    const int *rows = nullptr;
+    if (int rc = post_row_list(p, channels, n, &rows)) return rc;
+    CSDR_LAUNCH(p->ctx, LANE_POST, KID_DC_APPLY, rows_copy, dim3((unsigned)std::min<int64_t>(64, (nf + 255) / 256), n), dim3(256), 0,
+                post_buf(p, p->cur), p->chan_stride, rows, (float2 *)dst_dev, dst_stride, (const int *)nullptr, nf);
+    CSDR_HIP_TRY(hipGetLastError());
+    return CSDR_OK;
+}
+extern "C" int csdr_post_import_begin(csdr_post *p, int n_blocks, int block_len, int64_t frequency) {
+    DeviceScope dev__(p ? p->ctx : nullptr);
+    if (!p || !p->configured || p->mode == CSDR_POST_SINGLE) return fail(CSDR_ESTATE, "post is not a configured channelizer");
+    if (n_blocks <= 0 || n_blocks > p->max_blocks || block_len <= 0 || block_len > p->max_block_len || block_len % p->M) return fail(CSDR_ERANGE, "bad batch %d x %d", n_blocks, block_len);
+    csdr_ctx *c = p->ctx;
+    hipStream_t st = c->lanes[LANE_POST];
+    if (int rc = c->lane_begin(LANE_POST)) return rc;
+    if (frequency != p->frequency || p->centers.empty()) { p->frequency = frequency; post_update_channels(p); }
+    p->n_blocks = n_blocks; p->block_len = block_len;
+    const int k = c->same(LANE_POST, LANE_FE) ? 0 : (int)(p->seq % csdr_post::kPostBufs);
+    if (!c->same(LANE_FE, LANE_POST))
+        for (int q = 0; q < p->n_consumed[k]; ++q) CSDR_HIP_TRY(hipStreamWaitEvent(st, p->ev_consumed[k][q], 0));
+    p->n_consumed[k] = 0;
+    p->import_k = k;
+    return CSDR_OK;
+}
+extern "C" int csdr_post_import_rows(csdr_post *p, const int *channels, int n, const float *src_dev, int64_t src_stride, int64_t frame0, int64_t n_frames) {
+    DeviceScope dev__(p ? p->ctx : nullptr);
+    if (!p || p->import_k < 0) return fail(CSDR_ESTATE, "no import in progress");
+    if (!channels || !src_dev) return fail(CSDR_EINVAL, "null argument");
+    const int64_t nf = (int64_t)p->n_blocks * (p->block_len / p->hop);
+    if (frame0 < 0 || n_frames < 0 || frame0 + n_frames > nf || src_stride < n_frames) return fail(CSDR_ERANGE, "frames [%lld, +%lld) outside the batch of %lld", (long long)frame0, (long long)n_frames, (long long)nf);
+    if (n_frames == 0) return CSDR_OK;
+    const int *rows = nullptr;
+    if (int rc = post_row_list(p, channels, n, &rows)) return rc;
+    CSDR_LAUNCH(p->ctx, LANE_POST, KID_DC_APPLY, rows_copy, dim3((unsigned)std::min<int64_t>(64, (n_frames + 255) / 256), n), dim3(256), 0,
+                (const float2 *)src_dev, src_stride, (const int *)nullptr, post_buf(p, p->import_k) + frame0, p->chan_stride, rows, n_frames);
+    CSDR_HIP_TRY(hipGetLastError());
+    return CSDR_OK;
+}
+extern "C" int csdr_post_import_commit(csdr_post *p) {
+    DeviceScope dev__(p ? p->ctx : nullptr);
+    if (!p || p->import_k < 0) return fail(CSDR_ESTATE, "no import in progress");
+    csdr_ctx *c = p->ctx;
+    const int k = p->import_k;
+    p->import_k = -1;
+    const int64_t nf = (int64_t)p->n_blocks * (p->block_len / p->hop);
+    float2 *out = post_buf(p, k);
+    if (p->dc_enabled && !p->active_host.empty() && p->active_host[0] == 0)
+        if (int rc = run_dc_blocker(p, out, out, nf, false, 0)) return rc;
+    if (int rc2 = c->signal(p->ev_ready[k], LANE_POST, LANE_FE)) return rc2;
+    p->cur = k;
+    p->seq++;
     return CSDR_OK;
 }
 

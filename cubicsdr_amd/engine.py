@@ -15,6 +15,8 @@ from . import hip as H
 def _as_iq_arg(iq):
     """-> (pointer, is_dev, n_complex, keepalive)"""
     if isinstance(iq, np.ndarray):
+        if iq.dtype == np.float32 and iq.ndim == 2 and iq.shape[1] == 2:          # interleaved (re, im) pairs
+            iq = np.ascontiguousarray(iq).view(np.complex64).reshape(-1)
         a = np.ascontiguousarray(iq, dtype=np.complex64)
         return a.ctypes.data_as(C.c_void_p), 0, a.size, a
     # torch tensor on the GPU: complex64 [n] or float32 [n, 2] / [2n]
@@ -110,6 +112,40 @@ class SDRPost:
         H.check(self._l.csdr_post_execute(self.h, p, is_dev, int(n_blocks), int(block_len), int(frequency)))
         self._keep = keep
         self._last = (n_blocks, block_len)
+
+    # ---- time-slab sharding (csdr_hip.h: producer / owner halves; parallel.SlabStream drives them).  `buf` arguments are DEVICE
+    # buffers: torch tensors on the context's GPU (float32 [.., 2] or complex64); numpy arrays only when the library in use runs its kernels on the host (the test suite has such a build)
+    @staticmethod
+    def _dev_ptr(buf):
+        if isinstance(buf, np.ndarray):
+            return buf.ctypes.data_as(C.c_void_p)
+        return C.c_void_p(buf.data_ptr())
+
+    @property
+    def history_length(self):
+        return self._l.csdr_post_history_length(self.h)
+
+    def set_history(self, tail, n_samples):
+        H.check(self._l.csdr_post_set_history(self.h, self._dev_ptr(tail), int(n_samples)))
+        self._keep_hist = tail
+
+    def set_dc_blocker(self, enabled):
+        H.check(self._l.csdr_post_set_dc_blocker(self.h, 1 if enabled else 0))
+
+    def export_rows(self, channels, dst, dst_stride):
+        a = np.ascontiguousarray(channels, dtype=np.int32)
+        H.check(self._l.csdr_post_export_rows(self.h, a.ctypes.data_as(C.c_void_p), a.size, self._dev_ptr(dst), int(dst_stride)))
+
+    def import_begin(self, n_blocks, block_len, frequency):
+        H.check(self._l.csdr_post_import_begin(self.h, int(n_blocks), int(block_len), int(frequency)))
+        self._last = (n_blocks, block_len)
+
+    def import_rows(self, channels, src, src_stride, frame0, n_frames):
+        a = np.ascontiguousarray(channels, dtype=np.int32)
+        H.check(self._l.csdr_post_import_rows(self.h, a.ctypes.data_as(C.c_void_p), a.size, self._dev_ptr(src), int(src_stride), int(frame0), int(n_frames)))
+
+    def import_commit(self):
+        H.check(self._l.csdr_post_import_commit(self.h))
 
     @property
     def channel_bandwidth(self):

@@ -75,6 +75,13 @@ ABI = {
     "csdr_bank_fetch_audio": (_i, [_p, _i, _p, _i, C.POINTER(_i)]),
     "csdr_bank_fetch_iq": (_i, [_p, _i, _p, _i, C.POINTER(_i)]),
     "csdr_bank_fetch_demod_output": (_i, [_p, _i, _p, _i, C.POINTER(_i)]),
+    "csdr_post_history_length": (_i, [_p]),
+    "csdr_post_set_history": (_i, [_p, _p, _i64]),
+    "csdr_post_set_dc_blocker": (_i, [_p, _i]),
+    "csdr_post_export_rows": (_i, [_p, _p, _i, _p, _i64]),
+    "csdr_post_import_begin": (_i, [_p, _i, _i, _i64]),
+    "csdr_post_import_rows": (_i, [_p, _p, _i, _p, _i64, _i64, _i64]),
+    "csdr_post_import_commit": (_i, [_p]),
     "csdr_design_fms_pilot": (_i, [_i64, _p, _p]),
     "csdr_bank_set_fms_pilot": (_i, [_p, _i, _p, _p]),
     "csdr_bank_fetch_fms_stage": (_i, [_p, _i, _i, _p, _i, C.POINTER(_i)]),

@@ -145,6 +145,201 @@ class ShardedStream:
         self.bank.close(); self.post.close(); self.ctx.close()
 
 
+def slab_blocks(n_blocks: int, world: int):
+    """[(first block, blocks)] per rank: contiguous, the remainder on the first ranks"""
+    base, rem = divmod(n_blocks, world)
+    out, start = [], 0
+    for r in range(world):
+        cnt = base + (1 if r < rem else 0)
+        out.append((start, cnt))
+        start += cnt
+    return out
+
+
+class SlabStream:
+    """ONE IQ stream sharded by TIME for the channelizer and by CHANNEL for the demodulators (SURVEY.md 8e option 2) -- the variant
+    of ShardedStream that divides the channelizer's work as well.  Per batch of n_blocks blocks:
+
+        ingest rank: scatter  -> rank r holds blocks [b_r, b_r + n_r) of the batch plus the history_length input samples in front of them
+        every rank:  channelizer over ITS blocks, all M channels (SDRPost.set_history gives the polyphase windows their true contents;
+                     channel 0's DC blocker is a recurrence over the whole stream and is left to the channel's owner)
+        all-to-all:  rank r sends rank q the rows of q's channels for r's frames (RCCL over xGMI; gloo in CPU tests):
+                     8 bytes x frames x channels_q -- in total every channel sample crosses a link once
+        every rank:  assembles the full rows of ITS channels in a second post object (import_*: DC blocker on channel 0 there),
+                     then its own bank slots, as in ShardedStream.
+
+    The three phases are separate methods (produce / exchange / consume) so that one process can drive several "virtual ranks" on one
+    GPU and do the exchange by slicing (local_exchange): the sharded-equals-unsharded test.  Buffers are torch tensors on the GPU
+    (float32 [n, 2]); with use_torch=False (a host-executing test build of the library) they are numpy arrays."""
+
+    def __init__(self, device_index, rank, world, fs, M, block, demods, center, max_blocks, group=None, use_torch=True):
+        from .engine import Context, DemodBank, SDRPost
+        self.rank, self.world, self.group, self.use_torch = rank, world, group, use_torch
+        self.fs, self.M, self.block, self.center, self.max_blocks = fs, M, block, center, max_blocks
+        self.bc = block // M                                       # frames (samples per channel) of one block
+        self.demods = list(demods)
+        routed = [channel_at(f, center, fs, M) for _, _, f in self.demods]
+        self.channels = [data_channel(c, M) for c in routed]
+        self.plans = [plan(len(self.demods), self.channels, world, q) for q in range(world)]
+        self.plan = self.plans[rank]
+        self.owned = [p.active_channels for p in self.plans]        # rows each rank needs
+        stream = None
+        if use_torch:
+            import torch
+            if torch.cuda.is_available():
+                stream = torch.cuda.current_stream(device_index).cuda_stream
+        self.device_index = device_index
+        self.ctx = Context(device_index, stream=stream)
+        self.producer = SDRPost(self.ctx, fs, M, block, max_blocks=max(1, -(-max_blocks // world)))
+        self.producer.set_dc_blocker(False)
+        self.rows = SDRPost(self.ctx, fs, M, block, max_blocks=max_blocks)
+        self.rows.set_active_channels(self.owned[rank] if self.owned[rank] else [0])
+        self.hist = self.producer.history_length
+        self.bank = DemodBank(self.ctx, max(1, len(self.plan.demods)), max_blocks=max_blocks)
+        self.slot_of = {}
+        for slot, i in enumerate(self.plan.demods):
+            kind, bw, f = self.demods[i]
+            self.bank.configure(slot, self.rows, kind, bw, f)
+            self.slot_of[i] = slot
+        self._tail = self._empty(self.hist)                         # ingest rank: the input in front of the next batch
+        self._zero(self._tail)
+        self._keep = []
+
+    # ---- buffers
+    def _empty(self, n_samples):
+        if self.use_torch:
+            import torch
+            dev = torch.device("cuda", self.device_index) if torch.cuda.is_available() else torch.device("cpu")
+            return torch.empty((max(1, n_samples), 2), dtype=torch.float32, device=dev)
+        import numpy as np
+        return np.empty((max(1, n_samples), 2), np.float32)
+
+    @staticmethod
+    def _t(buf):
+        """the torch view a collective needs (numpy buffers of the CPU emulation share their memory with it)"""
+        if hasattr(buf, "data_ptr"):
+            return buf
+        import torch
+        return torch.from_numpy(buf)
+
+    @staticmethod
+    def _zero(buf):
+        if hasattr(buf, "zero_"):
+            buf.zero_()
+        else:
+            buf[...] = 0
+
+    # ---- ingest
+    def extended(self, batch, n_blocks):
+        """ingest rank: [history | batch] as one buffer and the new history; rank r's input is a window of it"""
+        n = n_blocks * self.block
+        ext = self._empty(self.hist + n)
+        ext[:self.hist] = self._tail
+        ext[self.hist:self.hist + n] = batch[:n]
+        self._tail = self._empty(self.hist)
+        self._tail[...] = ext[n:n + self.hist]
+        return ext
+
+    def window(self, ext, n_blocks, r):
+        start, cnt = slab_blocks(n_blocks, self.world)[r]
+        return ext[start * self.block: start * self.block + self.hist + cnt * self.block]
+
+    def scatter(self, batch, n_blocks, src=0):
+        """collective: every rank gets its window [history | its blocks]; needs n_blocks % world == 0 (equal windows)"""
+        import torch.distributed as dist
+        if n_blocks % self.world:
+            raise ValueError("scatter needs the batch's blocks to divide evenly over the ranks")
+        self.ctx.join()                                             # the previous batch's kernels have read the window buffer
+        mine = self._empty(self.hist + (n_blocks // self.world) * self.block)
+        parts = None
+        if self.rank == src:
+            ext = self.extended(batch, n_blocks)
+            parts = [self._t(self.window(ext, n_blocks, r)).contiguous() for r in range(self.world)]
+        dist.scatter(self._t(mine), parts, src=src, group=self.group)
+        return mine
+
+    # ---- the three phases
+    def produce(self, window, n_blocks):
+        """channelize this rank's blocks; returns the packed rows for every peer: [peer q][q's channels][this rank's frames]"""
+        start, cnt = slab_blocks(n_blocks, self.world)[self.rank]
+        frames = cnt * self.bc
+        send = self._empty(sum(len(o) for o in self.owned) * frames)
+        if cnt:
+            self.producer.set_history(window, self.hist)
+            self.producer.execute(window[self.hist:], cnt, self.block, self.center)
+            off = 0
+            for q in range(self.world):
+                if self.owned[q]:
+                    self.producer.export_rows(self.owned[q], send[off:], frames)
+                    off += len(self.owned[q]) * frames
+        self._keep = [window, send]
+        return send
+
+    def splits(self, n_blocks):
+        """(samples this rank sends to each peer, samples it receives from each peer)"""
+        sl = slab_blocks(n_blocks, self.world)
+        mine = sl[self.rank][1] * self.bc
+        return ([len(self.owned[q]) * mine for q in range(self.world)],
+                [len(self.owned[self.rank]) * sl[p][1] * self.bc for p in range(self.world)])
+
+    def exchange(self, send, n_blocks):
+        import torch.distributed as dist
+        ins, outs = self.splits(n_blocks)
+        recv = self._empty(sum(outs))
+        self.ctx.join()                                             # the export kernels have filled `send`
+        dist.all_to_all_single(self._t(recv)[:sum(outs)].view(-1), self._t(send)[:sum(ins)].view(-1), [2 * v for v in outs], [2 * v for v in ins], group=self.group)
+        return recv
+
+    def consume(self, recv, n_blocks):
+        sl = slab_blocks(n_blocks, self.world)
+        mine = self.owned[self.rank]
+        self.rows.import_begin(n_blocks, self.block, self.center)
+        off = 0
+        for p in range(self.world):
+            frames = sl[p][1] * self.bc
+            if mine and frames:
+                self.rows.import_rows(mine, recv[off:], frames, sl[p][0] * self.bc, frames)
+                off += len(mine) * frames
+        self.rows.import_commit()
+        self._keep.append(recv)
+        if self.plan.demods:
+            self.bank.execute(self.rows)
+
+    def step(self, window, n_blocks):
+        self.consume(self.exchange(self.produce(window, n_blocks), n_blocks), n_blocks)
+
+    def audio(self, demod_index):
+        return self.bank.audio(self.slot_of[demod_index])
+
+    def results(self, demod_index):
+        return self.bank.results(self.slot_of[demod_index])
+
+    def synchronize(self):
+        self.ctx.synchronize()
+
+    def close(self):
+        self.bank.close(); self.rows.close(); self.producer.close(); self.ctx.close()
+
+
+def local_exchange(streams, sends, n_blocks):
+    """the all-to-all of SlabStream done by slicing, for virtual ranks inside one process: returns each rank's receive buffer"""
+    world = len(streams)
+    for s in streams:
+        s.ctx.synchronize()
+    recvs = []
+    for q, sq in enumerate(streams):
+        _, outs = sq.splits(n_blocks)
+        recv = sq._empty(sum(outs))
+        off = 0
+        for p, sp in enumerate(streams):
+            ins, _ = sp.splits(n_blocks)
+            o = sum(ins[:q])
+            recv[off:off + outs[p]] = sends[p][o:o + ins[q]]
+            off += outs[p]
+        recvs.append(recv)
+    return recvs
+
+
 def broadcast_iq(batch, src: int = 0, group=None):
     """Broadcast one raw IQ batch (float32 [n, 2] or complex64 [n] tensor, pre-allocated on every rank) from the ingest
     rank.  One collective per batch, issued on the current stream so it overlaps the previous batch's kernels on the

@@ -1,8 +1,9 @@
 """bench.py --config C4: BASELINE config 4 -- ONE 100 MS/s IQ stream, firpfbch M = 1024, one NBFM demodulator per channel, the
 demodulators sharded over the ranks (cubicsdr_amd.parallel.ShardedStream): rank 0 owns the HBM-resident ring, every batch is
 broadcast (RCCL over xGMI), every rank channelizes for its own channels and runs its own slots.  scaling = "strong": the value is
-the one stream's MS/s (total work fixed as N grows).  The time-slab scatter + all-to-all variant (SURVEY.md 8e option 2) is not
-built; with the broadcast variant the redundant polyphase front bounds the speed-up (multi-GPU)."""
+the one stream's MS/s (total work fixed as N grows).  --shard slab runs the time-slab variant instead (SURVEY.md 8e option 2,
+cubicsdr_amd.parallel.SlabStream): scatter of [history | slab] windows, every rank channelizes ITS blocks for all channels, an
+all-to-all hands every rank the rows of its channels -- the channelizer's work is divided too."""
 import json
 import os
 import time
@@ -14,7 +15,7 @@ NBFM_BW, AUDIO = 12_500, 48_000
 def main(args):
     import torch
     from cubicsdr_amd import build as cbuild
-    from cubicsdr_amd.parallel import ShardedStream, channel_centers
+    from cubicsdr_amd.parallel import ShardedStream, SlabStream, channel_centers
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if rank == 0:
         cbuild.build(verbose=False)
@@ -34,11 +35,23 @@ def main(args):
     demods = [("NBFM", NBFM_BW, cc[ch] + 3700) for ch in range(M)]          # one per channel, 3.7 kHz off the channel centre (forces the NCO)
     g = torch.Generator(device=device); g.manual_seed(0xC0B1C5D2)
     ring = torch.randn(NB * BLOCK, 2, generator=g, device=device, dtype=torch.float32) * 0.05 + 0.01
-    st = ShardedStream(local_rank, rank, world, FS, M, BLOCK, demods, CENTER, NB)
+    slab = getattr(args, "shard", "broadcast") == "slab"
+    if slab and NB % world:
+        raise SystemExit("--shard slab needs --blocks divisible by the number of GPUs")
+    if slab:
+        st = SlabStream(local_rank, rank, world, FS, M, BLOCK, demods, CENTER, NB)
+    else:
+        st = ShardedStream(local_rank, rank, world, FS, M, BLOCK, demods, CENTER, NB)
 
     def step():
         for _ in range(NBATCH):
-            st.step(ring, NB, src=0)
+            if not slab:
+                st.step(ring, NB, src=0)
+            elif world > 1:
+                st.step(st.scatter(ring if rank == 0 else None, NB, src=0), NB)
+            else:
+                ext = st.extended(ring, NB)
+                st.consume(st.produce(st.window(ext, NB, 0), NB), NB)      # one rank: its own rows come straight back
 
     for _ in range(args.warmup):
         step()
@@ -61,10 +74,13 @@ def main(args):
     out = {"metric": "IQ MS/s sustained @ N demods + FFT size", "value": value, "unit": "MS/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "C4: 1024-channel firpfbch + 1024x NBFM (one per channel), 100 MS/s IQ, demodulators sharded over the ranks, IQ batches broadcast from rank 0 (RCCL)",
+           "config": {"workload": "C4: 1024-channel firpfbch + 1024x NBFM (one per channel), 100 MS/s IQ, demodulators sharded over the ranks, "
+                                  + ("time slabs scattered from rank 0, channel rows exchanged all-to-all (RCCL)" if slab else "IQ batches broadcast from rank 0 (RCCL)"),
+                      "shard": "slab" if slab else "broadcast",
                       "batches_per_step": NBATCH, "blocks_per_batch": NB, "block_len": BLOCK, "n_demods": M, "demods_on_rank0": len(st.plan.demods),
                       "channels_on_rank0": len(st.plan.active_channels), "realtime_multiple": value / (FS / 1e6), "timed_region_s": elapsed,
-                      "parallelism": "dp over demodulators (one IQ stream): broadcast + per-rank channel subset + per-rank bank"},
+                      "parallelism": ("time slabs -> per-rank channelizer -> all-to-all of channel rows -> per-rank bank" if slab else
+                                      "dp over demodulators (one IQ stream): broadcast + per-rank channel subset + per-rank bank")},
            "roofline": {"bound": "hbm", "whole_path": {"bytes_per_sample": round(bytes_per_sample, 1), "achieved": bytes_per_sample * value * 1e6 / 1e9,
                                                        "frac": bytes_per_sample * value * 1e6 / 1e9 / 8000.0 / world}}}
     st.close()

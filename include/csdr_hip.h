@@ -111,6 +111,20 @@ int     csdr_post_channel_at(const csdr_post *post, int64_t frequency);      /* 
 /* copy one channel's samples of the last execute to the host (tests / demod-visual tap); ch == M is the wrap
  * channel (alias of M/2, :359-361).  *n receives the number of complex samples written. */
 int  csdr_post_read_channel(csdr_post *post, int ch, float *host_out, int cap_samples, int *n);
+/* Time-slab sharding of ONE stream over several GPUs (SURVEY 8e option 2: each rank channelizes ITS blocks of a batch for all
+ * channels; an all-to-all gives every rank the full time series of the channels its demodulators sit on).  No reference
+ * counterpart: SDRPostThread runs on one thread.  Producer side: csdr_post_set_history (the csdr_post_history_length() input samples
+ * in front of the slab, device pointer; fewer = zeros in front), csdr_post_set_dc_blocker(0) (channel 0's DC blocker, SDRPostThread.cpp:375,
+ * is a recurrence over the whole stream: the owner of channel 0 runs it), csdr_post_execute, csdr_post_export_rows (rows of the listed
+ * channels of the last execute -> dst_dev[i * dst_stride + frame], complex float).  Owner side, on a second post object configured alike:
+ * csdr_post_import_begin, csdr_post_import_rows per peer (its frames at frame0), csdr_post_import_commit; then csdr_bank_execute. */
+int  csdr_post_history_length(const csdr_post *post);
+int  csdr_post_set_history(csdr_post *post, const float *dev_tail, int64_t n_samples);
+int  csdr_post_set_dc_blocker(csdr_post *post, int enabled);
+int  csdr_post_export_rows(csdr_post *post, const int *channels, int n, float *dst_dev, int64_t dst_stride);
+int  csdr_post_import_begin(csdr_post *post, int n_blocks, int block_len, int64_t frequency);
+int  csdr_post_import_rows(csdr_post *post, const int *channels, int n, const float *src_dev, int64_t src_stride, int64_t frame0, int64_t n_frames);
+int  csdr_post_import_commit(csdr_post *post);
 
 /* ------------------------------------------------------------------ demodulator bank
  * One slot == one DemodulatorInstance's DSP state: NCO shift + msresamp_crcf decimator

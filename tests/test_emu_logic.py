@@ -179,3 +179,7 @@ def test_emu_interpolating_iq_resampler(ctx):
 
 def test_emu_fm_stereo(ctx):
     print(G._fms_case(ctx, 2400000, 4, 20000, 4, 2))
+
+
+def test_emu_time_slab_sharding(ctx):
+    print(G._slab_case(ctx, 480000, 8, 8000, 6, 2, 4, 3, False, kinds=("NBFM", "AM")))

@@ -939,6 +939,66 @@ def test_sharded_stream_equals_unsharded(ctx):
         r.close()
 
 
+def _slab_case(ctx, fs, M, block, nd, n_batches, nb, world, use_torch, kinds=("NBFM",)):
+    """ONE stream sharded by time for the channelizer and by channel for the demodulators (parallel.SlabStream), `world` virtual ranks in
+    this process with the all-to-all done by slicing: every demodulator's audio and counts must equal the unsharded path's over
+    n_batches consecutive batches of nb blocks (the polyphase windows, channel 0's DC blocker and every demodulator state carry
+    across slabs AND batches).  A demodulator sits on channel 0 so that the deferred DC blocker is exercised."""
+    from cubicsdr_amd.engine import DemodBank, SDRPost
+    from cubicsdr_amd.parallel import SlabStream, local_exchange, slab_blocks
+    center = 400000000
+    freqs = demod_frequencies(center, fs, nd)
+    freqs[0] = center + 1500                                     # channel 0 (the DC-blocked row)
+    bw = {"NBFM": 12500, "AM": 6000, "USB": 5400}
+    demods = [(kinds[i % len(kinds)], bw[kinds[i % len(kinds)]], f) for i, f in enumerate(freqs)]
+    x = synth_iq(n_batches * nb * block, fs, center, [(k, f) for k, _, f in demods[:6]], seed=97)
+    post = SDRPost(ctx, fs, M, block, max_blocks=nb)
+    bank = DemodBank(ctx, nd, max_blocks=nb)
+    for i, (k, b, f) in enumerate(demods):
+        bank.configure(i, post, k, b, f)
+    whole, counts = [], []
+    for t in range(n_batches):
+        post.execute(x[t * nb * block:(t + 1) * nb * block], nb, block, center)
+        bank.execute(post)
+        whole.append([bank.audio(i) for i in range(nd)])
+        counts.append([[(r.n_iq, r.n_audio, r.nco_theta, r.resamp_phase) for r in bank.results(i)] for i in range(nd)])
+    bank.close(); post.close()
+    ranks = [SlabStream(0, r, world, fs, M, block, demods, center, nb, group=False, use_torch=use_torch) for r in range(world)]
+    assert sorted(sum((r.plan.demods for r in ranks), [])) == list(range(nd))
+    assert sum(c for _, c in slab_blocks(nb, world)) == nb
+    xf = x.view(np.float32).reshape(-1, 2)
+    worst = 0.0
+    for t in range(n_batches):
+        batch = xf[t * nb * block:(t + 1) * nb * block]
+        if use_torch:
+            import torch
+            batch = torch.from_numpy(batch.copy()).cuda()
+        ext = ranks[0].extended(batch, nb)                      # the ingest rank's [history | batch]
+        sends = [r.produce(r.window(ext, nb, r.rank), nb) for r in ranks]
+        recvs = local_exchange(ranks, sends, nb)
+        for r, rv in zip(ranks, recvs):
+            r.consume(rv, nb)
+        for r in ranks:
+            for i in r.plan.demods:
+                got = r.audio(i)
+                assert [(q.n_iq, q.n_audio, q.nco_theta, q.resamp_phase) for q in r.results(i)] == counts[t][i], (t, i)
+                assert got.shape == whole[t][i].shape, (t, i)
+                if not np.array_equal(got, whole[t][i]):
+                    worst = max(worst, rel_err(got, whole[t][i]))
+    for r in ranks:
+        r.close()
+    # rows are bit-identical except channel 0's, whose DC blocker scans tiles of another size (fp64 blocked scan: last-bit differences)
+    assert worst < 1e-6, worst
+    return worst
+
+
+def test_time_slab_sharding_equals_unsharded(ctx):
+    """SURVEY 8e option 2 on one GPU: 2 and 3 virtual ranks (3 does not divide the 4 blocks of a batch: uneven slabs), M = 64 channelizer,
+    24 mixed demodulators, 2 consecutive batches."""
+    print("slab worst", _slab_case(ctx, 6400000, 64, 106688, 24, 2, 4, 2, True, kinds=("NBFM", "AM", "USB")),
+          _slab_case(ctx, 6400000, 64, 106688, 24, 2, 4, 3, True))
+
+
 def test_c2_full_size_batching_invariance(ctx):
     """Size-independent property at the full C2 size: 64 NBFM demodulators, 16 blocks -- the audio, the resampled IQ and
     the per-block counts of one 16-block batch equal, bit for bit, those of 16 one-block batches."""

@@ -96,3 +96,67 @@ def test_channel_routing_twin_and_stream_plan():
             assert not (seen & set(p.active_channels))
             seen |= set(p.active_channels)
             assert abs(len(p.demods) - M // world) <= 1
+
+
+def _slab_worker(rank, world, port, q):
+    """one rank of parallel.SlabStream over gloo, its kernels run by the host-thread emulation of tests/emu (numpy buffers)"""
+    import ctypes as C
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import build_emu
+        import cubicsdr_amd.hip as H
+        lib = C.CDLL(build_emu.build(""))
+        for name, (res, args) in H.ABI.items():
+            fn = getattr(lib, name); fn.restype = res; fn.argtypes = args
+        H._lib = lib
+        from cubicsdr_amd.engine import Context, DemodBank, SDRPost
+        from cubicsdr_amd.parallel import SlabStream
+        from tests.util import demod_frequencies, synth_iq
+        fs, M, block, nd, nb, nbat, center = 480000, 8, 8000, 6, 4, 2, 400000000
+        freqs = demod_frequencies(center, fs, nd); freqs[0] = center + 1500
+        demods = [("NBFM" if i % 2 == 0 else "AM", 12500 if i % 2 == 0 else 6000, f) for i, f in enumerate(freqs)]
+        x = synth_iq(nbat * nb * block, fs, center, [(k, f) for k, _, f in demods], seed=97)
+        stream = SlabStream(0, rank, world, fs, M, block, demods, center, nb, use_torch=False)
+        # the unsharded answer for this rank's demodulators, computed locally
+        ctx = Context(0)
+        post = SDRPost(ctx, fs, M, block, max_blocks=nb); bank = DemodBank(ctx, nd, max_blocks=nb)
+        for i, (k, b, f) in enumerate(demods):
+            bank.configure(i, post, k, b, f)
+        ok, n_cmp = True, 0
+        xf = x.view(np.float32).reshape(-1, 2)
+        for t in range(nbat):
+            post.execute(x[t * nb * block:(t + 1) * nb * block], nb, block, center)
+            bank.execute(post)
+            window = stream.scatter(xf[t * nb * block:(t + 1) * nb * block] if rank == 0 else None, nb, src=0)
+            stream.step(window, nb)
+            for i in stream.plan.demods:
+                ok = ok and np.array_equal(stream.audio(i), bank.audio(i))
+                ok = ok and [(r.n_iq, r.n_audio, r.nco_theta) for r in stream.results(i)] == [(r.n_iq, r.n_audio, r.nco_theta) for r in bank.results(i)]
+                n_cmp += 1
+        stream.close(); bank.close(); post.close(); ctx.close()
+        q.put((rank, ok, n_cmp, stream.plan.demods))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_time_slab_stream_over_gloo():
+    """SURVEY 8e option 2 end to end on two processes: scatter of [history | slab] windows, per-rank channelizer over its slab, the
+    all-to-all of channel rows over gloo, assembly, demodulators -- each rank's audio equals the unsharded path's bit for bit (the HIP
+    kernels run through the CPU emulation; the GPU twin of this test is tests/test_gpu_parity.py::test_time_slab_sharding_equals_unsharded)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_slab_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    owned = []
+    for rank, ok, n_cmp, mine in res:
+        assert ok and n_cmp == 2 * len(mine), (rank, ok, n_cmp)
+        owned += mine
+    assert sorted(owned) == list(range(6))
