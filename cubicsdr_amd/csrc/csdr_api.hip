@@ -507,7 +507,8 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
         if (g.p2) {
             // persistent workgroups: as many as are resident at once, each walks over tiles blockIdx.x, + gridDim.x, ...
             const chan_p2_kernel_t k2 = chan_p2_kernel(g);
-            const int wgs = std::min(ntiles, c->wg_slots(k2, g.threads, chan_p2_lds_bytes(M)));
+            static const int chan_pct = getenv("CSDR_CHAN_PCT") ? std::max(10, std::min(100, atoi(getenv("CSDR_CHAN_PCT")))) : 100;
+            const int wgs = std::min(ntiles, std::max(1, c->wg_slots(k2, g.threads, chan_p2_lds_bytes(M)) * chan_pct / 100));
             CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, k2, dim3(wgs), dim3(g.threads), chan_p2_lds_bytes(M), x, hist, hist_new, p->taps.p,
                         p->twA.p, p->twM.p, p->active.p, g, n_frames, out, p->chan_stride, fused_ends ? p->tile_end.p : (d2 *)nullptr, p->dc_c);
         } else {
@@ -1143,7 +1144,8 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     // ranges per slot, PER LAUNCH (the slots are grouped by cascade depth, one launch per group on the same stream): as many as
     // make that launch's grid ONE round of resident workgroups (each range re-runs `warm` inputs, so fewer, longer ranges
     // waste less), but never shorter than 4 warm-up spans and never fewer than one
-    const int fe_slots = c->wg_slots(demod_frontend_s<5, 2048, true>, kFeThreads + 64, fes_lds_bytes<5, 2048>());
+    static const int fe_pct = getenv("CSDR_FE_PCT") ? std::max(10, std::min(100, atoi(getenv("CSDR_FE_PCT")))) : 100;
+    const int fe_slots = std::max(1, c->wg_slots(demod_frontend_s<5, 2048, true>, kFeThreads + 64, fes_lds_bytes<5, 2048>()) * fe_pct / 100);
     auto ranges_for = [&](int n_slots) {
         int P = (int)std::max<int64_t>(1, std::min<int64_t>(total / std::max<int64_t>(4096, 4 * (int64_t)warm_max), 4096));
         const int per_slot = fe_slots / std::max(1, n_slots) - 1;                          // one extra workgroup per slot carries the histories
