@@ -183,3 +183,7 @@ def test_emu_fm_stereo(ctx):
 
 def test_emu_time_slab_sharding(ctx):
     print(G._slab_case(ctx, 480000, 8, 8000, 6, 2, 4, 3, False, kinds=("NBFM", "AM")))
+@full
+def test_emu_fm_stereo_settings(ctx):
+    print(G._fms_case(ctx, 2400000, 4, 20000, 4, 2, bw=150000, audio_rate=44100, demph=0, seed=37))
+    print(G._fms_case(ctx, 2400000, 4, 20000, 4, 2, bw=50000, audio_rate=48000, demph=50, seed=37))

@@ -349,7 +349,7 @@ def test_bandwidth_above_channel_rate_interpolating_iq_resampler(ctx):
     print(_compare(got, want, "interp"))
 
 
-def _fms_case(ctx, fs, M, block, n_blocks, batch, bw=200000, seed=31):
+def _fms_case(ctx, fs, M, block, n_blocks, batch, bw=200000, seed=31, audio_rate=48000, demph=75):
     """FM stereo (ModemFMStereo.cpp) next to an NBFM demodulator.  What can and cannot be compared:
       * resampled IQ, counts, levels, the mono path and the SUM of the output channels (l + r = 2 x 0.568 x filtered mono: the
         stereo-difference stream cancels) -- within TOL like every other modem;
@@ -375,8 +375,8 @@ def _fms_case(ctx, fs, M, block, n_blocks, batch, bw=200000, seed=31):
     # ---- reference, twice: the second modem is fed the same resampled IQ plus noise of a TENTH of the IQ stream's parity tolerance
     prng = np.random.default_rng(seed + 1)
     ref_post = RefSDRPost("ref", fs, M)
-    r0 = RefDemod("ref", "FMS", bw, freqs[0], ref_post.chan_bw)
-    r1 = RefDemod("ref", "FMS", bw, freqs[0], ref_post.chan_bw)
+    r0 = RefDemod("ref", "FMS", bw, freqs[0], ref_post.chan_bw, audio_rate=audio_rate, demph=demph)
+    r1 = RefDemod("ref", "FMS", bw, freqs[0], ref_post.chan_bw, audio_rate=audio_rate, demph=demph)
     want, pert = [], []
     for b in range(n_blocks):
         ref_post.run_block(x[b * block:(b + 1) * block], center)
@@ -391,7 +391,7 @@ def _fms_case(ctx, fs, M, block, n_blocks, batch, bw=200000, seed=31):
     # ---- HIP path
     post = SDRPost(ctx, fs, M, block, max_blocks=batch)
     bank = DemodBank(ctx, 2, max_blocks=batch)
-    bank.configure(0, post, "FMS", bw, freqs[0])
+    bank.configure(0, post, "FMS", bw, freqs[0], audio_sample_rate=audio_rate, modem_arg=demph if demph else -1)
     bank.configure(1, post, "NBFM", 12500, freqs[1])
     got, theta, sdiff = [], [], []
     for b0 in range(0, n_blocks, batch):
@@ -436,7 +436,12 @@ def _fms_case(ctx, fs, M, block, n_blocks, batch, bw=200000, seed=31):
     n0 = theta.size // 3
     turns = np.cumsum(((np.diff(theta[n0:].astype(np.int64)) + 2 ** 31) % 2 ** 32 - 2 ** 31).astype(np.float64)) / 2 ** 32
     f_lock = turns[-1] / (theta.size - n0 - 1) * max(bw, 100000)
-    assert abs(f_lock - 19000.0) < 2.0, f_lock
+    assert want[0]["iq"].size * (fs / block) > 0.9 * max(bw, 100000)       # (the modem really runs at checkSampleRate(bw))
+    wturns = np.cumsum(((np.diff(wt[n0:].astype(np.int64)) + 2 ** 31) % 2 ** 32 - 2 ** 31).astype(np.float64)) / 2 ** 32
+    f_ref = wturns[-1] / (wt.size - n0 - 1) * max(bw, 100000)
+    assert abs(f_lock - f_ref) < 2.0, (f_lock, f_ref)           # the same lock as the reference's loop ...
+    if bw >= 150000:
+        assert abs(f_lock - 19000.0) < 2.0, f_lock               # ... which is the pilot when the multiplex fits the modem bandwidth
     dth = ((theta.astype(np.int64) - wt.astype(np.int64) + 2 ** 31) % 2 ** 32 - 2 ** 31) * (2 * np.pi / 2 ** 32)
     assert float(np.sqrt(np.mean(dth[n0:] ** 2))) < 4 * 2 * np.pi / 1024, float(np.sqrt(np.mean(dth[n0:] ** 2)))
     # ---- down-mix + c2r stage, given the HIP path's own phases: the reference's r2c / table oscillator / c2r functions on the
@@ -460,6 +465,12 @@ def _fms_case(ctx, fs, M, block, n_blocks, batch, bw=200000, seed=31):
     assert e_mix < TOL, e_mix
     return dict(iq=e_iq, sum=e_sum, diff=e_diff, ref_self_diff=self_diff, mix_stage=e_mix, lock_hz=float(f_lock), corr=corr,
                 theta_rms=float(np.sqrt(np.mean(dth[n0:] ** 2))))
+
+
+@pytest.mark.parametrize("bw,audio_rate,demph", [(250000, 44100, 50), (150000, 48000, 0), (50000, 48000, 75)])
+def test_fm_stereo_settings(ctx, bw, audio_rate, demph):
+    """other modem rates (250 kHz; 150 kHz; 50 kHz -> checkSampleRate lifts it to 100 kHz), 44.1 kHz audio, 50 us and no de-emphasis"""
+    print("fms", bw, audio_rate, demph, _fms_case(ctx, 2400000, 4, 40000, 4, 2, bw=bw, audio_rate=audio_rate, demph=demph, seed=37))
 
 
 def test_fm_stereo_modem(ctx):
