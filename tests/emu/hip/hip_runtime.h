@@ -129,6 +129,7 @@ static inline float __fadd_rn(float a, float b) { return a + b; }
 static inline float __fsub_rn(float a, float b) { return a - b; }
 static inline long long min(long long a, long long b) { return a < b ? a : b; }
 static inline long long max(long long a, long long b) { return a > b ? a : b; }
+static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 static inline unsigned __float_as_uint(float f) { unsigned u; __builtin_memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
