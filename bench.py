@@ -127,7 +127,7 @@ def measured_traffic(cfg_name):
     for name, v in t.items():
         if "FETCH_SIZE_KiB_avg_per_launch" in v and "WRITE_SIZE_KiB_avg_per_launch" in v:
             base = name.split("<")[0]
-            base = {"demod_frontend_s": "demod_frontend", "spec_fft_rows4096": "spec_fft_rows"}.get(base, base)
+            base = {"demod_frontend_s": "demod_frontend", "spec_fft_rows4096": "spec_fft_rows", "chan_analyze_p2": "chan_analyze"}.get(base, base)
             out[base] = out.get(base, 0.0) + (2.0 * v["FETCH_SIZE_KiB_avg_per_launch"] + v["WRITE_SIZE_KiB_avg_per_launch"]) * 1024.0 / blocks
     return out, os.path.relpath(files[-1], ROOT)
 

@@ -407,6 +407,23 @@ def _fms_case(ctx, fs, M, block, n_blocks, batch, bw=200000, seed=31, audio_rate
     assert bank.demod_output(0).size == 0                       # not a ModemAnalog: no demodOutputData tap
     post.close(); bank.close()
     theta = np.concatenate(theta); sdiff = np.concatenate(sdiff)
+    if batch > 1:
+        # block at a time: the pilot filter / loop state, the Hilbert windows, both resamplers and the output filters carry across
+        # every block boundary exactly as they do inside a batch -- same bits
+        post = SDRPost(ctx, fs, M, block, max_blocks=1)
+        bank = DemodBank(ctx, 2, max_blocks=1)
+        bank.configure(0, post, "FMS", bw, freqs[0], audio_sample_rate=audio_rate, modem_arg=demph if demph else -1)
+        bank.configure(1, post, "NBFM", 12500, freqs[1])
+        th1 = []
+        for b in range(n_blocks):
+            post.execute(x[b * block:(b + 1) * block], 1, block, center)
+            bank.execute(post)
+            r = bank.results(0)[0]
+            assert (r.n_iq, r.n_audio) == (got[b]["n_iq"], got[b]["n_audio"]), b
+            assert np.array_equal(bank.audio(0)[:r.n_audio], got[b]["audio"]), b
+            th1.append(bank.fms_stage(0, 0))
+        assert np.array_equal(np.concatenate(th1), theta)
+        post.close(); bank.close()
     # ---- counts, IQ, levels
     for b, (g, w) in enumerate(zip(got, want)):
         assert g["n_iq"] == w["iq"].size and g["n_audio"] == w["audio"].size and g["level_count"] == w["level_count"], b
