@@ -401,6 +401,12 @@ static int run_gpu() {
         auto d = mgr.newThread();
         d->setDemodulatorType("NBFM");
         d->setFrequency(center + 250000);
+        // a second instance, FM stereo at its default 200 kHz with the 50 us de-emphasis setting: stereo frames on its audio queue
+        auto dfms = mgr.newThread();
+        dfms->setDemodulatorType("FMS");
+        dfms->setFrequency(center - 600000);
+        dfms->writeModemSetting("demph", "50");
+        CHECK(dfms->getBandwidth() == 200000 && dfms->readModemSetting("demph") == "50");
         // demodulator spectrum (CubicSDR.cpp:373-381): the selected modem's channel -> a second processor in view mode
         mgr.setActiveDemodulator(d, false);
         SpectrumVisualProcessor demodSpec(ctx);
@@ -497,6 +503,13 @@ static int run_gpu() {
         while (aq->try_pop(ati)) { ++nblk; CHECK(ati->sampleRate == 48000 && ati->channels == 1); audio.insert(audio.end(), ati->data.begin(), ati->data.end()); }
         CHECK(nblk == 12);
         CHECK(std::abs((long)audio.size() - 9600) <= 4);
+        {
+            auto fq = dfms->getAudioOutputQueue();
+            int nf = 0; size_t fl = 0;
+            while (fq->try_pop(ati)) { ++nf; CHECK(ati->sampleRate == 48000 && ati->channels == 2 && ati->data.size() % 2 == 0); fl += ati->data.size(); }
+            std::printf("FM stereo audio blocks %d floats %zu\n", nf, fl);
+            CHECK(nf == 12 && std::abs((long)fl - 2 * 9600) <= 8);
+        }
         double re = 0, im = 0;
         const int a0 = 4800, na = (int)audio.size() - a0;
         for (int i = 0; i < na; ++i) { re += audio[a0 + i] * std::cos(2 * M_PI * 1000.0 * i / 48000.0); im += audio[a0 + i] * std::sin(2 * M_PI * 1000.0 * i / 48000.0); }
