@@ -43,13 +43,15 @@ extern "C" int csdr_ctx_create(int device, void *hip_stream, csdr_ctx **out) {
     std::unique_ptr<csdr_ctx> c(new csdr_ctx());
     c->device = device;
     if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cu < 1) c->n_cu = 256;
-    // Physical streams.  Measured on MI355X / ROCm 7.2: a per-batch cross-stream event edge costs ~0.3 ms, two orders
-    // of magnitude more than an in-stream kernel boundary, so by default the stages are folded onto the two chains that
-    // share no data: {SDRPostThread, demodulators} and {spectrum}.  CSDR_STREAMS = 1 | 2 | 3 | 5 selects other foldings
-    // (3: channelizer | demodulators | spectrum, 5: one stream per stage); the event protocol is the same for all.
-    int want = 2;
+    // Physical streams.  The five stage lanes are folded onto three streams by default: channelizer | demodulators | spectrum
+    // (the reference's own cut: SDRPostThread, the demodulator threads, the spectrum thread), so that the channelizer of batch
+    // n + 1 runs next to the demodulators of batch n.  Measured on MI355X / ROCm 7.2, C3: 1 / 2 / 3 / 5 streams = 51.0 / 50.9 /
+    // 52.8 / 52.3 GS/s at 128-block batches and 5.8 / 7.9 / 9.3 / 8.9 thousand one-block calls per second.  CSDR_STREAMS = 1 | 2 |
+    // 3 | 5 selects a folding (2: {channelizer + demodulators} | {spectrum}; 5: one stream per stage); the event protocol is the
+    // same for all.
+    int want = 3;
     if (const char *e = getenv("CSDR_STREAMS")) want = atoi(e);
-    if (want != 1 && want != 2 && want != 3 && want != 5) want = 2;
+    if (want != 1 && want != 2 && want != 3 && want != 5) want = 3;
     static const int kMap[6][LANE_COUNT] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 1, 1}, {0, 1, 1, 2, 2}, {0, 0, 0, 0, 0}, {0, 1, 2, 3, 4}};
     c->n_phys = want;
     for (int l = 0; l < want; ++l) {

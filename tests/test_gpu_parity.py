@@ -898,18 +898,20 @@ def test_active_channel_subset_matches_all_channels(ctx):
     from cubicsdr_amd.hip import CsdrError
     for fs, M, block in ((10000000, 20, 166680), (61440000, 122, 122 * 300)):
         center = 100000000
-        x = synth_iq(2 * block, fs, center, [("NBFM", center + 1234567)], seed=81)
+        x = synth_iq(4 * block, fs, center, [("NBFM", center + 1234567)], seed=81)
         full = SDRPost(ctx, fs, M, block, max_blocks=1)
         part = SDRPost(ctx, fs, M, block, max_blocks=1)
         active = sorted({0, 3, M // 2, M - 1, 7 % M})
         part.set_active_channels(active)
         sentinel = None
-        for b in range(2):
+        for b in range(4):
             full.execute(x[b * block:(b + 1) * block], 1, block, center)
             part.execute(x[b * block:(b + 1) * block], 1, block, center)
             for ch in range(M):
                 if ch in active:
                     assert np.array_equal(part.read_channel(ch), full.read_channel(ch)), (M, b, ch)
+            if b not in (0, 3):                                   # the output buffers rotate (three of them when the channelizer has
+                continue                                          # its own stream): blocks 0 and 3 land in the same one either way
             rows = {ch: part.read_channel(ch) for ch in range(M) if ch not in active}
             if sentinel is None:
                 sentinel = rows                                   # whatever the buffer held: it must not change any more
