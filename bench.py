@@ -321,6 +321,7 @@ def main():
                                           "frac": bytes_per_sample * value / world * 1e6 / 1e9 / HBM_PEAK_GBS,
                                           "traffic_bytes_per_sample": (sum(traffic.values()) / BLOCK if traffic else None)},
                            "profile_sampling": "HIP events around every %d-th launch of each kernel inside the timed region" % PROFILE_PERIOD,
+                           "concurrency": "the stages run on three streams (channelizer | demodulators | spectrum): during a launch of the dominant kernel up to two other kernels share the GPU, so this live duration is longer than the kernel's own (roofline.solo: the same batch on one stream)",
                            "kernels_avg_launch_ms": {k: v[0] / v[1] for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0] / kv[1][1])}}
     spec.close(); bank.close(); post.close(); ctx.close()
     if prof and rank == 0:
