@@ -198,6 +198,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline sample budget per leg (0 disables)")
     ap.add_argument("--shard", default="broadcast", choices=["broadcast", "slab"],
                     help="--config C4 only: how the ONE stream is spread over the GPUs (broadcast + channel subsets, or time slabs + all-to-all)")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2, 3, 5],
+                    help="physical HIP streams the stages of the TIMED pipeline are folded onto (default 1: every kernel runs alone, so the live "
+                         "per-kernel durations and roofline.frac are the kernel's own; the library's default folding is 3, measured next to it)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event profile")
     ap.add_argument("--no-latency", action="store_true", help="skip the small-batch (real-time shape) measurement")
     ap.add_argument("--ring", default="signal", choices=["signal", "noise"],
@@ -250,7 +253,12 @@ def main():
             b.configure(i, p, kind, MODEM_BW[kind], f, AUDIO_RATE)
         return c, p, b, SpectrumProcessor(c, FFT_SIZE, max_frames=(nb * BLOCK) // (2 * FFT_SIZE) + 2)
 
+    streams = int(os.environ.get("CSDR_STREAMS", args.streams))      # (an explicit environment setting wins)
+    env_had = os.environ.get("CSDR_STREAMS")
+    os.environ["CSDR_STREAMS"] = str(streams)
     ctx, post, bank, spec = make_pipeline(NB)
+    if env_had is None:
+        os.environ.pop("CSDR_STREAMS", None)
 
     def batch(p=post, b=bank, s=spec, nb=NB, x=ring):
         p.execute(x, nb, BLOCK, CENTER)
@@ -300,7 +308,8 @@ def main():
                    "realtime_multiple": value / world / (FS / 1e6), "audio_samples_per_batch": audio_total,
                    "timed_region_s": elapsed, "event_ms_per_step": ev_ms / args.steps,
                    "error_metric": "parity tests hold |gpu - reference| <= 1e-5 of the reference's peak magnitude per compared array (tests/util.py rel_err); integer items bit-exact",
-                   "parallelism": "one independent IQ stream per GPU; one HIP stream per pipeline chain, consecutive batches overlap"},
+                   "streams": streams,
+                   "parallelism": "one independent IQ stream per GPU; stages of the timed pipeline on %d HIP stream(s)" % streams},
     }
     if prof:
         units = NB * BLOCK                      # input samples one launch covers
@@ -321,10 +330,11 @@ def main():
                                           "frac": bytes_per_sample * value / world * 1e6 / 1e9 / HBM_PEAK_GBS,
                                           "traffic_bytes_per_sample": (sum(traffic.values()) / BLOCK if traffic else None)},
                            "profile_sampling": "HIP events around every %d-th launch of each kernel inside the timed region" % PROFILE_PERIOD,
-                           "concurrency": "the stages run on three streams (channelizer | demodulators | spectrum): during a launch of the dominant kernel up to two other kernels share the GPU, so this live duration is longer than the kernel's own (roofline.solo: the same batch on one stream)",
+                           "concurrency": ("one stream: every kernel runs alone, the live duration is the kernel's own" if streams == 1 else
+                                           "%d streams: other kernels share the GPU during a launch of the dominant kernel, so this live duration is longer than the kernel's own (roofline.solo: the same batch on one stream)" % streams),
                            "kernels_avg_launch_ms": {k: v[0] / v[1] for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0] / kv[1][1])}}
     spec.close(); bank.close(); post.close(); ctx.close()
-    if prof and rank == 0:
+    if prof and rank == 0 and streams != 1:
         # The live durations above include whatever the other stream's kernels took from the GPU at that moment (the two chains
         # overlap by design), so they move with the phase between the chains.  For a kernel-quality figure the same batch is run
         # once more, untimed, on ONE stream: every kernel alone on the device.
@@ -343,6 +353,22 @@ def main():
                                    "achieved": alg / (solo[dom] * 1e-3) / 1e9, "frac": alg / (solo[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "kernels_ms_per_launch": {k: v for k, v in sorted(solo.items(), key=lambda kv: -kv[1])}}
         spec1.close(); bank1.close(); post1.close(); ctx1.close()
+    if rank == 0 and world == 1 and not args.no_latency and streams != 3 and env_had is None:
+        # the library's default folding (three streams: channelizer | demodulators | spectrum) on the same batches, untimed part of the run
+        os.environ["CSDR_STREAMS"] = "3"
+        c3, p3, b3, s3 = make_pipeline(NB)
+        os.environ.pop("CSDR_STREAMS", None)
+        for _ in range(NBATCH):
+            batch(p3, b3, s3)
+        c3.synchronize()
+        t3 = time.perf_counter()
+        n3 = max(2, min(args.steps, 8))
+        for _ in range(n3 * NBATCH):
+            batch(p3, b3, s3)
+        c3.synchronize()
+        dt3 = time.perf_counter() - t3
+        out["config"]["library_default_streams"] = {"streams": 3, "MS_per_s": n3 * NBATCH * NB * BLOCK / dt3 / 1e6, "steps": n3}
+        s3.close(); b3.close(); p3.close(); c3.close()
     if rank == 0 and world == 1 and not args.no_latency:
         # the real-time shape: the reference hands ONE block (1/60 s of signal) per call (SoapySDRThread.cpp:12); small batches
         # through the same entry points, untimed part of the run, reported next to the throughput setting

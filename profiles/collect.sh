@@ -1,8 +1,9 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for bench.py on the GPU box (run from the repo root through gpurun):
 # usage: profiles/collect.sh TAG [BLOCKS_PER_BATCH] [CONFIG]
-#   1. --kernel-trace --stats            -> per-kernel call counts / average durations (default two-stream run, and once more
-#                                           with CSDR_STREAMS=1: every kernel alone on the device)
+#   1. --kernel-trace --stats            -> per-kernel call counts / average durations of the default command (stages on ONE stream:
+#                                           every kernel alone on the device), and once more with --streams 3 (the library's default
+#                                           folding: kernels of three stages share the GPU, their durations stretch accordingly)
 #   2. --pmc FETCH_SIZE  (own pass)      -> HBM read traffic per launch  (KiB; gfx950: doubled per MI355X_MICROARCH.md "HBM")
 #   3. --pmc WRITE_SIZE  (own pass)      -> HBM write traffic per launch (KiB)
 # Outputs land in gpurun_out/prof_<tag>/ ; the summaries are copied to profiles/ by hand and committed.
@@ -20,8 +21,8 @@ BENCH="python $REPO/bench.py --config $CFG --steps 2 --warmup 1 --batches 6 --cp
 # counter passes: the same command on a noise-only ring (the kernels' work does not depend on the sample values)
 PMCBENCH="$BENCH --ring noise"
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- $BENCH ) > $OUT/stats.log 2>&1
-# the same command with the stages on ONE stream: overlap-free kernel durations (compare with roofline.solo of bench.py)
-( cd /tmp && CSDR_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/solo -o b -- $BENCH ) > $OUT/solo.log 2>&1
+# the same command on the library's default three streams
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/solo -o b -- $BENCH --streams 3 ) > $OUT/solo.log 2>&1
 ( cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o b -- $PMCBENCH ) > $OUT/fetch.log 2>&1
 ( cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o b -- $PMCBENCH ) > $OUT/write.log 2>&1
 python - "$OUT" "$DST" "$NB" "$CFG" <<'PY'
@@ -34,7 +35,7 @@ for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
 for f in glob.glob(out + "/solo/**/*kernel_stats.csv", recursive=True):
     rows = [r for r in csv.reader(open(f))]
     keep = [rows[0]] + [r for r in rows[1:] if "csdr::" in r[0]]
-    csv.writer(open(dst + "/kernel_stats_one_stream.csv", "w")).writerows(keep)
+    csv.writer(open(dst + "/kernel_stats_three_streams.csv", "w")).writerows(keep)
 traffic = collections.defaultdict(dict)
 for name in ("fetch", "write"):
     acc = collections.defaultdict(list)
