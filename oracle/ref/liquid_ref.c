@@ -277,6 +277,7 @@ obj ampmodem_create(float mod_index, int type, int suppressed) { return ampmodem
 FN(int, ampmodem_destroy, obj)
 int ampmodem_destroy(obj q) { return ampmodem_destroy_get()(q); }
 FN(int, ampmodem_demodulate, obj, uint64_t, float *)
+int ampmodem_demodulate(obj q, cf32 x, float *y) { return ampmodem_demodulate_get()(q, pack(x), y); }
 int oracle_dsb_block(obj q, cf32 *in, unsigned n, float *out)
 { ampmodem_demodulate_t f = ampmodem_demodulate_get(); for (unsigned i = 0; i < n; i++) { uint64_t v; memcpy(&v, &in[i], 8); f(q, v, &out[i]); } return 0; }
 

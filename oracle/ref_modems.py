@@ -1,0 +1,145 @@
+"""TEST INFRASTRUCTURE ONLY (oracle/).  ctypes front of oracle/_ref/libref_modems.so: the reference's OWN modem classes
+(/root/reference/src/modules/modem/*.cpp, compiled in place by oracle/Makefile) running on the reference's own liquid binary.
+The strongest anchor this repository has for Modem::demodulate: oracle/cubicsdr_chain.py's RefDemod.demodulate -- the checker
+the GPU parity tests use -- is pinned against it, modem by modem, in tests/test_oracle_pin.py."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import liquid_api as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib_path():
+    return os.path.join(_HERE, "_ref", "libref_modems.so")
+
+
+def available():
+    return A.available("ref") and os.path.exists(lib_path())
+
+
+def load():
+    global _LIB
+    if _LIB is None:
+        A.load("ref")                                    # the liquid binary must be mapped before the first create()
+        C.CDLL(A.lib_path("ref"), mode=C.RTLD_GLOBAL)    # the modem library resolves liquid's names against this one
+        L = C.CDLL(lib_path())
+        L.refmodem_create.restype = C.c_void_p; L.refmodem_create.argtypes = [C.c_char_p]
+        L.refmodem_default_rate.restype = C.c_int; L.refmodem_default_rate.argtypes = [C.c_char_p]
+        L.refmodem_check_rate.restype = C.c_longlong; L.refmodem_check_rate.argtypes = [C.c_void_p, C.c_longlong, C.c_int]
+        L.refmodem_use_signal_output.restype = C.c_int; L.refmodem_use_signal_output.argtypes = [C.c_void_p]
+        L.refmodem_write_setting.restype = None; L.refmodem_write_setting.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.refmodem_build.restype = C.c_int; L.refmodem_build.argtypes = [C.c_void_p, C.c_longlong, C.c_int]
+        L.refmodem_demodulate.restype = C.c_int
+        L.refmodem_demodulate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.refmodem_demod_output.restype = C.c_int; L.refmodem_demod_output.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.refmodem_destroy.restype = None; L.refmodem_destroy.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+class RefModem:
+    """Modem::makeModem(name) + buildKit(checkSampleRate(bandwidth), audio_rate) + demodulate() block by block"""
+
+    def __init__(self, name, bandwidth, audio_rate=48000, settings=None):
+        self.L = load()
+        self.h = self.L.refmodem_create(name.encode())
+        if not self.h:
+            raise ValueError("the reference has no modem called %r" % name)
+        self.name = name
+        self.audio_rate = int(audio_rate)
+        self.rate = int(self.L.refmodem_check_rate(self.h, int(bandwidth), self.audio_rate))
+        for k, v in (settings or {}).items():
+            self.L.refmodem_write_setting(self.h, k.encode(), str(v).encode())
+        if self.L.refmodem_build(self.h, self.rate, self.audio_rate):
+            raise RuntimeError("buildKit failed")
+        self.use_signal_output = bool(self.L.refmodem_use_signal_output(self.h))
+
+    def demodulate(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        cap = 4 * iq.size + 4096
+        out = np.empty(cap, np.float32)
+        ch = C.c_int(0)
+        m = self.L.refmodem_demodulate(self.h, iq.ctypes.data_as(C.c_void_p), iq.size, self.rate, out.ctypes.data_as(C.c_void_p), cap, C.byref(ch))
+        if m < 0:
+            raise RuntimeError("audio buffer too small")
+        return out[:m].copy(), ch.value
+
+    def demod_output(self, cap=1 << 20):
+        out = np.empty(cap, np.float32)
+        m = self.L.refmodem_demod_output(self.h, out.ctypes.data_as(C.c_void_p), cap)
+        return None if m < 0 else out[:m].copy()
+
+    def close(self):
+        if self.h:
+            self.L.refmodem_destroy(self.h)
+            self.h = None
+
+
+# ---- the reference's own SpectrumVisualProcessor (oracle/_ref/libref_spectrum.so, oracle/ref/spectrum_harness.cpp) -------------
+_SLIB = None
+
+
+def spectrum_lib_path():
+    return os.path.join(_HERE, "_ref", "libref_spectrum.so")
+
+
+def spectrum_available():
+    return A.available("ref") and os.path.exists(spectrum_lib_path())
+
+
+def load_spectrum():
+    global _SLIB
+    if _SLIB is None:
+        A.load("ref")
+        C.CDLL(A.lib_path("ref"), mode=C.RTLD_GLOBAL)
+        L = C.CDLL(spectrum_lib_path())
+        L.refspec_create.restype = C.c_void_p; L.refspec_create.argtypes = [C.c_uint, C.c_longlong]
+        for name, args in (("refspec_set_average_rate", [C.c_void_p, C.c_float]), ("refspec_set_scale", [C.c_void_p, C.c_float]),
+                           ("refspec_set_peak_hold", [C.c_void_p, C.c_int]), ("refspec_set_hide_dc", [C.c_void_p, C.c_int]),
+                           ("refspec_set_center", [C.c_void_p, C.c_longlong]), ("refspec_set_bandwidth", [C.c_void_p, C.c_long]),
+                           ("refspec_set_view", [C.c_void_p, C.c_int, C.c_longlong, C.c_long]), ("refspec_destroy", [C.c_void_p])):
+            getattr(L, name).restype = None; getattr(L, name).argtypes = args
+        L.refspec_desired_input_size.restype = C.c_int; L.refspec_desired_input_size.argtypes = [C.c_void_p]
+        L.refspec_process.restype = C.c_int
+        L.refspec_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        _SLIB = L
+    return _SLIB
+
+
+class RefSpectrumCpp:
+    """SpectrumVisualProcessor of the reference: setup(fft_size), the setters, one process() per call"""
+
+    def __init__(self, fft_size, app_sample_rate=2400000):
+        self.L = load_spectrum()
+        self.F = int(fft_size)
+        self.h = self.L.refspec_create(self.F, int(app_sample_rate))
+
+    def set_average_rate(self, r): self.L.refspec_set_average_rate(self.h, float(r))
+    def set_scale(self, sf): self.L.refspec_set_scale(self.h, float(sf))
+    def set_peak_hold(self, on): self.L.refspec_set_peak_hold(self.h, 1 if on else 0)
+    def set_hide_dc(self, on): self.L.refspec_set_hide_dc(self.h, 1 if on else 0)
+    def set_center(self, f): self.L.refspec_set_center(self.h, int(f))
+    def set_bandwidth(self, bw): self.L.refspec_set_bandwidth(self.h, int(bw))
+    def set_view(self, on, center=0, bw=0): self.L.refspec_set_view(self.h, 1 if on else 0, int(center), int(bw))
+    def desired_input_size(self): return self.L.refspec_desired_input_size(self.h)
+
+    def process(self, iq, frequency, sample_rate):
+        """-> None (no output this call) or (points[2F], fft_ceiling, fft_floor, hold_points or None)"""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        cap = 2 * self.F + 16
+        pts = np.empty(cap, np.float32); hold = np.empty(cap, np.float32)
+        cf = np.zeros(2, np.float64); nh = C.c_int(0)
+        m = self.L.refspec_process(self.h, iq.ctypes.data_as(C.c_void_p), iq.size, int(frequency), int(sample_rate), pts.ctypes.data_as(C.c_void_p),
+                                   hold.ctypes.data_as(C.c_void_p), cap, cf.ctypes.data_as(C.c_void_p), C.byref(nh))
+        if m <= 0:
+            return None
+        return pts[:m].copy(), float(cf[0]), float(cf[1]), (hold[:nh.value].copy() if nh.value else None)
+
+    def close(self):
+        if self.h:
+            self.L.refspec_destroy(self.h)
+            self.h = None

@@ -212,6 +212,13 @@ def _ref_demods(x, fs, M, block, demods, bws, n_blocks, oversampled=False, modem
     be = _backend()
     ref_post = RefSDRPost(be, fs, M, oversampled=oversampled)
     refs = [RefDemod(be, k, bws[i], f, ref_post.chan_bw * (2 if oversampled and M > 1 else 1)) for i, (k, f) in enumerate(demods)]
+    # where the reference's own modem classes were built (oracle/_ref/libref_modems.so: src/modules/modem/analog/Modem*.cpp, unmodified),
+    # every block also goes through them: the Python glue the comparison uses must reproduce their audio bit for bit on THIS signal
+    cpp = None
+    if be == "ref" and len(demods) <= 64:
+        from oracle import ref_modems as RM
+        if RM.available():
+            cpp = [RM.RefModem(k, bws[i]) for i, (k, f) in enumerate(demods)]
     want = [[] for _ in demods]
     _ref_demods.last_channels = [None] * len(demods)          # the channel each demodulator was routed to (for the callers that ask)
     for b in range(n_blocks):
@@ -228,11 +235,17 @@ def _ref_demods(x, fs, M, block, demods, bws, n_blocks, oversampled=False, modem
                 want[i].append(None)
                 continue
             gpu_iq = modem_iq[i][b] if modem_iq and i in modem_iq else None
-            out = rd.demodulate(gpu_iq if gpu_iq is not None and gpu_iq.size == riq.size else riq)
+            miq = gpu_iq if gpu_iq is not None and gpu_iq.size == riq.size else riq
+            out = rd.demodulate(miq)
+            if cpp is not None and out is not None:
+                a, ch = cpp[i].demodulate(miq)
+                assert ch == out.get("channels", 1) and np.array_equal(a, out["audio"]), ("oracle glue differs from the reference's modem class", i, b)
             if out is None:       # no samples in this block: demodulate() returns at once, no audio item, no state change
                 out = dict(audio=np.zeros(0, np.float32), level_accum=0.0, level_count=0, peak=0.0)
             out["iq"] = riq
             want[i].append(out)
+    for m in cpp or []:
+        m.close()
     return want
 
 

@@ -220,3 +220,102 @@ def test_port_tracks_reference_on_fresh_inputs(P):
         S, bi, ph, st = C.c_uint(), C.c_uint(), C.c_uint32(), C.c_uint32()
         P.port_msresamp_get_state(C.c_void_p(qb), C.byref(S), C.byref(bi), C.byref(ph), C.byref(st))
         assert ph.value < (1 << 25)
+
+
+_MODEM_CASES = [("NBFM", 12500, 48000, {}), ("FM", 200000, 48000, {}), ("AM", 6000, 48000, {}), ("USB", 5400, 48000, {}), ("LSB", 5401, 44100, {}),
+                ("DSB", 5400, 48000, {}), ("CW", 500, 48000, {}), ("I/Q", 12345, 48000, {}), ("FMS", 200000, 48000, {}),
+                ("FMS", 250000, 44100, {"demph": 50}), ("FMS", 50000, 48000, {"demph": 0}), ("FM", 400000, 48000, {}), ("AM", 300, 48000, {})]
+
+
+@pytest.mark.parametrize("name,bw,audio_rate,settings", _MODEM_CASES)
+def test_python_modem_glue_equals_the_reference_modem_classes(name, bw, audio_rate, settings):
+    """oracle/cubicsdr_chain.py RefDemod.demodulate -- the checker of the GPU parity tests -- against the reference's OWN modem
+    sources (src/modules/modem/analog/Modem*.cpp compiled unmodified into oracle/_ref/libref_modems.so) on the reference's own liquid
+    binary: six consecutive blocks (ragged sizes, one empty), audio and channel count bit for bit, rate rules and useSignalOutput too."""
+    from oracle import ref_modems as RM
+    if not RM.available():
+        pytest.skip("oracle/_ref/libref_modems.so is built only where /root/reference is")
+    cpp = RM.RefModem(name, bw, audio_rate, settings)
+    py = RefDemod("ref", name, bw, 100000000, 600000, audio_rate=audio_rate, demph=int(settings.get("demph", 75)))
+    assert py.bandwidth == cpp.rate                                    # checkSampleRate
+    assert py.use_signal_output == cpp.use_signal_output
+    rng = np.random.default_rng(len(name) * 1000 + bw)
+    total = 0
+    for b in range(6):
+        n = 0 if b == 3 else int(round(cpp.rate / 60.0)) + (b % 3) - 1
+        t = (np.arange(n) + 1000 * b) / cpp.rate
+        iq = (0.3 * np.exp(2j * np.pi * 700.0 * t * (1 + 0.2 * np.sin(2 * np.pi * 300 * t))) * (1 + 0.5 * np.sin(2 * np.pi * 440 * t))
+              + 0.05 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+        w = py.demodulate(iq)
+        if n == 0:
+            assert w is None                                           # the reference's modems return at once on an empty block
+            continue
+        a, ch = cpp.demodulate(iq)
+        assert ch == w.get("channels", 1), (b, ch)
+        assert a.size == w["audio"].size and np.array_equal(a, w["audio"]), (name, b, a.size, w["audio"].size)
+        d = cpp.demod_output()
+        if d is not None and name not in ("CW",):                      # ModemAnalog::getDemodOutputData holds the block's (scaled) demodulator output
+            assert d.size == iq.size
+        total += a.size
+    assert total > 0
+    cpp.close()
+
+
+def _spectrum_pair(F, rate=2400000, freq=100000000):
+    from oracle import ref_modems as RM
+    cpp = RM.RefSpectrumCpp(F, rate)
+    cpp.set_center(freq); cpp.set_bandwidth(rate)
+    return cpp, RefSpectrum("ref", F)
+
+
+@pytest.mark.parametrize("case", ["full", "short_overlap", "scale_rate", "peak_hold", "hide_dc", "view"])
+def test_python_spectrum_glue_equals_the_reference_spectrum_processor(case):
+    """oracle/cubicsdr_chain.py RefSpectrum.process_input -- the checker of the GPU spectrum tests -- against the reference's OWN
+    src/process/SpectrumVisualProcessor.cpp (compiled unmodified into oracle/_ref/libref_spectrum.so) on its own liquid binary, one
+    process() per block: which calls produce output, the points, the held points, fft_ceiling / fft_floor -- bit for bit."""
+    from oracle import ref_modems as RM
+    if not RM.spectrum_available():
+        pytest.skip("oracle/_ref/libref_spectrum.so is built only where /root/reference is")
+    rng = np.random.default_rng(3)
+    freq, rate = 100000000, 2400000
+
+    def sig(n, t0):
+        t = np.arange(n) + t0
+        return (0.3 * np.exp(2j * np.pi * 0.07 * t) + 0.1 * np.exp(-2j * np.pi * 0.21 * t) * (1 + 0.5 * np.sin(2 * np.pi * t / 5000))
+                + 0.05 * (rng.standard_normal(n) + 1j * rng.standard_normal(n)) + 0.02).astype(np.complex64)
+
+    F, n, nblk, events = 1024, 40000, 6, {}
+    if case == "short_overlap":
+        F, n, nblk = 2048, 1500, 12
+    elif case == "scale_rate":
+        F, n = 512, 5000
+    elif case == "peak_hold":
+        nblk = 40
+    cpp, py = _spectrum_pair(F, rate, freq)
+    if case == "scale_rate":
+        cpp.set_scale(2.0); cpp.set_average_rate(0.3)
+        py.sf = float(np.float32(2.0)); py.rate = float(np.float32(0.3))
+    elif case == "peak_hold":
+        cpp.set_peak_hold(True); py.set_peak_hold(True)
+        events = {20: True, 33: False}                                   # a second "on" restarts the hold (PEAK_RESET_COUNT), then off
+    elif case == "hide_dc":
+        cpp.set_hide_dc(True); py.set_hide_dc(True, freq, rate, freq)
+    elif case == "view":
+        cpp.set_view(True, freq + 250000, 300000); py.set_view(True, freq + 250000, 300000)
+    nout = 0
+    for b in range(nblk):
+        if b in events:
+            cpp.set_peak_hold(events[b]); py.set_peak_hold(events[b])
+        x = sig(n, b * n)
+        a, w = cpp.process(x, freq, rate), py.process_input(x, freq, rate)
+        assert (a is None) == (w is None), (case, b)
+        if a is None:
+            continue
+        nout += 1
+        assert np.array_equal(a[0], w[0]), (case, b, float(np.abs(a[0] - w[0]).max()))
+        assert a[1] == w[1] and a[2] == w[2], (case, b)
+        assert (a[3] is None) == (w[3] is None), (case, b)
+        if a[3] is not None:
+            assert np.array_equal(a[3], w[3]), (case, b)
+    assert nout >= nblk - 2
+    cpp.close()
