@@ -319,3 +319,30 @@ def test_python_spectrum_glue_equals_the_reference_spectrum_processor(case):
             assert np.array_equal(a[3], w[3]), (case, b)
     assert nout >= nblk - 2
     cpp.close()
+
+
+@pytest.mark.parametrize("fft,lps,rate,blk", [(2048, 30, 2400000, 40000), (4096, 60, 10000000, 166680), (1024, 10, 250000, 4167), (2048, 120, 2400000, 40000)])
+def test_python_line_pacing_equals_the_reference_distributor(fft, lps, rate, blk):
+    """oracle/fft_distributor.py (the checker of the waterfall line pacing, host mirror and GPU tests) against the reference's OWN
+    src/process/FFTDataDistributor.cpp (oracle/_ref/libref_distributor.so): 40 blocks with a retune in the middle -- which input
+    produces which lines, each line's first sample and length, identical."""
+    from oracle.fft_distributor import FFTDataDistributorRef
+    path = os.path.join(os.path.dirname(A.lib_path("ref")), "libref_distributor.so")
+    if not (A.available("ref") and os.path.exists(path)):
+        pytest.skip("oracle/_ref/libref_distributor.so is built only where /root/reference is")
+    A.load("ref"); C.CDLL(A.lib_path("ref"), mode=C.RTLD_GLOBAL)
+    L = C.CDLL(path)
+    L.refdist_create.restype = C.c_void_p; L.refdist_create.argtypes = [C.c_uint, C.c_uint]
+    L.refdist_push.restype = C.c_int; L.refdist_push.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p, C.c_int]
+    L.refdist_destroy.argtypes = [C.c_void_p]
+    h = L.refdist_create(fft, lps); py = FFTDataDistributorRef(fft, lps)
+    nid = lines = 0
+    for b in range(40):
+        f = 100000000 if b < 25 else 101000000
+        ids = np.zeros(10000, np.int64); ln = np.zeros(10000, np.int32)
+        m = L.refdist_push(h, blk, f, rate, A.ptr(ids), A.ptr(ln), 10000)
+        want = py.push(list(range(nid, nid + blk)), f, rate); nid += blk
+        assert [(int(ids[i]), int(ln[i])) for i in range(m)] == [(w[0], w[1]) for w in want], b
+        lines += m
+    assert lines > 3
+    L.refdist_destroy(h)
