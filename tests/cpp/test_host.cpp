@@ -157,6 +157,73 @@ static void test_distributors() {
 }
 
 // the Modem registry / descriptor surface (Modem.h:127-166) and the DemodulatorInstance calls that go through it
+// cubicsdr_amd/host/ScopeVisualProcessor.h against the reference's OWN ScopeVisualProcessor.cpp (oracle/_ref/libref_scope.so, built by
+// oracle/Makefile from the unmodified source; test infrastructure, loaded only here): the same audio frames through both -- scope modes Y /
+// 2Y / XY, mono and stereo spectra, a decimated demodulator-output tap (sampleRate != inputRate), more samples than the scope shows.
+#include <dlfcn.h>
+static void test_scope_against_reference(csdr_ctx *ctx, const char *root) {
+    const std::string path = std::string(root) + "/oracle/_ref/libref_scope.so";
+    void *lib = dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) { std::printf("scope reference not built (%s): skipped\n", dlerror()); return; }
+    auto r_create = (void *(*)(int))dlsym(lib, "refscope_create");
+    auto r_push = (int (*)(void *, const float *, int, int, int, int, int))dlsym(lib, "refscope_push");
+    auto r_get = (int (*)(void *, int, float *, int, int *, double *))dlsym(lib, "refscope_get");
+    auto r_destroy = (void (*)(void *))dlsym(lib, "refscope_destroy");
+    CHECK(r_create && r_push && r_get && r_destroy);
+    if (!r_create || !r_push || !r_get || !r_destroy) return;
+    void *ref = r_create(DEFAULT_SCOPE_FFT_SIZE);
+    ScopeVisualProcessor scope(ctx);
+    auto in = std::make_shared<DemodulatorThreadOutputQueue>();
+    auto out = std::make_shared<ScopeRenderDataQueue>();
+    in->set_max_num_items(4); out->set_max_num_items(8);
+    scope.setInput(in); scope.attachOutput(out);
+    scope.setup(DEFAULT_SCOPE_FFT_SIZE);
+    struct Case { int n, channels, inputRate, sampleRate, type; };
+    const Case cases[] = {{800, 1, 48000, 48000, 0}, {800, 1, 48000, 48000, 0}, {1600, 2, 48000, 48000, 1}, {1600, 2, 48000, 48000, 2},
+                          {2048, 1, 200000, 48000, 0}, {3000, 1, 48000, 48000, 0}, {300, 1, 12500, 12500, 0}, {800, 1, 48000, 48000, 0}};
+    double worst = 0.0;
+    int frames = 0;
+    unsigned seed = 12345u;
+    for (const Case &c : cases) {
+        std::vector<float> data((size_t)c.n);
+        for (int i = 0; i < c.n; ++i) {
+            seed = seed * 1664525u + 1013904223u;
+            data[i] = (float)(0.7 * std::sin(2 * M_PI * 1000.0 * i / 48000.0 + 0.3 * c.type) + 0.4 * std::sin(2 * M_PI * 5200.0 * i / 48000.0)
+                              + 0.05 * ((double)(seed >> 8) / (1 << 24) - 0.5)) * (c.type == 2 ? 1.7f : 1.0f);
+        }
+        const int nref = r_push(ref, data.data(), c.n, c.channels, c.inputRate, c.sampleRate, c.type);
+        auto a = std::make_shared<AudioThreadInput>();
+        a->channels = c.channels; a->inputRate = c.inputRate; a->sampleRate = c.sampleRate; a->type = c.type; a->data = data;
+        in->push(a);
+        scope.run();
+        std::vector<ScopeRenderDataPtr> got;
+        ScopeRenderDataPtr o;
+        while (out->try_pop(o)) got.push_back(o);
+        CHECK((int)got.size() == nref && nref == 2);
+        for (int k = 0; k < nref && k < (int)got.size(); ++k) {
+            std::vector<float> pts(16384);
+            int meta[6]; double fc[2];
+            const int m = r_get(ref, k, pts.data(), (int)pts.size(), meta, fc);
+            CHECK(m == (int)got[k]->waveform_points.size());
+            CHECK(meta[0] == (int)got[k]->mode && (meta[1] != 0) == got[k]->spectrum && meta[2] == got[k]->channels && meta[3] == got[k]->inputRate && meta[4] == got[k]->sampleRate);
+            if (got[k]->spectrum) {
+                CHECK(meta[5] == got[k]->fft_size);
+                CHECK(std::fabs(fc[0] - got[k]->fft_floor) <= 1e-5 * std::fabs(fc[1]) && std::fabs(fc[1] - got[k]->fft_ceil) <= 1e-5 * std::fabs(fc[1]));
+            }
+            double peak = 1e-30, err = 0.0;
+            for (int i = 0; i < m && i < (int)got[k]->waveform_points.size(); ++i) {
+                peak = std::max(peak, (double)std::fabs(pts[i]));
+                err = std::max(err, (double)std::fabs(pts[i] - got[k]->waveform_points[i]));
+            }
+            worst = std::max(worst, err / peak);
+            ++frames;
+        }
+    }
+    std::printf("scope against the reference's ScopeVisualProcessor: %d frames, worst error %.2e of the frame's peak\n", frames, worst);
+    CHECK(worst < 1e-5);
+    r_destroy(ref);
+}
+
 static void test_modem_shim() {
     CHECK(Modem::getFactories().size() == 9);
     CHECK(Modem::getModemDefaultSampleRate("NBFM") == 12500 && Modem::getModemDefaultSampleRate("FM") == 200000 && Modem::getModemDefaultSampleRate("I/Q") == 48000);
@@ -374,9 +441,10 @@ static int run_level() {
     return 0;
 }
 
-static int run_gpu() {
+static int run_gpu(const char *root) {
     csdr_ctx *ctx = nullptr;
     csdr_must(csdr_ctx_create(0, nullptr, &ctx), "csdr_ctx_create");
+    test_scope_against_reference(ctx, root);
     {
         DemodulatorMgr mgr(8);
         SDRPostThread post(ctx, &mgr);
@@ -606,7 +674,7 @@ int main(int argc, char **argv) {
     if (argc > 1 && !std::strcmp(argv[1], "distrib")) return run_distrib();
     if (argc > 1 && !std::strcmp(argv[1], "level")) return run_level();
     const bool gpu = argc > 1 && !std::strcmp(argv[1], "gpu");
-    if (gpu) { int f = run_gpu(); std::printf(f ? "GPU HOST TEST FAILED (%d)\n" : "gpu host test ok\n", f); return f ? 1 : 0; }
+    if (gpu) { int f = run_gpu(argc > 2 ? argv[2] : "."); std::printf(f ? "GPU HOST TEST FAILED (%d)\n" : "gpu host test ok\n", f); return f ? 1 : 0; }
     test_queue();
     test_rebuffer();
     test_iothread();

@@ -17,7 +17,7 @@ def _build():
     if os.path.exists(EXE) and all(os.path.getmtime(d) <= os.path.getmtime(EXE) for d in deps):
         return
     subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-pthread", src, "-o", EXE, "-L" + os.path.join(ROOT, "cubicsdr_amd"),
-                    "-lcsdr_hip", "-Wl,-rpath," + os.path.join(ROOT, "cubicsdr_amd")], check=True)
+                    "-lcsdr_hip", "-ldl", "-Wl,-rpath," + os.path.join(ROOT, "cubicsdr_amd")], check=True)
 
 
 def test_queue_rebuffer_iothread_visualprocessor_semantics():
@@ -107,7 +107,7 @@ def test_level_squelch_state_machine_matches_oracle():
 def test_threaded_pipeline_on_gpu():
     """SDRThreadIQData blocks -> SDRPostThread (HIP) -> NBFM audio queue + spectrum queue, through real threads/queues"""
     _build()
-    r = subprocess.run([EXE, "gpu"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([EXE, "gpu", ROOT], capture_output=True, text=True, timeout=300)
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "gpu host test ok" in r.stdout
