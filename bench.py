@@ -230,7 +230,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("CSDR_DIST_BACKEND", "nccl"), rank=rank, world_size=world)   # ("nccl" is RCCL; the override exists for one-GPU dry runs of the multi-rank control flow)
         dist.barrier()
     else:
         torch.cuda.set_device(local_rank)

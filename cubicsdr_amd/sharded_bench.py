@@ -27,7 +27,7 @@ def main(args):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("CSDR_DIST_BACKEND", "nccl"), rank=rank, world_size=world)   # ("nccl" is RCCL; the override exists for one-GPU dry runs of the multi-rank control flow)
         dist.barrier()
     NB = args.blocks or 16
     NBATCH = args.batches or 24
