@@ -24,9 +24,8 @@ def available():
 def load():
     global _LIB
     if _LIB is None:
-        A.load("ref")                                    # the liquid binary must be mapped before the first create()
-        C.CDLL(A.lib_path("ref"), mode=C.RTLD_GLOBAL)    # the modem library resolves liquid's names against this one
-        L = C.CDLL(lib_path())
+        A.load("ref")                                    # the liquid binary is mapped before the first create(); the modem library names
+        L = C.CDLL(lib_path())                           # libliquid_ref.so as a dependency (same file: one instance), nothing goes global
         L.refmodem_create.restype = C.c_void_p; L.refmodem_create.argtypes = [C.c_char_p]
         L.refmodem_default_rate.restype = C.c_int; L.refmodem_default_rate.argtypes = [C.c_char_p]
         L.refmodem_check_rate.restype = C.c_longlong; L.refmodem_check_rate.argtypes = [C.c_void_p, C.c_longlong, C.c_int]
@@ -95,7 +94,6 @@ def load_spectrum():
     global _SLIB
     if _SLIB is None:
         A.load("ref")
-        C.CDLL(A.lib_path("ref"), mode=C.RTLD_GLOBAL)
         L = C.CDLL(spectrum_lib_path())
         L.refspec_create.restype = C.c_void_p; L.refspec_create.argtypes = [C.c_uint, C.c_longlong]
         for name, args in (("refspec_set_average_rate", [C.c_void_p, C.c_float]), ("refspec_set_scale", [C.c_void_p, C.c_float]),

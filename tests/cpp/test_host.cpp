@@ -163,7 +163,7 @@ static void test_distributors() {
 #include <dlfcn.h>
 static void test_scope_against_reference(csdr_ctx *ctx, const char *root) {
     const std::string path = std::string(root) + "/oracle/_ref/libref_scope.so";
-    void *lib = dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    void *lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!lib) { std::printf("scope reference not built (%s): skipped\n", dlerror()); return; }
     auto r_create = (void *(*)(int))dlsym(lib, "refscope_create");
     auto r_push = (int (*)(void *, const float *, int, int, int, int, int))dlsym(lib, "refscope_push");

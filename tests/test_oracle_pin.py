@@ -330,7 +330,7 @@ def test_python_line_pacing_equals_the_reference_distributor(fft, lps, rate, blk
     path = os.path.join(os.path.dirname(A.lib_path("ref")), "libref_distributor.so")
     if not (A.available("ref") and os.path.exists(path)):
         pytest.skip("oracle/_ref/libref_distributor.so is built only where /root/reference is")
-    A.load("ref"); C.CDLL(A.lib_path("ref"), mode=C.RTLD_GLOBAL)
+    A.load("ref")
     L = C.CDLL(path)
     L.refdist_create.restype = C.c_void_p; L.refdist_create.argtypes = [C.c_uint, C.c_uint]
     L.refdist_push.restype = C.c_int; L.refdist_push.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p, C.c_int]
