@@ -18,6 +18,11 @@ def _cptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+_LIBM = C.CDLL("libm.so.6")
+_LIBM.log10f.restype = C.c_float; _LIBM.log10f.argtypes = [C.c_float]
+_LIBM.powf.restype = C.c_float; _LIBM.powf.argtypes = [C.c_float, C.c_float]
+
+
 class RefSDRPost:
     """SDRPostThread (src/sdr/SDRPostThread.cpp): runSingleCH :248-299, runPFBCH :416-455, runDemodChannels :303-398."""
 
@@ -248,8 +253,9 @@ class RefDemod:
             self.ceil_ma = f32(self.ceil_ma + f32(f32(self.ceil - self.ceil_ma) * f32(0.025)))            # :182-183
             self.ceil_maa = f32(self.ceil_maa + f32(f32(self.ceil_ma - self.ceil_maa) * f32(0.025)))
             self.ceil = f32(max(0.0, float(d.max()))) if m else f32(0)                                    # :184-190 (signed maximum from 0)
-            self.cw_gain = f32(f32(10.0) * f32(np.log10(f32(f32(0.5) / self.ceil_maa))))                  # :192
-            audio = (d * f32(np.power(f32(10.0), f32(self.cw_gain / f32(10.0))))).astype(np.float32)     # :196-198
+            # std::log10(float) / std::pow(float, float) are the C library's log10f / powf (numpy's float32 routines differ in the last place)
+            self.cw_gain = f32(f32(10.0) * f32(_LIBM.log10f(float(f32(f32(0.5) / self.ceil_maa)))))        # :192
+            audio = (d * f32(_LIBM.powf(10.0, float(f32(self.cw_gain / f32(10.0)))))).astype(np.float32)   # :196-198
             accum = float(np.sum(np.abs(audio.astype(np.float64))))
             peak = float(np.max(np.abs(audio))) if m else 0.0
             return dict(audio=audio, level_accum=accum, level_count=m, peak=peak, demod=demod_unscaled)
