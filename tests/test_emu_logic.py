@@ -193,3 +193,13 @@ def test_emu_fm_stereo_settings(ctx):
 def test_emu_channelizer_m_twice_odd(ctx, fs, M, block):
     """M = 2 A, A odd: the one-lane-per-frame kernel with its mover wave (ragged and whole 64-frame tiles, carried history)"""
     G.test_channelizer_m_twice_odd(ctx, fs, M, block)
+
+
+def test_emu_spectrum_contiguous_batches_multi_row(ctx):
+    """the control flow of the headline spectrum test (carry across calls, > 256-frame rounds, row-pair tiles) at a size the emulation finishes"""
+    G._spectrum_contiguous_batches(ctx, 4096, 2400000, (8, 20, 5))
+
+
+@full
+def test_emu_spectrum_contiguous_batches_multi_row_rounds(ctx):
+    G._spectrum_contiguous_batches(ctx, 4096, 2400000, (40, 270, 33))

@@ -793,6 +793,78 @@ def test_spectrum_many_frames_one_batch(ctx):
     sp.close()
 
 
+def _ref_spectrum_frames(F, fs):
+    """per-frame checker for the large spectrum shapes: the reference's OWN SpectrumVisualProcessor (oracle/_ref/libref_spectrum.so,
+    compiled unmodified) where it travelled, else the pinned Python restatement.  Returns f(frame) -> (points, ceiling, floor)."""
+    import oracle.ref_modems as RM
+    from oracle.cubicsdr_chain import RefSpectrum
+    if _backend() == "ref" and RM.spectrum_available():
+        cpp = RM.RefSpectrumCpp(F, fs)
+        cpp.set_center(0); cpp.set_bandwidth(fs)                       # full span: bandwidth == the input rate (visualRatio 1, :534)
+
+        def step(frame):
+            pts, ce, fl, _ = cpp.process(frame, 0, fs)
+            return pts, ce, fl
+        return step, "reference class"
+    ref = RefSpectrum(_backend(), F)
+    return ref.process_frame, "restatement"
+
+
+@pytest.mark.parametrize("F,fs,frames_per_batch", [(65536, 61440000, (320, 300, 333)), (16384, 10000000, (300, 520, 301))])
+def test_spectrum_headline_shape_contiguous_batches(ctx, F, fs, frames_per_batch):
+    _spectrum_contiguous_batches(ctx, F, fs, frames_per_batch)
+
+
+def _spectrum_contiguous_batches(ctx, F, fs, frames_per_batch):
+    """The BASELINE spectrum shapes as the bench runs them: F = 65536 (C3: 32 rows of 4096 behind a radix-32 pass) and F = 16384 (C2),
+    CSDR_SPEC_CONTIGUOUS, >= 300 frames per call (several 256-frame rounds of the averaging scan, multi-row tiles), three consecutive
+    batches carrying the averagers, the ceiling / floor trackers and a partial frame (the batches are NOT whole multiples of 2F) from
+    one call to the next, input resident in HBM.  EVERY frame is compared with the reference processor fed the same frames one
+    process() at a time: points at 1e-5 of the frame's peak, ceiling / floor at 1e-5 (SpectrumVisualProcessor.cpp:387-576, :626-627)."""
+    from cubicsdr_amd.engine import SpectrumProcessor
+    try:
+        import torch
+        dev = torch.device("cuda", 0) if torch.cuda.is_available() else None
+    except Exception:
+        dev = None
+    N = 2 * F
+    odd = (1000, 77, N - 1077)                                        # samples left over after the last whole frame of each call
+    lens = [nf * N + o for nf, o in zip(frames_per_batch, odd)]
+    lens[1] -= 1000; lens[2] -= 77                                     # call k starts with the carry of call k - 1
+    total = sum(lens)
+    carriers = [("NBFM", 0.21 * fs), ("AM", -0.33 * fs), ("USB", 0.05 * fs), ("NBFM", -0.07 * fs)]
+    x = synth_iq_fast(total, fs, 0, carriers, seed=4242)
+    # slow fade so that ceiling / floor trackers and the averagers keep moving over the ~1000 frames
+    nfr = -(-total // N)
+    env = np.repeat((1.0 + 0.6 * np.sin(np.arange(nfr) * 0.05)).astype(np.float32), N)[:total]
+    x *= env
+    del env
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    step, kind = _ref_spectrum_frames(F, fs)
+    sp = SpectrumProcessor(ctx, F, max_frames=max(frames_per_batch) + 1)
+    pos = done = 0
+    worst = worst_c = 0.0
+    for k, n in enumerate(lens):
+        xd = torch.from_numpy(x[pos:pos + n].view(np.float32).reshape(-1, 2)).to(dev) if dev is not None else x[pos:pos + n]
+        nf = sp.process(xd, 1, n, contiguous=True)
+        expect = (pos + n) // N - done
+        assert nf == expect, (k, nf, expect)
+        for j in range(nf):
+            wp, wce, wfl = step(x[(done + j) * N:(done + j + 1) * N])
+            pts, ce, fl = sp.fetch(j)
+            e = rel_err(pts, wp)
+            worst = max(worst, e)
+            worst_c = max(worst_c, abs(ce - wce) / abs(wce), abs(fl - wfl) / abs(wce))
+            assert e < TOL, (k, j, e)
+            assert abs(ce - wce) <= TOL * abs(wce) and abs(fl - wfl) <= TOL * abs(wce), (k, j, ce, wce, fl, wfl)
+        done += nf
+        pos += n
+        del xd
+    assert done == total // N
+    print("spectrum F=%d (%s): %d frames, worst points %.3g, worst ceiling/floor %.3g" % (F, kind, done, worst, worst_c))
+    sp.close()
+
+
 def test_pipelined_batches_equal_synchronised_batches(ctx):
     """The stage streams let consecutive batches overlap (channelizer of batch i+1 while the demodulators work on batch
     i; buffer rotations guarded by events).  Enqueue 6 batches back to back without touching the results, then compare the
