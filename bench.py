@@ -90,19 +90,50 @@ def make_ring(torch, device, cfg, n_blocks, seed):
 
 # algorithmic HBM bytes per INPUT SAMPLE attributed to each kernel (DESIGN.md "Roofline accounting"):
 #   ingest read 8 + channelizer write 8 ; demod reads 8 N/M + audio writes ; spectrum read 8 + display write 4
+def cascade_depth(bw, chan_rate):
+    """half-band stages of the decimating msresamp for bandwidth / channel rate (liquid msresamp: while (r < 0.5) { S++; r *= 2 })"""
+    r, S = float(bw) / float(chan_rate), 0
+    while r < 0.5:
+        S += 1
+        r *= 2.0
+    return S
+
+
+def frontend_groups(cfg):
+    """demodulators per front-end kernel instance (one launch per cascade depth, csdr_api.hip: csdr_bank_execute)"""
+    out = {}
+    for i in range(cfg["n_demods"]):
+        kind = cfg["kinds"][i % len(cfg["kinds"])]
+        S = cascade_depth(MODEM_BW[kind], cfg["fs"] // cfg["M"])
+        name = "demod_frontend_s%d" % S if 3 <= S <= 6 else "demod_frontend_generic"
+        out[name] = out.get(name, 0) + 1
+    return out
+
+
+STAGE_OF = {"chan_analyze": "channelizer", "dc_tile_ends": "channelizer", "dc_apply": "channelizer",
+            "demod_modem": "modem+audio", "demod_gain_scan": "modem+audio", "demod_audio_interp": "modem+audio", "fms_stages": "modem+audio", "fms_out": "modem+audio",
+            "spec_fft_radix": "spectrum", "spec_fft_rows": "spectrum", "spec_fused": "spectrum", "spec_average": "spectrum", "spec_extrema": "spectrum",
+            "spec_display": "spectrum", "spec_misc": "spectrum"}
+
+
+def stage_of(kernel):
+    return "front-end" if kernel.startswith("demod_frontend") else STAGE_OF.get(kernel, kernel)
+
+
 def algorithmic_bytes_per_sample(kernel, cfg):
     audio = 4.0 * cfg["n_demods"] * AUDIO_RATE / cfg["fs"]
     table = {
         "chan_analyze": 16.0,
-        "demod_frontend": 8.0 * cfg["n_demods"] / cfg["M"],
         "demod_modem": 0.0,
         "demod_audio_interp": audio,
         "spec_fft_radix": 8.0,         # the frame is read once from HBM ...
         "spec_fft_rows": 0.0,          # ... later passes re-read intermediates that are not algorithmic traffic
-        "spec_fft_big": 12.0,          # one-pass transform: reads the frame, writes the display points' inputs
+        "spec_fused": 8.0,
         "spec_average": 0.0,
         "spec_display": 4.0,
     }
+    if kernel.startswith("demod_frontend"):
+        return 8.0 * frontend_groups(cfg).get(kernel, 0) / cfg["M"]          # each demodulator reads its channel once
     return table.get(kernel, 0.0)
 
 
@@ -127,7 +158,9 @@ def measured_traffic(cfg_name):
     for name, v in t.items():
         if "FETCH_SIZE_KiB_avg_per_launch" in v and "WRITE_SIZE_KiB_avg_per_launch" in v:
             base = name.split("<")[0]
-            base = {"demod_frontend_s": "demod_frontend", "spec_fft_rows4096": "spec_fft_rows", "chan_analyze_p2": "chan_analyze"}.get(base, base)
+            if base == "demod_frontend_s" and "<" in name:
+                base = "demod_frontend_s" + name.split("<")[1].split(",")[0].strip()          # demod_frontend_s<6, 2048, true> -> demod_frontend_s6
+            base = {"demod_frontend": "demod_frontend_generic", "spec_fft_rows4096": "spec_fft_rows", "chan_analyze_p2": "chan_analyze", "chan_analyze_mx": "chan_analyze"}.get(base, base)
             out[base] = out.get(base, 0.0) + (2.0 * v["FETCH_SIZE_KiB_avg_per_launch"] + v["WRITE_SIZE_KiB_avg_per_launch"]) * 1024.0 / blocks
     return out, os.path.relpath(files[-1], ROOT)
 
@@ -312,27 +345,45 @@ def main():
                    "parallelism": "one independent IQ stream per GPU; stages of the timed pipeline on %d HIP stream(s)" % streams},
     }
     if prof:
-        units = NB * BLOCK                      # input samples one launch covers
-        launches_per_step = {k: NBATCH * (2 if k == "spec_fft_radix" and 2 * FFT_SIZE > 32 * 4096 else 1) for k in prof}
-        dom = max(prof, key=lambda k: prof[k][0] / prof[k][1] * launches_per_step[k])
-        ms, launches = prof[dom]
-        avg_ms = ms / launches
+        units = NB * BLOCK                      # input samples one batch covers
+        n_batches = args.steps * NBATCH
+        # per kernel id: average launch duration (HIP events, every PROFILE_PERIOD-th launch) x the launches per batch the library
+        # really made (all launches are counted, bracketed or not) = its time per batch
+        avg = {k: v[0] / v[1] for k, v in prof.items()}
+        per_batch = {k: avg[k] * (v[2] / n_batches) for k, v in prof.items()}
+        dom = max(per_batch, key=lambda k: per_batch[k])
+        avg_ms = avg[dom]
+        launches_dom = prof[dom][2] / n_batches
         bps = algorithmic_bytes_per_sample(dom, cfg)
-        achieved = bps * units / (avg_ms * 1e-3) / 1e9
+        alg_launch = bps * units / launches_dom
+        achieved = alg_launch / (avg_ms * 1e-3) / 1e9
         traffic, traffic_file = measured_traffic(args.config)
+        stages = {}
+        for k in prof:
+            st = stages.setdefault(stage_of(k), {"ms_per_batch": 0.0, "algorithmic_bytes_per_sample": 0.0, "kernels": []})
+            st["ms_per_batch"] += per_batch[k]
+            st["algorithmic_bytes_per_sample"] += algorithmic_bytes_per_sample(k, cfg)
+            st["kernels"].append(k)
+        for st in stages.values():
+            st["achieved_GBps"] = st["algorithmic_bytes_per_sample"] * units / (st["ms_per_batch"] * 1e-3) / 1e9 if st["ms_per_batch"] > 0 else None
+            st["frac"] = st["achieved_GBps"] / HBM_PEAK_GBS if st["achieved_GBps"] is not None else None
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": (traffic[dom] * NB if dom in traffic else None),
+                           "traffic": (traffic[dom] * NB / launches_dom if dom in traffic else None),
                            "traffic_unit": "HBM bytes per launch of the dominant kernel (PMC pass %s: per IQ block, times the blocks of this launch)" % traffic_file,
-                           "avg_launch_ms": avg_ms,
-                           "algorithmic_bytes_per_launch": bps * units,
+                           "avg_launch_ms": avg_ms, "launches_per_batch": launches_dom,
+                           "algorithmic_bytes_per_launch": alg_launch,
                            "whole_path": {"bytes_per_sample": round(bytes_per_sample, 1), "achieved": bytes_per_sample * value / world * 1e6 / 1e9,
                                           "frac": bytes_per_sample * value / world * 1e6 / 1e9 / HBM_PEAK_GBS,
-                                          "traffic_bytes_per_sample": (sum(traffic.values()) / BLOCK if traffic else None)},
-                           "profile_sampling": "HIP events around every %d-th launch of each kernel inside the timed region" % PROFILE_PERIOD,
+                                          "traffic_bytes_per_sample": (sum(traffic.values()) / BLOCK if traffic else None),
+                                          "sum_of_kernel_ms_per_batch": sum(per_batch.values()), "ms_per_batch": 1e3 * elapsed / n_batches},
+                           "profile_sampling": "HIP events around every %d-th launch of EACH kernel id (one id per template instance) inside the timed region; "
+                                               "ms_per_batch = average launch x launches per batch counted by the library" % PROFILE_PERIOD,
                            "concurrency": ("one stream: every kernel runs alone, the live duration is the kernel's own" if streams == 1 else
                                            "%d streams: other kernels share the GPU during a launch of the dominant kernel, so this live duration is longer than the kernel's own (roofline.solo: the same batch on one stream)" % streams),
-                           "kernels_avg_launch_ms": {k: v[0] / v[1] for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0] / kv[1][1])}}
+                           "stages": {k: v for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms_per_batch"])},
+                           "kernels_avg_launch_ms": {k: avg[k] for k in sorted(avg, key=lambda k: -per_batch[k])},
+                           "kernels_ms_per_batch": {k: per_batch[k] for k in sorted(avg, key=lambda k: -per_batch[k])}}
     spec.close(); bank.close(); post.close(); ctx.close()
     if prof and rank == 0 and streams != 1:
         # The live durations above include whatever the other stream's kernels took from the GPU at that moment (the two chains

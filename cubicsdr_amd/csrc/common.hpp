@@ -197,9 +197,12 @@ template <int N> __device__ __forceinline__ void lds_read128(const float2 *pe, c
 }  // namespace csdr
 
 // kernel ids for the optional per-kernel HIP-event profile (csdr_ctx_profile_*)
+// (one id per kernel that can appear in a batch: two template instances of a kernel launched alternately under ONE id would
+// always be sampled at the same phase of the sampling period and the per-stage sums would miss the other instance)
 enum CsdrKernelId {
-    KID_CHAN_ANALYZE = 0, KID_DC_ENDS, KID_DC_APPLY,
-    KID_FRONTEND, KID_MODEM, KID_AUDIO,
+    KID_CHAN_ANALYZE = 0, KID_DC_ENDS, KID_DC_APPLY, KID_ROWS_COPY,
+    KID_FE_GENERIC, KID_FE_S3, KID_FE_S4, KID_FE_S5, KID_FE_S6, KID_FE_INTERP,
+    KID_MODEM, KID_GAIN_SCAN, KID_FMS, KID_AUDIO, KID_FMS_OUT,
     KID_FFT_COLS, KID_FFT_ROWS, KID_SPEC_AVG, KID_SPEC_TRACK, KID_SPEC_DISPLAY, KID_SPEC_MISC,
     KID_COUNT
 };
@@ -280,13 +283,20 @@ struct csdr_ctx {
 };
 
 // Every entry point of the C ABI that touches HIP runs on the device of its context, whichever host thread calls it (the
-// reference's pipeline calls from one IOThread per stage).  hipSetDevice is per host thread; the last device this thread
-// selected is remembered so that the common case costs one comparison.
+// reference's pipeline calls from one IOThread per stage) and whatever device that thread had selected before (a caller
+// that also drives torch or another HIP library may change it between two calls).  The thread's current device is queried,
+// changed only on a mismatch, and put back when the entry point returns.
 struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
     explicit DeviceScope(const csdr_ctx *c) {
-        static thread_local int current = -1;
-        if (c && current != c->device) { if (hipSetDevice(c->device) == hipSuccess) current = c->device; }
+        if (!c) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != c->device) switched = hipSetDevice(c->device) == hipSuccess;
     }
+    ~DeviceScope() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
 };
 
 // bracket one kernel launch with events when profiling is on

@@ -59,7 +59,8 @@ extern "C" int csdr_ctx_create(int device, void *hip_stream, csdr_ctx **out) {
         CSDR_HIP_TRY(hipEventCreateWithFlags(&c->ev_lane[l], hipEventDisableTiming));
     }
     for (int l = 0; l < LANE_COUNT; ++l) c->lanes[l] = c->phys[kMap[want][l]];
-    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+    if (hip_stream == CSDR_STREAM_NULL) { c->stream = nullptr; c->own_stream = false; }          // the device's null stream
+    else if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
     else { c->stream = c->phys[0]; c->own_stream = true; }      // a private boundary stream is just the first stage stream
     for (int l = 0; l < LANE_COUNT; ++l) CSDR_HIP_TRY(hipEventCreateWithFlags(&c->ev_in[l], hipEventDisableTiming));
     CSDR_HIP_TRY(hipEventCreate(&c->ev0));
@@ -96,6 +97,7 @@ extern "C" int csdr_ctx_join(csdr_ctx *c) {
     if (!c) return fail(CSDR_EINVAL, "ctx is null");
     return c->join();
 }
+extern "C" int csdr_ctx_owns_stream(const csdr_ctx *c) { return c && c->own_stream ? 1 : 0; }
 extern "C" void *csdr_ctx_stream(csdr_ctx *c) { return c ? (void *)c->stream : nullptr; }
 extern "C" int csdr_ctx_timer_start(csdr_ctx *c) {
     DeviceScope dev__(c);
@@ -117,8 +119,9 @@ extern "C" int csdr_ctx_timer_stop(csdr_ctx *c, float *ms) {
 }
 // ---- per-kernel HIP-event profile (bench.py roofline leg) ----
 static const char *kKernelNames[KID_COUNT] = {
-    "chan_analyze", "dc_tile_ends", "dc_apply",
-    "demod_frontend", "demod_modem", "demod_audio_interp",
+    "chan_analyze", "dc_tile_ends", "dc_apply", "rows_copy",
+    "demod_frontend_generic", "demod_frontend_s3", "demod_frontend_s4", "demod_frontend_s5", "demod_frontend_s6", "demod_frontend_interp",
+    "demod_modem", "demod_gain_scan", "fms_stages", "demod_audio_interp", "fms_out",
     "spec_fft_radix", "spec_fft_rows", "spec_average", "spec_extrema", "spec_display", "spec_misc"};
 static int prof_drain(csdr_ctx *c) {
     if (int rc = c->sync_all()) return rc;
@@ -138,6 +141,12 @@ extern "C" int csdr_ctx_profile_enable(csdr_ctx *c, int on) {
     c->prof_on = on != 0;
     c->prof_period = on > 1 ? on : 1;
     if (on) for (int i = 0; i < KID_COUNT; i++) { c->prof_ms[i] = 0.0; c->prof_n[i] = 0; c->prof_seen[i] = 0; }
+    return CSDR_OK;
+}
+extern "C" int csdr_ctx_profile_launches(csdr_ctx *c, int id, int64_t *launches) {
+    if (!c || id < 0 || id >= KID_COUNT || !launches) return fail(CSDR_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lk(c->prof_mu);
+    *launches = (int64_t)c->prof_seen[id];
     return CSDR_OK;
 }
 extern "C" int csdr_ctx_profile_num_kernels(void) { return KID_COUNT; }
@@ -621,7 +630,7 @@ extern "C" int csdr_post_export_rows(csdr_post *p, const int *channels, int n, f
     if (dst_stride < nf) return fail(CSDR_EINVAL, "destination stride %lld below %lld frames", (long long)dst_stride, (long long)nf);
     const int *rows = nullptr;
     if (int rc = post_row_list(p, channels, n, &rows)) return rc;
-    CSDR_LAUNCH(p->ctx, LANE_POST, KID_DC_APPLY, rows_copy, dim3((unsigned)std::min<int64_t>(64, (nf + 255) / 256), n), dim3(256), 0,
+    CSDR_LAUNCH(p->ctx, LANE_POST, KID_ROWS_COPY, rows_copy, dim3((unsigned)std::min<int64_t>(64, (nf + 255) / 256), n), dim3(256), 0,
                 post_buf(p, p->cur), p->chan_stride, rows, (float2 *)dst_dev, dst_stride, (const int *)nullptr, nf);
     CSDR_HIP_TRY(hipGetLastError());
     return CSDR_OK;
@@ -651,7 +660,7 @@ extern "C" int csdr_post_import_rows(csdr_post *p, const int *channels, int n, c
     if (n_frames == 0) return CSDR_OK;
     const int *rows = nullptr;
     if (int rc = post_row_list(p, channels, n, &rows)) return rc;
-    CSDR_LAUNCH(p->ctx, LANE_POST, KID_DC_APPLY, rows_copy, dim3((unsigned)std::min<int64_t>(64, (n_frames + 255) / 256), n), dim3(256), 0,
+    CSDR_LAUNCH(p->ctx, LANE_POST, KID_ROWS_COPY, rows_copy, dim3((unsigned)std::min<int64_t>(64, (n_frames + 255) / 256), n), dim3(256), 0,
                 (const float2 *)src_dev, src_stride, (const int *)nullptr, post_buf(p, p->import_k) + frame0, p->chan_stride, rows, n_frames);
     CSDR_HIP_TRY(hipGetLastError());
     return CSDR_OK;
@@ -821,7 +830,10 @@ extern "C" void csdr_bank_destroy(csdr_bank *b) {
 
 // internal: NCO + msresamp only, no modem / audio stage (the zoomed spectrum view's shift + resample, SpectrumVisualProcessor.cpp:306-379)
 #define CSDR_MODEM_FRONTEND_ONLY 100
+// no device modem / audio stage: the internal front-end-only slot, or a host plug-in modem (CSDR_MODEM_HOST) that demodulates the fetched IQ
+static inline bool is_fe_only(int modem) { return modem == CSDR_MODEM_FRONTEND_ONLY || modem == CSDR_MODEM_HOST; }
 static int modem_check_rate(int modem, int bw, int audio_rate) {   // Modem*::checkSampleRate (ModemAnalog.cpp:14-19, ModemUSB.cpp:29-37, ModemIQ.cpp:31-33)
+    if (modem == CSDR_MODEM_HOST) return bw;                       // the plug-in's own checkSampleRate ran on the host
     if (modem == CSDR_MODEM_IQ || modem == CSDR_MODEM_FRONTEND_ONLY) return audio_rate;
     if (modem == CSDR_MODEM_FMS) return bw < 100000 ? 100000 : bw;      // ModemFMStereo.cpp:27-35
     if (bw < 500) bw = 500;                          // MIN_BANDWIDTH, Modem.h:13
@@ -832,7 +844,7 @@ static int modem_check_rate(int modem, int bw, int audio_rate) {   // Modem*::ch
 static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *prm, const csdr_post *post);
 extern "C" int csdr_bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *prm, const csdr_post *post) {
     DeviceScope dev__(b ? b->ctx : nullptr);
-    if (prm && (prm->modem < CSDR_MODEM_NBFM || prm->modem > CSDR_MODEM_FMS)) return fail(CSDR_EUNSUPPORTED, "modem %d", prm->modem);
+    if (prm && (prm->modem < CSDR_MODEM_NBFM || prm->modem > CSDR_MODEM_HOST)) return fail(CSDR_EUNSUPPORTED, "modem %d", prm->modem);
     return bank_configure_slot(b, slot, prm, post);
 }
 static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *prm, const csdr_post *post) {
@@ -848,7 +860,7 @@ static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *
     s.chan_rate = csdr_post_channel_rate(post);
     const double iq_ratio = (double)s.prm.bandwidth / (double)s.chan_rate;        // DemodulatorWorkerThread.cpp:99-100
     s.iq = design::plan_msresamp((float)iq_ratio, 60.0f);        // bandwidth above the channel rate: the interpolating form (:97-101 creates it for any ratio)
-    const double au_ratio = double(s.prm.audio_sample_rate) / double(s.prm.bandwidth);   // ModemAnalog.cpp:29-30
+    const double au_ratio = is_fe_only(s.prm.modem) ? 1.0 : double(s.prm.audio_sample_rate) / double(s.prm.bandwidth);   // ModemAnalog.cpp:29-30
     s.au = design::plan_msresamp((float)au_ratio, 60.0f);
     if (s.iq.S > kMaxHb || s.au.S > kMaxHb) return fail(CSDR_EUNSUPPORTED, "resampling ratio needs %u half-band stages", s.iq.S);
     if (!s.au.interp) {      // decimating audio resampler: its cascade must fit the carried demodulator-output history
@@ -885,7 +897,7 @@ static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *
     // capacities for one execute
     const int64_t max_bc = post->max_block_len / post->hop;
     const int64_t cap_iq = (int64_t)std::ceil((double)b->max_blocks * (double)max_bc * iq_ratio) + b->max_blocks + 64;
-    const int64_t cap_audio = s.prm.modem == CSDR_MODEM_FRONTEND_ONLY ? 64 : s.prm.modem == CSDR_MODEM_IQ ? 2 * cap_iq + 64      // two floats per IQ sample, no audio resampler
+    const int64_t cap_audio = is_fe_only(s.prm.modem) ? 64 : s.prm.modem == CSDR_MODEM_IQ ? 2 * cap_iq + 64      // two floats per IQ sample, no audio resampler
         : (fms ? 2 : 1) * ((int64_t)std::ceil((double)cap_iq * au_ratio) + (int64_t)b->max_blocks * (2 << (s.au.interp ? s.au.S : 0)) + 64);
     // one slab per slot
     size_t off = 0;
@@ -1043,7 +1055,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         // per-block plan
         BlockPlan *pl = plans_h + (size_t)si * (NB + 1);
         const int S = (int)s.iq.S, aS = (int)s.au.S;
-        const bool fe_only = s.prm.modem == CSDR_MODEM_FRONTEND_ONLY;
+        const bool fe_only = is_fe_only(s.prm.modem);
         const bool iq_modem = s.prm.modem == CSDR_MODEM_IQ || fe_only;      // no audio resampler: 2 floats per resampled IQ sample
         const bool au_interp = s.au.interp;
         const bool fms = s.prm.modem == CSDR_MODEM_FMS;          // two floats (left, right) per audio sample
@@ -1125,7 +1137,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     }
     // the audio stage runs the slots that have one: compact the head of the list (the front-end groups above are copies)
     int n_audio_run = 0;
-    for (int i = 0; i < n_run; ++i) if (b->slots[slot_list_h[i]].prm.modem != CSDR_MODEM_FRONTEND_ONLY) slot_list_h[n_audio_run++] = slot_list_h[i];
+    for (int i = 0; i < n_run; ++i) if (!is_fe_only(b->slots[slot_list_h[i]].prm.modem)) slot_list_h[n_audio_run++] = slot_list_h[i];
     // lane FE: the channelizer output of this batch must be complete; the tables and the resampled-IQ buffers of this
     // parity were last read by the audio kernels two batches ago
     const int pk = post->cur;
@@ -1178,7 +1190,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     int hist_need = 2 * kArmTaps;
     for (int i = 0; i < n_run; ++i) {
         const SlotHost &s = b->slots[slot_list_h[i]];
-        if (s.prm.modem == CSDR_MODEM_FRONTEND_ONLY || s.prm.modem == CSDR_MODEM_IQ) continue;
+        if (is_fe_only(s.prm.modem) || s.prm.modem == CSDR_MODEM_IQ) continue;
         const int aS = (int)s.au.S;
         int64_t lo = 0, need;
         if (s.au.interp) {
@@ -1221,17 +1233,17 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     const float2 *chan_out = post_buf(post, pk);
     const int *grp_d = lists_d + 2 * (size_t)b->max_demods;
     if (grp_n[0] > 0)
-        CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, demod_frontend, dim3(ranges_for(grp_n[0]), grp_n[0]), dim3(kFeThreads), fe_lds, b->cfgs.p, dyns_d, grp_d + grp_off[0],
+        CSDR_LAUNCH(c, LANE_FE, KID_FE_GENERIC, demod_frontend, dim3(ranges_for(grp_n[0]), grp_n[0]), dim3(kFeThreads), fe_lds, b->cfgs.p, dyns_d, grp_d + grp_off[0],
                     chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
 #define CSDR_FE_S(S_, CH_)                                                                                                              \
     if (grp_n[S_] > 0)                                                                                                                  \
-        CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, (demod_frontend_s<S_, CH_>), dim3(ranges_for(grp_n[S_]) + 1, grp_n[S_]), dim3(kFeThreads), (fes_lds_bytes<S_, CH_>()), \
+        CSDR_LAUNCH(c, LANE_FE, KID_FE_S##S_, (demod_frontend_s<S_, CH_>), dim3(ranges_for(grp_n[S_]) + 1, grp_n[S_]), dim3(kFeThreads), (fes_lds_bytes<S_, CH_>()), \
                     b->cfgs.p, dyns_d, grp_d + grp_off[S_], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p)
     CSDR_FE_S(3, 2048); CSDR_FE_S(4, 2048);
     if (grp_n[6] > 0) {          // depth 6 (AM / SSB from ~500 kS/s channels): tail wave with three tail stages (CSDR_FE_TW6=0: without)
         static const bool tw6 = !(getenv("CSDR_FE_TW6") && atoi(getenv("CSDR_FE_TW6")) == 0);
         if (tw6)
-            CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, (demod_frontend_s<6, 2048, true>), dim3(ranges_for(grp_n[6]) + 1, grp_n[6]), dim3(kFeThreads + 64), (fes_lds_bytes<6, 2048>()),
+            CSDR_LAUNCH(c, LANE_FE, KID_FE_S6, (demod_frontend_s<6, 2048, true>), dim3(ranges_for(grp_n[6]) + 1, grp_n[6]), dim3(kFeThreads + 64), (fes_lds_bytes<6, 2048>()),
                         b->cfgs.p, dyns_d, grp_d + grp_off[6], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
         else CSDR_FE_S(6, 2048);
     }
@@ -1239,11 +1251,11 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         int64_t jmax = 0;
         for (int i = 0; i < grp_n[7]; ++i) jmax = std::max<int64_t>(jmax, b->slots[grp_h[grp_off[7] + i]].last_J);
         const int nchunks = (int)((jmax + kFiChunk - 1) / kFiChunk);
-        CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, demod_frontend_interp, dim3(nchunks + 1, grp_n[7]), dim3(kFeThreads), kFiLds, b->cfgs.p, dyns_d, grp_d + grp_off[7],
+        CSDR_LAUNCH(c, LANE_FE, KID_FE_INTERP, demod_frontend_interp, dim3(nchunks + 1, grp_n[7]), dim3(kFeThreads), kFiLds, b->cfgs.p, dyns_d, grp_d + grp_off[7],
                     chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
     }
     if (grp_n[5] > 0)            // depth 5 (NBFM from ~500 kS/s channels): a fifth wave runs the one-wave tail one chunk behind
-        CSDR_LAUNCH(c, LANE_FE, KID_FRONTEND, (demod_frontend_s<5, 2048, true>), dim3(ranges_for(grp_n[5]) + 1, grp_n[5]), dim3(kFeThreads + 64), (fes_lds_bytes<5, 2048>()),
+        CSDR_LAUNCH(c, LANE_FE, KID_FE_S5, (demod_frontend_s<5, 2048, true>), dim3(ranges_for(grp_n[5]) + 1, grp_n[5]), dim3(kFeThreads + 64), (fes_lds_bytes<5, 2048>()),
                     b->cfgs.p, dyns_d, grp_d + grp_off[5], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
 #undef CSDR_FE_S
     CSDR_HIP_TRY(hipGetLastError());
@@ -1262,12 +1274,12 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, demod_modem, dim3(n_ag, NB), dim3(audio_threads) /* one wave per block, like the audio kernel */, modem_lds, b->cfgs.p, dyns_d, lists_d + b->max_demods,
                     plans_d, NB, cap_stream, b->mconsts.p, c->sintab.p, b->arms.p, cap_cw);
     if (n_ag > 0)     // the auto-gain recurrence over the blocks, once per demodulator
-        CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, demod_gain_scan, dim3(n_ag), dim3(64), (size_t)NB * sizeof(float), b->cfgs.p, dyns_d, lists_d + b->max_demods, plans_d, NB);
+        CSDR_LAUNCH(c, LANE_AUDIO, KID_GAIN_SCAN, demod_gain_scan, dim3(n_ag), dim3(64), (size_t)NB * sizeof(float), b->cfgs.p, dyns_d, lists_d + b->max_demods, plans_d, NB);
     const int *fms_d = lists_d + b->max_demods + fms_off;
     if (n_fms > 0) {  // FM stereo, ahead of the audio stage: Hilbert r2c of the discriminator output, the pilot loop, the 38 kHz down-mix
-        CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, fms_pre, dim3(n_fms, NB), dim3(64), fms_pre_lds, b->cfgs.p, dyns_d, fms_d, plans_d, NB, b->mconsts.p);
-        CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, fms_pll, dim3(n_fms), dim3(kModemThreads), fms_pll_lds, b->cfgs.p, fms_d, plans_d, NB, fms_blk, c->sintab.p);
-        CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, fms_mix, dim3(n_fms, NB), dim3(64), fms_mix_lds, b->cfgs.p, dyns_d, fms_d, plans_d, NB, fms_blk - 4 * kHilbM, b->mconsts.p, c->sintab.p);
+        CSDR_LAUNCH(c, LANE_AUDIO, KID_FMS, fms_pre, dim3(n_fms, NB), dim3(64), fms_pre_lds, b->cfgs.p, dyns_d, fms_d, plans_d, NB, b->mconsts.p);
+        CSDR_LAUNCH(c, LANE_AUDIO, KID_FMS, fms_pll, dim3(n_fms), dim3(kModemThreads), fms_pll_lds, b->cfgs.p, fms_d, plans_d, NB, fms_blk, c->sintab.p);
+        CSDR_LAUNCH(c, LANE_AUDIO, KID_FMS, fms_mix, dim3(n_fms, NB), dim3(64), fms_mix_lds, b->cfgs.p, dyns_d, fms_d, plans_d, NB, fms_blk - 4 * kHilbM, b->mconsts.p, c->sintab.p);
     }
     if (n_audio_run > 0)
         CSDR_LAUNCH(c, LANE_AUDIO, KID_AUDIO, demod_audio_interp, grid, dim3(audio_threads), audio_lds, b->cfgs.p, dyns_d, lists_d, plans_d, NB,
@@ -1275,7 +1287,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     if (n_fms > 0) {  // the second msresamp_rrrf (stereo difference), then matrix + de-emphasis + low-pass into interleaved frames
         CSDR_LAUNCH(c, LANE_AUDIO, KID_AUDIO, demod_audio_interp, dim3(n_fms, NB), dim3(audio_threads), audio_lds, b->cfgs.p, dyns_d, fms_d, plans_d, NB,
                     cap_out, cap_win, b->arms.p, 1);
-        CSDR_LAUNCH(c, LANE_AUDIO, KID_AUDIO, fms_out, dim3(n_fms, NB), dim3(64), fms_out_lds, b->cfgs.p, dyns_d, fms_d, plans_d, NB, fms_au);
+        CSDR_LAUNCH(c, LANE_AUDIO, KID_FMS_OUT, fms_out, dim3(n_fms, NB), dim3(64), fms_out_lds, b->cfgs.p, dyns_d, fms_d, plans_d, NB, fms_au);
     }
     CSDR_HIP_TRY(hipGetLastError());
     if (int rc = c->signal(b->ev_audio_done[bpar], LANE_AUDIO, LANE_FE)) return rc;

@@ -35,12 +35,25 @@ def _as_iq_arg(iq):
 
 class Context:
     """device + streams (csdr_ctx): one internal HIP stream per pipeline stage; `stream` is the boundary stream the
-    caller's own GPU work is ordered on (None creates a private one; pass torch's raw stream to chain with torch)."""
+    caller's own GPU work is ordered on: None creates a private one; a raw hipStream_t handle (e.g. torch's
+    `torch.cuda.Stream.cuda_stream`) chains with the caller's work -- 0 is the device's null stream (torch's default
+    stream), passed on as CSDR_STREAM_NULL."""
 
     def __init__(self, device=0, stream=None):
         self._l = H.lib()
         self.h = C.c_void_p()
-        H.check(self._l.csdr_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self.h)))
+        if stream is None:
+            arg = None
+        elif int(stream) == 0:
+            arg = C.c_void_p(-1)                                  # CSDR_STREAM_NULL
+        else:
+            arg = C.c_void_p(int(stream))
+        H.check(self._l.csdr_ctx_create(device, arg, C.byref(self.h)))
+
+    @property
+    def owns_stream(self):
+        """True when the boundary stream is private to the library (nothing the caller enqueues is ordered against it)"""
+        return bool(self._l.csdr_ctx_owns_stream(self.h))
 
     def synchronize(self):
         H.check(self._l.csdr_ctx_synchronize(self.h))
@@ -62,13 +75,14 @@ class Context:
         H.check(self._l.csdr_ctx_profile_enable(self.h, int(on)))
 
     def profile(self):
-        """-> {kernel name: (total_ms, launches)} accumulated since profile_enable(True)"""
+        """-> {kernel name: (total_ms of the bracketed launches, bracketed launches, ALL launches)} since profile_enable(...)"""
         out = {}
         for i in range(self._l.csdr_ctx_profile_num_kernels()):
-            ms, n = C.c_double(), C.c_int64()
+            ms, n, seen = C.c_double(), C.c_int64(), C.c_int64()
             H.check(self._l.csdr_ctx_profile_fetch(self.h, i, C.byref(ms), C.byref(n)))
+            H.check(self._l.csdr_ctx_profile_launches(self.h, i, C.byref(seen)))
             if n.value:
-                out[self._l.csdr_ctx_profile_kernel_name(i).decode()] = (ms.value, n.value)
+                out[self._l.csdr_ctx_profile_kernel_name(i).decode()] = (ms.value, n.value, seen.value)
         return out
 
     def close(self):

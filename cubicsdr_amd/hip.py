@@ -42,12 +42,14 @@ ABI = {
     "csdr_ctx_synchronize": (_i, [_p]),
     "csdr_ctx_join": (_i, [_p]),
     "csdr_ctx_stream": (_p, [_p]),
+    "csdr_ctx_owns_stream": (_i, [_p]),
     "csdr_ctx_timer_start": (_i, [_p]),
     "csdr_ctx_timer_stop": (_i, [_p, C.POINTER(_f)]),
     "csdr_ctx_profile_enable": (_i, [_p, _i]),
     "csdr_ctx_profile_num_kernels": (_i, []),
     "csdr_ctx_profile_kernel_name": (C.c_char_p, [_i]),
     "csdr_ctx_profile_fetch": (_i, [_p, _i, C.POINTER(_d), C.POINTER(_i64)]),
+    "csdr_ctx_profile_launches": (_i, [_p, _i, C.POINTER(_i64)]),
     "csdr_dev_alloc": (_i, [_p, C.c_uint64, _pp]),
     "csdr_dev_free": (_i, [_p, _p]),
     "csdr_dev_upload": (_i, [_p, _p, _p, C.c_uint64]),

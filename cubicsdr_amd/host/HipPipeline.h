@@ -31,9 +31,30 @@
 #define DEMOD_VIS_SIZE 2048                      // DemodulatorThread.h:15
 #include "FFTDataDistributor.h"
 
+// Construction-time failures (no device, no memory) throw: the object cannot exist.
 inline void csdr_must(int rc, const char *what) {
     if (rc != CSDR_OK) throw std::runtime_error(std::string(what) + ": " + csdr_strerror(rc) + " (" + csdr_last_error() + ")");
 }
+// Failures INSIDE a running stage never leave run() / process() as exceptions (IOThread::threadMain would mark the thread
+// terminated and rethrow into the GUI, IOThread.cpp:44-51): the block is dropped, the failure counted and its text kept for the
+// owner to poll, and the stage goes on with the next block -- the reference's stages have no error path at all.
+class CsdrErrorLog {
+public:
+    bool ok(int rc, const char *what) {
+        if (rc == CSDR_OK) return true;
+        errors_.fetch_add(1);
+        std::lock_guard<std::mutex> g(mu_);
+        last_ = std::string(what) + ": " + csdr_strerror(rc) + " (" + csdr_last_error() + ")";
+        return false;
+    }
+    long long errorCount() const { return errors_.load(); }
+    std::string lastError() { std::lock_guard<std::mutex> g(mu_); return last_; }
+private:
+    std::atomic<long long> errors_{0};
+    std::mutex mu_;
+    std::string last_;
+};
+#define CSDR_STAGE_TRY(expr, what) do { if (!errlog.ok((expr), (what))) return; } while (0)
 
 class DemodulatorMgr;
 
@@ -51,6 +72,7 @@ public:
     }
     // --- lifecycle (DemodulatorInstance.cpp:111-196): the reference starts a pre-demod, a demod and an audio thread per instance;
     // here the arithmetic of all instances runs inside SDRPostThread's csdr_bank_execute, so run() only marks the instance live
+    ~DemodulatorInstance() { if (kit_ && modem_) modem_->disposeKit(kit_); }
     void run() { terminated_.store(false); active_.store(true); }
     void terminate() { active_.store(false); terminated_.store(true); if (pipeIQInputData_) pipeIQInputData_->flush(); audioQueue_->flush(); }
     bool isTerminated() { return terminated_.load(); }
@@ -61,6 +83,7 @@ public:
         std::unique_ptr<Modem> m(Modem::makeModem(t));
         if (!m) return;                                                                      // unknown type: keep the current modem
         std::lock_guard<std::mutex> g(mu_);
+        if (kit_ && modem_) { modem_->disposeKit(kit_); kit_ = nullptr; }                   // DemodulatorThread.cpp:98-108
         type_ = t; bandwidth_ = Modem::getModemDefaultSampleRate(t); modem_ = std::move(m); dirty_ = true;
         auto it = lastModemSettings_.find(t);
         if (it != lastModemSettings_.end()) modem_->writeSettings(it->second);
@@ -118,6 +141,7 @@ private:
     std::mutex mu_;
     std::string type_ = "NBFM", label_;
     std::unique_ptr<Modem> modem_;
+    ModemKit *kit_ = nullptr;                 // host plug-in modems (CSDR_MODEM_HOST): the kit their buildKit() made, disposed by the same modem
     std::map<std::string, ModemSettings> lastModemSettings_;
     int bandwidth_ = 12500, audioRate_ = 48000;
     bool dirty_ = true;                       // needs csdr_bank_configure_slot
@@ -199,6 +223,7 @@ public:
         if (iqIn) iqIn->flush();
     }
     std::atomic<long long> blocksProcessed{0};
+    CsdrErrorLog errlog;                                       // failures of the device library inside run(): counted, never thrown
 
     // SDRPostThreadChannelizerType (SDRPostThread.h:9-12, setChannelizerType :142-149): takes effect at the next block,
     // which rebuilds the channelizer (chanMode != lastChanMode, :418 / :474)
@@ -220,20 +245,26 @@ private:
             sampleRate_ = in.sampleRate; numChannels_ = M; lastChanMode_ = mode;
             maxBlock_ = (int)std::max<long long>(n, std::min<long long>(nominal, 1LL << 26));
             const int kind = M > 1 ? (mode == SDRPostPFBCH2 ? CSDR_POST_PFBCH2 : CSDR_POST_PFBCH) : CSDR_POST_SINGLE;
-            csdr_must(csdr_post_configure(post_, sampleRate_, M, kind, maxBlock_, 1), "csdr_post_configure");
+            CSDR_STAGE_TRY(csdr_post_configure(post_, sampleRate_, M, kind, maxBlock_, 1), "csdr_post_configure");
             for (auto &d : mgr_->getDemodulators()) { std::lock_guard<std::mutex> g(d->mu_); d->dirty_ = true; }
         }
         if (M == 1) {
             // runSingleCH (:248-299): the DC blocker runs on EVERY block; the DC-corrected data is what the main spectrum, the
             // waterfall and (when a demodulator is active) the demodulator spectrum see
-            csdr_must(csdr_post_execute(post_, (const float *)in.data.data(), 0, 1, n, in.frequency), "csdr_post_execute");
-            singleOut_ = visualBuffers_.getBuffer();
-            singleOut_->frequency = in.frequency; singleOut_->sampleRate = in.sampleRate;
-            singleOut_->data.resize((size_t)n);
-            int got = 0;
-            csdr_must(csdr_post_read_channel(post_, 0, (float *)singleOut_->data.data(), n, &got), "csdr_post_read_channel");
-            singleOut_->data.resize((size_t)got);
-            if (iqOut) { iqOut->try_push(singleOut_); if (iqVisual) iqVisual->try_push(singleOut_); }       // pushVisualData :233-245
+            CSDR_STAGE_TRY(csdr_post_execute(post_, (const float *)in.data.data(), 0, 1, n, in.frequency), "csdr_post_execute");
+            // the corrected block comes back to the host only for a consumer that is bound (a D2H copy + stream wait per block
+            // otherwise bought nothing and kept the demodulators waiting behind it); the demodulators read it on the device
+            auto iqActiveQ = std::static_pointer_cast<DemodulatorThreadInputQueue>(getOutputQueue("IQActiveDemodVisualDataOutput"));
+            singleOut_.reset();
+            if (iqOut || iqActiveQ) {
+                singleOut_ = visualBuffers_.getBuffer();
+                singleOut_->frequency = in.frequency; singleOut_->sampleRate = in.sampleRate;
+                singleOut_->data.resize((size_t)n);
+                int got = 0;
+                CSDR_STAGE_TRY(csdr_post_read_channel(post_, 0, (float *)singleOut_->data.data(), n, &got), "csdr_post_read_channel");
+                singleOut_->data.resize((size_t)got);
+                if (iqOut) { iqOut->try_push(singleOut_); if (iqVisual) iqVisual->try_push(singleOut_); }   // pushVisualData :233-245
+            }
         } else if (iqOut) {
             // full-rate copy to the visual queues first (getFullSampleRateIqData + pushVisualData, :221-245): never blocks
             DemodulatorThreadIQDataPtr vis = visualBuffers_.getBuffer();
@@ -256,20 +287,26 @@ private:
                 p.modem = d->modem_ ? d->modem_->csdrModemId() : -1; p.bandwidth = d->bandwidth_; p.audio_sample_rate = d->audioRate_;
                 p.modem_arg = d->modem_ ? d->modem_->csdrModemArg() : 0;
                 p.frequency = d->getFrequency();
-                if (rebuild && inRange) { d->dirty_ = false; d->builtRate_ = chanRate; }
+                if (rebuild && inRange) {
+                    d->dirty_ = false; d->builtRate_ = chanRate;
+                    if (d->modem_ && p.modem == CSDR_MODEM_HOST) {                  // DemodulatorWorkerThread.cpp:63-76: a fresh kit per (re)build
+                        if (d->kit_) d->modem_->disposeKit(d->kit_);
+                        d->kit_ = d->modem_->buildKit(d->bandwidth_, d->audioRate_);
+                    }
+                }
             }
             if (!inRange) { (void)csdr_bank_set_active(bank_, d->slot(), 0); continue; }
-            if (rebuild) csdr_must(csdr_bank_configure_slot(bank_, d->slot(), &p, post_), "csdr_bank_configure_slot");
-            csdr_must(csdr_bank_set_frequency(bank_, d->slot(), d->getFrequency()), "csdr_bank_set_frequency");
-            csdr_must(csdr_bank_set_active(bank_, d->slot(), 1), "csdr_bank_set_active");
+            if (rebuild) CSDR_STAGE_TRY(csdr_bank_configure_slot(bank_, d->slot(), &p, post_), "csdr_bank_configure_slot");
+            CSDR_STAGE_TRY(csdr_bank_set_frequency(bank_, d->slot(), d->getFrequency()), "csdr_bank_set_frequency");
+            CSDR_STAGE_TRY(csdr_bank_set_active(bank_, d->slot(), 1), "csdr_bank_set_active");
             run.push_back(d);
         }
         if (run.empty()) return;                                                     // :436 "if (!runDemods.empty())"
         auto iqActive = std::static_pointer_cast<DemodulatorThreadInputQueue>(getOutputQueue("IQActiveDemodVisualDataOutput"));
         if (M == 1) {
-            if (iqActive) iqActive->try_push(singleOut_);                            // :289-292
-        } else csdr_must(csdr_post_execute(post_, (const float *)in.data.data(), 0, 1, n, in.frequency), "csdr_post_execute");
-        csdr_must(csdr_bank_execute(bank_, post_), "csdr_bank_execute");
+            if (iqActive && singleOut_) iqActive->try_push(singleOut_);              // :289-292
+        } else CSDR_STAGE_TRY(csdr_post_execute(post_, (const float *)in.data.data(), 0, 1, n, in.frequency), "csdr_post_execute");
+        CSDR_STAGE_TRY(csdr_bank_execute(bank_, post_), "csdr_bank_execute");
         // the active demodulator's channel also feeds the demodulator spectrum (:334, :383-387)
         DemodulatorInstancePtr cur = mgr_->getCurrentModem();
         if (M > 1 && iqActive && cur && cur->isActive()) {
@@ -279,7 +316,7 @@ private:
                 const int cnt = n / std::max(1, (int)(in.sampleRate / std::max(1LL, (long long)csdr_post_channel_rate(post_)))) + 8;
                 tap->data.resize((size_t)cnt);
                 int got = 0;
-                csdr_must(csdr_post_read_channel(post_, ch, (float *)tap->data.data(), cnt, &got), "csdr_post_read_channel");
+                CSDR_STAGE_TRY(csdr_post_read_channel(post_, ch, (float *)tap->data.data(), cnt, &got), "csdr_post_read_channel");
                 tap->data.resize((size_t)got);
                 tap->frequency = csdr_post_channel_center(post_, ch);
                 tap->sampleRate = csdr_post_channel_rate(post_);
@@ -293,13 +330,46 @@ private:
     void finishDemod(DemodulatorInstance &d) {
         csdr_block_result r;
         int nb = 0;
-        csdr_must(csdr_bank_fetch_results(bank_, d.slot(), &r, 1, &nb), "csdr_bank_fetch_results");
+        CSDR_STAGE_TRY(csdr_bank_fetch_results(bank_, d.slot(), &r, 1, &nb), "csdr_bank_fetch_results");
         if (nb != 1 || r.skipped || r.n_iq == 0) return;
         AudioThreadInputPtr ati = d.outputBuffers_.getBuffer();
         ati->sampleRate = d.getAudioSampleRate(); ati->inputRate = d.getBandwidth(); ati->channels = (d.getDemodulatorType() == "I/Q" || d.getDemodulatorType() == "FMS") ? 2 : 1; ati->frequency = d.getFrequency();
-        ati->data.resize(r.n_audio);
         int got = 0;
-        if (r.n_audio) csdr_must(csdr_bank_fetch_audio(bank_, d.slot(), ati->data.data(), r.n_audio, &got), "csdr_bank_fetch_audio");
+        bool hostModem = false;
+        {
+            std::lock_guard<std::mutex> g(d.mu_);
+            hostModem = d.modem_ && d.kit_ && d.modem_->csdrModemId() == CSDR_MODEM_HOST;
+        }
+        if (hostModem) {
+            // a plug-in modem (Modem.h:127-166): the device ran DemodulatorPreThread's arithmetic; the block's resampled IQ comes back
+            // and the plug-in demodulates it here, on the thread that owns the instance, as DemodulatorThread::run does (:119-135).
+            // Level and peak are formed from what it produced with the reference's statements (:142-160, :223-233).
+            hostIq_.sampleRate = d.getBandwidth();
+            hostIq_.data.resize((size_t)r.n_iq);
+            CSDR_STAGE_TRY(csdr_bank_fetch_iq(bank_, d.slot(), (float *)hostIq_.data.data(), r.n_iq, &got), "csdr_bank_fetch_iq");
+            hostIq_.data.resize((size_t)got);
+            ati->channels = 1;
+            ati->data.resize(0);
+            bool useOut;
+            {
+                std::lock_guard<std::mutex> g(d.mu_);
+                if (d.modem_->getType() == "digital") ati->sampleRate = (int)d.kit_->sampleRate;     // :131-136
+                d.modem_->demodulate(d.kit_, &hostIq_, ati.get());
+                useOut = d.modem_->useSignalOutput();
+            }
+            double accum = 0;
+            if (!ati->data.empty()) {
+                if (useOut) for (float v : ati->data) accum += std::sqrt((double)v * (double)v);
+                else for (auto &x : hostIq_.data) accum += std::sqrt((double)x.real * (double)x.real + (double)x.imag * (double)x.imag);
+            }
+            r.level_accum = accum; r.level_count = (int)(useOut ? ati->data.size() : hostIq_.data.size());
+            r.audio_peak = 0.f;
+            for (float v : ati->data) r.audio_peak = std::max(r.audio_peak, std::fabs(v));
+            r.n_audio = (int)ati->data.size();
+        } else {
+            ati->data.resize(r.n_audio);
+            if (r.n_audio) CSDR_STAGE_TRY(csdr_bank_fetch_audio(bank_, d.slot(), ati->data.data(), r.n_audio, &got), "csdr_bank_fetch_audio");
+        }
         const double sampleTime = double(r.n_iq) / double(d.getBandwidth());
         DemodLevelState st;
         st.signalLevel = d.signalLevel_; st.signalFloor = d.signalFloor_; st.signalCeil = d.signalCeil_; st.squelchBreak = d.squelchBreak_;
@@ -360,6 +430,7 @@ private:
     std::atomic<int> chanMode{(int)SDRPostPFBCH};                                // ctor :23
     ReBuffer<DemodulatorThreadIQData> visualBuffers_{"SDRPostThreadVisualDataBuffers"};
     DemodulatorThreadIQDataPtr singleOut_;                                        // single-channel mode: the DC-corrected block
+    ModemIQData hostIq_;                                                          // a host plug-in modem's input block (modemData, DemodulatorThread.h)
 };
 
 class SpectrumVisualProcessor : public VisualProcessor<DemodulatorThreadIQData, SpectrumVisualData> {
@@ -374,6 +445,7 @@ public:
         csdr_must(csdr_spec_set_average_rate(spec_, fft_average_rate), "csdr_spec_set_average_rate");
         csdr_must(csdr_spec_set_scale_factor(spec_, scaleFactor), "csdr_spec_set_scale_factor");
     }
+    CsdrErrorLog errlog;
     void setFFTSize(unsigned int n) { std::lock_guard<std::mutex> g(busy_run); if (n != fftSize) { newFFTSize = n; fftSizeChanged = true; } }
     unsigned int getFFTSize() { std::lock_guard<std::mutex> g(busy_run); return fftSizeChanged ? newFFTSize : fftSize; }
     void setFFTAverageRate(float r) { std::lock_guard<std::mutex> g(busy_run); fft_average_rate = r; if (fftSize) csdr_spec_set_average_rate(spec_, r); }
@@ -394,30 +466,38 @@ public:
     int getDesiredInputSize() { std::lock_guard<std::mutex> g(busy_run); return fftSize ? csdr_spec_desired_input_size(spec_) : 0; }
 
 protected:
+    bool trySetup(unsigned int n) {                                                  // setup() from inside process(): no throw
+        std::lock_guard<std::mutex> g(busy_run);
+        if (!errlog.ok(csdr_spec_setup(spec_, (int)n, 1), "csdr_spec_setup")) return false;
+        fftSize = n;
+        (void)csdr_spec_set_average_rate(spec_, fft_average_rate);
+        (void)csdr_spec_set_scale_factor(spec_, scaleFactor);
+        return true;
+    }
     void process() override {                                                        // :212-637, full-span branch
         if (!isOutputEmpty()) return;
         if (!input || input->empty()) return;
         bool doSetup = false;
         { std::lock_guard<std::mutex> g(busy_run); if (fftSizeChanged) { doSetup = true; fftSizeChanged = false; } }
-        if (doSetup) setup(newFFTSize);
+        if (doSetup && !trySetup(newFFTSize)) return;
         DemodulatorThreadIQDataPtr iq;
         if (!input->pop(iq, HEARTBEAT_CHECK_PERIOD_MICROS) || !iq) return;
         std::lock_guard<std::mutex> g(busy_run);
         if (!fftSize || iq->data.empty()) return;
         const size_t N = 2 * (size_t)fftSize;
-        csdr_must(csdr_spec_set_input_frequency(spec_, iq->frequency), "csdr_spec_set_input_frequency");
-        csdr_must(csdr_spec_set_input_rate(spec_, iq->sampleRate), "csdr_spec_set_input_rate");
+        CSDR_STAGE_TRY(csdr_spec_set_input_frequency(spec_, iq->frequency), "csdr_spec_set_input_frequency");
+        CSDR_STAGE_TRY(csdr_spec_set_input_rate(spec_, iq->sampleRate), "csdr_spec_set_input_rate");
         // inputs of at least 2*fftSize samples are transformed directly (:401-404); shorter ones go through the
         // fftLastData priming / overlap rule (:406-420)
         const int mode = iq->data.size() >= N ? CSDR_SPEC_FIRST_FRAME : CSDR_SPEC_LINES;
-        csdr_must(csdr_spec_process(spec_, (const float *)iq->data.data(), 0, 1, (int)iq->data.size(), mode), "csdr_spec_process");
+        CSDR_STAGE_TRY(csdr_spec_process(spec_, (const float *)iq->data.data(), 0, 1, (int)iq->data.size(), mode), "csdr_spec_process");
         if (csdr_spec_frames(spec_) < 1) return;                                     // the input only primed fftLastData
         SpectrumVisualDataPtr out = outputBuffers.getBuffer();
         out->spectrum_points.resize(fftSize * 2);
-        csdr_must(csdr_spec_fetch(spec_, 0, out->spectrum_points.data(), (int)out->spectrum_points.size(), &out->fft_ceiling, &out->fft_floor), "csdr_spec_fetch");
+        CSDR_STAGE_TRY(csdr_spec_fetch(spec_, 0, out->spectrum_points.data(), (int)out->spectrum_points.size(), &out->fft_ceiling, &out->fft_floor), "csdr_spec_fetch");
         out->spectrum_hold_points.resize(fftSize * 2);
         int nh = 0;
-        csdr_must(csdr_spec_fetch_hold(spec_, 0, out->spectrum_hold_points.data(), (int)out->spectrum_hold_points.size(), &nh), "csdr_spec_fetch_hold");
+        CSDR_STAGE_TRY(csdr_spec_fetch_hold(spec_, 0, out->spectrum_hold_points.data(), (int)out->spectrum_hold_points.size(), &nh), "csdr_spec_fetch_hold");
         out->spectrum_hold_points.resize((size_t)nh);                                // empty unless peak hold is live (:432)
         out->centerFreq = centerFreq; out->bandwidth = (int)bandwidth;
         distribute(out);

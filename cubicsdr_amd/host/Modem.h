@@ -1,13 +1,18 @@
 // Modem.h -- the reference's modem plug-in surface (src/modules/modem/Modem.h:127-166, Modem.cpp:42-101) over the HIP library.
 //
-// In the reference a Modem object owns the demodulator arithmetic (demodulate()) and its kit; here that arithmetic runs on the
-// GPU inside csdr_bank_execute, so a Modem is the host-side DESCRIPTOR of one demodulator type: its name / type, its default
-// and admissible sample rates (checkSampleRate) and the CSDR_MODEM_* id the bank slot is configured with.  The registry
-// (addModemFactory / makeModem / getFactories / getModemDefaultSampleRate) and the settings calls keep the reference's
-// signatures, so DemodulatorInstance and the GUI's modem menus bind unchanged.  demodulate() is not a host path and says so.
+// In the reference a Modem object owns the demodulator arithmetic (demodulate()) and its kit.  Two kinds of modem exist here:
+//   * the reference's nine analog modems (ModemHip<ID>): their arithmetic runs on the GPU inside csdr_bank_execute, the object is the
+//     host-side DESCRIPTOR of the type -- name / type, default and admissible rates (checkSampleRate), the CSDR_MODEM_* id of its slot;
+//   * any OTHER class registered through addModemFactory (an integrator's plug-in, e.g. a digital modem): it keeps the reference's
+//     contract -- the pipeline runs DemodulatorPreThread's arithmetic (NCO shift + msresamp to the modem's rate) on the GPU in a
+//     CSDR_MODEM_HOST slot, fetches the block's resampled IQ and calls the plug-in's own buildKit / demodulate(kit, iq, audioOut) on
+//     the host thread, exactly where DemodulatorThread::run calls it (DemodulatorThread.cpp:119-135).
+// The registry (addModemFactory / makeModem / getFactories / getModemDefaultSampleRate) and the settings calls keep the reference's
+// signatures, so DemodulatorInstance and the GUI's modem menus bind unchanged.
 #pragma once
 #include <atomic>
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -45,16 +50,23 @@ typedef std::map<std::string, int> DefaultRatesList;
 class Modem : public ModemBase {
 public:
     static void addModemFactory(ModemFactoryFn factoryFunc, std::string modemName, int defaultRate) {     // Modem.cpp:42-45
+        std::lock_guard<std::mutex> g(registryMutex());
         factories()[modemName] = factoryFunc; defaultRates()[modemName] = defaultRate;
     }
-    static ModemFactoryList getFactories() { registerBuiltins(); return factories(); }
+    static ModemFactoryList getFactories() { registerBuiltins(); std::lock_guard<std::mutex> g(registryMutex()); return factories(); }
     static Modem *makeModem(std::string modemName) {                                                      // Modem.cpp:51-57
         registerBuiltins();
-        auto it = factories().find(modemName);
-        return it == factories().end() ? nullptr : (Modem *)it->second();
+        ModemFactoryFn fn = nullptr;
+        {
+            std::lock_guard<std::mutex> g(registryMutex());
+            auto it = factories().find(modemName);
+            if (it != factories().end()) fn = it->second;
+        }
+        return fn ? static_cast<Modem *>(fn()) : nullptr;
     }
     static int getModemDefaultSampleRate(std::string modemName) {                                         // Modem.cpp:59-65
         registerBuiltins();
+        std::lock_guard<std::mutex> g(registryMutex());
         auto it = defaultRates().find(modemName);
         return it == defaultRates().end() ? 0 : it->second;
     }
@@ -79,18 +91,17 @@ public:
         ModemKit *kit = new ModemKit; kit->sampleRate = sampleRate; kit->audioSampleRate = audioSampleRate; return kit;
     }
     virtual void disposeKit(ModemKit *kit) { delete kit; }
-    // the arithmetic of Modem*::demodulate runs on the GPU (csdr_bank_execute); calling the host entry is a wiring error
-    virtual void demodulate(ModemKit *, ModemIQData *, AudioThreadInput *) {
-        throw std::logic_error("Modem::demodulate: demodulation runs on the device (csdr_bank_execute); there is no host path");
-    }
+    // Modem.h:151: the plug-in's arithmetic.  Called by SDRPostThread::finishDemod for CSDR_MODEM_HOST slots, from the one thread
+    // that owns the instance (the reference's rule).
+    virtual void demodulate(ModemKit *kit, ModemIQData *input, AudioThreadInput *audioOut) = 0;
     bool shouldRebuildKit() { return refreshKit.load(); }
     void rebuildKit() { refreshKit.store(true); }
     void clearRebuildKit() { refreshKit.store(false); }
     bool useSignalOutput() { return _useSignalOutput.load(); }
     void useSignalOutput(bool useOutput) { _useSignalOutput.store(useOutput); }
 
-    // the CSDR_MODEM_* id of this modem in include/csdr_hip.h
-    virtual int csdrModemId() = 0;
+    // the CSDR_MODEM_* id of this modem's bank slot (include/csdr_hip.h): a plug-in runs the front end only and demodulates on the host
+    virtual int csdrModemId() { return CSDR_MODEM_HOST; }
     virtual int csdrModemArg() { return 0; }
 
     static void registerBuiltins();
@@ -98,6 +109,7 @@ public:
 private:
     static ModemFactoryList &factories() { static ModemFactoryList f; return f; }
     static DefaultRatesList &defaultRates() { static DefaultRatesList r; return r; }
+    static std::mutex &registryMutex() { static std::mutex m; return m; }
     std::atomic_bool refreshKit{false}, _useSignalOutput{false};
 };
 
@@ -135,6 +147,10 @@ public:
         return (int)sampleRate;
     }
     int csdrModemId() override { return ID; }
+    // the arithmetic of these nine modems runs on the device (csdr_bank_execute): nothing may route a block through the host entry
+    void demodulate(ModemKit *, ModemIQData *, AudioThreadInput *) override {
+        throw std::logic_error("ModemHip::demodulate: this modem's arithmetic runs on the device (csdr_bank_execute)");
+    }
     // FM stereo's one setting, "demph" (ModemFMStereo.cpp:42-89): de-emphasis in microseconds, "0" = none; a write asks for a rebuild
     ModemArgInfoList getSettings() override {
         ModemArgInfoList args;
@@ -159,9 +175,9 @@ private:
 };
 
 inline void Modem::registerBuiltins() {                                                   // CubicSDR.cpp:305-313
-    static bool done = false;
-    if (done) return;
-    done = true;
+    // (instances are created from several threads: DemodulatorInstance's constructor ends up here)
+    static std::once_flag once;
+    std::call_once(once, [] {
     addModemFactory(ModemHip<CSDR_MODEM_FM>::factory, "FM", 200000);
     addModemFactory(ModemHip<CSDR_MODEM_NBFM>::factory, "NBFM", 12500);
     addModemFactory(ModemHip<CSDR_MODEM_FMS>::factory, "FMS", 200000);
@@ -171,4 +187,5 @@ inline void Modem::registerBuiltins() {                                         
     addModemFactory(ModemHip<CSDR_MODEM_USB>::factory, "USB", 5400);
     addModemFactory(ModemHip<CSDR_MODEM_DSB>::factory, "DSB", 5400);
     addModemFactory(ModemHip<CSDR_MODEM_IQ>::factory, "I/Q", 48000);
+    });
 }

@@ -86,6 +86,42 @@ def data_channel(ch: int, M: int) -> int:
     return M // 2 if (M > 1 and ch == M) else ch
 
 
+class _Boundary:
+    """The stream every collective and every torch buffer operation of a sharded stream runs on, and which the library uses as its
+    boundary stream (csdr_ctx_create, "Streams"): a DEDICATED torch stream -- its raw handle is never 0, which the C ABI would read as
+    "no stream, make a private one" and then order nothing against torch.  `on()` makes it torch's current stream (NCCL / RCCL
+    collectives are ordered behind what is enqueued there and torch makes it wait for them), after making it wait for the
+    caller's own current stream, on which the caller produced the tensors it hands over.  Without CUDA (gloo tests, the
+    host-executing test build) there is nothing to order: `handle` is None and `on()` does nothing."""
+
+    def __init__(self, device_index, use_torch=True):
+        self.ts = None
+        self.handle = None
+        if use_torch:
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    self.ts = torch.cuda.Stream(device=device_index)
+                    self.handle = self.ts.cuda_stream
+                    assert self.handle != 0
+            except ImportError:
+                pass
+
+    def on(self):
+        import contextlib
+        if self.ts is None:
+            return contextlib.nullcontext()
+        import torch
+        self.ts.wait_stream(torch.cuda.current_stream(self.ts.device))
+        return torch.cuda.stream(self.ts)
+
+    def release_to_caller(self):
+        """the caller's current stream waits for what was enqueued on the boundary stream (e.g. before it reuses a batch tensor)"""
+        if self.ts is not None:
+            import torch
+            torch.cuda.current_stream(self.ts.device).wait_stream(self.ts)
+
+
 class ShardedStream:
     """ONE IQ stream whose DemodulatorInstances are spread over the ranks (BASELINE config 4; fan-out point
     SDRPostThread.cpp:389-396).  Every rank builds the same plan from the full demodulator list; per batch:
@@ -104,16 +140,11 @@ class ShardedStream:
         routed = [channel_at(f, center, fs, M) for _, _, f in self.demods]
         self.channels = [data_channel(c, M) for c in routed]
         self.plan = plan(len(self.demods), self.channels, world, rank)
-        # the collective runs on torch's current stream: that stream is the library's boundary stream, so the kernels of a batch
-        # are ordered behind its broadcast (csdr_ctx_create, "Streams") and the next broadcast behind their reads (join)
-        stream = None
-        try:
-            import torch
-            if torch.cuda.is_available():
-                stream = torch.cuda.current_stream(device_index).cuda_stream
-        except Exception:
-            stream = None
-        self.ctx = Context(device_index, stream=stream)
+        # the collective runs on the boundary stream, so the kernels of a batch are ordered behind its broadcast (lane_begin) and
+        # the next broadcast behind their reads (join)
+        self.boundary = _Boundary(device_index)
+        self.ctx = Context(device_index, stream=self.boundary.handle)
+        assert self.boundary.handle is None or not self.ctx.owns_stream
         self.post = SDRPost(self.ctx, fs, M, block, max_blocks=max_blocks, oversampled=oversampled)
         self.post.set_active_channels(self.plan.active_channels)
         self.bank = DemodBank(self.ctx, max(1, len(self.plan.demods)), max_blocks=max_blocks)
@@ -125,12 +156,19 @@ class ShardedStream:
 
     def step(self, iq, n_blocks, src=0):
         """iq: the batch tensor, pre-allocated on every rank (valid on `src`); returns after the work is enqueued"""
-        if self.world > 1 and self.group is not False:
-            self.ctx.join()                                      # the previous batch's kernels have read `iq` before it is overwritten
-            broadcast_iq(iq, src=src, group=self.group)
-        self.post.execute(iq, n_blocks, self.block, self.center)
-        if self.plan.demods:
-            self.bank.execute(self.post)
+        with self.boundary.on():
+            if self.world > 1 and self.group is not False:
+                self.ctx.join()                                  # the previous batch's kernels have read `iq` before it is overwritten
+                broadcast_iq(iq, src=src, group=self.group)
+            self.post.execute(iq, n_blocks, self.block, self.center)
+            if self.plan.demods:
+                self.bank.execute(self.post)
+
+    def release(self):
+        """the caller's stream waits for the kernels enqueued so far (call before overwriting a batch tensor from another stream)"""
+        with self.boundary.on():
+            self.ctx.join()
+        self.boundary.release_to_caller()
 
     def audio(self, demod_index):
         return self.bank.audio(self.slot_of[demod_index])
@@ -183,13 +221,10 @@ class SlabStream:
         self.plans = [plan(len(self.demods), self.channels, world, q) for q in range(world)]
         self.plan = self.plans[rank]
         self.owned = [p.active_channels for p in self.plans]        # rows each rank needs
-        stream = None
-        if use_torch:
-            import torch
-            if torch.cuda.is_available():
-                stream = torch.cuda.current_stream(device_index).cuda_stream
         self.device_index = device_index
-        self.ctx = Context(device_index, stream=stream)
+        self.boundary = _Boundary(device_index, use_torch)
+        self.ctx = Context(device_index, stream=self.boundary.handle)
+        assert self.boundary.handle is None or not self.ctx.owns_stream
         self.producer = SDRPost(self.ctx, fs, M, block, max_blocks=max(1, -(-max_blocks // world)))
         self.producer.set_dc_blocker(False)
         self.rows = SDRPost(self.ctx, fs, M, block, max_blocks=max_blocks)
@@ -201,8 +236,9 @@ class SlabStream:
             kind, bw, f = self.demods[i]
             self.bank.configure(slot, self.rows, kind, bw, f)
             self.slot_of[i] = slot
-        self._tail = self._empty(self.hist)                         # ingest rank: the input in front of the next batch
-        self._zero(self._tail)
+        with self.boundary.on():
+            self._tail = self._empty(self.hist)                     # ingest rank: the input in front of the next batch
+            self._zero(self._tail)
         self._keep = []
 
     # ---- buffers
@@ -233,11 +269,15 @@ class SlabStream:
     def extended(self, batch, n_blocks):
         """ingest rank: [history | batch] as one buffer and the new history; rank r's input is a window of it"""
         n = n_blocks * self.block
-        ext = self._empty(self.hist + n)
-        ext[:self.hist] = self._tail
-        ext[self.hist:self.hist + n] = batch[:n]
-        self._tail = self._empty(self.hist)
-        self._tail[...] = ext[n:n + self.hist]
+        with self.boundary.on():
+            # buffers come from torch's allocator, which only knows about torch's streams: the library's kernels that read the
+            # previous batch's buffers are joined into the boundary stream before anything is allocated or overwritten on it
+            self.ctx.join()
+            ext = self._empty(self.hist + n)
+            ext[:self.hist] = self._tail
+            ext[self.hist:self.hist + n] = batch[:n]
+            self._tail = self._empty(self.hist)
+            self._tail[...] = ext[n:n + self.hist]
         return ext
 
     def window(self, ext, n_blocks, r):
@@ -249,13 +289,14 @@ class SlabStream:
         import torch.distributed as dist
         if n_blocks % self.world:
             raise ValueError("scatter needs the batch's blocks to divide evenly over the ranks")
-        self.ctx.join()                                             # the previous batch's kernels have read the window buffer
-        mine = self._empty(self.hist + (n_blocks // self.world) * self.block)
-        parts = None
-        if self.rank == src:
-            ext = self.extended(batch, n_blocks)
-            parts = [self._t(self.window(ext, n_blocks, r)).contiguous() for r in range(self.world)]
-        dist.scatter(self._t(mine), parts, src=src, group=self.group)
+        with self.boundary.on():
+            self.ctx.join()                                         # the previous batch's kernels have read the window buffer
+            mine = self._empty(self.hist + (n_blocks // self.world) * self.block)
+            parts = None
+            if self.rank == src:
+                ext = self.extended(batch, n_blocks)
+                parts = [self._t(self.window(ext, n_blocks, r)).contiguous() for r in range(self.world)]
+            dist.scatter(self._t(mine), parts, src=src, group=self.group)
         return mine
 
     # ---- the three phases
@@ -263,16 +304,18 @@ class SlabStream:
         """channelize this rank's blocks; returns the packed rows for every peer: [peer q][q's channels][this rank's frames]"""
         start, cnt = slab_blocks(n_blocks, self.world)[self.rank]
         frames = cnt * self.bc
-        send = self._empty(sum(len(o) for o in self.owned) * frames)
-        if cnt:
-            self.producer.set_history(window, self.hist)
-            self.producer.execute(window[self.hist:], cnt, self.block, self.center)
-            off = 0
-            for q in range(self.world):
-                if self.owned[q]:
-                    self.producer.export_rows(self.owned[q], send[off:], frames)
-                    off += len(self.owned[q]) * frames
-        self._keep = [window, send]
+        with self.boundary.on():
+            self.ctx.join()                                         # (see extended(): the previous batch's buffers are dropped below)
+            send = self._empty(sum(len(o) for o in self.owned) * frames)
+            if cnt:
+                self.producer.set_history(window, self.hist)
+                self.producer.execute(window[self.hist:], cnt, self.block, self.center)
+                off = 0
+                for q in range(self.world):
+                    if self.owned[q]:
+                        self.producer.export_rows(self.owned[q], send[off:], frames)
+                        off += len(self.owned[q]) * frames
+            self._keep = [window, send]
         return send
 
     def splits(self, n_blocks):
@@ -285,25 +328,27 @@ class SlabStream:
     def exchange(self, send, n_blocks):
         import torch.distributed as dist
         ins, outs = self.splits(n_blocks)
-        recv = self._empty(sum(outs))
-        self.ctx.join()                                             # the export kernels have filled `send`
-        dist.all_to_all_single(self._t(recv)[:sum(outs)].view(-1), self._t(send)[:sum(ins)].view(-1), [2 * v for v in outs], [2 * v for v in ins], group=self.group)
+        with self.boundary.on():
+            self.ctx.join()                                         # the export kernels have filled `send`
+            recv = self._empty(sum(outs))
+            dist.all_to_all_single(self._t(recv)[:sum(outs)].view(-1), self._t(send)[:sum(ins)].view(-1), [2 * v for v in outs], [2 * v for v in ins], group=self.group)
         return recv
 
     def consume(self, recv, n_blocks):
         sl = slab_blocks(n_blocks, self.world)
         mine = self.owned[self.rank]
-        self.rows.import_begin(n_blocks, self.block, self.center)
-        off = 0
-        for p in range(self.world):
-            frames = sl[p][1] * self.bc
-            if mine and frames:
-                self.rows.import_rows(mine, recv[off:], frames, sl[p][0] * self.bc, frames)
-                off += len(mine) * frames
-        self.rows.import_commit()
-        self._keep.append(recv)
-        if self.plan.demods:
-            self.bank.execute(self.rows)
+        with self.boundary.on():
+            self.rows.import_begin(n_blocks, self.block, self.center)
+            off = 0
+            for p in range(self.world):
+                frames = sl[p][1] * self.bc
+                if mine and frames:
+                    self.rows.import_rows(mine, recv[off:], frames, sl[p][0] * self.bc, frames)
+                    off += len(mine) * frames
+            self.rows.import_commit()
+            self._keep.append(recv)
+            if self.plan.demods:
+                self.bank.execute(self.rows)
 
     def step(self, window, n_blocks):
         self.consume(self.exchange(self.produce(window, n_blocks), n_blocks), n_blocks)
@@ -329,13 +374,14 @@ def local_exchange(streams, sends, n_blocks):
     recvs = []
     for q, sq in enumerate(streams):
         _, outs = sq.splits(n_blocks)
-        recv = sq._empty(sum(outs))
-        off = 0
-        for p, sp in enumerate(streams):
-            ins, _ = sp.splits(n_blocks)
-            o = sum(ins[:q])
-            recv[off:off + outs[p]] = sends[p][o:o + ins[q]]
-            off += outs[p]
+        with sq.boundary.on():
+            recv = sq._empty(sum(outs))
+            off = 0
+            for p, sp in enumerate(streams):
+                ins, _ = sp.splits(n_blocks)
+                o = sum(ins[:q])
+                recv[off:off + outs[p]] = sends[p][o:o + ins[q]]
+                off += outs[p]
         recvs.append(recv)
     return recvs
 

@@ -50,8 +50,12 @@ const char *csdr_last_error(void);                 /* thread-local detail string
  * `hip_stream` is the BOUNDARY stream: an existing hipStream_t (e.g. PyTorch's current stream) on which the caller
  * produces device-resident IQ -- every execute first waits for what is enqueued there -- or NULL for a private one.
  * csdr_ctx_join makes the boundary stream wait for everything enqueued so far (for consumers chained on it);
- * csdr_ctx_synchronize blocks the host until all of it is done.  The fetch / read calls synchronise what they need. */
+ * csdr_ctx_synchronize blocks the host until all of it is done.  The fetch / read calls synchronise what they need.
+ * The device's NULL (default) stream has the handle 0 and cannot be told from "no stream" by its value: pass CSDR_STREAM_NULL to
+ * make it the boundary stream (e.g. PyTorch's default stream, whose raw handle is 0). */
+#define CSDR_STREAM_NULL ((void *)(intptr_t)-1)
 int  csdr_ctx_create(int device, void *hip_stream, csdr_ctx **out);
+int  csdr_ctx_owns_stream(const csdr_ctx *ctx);    /* 1: the boundary stream is private (created by csdr_ctx_create), 0: the caller's */
 void csdr_ctx_destroy(csdr_ctx *ctx);
 int  csdr_ctx_synchronize(csdr_ctx *ctx);
 int  csdr_ctx_join(csdr_ctx *ctx);
@@ -67,6 +71,8 @@ int  csdr_ctx_profile_enable(csdr_ctx *ctx, int on);
 int  csdr_ctx_profile_num_kernels(void);
 const char *csdr_ctx_profile_kernel_name(int id);
 int  csdr_ctx_profile_fetch(csdr_ctx *ctx, int id, double *total_ms, int64_t *launches);
+/* ALL launches of kernel `id` since the profile was enabled, bracketed or not (launches per batch = this / batches) */
+int  csdr_ctx_profile_launches(csdr_ctx *ctx, int id, int64_t *launches);
 /* raw device memory for callers without a GPU array library (tests written in C/C++) */
 int  csdr_dev_alloc(csdr_ctx *ctx, uint64_t bytes, void **dev);
 int  csdr_dev_free(csdr_ctx *ctx, void *dev);
@@ -145,6 +151,10 @@ int  csdr_post_import_commit(csdr_post *post);
                              * bandwidth is forced to the audio rate (checkSampleRate :31-33); 2 floats per IQ sample */
 
 #define CSDR_MODEM_FMS  8   /* ModemFMStereo.cpp:178-287  FM stereo: pilot band-pass + PLL, L-R down-mix, two audio resamplers, de-emphasis */
+#define CSDR_MODEM_HOST 9   /* a modem registered through Modem::addModemFactory whose demodulate() is host code (Modem.h:127-166): the slot runs
+                             * DemodulatorPreThread's arithmetic only (NCO shift + msresamp_crcf to `bandwidth`); the block's resampled IQ is
+                             * fetched with csdr_bank_fetch_iq and handed to the plug-in's demodulate(kit, iq, audioOut) on the host.
+                             * n_audio / level / peak of the block results stay 0: they are the plug-in's to produce. */
 
 typedef struct csdr_demod_params {
     int32_t modem;             /* CSDR_MODEM_* (DemodulatorInstance::setDemodulatorType) */

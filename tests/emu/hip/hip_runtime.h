@@ -143,6 +143,7 @@ static inline void sincosf_emu(float x, float *s, float *c) { *s = sinf(x); *c =
 const char *hipGetErrorString(hipError_t e);
 hipError_t hipGetDeviceCount(int *n);
 hipError_t hipSetDevice(int d);
+hipError_t hipGetDevice(int *d);
 hipError_t hipGetLastError();
 hipError_t hipMalloc(void **p, size_t n);
 hipError_t hipFree(void *p);

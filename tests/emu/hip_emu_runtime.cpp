@@ -65,6 +65,7 @@ void run(dim3 grid, dim3 block, size_t lds_bytes, void (*thunk)(void *), void *a
 const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipError(emu)"; }
 hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 hipError_t hipGetLastError() { return hipSuccess; }
 hipError_t hipMalloc(void **p, size_t n) {
     // exact-size allocation so AddressSanitizer sees every out-of-bounds device access; 0xA5 fill = "uninitialised HBM"
