@@ -12,6 +12,7 @@
 #include "kernels_fms.hpp"
 #include "kernels_post.hpp"
 #include "kernels_spec.hpp"
+#include "kernels_io.hpp"
 
 using namespace csdr;
 
@@ -121,7 +122,7 @@ extern "C" int csdr_ctx_timer_stop(csdr_ctx *c, float *ms) {
 static const char *kKernelNames[KID_COUNT] = {
     "chan_analyze", "dc_tile_ends", "dc_apply", "rows_copy",
     "demod_frontend_generic", "demod_frontend_s3", "demod_frontend_s4", "demod_frontend_s5", "demod_frontend_s6", "demod_frontend_interp",
-    "demod_modem", "demod_gain_scan", "fms_stages", "demod_audio_interp", "fms_out",
+    "demod_modem", "demod_gain_scan", "fms_stages", "demod_audio_interp", "fms_out", "audio_egress",
     "spec_fft_radix", "spec_fft_rows", "spec_average", "spec_extrema", "spec_display", "spec_misc"};
 static int prof_drain(csdr_ctx *c) {
     if (int rc = c->sync_all()) return rc;
@@ -732,6 +733,8 @@ struct csdr_bank {
     std::vector<float> arms_host;
     int n_run = 0, last_nb = 0;
     size_t lds_attr[7] = {0, 0, 0, 0, 0, 0, 0};
+    DevBuf<int16_t> pcm;                     // csdr_bank_fetch_pcm16: the converted audio of one slot
+    DevBuf<PcmJob> pcm_jobs;
 };
 
 static int bank_arm_bank(csdr_bank *b, const design::MsresampPlan &p, int *idx) {
@@ -825,6 +828,7 @@ extern "C" void csdr_bank_destroy(csdr_bank *b) {
         if (b->stage_ev[r]) (void)hipEventDestroy(b->stage_ev[r]);
     }
     b->bout_h.release();
+    b->pcm.release(); b->pcm_jobs.release();
     delete b;
 }
 
@@ -2047,3 +2051,5 @@ extern "C" int csdr_spec_fft_only(csdr_spec *s, const float *iq_host, float *out
     CSDR_HIP_TRY(hipStreamSynchronize(st));
     return CSDR_OK;
 }
+
+#include "csdr_io_api.hpp"

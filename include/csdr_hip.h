@@ -36,6 +36,9 @@ typedef struct csdr_ctx   csdr_ctx;    /* device + stream */
 typedef struct csdr_post  csdr_post;   /* SDRPostThread's arithmetic: DC blocker | firpfbch channelizer */
 typedef struct csdr_bank  csdr_bank;   /* N x {DemodulatorPreThread + DemodulatorThread + Modem} arithmetic */
 typedef struct csdr_spec  csdr_spec;   /* SpectrumVisualProcessor's arithmetic */
+typedef struct csdr_scope csdr_scope;  /* ScopeVisualProcessor's arithmetic (audio scope + audio spectrum) */
+typedef struct csdr_mix   csdr_mix;    /* AudioThread's mixing callback, PCM conversion */
+typedef struct csdr_ingest csdr_ingest; /* page-locked block ring -> HBM, one transfer per block */
 
 /* ------------------------------------------------------------------ context */
 int         csdr_abi_version(void);
@@ -258,6 +261,76 @@ int  csdr_spec_fetch(csdr_spec *spec, int frame, float *points_host, int cap_flo
 int  csdr_spec_fetch_hold(csdr_spec *spec, int frame, float *hold_host, int cap_floats, int *n_floats);
 /* raw forward FFT of one 2*fftSize frame (K13 alone), for parity tests against fft_execute */
 int  csdr_spec_fft_only(csdr_spec *spec, const float *iq_host, float *out_host);
+
+/* ------------------------------------------------------------------ ScopeVisualProcessor (src/process/ScopeVisualProcessor.cpp)
+ * replaces: setup :24-35 (fft_create_plan(fftSize)), process :45-217 -- waveform normalisation by max(1, peak) in the modes Y / 2Y / XY
+ * (:64-117), the audio spectrum: zero-padded real input (stereo: left + right) -> fft_execute :163 -> |X| in double -> the two averagers
+ * (the second one sees the UPDATED first one, :176-177) -> double extrema -> floor / ceil trackers :186-190 -> log10 scaling :202-206,
+ * outSize = floor(fftSize/2 * sampleRate / inputRate) :194-200.  Every frame is one AudioThreadInput; frames of a call are processed in
+ * order through ONE state, exactly as consecutive process() calls. */
+typedef struct csdr_scope_frame {
+    const float *data;          /* n floats; host memory, or device memory when csdr_scope_process(..., data_is_dev = 1) */
+    const int32_t *n_dev;       /* device frames only: NULL, or a device int that bounds n (csdr_bank_scope_frame sets it) */
+    int32_t n;                  /* AudioThreadInput::data.size() */
+    int32_t channels;           /* 1 | 2 */
+    int32_t type;               /* AudioThreadInput::type: 0 -> SCOPE_MODE_Y, 1 -> SCOPE_MODE_2Y, 2 -> SCOPE_MODE_XY (:84, :95, :104) */
+    int32_t sample_rate, input_rate;
+    int32_t layout;             /* 0: data is in AudioThreadInput order.  1 / 2: data is n/2 interleaved pairs (a, b) as a stereo demodulator
+                                 * wrote them; the frame the scope sees is  1: [a.. | b..] * scale   2: [b.. | a..] * scale  (the re-packing
+                                 * of DemodulatorThread.cpp:269-291 done while the tap is read, in place in HBM) */
+    float   scale;
+} csdr_scope_frame;
+typedef struct csdr_scope_info {   /* ScopeRenderData (ScopeVisualProcessor.h:10-21) without the points */
+    int32_t mode, spectrum, channels, input_rate, sample_rate, fft_size, n_floats, reserved;
+    double  fft_floor, fft_ceil;
+} csdr_scope_info;
+int  csdr_scope_create(csdr_ctx *ctx, csdr_scope **out);
+void csdr_scope_destroy(csdr_scope *scope);
+int  csdr_scope_setup(csdr_scope *scope, int fft_size, int max_frames, int max_samples);   /* setup(fftSize_in); fft_size <= 4096 */
+int  csdr_scope_set_enabled(csdr_scope *scope, int scope_enabled, int spectrum_enabled);  /* :37-43 */
+int  csdr_scope_set_max_scope_samples(csdr_scope *scope, int n);                            /* maxScopeSamples, default DEFAULT_DMOD_FFT_SIZE = 1024 (:13) */
+int  csdr_scope_set_average_rate(csdr_scope *scope, float rate);                            /* fft_average_rate, default 0.65 (:10) */
+int  csdr_scope_process(csdr_scope *scope, const csdr_scope_frame *frames, int n_frames, int data_is_dev);
+int  csdr_scope_frames(const csdr_scope *scope);
+/* item of frame `frame` of the last process: which = 0 the waveform, 1 the spectrum; info->n_floats == 0 when it was not produced */
+int  csdr_scope_fetch(csdr_scope *scope, int frame, int which, float *points_host, int cap_floats, csdr_scope_info *info);
+/* the audio-scope tap of a demodulator for the LAST block of the bank's last execute (DemodulatorThread.cpp:240-316), as a frame
+ * whose data lies in HBM (pass it to csdr_scope_process with data_is_dev = 1); out->n == 0: nothing to show */
+int  csdr_bank_scope_frame(csdr_bank *bank, int slot, csdr_scope_frame *out);
+
+/* ------------------------------------------------------------------ audio egress
+ * csdr_mix replaces the arithmetic AND the queue rules of audioCallback (src/audio/AudioThread.cpp:88-240): sources in binding order;
+ * a source takes part in a callback buffer only while bound, active and with a non-empty queue (:117); its first callback only latches a
+ * block (:121-129); blocks at another sample rate are discarded (:131-149); mono samples feed both output channels (:169-194), stereo
+ * ones are added float by float (:196-219); per source mixPeak = max(peak * gain) over the blocks it visited, and the buffer is scaled
+ * by (float)(1 / sum) when the sum exceeds 1 (:222-238).  Samples live in per-source rings in HBM; every operation is individually
+ * rounded in the callback's order, so the mix is the callback's bit for bit. */
+int  csdr_mix_create(csdr_ctx *ctx, int max_sources, int ring_floats, int sample_rate, csdr_mix **out);
+void csdr_mix_destroy(csdr_mix *mix);
+int  csdr_mix_set_source(csdr_mix *mix, int source, int bound, int active, float gain, int queue_blocks);
+/* one AudioThreadInput onto a source's queue (host or device memory); returns 1 when the queue was full and the block was dropped */
+int  csdr_mix_push(csdr_mix *mix, int source, const float *audio, int is_dev, int n_floats, int channels, int sample_rate, float peak);
+/* every block of the bank's last execute for n (slot, source) pairs: samples and peaks are appended in HBM by one kernel */
+int  csdr_mix_push_bank(csdr_mix *mix, csdr_bank *bank, const int *slots, const int *sources, int n);
+int  csdr_mix_queued(const csdr_mix *mix, int source);                  /* blocks waiting in the source's queue */
+/* n_buffers consecutive callbacks of `frames` stereo frames -> out_host[n_buffers * frames * 2] (NULL: keep the result on the device) */
+int  csdr_mix_render(csdr_mix *mix, int frames, int n_buffers, float *out_host);
+/* AudioFileWAV::writePayloadToFileStream's conversion (src/audio/AudioFileWAV.cpp:133-157): int(x * (peak < 1 ? 32767 : 32767 / peak)),
+ * low 16 bits.  Of the last render (peak: one value, or each buffer's summed peak), or of a demodulator's audio of the last execute --
+ * every block with its own peak, as one AudioThreadInput each. */
+int  csdr_mix_fetch_pcm16(csdr_mix *mix, int16_t *out_host, int cap_samples, float peak, int per_buffer_peak, int *n);
+int  csdr_bank_fetch_pcm16(csdr_bank *bank, int slot, int16_t *out_host, int cap_samples, int *n);
+
+/* ------------------------------------------------------------------ ingest
+ * The reference's reader fills pooled SDRThreadIQData blocks (SoapySDRThread.cpp:221-225) and SDRPostThread hands ONE buffer to the
+ * demodulator and the visual queues (SDRPostThread.cpp:227-245).  Here the reader fills a page-locked slot in place, commit moves it
+ * over the link ONCE on a transfer stream of its own (optionally exchanging I and Q on the way: the iq_swap option of
+ * SoapySDRThread.cpp:258-266) and returns the device pointer every consumer reads (csdr_post_execute / csdr_spec_process with
+ * iq_is_dev = 1); it stays valid until `depth - 1` further commits.  Slot k + 1 crosses the link while slot k is processed. */
+int  csdr_ingest_create(csdr_ctx *ctx, int64_t max_samples, int depth, csdr_ingest **out);
+void csdr_ingest_destroy(csdr_ingest *ing);
+int  csdr_ingest_acquire(csdr_ingest *ing, float **host_slot);
+int  csdr_ingest_commit(csdr_ingest *ing, int64_t n_samples, int iq_swap, const float **dev_iq);
 
 #ifdef __cplusplus
 }

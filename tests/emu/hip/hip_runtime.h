@@ -127,6 +127,7 @@ using std::min;
 static inline float __fmul_rn(float a, float b) { return a * b; }      // (the emulation is built with -ffp-contract=off)
 static inline float __fadd_rn(float a, float b) { return a + b; }
 static inline float __fsub_rn(float a, float b) { return a - b; }
+static inline float __fdiv_rn(float a, float b) { return a / b; }
 static inline long long min(long long a, long long b) { return a < b ? a : b; }
 static inline long long max(long long a, long long b) { return a > b ? a : b; }
 static inline void __builtin_amdgcn_s_sleep(int) {}
