@@ -384,7 +384,7 @@ extern "C" int csdr_mix_render(csdr_mix *m, int frames, int n_buffers, float *ou
     if (!pieces.empty()) CSDR_HIP_TRY(hipMemcpyAsync(m->pieces_d.p, pieces.data(), pieces.size() * sizeof(MixPiece), hipMemcpyHostToDevice, st));
     if (!refs.empty()) CSDR_HIP_TRY(hipMemcpyAsync(m->refs_d.p, refs.data(), refs.size() * sizeof(MixPeakRef), hipMemcpyHostToDevice, st));
     CSDR_HIP_TRY(hipStreamSynchronize(st));
-    CSDR_LAUNCH(c, LANE_AUDIO, KID_MIX, audio_mix, dim3((unsigned)n_buffers), dim3(kMixThreads), (size_t)kMixMaxSources * sizeof(double), m->bufs_d.p, m->pieces_d.p, m->refs_d.p,
+    CSDR_LAUNCH(c, LANE_AUDIO, KID_MIX, audio_mix, dim3((unsigned)n_buffers), dim3(kMixThreads), (size_t)kMixMaxSources * sizeof(double) + 16, m->bufs_d.p, m->pieces_d.p, m->refs_d.p,
                 frames, m->out.p, m->out_peak.p);
     CSDR_HIP_TRY(hipGetLastError());
     for (size_t j = 0; j < m->src.size(); ++j) m->src[j].buffered -= released[j];
@@ -511,27 +511,29 @@ extern "C" int csdr_ingest_acquire(csdr_ingest *g, float **host_slot) {
     *host_slot = (float *)g->host[(size_t)k];
     return CSDR_OK;
 }
-extern "C" int csdr_ingest_commit(csdr_ingest *g, int64_t n_samples, int iq_swap, const float **dev_iq) {
-    DeviceScope dev__(g ? g->ctx : nullptr);
-    if (!g || !dev_iq) return fail(CSDR_EINVAL, "bad argument");
-    if (g->acquired < 0) return fail(CSDR_ESTATE, "commit without acquire");
-    if (n_samples <= 0 || n_samples > g->cap) return fail(CSDR_ERANGE, "%lld samples (slot holds %lld)", (long long)n_samples, (long long)g->cap);
+// the transfer of slot k from `src` (its own page-locked twin, or caller memory), ordered against the slot's previous consumers
+static int ingest_transfer(csdr_ingest *g, int k, const float2 *src, bool src_is_slot, int64_t n_samples, int iq_swap, const float **dev_iq) {
     csdr_ctx *c = g->ctx;
-    const int k = g->acquired, prev = (k + g->depth - 1) % g->depth;
+    const int prev = (k + g->depth - 1) % g->depth;
     // everything enqueued so far may still read the PREVIOUS slot's device copy: mark it (one event per stream that can hold consumers)
     if (g->copied_valid[(size_t)prev]) {
         for (int l = 0; l < c->n_phys; ++l) CSDR_HIP_TRY(hipEventRecord(g->ev_done[(size_t)prev][(size_t)l], c->phys[l]));
         CSDR_HIP_TRY(hipEventRecord(g->ev_done[(size_t)prev][(size_t)c->n_phys], c->stream));
         g->done_valid[(size_t)prev] = 1;
     }
-    // the device twin of THIS slot was last read by the consumers of `depth` commits ago
+    // the device twin of THIS slot was last read by the consumers of `depth` transfers ago
     if (g->done_valid[(size_t)k]) for (auto &e : g->ev_done[(size_t)k]) CSDR_HIP_TRY(hipStreamWaitEvent(g->copy, e, 0));
-    if (iq_swap) {
-        const int grid = std::max(1, std::min(4 * c->n_cu, (int)((n_samples + 255) / 256)));
-        hipLaunchKernelGGL(ingest_swap, dim3((unsigned)grid), dim3(256), 0, g->copy, (const float2 *)g->host[(size_t)k], g->dev[(size_t)k], n_samples);
+    const int grid = std::max(1, std::min(4 * c->n_cu, (int)((n_samples + 255) / 256)));
+    if (iq_swap && src_is_slot) {
+        // the slot is mapped into the device's address space: the exchanging kernel IS the transfer
+        hipLaunchKernelGGL(ingest_swap, dim3((unsigned)grid), dim3(256), 0, g->copy, src, g->dev[(size_t)k], n_samples);
         CSDR_HIP_TRY(hipGetLastError());
     } else {
-        CSDR_HIP_TRY(hipMemcpyAsync(g->dev[(size_t)k], g->host[(size_t)k], (size_t)n_samples * sizeof(float2), hipMemcpyHostToDevice, g->copy));
+        CSDR_HIP_TRY(hipMemcpyAsync(g->dev[(size_t)k], src, (size_t)n_samples * sizeof(float2), hipMemcpyHostToDevice, g->copy));
+        if (iq_swap) {                                                                // caller memory may not be device-visible: exchange in HBM behind the DMA
+            hipLaunchKernelGGL(ingest_swap, dim3((unsigned)grid), dim3(256), 0, g->copy, (const float2 *)g->dev[(size_t)k], g->dev[(size_t)k], n_samples);
+            CSDR_HIP_TRY(hipGetLastError());
+        }
     }
     CSDR_HIP_TRY(hipEventRecord(g->ev_copied[(size_t)k], g->copy));
     g->copied_valid[(size_t)k] = 1;
@@ -539,7 +541,28 @@ extern "C" int csdr_ingest_commit(csdr_ingest *g, int64_t n_samples, int iq_swap
     for (int l = 0; l < c->n_phys; ++l) CSDR_HIP_TRY(hipStreamWaitEvent(c->phys[l], g->ev_copied[(size_t)k], 0));
     if (!c->own_stream) CSDR_HIP_TRY(hipStreamWaitEvent(c->stream, g->ev_copied[(size_t)k], 0));
     *dev_iq = (const float *)g->dev[(size_t)k];
-    g->acquired = -1;
     g->next = (k + 1) % g->depth;
     return CSDR_OK;
+}
+extern "C" int csdr_ingest_commit(csdr_ingest *g, int64_t n_samples, int iq_swap, const float **dev_iq) {
+    DeviceScope dev__(g ? g->ctx : nullptr);
+    if (!g || !dev_iq) return fail(CSDR_EINVAL, "bad argument");
+    if (g->acquired < 0) return fail(CSDR_ESTATE, "commit without acquire");
+    if (n_samples <= 0 || n_samples > g->cap) return fail(CSDR_ERANGE, "%lld samples (slot holds %lld)", (long long)n_samples, (long long)g->cap);
+    const int k = g->acquired;
+    g->acquired = -1;
+    return ingest_transfer(g, k, g->host[(size_t)k], true, n_samples, iq_swap, dev_iq);
+}
+// the slot the next commit / upload will use (a caller that ties a slot's lifetime to its own block objects asks before it transfers)
+extern "C" int csdr_ingest_next_slot(const csdr_ingest *g) { return g ? g->next : -1; }
+// One transfer of a block the caller assembled in ITS OWN memory (the pooled SDRThreadIQData blocks; page-lock them once with
+// csdr_host_register and the transfer is a DMA).  The previous upload is waited for first, so at most one is in flight and a caller that
+// alternates between at least two buffers never rewrites one that is still being read.
+extern "C" int csdr_ingest_upload(csdr_ingest *g, const float *host_iq, int64_t n_samples, int iq_swap, const float **dev_iq) {
+    DeviceScope dev__(g ? g->ctx : nullptr);
+    if (!g || !host_iq || !dev_iq) return fail(CSDR_EINVAL, "bad argument");
+    if (n_samples <= 0 || n_samples > g->cap) return fail(CSDR_ERANGE, "%lld samples (slot holds %lld)", (long long)n_samples, (long long)g->cap);
+    const int k = g->next, prev = (k + g->depth - 1) % g->depth;
+    if (g->copied_valid[(size_t)prev]) CSDR_HIP_TRY(hipEventSynchronize(g->ev_copied[(size_t)prev]));
+    return ingest_transfer(g, k, (const float2 *)host_iq, false, n_samples, iq_swap, dev_iq);
 }

@@ -187,8 +187,8 @@ __global__ __launch_bounds__(kMixThreads) void audio_mix(const MixBuffer *__rest
                                                         const MixPeakRef *__restrict__ refs, int frames, float *__restrict__ out,
                                                         float *__restrict__ out_peak /* per buffer: the summed peak (diagnostic / PCM scale) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *s_peak = reinterpret_cast<double *>(smem);                     // [n_sources] mixPeak of each contributing source
-    __shared__ float s_inv;
+    double *s_peak = reinterpret_cast<double *>(smem);                     // [kMixMaxSources] mixPeak of each contributing source
+    float *s_inv = reinterpret_cast<float *>(s_peak + kMixMaxSources);
     const MixBuffer mb = bufs[blockIdx.x];
     const int tid = threadIdx.x;
     for (int s = tid; s < mb.n_sources; s += kMixThreads) s_peak[s] = -1.0;
@@ -202,11 +202,11 @@ __global__ __launch_bounds__(kMixThreads) void audio_mix(const MixBuffer *__rest
         }
         double peak = 0.0;
         for (int s = 0; s < mb.n_sources; ++s) peak += s_peak[s] < 0.0 ? 0.0 : s_peak[s];
-        s_inv = peak > 1.0 ? (float)(1.0 / peak) : 1.0f;
+        *s_inv = peak > 1.0 ? (float)(1.0 / peak) : 1.0f;
         out_peak[blockIdx.x] = (float)peak;
     }
     __syncthreads();
-    const float inv = s_inv;
+    const float inv = *s_inv;
     float *o = out + (size_t)blockIdx.x * 2 * frames;
     for (int j = tid; j < 2 * frames; j += kMixThreads) {
         float acc = 0.f;                                                    // memset(out, 0, ...) (:96)
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void pcm16_convert(const PcmJob *__restrict__ 
 
 // ---- ingest: host block -> HBM with I and Q exchanged on the way (the reference swaps while it copies the block together).
 // `src` is page-locked host memory mapped into the device's address space: the kernel IS the transfer over the link.
-__global__ __launch_bounds__(256) void ingest_swap(const float2 *__restrict__ src, float2 *__restrict__ dst, int64_t n) {
+__global__ __launch_bounds__(256) void ingest_swap(const float2 *src, float2 *dst /* may be src: exchange in place */, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)256 * gridDim.x) {
         const float2 v = src[i];
         dst[i] = make_float2(v.y, v.x);

@@ -19,6 +19,8 @@ def _as_iq_arg(iq):
             iq = np.ascontiguousarray(iq).view(np.complex64).reshape(-1)
         a = np.ascontiguousarray(iq, dtype=np.complex64)
         return a.ctypes.data_as(C.c_void_p), 0, a.size, a
+    if isinstance(iq, DevicePointer):
+        return C.c_void_p(iq.ptr), 1, iq.n, iq
     # torch tensor on the GPU: complex64 [n] or float32 [n, 2] / [2n]
     import torch
     if not isinstance(iq, torch.Tensor) or not iq.is_cuda:
@@ -255,6 +257,19 @@ class DemodBank:
         H.check(self._l.csdr_bank_fetch_fms_stage(self.h, int(slot), int(which), out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
         return out[:n.value].copy()
 
+    def pcm16(self, slot, cap=1 << 22):
+        """the slot's audio of the last execute as 16-bit PCM, every block scaled by its own peak (AudioFileWAV.cpp:133-157), converted on the device"""
+        out = np.empty(cap, np.int16)
+        n = C.c_int()
+        H.check(self._l.csdr_bank_fetch_pcm16(self.h, int(slot), out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def scope_frame(self, slot):
+        """the audio-scope tap of the last block as a device-resident frame (H.ScopeFrame; n == 0: nothing to show)"""
+        f = H.ScopeFrame()
+        H.check(self._l.csdr_bank_scope_frame(self.h, int(slot), C.byref(f)))
+        return f
+
     def total_audio(self):
         n = C.c_int64()
         H.check(self._l.csdr_bank_total_audio(self.h, C.byref(n)))
@@ -347,3 +362,132 @@ class SpectrumProcessor:
         if self.h:
             self._l.csdr_spec_destroy(self.h)
             self.h = C.c_void_p()
+
+
+class ScopeProcessor:
+    """ScopeVisualProcessor's arithmetic (csdr_scope): waveform normalisation + audio spectrum of AudioThreadInput frames."""
+
+    def __init__(self, ctx, fft_size=1024, max_frames=8, max_samples=8192):
+        self._l = H.lib()
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        H.check(self._l.csdr_scope_create(ctx.h, C.byref(self.h)))
+        H.check(self._l.csdr_scope_setup(self.h, int(fft_size), int(max_frames), int(max_samples)))
+
+    def set_enabled(self, scope=True, spectrum=True):
+        H.check(self._l.csdr_scope_set_enabled(self.h, int(scope), int(spectrum)))
+
+    def process(self, frames):
+        """frames: list of dicts {data (numpy float32), channels, type, sample_rate, input_rate} (host frames), or of H.ScopeFrame
+        structures whose data lies in HBM (DemodBank.scope_frame)"""
+        n = len(frames)
+        arr = (H.ScopeFrame * n)()
+        keep = []
+        dev = isinstance(frames[0], H.ScopeFrame)
+        for i, f in enumerate(frames):
+            if dev:
+                arr[i] = f
+            else:
+                a = np.ascontiguousarray(f["data"], dtype=np.float32)
+                keep.append(a)
+                arr[i] = H.ScopeFrame(a.ctypes.data, None, a.size, int(f["channels"]), int(f.get("type", 0)), int(f["sample_rate"]), int(f["input_rate"]),
+                                      int(f.get("layout", 0)), float(f.get("scale", 1.0)))
+        H.check(self._l.csdr_scope_process(self.h, arr, n, 1 if dev else 0))
+
+    def fetch(self, frame, spectrum):
+        """-> dict like oracle.ref_modems.RefScopeCpp.push items, or None when that item was not produced"""
+        pts = np.empty(1 << 15, np.float32)
+        info = H.ScopeInfo()
+        H.check(self._l.csdr_scope_fetch(self.h, int(frame), 1 if spectrum else 0, pts.ctypes.data_as(C.c_void_p), pts.size, C.byref(info)))
+        if info.n_floats == 0:
+            return None
+        return dict(points=pts[:info.n_floats].copy(), mode=info.mode, spectrum=bool(info.spectrum), channels=info.channels, input_rate=info.input_rate,
+                    sample_rate=info.sample_rate, fft_size=info.fft_size, fft_floor=info.fft_floor, fft_ceil=info.fft_ceil)
+
+    def close(self):
+        if self.h:
+            self._l.csdr_scope_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class AudioMixer:
+    """AudioThread's mixing callback (csdr_mix): per-source block queues, rings in HBM, bit-exact mix-down."""
+
+    def __init__(self, ctx, n_sources, sample_rate=48000, ring_floats=1 << 20, queue_blocks=0):
+        self._l = H.lib()
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        H.check(self._l.csdr_mix_create(ctx.h, int(n_sources), int(ring_floats), int(sample_rate), C.byref(self.h)))
+        for i in range(n_sources):
+            self.set_source(i, queue_blocks=queue_blocks)
+
+    def set_source(self, i, bound=True, active=True, gain=1.0, queue_blocks=0):
+        H.check(self._l.csdr_mix_set_source(self.h, int(i), int(bound), int(active), float(gain), int(queue_blocks)))
+
+    def push(self, i, data, channels, sample_rate, peak):
+        """-> True when the queue took the block (False: full, dropped -- try_push semantics)"""
+        a = np.ascontiguousarray(data, dtype=np.float32)
+        rc = self._l.csdr_mix_push(self.h, int(i), a.ctypes.data_as(C.c_void_p), 0, a.size, int(channels), int(sample_rate), float(peak))
+        if rc == 1:
+            return False
+        H.check(rc)
+        return True
+
+    def push_bank(self, bank, slots, sources=None):
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        so = np.ascontiguousarray(sources if sources is not None else slots, dtype=np.int32)
+        H.check(self._l.csdr_mix_push_bank(self.h, bank.h, sl.ctypes.data_as(C.c_void_p), so.ctypes.data_as(C.c_void_p), sl.size))
+
+    def queued(self, i):
+        return self._l.csdr_mix_queued(self.h, int(i))
+
+    def render(self, frames, n_buffers=1, fetch=True):
+        out = np.empty(n_buffers * frames * 2, np.float32) if fetch else None
+        H.check(self._l.csdr_mix_render(self.h, int(frames), int(n_buffers), out.ctypes.data_as(C.c_void_p) if fetch else None))
+        return out
+
+    def pcm16(self, peak=1.0, per_buffer_peak=False, cap=1 << 22):
+        out = np.empty(cap, np.int16)
+        n = C.c_int()
+        H.check(self._l.csdr_mix_fetch_pcm16(self.h, out.ctypes.data_as(C.c_void_p), cap, float(peak), int(per_buffer_peak), C.byref(n)))
+        return out[:n.value].copy()
+
+    def close(self):
+        if self.h:
+            self._l.csdr_mix_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Ingest:
+    """page-locked block ring -> HBM, ONE transfer per block (csdr_ingest); commit returns the device pointer as an integer"""
+
+    def __init__(self, ctx, max_samples, depth=3):
+        self._l = H.lib()
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        self.max_samples = int(max_samples)
+        H.check(self._l.csdr_ingest_create(ctx.h, self.max_samples, int(depth), C.byref(self.h)))
+
+    def acquire(self):
+        """-> numpy complex64 view of the page-locked slot (max_samples long)"""
+        p = C.c_void_p()
+        H.check(self._l.csdr_ingest_acquire(self.h, C.byref(p)))
+        buf = (C.c_float * (2 * self.max_samples)).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.complex64)
+
+    def commit(self, n_samples, iq_swap=False):
+        p = C.c_void_p()
+        H.check(self._l.csdr_ingest_commit(self.h, int(n_samples), int(iq_swap), C.byref(p)))
+        return DevicePointer(p.value, int(n_samples))
+
+    def close(self):
+        if self.h:
+            self._l.csdr_ingest_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class DevicePointer:
+    """a raw device IQ buffer (complex64 samples) that SDRPost.execute / SpectrumProcessor.process accept like a CUDA tensor"""
+
+    def __init__(self, ptr, n):
+        self.ptr, self.n = ptr, n

@@ -12,9 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcsdr_hip.so")
 
 CSDR_POST_SINGLE, CSDR_POST_PFBCH, CSDR_POST_PFBCH2 = 0, 1, 2
-CSDR_MODEM_NBFM, CSDR_MODEM_FM, CSDR_MODEM_AM, CSDR_MODEM_USB, CSDR_MODEM_LSB, CSDR_MODEM_IQ, CSDR_MODEM_CW, CSDR_MODEM_DSB, CSDR_MODEM_FMS = range(9)
+CSDR_MODEM_NBFM, CSDR_MODEM_FM, CSDR_MODEM_AM, CSDR_MODEM_USB, CSDR_MODEM_LSB, CSDR_MODEM_IQ, CSDR_MODEM_CW, CSDR_MODEM_DSB, CSDR_MODEM_FMS, CSDR_MODEM_HOST = range(10)
 CSDR_SPEC_FIRST_FRAME, CSDR_SPEC_CONTIGUOUS, CSDR_SPEC_LINES = 0, 1, 2
-MODEM_BY_NAME = {"NBFM": 0, "FM": 1, "AM": 2, "USB": 3, "LSB": 4, "I/Q": 5, "IQ": 5, "CW": 6, "DSB": 7, "FMS": 8}
+MODEM_BY_NAME = {"NBFM": 0, "FM": 1, "AM": 2, "USB": 3, "LSB": 4, "I/Q": 5, "IQ": 5, "CW": 6, "DSB": 7, "FMS": 8, "HOST": 9}
 
 
 class DemodParams(C.Structure):
@@ -27,6 +27,16 @@ class BlockResult(C.Structure):
                 ("level_accum", C.c_double), ("level_count", C.c_int32), ("audio_peak", C.c_float),
                 ("nco_theta", C.c_uint32), ("resamp_phase", C.c_uint32), ("buffer_index", C.c_uint32),
                 ("reserved", C.c_uint32)]
+
+
+class ScopeFrame(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("n_dev", C.c_void_p), ("n", C.c_int32), ("channels", C.c_int32), ("type", C.c_int32),
+                ("sample_rate", C.c_int32), ("input_rate", C.c_int32), ("layout", C.c_int32), ("scale", C.c_float)]
+
+
+class ScopeInfo(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("spectrum", C.c_int32), ("channels", C.c_int32), ("input_rate", C.c_int32), ("sample_rate", C.c_int32),
+                ("fft_size", C.c_int32), ("n_floats", C.c_int32), ("reserved", C.c_int32), ("fft_floor", C.c_double), ("fft_ceil", C.c_double)]
 
 
 _p, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
@@ -108,6 +118,31 @@ ABI = {
     "csdr_spec_fetch": (_i, [_p, _i, _p, _i, C.POINTER(_d), C.POINTER(_d)]),
     "csdr_spec_fetch_hold": (_i, [_p, _i, _p, _i, C.POINTER(_i)]),
     "csdr_spec_fft_only": (_i, [_p, _p, _p]),
+    "csdr_scope_create": (_i, [_p, _pp]),
+    "csdr_scope_destroy": (None, [_p]),
+    "csdr_scope_setup": (_i, [_p, _i, _i, _i]),
+    "csdr_scope_set_enabled": (_i, [_p, _i, _i]),
+    "csdr_scope_set_max_scope_samples": (_i, [_p, _i]),
+    "csdr_scope_set_average_rate": (_i, [_p, _f]),
+    "csdr_scope_process": (_i, [_p, C.POINTER(ScopeFrame), _i, _i]),
+    "csdr_scope_frames": (_i, [_p]),
+    "csdr_scope_fetch": (_i, [_p, _i, _i, _p, _i, C.POINTER(ScopeInfo)]),
+    "csdr_bank_scope_frame": (_i, [_p, _i, C.POINTER(ScopeFrame)]),
+    "csdr_mix_create": (_i, [_p, _i, _i, _i, _pp]),
+    "csdr_mix_destroy": (None, [_p]),
+    "csdr_mix_set_source": (_i, [_p, _i, _i, _i, _f, _i]),
+    "csdr_mix_push": (_i, [_p, _i, _p, _i, _i, _i, _i, _f]),
+    "csdr_mix_push_bank": (_i, [_p, _p, _p, _p, _i]),
+    "csdr_mix_queued": (_i, [_p, _i]),
+    "csdr_mix_render": (_i, [_p, _i, _i, _p]),
+    "csdr_mix_fetch_pcm16": (_i, [_p, _p, _i, _f, _i, C.POINTER(_i)]),
+    "csdr_bank_fetch_pcm16": (_i, [_p, _i, _p, _i, C.POINTER(_i)]),
+    "csdr_ingest_create": (_i, [_p, _i64, _i, _pp]),
+    "csdr_ingest_destroy": (None, [_p]),
+    "csdr_ingest_acquire": (_i, [_p, _pp]),
+    "csdr_ingest_commit": (_i, [_p, _i64, _i, _pp]),
+    "csdr_ingest_upload": (_i, [_p, _p, _i64, _i, _pp]),
+    "csdr_ingest_next_slot": (_i, [_p]),
 }
 
 _lib = None

@@ -1,24 +1,30 @@
-// Adapters.h -- the ingest / egress edges of the hot path, device-agnostic (no SoapySDR / RtAudio / wx dependency):
+// Adapters.h -- the ingest / egress edges of the hot path over the device library (no SoapySDR / RtAudio / wx dependency).
 //
-//   SDRBlockAssembler : SDRThread::readStream's block semantics (reference src/sdr/SoapySDRThread.cpp:195-402) over any
-//       CF32 stream source: MTU-sized reads appended until numElems samples are in the block, the excess of the last read carried
-//       to the next block (overflowBuffer), optional I/Q swap, drop when the consumer queue is full; numChannels / numElems by
-//       getOptimalChannelCount / getOptimalElementCount (:668-693).  The pooled block buffers can be page-locked once
-//       (csdr_host_register) so that csdr_post_execute's host-to-device copy is a DMA from the block itself.
-//   AudioMixer : the RtAudio callback's mixing of the bound demodulators' audio queues into one interleaved stereo buffer
-//       (src/audio/AudioThread.cpp:88-240): per source gain, mono fan-out, sample-rate filtering, peak-normalised sum.
-//   AudioSinkWAV : AudioFileWAV::writeToFile (src/audio/AudioFileWAV.cpp:63-170): 16-bit PCM with the peak-based anti-clipping
-//       scale, header patched on close, 2 GB roll-over into numbered files.
+// The reference does this work sample by sample on the CPU; here the host keeps only bookkeeping and every per-sample operation
+// happens where the samples already are:
+//
+//   StreamReblocker   what SDRThread::readStream does to the device stream (src/sdr/SoapySDRThread.cpp:195-402): MTU-sized reads become
+//                     blocks of numElems samples, the surplus of the last read opens the next block, a saturated consumer loses the
+//                     block.  Reads land DIRECTLY in the block (no intermediate MTU buffer, no per-sample copy loop); the I/Q
+//                     exchange (:258-266) is not done here at all: the block carries a flag and the exchange happens while the block
+//                     crosses the link (csdr_ingest_upload).  numChannels / numElems: :668-693.
+//   DeviceIngest      ONE transfer per block into a ring of HBM slots (csdr_ingest); the block then carries its device address, which
+//                     SDRPostThread and the spectrum processors read instead of uploading the host copy again (SDRPostThread.cpp:227-245
+//                     hands one buffer to all consumers).
+//   AudioMixer        the sound device's callback (src/audio/AudioThread.cpp:88-240) over csdr_mix: the demodulators' audio goes from the
+//                     bank to per-source rings in HBM, the mix-down of a callback buffer is one kernel, one buffer comes back.
+//   WavWriter         AudioFileWAV (src/audio/AudioFileWAV.cpp:63-170): RIFF bookkeeping on the host, the float -> int16 conversion with
+//                     the anti-clipping scale on the device (csdr_bank_fetch_pcm16 / csdr_mix_fetch_pcm16).
 #pragma once
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdint>
+#include <cstdio>
 #include <cstring>
-#include <fstream>
-#include <iomanip>
 #include <memory>
 #include <mutex>
-#include <sstream>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -36,254 +42,306 @@ struct IQStreamSource {
     virtual int readStream(float *buff, int maxElems) = 0;
 };
 
-class SDRBlockAssembler {
-public:
-    explicit SDRBlockAssembler(csdr_ctx *ctx = nullptr) : ctx_(ctx), buffers("SDRThreadBuffers") {}
-    ~SDRBlockAssembler() { for (void *p : registered_) if (ctx_) (void)csdr_host_unregister(ctx_, p); }
-
-    static int getOptimalChannelCount(long long sampleRate_in) {                       // :676-693
-        if (sampleRate_in <= CHANNELIZER_RATE_MAX) return 1;
-        int optimal_count = int(std::ceil(double(sampleRate_in) / double(CHANNELIZER_RATE_MAX)));
-        if (optimal_count % 2 == 1) optimal_count--;
-        if (optimal_count < 2) optimal_count = 2;
-        return optimal_count;
-    }
-    static int getOptimalElementCount(long long sampleRate_in, int fps, int nch) {     // :668-674
-        int elemCount = (int)std::floor((double)sampleRate_in / (double)fps);
-        return int(std::ceil((double)elemCount / (double)nch)) * nch;
-    }
-    void setSampleRate(long long rate) {                                               // updateSettings :505-516
-        sampleRate.store(rate);
-        numChannels.store(getOptimalChannelCount(rate));
-        numElems.store(getOptimalElementCount(rate, TARGET_DISPLAY_FPS, numChannels.load()));
-    }
-    void setFrequency(long long f) { frequency.store(f < sampleRate.load() / 2 ? sampleRate.load() / 2 : f); }   // :696-701
-    void setMTU(int mtu) { mtuElems.store(mtu); mtuBuf_.resize((size_t)2 * mtu); }
-    void setIQSwap(bool s) { iq_swap.store(s); }
-    int getNumChannels() const { return numChannels.load(); }
-    int getNumElems() const { return numElems.load(); }
-
-    // one block: returns the last read code (> 0 samples of the last read, 0 when nothing was posted, < 0 stream error)
-    int readStream(IQStreamSource &device, const SDRThreadIQDataQueuePtr &iqDataOutQueue, const std::atomic_bool &stopping) {
-        int n_read = 0;
-        const int nElems = numElems.load(), mtElems = mtuElems.load();
-        SDRThreadIQDataPtr dataOut = buffers.getBuffer();
-        assure(dataOut.get(), nElems);
-        if (numOverflow > 0) {                                                         // 1. the previous read's excess comes first
-            const int n_overflow = std::min(numOverflow, nElems);
-            std::memcpy(&dataOut->data[0], &overflowBuffer.data[0], (size_t)n_overflow * sizeof(liquid_float_complex_t));
-            n_read = n_overflow;
-            numOverflow -= n_overflow;
-            if (numOverflow > 0) std::memmove(&overflowBuffer.data[0], &overflowBuffer.data[n_overflow], (size_t)numOverflow * sizeof(liquid_float_complex_t));
+// ---- block geometry of a sample rate (SoapySDRThread.cpp:668-693) -------------------------------------------------------------
+struct BlockGeometry {
+    int channels = 1, elems = 0;
+    static BlockGeometry forRate(long long rate, int fps = TARGET_DISPLAY_FPS) {
+        BlockGeometry g;
+        if (rate > CHANNELIZER_RATE_MAX) {
+            // as many <= 500 kHz channels as cover the rate, rounded DOWN to an even count, at least two
+            const int covering = (int)std::ceil((double)rate / (double)CHANNELIZER_RATE_MAX);
+            g.channels = std::max(2, covering & ~1);
         }
-        int readStreamCode = 0;
-        while (n_read < nElems && !stopping) {                                         // 2. MTU-sized reads until the block is full
-            const int n_stream_read = device.readStream(mtuBuf_.data(), mtElems);
-            readStreamCode = n_stream_read;
-            if (n_stream_read <= 0) break;
-            const float *pp = mtuBuf_.data();
-            const bool swap = iq_swap.load();
-            auto put = [&](liquid_float_complex_t &d, const float *s) { if (swap) { d.imag = s[0]; d.real = s[1]; } else { d.real = s[0]; d.imag = s[1]; } };
-            if (n_read + n_stream_read > nElems) {
-                const int n_requested = nElems - n_read;
-                assure(dataOut.get(), n_read + n_requested);
-                for (int i = 0; i < n_requested; i++) put(dataOut->data[n_read + i], pp + 2 * i);
-                pp += 2 * n_requested;
-                const int numNewOverflow = n_stream_read - n_requested;
-                assure(&overflowBuffer, numOverflow + numNewOverflow);
-                for (int i = 0; i < numNewOverflow; i++) put(overflowBuffer.data[numOverflow + i], pp + 2 * i);
-                numOverflow += numNewOverflow;
-                n_read += n_requested;
-            } else {
-                assure(dataOut.get(), n_read + n_stream_read);
-                for (int i = 0; i < n_stream_read; i++) put(dataOut->data[n_read + i], pp + 2 * i);
-                n_read += n_stream_read;
-            }
-        }
-        if (n_read > 0 && !stopping && !iqDataOutQueue->full()) {                      // 3. post, or discard when the consumer is saturated
-            dataOut->data.resize((size_t)n_read);
-            dataOut->frequency = frequency.load();
-            dataOut->sampleRate = sampleRate.load();
-            dataOut->dcCorrected = false;
-            dataOut->numChannels = numChannels.load();
-            if (!iqDataOutQueue->try_push(dataOut)) readStreamCode = 0;
-        } else readStreamCode = 0;
-        return readStreamCode;
+        const int perFrame = (int)std::floor((double)rate / (double)fps);
+        g.elems = ((perFrame + g.channels - 1) / g.channels) * g.channels;      // whole channelizer frames
+        return g;
     }
-    int pendingOverflow() const { return numOverflow; }
-
-private:
-    // resize to at least n samples; a buffer whose storage moved (or is new) is page-locked for the H2D copy
-    void assure(SDRThreadIQData *d, int n) {
-        if ((int)d->data.size() >= n) return;
-        const void *before = d->data.data();
-        d->data.resize((size_t)std::max(n, numElems.load()));
-        if (ctx_ && d != &overflowBuffer && d->data.data() != before) {
-            if (before) { auto it = std::find(registered_.begin(), registered_.end(), (void *)before); if (it != registered_.end()) { (void)csdr_host_unregister(ctx_, *it); registered_.erase(it); } }
-            if (csdr_host_register(ctx_, d->data.data(), d->data.size() * sizeof(liquid_float_complex_t)) == CSDR_OK) registered_.push_back(d->data.data());
-        }
-    }
-    csdr_ctx *ctx_;
-    ReBuffer<SDRThreadIQData> buffers;
-    SDRThreadIQData overflowBuffer;
-    int numOverflow = 0;
-    std::vector<float> mtuBuf_;
-    std::vector<void *> registered_;
-    std::atomic<long long> sampleRate{0}, frequency{0};
-    std::atomic_int numChannels{1}, numElems{0}, mtuElems{0};
-    std::atomic_bool iq_swap{false};
 };
 
-// ---- audio egress: one mixer source per demodulator (an AudioThread bound to the device controller, AudioThread.cpp:52-72)
-struct AudioMixSource {
-    AudioThreadInputQueuePtr inputQueue;
-    AudioThreadInputPtr currentInput;
-    size_t audioQueuePtr = 0;
-    float gain = 1.0f;
-    std::atomic_bool active{true}, terminated{false};
-    std::recursive_mutex mu;
+// ---- one transfer per block into a ring of HBM slots ----------------------------------------------------------------------------
+class DeviceIngest {
+public:
+    DeviceIngest(csdr_ctx *ctx, long long maxSamples, int depth = 4) : holds_((size_t)depth) {
+        if (csdr_ingest_create(ctx, maxSamples, depth, &ing_) != CSDR_OK) throw std::runtime_error(std::string("csdr_ingest_create: ") + csdr_last_error());
+    }
+    ~DeviceIngest() { if (ing_) csdr_ingest_destroy(ing_); }
+    // Moves blk.data over the link (exchanging I and Q on the way when blk.iqSwapPending) and records the HBM address in the block.
+    // false: the slot that is next in the ring is still held by a consumer (or the transfer failed) -- the block stays host-only.
+    bool upload(SDRThreadIQData &blk) {
+        const int k = csdr_ingest_next_slot(ing_);
+        if (k < 0 || (holds_[(size_t)k] && holds_[(size_t)k].use_count() > 1)) return false;
+        const float *dev = nullptr;
+        if (csdr_ingest_upload(ing_, reinterpret_cast<const float *>(blk.data.data()), (long long)blk.data.size(), blk.iqSwapPending ? 1 : 0, &dev) != CSDR_OK) return false;
+        holds_[(size_t)k] = std::make_shared<int>(k);
+        blk.deviceData = dev; blk.deviceSamples = blk.data.size(); blk.deviceHold = holds_[(size_t)k];
+        return true;
+    }
+
+private:
+    csdr_ingest *ing_ = nullptr;
+    std::vector<std::shared_ptr<void>> holds_;
+};
+
+// ---- the device stream cut into blocks ----------------------------------------------------------------------------------------
+// A block buffer holds numElems samples plus room for one whole read: every read is written straight behind what the block already
+// holds; when that passes numElems the surplus is the head of the NEXT block and is moved there once, as one memmove.
+class StreamReblocker {
+public:
+    explicit StreamReblocker(csdr_ctx *ctx = nullptr) : ctx_(ctx), pool_("SDRThreadBuffers") {}
+    ~StreamReblocker() { for (void *p : pinned_) if (ctx_) (void)csdr_host_unregister(ctx_, p); }
+
+    static int getOptimalChannelCount(long long rate) { return BlockGeometry::forRate(rate).channels; }
+    static int getOptimalElementCount(long long rate, int fps, int nch) {
+        const int perFrame = (int)std::floor((double)rate / (double)fps);
+        return ((perFrame + nch - 1) / nch) * nch;
+    }
+    void setSampleRate(long long rate) {                                               // updateSettings :505-516
+        const BlockGeometry g = BlockGeometry::forRate(rate);
+        rate_.store(rate); channels_.store(g.channels); elems_.store(g.elems);
+    }
+    void setFrequency(long long f) { const long long lo = rate_.load() / 2; freq_.store(f < lo ? lo : f); }   // :696-701
+    void setMTU(int mtu) { mtu_.store(mtu); }
+    void setIQSwap(bool s) { swap_.store(s); }
+    int getNumChannels() const { return channels_.load(); }
+    int getNumElems() const { return elems_.load(); }
+    int pendingOverflow() const { return (int)spill_.size(); }
+
+    // Assemble and post ONE block.  Returns the code of the last read: > 0 its sample count, 0 when nothing was posted (would-block
+    // read with an empty block, stop request, saturated consumer), < 0 the stream's error code (what was read so far is still posted).
+    int readStream(IQStreamSource &dev, const SDRThreadIQDataQueuePtr &out, const std::atomic_bool &stopping) {
+        const int want = elems_.load(), mtu = std::max(1, mtu_.load());
+        SDRThreadIQDataPtr blk = pool_.getBuffer();
+        reserve(*blk, (size_t)want + (size_t)mtu);
+        liquid_float_complex_t *base = blk->data.data();
+        // the surplus of the previous block comes first; with a small block and a large MTU it can exceed a whole block
+        size_t have = std::min(spill_.size(), (size_t)want);
+        bool swapped = false;                                                          // what the block holds so far still needs the I/Q exchange
+        if (have) {
+            std::memcpy(base, spill_.data(), have * sizeof *base);
+            spill_.erase(spill_.begin(), spill_.begin() + (long)have);
+            swapped = spillSwapped_;
+        }
+        int code = 0;
+        while ((int)have < want && !stopping.load()) {
+            const bool sw = swap_.load();
+            code = dev.readStream(reinterpret_cast<float *>(base + have), mtu);         // straight into the block
+            if (code <= 0) break;
+            if (have == 0) swapped = sw;
+            else if (sw != swapped) {
+                // the option changed inside this block (a user action): exchange what is there on the host, once, so that the whole
+                // block needs the same treatment again (the exchange is its own inverse)
+                exchange(base, have);
+                swapped = sw;
+            }
+            have += (size_t)code;
+        }
+        if ((int)have > want) {                                                        // the last read ran past the block: carry the rest
+            spill_.insert(spill_.end(), base + want, base + have);
+            spillSwapped_ = swapped;
+            have = (size_t)want;
+        }
+        if (have == 0 || stopping.load() || out->full()) return 0;                     // nothing to hand over / the consumer is saturated
+        blk->data.resize(have);
+        blk->frequency = freq_.load(); blk->sampleRate = rate_.load(); blk->numChannels = channels_.load(); blk->dcCorrected = false;
+        blk->iqSwapPending = swapped;
+        blk->dropDeviceCopy();
+        // with an ingest bound the block crosses the link ONCE, here, and the exchange rides along; host readers of `data` get the
+        // same orientation afterwards (one pass over the host copy, only while the option is on)
+        const bool inHbm = ingest_ && ingest_->upload(*blk);
+        if (blk->iqSwapPending) exchange(blk->data.data(), have);
+        blk->iqSwapPending = false;
+        (void)inHbm;
+        if (!out->try_push(blk)) return 0;
+        return code;
+    }
+    void bindIngest(DeviceIngest *ing) { ingest_ = ing; }
+
+private:
+    static void exchange(liquid_float_complex_t *p, size_t n) { for (size_t i = 0; i < n; ++i) std::swap(p[i].real, p[i].imag); }
+    // capacity only: the pooled vector keeps its storage (page-locked once per storage so that the transfer is a DMA from the block)
+    void reserve(SDRThreadIQData &blk, size_t n) {
+        if (blk.data.size() >= n) return;
+        const void *before = blk.data.empty() ? nullptr : blk.data.data();
+        blk.data.resize(n);
+        if (!ctx_ || blk.data.data() == before) return;
+        auto it = std::find(pinned_.begin(), pinned_.end(), (void *)before);
+        if (it != pinned_.end()) { (void)csdr_host_unregister(ctx_, *it); pinned_.erase(it); }
+        if (csdr_host_register(ctx_, blk.data.data(), blk.data.size() * sizeof(liquid_float_complex_t)) == CSDR_OK) pinned_.push_back(blk.data.data());
+    }
+    csdr_ctx *ctx_;
+    DeviceIngest *ingest_ = nullptr;
+    ReBuffer<SDRThreadIQData> pool_;
+    std::vector<liquid_float_complex_t> spill_;
+    bool spillSwapped_ = false;
+    std::vector<void *> pinned_;
+    std::atomic<long long> rate_{0}, freq_{0};
+    std::atomic_int channels_{1}, elems_{0}, mtu_{0};
+    std::atomic_bool swap_{false};
+};
+typedef StreamReblocker SDRBlockAssembler;          // (the name earlier revisions and INTEGRATION.md use)
+
+// ---- audio egress -------------------------------------------------------------------------------------------------------------
+// One source per demodulator (the reference binds one AudioThread per DemodulatorInstance to the device's controller thread,
+// AudioThread.cpp:52-74).  A source's queue lives in the device library: blocks go in from the host (try_push) or straight from the
+// bank in HBM (AudioMixer::takeBankAudio).
+class AudioMixer;
+class AudioMixSource {
+public:
+    // AudioThreadInputQueue::try_push of the reference's inputQueue: false when the queue is full (the block is lost, :322)
+    bool try_push(const AudioThreadInputPtr &a);
+    size_t queued() const;
+    void setGain(float g) { gain_ = g < 0.005f ? 0.005f : (g > 40.0f ? 40.0f : g); apply(); }    // AudioThread::setGain clamps (:523-531)
+    float getGain() const { return gain_; }
+    void setActive(bool a) { active_ = a; apply(); }
+    bool isActive() const { return active_; }
+    int index() const { return index_; }
+
+private:
+    friend class AudioMixer;
+    void apply();
+    AudioMixer *mixer_ = nullptr;
+    int index_ = -1, queueBlocks_ = 0;
+    float gain_ = 1.0f;
+    bool active_ = true;
 };
 
 class AudioMixer {
 public:
-    explicit AudioMixer(int sampleRate) : sampleRate_(sampleRate) {}
-    void bindThread(const std::shared_ptr<AudioMixSource> &s) { std::lock_guard<std::recursive_mutex> g(mu_); if (std::find(bound_.begin(), bound_.end(), s) == bound_.end()) bound_.push_back(s); }
-    void removeThread(const std::shared_ptr<AudioMixSource> &s) { std::lock_guard<std::recursive_mutex> g(mu_); bound_.erase(std::remove(bound_.begin(), bound_.end(), s), bound_.end()); }
-    int getSampleRate() const { return sampleRate_; }
+    AudioMixer(csdr_ctx *ctx, int sampleRate, int maxSources = 64, int queueBlocks = 100, int ringFloats = 1 << 20) : rate_(sampleRate), queueBlocks_(queueBlocks) {
+        if (csdr_mix_create(ctx, maxSources, ringFloats, sampleRate, &mix_) != CSDR_OK) throw std::runtime_error(std::string("csdr_mix_create: ") + csdr_last_error());
+        slots_.assign((size_t)maxSources, nullptr);
+    }
+    ~AudioMixer() { if (mix_) csdr_mix_destroy(mix_); }
+    int getSampleRate() const { return rate_; }
 
-    // the body of audioCallback (:88-240): `out` receives nBufferFrames interleaved stereo frames
+    std::shared_ptr<AudioMixSource> bindThread() {                                    // bindThread (:52-62): binding order = mixing order
+        std::lock_guard<std::mutex> g(mu_);
+        for (size_t i = 0; i < slots_.size(); ++i)
+            if (!slots_[i]) {
+                auto s = std::make_shared<AudioMixSource>();
+                s->mixer_ = this; s->index_ = (int)i; s->queueBlocks_ = queueBlocks_;
+                slots_[i] = s;
+                (void)csdr_mix_set_source(mix_, (int)i, 1, 1, 1.0f, queueBlocks_);
+                return s;
+            }
+        return nullptr;
+    }
+    void removeThread(const std::shared_ptr<AudioMixSource> &s) {                     // :64-74
+        std::lock_guard<std::mutex> g(mu_);
+        if (!s || s->index_ < 0 || slots_[(size_t)s->index_] != s) return;
+        (void)csdr_mix_set_source(mix_, s->index_, 0, 0, 1.0f, 0);
+        slots_[(size_t)s->index_] = nullptr;
+        s->mixer_ = nullptr;
+    }
+    // the audio of every block of the bank's last execute for these demodulators, HBM to HBM (squelched / muted ones are simply not listed)
+    bool takeBankAudio(csdr_bank *bank, const std::vector<int> &bankSlots, const std::vector<std::shared_ptr<AudioMixSource>> &sources) {
+        std::lock_guard<std::mutex> g(mu_);
+        std::vector<int> idx;
+        for (auto &s : sources) idx.push_back(s ? s->index_ : -1);
+        return !bankSlots.empty() && csdr_mix_push_bank(mix_, bank, bankSlots.data(), idx.data(), (int)bankSlots.size()) == CSDR_OK;
+    }
+    // the sound device's callback: nBufferFrames interleaved stereo frames into `out`; always 0 (the reference returns 1 only when terminated)
     int callback(float *out, unsigned int nBufferFrames) {
-        std::memset(out, 0, (size_t)nBufferFrames * 2 * sizeof(float));
-        std::lock_guard<std::recursive_mutex> lock(mu_);
-        double peak = 0.0;
-        for (auto &sp : bound_) {
-            AudioMixSource *srcmix = sp.get();
-            std::lock_guard<std::recursive_mutex> l2(srcmix->mu);
-            if (srcmix->terminated || !srcmix->inputQueue || srcmix->inputQueue->empty() || !srcmix->active) continue;
-            if (!srcmix->currentInput) {
-                srcmix->audioQueuePtr = 0;
-                (void)srcmix->inputQueue->try_pop(srcmix->currentInput);
-                continue;
-            }
-            if (srcmix->currentInput->sampleRate != sampleRate_) {
-                while (srcmix->inputQueue->try_pop(srcmix->currentInput)) {
-                    if (srcmix->currentInput && srcmix->currentInput->sampleRate == sampleRate_) break;
-                    srcmix->currentInput = nullptr;
-                }
-                srcmix->audioQueuePtr = 0;
-                if (!srcmix->currentInput) continue;
-            }
-            if (srcmix->currentInput->channels == 0 || srcmix->currentInput->data.empty()) {
-                if (!srcmix->inputQueue->empty()) {
-                    srcmix->audioQueuePtr = 0;
-                    srcmix->currentInput = nullptr;
-                    if (!srcmix->inputQueue->try_pop(srcmix->currentInput)) continue;
-                }
-                continue;
-            }
-            double mixPeak = srcmix->currentInput->peak * srcmix->gain;
-            auto next_input = [&]() -> bool {                                          // the block is used up: take the next one
-                srcmix->audioQueuePtr = 0;
-                srcmix->currentInput = nullptr;
-                if (!srcmix->inputQueue->try_pop(srcmix->currentInput)) return false;
-                const double srcPeak = srcmix->currentInput->peak * srcmix->gain;
-                if (mixPeak < srcPeak) mixPeak = srcPeak;
-                return true;
-            };
-            if (srcmix->currentInput->channels == 1) {
-                for (unsigned int i = 0; i < nBufferFrames; i++) {
-                    if (srcmix->audioQueuePtr >= srcmix->currentInput->data.size() && !next_input()) break;
-                    if (srcmix->currentInput && !srcmix->currentInput->data.empty()) {
-                        const float v = srcmix->currentInput->data[srcmix->audioQueuePtr] * srcmix->gain;
-                        out[i * 2] += v; out[i * 2 + 1] += v;
-                    }
-                    srcmix->audioQueuePtr++;
-                }
-            } else {
-                for (unsigned int i = 0, iMax = srcmix->currentInput->channels * nBufferFrames; i < iMax; i++) {
-                    if (srcmix->audioQueuePtr >= srcmix->currentInput->data.size() && !next_input()) break;
-                    if (srcmix->currentInput && !srcmix->currentInput->data.empty()) out[i] = out[i] + srcmix->currentInput->data[srcmix->audioQueuePtr] * srcmix->gain;
-                    srcmix->audioQueuePtr++;
-                }
-            }
-            peak += mixPeak;
-        }
-        if (peak > 1.0) {                                                             // normalise the volume
-            const float invPeak = (float)(1.0 / peak);
-            for (unsigned int i = 0; i < nBufferFrames * 2; i++) out[i] *= invPeak;
-        }
+        std::lock_guard<std::mutex> g(mu_);
+        if (csdr_mix_render(mix_, (int)nBufferFrames, 1, out) != CSDR_OK) std::memset(out, 0, (size_t)nBufferFrames * 2 * sizeof(float));
         return 0;
     }
+    // the last callback buffer as 16-bit PCM (a recording of the mixed output)
+    bool lastBufferPcm16(std::vector<int16_t> &pcm, float peak) {
+        std::lock_guard<std::mutex> g(mu_);
+        int n = 0;
+        pcm.resize(1 << 16);
+        if (csdr_mix_fetch_pcm16(mix_, pcm.data(), (int)pcm.size(), peak, 0, &n) != CSDR_OK) return false;
+        pcm.resize((size_t)n);
+        return true;
+    }
 
 private:
-    int sampleRate_;
-    std::recursive_mutex mu_;
-    std::vector<std::shared_ptr<AudioMixSource>> bound_;
+    friend class AudioMixSource;
+    csdr_mix *mix_ = nullptr;
+    int rate_, queueBlocks_;
+    std::mutex mu_;
+    std::vector<std::shared_ptr<AudioMixSource>> slots_;
 };
+inline bool AudioMixSource::try_push(const AudioThreadInputPtr &a) {
+    if (!mixer_ || !a) return false;
+    std::lock_guard<std::mutex> g(mixer_->mu_);
+    return csdr_mix_push(mixer_->mix_, index_, a->data.empty() ? nullptr : a->data.data(), 0, (int)a->data.size(), a->channels, a->sampleRate, a->peak) == CSDR_OK;
+}
+inline size_t AudioMixSource::queued() const { return mixer_ ? (size_t)csdr_mix_queued(mixer_->mix_, index_) : 0; }
+inline void AudioMixSource::apply() {
+    if (!mixer_) return;
+    std::lock_guard<std::mutex> g(mixer_->mu_);
+    (void)csdr_mix_set_source(mixer_->mix_, index_, 1, active_ ? 1 : 0, gain_, queueBlocks_);
+}
 
-// ---- WAV sink (AudioFileWAV.cpp:63-170; the file name policy of AudioFile / AudioSinkFileThread is the caller's)
-class AudioSinkWAV {
+// ---- WAV files ----------------------------------------------------------------------------------------------------------------
+// Canonical 44-byte PCM header (AudioFileWAV.cpp:108-131), sizes patched on close (:93-106), a new numbered file when the size limit
+// would be passed (:76-91).  Samples arrive as 16-bit PCM made on the device; AudioThreadInput blocks with host floats are accepted
+// for callers that have nothing else (same conversion, :133-157).
+class WavWriter {
 public:
-    static constexpr long long kMaxFileSize = 0x7FFFFFFFLL - 1024;                   // MAX_WAV_FILE_SIZE
-    explicit AudioSinkWAV(std::string base, long long maxFileSize = kMaxFileSize) : base_(std::move(base)), maxFileSize_(maxFileSize) {}
-    ~AudioSinkWAV() { closeFile(); }
+    static constexpr long long kMaxFileSize = 0x7FFFFFFFLL - 1024;                   // MAX_WAV_FILE_SIZE (:9)
+    explicit WavWriter(std::string base, long long maxFileSize = kMaxFileSize) : base_(std::move(base)), limit_(maxFileSize) {}
+    ~WavWriter() { closeFile(); }
     std::string getOutputFileName() const {
-        std::stringstream n;
-        n << base_;
-        if (seq_ > 0) n << "_" << std::setfill('0') << std::setw(3) << seq_;
-        n << ".wav";
-        return n.str();
+        char suffix[16] = "";
+        if (seq_ > 0) std::snprintf(suffix, sizeof suffix, "_%03d", seq_);
+        return base_ + suffix + ".wav";
     }
-    bool writeToFile(const AudioThreadInputPtr &input) {
-        if (!out_.is_open()) { out_.open(getOutputFileName().c_str(), std::ios::binary); currentFileSize_ = 0; writeHeader(input); }
-        const size_t room = (size_t)((maxFileSize_ - currentFileSize_) / (input->channels * 2));
-        if (room >= input->data.size()) writePayload(input, 0, input->data.size());
-        else {
-            writePayload(input, 0, room);
-            closeFile();
-            seq_++;
-            currentFileSize_ = 0;
-            out_.open(getOutputFileName().c_str(), std::ios::binary);
-            writeHeader(input);
-            writePayload(input, room, input->data.size());
+    // n 16-bit samples (interleaved when channels == 2)
+    bool writePcm16(const int16_t *pcm, size_t n, int channels, int sampleRate) {
+        if (channels < 1 || channels > 2) return false;
+        while (n) {
+            if (!f_ && !open(channels, sampleRate)) return false;
+            // whole samples that still fit under the limit; the reference counts the file size from the data chunk header on
+            const size_t room = (size_t)std::max<long long>(0, (limit_ - size_) / (2 * channels)) * (size_t)channels;   // whole frames
+            const size_t take = std::min(n, room);
+            if (take) {
+                if (std::fwrite(pcm, sizeof(int16_t), take, f_) != take) return false;
+                size_ += (long long)take * 2; pcm += take; n -= take;
+            }
+            if (n) { closeFile(); ++seq_; }                                           // the rest opens the next file of the sequence
         }
         return true;
+    }
+    // an AudioThreadInput with host floats: int(x * scale) with scale = peak < 1 ? 32767 : 32767 / peak, low 16 bits
+    bool writeToFile(const AudioThreadInputPtr &in) {
+        if (!in || in->channels < 1 || in->channels > 2) return false;
+        const float scale = in->peak < 1.0f ? 32767.0f : 32767.0f / in->peak;
+        const size_t n = in->channels == 2 ? in->data.size() & ~(size_t)1 : in->data.size();
+        conv_.resize(n);
+        for (size_t i = 0; i < n; ++i) conv_[i] = (int16_t)(int)(in->data[i] * scale);
+        return writePcm16(conv_.data(), n, in->channels, in->sampleRate);
     }
     bool closeFile() {
-        if (out_.is_open()) {
-            const size_t file_length = (size_t)out_.tellp();
-            out_.seekp((std::streamoff)dataChunkPos_ + 4); word(file_length - (dataChunkPos_ + 8), 4);
-            out_.seekp(4); word(file_length - 8, 4);
-            out_.close();
-            currentFileSize_ = 0;
-        }
+        if (!f_) return true;
+        const long end = std::ftell(f_);
+        put32(40, (uint32_t)(end - 44));                                               // data chunk size
+        put32(4, (uint32_t)(end - 8));                                                 // RIFF chunk size
+        std::fclose(f_);
+        f_ = nullptr; size_ = 0;
         return true;
     }
 
 private:
-    template <typename W> void word(W value, unsigned size) { for (; size; --size, value >>= 8) out_.put(static_cast<char>(value & 0xFF)); }
-    void writeHeader(const AudioThreadInputPtr &input) {
-        out_ << "RIFF----WAVEfmt ";
-        word(16, 4); word(1, 2); word(input->channels, 2); word(input->sampleRate, 4);
-        word((input->sampleRate * 16 * input->channels) / 8, 4); word(input->channels * 2, 2); word(16, 2);
-        dataChunkPos_ = (size_t)out_.tellp();
-        currentFileSize_ = (long long)dataChunkPos_;
-        out_ << "data----";
+    bool open(int channels, int rate) {
+        f_ = std::fopen(getOutputFileName().c_str(), "wb");
+        if (!f_) return false;
+        unsigned char h[44];
+        std::memcpy(h, "RIFF\0\0\0\0WAVEfmt ", 16);
+        le(h + 16, 16, 4); le(h + 20, 1, 2); le(h + 22, (uint32_t)channels, 2); le(h + 24, (uint32_t)rate, 4);
+        le(h + 28, (uint32_t)(rate * 2 * channels), 4); le(h + 32, (uint32_t)(2 * channels), 2); le(h + 34, 16, 2);
+        std::memcpy(h + 36, "data\0\0\0\0", 8);
+        size_ = 36;                                                                    // currentFileSize = dataChunkPos (:128-129)
+        return std::fwrite(h, 1, 44, f_) == 44;
     }
-    void writePayload(const AudioThreadInputPtr &input, size_t start, size_t end) {
-        const float intScale = (input->peak < 1.0) ? 32767.0f : (32767.0f / input->peak);     // prevent clipping
-        if (input->channels == 1) {
-            for (size_t i = start; i < end; i++) { word(int(input->data[i] * intScale), 2); currentFileSize_ += 2; }
-        } else if (input->channels == 2) {
-            for (size_t i = start, iMax = end / 2; i < iMax; i++) {
-                word(int(input->data[i * 2] * intScale), 2); word(int(input->data[i * 2 + 1] * intScale), 2);
-                currentFileSize_ += 4;
-            }
-        }
-    }
+    static void le(unsigned char *p, uint32_t v, int bytes) { for (int i = 0; i < bytes; ++i) p[i] = (unsigned char)(v >> (8 * i)); }
+    void put32(long at, uint32_t v) { unsigned char b[4]; le(b, v, 4); std::fseek(f_, at, SEEK_SET); (void)std::fwrite(b, 1, 4, f_); }
     std::string base_;
-    long long maxFileSize_, currentFileSize_ = 0;
+    long long limit_, size_ = 0;
     int seq_ = 0;
-    size_t dataChunkPos_ = 0;
-    std::ofstream out_;
+    std::FILE *f_ = nullptr;
+    std::vector<int16_t> conv_;
 };
+typedef WavWriter AudioSinkWAV;

@@ -10,12 +10,25 @@
 
 struct liquid_float_complex_t { float real, imag; };     // layout of liquid_float_complex (liquid.h:149-157)
 
-class SDRThreadIQData {
+// Where a block's samples ALSO live in HBM once the ingest has moved them there (null: host copy only).  Consumers that run on the
+// device read this address instead of uploading `data` again (the reference hands ONE buffer to all consumers, SDRPostThread.cpp:227-245).
+// `hold` keeps the HBM slot from being overwritten while any block that points into it is alive -- the ReBuffer rule (use_count() == 1
+// means free, IOThread.h:62-110) applied to device slots.
+struct DeviceResidentIQ {
+    const float *deviceData = nullptr;
+    size_t deviceSamples = 0;
+    std::shared_ptr<void> deviceHold;
+    void shareDeviceCopy(const DeviceResidentIQ &o) { deviceData = o.deviceData; deviceSamples = o.deviceSamples; deviceHold = o.deviceHold; }
+    void dropDeviceCopy() { deviceData = nullptr; deviceSamples = 0; deviceHold.reset(); }
+};
+
+class SDRThreadIQData : public DeviceResidentIQ {
 public:
     long long frequency = 0;
     long long sampleRate = 0;
     bool dcCorrected = true;
     int numChannels = 0;
+    bool iqSwapPending = false;               // internal to the block assembler: `data` still holds Q, I (exchanged during the transfer)
     std::vector<liquid_float_complex_t> data;
     virtual ~SDRThreadIQData() = default;
 };
@@ -23,7 +36,7 @@ typedef std::shared_ptr<SDRThreadIQData> SDRThreadIQDataPtr;
 typedef ThreadBlockingQueue<SDRThreadIQDataPtr> SDRThreadIQDataQueue;
 typedef std::shared_ptr<SDRThreadIQDataQueue> SDRThreadIQDataQueuePtr;
 
-class DemodulatorThreadIQData {
+class DemodulatorThreadIQData : public DeviceResidentIQ {
 public:
     long long frequency = 0;
     long long sampleRate = 0;

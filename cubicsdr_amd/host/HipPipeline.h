@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/csdr_hip.h"
+#include "Adapters.h"
 #include "DataTypes.h"
 #include "DemodLevel.h"
 #include "IOThread.h"
@@ -119,6 +120,10 @@ public:
     DemodulatorThreadInputQueuePtr getIQInputDataPipe() { return pipeIQInputData_; }
     // the audio-scope queue (DemodulatorInstance.cpp:103-105 -> DemodulatorThread::setOutputQueue("AudioVisualOutput"))
     void setVisualOutputQueue(const DemodulatorThreadOutputQueuePtr &q) { std::lock_guard<std::mutex> g(mu_); audioVisQueue_ = q; }
+    // the sound output of this demodulator (the reference owns an AudioThread bound to the device controller, DemodulatorInstance.cpp:60-66):
+    // with a source set AND SDRPostThread::setAudioMixer, the block's audio goes from the bank to the mixer's ring inside HBM
+    void setAudioMixSource(const std::shared_ptr<AudioMixSource> &s) { std::lock_guard<std::mutex> g(mu_); mixSource_ = s; }
+    std::shared_ptr<AudioMixSource> getAudioMixSource() { std::lock_guard<std::mutex> g(mu_); return mixSource_; }
     // modem settings (DemodulatorInstance.cpp:451-498)
     ModemArgInfoList getModemArgs() { std::lock_guard<std::mutex> g(mu_); return modem_ ? modem_->getSettings() : ModemArgInfoList(); }
     std::string readModemSetting(const std::string &setting) { std::lock_guard<std::mutex> g(mu_); return modem_ ? modem_->readSetting(setting) : ""; }
@@ -153,6 +158,7 @@ private:
     AudioThreadInputQueuePtr audioQueue_;
     DemodulatorThreadInputQueuePtr pipeIQInputData_;
     DemodulatorThreadOutputQueuePtr audioVisQueue_;
+    std::shared_ptr<AudioMixSource> mixSource_;
     ReBuffer<AudioThreadInput> outputBuffers_{"DemodulatorThreadBuffers"};
 };
 typedef std::shared_ptr<DemodulatorInstance> DemodulatorInstancePtr;
@@ -229,6 +235,8 @@ public:
     // which rebuilds the channelizer (chanMode != lastChanMode, :418 / :474)
     enum SDRPostThreadChannelizerType { SDRPostPFBCH = 1, SDRPostPFBCH2 = 2 };
     void setChannelizerType(SDRPostThreadChannelizerType t) { chanMode.store((int)t); }
+    // sound output on the device: demodulators that carry an AudioMixSource hand their audio to this mixer without a host round trip
+    void setAudioMixer(AudioMixer *m) { mixer_.store(m); }
     SDRPostThreadChannelizerType getChannelizerType() { return (SDRPostThreadChannelizerType)chanMode.load(); }
 
 private:
@@ -269,6 +277,7 @@ private:
             // full-rate copy to the visual queues first (getFullSampleRateIqData + pushVisualData, :221-245): never blocks
             DemodulatorThreadIQDataPtr vis = visualBuffers_.getBuffer();
             vis->frequency = in.frequency; vis->sampleRate = in.sampleRate; vis->data = in.data;
+            vis->shareDeviceCopy(in);                                               // the spectrum reads the block where the ingest put it
             iqOut->try_push(vis);
             if (iqVisual) iqVisual->try_push(vis);
         }
@@ -305,7 +314,9 @@ private:
         auto iqActive = std::static_pointer_cast<DemodulatorThreadInputQueue>(getOutputQueue("IQActiveDemodVisualDataOutput"));
         if (M == 1) {
             if (iqActive && singleOut_) iqActive->try_push(singleOut_);              // :289-292
-        } else CSDR_STAGE_TRY(csdr_post_execute(post_, (const float *)in.data.data(), 0, 1, n, in.frequency), "csdr_post_execute");
+        } else if (in.deviceData && in.deviceSamples >= (size_t)n)                  // already in HBM (DeviceIngest): no second transfer
+            CSDR_STAGE_TRY(csdr_post_execute(post_, in.deviceData, 1, 1, n, in.frequency), "csdr_post_execute");
+        else CSDR_STAGE_TRY(csdr_post_execute(post_, (const float *)in.data.data(), 0, 1, n, in.frequency), "csdr_post_execute");
         CSDR_STAGE_TRY(csdr_bank_execute(bank_, post_), "csdr_bank_execute");
         // the active demodulator's channel also feeds the demodulator spectrum (:334, :383-387)
         DemodulatorInstancePtr cur = mgr_->getCurrentModem();
@@ -323,7 +334,9 @@ private:
                 iqActive->try_push(tap);                                              // never blocks (:386)
             }
         }
+        mixSlots_.clear(); mixSources_.clear();
         for (auto &d : run) finishDemod(*d);
+        if (!mixSlots_.empty()) { AudioMixer *mx = mixer_.load(); if (mx) (void)mx->takeBankAudio(bank_, mixSlots_, mixSources_); }
     }
 
     // DemodulatorThread::run after demodulate(): :142-233, :318-328
@@ -336,10 +349,16 @@ private:
         ati->sampleRate = d.getAudioSampleRate(); ati->inputRate = d.getBandwidth(); ati->channels = (d.getDemodulatorType() == "I/Q" || d.getDemodulatorType() == "FMS") ? 2 : 1; ati->frequency = d.getFrequency();
         int got = 0;
         bool hostModem = false;
+        std::shared_ptr<AudioMixSource> mixSource;
+        DemodulatorThreadOutputQueuePtr vis;
         {
             std::lock_guard<std::mutex> g(d.mu_);
             hostModem = d.modem_ && d.kit_ && d.modem_->csdrModemId() == CSDR_MODEM_HOST;
+            if (mixer_.load() && !hostModem) mixSource = d.mixSource_;
+            vis = d.audioVisQueue_;
         }
+        // with a device mixer the audio stays in HBM; it comes to the host only for the scope tap, when a scope is bound and waiting
+        const bool audioToHost = !mixSource || (vis && vis->empty());
         if (hostModem) {
             // a plug-in modem (Modem.h:127-166): the device ran DemodulatorPreThread's arithmetic; the block's resampled IQ comes back
             // and the plug-in demodulates it here, on the thread that owns the instance, as DemodulatorThread::run does (:119-135).
@@ -366,21 +385,19 @@ private:
             r.audio_peak = 0.f;
             for (float v : ati->data) r.audio_peak = std::max(r.audio_peak, std::fabs(v));
             r.n_audio = (int)ati->data.size();
-        } else {
+        } else if (audioToHost) {
             ati->data.resize(r.n_audio);
             if (r.n_audio) CSDR_STAGE_TRY(csdr_bank_fetch_audio(bank_, d.slot(), ati->data.data(), r.n_audio, &got), "csdr_bank_fetch_audio");
-        }
+        } else ati->data.resize(0);
         const double sampleTime = double(r.n_iq) / double(d.getBandwidth());
         DemodLevelState st;
         st.signalLevel = d.signalLevel_; st.signalFloor = d.signalFloor_; st.signalCeil = d.signalCeil_; st.squelchBreak = d.squelchBreak_;
-        const bool squelched = demodLevelStep(st, !ati->data.empty(), r.level_accum, r.level_count, sampleTime, d.squelchEnabled_, d.squelchLevel_);
+        const bool squelched = demodLevelStep(st, hostModem ? !ati->data.empty() : r.n_audio > 0, r.level_accum, r.level_count, sampleTime, d.squelchEnabled_, d.squelchLevel_);
         d.signalLevel_ = st.signalLevel; d.signalFloor_ = st.signalFloor; d.signalCeil_ = st.signalCeil; d.squelchBreak_ = st.squelchBreak;
         ati->peak = r.audio_peak;
         ati->is_squelch_active = squelched;
         // the audio scope tap (:240-316): only when the scope queue is bound and empty
-        DemodulatorThreadOutputQueuePtr vis;
-        { std::lock_guard<std::mutex> g(d.mu_); vis = d.audioVisQueue_; }
-        if (!squelched && vis && vis->empty()) {
+        if (!squelched && vis && vis->empty() && !ati->data.empty()) {
             AudioThreadInputPtr ati_vis = std::make_shared<AudioThreadInput>();
             ati_vis->sampleRate = d.getBandwidth(); ati_vis->inputRate = d.getBandwidth();       // inp->sampleRate
             size_t num_vis = DEMOD_VIS_SIZE;
@@ -418,7 +435,10 @@ private:
             }
             (void)vis->try_push(ati_vis);                                                         // non-blocking (:314)
         }
-        if (!squelched && !d.muted_) (void)d.audioQueue_->try_push(ati);            // never blocks (:322)
+        if (!squelched && !d.muted_) {
+            if (mixSource) { mixSlots_.push_back(d.slot()); mixSources_.push_back(mixSource); }      // HBM -> the mixer's ring, after the loop
+            else (void)d.audioQueue_->try_push(ati);                                   // never blocks (:322)
+        }
     }
 
     csdr_ctx *ctx_;
@@ -430,6 +450,9 @@ private:
     std::atomic<int> chanMode{(int)SDRPostPFBCH};                                // ctor :23
     ReBuffer<DemodulatorThreadIQData> visualBuffers_{"SDRPostThreadVisualDataBuffers"};
     DemodulatorThreadIQDataPtr singleOut_;                                        // single-channel mode: the DC-corrected block
+    std::atomic<AudioMixer *> mixer_{nullptr};
+    std::vector<int> mixSlots_;
+    std::vector<std::shared_ptr<AudioMixSource>> mixSources_;
     ModemIQData hostIq_;                                                          // a host plug-in modem's input block (modemData, DemodulatorThread.h)
 };
 
@@ -490,7 +513,8 @@ protected:
         // inputs of at least 2*fftSize samples are transformed directly (:401-404); shorter ones go through the
         // fftLastData priming / overlap rule (:406-420)
         const int mode = iq->data.size() >= N ? CSDR_SPEC_FIRST_FRAME : CSDR_SPEC_LINES;
-        CSDR_STAGE_TRY(csdr_spec_process(spec_, (const float *)iq->data.data(), 0, 1, (int)iq->data.size(), mode), "csdr_spec_process");
+        const bool inHbm = iq->deviceData && iq->deviceSamples == iq->data.size();     // the ingest's copy: read it in place
+        CSDR_STAGE_TRY(csdr_spec_process(spec_, inHbm ? iq->deviceData : (const float *)iq->data.data(), inHbm ? 1 : 0, 1, (int)iq->data.size(), mode), "csdr_spec_process");
         if (csdr_spec_frames(spec_) < 1) return;                                     // the input only primed fftLastData
         SpectrumVisualDataPtr out = outputBuffers.getBuffer();
         out->spectrum_points.resize(fftSize * 2);

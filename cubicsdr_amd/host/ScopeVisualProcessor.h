@@ -1,7 +1,8 @@
-// ScopeVisualProcessor.h -- the audio scope / audio spectrum processor (reference src/process/ScopeVisualProcessor.cpp:45-217,
-// ScopeVisualProcessor.h:11-66) over the HIP library: the waveform path is a copy with peak normalisation (host, a few thousand
-// floats per frame), the spectrum path's fft_execute (:163) runs on the GPU (csdr_spec_fft_only on a private csdr_spec of
-// fftSize points); its averaging / log scaling of fftSize / 2 bins follows in double on the host exactly as the reference's.
+// ScopeVisualProcessor.h -- the audio scope / audio spectrum processor behind the reference's interface (src/process/
+// ScopeVisualProcessor.h:11-66) with ALL of its arithmetic on the device (csdr_scope, cubicsdr_amd/csrc/kernels_io.hpp): one frame
+// goes up, the waveform kernel and the spectrum kernel (transform, double averagers, trackers, log scaling) run, and the finished
+// ScopeRenderData items come back -- no per-sample loop on the host.  Frames that already lie in HBM (the demodulator's tap,
+// csdr_bank_scope_frame) skip the upload: processDeviceFrame().
 #pragma once
 #include <atomic>
 #include <cmath>
@@ -38,125 +39,56 @@ typedef std::shared_ptr<ScopeRenderDataQueue> ScopeRenderDataQueuePtr;
 
 class ScopeVisualProcessor : public VisualProcessor<AudioThreadInput, ScopeRenderData> {
 public:
-    explicit ScopeVisualProcessor(csdr_ctx *ctx) : ctx_(ctx), outputBuffers("ScopeVisualProcessorBuffers") {
-        scopeEnabled.store(true);
-        spectrumEnabled.store(true);
-        if (csdr_spec_create(ctx_, &spec_) != CSDR_OK) throw std::runtime_error(std::string("csdr_spec_create: ") + csdr_last_error());
+    explicit ScopeVisualProcessor(csdr_ctx *ctx) : pool_("ScopeVisualProcessorBuffers") {
+        if (csdr_scope_create(ctx, &scope_) != CSDR_OK) throw std::runtime_error(std::string("csdr_scope_create: ") + csdr_last_error());
     }
-    ~ScopeVisualProcessor() override { if (spec_) csdr_spec_destroy(spec_); }
-    void setup(int fftSize_in) {                                 // :24-35: fft_create_plan(fftSize, FORWARD)
-        fftSize = (unsigned)fftSize_in;
-        desiredInputSize = fftSize_in;
-        fftInData.assign(fftSize, liquid_float_complex_t{0.f, 0.f});
-        fftOutput.assign(fftSize, liquid_float_complex_t{0.f, 0.f});
-        // csdr_spec transforms 2 * fft_size points: a private instance of fftSize / 2 "display points" is an fftSize-point plan
-        if (csdr_spec_setup(spec_, fftSize_in / 2, 1) != CSDR_OK) throw std::runtime_error(std::string("csdr_spec_setup: ") + csdr_last_error());
+    ~ScopeVisualProcessor() override { if (scope_) csdr_scope_destroy(scope_); }
+
+    void setup(int fftSize_in) {                                 // setup :24-35
+        // one frame per call; a frame is at most 2 * DEMOD_VIS_SIZE floats (the stereo tap, DemodulatorThread.cpp:271-275)
+        if (csdr_scope_setup(scope_, fftSize_in, 1, kMaxFrameFloats) != CSDR_OK) throw std::runtime_error(std::string("csdr_scope_setup: ") + csdr_last_error());
+        fftSize_ = fftSize_in;
     }
-    void setScopeEnabled(bool e) { scopeEnabled.store(e); }
-    void setSpectrumEnabled(bool e) { spectrumEnabled.store(e); }
+    void setScopeEnabled(bool on) { scopeOn_.store(on); pushEnables(); }               // :37-43
+    void setSpectrumEnabled(bool on) { spectrumOn_.store(on); pushEnables(); }
+    long long errorCount() const { return errors_.load(); }
+
+    // a frame that is already device memory (csdr_bank_scope_frame): same outputs, nothing uploaded
+    void processDeviceFrame(const csdr_scope_frame &f) { if (f.n > 0 && isOutputEmpty()) runFrame(f, true); }
 
 protected:
     void process() override {                                    // :45-217
-        if (!isOutputEmpty()) return;
-        AudioThreadInputPtr audioInputData;
-        if (!input->try_pop(audioInputData) || !audioInputData) return;
-        size_t i, iMax = audioInputData->data.size();
-        if (!iMax) return;
-        ScopeRenderDataPtr renderData;
-        if (scopeEnabled) {
-            if (iMax > maxScopeSamples) iMax = maxScopeSamples;
-            renderData = outputBuffers.getBuffer();
-            renderData->channels = audioInputData->channels;
-            renderData->inputRate = audioInputData->inputRate;
-            renderData->sampleRate = audioInputData->sampleRate;
-            if (renderData->waveform_points.size() != iMax * 2) renderData->waveform_points.resize(iMax * 2);
-            float peak = 1.0f;
-            for (i = 0; i < iMax; i++) { const float p = std::fabs(audioInputData->data[i]); if (p > peak) peak = p; }
-            if (audioInputData->type == 1) {
-                iMax = audioInputData->data.size();
-                if (renderData->waveform_points.size() != iMax * 2) renderData->waveform_points.resize(iMax * 2);
-                for (i = 0; i < iMax; i++) {
-                    renderData->waveform_points[i * 2] = (float)((((double)(i % (iMax / 2)) / (double)iMax) * 2.0 - 0.5) * 2.0);
-                    renderData->waveform_points[i * 2 + 1] = audioInputData->data[i] / peak;
-                }
-                renderData->mode = ScopePanel::SCOPE_MODE_2Y;
-            } else if (audioInputData->type == 2) {
-                iMax = audioInputData->data.size();
-                if (renderData->waveform_points.size() != iMax) renderData->waveform_points.resize(iMax);
-                for (i = 0; i < iMax / 2; i++) {
-                    renderData->waveform_points[i * 2] = audioInputData->data[i * 2] / peak;
-                    renderData->waveform_points[i * 2 + 1] = audioInputData->data[i * 2 + 1] / peak;
-                }
-                renderData->mode = ScopePanel::SCOPE_MODE_XY;
-            } else {
-                for (i = 0; i < iMax; i++) {
-                    renderData->waveform_points[i * 2] = (float)((((double)i / (double)iMax) - 0.5) * 2.0);
-                    renderData->waveform_points[i * 2 + 1] = audioInputData->data[i] / peak;
-                }
-                renderData->mode = ScopePanel::SCOPE_MODE_Y;
-            }
-            renderData->spectrum = false;
-            distribute(renderData);
-        }
-        if (spectrumEnabled && fftSize) {
-            iMax = audioInputData->data.size();
-            if (audioInputData->channels == 1) {
-                for (i = 0; i < fftSize; i++) { fftInData[i].real = i < iMax ? audioInputData->data[i] : 0.f; fftInData[i].imag = 0.f; }
-            } else if (audioInputData->channels == 2) {
-                iMax = iMax / 2;
-                for (i = 0; i < fftSize; i++) { fftInData[i].real = i < iMax ? audioInputData->data[i] + audioInputData->data[iMax + i] : 0.f; fftInData[i].imag = 0.f; }
-            }
-            renderData = outputBuffers.getBuffer();
-            renderData->channels = audioInputData->channels;
-            renderData->inputRate = audioInputData->inputRate;
-            renderData->sampleRate = audioInputData->sampleRate;
-            audioInputData = nullptr;
-            double fft_ceil = 0, fft_floor = 1;
-            if (fft_result.size() < fftSize / 2) { fft_result.resize(fftSize / 2); fft_result_ma.resize(fftSize / 2); fft_result_maa.resize(fftSize / 2); }
-            // fft_execute(fftPlan) (:163) on the device
-            if (csdr_spec_fft_only(spec_, (const float *)fftInData.data(), (float *)fftOutput.data()) != CSDR_OK)
-                throw std::runtime_error(std::string("csdr_spec_fft_only: ") + csdr_last_error());
-            for (i = 0; i < fftSize / 2; i++) {
-                const double a = (double)fftOutput[i].real, b = (double)fftOutput[i].imag;
-                fft_result[i] = std::sqrt(a * a + b * b);
-            }
-            for (i = 0; i < fftSize / 2; i++) {
-                fft_result_ma[i] += (fft_result[i] - fft_result_ma[i]) * fft_average_rate;
-                fft_result_maa[i] += (fft_result_ma[i] - fft_result_maa[i]) * fft_average_rate;
-                if (fft_result_maa[i] > fft_ceil) fft_ceil = fft_result_maa[i];
-                if (fft_result_maa[i] < fft_floor) fft_floor = fft_result_maa[i];
-            }
-            fft_ceil_ma = fft_ceil_ma + (fft_ceil - fft_ceil_ma) * 0.05;
-            fft_ceil_maa = fft_ceil_maa + (fft_ceil_ma - fft_ceil_maa) * 0.05;
-            fft_floor_ma = fft_floor_ma + (fft_floor - fft_floor_ma) * 0.05;
-            fft_floor_maa = fft_floor_maa + (fft_floor_ma - fft_floor_maa) * 0.05;
-            unsigned int outSize = fftSize / 2;
-            if (renderData->sampleRate != renderData->inputRate)
-                outSize = (unsigned)(int)std::floor((float)outSize * ((float)renderData->sampleRate / (float)renderData->inputRate));
-            if (outSize > fftSize / 2) outSize = fftSize / 2;     // (the reference would read past fft_result_maa when sampleRate > inputRate)
-            if (renderData->waveform_points.size() != outSize * 2) renderData->waveform_points.resize(outSize * 2);
-            for (i = 0; i < outSize; i++) {
-                const float v = (float)(std::log10(fft_result_maa[i] + 0.25 - (fft_floor_maa - 0.75)) / std::log10((fft_ceil_maa + 0.25) - (fft_floor_maa - 0.75)));
-                renderData->waveform_points[i * 2] = (float)((double)i / (double)outSize);
-                renderData->waveform_points[i * 2 + 1] = v;
-            }
-            renderData->fft_floor = fft_floor_maa;
-            renderData->fft_ceil = fft_ceil_maa;
-            renderData->fft_size = (int)(fftSize / 2);
-            renderData->spectrum = true;
-            distribute(renderData);
-        }
+        if (!isOutputEmpty()) return;                            // the previous items have not been drawn yet
+        AudioThreadInputPtr in;
+        if (!input || !input->try_pop(in) || !in || in->data.empty()) return;
+        csdr_scope_frame f{};
+        f.data = in->data.data(); f.n = (int)std::min<size_t>(in->data.size(), (size_t)kMaxFrameFloats);
+        f.channels = in->channels; f.type = in->type; f.sample_rate = in->sampleRate; f.input_rate = in->inputRate; f.scale = 1.0f;
+        runFrame(f, false);
     }
 
-    csdr_ctx *ctx_;
-    csdr_spec *spec_ = nullptr;
-    ReBuffer<ScopeRenderData> outputBuffers;
-    std::atomic_bool scopeEnabled, spectrumEnabled;
-    std::vector<liquid_float_complex_t> fftInData, fftOutput;
-    unsigned int fftSize = 0;
-    int desiredInputSize = 0;
-    unsigned int maxScopeSamples = DEFAULT_DMOD_FFT_SIZE;
-    double fft_ceil_ma = 0, fft_ceil_maa = 0, fft_floor_ma = 0, fft_floor_maa = 0;
-    double fft_average_rate = 0.65f;
-    std::vector<double> fft_result, fft_result_ma, fft_result_maa;
+private:
+    static constexpr int kMaxFrameFloats = 4096;
+    void pushEnables() { (void)csdr_scope_set_enabled(scope_, scopeOn_.load() ? 1 : 0, spectrumOn_.load() ? 1 : 0); }
+    void runFrame(const csdr_scope_frame &f, bool onDevice) {
+        if (!fftSize_ || (f.channels != 1 && f.channels != 2)) return;
+        if (csdr_scope_process(scope_, &f, 1, onDevice ? 1 : 0) != CSDR_OK) { errors_.fetch_add(1); return; }
+        for (int which = 0; which < 2; ++which) {                // the waveform item first, then the spectrum item (:118, :214)
+            ScopeRenderDataPtr item = pool_.getBuffer();
+            item->waveform_points.resize((size_t)std::max(2 * kMaxFrameFloats, fftSize_));
+            csdr_scope_info info{};
+            if (csdr_scope_fetch(scope_, 0, which, item->waveform_points.data(), (int)item->waveform_points.size(), &info) != CSDR_OK) { errors_.fetch_add(1); return; }
+            if (info.n_floats == 0) continue;                    // that half is switched off
+            item->waveform_points.resize((size_t)info.n_floats);
+            item->mode = (ScopePanel::ScopeMode)info.mode; item->spectrum = info.spectrum != 0;
+            item->channels = info.channels; item->inputRate = info.input_rate; item->sampleRate = info.sample_rate;
+            item->fft_size = info.fft_size; item->fft_floor = info.fft_floor; item->fft_ceil = info.fft_ceil;
+            distribute(item);
+        }
+    }
+    csdr_scope *scope_ = nullptr;
+    int fftSize_ = 0;
+    std::atomic_bool scopeOn_{true}, spectrumOn_{true};
+    std::atomic<long long> errors_{0};
+    ReBuffer<ScopeRenderData> pool_;
 };

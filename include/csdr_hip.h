@@ -331,6 +331,10 @@ int  csdr_ingest_create(csdr_ctx *ctx, int64_t max_samples, int depth, csdr_inge
 void csdr_ingest_destroy(csdr_ingest *ing);
 int  csdr_ingest_acquire(csdr_ingest *ing, float **host_slot);
 int  csdr_ingest_commit(csdr_ingest *ing, int64_t n_samples, int iq_swap, const float **dev_iq);
+/* the same single transfer for a block assembled in the caller's own memory (pooled SDRThreadIQData blocks, page-locked once with
+ * csdr_host_register); waits for the previous upload first.  csdr_ingest_next_slot: the ring slot the next transfer will overwrite. */
+int  csdr_ingest_upload(csdr_ingest *ing, const float *host_iq, int64_t n_samples, int iq_swap, const float **dev_iq);
+int  csdr_ingest_next_slot(const csdr_ingest *ing);
 
 #ifdef __cplusplus
 }

@@ -141,3 +141,126 @@ class RefSpectrumCpp:
         if self.h:
             self.L.refspec_destroy(self.h)
             self.h = None
+
+
+# ---- the reference's own ScopeVisualProcessor (oracle/_ref/libref_scope.so, oracle/ref/scope_harness.cpp) -----------------------
+_SCLIB = None
+
+
+def scope_available():
+    return A.available("ref") and os.path.exists(os.path.join(_HERE, "_ref", "libref_scope.so"))
+
+
+def load_scope():
+    global _SCLIB
+    if _SCLIB is None:
+        A.load("ref")
+        L = C.CDLL(os.path.join(_HERE, "_ref", "libref_scope.so"))
+        L.refscope_create.restype = C.c_void_p; L.refscope_create.argtypes = [C.c_int]
+        L.refscope_enable.restype = None; L.refscope_enable.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.refscope_push.restype = C.c_int; L.refscope_push.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.refscope_get.restype = C.c_int; L.refscope_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.refscope_destroy.restype = None; L.refscope_destroy.argtypes = [C.c_void_p]
+        _SCLIB = L
+    return _SCLIB
+
+
+class RefScopeCpp:
+    """ScopeVisualProcessor of the reference: one AudioThreadInput per push -> the ScopeRenderData items it distributed"""
+
+    def __init__(self, fft_size=1024):
+        self.L = load_scope()
+        self.h = self.L.refscope_create(int(fft_size))
+
+    def enable(self, scope=True, spectrum=True):
+        self.L.refscope_enable(self.h, int(scope), int(spectrum))
+
+    def push(self, data, channels, input_rate, sample_rate, typ):
+        """-> list of dicts {points, mode, spectrum, channels, input_rate, sample_rate, fft_size, fft_floor, fft_ceil}"""
+        a = np.ascontiguousarray(data, dtype=np.float32)
+        n = self.L.refscope_push(self.h, a.ctypes.data_as(C.c_void_p), a.size, int(channels), int(input_rate), int(sample_rate), int(typ))
+        out = []
+        for i in range(n):
+            pts = np.empty(1 << 16, np.float32); meta = np.zeros(6, np.int32); fc = np.zeros(2, np.float64)
+            m = self.L.refscope_get(self.h, i, pts.ctypes.data_as(C.c_void_p), pts.size, meta.ctypes.data_as(C.c_void_p), fc.ctypes.data_as(C.c_void_p))
+            assert m >= 0
+            out.append(dict(points=pts[:m].copy(), mode=int(meta[0]), spectrum=bool(meta[1]), channels=int(meta[2]), input_rate=int(meta[3]),
+                            sample_rate=int(meta[4]), fft_size=int(meta[5]), fft_floor=float(fc[0]), fft_ceil=float(fc[1])))
+        return out
+
+    def close(self):
+        if self.h:
+            self.L.refscope_destroy(self.h)
+            self.h = None
+
+
+# ---- the reference's own audioCallback and AudioFileWAV (oracle/_ref/libref_audio.so, oracle/ref/audio_harness.cpp) --------------
+_AULIB = None
+
+
+def audio_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libref_audio.so"))
+
+
+def load_audio():
+    global _AULIB
+    if _AULIB is None:
+        L = C.CDLL(os.path.join(_HERE, "_ref", "libref_audio.so"))
+        L.refaudio_create.restype = C.c_void_p; L.refaudio_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.refaudio_set_source.restype = None; L.refaudio_set_source.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float]
+        L.refaudio_push.restype = C.c_int; L.refaudio_push.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float]
+        L.refaudio_queued.restype = C.c_int; L.refaudio_queued.argtypes = [C.c_void_p, C.c_int]
+        L.refaudio_callback.restype = C.c_int; L.refaudio_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.refaudio_destroy.restype = None; L.refaudio_destroy.argtypes = [C.c_void_p]
+        L.refwav_create.restype = C.c_void_p; L.refwav_create.argtypes = [C.c_char_p, C.c_char_p]
+        L.refwav_write.restype = C.c_int; L.refwav_write.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float]
+        L.refwav_close.restype = None; L.refwav_close.argtypes = [C.c_void_p]
+        L.refwav_destroy.restype = None; L.refwav_destroy.argtypes = [C.c_void_p]
+        _AULIB = L
+    return _AULIB
+
+
+class RefAudioMixCpp:
+    """a controller AudioThread with n bound source threads, driven through the reference's audioCallback"""
+
+    def __init__(self, sample_rate, n_sources, queue_blocks=0):
+        self.L = load_audio()
+        self.h = self.L.refaudio_create(int(sample_rate), int(n_sources), int(queue_blocks))
+
+    def set_source(self, i, active=True, gain=1.0):
+        self.L.refaudio_set_source(self.h, int(i), int(active), float(gain))
+
+    def push(self, i, data, channels, sample_rate, peak):
+        a = np.ascontiguousarray(data, dtype=np.float32)
+        return bool(self.L.refaudio_push(self.h, int(i), a.ctypes.data_as(C.c_void_p), a.size, int(channels), int(sample_rate), float(peak)))
+
+    def queued(self, i):
+        return self.L.refaudio_queued(self.h, int(i))
+
+    def callback(self, frames):
+        out = np.empty(2 * frames, np.float32)
+        self.L.refaudio_callback(self.h, out.ctypes.data_as(C.c_void_p), int(frames))
+        return out
+
+    def close(self):
+        if self.h:
+            self.L.refaudio_destroy(self.h)
+            self.h = None
+
+
+class RefWavCpp:
+    """AudioFileWAV of the reference writing under `directory` (its getOutputFileName appends -N when the name exists)"""
+
+    def __init__(self, directory, base):
+        self.L = load_audio()
+        self.h = self.L.refwav_create(directory.encode(), base.encode())
+
+    def write(self, data, channels, sample_rate, peak):
+        a = np.ascontiguousarray(data, dtype=np.float32)
+        return bool(self.L.refwav_write(self.h, a.ctypes.data_as(C.c_void_p), a.size, int(channels), int(sample_rate), float(peak)))
+
+    def close(self):
+        if self.h:
+            self.L.refwav_close(self.h)
+            self.L.refwav_destroy(self.h)
+            self.h = None

@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
+#include <iterator>
 #include <thread>
 
 #include "../../cubicsdr_amd/host/HipPipeline.h"
@@ -321,58 +323,107 @@ static void test_block_assembler() {
     CHECK(code < 0 && q->try_pop(blk) && blk->data.size() < 40000 && !blk->data.empty());
 }
 
-// the RtAudio callback's mixing (AudioThread.cpp:88-240) and the WAV writer (AudioFileWAV.cpp:63-170)
-static void test_audio_egress() {
-    AudioMixer mix(48000);
-    auto s1 = std::make_shared<AudioMixSource>(), s2 = std::make_shared<AudioMixSource>();
-    s1->inputQueue = std::make_shared<AudioThreadInputQueue>(); s2->inputQueue = std::make_shared<AudioThreadInputQueue>();
-    s1->inputQueue->set_max_num_items(8); s2->inputQueue->set_max_num_items(8);
-    s2->gain = 0.5f;
-    mix.bindThread(s1); mix.bindThread(s2);
+// the WAV writer (AudioFileWAV.cpp:63-170) with host floats: header fields, 16-bit payload with the anti-clipping scale, sizes patched on
+// close, roll-over at the size limit.  (Device-made PCM through the same writer: test_audio_egress_device; byte-for-byte against the
+// reference's own AudioFileWAV: tests/test_gpu_io.py.)
+static void test_wav_writer() {
     auto mk = [](int ch, int rate, int n, float v, float peak) { auto a = std::make_shared<AudioThreadInput>(); a->channels = ch; a->sampleRate = rate; a->data.assign((size_t)n, v); a->peak = peak; return a; };
-    for (int k = 0; k < 3; ++k) s1->inputQueue->push(mk(1, 48000, 100, 0.25f, 0.25f));        // mono
-    for (int k = 0; k < 3; ++k) s2->inputQueue->push(mk(2, 48000, 200, 0.5f, 0.5f));          // stereo, gain 0.5
+    const std::string base = "/tmp/csdr_test_wav";
+    WavWriter w(base, 44 + 300);           // tiny limit; the reference counts the file size from the data chunk header (36): 154 samples fit
+    auto a = mk(1, 48000, 200, 0.5f, 0.5f);
+    CHECK(w.writeToFile(a));
+    w.closeFile();
+    std::ifstream f0(base + ".wav", std::ios::binary), f1(base + "_001.wav", std::ios::binary);
+    std::vector<unsigned char> b0((std::istreambuf_iterator<char>(f0)), std::istreambuf_iterator<char>()), b1((std::istreambuf_iterator<char>(f1)), std::istreambuf_iterator<char>());
+    auto u32 = [](const std::vector<unsigned char> &b, size_t o) { return (unsigned)b[o] | ((unsigned)b[o + 1] << 8) | ((unsigned)b[o + 2] << 16) | ((unsigned)b[o + 3] << 24); };
+    CHECK(b0.size() == 44 + 308 && b1.size() == 44 + 92);
+    CHECK(std::memcmp(b0.data(), "RIFF", 4) == 0 && std::memcmp(b0.data() + 8, "WAVEfmt ", 8) == 0 && std::memcmp(b0.data() + 36, "data", 4) == 0);
+    CHECK(u32(b0, 4) == b0.size() - 8 && u32(b0, 40) == 308 && u32(b0, 24) == 48000 && b0[22] == 1 && b0[34] == 16);
+    const short v = (short)(b0[44] | (b0[45] << 8));
+    CHECK(v == (short)int(0.5f * 32767.0f));
+    // a loud block: scaled by 32767 / peak
+    WavWriter w2(base + "2");
+    auto loud = mk(2, 44100, 64, 2.0f, 4.0f);
+    CHECK(w2.writeToFile(loud));
+    w2.closeFile();
+    std::ifstream f2(base + "2.wav", std::ios::binary);
+    std::vector<unsigned char> b2((std::istreambuf_iterator<char>(f2)), std::istreambuf_iterator<char>());
+    CHECK(b2.size() == 44 + 128 && b2[22] == 2 && u32(b2, 24) == 44100 && u32(b2, 28) == 44100 * 4 && b2[32] == 4);
+    CHECK((short)(b2[44] | (b2[45] << 8)) == (short)int(2.0f * (32767.0f / 4.0f)));
+    std::remove((base + ".wav").c_str()); std::remove((base + "_001.wav").c_str()); std::remove((base + "2.wav").c_str());
+}
+
+// AudioMixer over csdr_mix: the queue rules of the sound callback (AudioThread.cpp:88-240) seen through the host class; bit-for-bit
+// parity with the reference's own callback is tests/test_gpu_io.py::test_mixer_is_the_reference_callback_bit_for_bit
+static void test_audio_egress_device(csdr_ctx *ctx) {
+    auto mk = [](int ch, int rate, int n, float v, float peak) { auto a = std::make_shared<AudioThreadInput>(); a->channels = ch; a->sampleRate = rate; a->data.assign((size_t)n, v); a->peak = peak; return a; };
+    AudioMixer mix(ctx, 48000, 8, 8);
+    auto s1 = mix.bindThread(), s2 = mix.bindThread();
+    CHECK(s1 && s2 && s1->index() == 0 && s2->index() == 1);
+    s2->setGain(0.5f);
+    for (int k = 0; k < 3; ++k) CHECK(s1->try_push(mk(1, 48000, 100, 0.25f, 0.25f)));        // mono
+    for (int k = 0; k < 3; ++k) CHECK(s2->try_push(mk(2, 48000, 200, 0.5f, 0.5f)));          // stereo, gain 0.5
+    CHECK(s1->queued() == 3);
     std::vector<float> out(2 * 64);
-    mix.callback(out.data(), 64);                 // the first call only latches each source's first block (:131-139)
-    CHECK(out[0] == 0.f && out[127] == 0.f);
+    mix.callback(out.data(), 64);                 // the first call only latches each source's first block (:121-129)
+    CHECK(out[0] == 0.f && out[127] == 0.f && s1->queued() == 2);
     mix.callback(out.data(), 64);
     CHECK(std::fabs(out[0] - 0.5f) < 1e-6f && std::fabs(out[127] - 0.5f) < 1e-6f);             // 0.25 + 0.5 * 0.5 on both channels
     mix.callback(out.data(), 64);                 // crosses the first mono block (100 samples) into the second one
     CHECK(std::fabs(out[2 * 40] - 0.5f) < 1e-6f);
+    // the last buffer as PCM made on the device, written by the WAV writer
+    std::vector<int16_t> pcm;
+    CHECK(mix.lastBufferPcm16(pcm, 0.5f) && pcm.size() == 128 && pcm[0] == (int16_t)int(out[0] * 32767.0f));
+    WavWriter w("/tmp/csdr_test_mix");
+    CHECK(w.writePcm16(pcm.data(), pcm.size(), 2, 48000));
+    w.closeFile();
+    std::ifstream fm("/tmp/csdr_test_mix.wav", std::ios::binary);
+    std::vector<unsigned char> bm((std::istreambuf_iterator<char>(fm)), std::istreambuf_iterator<char>());
+    CHECK(bm.size() == 44 + 256 && (short)(bm[44] | (bm[45] << 8)) == pcm[0]);
+    std::remove("/tmp/csdr_test_mix.wav");
     // a loud source: the sum of the peaks exceeds 1 -> the buffer is scaled by 1 / peak
-    auto s3 = std::make_shared<AudioMixSource>();
-    s3->inputQueue = std::make_shared<AudioThreadInputQueue>(); s3->inputQueue->set_max_num_items(8);
-    for (int k = 0; k < 4; ++k) s3->inputQueue->push(mk(1, 48000, 64, 2.0f, 2.0f));
-    AudioMixer loud(48000);
-    loud.bindThread(s3);
+    AudioMixer loud(ctx, 48000, 2, 8);
+    auto s3 = loud.bindThread();
+    for (int k = 0; k < 4; ++k) CHECK(s3->try_push(mk(1, 48000, 64, 2.0f, 2.0f)));
     loud.callback(out.data(), 64); loud.callback(out.data(), 64);
     CHECK(std::fabs(out[10] - 1.0f) < 1e-6f);
-    // blocks at another sample rate are skipped (:141-158)
-    auto s4 = std::make_shared<AudioMixSource>();
-    s4->inputQueue = std::make_shared<AudioThreadInputQueue>(); s4->inputQueue->set_max_num_items(8);
-    s4->inputQueue->push(mk(1, 44100, 64, 0.3f, 0.3f)); s4->inputQueue->push(mk(1, 44100, 64, 0.3f, 0.3f)); s4->inputQueue->push(mk(1, 48000, 64, 0.1f, 0.1f)); s4->inputQueue->push(mk(1, 48000, 64, 0.1f, 0.1f));
-    AudioMixer m4(48000);
-    m4.bindThread(s4);
+    // a bounded queue refuses the block that does not fit (try_push, DemodulatorThread.cpp:322)
+    AudioMixer small(ctx, 48000, 1, 2);
+    auto s4 = small.bindThread();
+    CHECK(s4->try_push(mk(1, 48000, 64, 0.1f, 0.1f)) && s4->try_push(mk(1, 48000, 64, 0.1f, 0.1f)) && !s4->try_push(mk(1, 48000, 64, 0.1f, 0.1f)));
+    // blocks at another sample rate are skipped (:131-149)
+    AudioMixer m4(ctx, 48000, 1, 8);
+    auto s5 = m4.bindThread();
+    s5->try_push(mk(1, 44100, 64, 0.3f, 0.3f)); s5->try_push(mk(1, 44100, 64, 0.3f, 0.3f)); s5->try_push(mk(1, 48000, 64, 0.1f, 0.1f)); s5->try_push(mk(1, 48000, 64, 0.1f, 0.1f));
     m4.callback(out.data(), 32); m4.callback(out.data(), 32);
     CHECK(std::fabs(out[0] - 0.1f) < 1e-6f);
-    // WAV: header fields, 16-bit payload with the anti-clipping scale, sizes patched on close, roll-over at the size limit
-    {
-        const std::string base = "/tmp/csdr_test_wav";
-        AudioSinkWAV w(base, 44 + 300);           // tiny limit; the reference counts the file size from the data chunk header (36): 154 samples fit
-        auto a = mk(1, 48000, 200, 0.5f, 0.5f);
-        w.writeToFile(a);
-        w.closeFile();
-        std::ifstream f0(base + ".wav", std::ios::binary), f1(base + "_001.wav", std::ios::binary);
-        std::vector<unsigned char> b0((std::istreambuf_iterator<char>(f0)), std::istreambuf_iterator<char>()), b1((std::istreambuf_iterator<char>(f1)), std::istreambuf_iterator<char>());
-        auto u32 = [](const std::vector<unsigned char> &b, size_t o) { return (unsigned)b[o] | ((unsigned)b[o + 1] << 8) | ((unsigned)b[o + 2] << 16) | ((unsigned)b[o + 3] << 24); };
-        CHECK(b0.size() == 44 + 308 && b1.size() == 44 + 92);
-        CHECK(std::memcmp(b0.data(), "RIFF", 4) == 0 && std::memcmp(b0.data() + 8, "WAVEfmt ", 8) == 0 && std::memcmp(b0.data() + 36, "data", 4) == 0);
-        CHECK(u32(b0, 4) == b0.size() - 8 && u32(b0, 40) == 308 && u32(b0, 24) == 48000 && b0[22] == 1 && b0[34] == 16);
-        const short v = (short)(b0[44] | (b0[45] << 8));
-        CHECK(v == (short)int(0.5f * 32767.0f));
-        std::remove((base + ".wav").c_str()); std::remove((base + "_001.wav").c_str());
-    }
+    m4.removeThread(s5);
+    CHECK(!s5->try_push(mk(1, 48000, 64, 0.1f, 0.1f)));
 }
+
+// a modem that is NOT one of the nine built-in descriptors: an integrator's plug-in registered through Modem::addModemFactory.  Its
+// demodulate() is host code (here: envelope detection at the modem rate, audio = |x|); the pipeline runs the front end on the device
+// (CSDR_MODEM_HOST), fetches the block's resampled IQ and calls it -- DemodulatorThread.cpp:119-135.
+struct EnvelopeModem : Modem {
+    static ModemBase *factory() { return new EnvelopeModem(); }
+    static std::atomic<int> kits, calls;
+    std::string getType() override { return "analog"; }
+    std::string getName() override { return "ENV"; }
+    int checkSampleRate(long long rate, int) override { return rate < 2000 ? 2000 : (int)rate; }
+    int getDefaultSampleRate() override { return 8000; }
+    ModemKit *buildKit(long long sampleRate, int audioSampleRate) override { kits++; return Modem::buildKit(sampleRate, audioSampleRate); }
+    void demodulate(ModemKit *kit, ModemIQData *input, AudioThreadInput *audioOut) override {
+        calls++;
+        lastRate = kit->sampleRate;
+        audioOut->channels = 1; audioOut->sampleRate = (int)kit->sampleRate;
+        audioOut->data.resize(input->data.size());
+        for (size_t i = 0; i < input->data.size(); ++i) audioOut->data[i] = std::sqrt(input->data[i].real * input->data[i].real + input->data[i].imag * input->data[i].imag);
+        lastInput = input->data;
+    }
+    long long lastRate = 0;
+    std::vector<liquid_float_complex_t> lastInput;
+};
+std::atomic<int> EnvelopeModem::kits{0}, EnvelopeModem::calls{0};
 
 // FFTDataDistributor scenarios (no GPU): the sample values carry their stream position so that the emitted lines can be
 // identified; output is compared with oracle/fft_distributor.py by tests/test_host_mirror.py.
@@ -441,10 +492,83 @@ static int run_level() {
     return 0;
 }
 
+// plug-in modem + the one-transfer ingest, end to end: StreamReblocker blocks (I/Q exchanged by the "device") -> DeviceIngest ->
+// SDRPostThread reads the HBM copy -> front end on the device -> EnvelopeModem::demodulate on the host -> audio queue
+struct ToneSource : IQStreamSource {
+    long long pos = 0; double fs, f0; bool qi;
+    ToneSource(double fs_, double f0_, bool qi_) : fs(fs_), f0(f0_), qi(qi_) {}
+    int readStream(float *buff, int maxElems) override {
+        for (int i = 0; i < maxElems; ++i) {
+            const double ph = 2 * M_PI * f0 * double(pos + i) / fs;
+            const float re = (float)(0.4 * std::cos(ph)), im = (float)(0.4 * std::sin(ph));
+            buff[2 * i] = qi ? im : re; buff[2 * i + 1] = qi ? re : im;       // a device that delivers Q, I
+        }
+        pos += maxElems;
+        return maxElems;
+    }
+};
+static void test_plugin_modem_and_device_ingest(csdr_ctx *ctx) {
+    Modem::addModemFactory(EnvelopeModem::factory, "ENV", 8000);
+    CHECK(Modem::getFactories().size() == 10 && Modem::getModemDefaultSampleRate("ENV") == 8000);
+    const long long fs = 2400000, center = 100000000;
+    DemodulatorMgr mgr(4);
+    SDRPostThread post(ctx, &mgr);
+    auto in = std::make_shared<SDRThreadIQDataQueue>();
+    in->set_max_num_items(4);
+    post.setInputQueue("IQDataInput", in);
+    auto d = mgr.newThread();
+    d->setDemodulatorType("ENV");
+    CHECK(d->getDemodulatorType() == "ENV" && d->getBandwidth() == 8000);
+    d->setFrequency(center + 200000);
+    StreamReblocker rb(ctx);
+    rb.setSampleRate(fs); rb.setFrequency(center); rb.setMTU(16384); rb.setIQSwap(true);
+    DeviceIngest ingest(ctx, rb.getNumElems() + 16384, 4);
+    rb.bindIngest(&ingest);
+    ToneSource dev((double)fs, 200000.0 + 500.0, true);                       // 500 Hz off the demodulator's centre
+    std::atomic_bool stopping{false};
+    std::thread tp(&IOThread::threadMain, &post);
+    int inHbm = 0;
+    for (int b = 0; b < 8; ++b) {
+        CHECK(rb.readStream(dev, in, stopping) > 0);
+        while (post.blocksProcessed.load() <= b) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    // the blocks really went through the device copy: the pooled block objects still carry their HBM address
+    {
+        auto probe = std::make_shared<SDRThreadIQDataQueue>();
+        probe->set_max_num_items(2);
+        CHECK(rb.readStream(dev, probe, stopping) > 0);
+        SDRThreadIQDataPtr blk;
+        CHECK(probe->try_pop(blk) && blk->data.size() == 40000);
+        if (blk->deviceData && blk->deviceSamples == 40000) ++inHbm;
+        // host readers see I, Q: the carrier rotates counter-clockwise at +200.5 kHz (positive frequency)
+        const double cr = (double)blk->data[10].real * blk->data[11].imag - (double)blk->data[10].imag * blk->data[11].real;
+        CHECK(cr > 0);
+    }
+    CHECK(inHbm == 1);
+    CHECK(post.errlog.errorCount() == 0);
+    auto aq = d->getAudioOutputQueue();
+    AudioThreadInputPtr ati;
+    int nblk = 0; double mean = 0; size_t cnt = 0;
+    while (aq->try_pop(ati)) {
+        ++nblk;
+        CHECK(ati->channels == 1 && !ati->data.empty());
+        if (nblk > 3) for (float v : ati->data) { mean += v; ++cnt; }
+    }
+    std::printf("plug-in modem: kits %d, demodulate calls %d, audio blocks %d, envelope %.4f (carrier 0.4 x the 4-channel analyzer's gain of 4)\n", EnvelopeModem::kits.load(),
+                EnvelopeModem::calls.load(), nblk, cnt ? mean / (double)cnt : 0.0);
+    CHECK(EnvelopeModem::kits.load() >= 1 && EnvelopeModem::calls.load() == 8 && nblk == 8);
+    CHECK(cnt > 0 && std::fabs(mean / (double)cnt - 1.6) < 0.1);                     // a constant-envelope carrier: |x| = amplitude x analyzer gain (M = 4)
+    CHECK(d->getSignalLevel() > -10.0f);                                              // level from the IQ magnitudes (:150-158): 20 log10(1.55) = +3.8 dB
+    post.terminate();
+    tp.join();
+}
+
 static int run_gpu(const char *root) {
     csdr_ctx *ctx = nullptr;
     csdr_must(csdr_ctx_create(0, nullptr, &ctx), "csdr_ctx_create");
     test_scope_against_reference(ctx, root);
+    test_audio_egress_device(ctx);
+    test_plugin_modem_and_device_ingest(ctx);
     {
         DemodulatorMgr mgr(8);
         SDRPostThread post(ctx, &mgr);
@@ -475,6 +599,15 @@ static int run_gpu(const char *root) {
         dfms->setFrequency(center - 600000);
         dfms->writeModemSetting("demph", "50");
         CHECK(dfms->getBandwidth() == 200000 && dfms->readModemSetting("demph") == "50");
+        // a third instance whose sound goes to the device mixer: bank audio -> the mixer's ring inside HBM, nothing on its host audio queue
+        AudioMixer mixer(ctx, 48000, 4, 100);
+        auto dmix = mgr.newThread();
+        dmix->setDemodulatorType("NBFM");
+        dmix->setFrequency(center + 250000);
+        auto mixSrc = mixer.bindThread();
+        mixSrc->setGain(0.5f);
+        dmix->setAudioMixSource(mixSrc);
+        post.setAudioMixer(&mixer);
         // demodulator spectrum (CubicSDR.cpp:373-381): the selected modem's channel -> a second processor in view mode
         mgr.setActiveDemodulator(d, false);
         SpectrumVisualProcessor demodSpec(ctx);
@@ -577,6 +710,18 @@ static int run_gpu(const char *root) {
             while (fq->try_pop(ati)) { ++nf; CHECK(ati->sampleRate == 48000 && ati->channels == 2 && ati->data.size() % 2 == 0); fl += ati->data.size(); }
             std::printf("FM stereo audio blocks %d floats %zu\n", nf, fl);
             CHECK(nf == 12 && std::abs((long)fl - 2 * 9600) <= 8);
+        }
+        {
+            // the mixer holds dmix's 12 blocks (~9600 samples): 9 callbacks of 1024 frames; the 1 kHz tone comes out at gain 0.5 on both channels
+            CHECK(dmix->getAudioOutputQueue()->empty() && mixSrc->queued() == 12);
+            std::vector<float> mo, cb(2048);
+            for (int k = 0; k < 9; ++k) { mixer.callback(cb.data(), 1024); mo.insert(mo.end(), cb.begin(), cb.end()); }
+            double mr = 0, mi = 0;
+            const int f0 = 5000, nfm = 9 * 1024 - f0 - 600;
+            for (int i = 0; i < nfm; ++i) { mr += mo[2 * (f0 + i)] * std::cos(2 * M_PI * 1000.0 * i / 48000.0); mi += mo[2 * (f0 + i)] * std::sin(2 * M_PI * 1000.0 * i / 48000.0); }
+            const double mt = 2.0 * std::sqrt(mr * mr + mi * mi) / nfm;
+            std::printf("device mixer: tone amplitude %.4f (expect 0.20), left == right %d\n", mt, mo[2 * 6000] == mo[2 * 6000 + 1] ? 1 : 0);
+            CHECK(std::fabs(mt - 0.2) < 0.01 && mo[2 * 6000] == mo[2 * 6000 + 1]);
         }
         double re = 0, im = 0;
         const int a0 = 4800, na = (int)audio.size() - a0;
@@ -682,7 +827,7 @@ int main(int argc, char **argv) {
     test_distributors();
     test_modem_shim();
     test_block_assembler();
-    test_audio_egress();
+    test_wav_writer();
     std::printf(g_fail ? "HOST TEST FAILED (%d)\n" : "host test ok\n", g_fail);
     return g_fail ? 1 : 0;
 }

@@ -203,3 +203,18 @@ def test_emu_spectrum_contiguous_batches_multi_row(ctx):
 @full
 def test_emu_spectrum_contiguous_batches_multi_row_rounds(ctx):
     G._spectrum_contiguous_batches(ctx, 4096, 2400000, (40, 270, 33))
+
+
+def test_emu_scope_against_reference(ctx):
+    import tests.test_gpu_io as IO
+    IO.scope_scenario(ctx)
+
+
+def test_emu_mixer_against_reference_callback(ctx):
+    import tests.test_gpu_io as IO
+    IO.mixer_scenario(ctx, n_callbacks=70)
+
+
+def test_emu_ingest_shared_device_buffer(ctx):
+    import tests.test_gpu_io as IO
+    IO.ingest_scenario(ctx, rounds=4)
