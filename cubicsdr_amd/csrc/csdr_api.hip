@@ -298,6 +298,9 @@ static int chan_geometry(int M, int hop, ChanGeom &g) {
         g.nkA = (slots + g.KA - 1) / g.KA;
         g.PA = g.nkA * g.KA;
         g.TF = kP2Frames; g.lgTF = 6; g.S = M; g.taps_lds = 0; g.stage_in = 1; g.threads = kP2Threads;
+        // The prime-length DFT is matrix-shaped work: A >= 17 runs it on the fp32 matrix pipe (bit-identical results; the kernel was
+        // bound by vector-ALU issue, not by bandwidth).  CSDR_CHAN_MX=0 keeps the vector form (A/B measurements).
+        g.mx = (g.A >= 17 && !(getenv("CSDR_CHAN_MX") && atoi(getenv("CSDR_CHAN_MX")) == 0)) ? 1 : 0;
         return CSDR_OK;
     }
     g.taps_lds = (M <= 512) ? 1 : 0;
@@ -326,6 +329,7 @@ typedef void (*chan_kernel_t)(const float2 *, const float2 *, float2 *, const fl
 typedef void (*chan_p2_kernel_t)(const float2 *, const float2 *, float2 *, const float *, const float2 *, const float2 *, const int *, ChanGeom,
                                  int64_t, float2 *, int64_t, d2 *, double);
 static chan_p2_kernel_t chan_p2_kernel(const ChanGeom &g) {
+    if (g.mx) return chan_analyze_p2<4, true>;
 #define CSDR_P2_CASE(K_) case K_: return chan_analyze_p2<K_>
     switch (g.KA) {
         CSDR_P2_CASE(1); CSDR_P2_CASE(2); CSDR_P2_CASE(3); CSDR_P2_CASE(4); CSDR_P2_CASE(5); CSDR_P2_CASE(6); CSDR_P2_CASE(7);
@@ -388,7 +392,10 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
         for (int c = 0; c < M; c++) for (int n = 0; n < kChanTaps; n++) tapsT[(size_t)n * M + c] = taps[(size_t)c * kChanTaps + n];
         std::vector<float2> twA((size_t)g.A * g.PA, make_float2(0.f, 0.f)), twB((size_t)g.B * g.PB, make_float2(0.f, 0.f)), twM((size_t)g.A * g.B);
         auto W = [](int64_t num, int den) { const double a = -2.0 * M_PI * (double)(num % den) / (double)den; return make_float2((float)std::cos(a), (float)std::sin(a)); };
-        if (g.p2) {          // slot q: output pair k = q + 1 (q < H), k = 0 as (1, 0) (q == H), unused (0, 0) beyond
+        if (g.p2 && g.mx) {  // coefficient fragments of the matrix-pipe form (kernels_post.hpp: chan_mx_table)
+            twA.assign((size_t)2 * kMxSteps * 64, make_float2(0.f, 0.f));        // 2 x 2 x kMxSteps x 64 floats
+            chan_mx_table(g.A, reinterpret_cast<float *>(twA.data()));
+        } else if (g.p2) {   // slot q: output pair k = q + 1 (q < H), k = 0 as (1, 0) (q == H), unused (0, 0) beyond
             const int H = (g.A - 1) / 2;
             twA.assign((size_t)H * g.PA, make_float2(0.f, 0.f));
             for (int c = 1; c <= H; c++) for (int q = 0; q <= H; q++) {

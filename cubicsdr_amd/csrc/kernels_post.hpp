@@ -208,6 +208,7 @@ struct ChanGeom {
     int oddA;                 // 1: A is odd (>= 3) and phase 1 uses the conjugate-pair form: KA / nkA / PA then count output PAIRS (k, A - k)
     int threads;              // workgroup size (whole waves, 256..512): chosen so each phase splits evenly over the waves
     int p2;                   // 1: M = 2 A, A odd <= 63, critically sampled: chan_analyze_p2 (KA = slots per pass, nkA = passes, PA = row pitch)
+    int mx;                   // p2 only: the A-point DFTs run on the fp32 matrix pipe (chan_analyze_p2<.., true>)
 };
 __host__ __device__ inline size_t chan_zin_floats2(const ChanGeom &g) {      // Z array, or the staged input tile if larger
     const size_t z = (size_t)g.TF * g.S, in = g.stage_in ? (size_t)(g.TF - 1) * g.hop + (size_t)kChanTaps * g.M : 0;
@@ -502,7 +503,24 @@ constexpr int kP2Waves = 8;
 constexpr int kP2Threads = 64 * kP2Waves;
 constexpr int kP2MaxA = 63;
 constexpr int kP2Pre = ((kP2Frames + kChanTaps - 1) * kP2MaxA + kP2Threads - 1) / kP2Threads;     // float4 registers per thread holding a tile's input
-__host__ __device__ inline size_t chan_p2_lds_bytes(int M) { return (size_t)(kP2Frames + kChanTaps - 1) * M * sizeof(float2); }
+__host__ __device__ inline size_t chan_p2_lds_bytes(int M) { return (size_t)(kP2Frames + kChanTaps - 1) * M * sizeof(float2) + 4 * 2 * sizeof(double); }
+// matrix-pipe form: K steps of 4 terms cover n = 0 .. 31 (H <= 31), two row tiles of 16 outputs cover k = 0 .. 31
+constexpr int kMxSteps = 8;
+// coefficient fragments, [2 (cos | sin)][2 row tiles][kMxSteps][64 lanes]: lane l of step J holds the coefficient of output
+// k = 16 rt + (l & 15) and term n = 4 J + (l >> 4) -- the A operand of v_mfma_f32_16x16x4_f32 (A[i = l & 15][k = l >> 4])
+__host__ inline void chan_mx_table(int A, float *tab /* [2][2][kMxSteps][64] */) {
+    const int H = (A - 1) / 2;
+    for (int kind = 0; kind < 2; ++kind) for (int rt = 0; rt < 2; ++rt) for (int J = 0; J < kMxSteps; ++J) for (int l = 0; l < 64; ++l) {
+        const int k = 16 * rt + (l & 15), n = 4 * J + (l >> 4);
+        float v = 0.f;
+        if (k <= H && n <= H) {
+            const double ang = 2.0 * M_PI * (double)(((long long)n * k) % A) / (double)A;      // the same expression as the VALU form's (cos, sin) rows
+            if (kind == 0) v = n == 0 ? 1.0f : (float)std::cos(ang);
+            else v = n == 0 ? 0.0f : (float)std::sin(ang);
+        }
+        tab[(((size_t)kind * 2 + rt) * kMxSteps + J) * 64 + l] = v;
+    }
+}
 
 // store to a wave-uniform row base plus a 32-bit per-lane byte offset (scalar-base addressing: no 64-bit address arithmetic per lane)
 __device__ __forceinline__ void store_row(float2 *row_base, unsigned byte_off, float2 v) {
@@ -557,7 +575,9 @@ __device__ __forceinline__ void chan_p2_request(const float2 *__restrict__ x, co
     }
 }
 
-template <int KP>
+// MX = true: the DFT phase runs on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32), see "DFT on the matrix pipe" below; `cs` then is
+// the coefficient-fragment table of chan_mx_table().
+template <int KP, bool MX = false>
 __global__ __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
     const float2 *__restrict__ x, const float2 *__restrict__ hist, float2 *__restrict__ hist_new,
     const float *__restrict__ tapsT,      // [8][M]
@@ -568,6 +588,7 @@ __global__ __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *rows = reinterpret_cast<float4 *>(smem);          // row r (input row f0 + r - 7, later X[r]) at rows + r A
     const int M = g.M, A = g.A, H = (A - 1) >> 1;
+    d2 *dc_part = reinterpret_cast<d2 *>(smem + (size_t)(kP2Frames + kChanTaps - 1) * M * sizeof(float2));      // [4] per-column-tile partial sums (MX)
     const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = wave_uniform(tid0 >> 6);
     const int64_t n_tiles = (n_frames + kP2Frames - 1) / kP2Frames;
     const int64_t Hs = (int64_t)(kChanTaps - 1) * M;          // samples in front of a tile's own first row = carried history length
@@ -579,6 +600,13 @@ __global__ __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
             const int64_t gsrc = n - Hs + j;
             hist_new[j] = gsrc >= 0 ? x[gsrc] : hist[gsrc + Hs];
         }
+    }
+    // MX: this wave's coefficient fragments stay in registers for the whole launch (persistent workgroup)
+    float mxc[kMxSteps], mxs[kMxSteps];
+    if constexpr (MX) {
+        const float *tab = reinterpret_cast<const float *>(cs) + (size_t)(wave >> 2) * kMxSteps * 64 + lane0;
+#pragma unroll
+        for (int J = 0; J < kMxSteps; ++J) { mxc[J] = tab[J * 64]; mxs[J] = tab[(2 * kMxSteps + J) * 64]; }
     }
     float4 pre[kP2Pre];
     int64_t tile = blockIdx.x;
@@ -630,81 +658,151 @@ __global__ __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
         lds_barrier();
         // the next tile's input is on its way while this one is transformed
         chan_p2_request<false>(x, hist, M, n_frames, tile + gridDim.x, tile + gridDim.x < n_tiles, pre);
-        // ---- DFT: lane = frame t; wave = pass of KP output-pair slots
-        const int t = lane;
+        if constexpr (MX) {
+        // ---- DFT on the matrix pipe.  The conjugate-pair sums are two real matrix products per component:
+        //        P[k][t] = sum_n Cos[k][n] s_n[t]      Q[k][t] = sum_n Sin[k][n] d_n[t]        k, n = 0 .. H   (s_0 = x_0, Cos[k][0] = 1, Sin[k][0] = 0)
+        //      for the four components (c2 = 0 / 1) x (re / im) of s and d: eight products, tiled 16 (k) x 16 (t) x 4 (n) on
+        //      v_mfma_f32_16x16x4_f32.  Wave = (row tile rt = wave >> 2: k = 16 rt .. 16 rt + 15, column tile ct = wave & 3: frames
+        //      16 ct .. 16 ct + 15); lane (q = lane >> 4, j = lane & 15) feeds term n = 4 J + q of frame t = 16 ct + j in step J -- the
+        //      float4 sums / differences of ONE ds_read_b128 pair are the B operands of all eight products -- and receives outputs
+        //      k = 16 rt + 4 q + r (r = 0..3) of that frame for all eight, so the radix-2 butterfly and the stores stay in-lane.
+        //      An MFMA is a k-ordered fmaf chain: the accumulation order (n ascending, starting from x_0) is the VALU form's, and so
+        //      are the results, bit for bit.  64 MFMAs (2048 matrix-pipe cycles) per wave and tile against ~70 VALU instructions.
+        const int q = lane >> 4, t = 16 * (wave & 3) + (lane & 15), rt = wave >> 2;
         const float4 *row = rows + t * A;
         const bool tv = t < nf;
-        for (int p = wave; p < g.nkA; p += kP2Waves) {
-            const int q0 = p * KP;
-            const float4 x0 = row[0];
-            float2 P0[KP], Q0[KP], P1[KP], Q1[KP];
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        csdr_f32x4 P0r = {0.f, 0.f, 0.f, 0.f}, P0i = P0r, P1r = P0r, P1i = P0r, Q0r = P0r, Q0i = P0r, Q1r = P0r, Q1i = P0r;
+        float4 a = q <= H ? row[q] : z4, b = (q >= 1 && q <= H) ? row[A - q] : z4;     // step 0: n = q
 #pragma unroll
-            for (int j = 0; j < KP; ++j) {
-                P0[j] = make_float2(x0.x, x0.y); P1[j] = make_float2(x0.z, x0.w);
-                Q0[j] = make_float2(0.f, 0.f); Q1[j] = make_float2(0.f, 0.f);
+        for (int J = 0; J < kMxSteps; ++J) {
+            float4 a2 = z4, b2 = z4;
+            if (J + 1 < kMxSteps) {                                  // the next step's rows are requested ahead of this step's products
+                const int n2 = 4 * (J + 1) + q;
+                if (n2 <= H) { a2 = row[n2]; b2 = row[A - n2]; }
             }
-            // software pipeline, two terms per trip with two register sets (no copies): the rows and the (cos, sin) row of the
-            // next term are requested before the current one is accumulated
-            const float2 *w = cs + q0;
-            float4 a = row[1], b = row[A - 1], a2 = a, b2 = b;
-            float2 eA[KP], eB[KP];
+            const float4 sv = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+            const float4 dv = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+            P0r = csdr_mfma16(mxc[J], sv.x, P0r); P0i = csdr_mfma16(mxc[J], sv.y, P0i);
+            P1r = csdr_mfma16(mxc[J], sv.z, P1r); P1i = csdr_mfma16(mxc[J], sv.w, P1i);
+            Q0r = csdr_mfma16(mxs[J], dv.x, Q0r); Q0i = csdr_mfma16(mxs[J], dv.y, Q0i);
+            Q1r = csdr_mfma16(mxs[J], dv.z, Q1r); Q1i = csdr_mfma16(mxs[J], dv.w, Q1i);
+            a = a2; b = b2;
+        }
+        float2 *ob = out + f0 + t;
 #pragma unroll
-            for (int j = 0; j < KP; ++j) { eA[j] = w[j]; eB[j] = eA[j]; }
-            int c = 1;
-            for (; c + 1 <= H; c += 2) {
-                w += g.PA;
-                a2 = row[c + 1]; b2 = row[A - c - 1];
-#pragma unroll
-                for (int j = 0; j < KP; ++j) eB[j] = w[j];
-                sched_fence();
-                chan_p2_term<KP>(a, b, eA, P0, Q0, P1, Q1);
-                sched_fence();
-                w += g.PA;
-                if (c + 2 <= H) {
-                    a = row[c + 2]; b = row[A - c - 2];
-#pragma unroll
-                    for (int j = 0; j < KP; ++j) eA[j] = w[j];
+        for (int r = 0; r < 4; ++r) {
+            const int k = 16 * rt + 4 * q + r;
+            if (k <= H && tv) {
+                const int kn = A - k;
+                const float2 P0 = make_float2(P0r[r], P0i[r]), Q0 = make_float2(Q0r[r], Q0i[r]), P1 = make_float2(P1r[r], P1i[r]), Q1 = make_float2(Q1r[r], Q1i[r]);
+                const float2 wk = twM[2 * k + 1];
+                const float2 z0k = make_float2(P0.x + Q0.y, P0.y - Q0.x);
+                const float2 u = cmul(make_float2(P1.x + Q1.y, P1.y - Q1.x), wk);
+                if (active[k]) ob[(int64_t)k * out_stride] = make_float2(z0k.x + u.x, z0k.y + u.y);
+                if (active[k + A]) ob[(int64_t)(k + A) * out_stride] = make_float2(z0k.x - u.x, z0k.y - u.y);
+                if (k > 0) {                                        // k = 0 has no conjugate partner
+                    const float2 wn = twM[2 * kn + 1];
+                    const float2 z0n = make_float2(P0.x - Q0.y, P0.y + Q0.x);
+                    const float2 v = cmul(make_float2(P1.x - Q1.y, P1.y + Q1.x), wn);
+                    if (active[kn]) ob[(int64_t)kn * out_stride] = make_float2(z0n.x + v.x, z0n.y + v.y);
+                    if (active[kn + A]) ob[(int64_t)(kn + A) * out_stride] = make_float2(z0n.x - v.x, z0n.y - v.y);
                 }
-                sched_fence();
-                chan_p2_term<KP>(a2, b2, eB, P0, Q0, P1, Q1);
-                sched_fence();
             }
-            if (c <= H) chan_p2_term<KP>(a, b, eA, P0, Q0, P1, Q1);        // H odd: the last term
-            float2 *ob = out + f0;                                  // wave-uniform row bases + a 32-bit lane offset: scalar-base stores
-            const unsigned tb = (unsigned)t * (unsigned)sizeof(float2);   // byte offset of this lane inside a channel row
-#pragma unroll
-            for (int j = 0; j < KP; ++j) {
-                const int q = q0 + j;                               // wave-uniform
-                if (q < H) {
-                    const int k = q + 1, kn = A - k;
-                    const float2 wk = twM[2 * k + 1], wn = twM[2 * kn + 1];
-                    const int on0 = active[k], on1 = active[k + A], on2 = active[kn], on3 = active[kn + A];
-                    const float2 z0k = make_float2(P0[j].x + Q0[j].y, P0[j].y - Q0[j].x), z0n = make_float2(P0[j].x - Q0[j].y, P0[j].y + Q0[j].x);
-                    const float2 u = cmul(make_float2(P1[j].x + Q1[j].y, P1[j].y - Q1[j].x), wk);
-                    const float2 v = cmul(make_float2(P1[j].x - Q1[j].y, P1[j].y + Q1[j].x), wn);
-                    if (tv) {
-                        if (on0) store_row(ob + (int64_t)k * out_stride, tb, make_float2(z0k.x + u.x, z0k.y + u.y));
-                        if (on1) store_row(ob + (int64_t)(k + A) * out_stride, tb, make_float2(z0k.x - u.x, z0k.y - u.y));
-                        if (on2) store_row(ob + (int64_t)kn * out_stride, tb, make_float2(z0n.x + v.x, z0n.y + v.y));
-                        if (on3) store_row(ob + (int64_t)(kn + A) * out_stride, tb, make_float2(z0n.x - v.x, z0n.y - v.y));
+        }
+        if (dc_ends && rt == 0) {
+            // v_end = sum_t c^(nf-1-t) y0[t] over the tile (the DC blocker's state after it from a zero state, iirfilt :375): channel 0
+            // sits in r = 0 of the lanes with q = 0; each column tile contributes a partial sum, added up after the tile's last barrier
+            const bool mine = q == 0 && tv;
+            const double wgt = mine ? dc_pow(dc_c, nf - 1 - t) : 0.0;
+            double vx = mine ? wgt * (double)(P0r[0] + P1r[0]) : 0.0, vy = mine ? wgt * (double)(P0i[0] + P1i[0]) : 0.0;
+            for (int s2 = 8; s2 > 0; s2 >>= 1) { vx += __shfl_down(vx, s2, 64); vy += __shfl_down(vy, s2, 64); }
+            if (lane == 0) dc_part[wave & 3] = d2{vx, vy};
+        }
+        } else {
+        // ---- DFT: lane = frame t; wave = pass of KP output-pair slots
+            const int t = lane;
+            const float4 *row = rows + t * A;
+            const bool tv = t < nf;
+            for (int p = wave; p < g.nkA; p += kP2Waves) {
+                const int q0 = p * KP;
+                const float4 x0 = row[0];
+                float2 P0[KP], Q0[KP], P1[KP], Q1[KP];
+    #pragma unroll
+                for (int j = 0; j < KP; ++j) {
+                    P0[j] = make_float2(x0.x, x0.y); P1[j] = make_float2(x0.z, x0.w);
+                    Q0[j] = make_float2(0.f, 0.f); Q1[j] = make_float2(0.f, 0.f);
+                }
+                // software pipeline, two terms per trip with two register sets (no copies): the rows and the (cos, sin) row of the
+                // next term are requested before the current one is accumulated
+                const float2 *w = cs + q0;
+                float4 a = row[1], b = row[A - 1], a2 = a, b2 = b;
+                float2 eA[KP], eB[KP];
+    #pragma unroll
+                for (int j = 0; j < KP; ++j) { eA[j] = w[j]; eB[j] = eA[j]; }
+                int c = 1;
+                for (; c + 1 <= H; c += 2) {
+                    w += g.PA;
+                    a2 = row[c + 1]; b2 = row[A - c - 1];
+    #pragma unroll
+                    for (int j = 0; j < KP; ++j) eB[j] = w[j];
+                    sched_fence();
+                    chan_p2_term<KP>(a, b, eA, P0, Q0, P1, Q1);
+                    sched_fence();
+                    w += g.PA;
+                    if (c + 2 <= H) {
+                        a = row[c + 2]; b = row[A - c - 2];
+    #pragma unroll
+                        for (int j = 0; j < KP; ++j) eA[j] = w[j];
                     }
-                } else if (q == H) {                                // k = 0: P = sum of the column, Q = 0
-                    const float2 y0 = make_float2(P0[j].x + P1[j].x, P0[j].y + P1[j].y);
-                    if (tv) {
-                        if (active[0]) store_row(ob, tb, y0);
-                        if (active[A]) store_row(ob + (int64_t)A * out_stride, tb, make_float2(P0[j].x - P1[j].x, P0[j].y - P1[j].y));
-                    }
-                    if (dc_ends) {
-                        // v_end = sum_t c^(nf-1-t) y0[t]: the DC blocker's state after this tile if it entered with zero (iirfilt, :375)
-                        const double wgt = tv ? dc_pow(dc_c, nf - 1 - t) : 0.0;
-                        double vx = tv ? wgt * (double)y0.x : 0.0, vy = tv ? wgt * (double)y0.y : 0.0;      // rows past the last frame hold no data
-                        for (int s2 = 32; s2 > 0; s2 >>= 1) { vx += __shfl_down(vx, s2, 64); vy += __shfl_down(vy, s2, 64); }
-                        if (lane == 0) dc_ends[tile] = d2{vx, vy};
+                    sched_fence();
+                    chan_p2_term<KP>(a2, b2, eB, P0, Q0, P1, Q1);
+                    sched_fence();
+                }
+                if (c <= H) chan_p2_term<KP>(a, b, eA, P0, Q0, P1, Q1);        // H odd: the last term
+                float2 *ob = out + f0;                                  // wave-uniform row bases + a 32-bit lane offset: scalar-base stores
+                const unsigned tb = (unsigned)t * (unsigned)sizeof(float2);   // byte offset of this lane inside a channel row
+    #pragma unroll
+                for (int j = 0; j < KP; ++j) {
+                    const int q = q0 + j;                               // wave-uniform
+                    if (q < H) {
+                        const int k = q + 1, kn = A - k;
+                        const float2 wk = twM[2 * k + 1], wn = twM[2 * kn + 1];
+                        const int on0 = active[k], on1 = active[k + A], on2 = active[kn], on3 = active[kn + A];
+                        const float2 z0k = make_float2(P0[j].x + Q0[j].y, P0[j].y - Q0[j].x), z0n = make_float2(P0[j].x - Q0[j].y, P0[j].y + Q0[j].x);
+                        const float2 u = cmul(make_float2(P1[j].x + Q1[j].y, P1[j].y - Q1[j].x), wk);
+                        const float2 v = cmul(make_float2(P1[j].x - Q1[j].y, P1[j].y + Q1[j].x), wn);
+                        if (tv) {
+                            if (on0) store_row(ob + (int64_t)k * out_stride, tb, make_float2(z0k.x + u.x, z0k.y + u.y));
+                            if (on1) store_row(ob + (int64_t)(k + A) * out_stride, tb, make_float2(z0k.x - u.x, z0k.y - u.y));
+                            if (on2) store_row(ob + (int64_t)kn * out_stride, tb, make_float2(z0n.x + v.x, z0n.y + v.y));
+                            if (on3) store_row(ob + (int64_t)(kn + A) * out_stride, tb, make_float2(z0n.x - v.x, z0n.y - v.y));
+                        }
+                    } else if (q == H) {                                // k = 0: P = sum of the column, Q = 0
+                        const float2 y0 = make_float2(P0[j].x + P1[j].x, P0[j].y + P1[j].y);
+                        if (tv) {
+                            if (active[0]) store_row(ob, tb, y0);
+                            if (active[A]) store_row(ob + (int64_t)A * out_stride, tb, make_float2(P0[j].x - P1[j].x, P0[j].y - P1[j].y));
+                        }
+                        if (dc_ends) {
+                            // v_end = sum_t c^(nf-1-t) y0[t]: the DC blocker's state after this tile if it entered with zero (iirfilt, :375)
+                            const double wgt = tv ? dc_pow(dc_c, nf - 1 - t) : 0.0;
+                            double vx = tv ? wgt * (double)y0.x : 0.0, vy = tv ? wgt * (double)y0.y : 0.0;      // rows past the last frame hold no data
+                            for (int s2 = 32; s2 > 0; s2 >>= 1) { vx += __shfl_down(vx, s2, 64); vy += __shfl_down(vy, s2, 64); }
+                            if (lane == 0) dc_ends[tile] = d2{vx, vy};
+                        }
                     }
                 }
             }
         }
         lds_barrier();                                      // the rows are free for the next tile
+        if constexpr (MX) {
+            if (dc_ends && tid0 == 0) {
+                d2 v = dc_part[0];
+                for (int i = 1; i < 4; ++i) { v.x += dc_part[i].x; v.y += dc_part[i].y; }
+                dc_ends[tile] = v;
+            }
+        }
     }
 }
 

@@ -121,6 +121,31 @@ static inline T __shfl(T v, int src, int width = 64) {
     return hip_emu::lane_exchange(v, base + (src % width), true);
 }
 
+// v_mfma_f32_16x16x4_f32 on one wave: lane l supplies A[l & 15][l >> 4], B[l >> 4][l & 15]; element r of the result is
+// D[4 (l >> 4) + r][l & 15] = fma chain over k ascending (exact f32, as the hardware's)
+typedef float hip_emu_f32x4 __attribute__((vector_size(16)));
+static inline hip_emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hip_emu_f32x4 c, int, int, int) {
+    hip_emu::State &s = hip_emu::state();
+    const unsigned tid = hip_emu::flat_tid(), w0 = tid & ~63u, l = tid & 63u;
+    float ab[2] = {a, b};
+    std::memcpy(s.xch[tid], ab, sizeof ab);
+    s.wbar[tid >> 6]->arrive_and_wait();
+    hip_emu_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const unsigned i = 4 * (l >> 4) + (unsigned)r, j = l & 15u;
+        float acc = c[r];
+        for (unsigned k = 0; k < 4; ++k) {
+            float pa[2], pb[2];
+            std::memcpy(pa, s.xch[w0 + i + 16 * k], sizeof pa);      // A[i][k] lives in lane i + 16 k
+            std::memcpy(pb, s.xch[w0 + 16 * k + j], sizeof pb);      // B[k][j] lives in lane 16 k + j
+            acc = std::fmaf(pa[0], pb[1], acc);
+        }
+        d[r] = acc;
+    }
+    s.wbar[tid >> 6]->arrive_and_wait();
+    return d;
+}
+
 // device math the kernels use beyond <cmath>
 using std::max;
 using std::min;

@@ -125,6 +125,35 @@ def test_channelizer_m_twice_odd(ctx, fs, M, block):
     batch.close()
 
 
+@pytest.mark.parametrize("M,frames", [(122, 8394), (126, 300), (62, 1000), (34, 64)])
+def test_channelizer_matrix_pipe_equals_vector_form_bit_for_bit(ctx, M, frames):
+    """M = 2 A with A odd >= 17 runs its A-point DFTs on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: a k-ordered fmaf chain per output);
+    the vector form (CSDR_CHAN_MX=0) accumulates the same terms in the same order, so every channel sample -- the DC-blocked channel 0
+    included -- must be IDENTICAL.  M = 122 at the headline block length (8394 frames: whole and ragged 64-frame tiles), A = 63 (all
+    32 x 32 coefficient slots in use), A = 31, A = 17."""
+    import os
+    from cubicsdr_amd.engine import SDRPost
+    fs, center = M * 50000, 100000000
+    block = M * frames
+    x = synth_iq_fast(3 * block, fs, center, [("NBFM", center + 123456), ("AM", center - 3 * (fs // M) + 999)], seed=5)
+    outs = []
+    saved = os.environ.get("CSDR_CHAN_MX")
+    try:
+        for mx in ("1", "0"):
+            os.environ["CSDR_CHAN_MX"] = mx
+            p = SDRPost(ctx, fs, M, block, max_blocks=3)
+            p.execute(x, 3, block, center)
+            outs.append([p.read_channel(ch) for ch in range(M)])
+            p.close()
+    finally:
+        if saved is None:
+            os.environ.pop("CSDR_CHAN_MX", None)
+        else:
+            os.environ["CSDR_CHAN_MX"] = saved
+    for ch, (a, b) in enumerate(zip(*outs)):
+        assert a.size == 3 * frames and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (M, ch, float(np.max(np.abs(a - b))))
+
+
 def test_channelizer_batched_equals_blockwise(ctx):
     from cubicsdr_amd.engine import SDRPost
     fs, M, block, center = 2400000, 4, 40000, 100000000
