@@ -44,6 +44,9 @@ CONFIGS = {
                label="C2: 64x NBFM demods (12.5 kHz -> 48 kHz audio), 10 MS/s complex-float IQ, firpfbch M=20, 16384-pt spectrum FFT (internal 32768) over every sample"),
     "C3": dict(fs=61_440_000, M=122, block=1_024_068, n_demods=256, fft=65536, kinds=["NBFM", "AM", "USB"], blocks=128, batches=48,
                label="C3: 256 mixed NBFM/AM/USB demods, 61.44 MS/s complex-float IQ, firpfbch M=122, 65536-pt spectrum FFT (internal 131072) over every sample"),
+    "C5": dict(fs=100_000_000, M=200, block=1_666_800, n_demods=512, fft=1_048_576, kinds=["NBFM", "AM", "USB"], blocks=32, batches=24,
+               label="C5: one 100 MS/s complex-float IQ stream per GPU (BASELINE config 5: replicas, no cross-GPU traffic), firpfbch M=200, 512 mixed NBFM/AM/USB demods, "
+                     "1048576-pt spectrum FFT (internal 2097152) over every sample"),
     "C3N": dict(fs=61_440_000, M=122, block=1_024_068, n_demods=256, fft=65536, kinds=["NBFM"], blocks=128, batches=48,
                 label="C3N: 256 NBFM demods, 61.44 MS/s complex-float IQ, firpfbch M=122, 65536-pt spectrum FFT (internal 131072) over every sample"),
 }
@@ -225,7 +228,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS) + ["C4"],
                     help="BASELINE.json workload: C3 (default: 256 mixed demods, 61.44 MS/s, M=122, 65536-pt FFT -- the configuration the target is quoted on), "
-                         "C3N (same, all NBFM), C2 (64 NBFM, 10 MS/s, M=20, 16384-pt), C4 (M=1024 channelizer + 1024 NBFM, demodulators sharded over the ranks)")
+                         "C3N (same, all NBFM), C2 (64 NBFM, 10 MS/s, M=20, 16384-pt), C4 (M=1024 channelizer + 1024 NBFM, demodulators sharded over the ranks), "
+                         "C5 (100 MS/s, M=200, 512 mixed demods, 2^20-pt FFT: with --gpus N one such stream per GPU)")
     ap.add_argument("--blocks", type=int, default=0, help="IQ blocks per batch (HBM-resident ring); default per config")
     ap.add_argument("--batches", type=int, default=0, help="batches per step; default per config (a step is ~0.1-0.2 s of GPU work)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline sample budget per leg (0 disables)")
@@ -442,6 +446,40 @@ def main():
                             "streams_at_60_blocks_per_s": calls * nb / dt / 60.0}
             s2.close(); b2.close(); p2.close(); c2.close()
         out["config"]["small_batches"] = lat
+    if rank == 0 and world == 1 and not args.no_latency:
+        # Host-fed rate (never `value`): the SAME pipeline when the IQ blocks start in page-locked HOST memory, as an SDR reader leaves them:
+        # csdr_ingest moves each batch over the link ONCE (its own transfer stream, slot k + 1 in flight while slot k is processed) and the
+        # channelizer and the spectrum both read that one HBM copy.  The slots are filled once, before the clock starts: a real reader's
+        # DMA writes them; a host memcpy per batch would measure the host's copy loop instead of the link.
+        try:
+            from cubicsdr_amd.engine import Ingest
+            nbh = min(16, NB)
+            ch, ph, bh, sh = make_pipeline(nbh)
+            ing = Ingest(ch, nbh * BLOCK, depth=3)
+            src = ring[: nbh * BLOCK].cpu().numpy().view("complex64").reshape(-1)
+            for _ in range(3):
+                slot = ing.acquire(); slot[:src.size] = src; ing.commit(src.size)
+            ch.synchronize()
+
+            def host_batch():
+                ing.acquire()
+                dev = ing.commit(nbh * BLOCK)
+                ph.execute(dev, nbh, BLOCK, CENTER); bh.execute(ph); sh.process(dev, nbh, BLOCK, contiguous=True)
+            for _ in range(4):
+                host_batch()
+            ch.synchronize()
+            th = time.perf_counter()
+            nh = max(8, int(1.5e9 / (nbh * BLOCK)))                    # ~1.5 G samples
+            for _ in range(nh):
+                host_batch()
+            ch.synchronize()
+            dth = time.perf_counter() - th
+            out["config"]["host_fed"] = {"MS_per_s": nh * nbh * BLOCK / dth / 1e6, "GB_per_s_over_the_link": nh * nbh * BLOCK * 8 / dth / 1e9, "blocks_per_call": nbh,
+                                         "calls": nh, "note": "blocks in page-locked host memory -> csdr_ingest (ONE transfer per block, overlapped with compute) -> "
+                                                              "channelizer + demodulators + spectrum all read the one HBM copy; PCIe-inclusive, never `value`"}
+            ing.close(); sh.close(); bh.close(); ph.close(); ch.close()
+        except Exception as e:
+            out["config"]["host_fed"] = {"MS_per_s": None, "note": repr(e)}
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         try:
             out["cpu_baseline"] = cpu_baseline(cfg, ring.cpu().numpy().view("complex64").reshape(-1), args.cpu_seconds)

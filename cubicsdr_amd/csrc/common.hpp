@@ -107,6 +107,14 @@ __device__ __forceinline__ void opaque(int &v) {
     asm volatile("" : "+v"(v));
 #endif
 }
+// a product (or sum) that must be rounded on its own: hipcc contracts a * b + c into one fused operation by default (and its
+// __fmul_rn / __fadd_rn are plain operators), which differs from the reference's separately rounded multiply and add in the last bit
+__device__ __forceinline__ float rounded(float v) {
+#if defined(__AMDGCN__)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
 // value of the neighbouring lane (lane ^ 1): a DPP quad permute on the device, no LDS traffic
 __device__ __forceinline__ float lane_xor1(float v) {
 #if defined(__AMDGCN__)

@@ -300,7 +300,11 @@ static int chan_geometry(int M, int hop, ChanGeom &g) {
         g.TF = kP2Frames; g.lgTF = 6; g.S = M; g.taps_lds = 0; g.stage_in = 1; g.threads = kP2Threads;
         // The prime-length DFT is matrix-shaped work: A >= 17 runs it on the fp32 matrix pipe (bit-identical results; the kernel was
         // bound by vector-ALU issue, not by bandwidth).  CSDR_CHAN_MX=0 keeps the vector form (A/B measurements).
-        g.mx = (g.A >= 17 && !(getenv("CSDR_CHAN_MX") && atoi(getenv("CSDR_CHAN_MX")) == 0)) ? 1 : 0;
+        // CSDR_CHAN_MX: 0 vector form | 1 matrix pipe, 64-frame tiles, stores straight from the accumulators | 2 the same with stores staged
+        // through LDS (512-byte row runs) | 3 / 4: as 1 / 2 with 32-frame tiles in four-wave workgroups (four per CU instead of two)
+        g.mx = 0;
+        if (const char *e = getenv("CSDR_CHAN_MX")) g.mx = g.A >= 17 ? std::max(0, std::min(4, atoi(e))) : 0;
+        if (g.mx >= 3) { g.TF = 32; g.lgTF = 5; g.threads = P2Tile<32>::threads; }
         return CSDR_OK;
     }
     g.taps_lds = (M <= 512) ? 1 : 0;
@@ -329,7 +333,8 @@ typedef void (*chan_kernel_t)(const float2 *, const float2 *, float2 *, const fl
 typedef void (*chan_p2_kernel_t)(const float2 *, const float2 *, float2 *, const float *, const float2 *, const float2 *, const int *, ChanGeom,
                                  int64_t, float2 *, int64_t, d2 *, double);
 static chan_p2_kernel_t chan_p2_kernel(const ChanGeom &g) {
-    if (g.mx) return chan_analyze_p2<4, true>;
+    if (g.mx >= 3) return chan_analyze_p2<4, true, 32>;
+    if (g.mx) return chan_analyze_p2<4, true, 64>;
 #define CSDR_P2_CASE(K_) case K_: return chan_analyze_p2<K_>
     switch (g.KA) {
         CSDR_P2_CASE(1); CSDR_P2_CASE(2); CSDR_P2_CASE(3); CSDR_P2_CASE(4); CSDR_P2_CASE(5); CSDR_P2_CASE(6); CSDR_P2_CASE(7);
@@ -427,7 +432,7 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
         CSDR_HIP_TRY(hipMemsetAsync(p->hist0.p, 0, H * sizeof(float2), st));
         CSDR_HIP_TRY(hipMemsetAsync(p->hist1.p, 0, H * sizeof(float2), st));
         CSDR_HIP_TRY(hipStreamSynchronize(st));   // host vectors above go out of scope
-        const size_t lds = g.p2 ? chan_p2_lds_bytes(M) : chan_lds_bytes(g);
+        const size_t lds = g.p2 ? chan_p2_lds_bytes(M, g.TF) : chan_lds_bytes(g);
         if (lds > 64 * 1024) CSDR_HIP_TRY(hipFuncSetAttribute(g.p2 ? (const void *)chan_p2_kernel(g) : (const void *)chan_kernel(g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     p->hist_parity = 0;
@@ -527,8 +532,8 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
             // persistent workgroups: as many as are resident at once, each walks over tiles blockIdx.x, + gridDim.x, ...
             const chan_p2_kernel_t k2 = chan_p2_kernel(g);
             static const int chan_pct = getenv("CSDR_CHAN_PCT") ? std::max(10, std::min(100, atoi(getenv("CSDR_CHAN_PCT")))) : 100;
-            const int wgs = std::min(ntiles, std::max(1, c->wg_slots(k2, g.threads, chan_p2_lds_bytes(M)) * chan_pct / 100));
-            CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, k2, dim3(wgs), dim3(g.threads), chan_p2_lds_bytes(M), x, hist, hist_new, p->taps.p,
+            const int wgs = std::min(ntiles, std::max(1, c->wg_slots(k2, g.threads, chan_p2_lds_bytes(M, g.TF)) * chan_pct / 100));
+            CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, k2, dim3(wgs), dim3(g.threads), chan_p2_lds_bytes(M, g.TF), x, hist, hist_new, p->taps.p,
                         p->twA.p, p->twM.p, p->active.p, g, n_frames, out, p->chan_stride, fused_ends ? p->tile_end.p : (d2 *)nullptr, p->dc_c);
         } else {
         const chan_kernel_t kern = chan_kernel(g);

@@ -86,6 +86,15 @@ extern "C" int csdr_scope_process(csdr_scope *s, const csdr_scope_frame *frames,
     csdr_ctx *c = s->ctx;
     hipStream_t st = c->lanes[LANE_AVG];
     if (int rc = c->lane_begin(LANE_AVG)) return rc;
+    if (data_is_dev) {
+        // frames that lie in HBM were produced by kernels on another stage's stream (the bank's audio kernels): everything enqueued on
+        // the other streams so far precedes the scope kernels
+        for (int l = 0; l < c->n_phys; ++l) {
+            if (c->phys[l] == st) continue;
+            CSDR_HIP_TRY(hipEventRecord(c->ev_lane[l], c->phys[l]));
+            CSDR_HIP_TRY(hipStreamWaitEvent(st, c->ev_lane[l], 0));
+        }
+    }
     std::vector<ScopeFrame> fr((size_t)n_frames);
     std::vector<float> host_stage;
     size_t off = 0;

@@ -1284,44 +1284,34 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
     const int jb0 = pl[b].j0, jbp = b > 0 ? pl[b - 1].j0 : 0;
     // g_cur / g_prev are the gains of blocks b and b - 1 only when both hold samples (empty blocks do not step the gain)
     const bool fast_gain = pl[b + 1].j0 > jb0 && (b == 0 || jb0 > jbp);
-    if (plain) {
-        for (int i = tid; i < nwin; i += nthr) {
-            const int64_t j = jlo + i;
-            s_d[i] = j < 0 ? (j >= -(int64_t)kDHist ? dh_in[kDHist + j] : 0.f) : cfg.d[j];
+    // the scaled demodulator sample j of this batch's stream (j < 0: the carried history), as the modem hands it to its audio resampler
+    auto demod_sample = [&](int64_t j) -> float {
+        if (plain) return j < 0 ? (j >= -(int64_t)kDHist ? dh_in[kDHist + j] : 0.f) : cfg.d[j];
+        if (!autogain) {
+            // NBFM / FM (ModemNBFM.cpp:36, ModemFM.cpp:36): m[j] = atan2f(Im(x_j conj x_{j-1}), Re(..)) / (2 pi kf), gain 1.
+            // Formed here from the resampled IQ stream (history included: x_{-1} of a fresh demodulator is 0 -> m = 0).
+            if (j < -(int64_t)(kIqHist - 1)) return 0.f;
+            const float2 c = iq[j], p = iq[j - 1];
+            return atan2f(c.y * p.x - c.x * p.y, c.x * p.x + c.y * p.y) * fm_ref;
         }
-    } else if (!autogain) {
-        // NBFM / FM (ModemNBFM.cpp:36, ModemFM.cpp:36): m[j] = atan2f(Im(x_j conj x_{j-1}), Re(..)) / (2 pi kf), gain 1.
-        // Formed here from the resampled IQ stream (history included: x_{-1} of a fresh demodulator is 0 -> m = 0).
-        for (int i = tid; i < nwin; i += nthr) {
-            const int64_t j = jlo + i;
-            float x = 0.f;
-            if (j >= -(int64_t)(kIqHist - 1)) {
-                const float2 c = iq[j], p = iq[j - 1];
-                x = atan2f(c.y * p.x - c.x * p.y, c.x * p.x + c.y * p.y) * fm_ref;
-            }
-            s_d[i] = x;
-        }
-    } else
-    for (int i = tid; i < nwin; i += nthr) {
-        const int64_t j = jlo + i;
-        float x;
-        if (j < 0) x = j >= -(int64_t)kDHist ? dh_in[kDHist + j] : 0.f;
-        else if (fast_gain && j >= jb0) x = cfg.d[j] * g_cur;
-        else if (fast_gain && j >= jbp) x = cfg.d[j] * g_prev;
-        else {
-            // more than one block back, or empty blocks nearby (tiny blocks): replay the gain of the block that holds j
-            int bb = b;
-            while (bb > 0 && j < pl[bb].j0) --bb;
-            x = cfg.d[j] * (0.5f / cfg.blockmaa[bb]);              // block bb holds sample j, so it stepped the gain
-        }
-        s_d[i] = x;
-    }
-    // the last block's own scaled samples are the scope tap (DemodulatorThread.cpp:293-305); they lie inside the staged window
+        if (j < 0) return j >= -(int64_t)kDHist ? dh_in[kDHist + j] : 0.f;
+        if (fast_gain && j >= jb0) return cfg.d[j] * g_cur;
+        if (fast_gain && j >= jbp) return cfg.d[j] * g_prev;
+        // more than one block back, or empty blocks nearby (tiny blocks): replay the gain of the block that holds j
+        int bb = b;
+        while (bb > 0 && j < pl[bb].j0) --bb;
+        return cfg.d[j] * (0.5f / cfg.blockmaa[bb]);                  // block bb holds sample j, so it stepped the gain
+    };
+    for (int i = tid; i < nwin; i += nthr) s_d[i] = demod_sample(jlo + i);
+    // the last block's own scaled samples are the scope tap (ModemAnalog::getDemodOutputData, DemodulatorThread.cpp:293-305): the WHOLE
+    // block, up to DEMOD_VIS_SIZE -- those the cascade of this block already staged, and the trailing ones a decimating cascade leaves
+    // to the next block's outputs
     if (b == NB - 1 && !fms) {
         const int n_own = pl[b + 1].j0 - jb0;
-        const int ns = max(0, min(min(n_own, kScopeMax), (int)(jhi - (int64_t)jb0)));
+        const int ns = max(0, min(n_own, kScopeMax));
+        const int staged = max(0, min(ns, (int)(jhi - (int64_t)jb0)));
         __syncthreads();
-        for (int i = tid; i < ns; i += nthr) cfg.scope[i] = s_d[(int)((int64_t)jb0 - jlo) + i];
+        for (int i = tid; i < ns; i += nthr) cfg.scope[i] = (i < staged && (int64_t)jb0 >= jlo) ? s_d[(int)((int64_t)jb0 - jlo) + i] : demod_sample((int64_t)jb0 + i);
         if (tid == 0) *cfg.scope_n = ns;
     }
     // the filter arms of this thread's first two arbitrary-stage outputs travel while the staging above lands

@@ -36,7 +36,7 @@ __device__ __forceinline__ float scope_at(const ScopeFrame &f, int i) {
     const bool first = i < half;
     const int k = first ? i : i - half;
     const float v = f.data[2 * k + ((f.layout == 1) == first ? 0 : 1)];
-    return __fmul_rn(v, f.scale);
+    return rounded(v * f.scale);
 }
 __device__ __forceinline__ ScopeFrame scope_load(const ScopeFrame *frames, int i) {
     ScopeFrame f = frames[i];
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kFftThreads) void scope_spectrum(const ScopeFrame *
         const int cnt = fr.channels == 2 ? (fr.n >> 1) : fr.n;            // samples per channel handed to the transform
         for (int i = tid; i < L; i += kFftThreads) {
             float v = 0.f;
-            if (i < cnt) v = fr.channels == 2 ? __fadd_rn(scope_at(fr, i), scope_at(fr, cnt + i)) : scope_at(fr, i);   // stereo: left + right (:132-141)
+            if (i < cnt) v = fr.channels == 2 ? scope_at(fr, i) + scope_at(fr, cnt + i) : scope_at(fr, i);   // stereo: left + right (:132-141)
             sa[i] = make_float2(v, 0.f);
         }
         __syncthreads();
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kMixThreads) void audio_mix(const MixBuffer *__rest
     if (tid == 0) {
         // mixPeak per source: the first visited block sets it, later ones raise it (:175, :190-193); summed in source order (:233)
         for (int r = mb.ref0; r < mb.ref1; ++r) {
-            const double p = (double)__fmul_rn(*refs[r].peak, refs[r].gain);
+            const double p = (double)rounded(*refs[r].peak * refs[r].gain);
             double &m = s_peak[refs[r].source_slot];
             m = m < 0.0 ? p : fmax(m, p);
         }
@@ -214,10 +214,10 @@ __global__ __launch_bounds__(kMixThreads) void audio_mix(const MixBuffer *__rest
             const MixPiece pc = pieces[p];
             if (j < pc.out_begin || j >= pc.out_end) continue;
             const uint32_t k = pc.mono ? (uint32_t)((j >> 1) - (pc.out_begin >> 1)) : (uint32_t)(j - pc.out_begin);
-            const float v = __fmul_rn(pc.ring[(pc.ring_pos + k) & pc.ring_mask], pc.gain);
-            acc = __fadd_rn(acc, v);
+            const float v = rounded(pc.ring[(pc.ring_pos + k) & pc.ring_mask] * pc.gain);        // v = sample * gain; out += v (:188-190, :215)
+            acc = rounded(acc + v);
         }
-        o[j] = inv != 1.0f ? __fmul_rn(acc, inv) : acc;
+        o[j] = inv != 1.0f ? acc * inv : acc;
     }
 }
 
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void pcm16_convert(const PcmJob *__restrict__ 
     const float pk = *jb.peak;
     const float scale = pk < 1.0f ? 32767.0f : __fdiv_rn(32767.0f, pk);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < jb.n; i += 256 * gridDim.x)
-        jb.dst[i] = (int16_t)(int)__fmul_rn(jb.src[i], scale);              // float -> int truncates toward zero; the writer keeps the low 16 bits
+        jb.dst[i] = (int16_t)(int)rounded(jb.src[i] * scale);              // float -> int truncates toward zero; the writer keeps the low 16 bits
 }
 
 // ---- ingest: host block -> HBM with I and Q exchanged on the way (the reference swaps while it copies the block together).

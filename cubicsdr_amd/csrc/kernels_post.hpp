@@ -498,12 +498,17 @@ __global__ __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
 //           offset).  k = 0 rides along as a pseudo pair with (cos, sin) = (1, 0).  No Z array, no third phase.
 // (v_pk_fma_f32 issues every ~5 clk per SIMD with >= 2 waves resident on it, 13 clk with one: measured, scratch/ubench.)
 // ------------------------------------------------------------------------------------------------------------
-constexpr int kP2Frames = 64;          // frames per tile
+constexpr int kP2Frames = 64;          // frames per tile of the vector form (lane = frame in its DFT phase)
 constexpr int kP2Waves = 8;
 constexpr int kP2Threads = 64 * kP2Waves;
 constexpr int kP2MaxA = 63;
-constexpr int kP2Pre = ((kP2Frames + kChanTaps - 1) * kP2MaxA + kP2Threads - 1) / kP2Threads;     // float4 registers per thread holding a tile's input
-__host__ __device__ inline size_t chan_p2_lds_bytes(int M) { return (size_t)(kP2Frames + kChanTaps - 1) * M * sizeof(float2) + 4 * 2 * sizeof(double); }
+// tile geometry as a function of the frames per tile TF (64, or 32 for the matrix-pipe form): eight frames per wave in the FIR phase
+template <int TF> struct P2Tile {
+    static constexpr int waves = TF / kChanTaps, threads = 64 * waves;
+    static constexpr int pre = ((TF + kChanTaps - 1) * kP2MaxA + threads - 1) / threads;     // float4 registers per thread holding a tile's input
+    static constexpr int ctiles = TF / 16;                                                  // 16-frame column tiles of the matrix-pipe form
+};
+__host__ __device__ inline size_t chan_p2_lds_bytes(int M, int TF = kP2Frames) { return (size_t)(TF + kChanTaps - 1) * M * sizeof(float2) + 4 * 2 * sizeof(double); }
 // matrix-pipe form: K steps of 4 terms cover n = 0 .. 31 (H <= 31), two row tiles of 16 outputs cover k = 0 .. 31
 constexpr int kMxSteps = 8;
 // coefficient fragments, [2 (cos | sin)][2 row tiles][kMxSteps][64 lanes]: lane l of step J holds the coefficient of output
@@ -514,14 +519,13 @@ __host__ inline void chan_mx_table(int A, float *tab /* [2][2][kMxSteps][64] */)
         const int k = 16 * rt + (l & 15), n = 4 * J + (l >> 4);
         float v = 0.f;
         if (k <= H && n <= H) {
-            const double ang = 2.0 * M_PI * (double)(((long long)n * k) % A) / (double)A;      // the same expression as the VALU form's (cos, sin) rows
+            const double ang = 2.0 * M_PI * (double)(((long long)n * k) % A) / (double)A;      // the same expression as the vector form's (cos, sin) rows
             if (kind == 0) v = n == 0 ? 1.0f : (float)std::cos(ang);
             else v = n == 0 ? 0.0f : (float)std::sin(ang);
         }
         tab[(((size_t)kind * 2 + rt) * kMxSteps + J) * 64 + l] = v;
     }
 }
-
 // store to a wave-uniform row base plus a 32-bit per-lane byte offset (scalar-base addressing: no 64-bit address arithmetic per lane)
 __device__ __forceinline__ void store_row(float2 *row_base, unsigned byte_off, float2 v) {
     *reinterpret_cast<float2 *>(reinterpret_cast<char *>(row_base) + byte_off) = v;
@@ -543,9 +547,10 @@ __device__ __forceinline__ void chan_p2_term(const float4 a, const float4 b, con
 
 // request the input of `tile` (rows f0 - 7 .. f0 + nf - 1 as one flat run of float4) into registers.  Every element of `pre`
 // is assigned (zero where there is nothing to load) so that the registers are dead between a commit and the next request.
-template <bool FIRST /* the tile may reach back into the carried history (tile 0 only) */>
+template <bool FIRST /* the tile may reach back into the carried history (tile 0 only) */, int TF>
 __device__ __forceinline__ void chan_p2_request(const float2 *__restrict__ x, const float2 *__restrict__ hist, int M, int64_t n_frames, int64_t tile,
-                                                bool valid, float4 (&pre)[kP2Pre]) {
+                                                bool valid, float4 (&pre)[P2Tile<TF>::pre]) {
+    constexpr int kP2Frames = TF, kP2Threads = P2Tile<TF>::threads, kP2Pre = P2Tile<TF>::pre;
     const int tid = threadIdx.x;
     const int64_t f0 = tile * kP2Frames, Hs = (int64_t)(kChanTaps - 1) * M;
     const int nf = (int)min((int64_t)kP2Frames, n_frames - f0);
@@ -577,14 +582,16 @@ __device__ __forceinline__ void chan_p2_request(const float2 *__restrict__ x, co
 
 // MX = true: the DFT phase runs on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32), see "DFT on the matrix pipe" below; `cs` then is
 // the coefficient-fragment table of chan_mx_table().
-template <int KP, bool MX = false>
-__global__ __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
+template <int KP, bool MX = false, int TF = 64>
+__global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
     const float2 *__restrict__ x, const float2 *__restrict__ hist, float2 *__restrict__ hist_new,
     const float *__restrict__ tapsT,      // [8][M]
     const float2 *__restrict__ cs,        // [(A-1)/2][PA]: (cos, sin)(2 pi k(q) c / A) at [(c - 1) PA + q]; slot q: k = q + 1 (q < H), k = 0 (q == H), else (0, 0)
     const float2 *__restrict__ twM,       // [A][2]: exp(-j 2 pi k1 c2 / M) at [2 k1 + c2]
     const int *__restrict__ active, ChanGeom g, int64_t n_frames,
     float2 *__restrict__ out, int64_t out_stride, d2 *__restrict__ dc_ends, double dc_c) {
+    static_assert(TF == 64 || (MX && TF == 32), "the vector form's DFT phase has one frame per lane: 64-frame tiles");
+    constexpr int kP2Frames = TF, kP2Waves = P2Tile<TF>::waves, kP2Threads = P2Tile<TF>::threads, kP2Pre = P2Tile<TF>::pre, kCt = P2Tile<TF>::ctiles;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *rows = reinterpret_cast<float4 *>(smem);          // row r (input row f0 + r - 7, later X[r]) at rows + r A
     const int M = g.M, A = g.A, H = (A - 1) >> 1;
@@ -603,15 +610,23 @@ __global__ __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
     }
     // MX: this wave's coefficient fragments stay in registers for the whole launch (persistent workgroup)
     float mxc[kMxSteps], mxs[kMxSteps];
+    float2 mx_wk[4], mx_wn[4];                                  // W_M^k of this lane's four outputs k and of their partners A - k
+    int mx_on[4];                                               // consumer flags of rows k, k + A, A - k, 2 A - k (bits 0..3)
     if constexpr (MX) {
-        const float *tab = reinterpret_cast<const float *>(cs) + (size_t)(wave >> 2) * kMxSteps * 64 + lane0;
+        const float *tab = reinterpret_cast<const float *>(cs) + (size_t)(wave / kCt) * kMxSteps * 64 + lane0;
 #pragma unroll
         for (int J = 0; J < kMxSteps; ++J) { mxc[J] = tab[J * 64]; mxs[J] = tab[(2 * kMxSteps + J) * 64]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = min(16 * (wave / kCt) + 4 * (lane0 >> 4) + r, H), kn = k ? A - k : 0;
+            mx_wk[r] = twM[2 * k + 1]; mx_wn[r] = twM[2 * kn + 1];
+            mx_on[r] = (active[k] ? 1 : 0) | (active[k + A] ? 2 : 0) | (active[kn] ? 4 : 0) | (active[kn + A] ? 8 : 0);
+        }
     }
     float4 pre[kP2Pre];
     int64_t tile = blockIdx.x;
-    if (tile == 0) chan_p2_request<true>(x, hist, M, n_frames, tile, true, pre);
-    else chan_p2_request<false>(x, hist, M, n_frames, tile, tile < n_tiles, pre);
+    if (tile == 0) chan_p2_request<true, TF>(x, hist, M, n_frames, tile, true, pre);
+    else chan_p2_request<false, TF>(x, hist, M, n_frames, tile, tile < n_tiles, pre);
     for (; tile < n_tiles; tile += gridDim.x) {
         const int64_t f0 = tile * kP2Frames;
         const int nf = (int)min((int64_t)kP2Frames, n_frames - f0);
@@ -657,7 +672,7 @@ __global__ __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
         }
         lds_barrier();
         // the next tile's input is on its way while this one is transformed
-        chan_p2_request<false>(x, hist, M, n_frames, tile + gridDim.x, tile + gridDim.x < n_tiles, pre);
+        chan_p2_request<false, TF>(x, hist, M, n_frames, tile + gridDim.x, tile + gridDim.x < n_tiles, pre);
         if constexpr (MX) {
         // ---- DFT on the matrix pipe.  The conjugate-pair sums are two real matrix products per component:
         //        P[k][t] = sum_n Cos[k][n] s_n[t]      Q[k][t] = sum_n Sin[k][n] d_n[t]        k, n = 0 .. H   (s_0 = x_0, Cos[k][0] = 1, Sin[k][0] = 0)
@@ -668,7 +683,7 @@ __global__ __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
         //      k = 16 rt + 4 q + r (r = 0..3) of that frame for all eight, so the radix-2 butterfly and the stores stay in-lane.
         //      An MFMA is a k-ordered fmaf chain: the accumulation order (n ascending, starting from x_0) is the VALU form's, and so
         //      are the results, bit for bit.  64 MFMAs (2048 matrix-pipe cycles) per wave and tile against ~70 VALU instructions.
-        const int q = lane >> 4, t = 16 * (wave & 3) + (lane & 15), rt = wave >> 2;
+        const int q = lane >> 4, t = 16 * (wave % kCt) + (lane & 15), rt = wave / kCt;
         const float4 *row = rows + t * A;
         const bool tv = t < nf;
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -689,24 +704,53 @@ __global__ __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
             Q1r = csdr_mfma16(mxs[J], dv.z, Q1r); Q1i = csdr_mfma16(mxs[J], dv.w, Q1i);
             a = a2; b = b2;
         }
-        float2 *ob = out + f0 + t;
+        // Epilogue.  The radix-2 butterfly is in-lane; the stores are not lane-friendly as they stand: a lane group holds 16 frames of
+        // FOUR different channel rows, i.e. 128-byte pieces 8 MB apart.  g.mx == 2 (default) passes the tile through the (now free)
+        // row array so that every store instruction writes 512 contiguous bytes of ONE channel row, as the vector form does;
+        // g.mx == 1 stores straight from the accumulators (measured slower: scattered partial rows).
+        const bool staged = (g.mx & 1) == 0;                         // mx = 2 / 4
+        if (staged) lds_barrier();                                  // every wave has read its last input rows: the array is free
+        float2 *stage = reinterpret_cast<float2 *>(rows);           // [k][64 frames]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int k = 16 * rt + 4 * q + r;
-            if (k <= H && tv) {
+            if (k <= H) {
                 const int kn = A - k;
                 const float2 P0 = make_float2(P0r[r], P0i[r]), Q0 = make_float2(Q0r[r], Q0i[r]), P1 = make_float2(P1r[r], P1i[r]), Q1 = make_float2(Q1r[r], Q1i[r]);
-                const float2 wk = twM[2 * k + 1];
-                const float2 z0k = make_float2(P0.x + Q0.y, P0.y - Q0.x);
+                const float2 wk = mx_wk[r], wn = mx_wn[r];
+                const float2 z0k = make_float2(P0.x + Q0.y, P0.y - Q0.x), z0n = make_float2(P0.x - Q0.y, P0.y + Q0.x);
                 const float2 u = cmul(make_float2(P1.x + Q1.y, P1.y - Q1.x), wk);
-                if (active[k]) ob[(int64_t)k * out_stride] = make_float2(z0k.x + u.x, z0k.y + u.y);
-                if (active[k + A]) ob[(int64_t)(k + A) * out_stride] = make_float2(z0k.x - u.x, z0k.y - u.y);
-                if (k > 0) {                                        // k = 0 has no conjugate partner
-                    const float2 wn = twM[2 * kn + 1];
-                    const float2 z0n = make_float2(P0.x - Q0.y, P0.y + Q0.x);
-                    const float2 v = cmul(make_float2(P1.x - Q1.y, P1.y + Q1.x), wn);
-                    if (active[kn]) ob[(int64_t)kn * out_stride] = make_float2(z0n.x + v.x, z0n.y + v.y);
-                    if (active[kn + A]) ob[(int64_t)(kn + A) * out_stride] = make_float2(z0n.x - v.x, z0n.y - v.y);
+                const float2 v = cmul(make_float2(P1.x - Q1.y, P1.y + Q1.x), wn);
+                const float2 y0 = make_float2(z0k.x + u.x, z0k.y + u.y), y1 = make_float2(z0k.x - u.x, z0k.y - u.y);
+                const float2 y2 = make_float2(z0n.x + v.x, z0n.y + v.y), y3 = make_float2(z0n.x - v.x, z0n.y - v.y);
+                if (staged) {
+                    stage[k * kP2Frames + t] = y0; stage[(k + A) * kP2Frames + t] = y1;
+                    if (k > 0) { stage[kn * kP2Frames + t] = y2; stage[(kn + A) * kP2Frames + t] = y3; }      // k = 0 has no conjugate partner
+                } else if (tv) {
+                    float2 *ob = out + f0 + t;
+                    const int on = mx_on[r];
+                    if (on & 1) ob[(int64_t)k * out_stride] = y0;
+                    if (on & 2) ob[(int64_t)(k + A) * out_stride] = y1;
+                    if (k > 0) {
+                        if (on & 4) ob[(int64_t)kn * out_stride] = y2;
+                        if (on & 8) ob[(int64_t)(kn + A) * out_stride] = y3;
+                    }
+                }
+            }
+        }
+        if (staged) {
+            lds_barrier();
+            // rows wave, wave + 8, ...: lane = frame, one 512-byte run per row (scalar row base + lane offset)
+            float2 *ob = out + f0;
+            constexpr int kRowsPer = 64 / TF;                         // channel rows one store instruction covers (lanes run along the frames)
+            const int tl = lane % TF, kofs = lane / TF;
+            const unsigned tb = (unsigned)tl * (unsigned)sizeof(float2);
+            const bool lv = tl < nf;
+            for (int k0 = wave * kRowsPer; k0 < M; k0 += kP2Waves * kRowsPer) {
+                const int k = k0 + kofs;
+                if (k < M) {
+                    const float2 yv = stage[k * kP2Frames + tl];
+                    if (active[k] && lv) store_row(ob + (int64_t)k * out_stride, tb, yv);
                 }
             }
         }
@@ -717,7 +761,7 @@ __global__ __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
             const double wgt = mine ? dc_pow(dc_c, nf - 1 - t) : 0.0;
             double vx = mine ? wgt * (double)(P0r[0] + P1r[0]) : 0.0, vy = mine ? wgt * (double)(P0i[0] + P1i[0]) : 0.0;
             for (int s2 = 8; s2 > 0; s2 >>= 1) { vx += __shfl_down(vx, s2, 64); vy += __shfl_down(vy, s2, 64); }
-            if (lane == 0) dc_part[wave & 3] = d2{vx, vy};
+            if (lane == 0) dc_part[wave % kCt] = d2{vx, vy};
         }
         } else {
         // ---- DFT: lane = frame t; wave = pass of KP output-pair slots
@@ -799,7 +843,7 @@ __global__ __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
         if constexpr (MX) {
             if (dc_ends && tid0 == 0) {
                 d2 v = dc_part[0];
-                for (int i = 1; i < 4; ++i) { v.x += dc_part[i].x; v.y += dc_part[i].y; }
+                for (int i = 1; i < kCt; ++i) { v.x += dc_part[i].x; v.y += dc_part[i].y; }
                 dc_ends[tile] = v;
             }
         }

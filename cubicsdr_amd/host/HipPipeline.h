@@ -107,7 +107,7 @@ public:
     bool isActive() { return active_.load(); }
     void setSquelchEnabled(bool e) { squelchEnabled_.store(e); }
     bool isSquelchEnabled() { return squelchEnabled_.load(); }
-    void setSquelchLevel(float l) { squelchLevel_.store(l); }
+    void setSquelchLevel(float l) { if (!squelchEnabled_.load()) squelchEnabled_.store(true); squelchLevel_.store(l); }   // setting a level switches the squelch on (DemodulatorThread.cpp:392-397)
     float getSquelchLevel() { return squelchLevel_.load(); }
     void setMuted(bool m) { muted_.store(m); }
     bool isMuted() { return muted_.load(); }

@@ -264,3 +264,124 @@ class RefWavCpp:
             self.L.refwav_close(self.h)
             self.L.refwav_destroy(self.h)
             self.h = None
+
+
+# ---- the reference's own DemodulatorThread::run (oracle/_ref/libref_demodthread.so, oracle/ref/demod_thread_harness.cpp) ------------
+_DTLIB = None
+
+
+def demodthread_available():
+    return A.available("ref") and os.path.exists(os.path.join(_HERE, "_ref", "libref_demodthread.so"))
+
+
+def load_demodthread():
+    global _DTLIB
+    if _DTLIB is None:
+        A.load("ref")
+        L = C.CDLL(os.path.join(_HERE, "_ref", "libref_demodthread.so"))
+        L.refdt_create.restype = C.c_void_p; L.refdt_create.argtypes = [C.c_int, C.c_longlong, C.c_int]
+        L.refdt_set.restype = None; L.refdt_set.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int]
+        L.refdt_block.restype = C.c_int
+        L.refdt_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.refdt_destroy.restype = None; L.refdt_destroy.argtypes = [C.c_void_p]
+        _DTLIB = L
+    return _DTLIB
+
+
+class RefDemodThreadCpp:
+    """DemodulatorThread of the reference on its own thread; block(iq, audio) runs one input through run() and reports what it left behind"""
+
+    def __init__(self, use_signal_output, modem_rate=12500, audio_rate=48000):
+        self.L = load_demodthread()
+        self.rate = int(modem_rate)
+        self.h = self.L.refdt_create(int(use_signal_output), self.rate, int(audio_rate))
+
+    def set(self, squelch_enabled=False, squelch_level=-100.0, muted=False):
+        self.L.refdt_set(self.h, int(squelch_enabled), float(squelch_level), int(muted))
+
+    def block(self, iq, audio, channels=1):
+        iq = np.ascontiguousarray(iq, dtype=np.complex64); audio = np.ascontiguousarray(audio, dtype=np.float32)
+        out = np.zeros(11, np.float64); tap = np.zeros(8192, np.float32)
+        ok = self.L.refdt_block(self.h, iq.ctypes.data_as(C.c_void_p), iq.size, self.rate, audio.ctypes.data_as(C.c_void_p), audio.size, int(channels),
+                                out.ctypes.data_as(C.c_void_p), tap.ctypes.data_as(C.c_void_p), tap.size)
+        if not ok:
+            raise RuntimeError("the reference demodulator thread did not answer")
+        return dict(level=np.float32(out[0]), floor=np.float32(out[1]), ceil=np.float32(out[2]), squelch_break=bool(out[3]), pushed=bool(out[4]), peak=np.float32(out[5]),
+                    tap=(tap[:int(out[7])].copy() if out[6] else None), tap_input_rate=int(out[8]), tap_sample_rate=int(out[9]), tap_type=int(out[10]))
+
+    def close(self):
+        if self.h:
+            self.L.refdt_destroy(self.h)
+            self.h = None
+
+
+# ---- the reference's own SDRPostThread::run (oracle/_ref/libref_post.so, oracle/ref/post_harness.cpp) ------------------------------
+_PLIB = None
+
+
+def post_available():
+    return A.available("ref") and os.path.exists(os.path.join(_HERE, "_ref", "libref_post.so"))
+
+
+def load_post():
+    global _PLIB
+    if _PLIB is None:
+        A.load("ref")
+        L = C.CDLL(os.path.join(_HERE, "_ref", "libref_post.so"))
+        L.refpost_create.restype = C.c_void_p; L.refpost_create.argtypes = [C.c_int]
+        L.refpost_add_demod.restype = C.c_int; L.refpost_add_demod.argtypes = [C.c_void_p, C.c_longlong, C.c_int]
+        L.refpost_set_demod_frequency.restype = None; L.refpost_set_demod_frequency.argtypes = [C.c_void_p, C.c_int, C.c_longlong]
+        L.refpost_notify.restype = None; L.refpost_notify.argtypes = [C.c_void_p]
+        L.refpost_set_app.restype = None; L.refpost_set_app.argtypes = [C.c_longlong, C.c_longlong]
+        L.refpost_block.restype = C.c_int; L.refpost_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_void_p, C.c_int]
+        L.refpost_fetch.restype = C.c_int; L.refpost_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.refpost_fetch_visual.restype = C.c_int; L.refpost_fetch_visual.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.refpost_destroy.restype = None; L.refpost_destroy.argtypes = [C.c_void_p]
+        _PLIB = L
+    return _PLIB
+
+
+class RefPostThreadCpp:
+    """SDRPostThread of the reference on its own thread with n demodulators attached"""
+
+    def __init__(self, center, rate, oversampled=False):
+        self.L = load_post()
+        self.L.refpost_set_app(int(center), int(rate))
+        self.h = self.L.refpost_create(int(oversampled))
+        self.n = 0
+
+    def add_demod(self, frequency, current=False):
+        self.n = self.L.refpost_add_demod(self.h, int(frequency), int(current)) + 1
+        return self.n - 1
+
+    def set_demod_frequency(self, i, f):
+        self.L.refpost_set_demod_frequency(self.h, int(i), int(f))
+
+    def notify(self):
+        self.L.refpost_notify(self.h)
+
+    def block(self, x, frequency, rate, num_channels):
+        """-> list of isActive() per demodulator after the block"""
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        act = np.zeros(max(self.n, 1), np.int32)
+        if not self.L.refpost_block(self.h, x.ctypes.data_as(C.c_void_p), x.size, int(frequency), int(rate), int(num_channels), act.ctypes.data_as(C.c_void_p), self.n):
+            raise RuntimeError("the reference post thread did not finish the block")
+        return [bool(a) for a in act[:self.n]]
+
+    def _fetch(self, fn, *args):
+        buf = np.empty(1 << 22, np.complex64); meta = np.zeros(2, np.int64)
+        n = fn(self.h, *args, buf.ctypes.data_as(C.c_void_p), buf.size, meta.ctypes.data_as(C.c_void_p))
+        assert n >= 0
+        return None if n == 0 else (buf[:n].copy(), int(meta[0]), int(meta[1]))
+
+    def fetch(self, i):
+        """what demodulator i's input pipe received for the last block: (samples, frequency, sampleRate) or None"""
+        return self._fetch(self.L.refpost_fetch, int(i))
+
+    def fetch_visual(self, which):
+        return self._fetch(self.L.refpost_fetch_visual, int(which))
+
+    def close(self):
+        if self.h:
+            self.L.refpost_destroy(self.h)
+            self.h = None

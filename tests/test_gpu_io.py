@@ -104,11 +104,47 @@ def test_scope_matches_reference_processor(ctx):
     print("audio scope against the reference's ScopeVisualProcessor: worst %.3g" % scope_scenario(ctx))
 
 
+def test_scope_tap_is_the_modems_demod_output(ctx):
+    """csdr_bank_fetch_demod_output = ModemAnalog::getDemodOutputData of the last block (the gain-scaled demodulator output in front of the audio
+    resampler, whole block, at most DEMOD_VIS_SIZE samples): compared with the reference's OWN modem classes (libref_modems.so) fed the same
+    resampled IQ block by block -- NBFM, AM at 6 kHz (interpolating audio), AM at 100 kHz and FM at 200 kHz (decimating audio cascades, whose
+    trailing samples of a block are only consumed by the NEXT block's outputs), USB."""
+    import oracle.ref_modems as RM
+    from cubicsdr_amd.engine import DemodBank, SDRPost
+    _need(RM.available(), "libref_modems.so")
+    fs, M, block, center = 2400000, 4, 40000, 100000000
+    kinds = [("NBFM", 12500), ("AM", 6000), ("AM", 100000), ("FM", 200000), ("USB", 5400)]
+    freqs = demod_frequencies(center, fs, len(kinds))
+    post = SDRPost(ctx, fs, M, block, max_blocks=1)
+    bank = DemodBank(ctx, len(kinds), max_blocks=1)
+    refs = [RM.RefModem(k, bw) for k, bw in kinds]
+    for i, ((k, bw), f) in enumerate(zip(kinds, freqs)):
+        bank.configure(i, post, k, bw, f)
+    worst = 0.0
+    for b in range(4):
+        x = synth_iq(block, fs, center, [(k, f) for (k, _), f in zip(kinds, freqs)], seed=300 + b, t0=b * block)
+        post.execute(x, 1, block, center)
+        bank.execute(post)
+        for i, (k, bw) in enumerate(kinds):
+            iq = bank.iq(i)
+            refs[i].demodulate(iq)
+            want = refs[i].demod_output()[:2048]
+            got = bank.demod_output(i)
+            assert got.size == want.size == min(iq.size, 2048), (b, k, bw, got.size, want.size, iq.size)
+            e = rel_err(got, want)
+            assert e < TOL, (b, k, bw, e)
+            worst = max(worst, e)
+    print("scope tap against the reference modems' demodOutputData: worst %.3g" % worst)
+    for r in refs:
+        r.close()
+    bank.close(); post.close()
+
+
 def test_scope_taps_read_in_place_from_the_bank(ctx):
-    """csdr_bank_scope_frame: the tap of DemodulatorThread.cpp:240-316 as a device-resident frame -- NBFM (audio tap), USB (demodulator-output
-    tap: the audio is decimated... no: 5.4 kHz -> 48 kHz interpolates, so AM at 100 kHz stands in for the decimated case), I/Q (0.75 x re | im),
-    FM stereo (left | right, labelled 36000) -- through csdr_scope on the device, against the reference scope fed the AudioThreadInput the
-    reference's statements would have assembled from the fetched audio."""
+    """csdr_bank_scope_frame: the tap of DemodulatorThread.cpp:240-316 as a device-resident frame -- NBFM and USB (audio tap: more audio than
+    IQ samples), AM at 100 kHz (demodulator-output tap), I/Q (0.75 x re | im), FM stereo (left | right, labelled 36000) -- through csdr_scope
+    on the device, against the reference scope fed the AudioThreadInput the reference's statements would have assembled from the fetched
+    audio / tap (the tap's content itself: test_scope_tap_is_the_modems_demod_output)."""
     import oracle.ref_modems as RM
     from cubicsdr_amd.engine import DemodBank, ScopeProcessor, SDRPost
     _need(RM.scope_available(), "libref_scope.so")

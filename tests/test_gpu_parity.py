@@ -139,7 +139,7 @@ def test_channelizer_matrix_pipe_equals_vector_form_bit_for_bit(ctx, M, frames):
     outs = []
     saved = os.environ.get("CSDR_CHAN_MX")
     try:
-        for mx in ("1", "0"):
+        for mx in ("0", "1", "2", "3", "4"):                          # vector form, then the four matrix-pipe variants (csdr_api.hip: chan_geometry)
             os.environ["CSDR_CHAN_MX"] = mx
             p = SDRPost(ctx, fs, M, block, max_blocks=3)
             p.execute(x, 3, block, center)
@@ -150,8 +150,9 @@ def test_channelizer_matrix_pipe_equals_vector_form_bit_for_bit(ctx, M, frames):
             os.environ.pop("CSDR_CHAN_MX", None)
         else:
             os.environ["CSDR_CHAN_MX"] = saved
-    for ch, (a, b) in enumerate(zip(*outs)):
-        assert a.size == 3 * frames and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (M, ch, float(np.max(np.abs(a - b))))
+    for v in range(1, 5):
+        for ch, (a, b) in enumerate(zip(outs[0], outs[v])):
+            assert a.size == 3 * frames and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (M, v, ch, float(np.max(np.abs(a - b))))
 
 
 def test_channelizer_batched_equals_blockwise(ctx):

@@ -346,3 +346,116 @@ def test_python_line_pacing_equals_the_reference_distributor(fft, lps, rate, blk
         lines += m
     assert lines > 3
     L.refdist_destroy(h)
+
+
+@pytest.mark.parametrize("use_signal_output", [False, True])
+def test_level_squelch_restatement_equals_the_reference_demodulator_thread(use_signal_output):
+    """oracle/cubicsdr_chain.py RefLevelSquelch -- the checker cubicsdr_amd/host/DemodLevel.h is held to -- against the reference's OWN
+    src/demod/DemodulatorThread.cpp running on its thread (oracle/_ref/libref_demodthread.so), fed 300 blocks through a feed modem: quiet and
+    loud stretches, empty audio, the squelch switched on with a moving threshold, muting.  Signal level / floor / ceiling bit for bit
+    (float32), the squelch-break flag, whether the audio was pushed on, the audio peak, and the scope tap rule (audio when it outnumbers the
+    block's IQ samples, else the modem's demodulator output; at most DEMOD_VIS_SIZE samples; the rates it is labelled with)."""
+    from oracle import ref_modems as RM
+    from oracle.cubicsdr_chain import RefLevelSquelch
+    if not RM.demodthread_available():
+        pytest.skip("oracle/_ref/libref_demodthread.so is built only where /root/reference is")
+    rng = np.random.default_rng(17)
+    ref = RM.RefDemodThreadCpp(use_signal_output, 12500, 48000)
+    py = RefLevelSquelch()
+    flips = pushed = taps_audio = taps_demod = 0
+    last = None
+    for b in range(300):
+        n_iq = 208 + b % 3
+        loud = (b // 40) % 2 == 1
+        amp = 0.25 if loud else 0.003
+        iq = (amp * (rng.standard_normal(n_iq) + 1j * rng.standard_normal(n_iq))).astype(np.complex64)
+        n_audio = 0 if b % 23 == 7 else (150 if b % 5 == 4 else 800 + b % 2)          # empty audio; fewer audio samples than IQ samples; the usual 800
+        audio = (amp * 2.0 * rng.standard_normal(n_audio)).astype(np.float32)
+        sq = 100 <= b < 260
+        sl = -30.0 if b < 180 else -8.0
+        muted = 270 <= b < 280
+        ref.set(sq, sl, muted)
+        got = ref.block(iq, audio)
+        have = n_audio > 0
+        if use_signal_output:
+            accum, count = float(np.sum(np.abs(audio.astype(np.float64)))), n_audio
+        else:
+            accum, count = float(np.sum(np.sqrt(iq.real.astype(np.float64) ** 2 + iq.imag.astype(np.float64) ** 2))), n_iq
+        squelched = py.step(have, accum, count, float(n_iq) / 12500.0, sq, sl)
+        assert got["level"] == py.level and got["floor"] == py.floor and got["ceil"] == py.ceil, (b, got, py.level, py.floor, py.ceil)
+        assert got["squelch_break"] == py.squelch_break, b
+        assert got["pushed"] == (not squelched and not muted), (b, got["pushed"], squelched, muted)
+        assert got["peak"] == (np.float32(np.max(np.abs(audio))) if n_audio else np.float32(0)), b
+        # scope tap (:240-316): only un-squelched blocks; audio when numAudioWritten > bufSize, else getDemodOutputData (here: Re of the IQ)
+        if squelched:
+            assert got["tap"] is None, b
+        else:
+            assert got["tap"] is not None, b
+            if n_audio > n_iq:
+                assert np.array_equal(got["tap"], audio[:2048]) and got["tap_input_rate"] == 48000 and got["tap_sample_rate"] == 12500, b
+                taps_audio += 1
+            else:
+                assert np.array_equal(got["tap"], iq.real[:2048]) and got["tap_input_rate"] == 12500 and got["tap_sample_rate"] == 12500, b
+                taps_demod += 1
+            assert got["tap_type"] == 0
+        flips += last is not None and squelched != last
+        last = squelched
+        pushed += got["pushed"]
+    ref.close()
+    assert flips >= 2 and pushed > 50 and taps_audio > 20 and taps_demod > 5, (flips, pushed, taps_audio, taps_demod)
+
+
+@pytest.mark.parametrize("fs,M,oversampled", [(2400000, 4, False), (6100000, 122, False), (2400000, 4, True), (480000, 1, False)])
+def test_post_restatement_equals_the_reference_post_thread(fs, M, oversampled):
+    """oracle/cubicsdr_chain.py RefSDRPost -- the checker of every GPU channelizer / routing test -- against the reference's OWN
+    src/sdr/SDRPostThread.cpp running on its thread on the reference's liquid binary (oracle/_ref/libref_post.so): what every demodulator
+    finds in its input pipe after each block -- the channel it was routed to (its centre frequency stamp), the channel rate, the samples
+    (channel 0 behind the DC blocker, the wrap channel) -- bit for bit, for M = 4, M = 122 (the headline channel count), the oversampled
+    analyzer and single-channel mode; the active list after a retune that moves demodulators out of range; the visual queues."""
+    from oracle import ref_modems as RM
+    if not RM.post_available():
+        pytest.skip("oracle/_ref/libref_post.so is built only where /root/reference is")
+    center = 100000000
+    block = (fs // 60 // M) * M if M > 1 else 8000
+    ref = RM.RefPostThreadCpp(center, fs, oversampled)
+    py = RefSDRPost("ref", fs, M, oversampled=oversampled)
+    chan_bw = fs // M
+    # demodulators: off-centre ones, one exactly on a channel edge (tie -> the lower index wins), one at the wrap channel, one on channel 0
+    freqs = [center + 3700, center + chan_bw // 2, center + fs // 2 - 1000, center - fs // 2 + chan_bw + 900, center - chan_bw - 250] if M > 1 else [center + 10000, center - 50000]
+    for i, f in enumerate(freqs):
+        ref.add_demod(f, current=(i == 0))
+    ref.notify()
+    rng = np.random.default_rng(9)
+    t = np.arange(block)
+    checked = 0
+    for b in range(6):
+        cf = center if b < 4 else center + fs // 2 + chan_bw            # the last blocks: a retune that leaves some demodulators out of range
+        x = (0.1 * (rng.standard_normal(block) + 1j * rng.standard_normal(block)) + 0.3 * np.exp(2j * np.pi * 0.013 * (t + b * block)) + (0.01 + 0.01j)).astype(np.complex64)
+        active = ref.block(x, cf, fs, M)                                # (the first block builds the channelizer AND the active list before it runs, :418-430)
+        py.run_block(x, cf)
+        cache = {}                                                       # one buffer per channel and block, shared by its demodulators (:341-396)
+        for i, f in enumerate(freqs):
+            got = ref.fetch(i)
+            in_range = abs(cf - f) <= fs // 2
+            if b >= 4 and not in_range:
+                # the block that FOLLOWS the retune still runs the old list (:187-200): only from the next one on is the demodulator off
+                if b == 5:
+                    assert got is None and not active[i], (b, i)
+                continue
+            if got is None:
+                continue
+            ch = py.channel_at(f)
+            if ch not in cache:
+                cache[ch] = py.channel_data(ch)
+            want, fc, rate = cache[ch]
+            assert got[1] == fc and got[2] == rate, (b, i, got[1], fc, got[2], rate)
+            assert got[0].size == want.size and np.array_equal(got[0].view(np.uint32), want.view(np.uint32)), (b, i)
+            checked += 1
+        vis = ref.fetch_visual(0)
+        assert vis is not None and vis[1] == cf and vis[2] == fs
+        if M == 1:
+            assert np.array_equal(vis[0], py.data_out)                   # single-channel mode shows the DC-corrected block (:284-299)
+        else:
+            assert np.array_equal(vis[0], x)                             # the full-rate copy (:221-245)
+    ref.close()
+    assert checked >= (8 if M > 1 else 4), checked
