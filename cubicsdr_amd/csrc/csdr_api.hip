@@ -889,7 +889,6 @@ static int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *
     if (fms) {
         // csdr_demod_params::modem_arg = the "demph" setting (ModemFMStereo.cpp:42-81): microseconds, 0 -> the default 75, < 0 -> none
         const int demph = s.prm.modem_arg == 0 ? 75 : (s.prm.modem_arg < 0 ? 0 : s.prm.modem_arg);
-        if (s.au.interp) return fail(CSDR_EUNSUPPORTED, "FM stereo at %d Hz into %d Hz audio: the audio resamplers must decimate", s.prm.bandwidth, s.prm.audio_sample_rate);
         fms_fir = design::fms_output_fir(s.prm.audio_sample_rate, demph, kFmsFirMax);
         if (fms_fir.empty()) return fail(CSDR_EUNSUPPORTED, "FM stereo output filter at %d Hz exceeds %d taps", s.prm.audio_sample_rate, kFmsFirMax);
     }
@@ -1075,7 +1074,9 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         const bool iq_modem = s.prm.modem == CSDR_MODEM_IQ || fe_only;      // no audio resampler: 2 floats per resampled IQ sample
         const bool au_interp = s.au.interp;
         const bool fms = s.prm.modem == CSDR_MODEM_FMS;          // two floats (left, right) per audio sample
-        const int ash = (iq_modem || fms) ? 1 : (au_interp ? aS : 0);     // floats written per arbitrary-stage output = 2^ash
+        // floats written per arbitrary-stage output = 2^ash: an interpolating audio resampler fans every arbitrary-stage output out to
+        // 2^aS samples; I/Q and FM stereo write two floats per sample (FM stereo with either kind of resampler, ModemFMStereo.cpp:91-105)
+        const int ash = iq_modem ? 1 : (au_interp ? aS : 0) + (fms ? 1 : 0);
         const bool iq_interp = s.iq.interp;      // arbitrary stage first: it consumes the channel samples directly, each output fans out to 2^S
         for (int bb = 0; bb <= NB; ++bb) {
             const int64_t K = iq_interp ? (int64_t)bb * Bc : (((int64_t)s.buf_idx + (int64_t)bb * Bc) >> S);

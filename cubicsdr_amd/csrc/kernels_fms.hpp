@@ -19,7 +19,7 @@
 namespace csdr {
 
 constexpr int kFmsYHist = 32;        // down-mixed samples kept in front of a batch (c2r Hilbert window: 4 m = 20)
-constexpr int kFmsFirMax = 1024;     // longest de-emphasis * low-pass response (175 + ~70 taps at 48 kHz)
+constexpr int kFmsFirMax = 2048;     // longest de-emphasis * low-pass response (175 + ~70 taps at 48 kHz; ~1400 at 192 kHz)
 constexpr int kFmsStateWords = 24;   // v1, v2 of five sections (re, im) + phase word + frequency word
 
 __device__ inline float fms_freqdem(const float2 *iq, int64_t j) {
@@ -167,7 +167,9 @@ __global__ __launch_bounds__(64) void fms_out(const SlotCfg *__restrict__ cfgs, 
     const int L = cfg.fms_fir_len, H = L - 1;
     float *s_l = reinterpret_cast<float *>(smem), *s_rt = s_l + cap_au + kFmsFirMax, *s_g = s_rt + cap_au + kFmsFirMax;
     float *s_redf = s_g + kFmsFirMax;
-    const int a0 = pl[b].q0, n = pl[b + 1].q0 - a0;
+    // audio samples of this block per channel: one per arbitrary-stage output of the two audio resamplers, 2^S each when they interpolate
+    const int ush = cfg.rs_au.interp ? cfg.rs_au.S : 0;
+    const int a0 = pl[b].q0 << ush, n = (pl[b + 1].q0 << ush) - a0;
     const float *uh_in = cfg.fms_uh + (size_t)2 * kFmsFirMax * dyn.hist_parity;
     for (int i = tid; i < L; i += nthr) s_g[i] = cfg.fms_fir[i];
     for (int i = tid; i < n + H; i += nthr) {
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(64) void fms_out(const SlotCfg *__restrict__ cfgs, 
     const float pk = block_max_float(lpk, s_redf);
     if (tid == 0) cfg.bout[b].audio_peak = pk;
     if (b == NB - 1) {
-        const int A = pl[NB].q0;
+        const int A = pl[NB].q0 << ush;
         float *uh_out = cfg.fms_uh + (size_t)2 * kFmsFirMax * (dyn.hist_parity ^ 1);
         for (int t = tid; t < kFmsFirMax; t += nthr) {
             const int a = A - kFmsFirMax + t;

@@ -527,7 +527,8 @@ def _fms_case(ctx, fs, M, block, n_blocks, batch, bw=200000, seed=31, audio_rate
                 theta_rms=float(np.sqrt(np.mean(dth[n0:] ** 2))))
 
 
-@pytest.mark.parametrize("bw,audio_rate,demph", [(250000, 44100, 50), (150000, 48000, 0), (50000, 48000, 75)])
+@pytest.mark.parametrize("bw,audio_rate,demph", [(250000, 44100, 50), (150000, 48000, 0), (50000, 48000, 75),
+                                                 (100000, 192000, 75), (100000, 120000, 50)])     # the last two: audio ABOVE the modem rate (interpolating audio resamplers, ModemFMStereo.cpp:91-105)
 def test_fm_stereo_settings(ctx, bw, audio_rate, demph):
     """other modem rates (250 kHz; 150 kHz; 50 kHz -> checkSampleRate lifts it to 100 kHz), 44.1 kHz audio, 50 us and no de-emphasis"""
     print("fms", bw, audio_rate, demph, _fms_case(ctx, 2400000, 4, 40000, 4, 2, bw=bw, audio_rate=audio_rate, demph=demph, seed=37))
