@@ -121,7 +121,7 @@ extern "C" int csdr_ctx_timer_stop(csdr_ctx *c, float *ms) {
 // ---- per-kernel HIP-event profile (bench.py roofline leg) ----
 static const char *kKernelNames[KID_COUNT] = {
     "chan_analyze", "dc_tile_ends", "dc_apply", "rows_copy",
-    "demod_frontend_generic", "demod_frontend_s3", "demod_frontend_s4", "demod_frontend_s5", "demod_frontend_s6", "demod_frontend_interp",
+    "demod_frontend_generic", "demod_frontend_s3", "demod_frontend_s4", "demod_frontend_s5", "demod_frontend_s6", "demod_frontend_s56", "demod_frontend_interp",
     "demod_modem", "demod_gain_scan", "fms_stages", "demod_audio_interp", "fms_out", "audio_egress",
     "spec_fft_radix", "spec_fft_rows", "spec_average", "spec_extrema", "spec_display", "spec_misc"};
 static int prof_drain(csdr_ctx *c) {
@@ -1257,8 +1257,16 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         CSDR_LAUNCH(c, LANE_FE, KID_FE_S##S_, (demod_frontend_s<S_, CH_>), dim3(ranges_for(grp_n[S_]) + 1, grp_n[S_]), dim3(kFeThreads), (fes_lds_bytes<S_, CH_>()), \
                     b->cfgs.p, dyns_d, grp_d + grp_off[S_], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p)
     CSDR_FE_S(3, 2048); CSDR_FE_S(4, 2048);
-    if (grp_n[6] > 0) {          // depth 6 (AM / SSB from ~500 kS/s channels): tail wave with three tail stages (CSDR_FE_TW6=0: without)
-        static const bool tw6 = !(getenv("CSDR_FE_TW6") && atoi(getenv("CSDR_FE_TW6")) == 0);
+    static const bool tw6 = !(getenv("CSDR_FE_TW6") && atoi(getenv("CSDR_FE_TW6")) == 0);
+    static const bool fe_merge = !(getenv("CSDR_FE_MERGE") && atoi(getenv("CSDR_FE_MERGE")) == 0);
+    const bool merged = fe_merge && tw6 && grp_n[6] > 0 && grp_n[5] > 0;
+    if (merged) {
+        // both tail-wave depths in one launch: each group gets the range count one round of resident workgroups would give it alone
+        const int P6 = ranges_for(grp_n[6]), P5 = ranges_for(grp_n[5]);
+        CSDR_LAUNCH(c, LANE_FE, KID_FE_S56, demod_frontend_s56, dim3(std::max(P6, P5) + 1, grp_n[6] + grp_n[5]), dim3(kFeThreads + 64), (fes_lds_bytes<6, 2048>()),
+                    b->cfgs.p, dyns_d, grp_d + grp_off[6], grp_n[6], P6, grp_d + grp_off[5], P5, chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
+    }
+    if (grp_n[6] > 0 && !merged) {          // depth 6 (AM / SSB from ~500 kS/s channels): tail wave with three tail stages (CSDR_FE_TW6=0: without)
         if (tw6)
             CSDR_LAUNCH(c, LANE_FE, KID_FE_S6, (demod_frontend_s<6, 2048, true>), dim3(ranges_for(grp_n[6]) + 1, grp_n[6]), dim3(kFeThreads + 64), (fes_lds_bytes<6, 2048>()),
                         b->cfgs.p, dyns_d, grp_d + grp_off[6], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
@@ -1271,7 +1279,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         CSDR_LAUNCH(c, LANE_FE, KID_FE_INTERP, demod_frontend_interp, dim3(nchunks + 1, grp_n[7]), dim3(kFeThreads), kFiLds, b->cfgs.p, dyns_d, grp_d + grp_off[7],
                     chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
     }
-    if (grp_n[5] > 0)            // depth 5 (NBFM from ~500 kS/s channels): a fifth wave runs the one-wave tail one chunk behind
+    if (grp_n[5] > 0 && !merged)            // depth 5 (NBFM from ~500 kS/s channels): a fifth wave runs the one-wave tail one chunk behind
         CSDR_LAUNCH(c, LANE_FE, KID_FE_S5, (demod_frontend_s<5, 2048, true>), dim3(ranges_for(grp_n[5]) + 1, grp_n[5]), dim3(kFeThreads + 64), (fes_lds_bytes<5, 2048>()),
                     b->cfgs.p, dyns_d, grp_d + grp_off[5], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
 #undef CSDR_FE_S
@@ -1553,7 +1561,7 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     if (int rc = s->ext.reserve(max_frames)) return rc;
     if (int rc = s->pairsum.reserve(nfN / 2)) return rc;
     if (int rc = s->first_b.reserve(max_frames)) return rc;
-    if (int rc = s->points.reserve(nfN)) return rc;               // 2 * F floats per frame
+    if (int rc = s->points.reserve(nfN / 2)) return rc;           // F floats per frame: the y of every point (x = i / F is filled in by the fetch)
     if (int rc = s->ma.reserve(2 * F)) return rc;
     if (int rc = s->maa.reserve(2 * F)) return rc;
     if (int rc = s->fo.reserve(max_frames)) return rc;
@@ -1656,9 +1664,9 @@ static int spec_post_range(csdr_spec *s, const float *mag, int f0, int cnt, int 
     const int disp_gx = std::max(1, std::min((g.F / 2 + kDispThreads - 1) / kDispThreads, c->wg_slots(spec_display, kDispThreads, kDispLds) / std::max(1, cnt)));
     CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_DISPLAY, spec_display, dim3(disp_gx, cnt), dim3(kDispThreads), kDispLds,
                 s->pairsum.p + f0 * F, s->first_b.p + f0, s->ext.p + f0, cnt, g, s->scale, st_in, s->scal.p + (s->scal_parity ^ 1), s->fo.p + f0,
-                s->points.p + f0 * 2 * F, hold ? pk_from : cnt, hold ? s->pfo.p + f0 : (const SpecFrameOut *)nullptr,
+                s->points.p + f0 * F, hold ? pk_from : cnt, hold ? s->pfo.p + f0 : (const SpecFrameOut *)nullptr,
                 hold ? s->peaksum.p + f0 * F : (const float *)nullptr, hold ? s->peak_b.p + f0 : (const float *)nullptr,
-                hold ? s->hold_points.p + f0 * 2 * F : (float *)nullptr,
+                hold ? s->hold_points.p + f0 * F : (float *)nullptr,
                 view ? s->vmap.p : (const int2 *)nullptr, view ? s->maaf.p + f0 * F : (const float2 *)nullptr,
                 view && hold ? s->peakf.p + f0 * F : (const float2 *)nullptr);
     s->scal_parity ^= 1;
@@ -1690,7 +1698,7 @@ static int spec_post_frames(csdr_spec *s, const float *mag, int nf, int n_inputs
             if (int rc = s->maaf.reserve(nfF)) return rc;
             if (int rc = s->peaksum.reserve(nfF)) return rc;
             if (int rc = s->peak_b.reserve(s->max_frames)) return rc;
-            if (int rc = s->hold_points.reserve(2 * nfF)) return rc;
+            if (int rc = s->hold_points.reserve(nfF)) return rc;
             if (int rc = s->pfo.reserve(s->max_frames)) return rc;
         }
     }
@@ -1898,7 +1906,7 @@ static int spec_process_view(csdr_spec *s, const float *iq, int iq_is_dev, int b
         if (do_peak) {
             if (int rc = s->peaksum.reserve(nfF)) return rc;
             if (int rc = s->peak_b.reserve(s->max_frames)) return rc;
-            if (int rc = s->hold_points.reserve(2 * nfF)) return rc;
+            if (int rc = s->hold_points.reserve(nfF)) return rc;
             if (int rc = s->pfo.reserve(s->max_frames)) return rc;
             if (int rc = s->peakf.reserve(nfF)) return rc;
         }
@@ -2017,6 +2025,14 @@ static void spec_hide_dc(const csdr_spec *s, float *pts) {
     }
 }
 
+// The device keeps only the y of every display point (the x of point i is i / F in every frame, SpectrumVisualProcessor.cpp:562: half of
+// the display kernel's stores and of the fetch's transfer were that constant).  pts[F .. 2F) holds the F values just fetched: interleave
+// in place, front to back (the value of point i is read before slots 2i, 2i + 1 <= F + i are written).
+static void spec_expand_points(float *pts, int F) {
+    const float inv_F = 1.0f / (float)F;                                  // F is a power of two: i * inv_F == i / F exactly
+    for (int i = 0; i < F; ++i) { const float y = pts[F + i]; pts[2 * i] = (float)i * inv_F; pts[2 * i + 1] = y; }
+}
+
 extern "C" int csdr_spec_fetch_hold(csdr_spec *s, int frame, float *hold_host, int cap_floats, int *n_floats) {
     DeviceScope dev__(s ? s->ctx : nullptr);
     if (!s || !s->ready || !hold_host || !n_floats) return fail(CSDR_EINVAL, "bad argument");
@@ -2026,8 +2042,9 @@ extern "C" int csdr_spec_fetch_hold(csdr_spec *s, int frame, float *hold_host, i
     if ((size_t)frame >= s->hold_valid.size() || !s->hold_valid[frame]) return CSDR_OK;     // spectrum_hold_points.resize(0) (:432)
     if (cap_floats < 2 * F) return fail(CSDR_ERANGE, "need %d floats", 2 * F);
     hipStream_t st = s->ctx->lanes[LANE_AVG];
-    CSDR_HIP_TRY(hipMemcpyAsync(hold_host, s->hold_points.p + (size_t)frame * 2 * F, (size_t)2 * F * sizeof(float), hipMemcpyDeviceToHost, st));
+    CSDR_HIP_TRY(hipMemcpyAsync(hold_host + F, s->hold_points.p + (size_t)frame * F, (size_t)F * sizeof(float), hipMemcpyDeviceToHost, st));
     CSDR_HIP_TRY(hipStreamSynchronize(st));
+    spec_expand_points(hold_host, F);
     if (s->hide_dc) spec_hide_dc(s, hold_host);
     *n_floats = 2 * F;
     return CSDR_OK;
@@ -2041,9 +2058,10 @@ extern "C" int csdr_spec_fetch(csdr_spec *s, int frame, float *points_host, int 
     if (cap_floats < 2 * F) return fail(CSDR_ERANGE, "need %d floats", 2 * F);
     hipStream_t st = s->ctx->lanes[LANE_AVG];
     SpecFrameOut fo;
-    CSDR_HIP_TRY(hipMemcpyAsync(points_host, s->points.p + (size_t)frame * 2 * F, (size_t)2 * F * sizeof(float), hipMemcpyDeviceToHost, st));
+    CSDR_HIP_TRY(hipMemcpyAsync(points_host + F, s->points.p + (size_t)frame * F, (size_t)F * sizeof(float), hipMemcpyDeviceToHost, st));
     CSDR_HIP_TRY(hipMemcpyAsync(&fo, s->fo.p + frame, sizeof fo, hipMemcpyDeviceToHost, st));
     CSDR_HIP_TRY(hipStreamSynchronize(st));
+    spec_expand_points(points_host, F);
     if (s->hide_dc) spec_hide_dc(s, points_host);
     if (fft_ceiling) *fft_ceiling = fo.point_ceil / (double)s->scale;     // :626
     if (fft_floor) *fft_floor = fo.point_floor;                            // :627

@@ -528,9 +528,10 @@ struct FesStages<S, CH, END, END, WAVE> {
 //   tail wave    stage S-2 of chunk k-1 (+ its carry) | B1 | Z tail, stage S-1 | B2 | resampler | B3 | - | B4
 // The tail's input region is read before B1 of chunk k and rewritten only after B3 of chunk k; everything else it touches
 // is its own.  After the last chunk it runs once more without barriers.
-template <int S, int CH, bool TW = false>
-__global__ __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? 5 : 4) void demod_frontend_s(
-    const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
+// the workgroup's work: demodulator `slot`, range `part` of P (part == P: the carried streams)
+template <int S, int CH, bool TW>
+__device__ __forceinline__ void fes_body(
+    const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int slot, const int part, const int P,
     const float2 *__restrict__ chan_base, int64_t chan_stride, int64_t total /* batch samples per channel */,
     const float *__restrict__ arms_all, const float *__restrict__ sintab) {
     static_assert(S >= 2 && (CH >> S) >= 32 && (CH >> S) <= kFeThreads && CH % (2 * kFeThreads) == 0, "chunk does not suit this cascade depth");
@@ -539,8 +540,6 @@ __global__ __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? 5 : 4) void demod_
     constexpr int CZ = CH >> S;                                  // half-band chain outputs per chunk
     constexpr int ALEN = S * kFeTail + CH - (CH >> S);
 
-    const int slot = slot_list[blockIdx.y];
-    const int part = blockIdx.x, P = (int)gridDim.x - 1;
     const SlotCfg &cfg = cfgs[slot];
     const SlotDyn dyn = dyns[slot];
     const int tid = threadIdx.x;
@@ -768,6 +767,30 @@ __global__ __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? 5 : 4) void demod_
             }
             iq_cur[kIqHist + jmine] = make_float2(ar, ai);
         }
+    }
+}
+
+template <int S, int CH, bool TW = false>
+__global__ __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? 5 : 4) void demod_frontend_s(
+    const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
+    const float2 *__restrict__ chan_base, int64_t chan_stride, int64_t total, const float *__restrict__ arms_all, const float *__restrict__ sintab) {
+    fes_body<S, CH, TW>(cfgs, dyns, slot_list[blockIdx.y], (int)blockIdx.x, (int)gridDim.x - 1, chan_base, chan_stride, total, arms_all, sintab);
+}
+// Depth 6 (AM / SSB from ~500 kS/s channels) and depth 5 (NBFM) demodulators in ONE launch: rows [0, n6) of the grid run the depth-6
+// body on list6 with P6 ranges, the rest the depth-5 body on list5 with P5 ranges (grid.x = max(P6, P5) + 1; a column past a row's own
+// range count returns at once).  As two launches on one stream the second waits for the slowest workgroup of the first; here the
+// depth-5 workgroups fill the slots the depth-6 stragglers leave.
+__global__ __launch_bounds__(kFeThreads + 64, 5) void demod_frontend_s56(
+    const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ list6, int n6, int P6,
+    const int *__restrict__ list5, int P5, const float2 *__restrict__ chan_base, int64_t chan_stride, int64_t total,
+    const float *__restrict__ arms_all, const float *__restrict__ sintab) {
+    const int y = (int)blockIdx.y, x = (int)blockIdx.x;
+    if (y < n6) {
+        if (x > P6) return;
+        fes_body<6, 2048, true>(cfgs, dyns, list6[y], x, P6, chan_base, chan_stride, total, arms_all, sintab);
+    } else {
+        if (x > P5) return;
+        fes_body<5, 2048, true>(cfgs, dyns, list5[y - n6], x, P5, chan_base, chan_stride, total, arms_all, sintab);
     }
 }
 

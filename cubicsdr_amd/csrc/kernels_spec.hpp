@@ -672,7 +672,6 @@ __global__ __launch_bounds__(kDispThreads) void spec_display(const float *__rest
     const double pc = s_pc[0], pf = s_pc[1], fl = s_pc[2];
     const bool hold = f >= pk_from;
     const float inv_den = 1.0f / log1pf((float)(pc - pf));          // (pc + 0.25) - (pf - 0.75) = 1 + (pc - pf)
-    const float inv_F = 1.0f / (float)F;                             // F is a power of two: x * inv_F == x / F exactly
     // Full-span view of a multi-pass transform: the pair sums lie in PAIR order (spec_pair_index).  A tile of kDispTile
     // consecutive display points = nk3 consecutive k3 of every row pair: the threads read it row by row (runs of nk3 floats),
     // form y, drop it at its display position in LDS and write the tile out as whole 16-byte (x, y, x, y) groups.
@@ -702,11 +701,9 @@ __global__ __launch_bounds__(kDispThreads) void spec_display(const float *__rest
             {
                 const int j = 2 * tid, xo = x0 + j;
                 const float2 yy = *reinterpret_cast<const float2 *>(s_y + j);
-                *reinterpret_cast<float4 *>(points + ((int64_t)f * F + xo) * 2) = make_float4((float)xo * inv_F, yy.x, (float)(xo + 1) * inv_F, yy.y);
-                if (hold) {
-                    const float2 yh = *reinterpret_cast<const float2 *>(s_y + kDispTile + j);
-                    *reinterpret_cast<float4 *>(hold_points + ((int64_t)f * F + xo) * 2) = make_float4((float)xo * inv_F, yh.x, (float)(xo + 1) * inv_F, yh.y);
-                }
+                // only y is stored: the x of point i is i / F for every frame (:562) and is filled in when a frame is fetched
+                *reinterpret_cast<float2 *>(points + (int64_t)f * F + xo) = yy;
+                if (hold) *reinterpret_cast<float2 *>(hold_points + (int64_t)f * F + xo) = *reinterpret_cast<const float2 *>(s_y + kDispTile + j);
             }
             __syncthreads();
         }
@@ -742,13 +739,13 @@ __global__ __launch_bounds__(kDispThreads) void spec_display(const float *__rest
         y[u] = log1p_fast((float)(acc * inv_n - pf)) * inv_den * sf;  // acc / n + 0.25 - (pf - 0.75) = 1 + (acc / n - pf)
         if (hold) yh[u] = log1p_fast((float)(pacc * inv_n - pf)) * inv_den * sf;
     }
-    float *o = points + ((int64_t)f * F + x0) * 2;
-    if (x0 + 1 < F) *reinterpret_cast<float4 *>(o) = make_float4((float)x0 * inv_F, y[0], (float)(x0 + 1) * inv_F, y[1]);
-    else { o[0] = (float)x0 * inv_F; o[1] = y[0]; }
+    float *o = points + (int64_t)f * F + x0;
+    if (x0 + 1 < F) *reinterpret_cast<float2 *>(o) = make_float2(y[0], y[1]);
+    else o[0] = y[0];
     if (hold) {
-        float *h = hold_points + ((int64_t)f * F + x0) * 2;
-        if (x0 + 1 < F) *reinterpret_cast<float4 *>(h) = make_float4((float)x0 * inv_F, yh[0], (float)(x0 + 1) * inv_F, yh[1]);
-        else { h[0] = (float)x0 * inv_F; h[1] = yh[0]; }
+        float *h = hold_points + (int64_t)f * F + x0;
+        if (x0 + 1 < F) *reinterpret_cast<float2 *>(h) = make_float2(yh[0], yh[1]);
+        else h[0] = yh[0];
     }
     }
 }
