@@ -217,4 +217,4 @@ def test_emu_mixer_against_reference_callback(ctx):
 
 def test_emu_ingest_shared_device_buffer(ctx):
     import tests.test_gpu_io as IO
-    IO.ingest_scenario(ctx, rounds=4)
+    IO.ingest_scenario(ctx, block=8000, rounds=3, F=512)

@@ -1264,8 +1264,8 @@ def test_error_codes_and_edge_inputs(ctx):
     assert L.csdr_bank_configure_slot(bank, 0, C.byref(bad), post) == EUNSUP
     wide = H.DemodParams(H.CSDR_MODEM_FM, 900000, 48000, 0, 300000)                 # bandwidth above the channel rate: the interpolating resampler
     assert L.csdr_bank_configure_slot(bank, 0, C.byref(wide), post) == 0
-    up = H.DemodParams(H.CSDR_MODEM_FMS, 100000, 192000, 0, 300000)                 # FM stereo whose audio resamplers would have to interpolate
-    assert L.csdr_bank_configure_slot(bank, 0, C.byref(up), post) == EUNSUP
+    up = H.DemodParams(H.CSDR_MODEM_FMS, 100000, 192000, 0, 300000)                 # FM stereo whose audio resamplers interpolate (round 3: supported)
+    assert L.csdr_bank_configure_slot(bank, 0, C.byref(up), post) == 0
     assert L.csdr_bank_configure_slot(bank, 0, C.byref(prm), post) == 0
     res = (H.BlockResult * 1)()
     assert L.csdr_bank_execute(bank, post) == 0
