@@ -315,9 +315,9 @@ __global__ __launch_bounds__(kFftThreads) void spec_fft_small(FrameSrc fs, int N
 // 16 consecutive groups: every thread loads the magnitudes of its group, runs the recurrence from a zero state, the
 // group end states are combined through LDS (state_in(g) = M^G state_in(g-1) + local_end(g-1), M = [[a,0],[rate,a]],
 // a = 1 - rate), and the thread re-runs its frames from the true entering state with the reference's statements.
-// In exact arithmetic this is the sequential result; in double it differs by ~1e-16 relative.  (A NaN magnitude
-// poisons the entering states of the later groups of that batch, where the reference would have recovered after two
-// frames: NaN input is outside the parity contract.)
+// In exact arithmetic this is the sequential result; in double it differs by ~1e-16 relative.  A round of a tile that holds a
+// magnitude that is not finite (or enters with a NaN state) is run in frame order instead, with the reference's NaN repairs
+// applied frame by frame (:494-497): the reference recovers two frames after a NaN sample, and so does this.
 // The per-frame extrema the reference tracks are (float) max / min of maa; float rounding is monotonic, so each thread
 // forms (float max, float min) per frame and the wave (= 64 points of one frame) reduces them.
 constexpr int kAvgLanes = 64;
@@ -387,7 +387,7 @@ __device__ __forceinline__ void row16_max_min(float &mx, float &mn) {
 }
 
 constexpr int kAvgExtFrames = 4;           // frames whose per-lane extrema sit in LDS before one transposed reduction
-constexpr size_t kAvgLds = (size_t)(kAvgGroups + 1) * kAvgLanes * 4 * sizeof(double) + (size_t)kAvgGroups * 2 * kAvgExtFrames * kAvgLanes * sizeof(float);
+constexpr size_t kAvgLds = (size_t)(kAvgGroups + 1) * kAvgLanes * 4 * sizeof(double) + (size_t)kAvgGroups * 2 * kAvgExtFrames * kAvgLanes * sizeof(float) + 16;
 
 __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restrict__ mag, int nf, SpecGeom g, double rate,
                                                             double *__restrict__ ma, double *__restrict__ maa,
@@ -400,7 +400,8 @@ __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restr
     AvgState *s_loc = reinterpret_cast<AvgState *>(smem);               // [ng][64] group end states (zero entering state)
     AvgState *s_carry = s_loc + ng * kAvgLanes;                          // [64] state after the round
     const int F = g.F, lane = threadIdx.x & 63, grp = wave_uniform((int)(threadIdx.x >> 6));
-    float *s_ex = reinterpret_cast<float *>(s_carry + kAvgLanes) + grp * 2 * kAvgExtFrames * kAvgLanes;   // this wave's [max | min][4 frames][64 lanes]
+    float *s_ex_all = reinterpret_cast<float *>(s_carry + kAvgLanes);
+    float *s_ex = s_ex_all + grp * 2 * kAvgExtFrames * kAvgLanes;       // this wave's [max | min][4 frames][64 lanes]
     // The magnitudes lie in the row order of the last FFT pass: bin k1 + Ra (k2 + Rb k3) at [(k1 Rb + k2) 4096 + k3].  A tile is
     // 64 consecutive k3 of ONE row pair (k1 even, k1 + 1): two 256-byte runs per load, and the averaged pair sums are written in
     // the same pair order (one 256-byte run per store); the display kernel does the permutation to display order on its read side.
@@ -429,6 +430,10 @@ __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restr
     const unsigned off_a = (unsigned)t * 4u, off_b = (unsigned)(t + db) * 4u, off_p = (unsigned)pt * 4u;
     const bool adjacent = db == 1;                                       // (uniform) single-pass sizes: the two bins are one 8-byte load
     AvgState s0 = {ma[xs], maa[xs], ma[F + xs], maa[F + xs]};            // state entering the batch
+    int *s_flag = reinterpret_cast<int *>(s_ex_all + (size_t)kAvgGroups * 2 * kAvgExtFrames * kAvgLanes);   // [2] "this round needs the repairs", by round parity
+    if (threadIdx.x == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+    __syncthreads();
+    int round = 0;
     for (int fb = 0; fb < nf; fb += ng * kAvgGMax) {
         const int nfb = min(ng * kAvgGMax, nf - fb);
         const int G = (nfb + ng - 1) / ng;                               // frames per group (block-uniform)
@@ -451,6 +456,13 @@ __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restr
         for (int i = 0; i < kAvgGMax; ++i)
             if (i < cnt) avg_step_fast(loc, (double)m[i].x, (double)m[i].y, rate);
         s_loc[grp * kAvgLanes + lane] = loc;
+        {   // anything not finite among my magnitudes (x - x is NaN for NaN and Inf), or a NaN state entering the round?
+            bool odd = (s0.ma_a != s0.ma_a) | (s0.maa_a != s0.maa_a) | (s0.ma_b != s0.ma_b) | (s0.maa_b != s0.maa_b);
+#pragma unroll
+            for (int i = 0; i < kAvgGMax; ++i)
+                if (i < cnt) odd |= ((m[i].x - m[i].x) != 0.f) | ((m[i].y - m[i].y) != 0.f);
+            if (wave_any(odd) && lane == 0) s_flag[round & 1] = 1;
+        }
         __syncthreads();
         // 2. entering state of my group
         AvgState s = s0;
@@ -460,45 +472,62 @@ __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restr
             s.ma_a = aG * o.ma_a + e.ma_a;  s.maa_a = aG * o.maa_a + cG * o.ma_a + e.maa_a;
             s.ma_b = aG * o.ma_b + e.ma_b;  s.maa_b = aG * o.maa_b + cG * o.ma_b + e.maa_b;
         }
-        // 3. final pass with the reference's statements.  Its NaN repairs only ever fire when a state is NaN, which a finite input
-        // stream never produces: one wave-wide test of the entering state picks the plain form (a NaN arriving inside the round is
-        // then repaired at the head of the next one: NaN input is outside the parity contract either way)
-        const bool sick = (s.ma_a != s.ma_a) | (s.maa_a != s.maa_a) | (s.ma_b != s.ma_b) | (s.maa_b != s.maa_b);
-        const bool slow = wave_any(sick);
+        // 3. final pass with the reference's statements, the entering state being the true one
+        auto final_pass = [&](bool repairs) {
 #pragma unroll
-        for (int i = 0; i < kAvgGMax; ++i) {
-            if (i < cnt) {                                                // wave-uniform
-                const int f = fb + fg + i;
-                if (slow) avg_step(s, (double)m[i].x, (double)m[i].y, rate);
-                else avg_step_fast(s, (double)m[i].x, (double)m[i].y, rate);
-                const float fa = (float)s.maa_a, fbb = (float)s.maa_b;    // float rounding is monotonic: extrema of the rounded values
-                float mx = 0.f, mn = 3.0e38f;
-                if (valid) {
-                    stf(pairsum + (int64_t)f * F, off_p, (float)(s.maa_a + s.maa_b));
-                    if (f >= pk_from) maaf[(int64_t)f * F + x] = make_float2(fa, fbb);
-                    mx = fmaxf(fa, fbb); mn = fminf(fa, fbb);
-                    if (x == 0) first_b[f] = fbb;
+            for (int i = 0; i < kAvgGMax; ++i) {
+                if (i < cnt) {                                                // wave-uniform
+                    const int f = fb + fg + i;
+                    if (repairs) avg_step(s, (double)m[i].x, (double)m[i].y, rate);
+                    else avg_step_fast(s, (double)m[i].x, (double)m[i].y, rate);
+                    const float fa = (float)s.maa_a, fbb = (float)s.maa_b;    // float rounding is monotonic: extrema of the rounded values
+                    float mx = 0.f, mn = 3.0e38f;
+                    if (valid) {
+                        stf(pairsum + (int64_t)f * F, off_p, (float)(s.maa_a + s.maa_b));
+                        if (f >= pk_from) maaf[(int64_t)f * F + x] = make_float2(fa, fbb);
+                        mx = fmaxf(fa, fbb); mn = fminf(fa, fbb);             // (fmaxf / fminf skip a NaN operand, as the reference's comparisons do)
+                        if (x == 0) first_b[f] = fbb;
+                    }
+                    s_ex[(i & (kAvgExtFrames - 1)) * kAvgLanes + lane] = mx;
+                    s_ex[(kAvgExtFrames + (i & (kAvgExtFrames - 1))) * kAvgLanes + lane] = mn;
                 }
-                s_ex[(i & (kAvgExtFrames - 1)) * kAvgLanes + lane] = mx;
-                s_ex[(kAvgExtFrames + (i & (kAvgExtFrames - 1))) * kAvgLanes + lane] = mn;
+                // every four frames (and after the last one): transposed reduction through LDS -- lane = (frame q, sixteenth p) folds four
+                // lanes' values in registers, then a 16-lane row reduction: ~10 instructions per frame instead of 36
+                if ((i & (kAvgExtFrames - 1)) == kAvgExtFrames - 1 && i - (kAvgExtFrames - 1) < cnt) {
+                    wave_sync();
+                    const int q = lane >> 4, p16 = lane & 15, fq = i - (kAvgExtFrames - 1) + q;
+                    const float4 vx = *reinterpret_cast<const float4 *>(s_ex + q * kAvgLanes + 4 * p16);
+                    const float4 vn = *reinterpret_cast<const float4 *>(s_ex + (kAvgExtFrames + q) * kAvgLanes + 4 * p16);
+                    float mx = fmaxf(fmaxf(vx.x, vx.y), fmaxf(vx.z, vx.w)), mn = fminf(fminf(vn.x, vn.y), fminf(vn.z, vn.w));
+                    row16_max_min(mx, mn);
+                    if (p16 == 0 && fq < cnt) ext_w[(int64_t)(fb + fg + fq) * ntiles + blockIdx.x] = make_float2(mx, mn);
+                    wave_sync();
+                }
             }
-            // every four frames (and after the last one): transposed reduction through LDS -- lane = (frame q, sixteenth p) folds four
-            // lanes' values in registers, then a 16-lane row reduction: ~10 instructions per frame instead of 36
-            if ((i & (kAvgExtFrames - 1)) == kAvgExtFrames - 1 && i - (kAvgExtFrames - 1) < cnt) {
-                wave_sync();
-                const int q = lane >> 4, p16 = lane & 15, fq = i - (kAvgExtFrames - 1) + q;
-                const float4 vx = *reinterpret_cast<const float4 *>(s_ex + q * kAvgLanes + 4 * p16);
-                const float4 vn = *reinterpret_cast<const float4 *>(s_ex + (kAvgExtFrames + q) * kAvgLanes + 4 * p16);
-                float mx = fmaxf(fmaxf(vx.x, vx.y), fmaxf(vx.z, vx.w)), mn = fminf(fminf(vn.x, vn.y), fminf(vn.z, vn.w));
-                row16_max_min(mx, mn);
-                if (p16 == 0 && fq < cnt) ext_w[(int64_t)(fb + fg + fq) * ntiles + blockIdx.x] = make_float2(mx, mn);
-                wave_sync();
+        };
+        const bool repairs = s_flag[round & 1] != 0;                     // (block-uniform; read between the two barriers of the round)
+        if (threadIdx.x == 0) s_flag[(round + 1) & 1] = 0;               // nobody reads or sets the other flag before this round's closing barrier
+        if (!repairs) {
+            // every magnitude of the round and the entering state are finite: the NaN repairs of :494-497 are no-ops, the blocked scan is the
+            // sequential result
+            final_pass(false);
+            // 4. the group that holds the last frame of the round publishes the state entering the next round
+            if (grp == (nfb - 1) / G) s_carry[lane] = s;
+            __syncthreads();
+        } else {
+            // a NaN / Inf magnitude (or a NaN state) somewhere in this tile's round: the repairs make the recurrence non-linear, so the groups
+            // take turns in frame order, each entering with the state the previous one left, statement by statement as the reference does
+            for (int q = 0; q < ng; ++q) {
+                if (grp == q && cnt > 0) {
+                    s = (q == 0) ? s0 : s_carry[lane];
+                    final_pass(true);
+                    s_carry[lane] = s;
+                }
+                __syncthreads();
             }
         }
-        // 4. the group that holds the last frame of the round publishes the state entering the next round
-        if (grp == (nfb - 1) / G) s_carry[lane] = s;
-        __syncthreads();
         s0 = s_carry[lane];
+        ++round;
     }
     if (grp == 0 && valid) { ma[x] = s0.ma_a; maa[x] = s0.maa_a; ma[F + x] = s0.ma_b; maa[F + x] = s0.maa_b; }
 }

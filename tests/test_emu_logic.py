@@ -218,3 +218,7 @@ def test_emu_mixer_against_reference_callback(ctx):
 def test_emu_ingest_shared_device_buffer(ctx):
     import tests.test_gpu_io as IO
     IO.ingest_scenario(ctx, block=8000, rounds=3, F=512)
+
+
+def test_emu_spectrum_nan_repairs_frame_by_frame(ctx):
+    G.test_spectrum_nan_samples_recover_frame_by_frame(ctx, 2048, (40, 23), ((5, 100), (38, 7), (41, 3000)))

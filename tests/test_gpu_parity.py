@@ -896,6 +896,43 @@ def _spectrum_contiguous_batches(ctx, F, fs, frames_per_batch):
     sp.close()
 
 
+@pytest.mark.parametrize("F,frames,nan_at", [(2048, (40, 23), ((5, 100), (38, 7), (41, 3000))), (4096, (300,), ((17, 9), (255, 0), (256, 11), (290, 5000)))])
+def test_spectrum_nan_samples_recover_frame_by_frame(ctx, F, frames, nan_at):
+    """A NaN IQ sample makes every magnitude of its frame NaN; the reference repairs its averagers frame by frame (SpectrumVisualProcessor.cpp
+    :494-497: `if (maa != maa) maa = x; ... if (ma != ma) ma = x`) and shows finite points again two frames later.  The averaging kernel is a
+    blocked scan over frame groups; a round that holds a non-finite magnitude takes the frame-ordered path with the same statements.  NaN
+    frames at the start / inside / at the end of a frame group, at a 256-frame round boundary and in the last frames of a call (the NaN state
+    is carried into the next call): the NaN masks of the points are identical, every finite point, ceiling and floor within 1e-5."""
+    from cubicsdr_amd.engine import SpectrumProcessor
+    N = 2 * F
+    fs = 2400000
+    total = sum(frames) * N
+    x = synth_iq(total, fs, 0, [("NBFM", 300000.0), ("AM", -500000.0)], seed=77)
+    for fr, off in nan_at:
+        x[fr * N + off] = np.complex64(complex(np.nan, 0.25))
+    step, kind = _ref_spectrum_frames(F, fs)
+    sp = SpectrumProcessor(ctx, F, max_frames=max(frames))
+    done = nan_frames = 0
+    for nfc in frames:
+        nf = sp.process(x[done * N:(done + nfc) * N], 1, nfc * N, contiguous=True)
+        assert nf == nfc
+        for j in range(nf):
+            wp, wce, wfl = step(x[(done + j) * N:(done + j + 1) * N])
+            pts, ce, fl = sp.fetch(j)
+            bad = np.isnan(wp)
+            assert np.array_equal(np.isnan(pts), bad), (done + j, int(bad.sum()), int(np.isnan(pts).sum()))
+            nan_frames += int(bad.any())
+            if not bad.all():
+                ok = ~bad
+                assert rel_err(pts[ok], wp[ok]) < TOL, (done + j,)
+            for g, w in ((ce, wce), (fl, wfl)):
+                assert (np.isnan(g) and np.isnan(w)) or abs(g - w) <= TOL * abs(wce), (done + j, ce, wce, fl, wfl)
+        done += nf
+    assert nan_frames >= len(nan_at)
+    print("spectrum with NaN samples (%s): %d frames, %d of them with NaN points, as in the reference" % (kind, done, nan_frames))
+    sp.close()
+
+
 def test_pipelined_batches_equal_synchronised_batches(ctx):
     """The stage streams let consecutive batches overlap (channelizer of batch i+1 while the demodulators work on batch
     i; buffer rotations guarded by events).  Enqueue 6 batches back to back without touching the results, then compare the
