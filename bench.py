@@ -226,6 +226,55 @@ def cpu_baseline(cfg, ring_host, target_seconds):
     return out
 
 
+def parity_sample(cfg, ring_host, make_pipeline, n_check=12, n_blocks=2):
+    """Part of the cpu_baseline leg (the oracle as the CHECKER, never the thing measured): the first blocks of the bench's own ring through a
+    fresh pipeline of the bench's own configuration as ONE batch, against the reference chain (oracle/cubicsdr_chain.py on the reference's
+    liquid binary where it travelled) -- a spread of the demodulators (every modem kind of the configuration; resampled IQ, audio, counts)
+    and the first spectrum frames.  Error metric as in the tests: max |gpu - reference| / peak |reference| per compared array; bound 1e-5."""
+    import numpy as np
+    import oracle.liquid_api as A
+    from oracle.cubicsdr_chain import RefDemod, RefSDRPost, RefSpectrum
+    be = "ref" if A.available("ref") else "port"
+    fs, M, BLOCK, n_demods, kinds, F = cfg["fs"], cfg["M"], cfg["block"], cfg["n_demods"], cfg["kinds"], cfg["fft"]
+    x = np.ascontiguousarray(ring_host[: n_blocks * BLOCK])
+    c, post, bank, spec = make_pipeline(n_blocks)
+    post.execute(x, n_blocks, BLOCK, CENTER); bank.execute(post)
+    nfr = spec.process(x, n_blocks, BLOCK, contiguous=True)
+    rp = RefSDRPost(be, fs, M)
+    rp.frequency = CENTER; rp.update_channels()
+    freqs = demod_frequencies(CENTER, fs, n_demods)
+    pick = [i for i in sorted({(j * n_demods) // n_check + (j % len(kinds)) for j in range(n_check)}) if i < n_demods and rp.channel_at(freqs[i]) != 0]
+    rds = {i: RefDemod(be, kinds[i % len(kinds)], MODEM_BW[kinds[i % len(kinds)]], freqs[i], rp.chan_bw, AUDIO_RATE) for i in pick}
+    want = {i: {"iq": [], "audio": []} for i in pick}
+    for b in range(n_blocks):
+        rp.run_block(x[b * BLOCK:(b + 1) * BLOCK], CENTER)
+        cache = {}
+        for i, rd in rds.items():
+            ch = rp.channel_at(rd.frequency)
+            if ch not in cache:
+                cache[ch] = rp.channel_data(ch)
+            riq = rd.pre(*cache[ch])
+            want[i]["iq"].append(riq); want[i]["audio"].append(rd.demodulate(riq)["audio"])
+    rel = lambda g, w: float(np.max(np.abs(g - w)) / np.max(np.abs(w))) if w.size and g.size == w.size else float("inf")
+    e_iq = e_au = e_sp = 0.0
+    counts_exact = True
+    for i in pick:
+        wi, wa = np.concatenate(want[i]["iq"]), np.concatenate(want[i]["audio"])
+        res = bank.results(i)
+        counts_exact &= [r.n_iq for r in res] == [w.size for w in want[i]["iq"]] and [r.n_audio for r in res] == [w.size for w in want[i]["audio"]]
+        e_iq = max(e_iq, rel(bank.iq(i), wi)); e_au = max(e_au, rel(bank.audio(i), wa))
+    rs = RefSpectrum(be, F)
+    nchk = min(nfr, 3)
+    for k in range(nchk):
+        wp = rs.process_frame(x[k * 2 * F:(k + 1) * 2 * F])[0]
+        e_sp = max(e_sp, rel(spec.fetch(k)[0], wp))
+    spec.close(); bank.close(); post.close(); c.close()
+    return {"oracle": "reference liquid binary" if be == "ref" else "C restatement", "tolerance": 1e-5, "metric": "max|gpu-ref| / peak|ref| per array",
+            "blocks": n_blocks, "demodulators_checked": len(pick), "kinds": sorted({kinds[i % len(kinds)] for i in pick}), "counts_exact": bool(counts_exact),
+            "iq": e_iq, "audio": e_au, "spectrum_frames": nchk, "spectrum": e_sp, "ok": bool(counts_exact and max(e_iq, e_au, e_sp) < 1e-5),
+            "full_suite": "tests/test_gpu_parity.py compares every demodulator x 3 blocks and ~1000 spectrum frames of this configuration (DESIGN.md 2)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -487,7 +536,13 @@ def main():
             out["config"]["host_fed"] = {"MS_per_s": None, "note": repr(e)}
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         try:
-            out["cpu_baseline"] = cpu_baseline(cfg, ring.cpu().numpy().view("complex64").reshape(-1), args.cpu_seconds)
+            ring_host = ring.cpu().numpy().view("complex64").reshape(-1)
+            out["cpu_baseline"] = cpu_baseline(cfg, ring_host, args.cpu_seconds)
+            if args.ring != "noise":
+                try:
+                    out["cpu_baseline"]["parity"] = parity_sample(cfg, ring_host, make_pipeline)
+                except Exception as e:
+                    out["cpu_baseline"]["parity"] = {"ok": None, "note": repr(e)}
         except Exception as e:  # the baseline is reported, never required for the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "MS/s", "cores": 0, "kind": "unavailable", "sample": repr(e)}
     if rank == 0:
