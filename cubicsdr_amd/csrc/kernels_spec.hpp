@@ -456,11 +456,10 @@ __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restr
         for (int i = 0; i < kAvgGMax; ++i)
             if (i < cnt) avg_step_fast(loc, (double)m[i].x, (double)m[i].y, rate);
         s_loc[grp * kAvgLanes + lane] = loc;
-        {   // anything not finite among my magnitudes (x - x is NaN for NaN and Inf), or a NaN state entering the round?
-            bool odd = (s0.ma_a != s0.ma_a) | (s0.maa_a != s0.maa_a) | (s0.ma_b != s0.ma_b) | (s0.maa_b != s0.maa_b);
-#pragma unroll
-            for (int i = 0; i < kAvgGMax; ++i)
-                if (i < cnt) odd |= ((m[i].x - m[i].x) != 0.f) | ((m[i].y - m[i].y) != 0.f);
+        {   // anything not finite among my magnitudes (the zero-state pass has summed them all with positive weights: a NaN or Inf magnitude
+            // leaves a NaN or Inf there; x - x is NaN for both), or a NaN state entering the round?
+            const bool odd = (s0.ma_a != s0.ma_a) | (s0.maa_a != s0.maa_a) | (s0.ma_b != s0.ma_b) | (s0.maa_b != s0.maa_b)
+                           | ((loc.ma_a - loc.ma_a) != 0.0) | ((loc.ma_b - loc.ma_b) != 0.0);
             if (wave_any(odd) && lane == 0) s_flag[round & 1] = 1;
         }
         __syncthreads();
@@ -472,20 +471,22 @@ __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restr
             s.ma_a = aG * o.ma_a + e.ma_a;  s.maa_a = aG * o.maa_a + cG * o.ma_a + e.maa_a;
             s.ma_b = aG * o.ma_b + e.ma_b;  s.maa_b = aG * o.maa_b + cG * o.ma_b + e.maa_b;
         }
-        // 3. final pass with the reference's statements, the entering state being the true one
-        auto final_pass = [&](bool repairs) {
+        const bool repairs = s_flag[round & 1] != 0;                     // (block-uniform; read between the two barriers of the round)
+        if (threadIdx.x == 0) s_flag[(round + 1) & 1] = 0;               // nobody reads or sets the other flag before this round's closing barrier
+        if (!repairs) {
+            // 3. final pass from the true entering state.  Every magnitude of the round and the entering state are finite: the NaN repairs
+            // of :494-497 are no-ops and the blocked scan is the sequential result
 #pragma unroll
             for (int i = 0; i < kAvgGMax; ++i) {
                 if (i < cnt) {                                                // wave-uniform
                     const int f = fb + fg + i;
-                    if (repairs) avg_step(s, (double)m[i].x, (double)m[i].y, rate);
-                    else avg_step_fast(s, (double)m[i].x, (double)m[i].y, rate);
+                    avg_step_fast(s, (double)m[i].x, (double)m[i].y, rate);
                     const float fa = (float)s.maa_a, fbb = (float)s.maa_b;    // float rounding is monotonic: extrema of the rounded values
                     float mx = 0.f, mn = 3.0e38f;
                     if (valid) {
                         stf(pairsum + (int64_t)f * F, off_p, (float)(s.maa_a + s.maa_b));
                         if (f >= pk_from) maaf[(int64_t)f * F + x] = make_float2(fa, fbb);
-                        mx = fmaxf(fa, fbb); mn = fminf(fa, fbb);             // (fmaxf / fminf skip a NaN operand, as the reference's comparisons do)
+                        mx = fmaxf(fa, fbb); mn = fminf(fa, fbb);
                         if (x == 0) first_b[f] = fbb;
                     }
                     s_ex[(i & (kAvgExtFrames - 1)) * kAvgLanes + lane] = mx;
@@ -504,23 +505,39 @@ __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restr
                     wave_sync();
                 }
             }
-        };
-        const bool repairs = s_flag[round & 1] != 0;                     // (block-uniform; read between the two barriers of the round)
-        if (threadIdx.x == 0) s_flag[(round + 1) & 1] = 0;               // nobody reads or sets the other flag before this round's closing barrier
-        if (!repairs) {
-            // every magnitude of the round and the entering state are finite: the NaN repairs of :494-497 are no-ops, the blocked scan is the
-            // sequential result
-            final_pass(false);
             // 4. the group that holds the last frame of the round publishes the state entering the next round
             if (grp == (nfb - 1) / G) s_carry[lane] = s;
             __syncthreads();
         } else {
             // a NaN / Inf magnitude (or a NaN state) somewhere in this tile's round: the repairs make the recurrence non-linear, so the groups
             // take turns in frame order, each entering with the state the previous one left, statement by statement as the reference does
+            // (a rare path kept small: magnitudes re-read, the extrema folded by one lane; fmaxf / fminf skip a NaN operand as the reference's
+            // comparisons do)
             for (int q = 0; q < ng; ++q) {
                 if (grp == q && cnt > 0) {
                     s = (q == 0) ? s0 : s_carry[lane];
-                    final_pass(true);
+#pragma unroll 1
+                    for (int i = 0; i < cnt; ++i) {
+                        const int f = fb + fg + i;
+                        const float *mf = mag + (int64_t)f * NN;
+                        const float2 v = adjacent ? ldf2(mf, off_a) : make_float2(ldf(mf, off_a), ldf(mf, off_b));
+                        avg_step(s, (double)v.x, (double)v.y, rate);
+                        const float fa = (float)s.maa_a, fbb = (float)s.maa_b;
+                        float mx = 0.f, mn = 3.0e38f;
+                        if (valid) {
+                            stf(pairsum + (int64_t)f * F, off_p, (float)(s.maa_a + s.maa_b));
+                            if (f >= pk_from) maaf[(int64_t)f * F + x] = make_float2(fa, fbb);
+                            mx = fmaxf(fa, fbb); mn = fminf(fa, fbb);
+                            if (x == 0) first_b[f] = fbb;
+                        }
+                        s_ex[lane] = mx; s_ex[kAvgLanes + lane] = mn;
+                        wave_sync();
+                        if (lane == 0) {
+                            for (int l = 1; l < kAvgLanes; ++l) { mx = fmaxf(mx, s_ex[l]); mn = fminf(mn, s_ex[kAvgLanes + l]); }
+                            ext_w[(int64_t)f * ntiles + blockIdx.x] = make_float2(mx, mn);
+                        }
+                        wave_sync();
+                    }
                     s_carry[lane] = s;
                 }
                 __syncthreads();
