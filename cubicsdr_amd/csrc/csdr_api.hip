@@ -304,6 +304,7 @@ static int chan_geometry(int M, int hop, ChanGeom &g) {
         // through LDS (512-byte row runs) | 3 / 4: as 1 / 2 with 32-frame tiles in four-wave workgroups (four per CU instead of two)
         g.mx = 0;
         if (const char *e = getenv("CSDR_CHAN_MX")) g.mx = g.A >= 17 ? std::max(0, std::min(4, atoi(e))) : 0;
+        g.alt = getenv("CSDR_CHAN_ALT") ? atoi(getenv("CSDR_CHAN_ALT")) : 0;
         if (g.mx >= 3) { g.TF = 32; g.lgTF = 5; g.threads = P2Tile<32>::threads; }
         return CSDR_OK;
     }
@@ -1268,7 +1269,29 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         CSDR_LAUNCH(c, LANE_FE, KID_FE_S56, demod_frontend_s56, dim3(std::max(P6, P5) + 1, grp_n[6] + grp_n[5]), dim3(kFeThreads + 64), (fes_lds_bytes<6, 2048>()),
                     b->cfgs.p, dyns_d, grp_d + grp_off[6], grp_n[6], P6, grp_d + grp_off[5], P5, chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
     }
-    if (grp_n[6] > 0 && !merged) {          // depth 6 (AM / SSB from ~500 kS/s channels): tail wave with three tail stages (CSDR_FE_TW6=0: without)
+    // CSDR_FE_CH=1536: 1536-sample chunks for the two tail-wave depths (five resident workgroups per CU instead of four)
+    static const bool fe_ch1536 = getenv("CSDR_FE_CH") ? atoi(getenv("CSDR_FE_CH")) == 1536 : kFeChunk1536Default;
+    if (fe_ch1536 && !merged && tw6) {
+        const int slots15 = std::max(1, c->wg_slots(demod_frontend_s<5, 1536, true>, kFeThreads + 64, fes_lds_bytes<5, 1536>()) * fe_pct / 100);
+        auto ranges15 = [&](int n_slots) {
+            int P = (int)std::max<int64_t>(1, std::min<int64_t>(total / std::max<int64_t>(4096, 4 * (int64_t)warm_max), 4096));
+            const int per_slot = slots15 / std::max(1, n_slots) - 1;
+            if (per_slot >= 1) P = std::min(P, per_slot);
+            else {
+                const int rounds = (n_slots * 2 + slots15 - 1) / slots15;
+                P = std::max(1, std::min(P, rounds * slots15 / std::max(1, n_slots) - 1));
+            }
+            return P;
+        };
+        if (grp_n[6] > 0)
+            CSDR_LAUNCH(c, LANE_FE, KID_FE_S6, (demod_frontend_s<6, 1536, true>), dim3(ranges15(grp_n[6]) + 1, grp_n[6]), dim3(kFeThreads + 64), (fes_lds_bytes<6, 1536>()),
+                        b->cfgs.p, dyns_d, grp_d + grp_off[6], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
+        if (grp_n[5] > 0)
+            CSDR_LAUNCH(c, LANE_FE, KID_FE_S5, (demod_frontend_s<5, 1536, true>), dim3(ranges15(grp_n[5]) + 1, grp_n[5]), dim3(kFeThreads + 64), (fes_lds_bytes<5, 1536>()),
+                        b->cfgs.p, dyns_d, grp_d + grp_off[5], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
+    }
+    const bool done56 = fe_ch1536 && !merged && tw6;
+    if (grp_n[6] > 0 && !merged && !done56) {          // depth 6 (AM / SSB from ~500 kS/s channels): tail wave with three tail stages (CSDR_FE_TW6=0: without)
         if (tw6)
             CSDR_LAUNCH(c, LANE_FE, KID_FE_S6, (demod_frontend_s<6, 2048, true>), dim3(ranges_for(grp_n[6]) + 1, grp_n[6]), dim3(kFeThreads + 64), (fes_lds_bytes<6, 2048>()),
                         b->cfgs.p, dyns_d, grp_d + grp_off[6], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
@@ -1281,7 +1304,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         CSDR_LAUNCH(c, LANE_FE, KID_FE_INTERP, demod_frontend_interp, dim3(nchunks + 1, grp_n[7]), dim3(kFeThreads), kFiLds, b->cfgs.p, dyns_d, grp_d + grp_off[7],
                     chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
     }
-    if (grp_n[5] > 0 && !merged)            // depth 5 (NBFM from ~500 kS/s channels): a fifth wave runs the one-wave tail one chunk behind
+    if (grp_n[5] > 0 && !merged && !done56)            // depth 5 (NBFM from ~500 kS/s channels): a fifth wave runs the one-wave tail one chunk behind
         CSDR_LAUNCH(c, LANE_FE, KID_FE_S5, (demod_frontend_s<5, 2048, true>), dim3(ranges_for(grp_n[5]) + 1, grp_n[5]), dim3(kFeThreads + 64), (fes_lds_bytes<5, 2048>()),
                     b->cfgs.p, dyns_d, grp_d + grp_off[5], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
 #undef CSDR_FE_S
@@ -1458,6 +1481,7 @@ struct csdr_spec {
     DevBuf<float2> ext_w, ext;
     int n_avg_tiles = 0, scal_parity = 0;
     DevBuf<SpecFrameOut> fo;
+    DevBuf<SpecFrameScal> fsc;                      // per frame: point_ceil, point_floor, fft_floor_maa (spec_trackers -> spec_display)
     DevBuf<SpecScalars> scal;
     int carry_len = 0;
     // CSDR_SPEC_LINES: fftLastData (the previous FFT input, :399-421) in two copies written alternately, lastDataSize != 0
@@ -1514,7 +1538,7 @@ extern "C" void csdr_spec_destroy(csdr_spec *s) {
     }
     s->tw4096.release(); s->tw_hi.release(); s->tw_lo.release(); s->tmp.release(); s->carry.release();
     s->stage_in.release(); s->raw.release(); s->mag.release(); s->ext_w.release(); s->ext.release(); s->pairsum.release(); s->first_b.release(); s->points.release();
-    s->ma.release(); s->maa.release(); s->fo.release(); s->scal.release();
+    s->ma.release(); s->maa.release(); s->fo.release(); s->fsc.release(); s->scal.release();
     s->last[0].release(); s->last[1].release(); s->lines.release();
     s->peak.release(); s->maaf.release(); s->peaksum.release(); s->peak_b.release(); s->hold_points.release(); s->pk.release(); s->pfo.release();
     s->ma2.release(); s->maa2.release(); s->vmap.release(); s->peakf.release();
@@ -1567,6 +1591,7 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     if (int rc = s->ma.reserve(2 * F)) return rc;
     if (int rc = s->maa.reserve(2 * F)) return rc;
     if (int rc = s->fo.reserve(max_frames)) return rc;
+    if (int rc = s->fsc.reserve(max_frames)) return rc;
     if (int rc = s->scal.reserve(2)) return rc;
     if (int rc = s->carry.reserve(N)) return rc;
     CSDR_HIP_TRY(hipMemset(s->ma.p, 0, 2 * F * sizeof(double)));      // vector<double>::resize -> zeros (:243-257)
@@ -1651,8 +1676,11 @@ static int spec_post_range(csdr_spec *s, const float *mag, int f0, int cnt, int 
     const bool hold = pk_from < cnt, view = s->view_frame;
     const bool bins = hold || view;                                  // per-bin averaged values are kept (maaf)
     // frame groups per workgroup: up to 16 frames each, so a short batch does not pay the set-up of sixteen groups
-    const int avg_groups = std::max(1, std::min(kAvgGroups, (cnt + kAvgGMax - 1) / kAvgGMax));
-    CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_average, dim3(s->n_avg_tiles), dim3(kAvgLanes * avg_groups), kAvgLds, mag + (size_t)f0 * g.N, cnt, g, (double)s->avg_rate,
+    // (CSDR_AVG_GROUPS = 4 | 8 | 16 caps the groups: fewer, smaller workgroups let two of them share a CU -- one loads its round while the
+    // other scans)
+    static const int avg_cap = getenv("CSDR_AVG_GROUPS") ? std::max(1, std::min(kAvgGroups, atoi(getenv("CSDR_AVG_GROUPS")))) : kAvgGroupsDefault;
+    const int avg_groups = std::max(1, std::min(avg_cap, (cnt + kAvgGMax - 1) / kAvgGMax));
+    CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_average, dim3(s->n_avg_tiles), dim3(kAvgLanes * avg_groups), avg_lds_bytes(avg_groups), mag + (size_t)f0 * g.N, cnt, g, (double)s->avg_rate,
                 s->ma.p, s->maa.p, s->pairsum.p + f0 * F, s->first_b.p + f0, s->ext_w.p + (size_t)f0 * s->n_avg_tiles,
                 bins ? s->maaf.p + f0 * F : (float2 *)nullptr, view ? 0 : (hold ? pk_from : cnt));
     CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_extrema, dim3(cnt), dim3(256), 64, s->ext_w.p + (size_t)f0 * s->n_avg_tiles, s->n_avg_tiles, s->ext.p + f0);
@@ -1662,11 +1690,14 @@ static int spec_post_range(csdr_spec *s, const float *mag, int f0, int cnt, int 
                     s->peaksum.p + f0 * F, s->peak_b.p + f0, view ? s->peakf.p + f0 * F : (float2 *)nullptr);
         CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_MISC, spec_peak_trackers, dim3(1), dim3(64), 0, s->ext.p + f0, cnt, pk_from, st_in, s->pk.p, s->pfo.p + f0);
     }
-    // display: column blocks per frame sized so that the grid is about one round of resident workgroups
-    const int disp_gx = std::max(1, std::min((g.F / 2 + kDispThreads - 1) / kDispThreads, c->wg_slots(spec_display, kDispThreads, kDispLds) / std::max(1, cnt)));
+    // trackers of every frame (closed form, one workgroup per frame), then the display: the transposing path takes kDispTpi tiles per workgroup
+    CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_trackers, dim3(cnt), dim3(kDispThreads), kTrackLds, s->ext.p + f0, cnt, st_in, s->scal.p + (s->scal_parity ^ 1),
+                s->fo.p + f0, s->fsc.p + f0, hold ? pk_from : cnt, hold ? s->pfo.p + f0 : (const SpecFrameOut *)nullptr);
+    const bool transposing = !view && g.Ra > 1 && (g.Ra >> 1) * g.Rb <= kDispTile && g.F >= kDispTile;
+    const int disp_gx = transposing ? std::max(1, (g.F / kDispTile + kDispTpi - 1) / kDispTpi)
+                                    : std::max(1, std::min((g.F / 2 + kDispThreads - 1) / kDispThreads, c->wg_slots(spec_display, kDispThreads, kDispLds) / std::max(1, cnt)));
     CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_DISPLAY, spec_display, dim3(disp_gx, cnt), dim3(kDispThreads), kDispLds,
-                s->pairsum.p + f0 * F, s->first_b.p + f0, s->ext.p + f0, cnt, g, s->scale, st_in, s->scal.p + (s->scal_parity ^ 1), s->fo.p + f0,
-                s->points.p + f0 * F, hold ? pk_from : cnt, hold ? s->pfo.p + f0 : (const SpecFrameOut *)nullptr,
+                s->pairsum.p + f0 * F, s->first_b.p + f0, s->fsc.p + f0, g, s->scale, s->points.p + f0 * F, hold ? pk_from : cnt,
                 hold ? s->peaksum.p + f0 * F : (const float *)nullptr, hold ? s->peak_b.p + f0 : (const float *)nullptr,
                 hold ? s->hold_points.p + f0 * F : (float *)nullptr,
                 view ? s->vmap.p : (const int2 *)nullptr, view ? s->maaf.p + f0 * F : (const float2 *)nullptr,

@@ -29,6 +29,7 @@ constexpr int kScopeMax = 2048;   // DEMOD_VIS_SIZE (DemodulatorThread.h:15)
 constexpr int kFeThreads = 256;
 constexpr int kFeChunk = 2048;    // input samples one inner iteration of the front-end stages through LDS
 constexpr int kFePairs = kFeChunk / 2 / kFeThreads;   // 16-byte loads per thread per chunk
+constexpr bool kFeChunk1536Default = false;   // tail-wave depths (5, 6): 1536-sample chunks instead of 2048 (CSDR_FE_CH overrides)
 constexpr int kFeTail = 24;       // per-stage carried tail (>= 2 * kHbMaxM)
 constexpr int kFeZTail = 16;      // carried tail of the half-band chain output (>= 13)
 
@@ -435,7 +436,7 @@ __device__ inline void fes_stage_pairs(const float2 *__restrict__ Ein, const flo
 #pragma unroll
     for (int t0 = 0; t0 < NP; t0 += kFeThreads) {
         const int t = t0 + tx;
-        if (NP >= kFeThreads || t < NP) {
+        if (t0 + kFeThreads <= NP || t < NP) {                   // (compile-time for whole rounds of the workgroup)
             float2 ev[2 * M + 2];                               // ev[i] = E[2t - 2M + i]
             float4 e4[M + 1], o4;                               // both windows are 16-byte aligned (fes_offo)
             lds_read128<M + 1>(Ein + 2 * t - 2 * M, Oin + 2 * t - M, e4, o4);
@@ -480,6 +481,47 @@ __device__ inline void fes_carry_tail(float2 *__restrict__ LE, float2 *__restric
         const int k = c < kFeTail ? c : c - kFeTail;
         arr[k] = arr[CNT + k];
     }
+}
+
+// mix the prefetched chunk (pair p = tid + q kFeThreads holds samples 2p, 2p + 1) and drop it into the stage-0 arrays.  All table
+// look-ups of the thread are issued before the first product needs one (one wait instead of one per sample); a chunk that lies wholly
+// inside the batch (rel0 >= 0, chunk-uniform) skips the per-sample "history samples are mixed already" tests.
+template <int NPF>
+__device__ __forceinline__ void fes_mix_store(const float4 (&pf)[NPF], const int tid, const int64_t rel0, const SlotDyn &dyn, const float sgn,
+                                              const float *__restrict__ tab, float2 *__restrict__ LEd, float2 *__restrict__ LOd) {
+    float2 a[NPF], b[NPF];
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) { a[q] = make_float2(pf[q].x, pf[q].y); b[q] = make_float2(pf[q].z, pf[q].w); }
+    if (dyn.mixdir != 0) {
+        const uint32_t th0 = dyn.theta0 + (uint32_t)rel0 * dyn.dtheta;
+        float sa[NPF], ca[NPF], sb[NPF], cb[NPF];
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int p = tid + q * kFeThreads;
+            const uint32_t tha = th0 + (uint32_t)(2 * p) * dyn.dtheta, thb = tha + dyn.dtheta;
+            const uint32_t ia = (tha + (1u << 21)) >> 22, ib = (thb + (1u << 21)) >> 22;      // 0 .. 1023
+            sa[q] = tab[ia]; ca[q] = tab[ia + 256]; sb[q] = tab[ib]; cb[q] = tab[ib + 256];
+        }
+        if (rel0 >= 0) {
+#pragma unroll
+            for (int q = 0; q < NPF; ++q) {
+                const float s0 = sa[q] * sgn, s1 = sb[q] * sgn;
+                a[q] = make_float2(fmaf(a[q].x, ca[q], -(a[q].y * s0)), fmaf(a[q].y, ca[q], a[q].x * s0));
+                b[q] = make_float2(fmaf(b[q].x, cb[q], -(b[q].y * s1)), fmaf(b[q].y, cb[q], b[q].x * s1));
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NPF; ++q) {
+                const int p = tid + q * kFeThreads;
+                const float s0 = sa[q] * sgn, s1 = sb[q] * sgn;
+                // samples before the batch (rel < 0) come from the history and are mixed already
+                if (rel0 + 2 * p >= 0) a[q] = make_float2(fmaf(a[q].x, ca[q], -(a[q].y * s0)), fmaf(a[q].y, ca[q], a[q].x * s0));
+                if (rel0 + 2 * p + 1 >= 0) b[q] = make_float2(fmaf(b[q].x, cb[q], -(b[q].y * s1)), fmaf(b[q].y, cb[q], b[q].x * s1));
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) { const int p = tid + q * kFeThreads; LEd[p] = a[q]; LOd[p] = b[q]; }
 }
 
 // Stages [0, fes_blk) run on the whole workgroup, one barrier each; when the remaining stages are small enough for
@@ -534,7 +576,7 @@ __device__ __forceinline__ void fes_body(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int slot, const int part, const int P,
     const float2 *__restrict__ chan_base, int64_t chan_stride, int64_t total /* batch samples per channel */,
     const float *__restrict__ arms_all, const float *__restrict__ sintab) {
-    static_assert(S >= 2 && (CH >> S) >= 32 && (CH >> S) <= kFeThreads && CH % (2 * kFeThreads) == 0, "chunk does not suit this cascade depth");
+    static_assert(S >= 2 && (CH >> S) >= kFeTail && (CH >> S) <= kFeThreads && CH % (2 * kFeThreads) == 0 && (CH >> S) % 2 == 0, "chunk does not suit this cascade depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NPF = CH / 2 / kFeThreads;
     constexpr int CZ = CH >> S;                                  // half-band chain outputs per chunk
@@ -616,21 +658,7 @@ __device__ __forceinline__ void fes_body(
             for (int k = 0; k < nch; ++k) {
                 const int64_t uc = u_lo + (int64_t)k * CH;
                 const int64_t rel0 = uc - (int64_t)dyn.buf0;
-                const bool do_mix = dyn.mixdir != 0;
-                const uint32_t th0 = dyn.theta0 + (uint32_t)rel0 * dyn.dtheta;
-#pragma unroll
-                for (int q = 0; q < NPF; ++q) {
-                    const int p = tid + q * kFeThreads;
-                    float2 a = make_float2(pf[q].x, pf[q].y), b = make_float2(pf[q].z, pf[q].w);
-                    if (do_mix) {
-                        const uint32_t tha = th0 + (uint32_t)(2 * p) * dyn.dtheta, thb = tha + dyn.dtheta;
-                        const uint32_t ia = (tha + (1u << 21)) >> 22, ib = (thb + (1u << 21)) >> 22;
-                        const float sa = tab[ia] * sgn, ca = tab[ia + 256], sb = tab[ib] * sgn, cb = tab[ib + 256];
-                        if (rel0 + 2 * p >= 0) a = make_float2(fmaf(a.x, ca, -(a.y * sa)), fmaf(a.y, ca, a.x * sa));
-                        if (rel0 + 2 * p + 1 >= 0) b = make_float2(fmaf(b.x, cb, -(b.y * sb)), fmaf(b.y, cb, b.x * sb));
-                    }
-                    LE[kFeTail + p] = a; LO[fes_offo<S, CH>(0) + kFeTail + p] = b;
-                }
+                fes_mix_store<NPF>(pf, tid, rel0, dyn, sgn, tab, LE + kFeTail, LO + fes_offo<S, CH>(0) + kFeTail);
                 if (k + 1 < nch) {
                     const int64_t reln = rel0 + CH;
                     const bool inside = reln >= 0 && reln + CH <= total;
@@ -707,24 +735,7 @@ __device__ __forceinline__ void fes_body(
     for (int64_t uc = u_lo; uc < u_stop; uc += CH) {
         const int64_t rel0 = uc - (int64_t)dyn.buf0;          // batch-relative index of the chunk's first input
         // ---- mix the prefetched chunk into the stage-0 arrays
-        {
-            const bool do_mix = dyn.mixdir != 0;
-            const uint32_t th0 = dyn.theta0 + (uint32_t)rel0 * dyn.dtheta;
-#pragma unroll
-            for (int q = 0; q < NPF; ++q) {
-                const int p = tid + q * kFeThreads;
-                float2 a = make_float2(pf[q].x, pf[q].y), b = make_float2(pf[q].z, pf[q].w);
-                if (do_mix) {
-                    const uint32_t tha = th0 + (uint32_t)(2 * p) * dyn.dtheta, thb = tha + dyn.dtheta;
-                    const uint32_t ia = (tha + (1u << 21)) >> 22, ib = (thb + (1u << 21)) >> 22;      // 0 .. 1023
-                    const float sa = tab[ia] * sgn, ca = tab[ia + 256], sb = tab[ib] * sgn, cb = tab[ib + 256];
-                    // samples before the batch (rel < 0) come from the history and are mixed already
-                    if (rel0 + 2 * p >= 0) a = make_float2(fmaf(a.x, ca, -(a.y * sa)), fmaf(a.y, ca, a.x * sa));
-                    if (rel0 + 2 * p + 1 >= 0) b = make_float2(fmaf(b.x, cb, -(b.y * sb)), fmaf(b.y, cb, b.x * sb));
-                }
-                LE[kFeTail + p] = a; LO[fes_offo<S, CH>(0) + kFeTail + p] = b;
-            }
-        }
+        fes_mix_store<NPF>(pf, tid, rel0, dyn, sgn, tab, LE + kFeTail, LO + fes_offo<S, CH>(0) + kFeTail);
         // ---- resampler outputs of this chunk: fetch their filter arms before the prefetch (vector-memory waits retire in order)
         const int64_t kz0 = uc >> S;
         int64_t jb = resamp_first_out(kz0 + CZ, dyn.phase0, step);
@@ -770,8 +781,9 @@ __device__ __forceinline__ void fes_body(
     }
 }
 
+// (CH = 1536 with the tail wave: 31.5 KB of LDS and <= 72 registers, so that FIVE workgroups of five waves share a CU instead of four)
 template <int S, int CH, bool TW = false>
-__global__ __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? 5 : 4) void demod_frontend_s(
+__global__ __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? (CH <= 1536 ? 7 : 5) : 4) void demod_frontend_s(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
     const float2 *__restrict__ chan_base, int64_t chan_stride, int64_t total, const float *__restrict__ arms_all, const float *__restrict__ sintab) {
     fes_body<S, CH, TW>(cfgs, dyns, slot_list[blockIdx.y], (int)blockIdx.x, (int)gridDim.x - 1, chan_base, chan_stride, total, arms_all, sintab);
@@ -1388,18 +1400,17 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
 #pragma unroll
         for (int j = 0; j < kHbMaxM; ++j) hs[j] = au.h_x[s][j];
         const int qoff = (int)((olo >> 1) - ilo), par0 = (int)(olo & 1);
-        for (int i = tid; i < nout; i += nthr) {
-            const int a = i + par0;                              // output index relative to the even index at or below olo
-            const int qi = qoff + (a >> 1);
-            float v;
-            if ((a & 1) == 0) v = src[qi - m];
-            else {
-                v = 0.f;
+        // a thread forms the output PAIR (2p, 2p + 1) relative to the even index at or below olo: the delayed sample and the filtered one
+        // (one lane per output would have half of every wave copy while the other half filters)
+        for (int p = tid; 2 * p - par0 < nout; p += nthr) {
+            const int qi = qoff + p, i0 = 2 * p - par0;
+            const float ve = src[qi - m];
+            float vo = 0.f;
 #pragma unroll
-                for (int j = 0; j < kHbMaxM; ++j)
-                    if (j < m) v = fmaf(hs[j], src[qi - j] + src[qi - (2 * m - 1) + j], v);
-            }
-            dst[i] = v;
+            for (int j = 0; j < kHbMaxM; ++j)
+                if (j < m) vo = fmaf(hs[j], src[qi - j] + src[qi - (2 * m - 1) + j], vo);
+            if (i0 >= 0) dst[i0] = ve;
+            if (i0 + 1 < nout) dst[i0 + 1] = vo;
         }
         __syncthreads();
         float *t = src; src = dst; dst = t;

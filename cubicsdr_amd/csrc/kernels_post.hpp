@@ -209,6 +209,7 @@ struct ChanGeom {
     int threads;              // workgroup size (whole waves, 256..512): chosen so each phase splits evenly over the waves
     int p2;                   // 1: M = 2 A, A odd <= 63, critically sampled: chan_analyze_p2 (KA = slots per pass, nkA = passes, PA = row pitch)
     int mx;                   // p2 only: the A-point DFTs run on the fp32 matrix pipe (chan_analyze_p2<.., true>)
+    int alt;                  // p2 only: experiment switches of the vector form (CSDR_CHAN_ALT)
 };
 __host__ __device__ inline size_t chan_zin_floats2(const ChanGeom &g) {      // Z array, or the staged input tile if larger
     const size_t z = (size_t)g.TF * g.S, in = g.stage_in ? (size_t)(g.TF - 1) * g.hop + (size_t)kChanTaps * g.M : 0;
@@ -531,11 +532,12 @@ __device__ __forceinline__ void store_row(float2 *row_base, unsigned byte_off, f
     *reinterpret_cast<float2 *>(reinterpret_cast<char *>(row_base) + byte_off) = v;
 }
 // one term of the conjugate-pair sums for KP slots and both c2: s = x_c + x_{A-c}, d = x_c - x_{A-c}; e = (cos, sin) rows
-template <int KP>
+// (SD: the FIR phase already left s at row c and d at row A - c)
+template <int KP, bool SD = false>
 __device__ __forceinline__ void chan_p2_term(const float4 a, const float4 b, const float2 (&e)[KP], float2 (&P0)[KP], float2 (&Q0)[KP],
                                              float2 (&P1)[KP], float2 (&Q1)[KP]) {
-    const float4 s = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-    const float4 d = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+    const float4 s = SD ? a : make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    const float4 d = SD ? b : make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
 #pragma unroll
     for (int j = 0; j < KP; ++j) {
         P0[j].x = fmaf(s.x, e[j].x, P0[j].x); P0[j].y = fmaf(s.y, e[j].x, P0[j].y);
@@ -543,6 +545,47 @@ __device__ __forceinline__ void chan_p2_term(const float4 a, const float4 b, con
         Q0[j].x = fmaf(d.x, e[j].y, Q0[j].x); Q0[j].y = fmaf(d.y, e[j].y, Q0[j].y);
         Q1[j].x = fmaf(d.z, e[j].y, Q1[j].x); Q1[j].y = fmaf(d.w, e[j].y, Q1[j].y);
     }
+}
+
+// the conjugate-pair sums of one pass (KP slots, both c2) over the terms c = 1 .. H.  Software pipeline, two terms per trip with two
+// register sets: the rows and the (cos, sin) row of the next term are requested before the current one is accumulated.
+// UNC: the second request of a trip is unconditional (the last trip re-reads term H) instead of guarded -- A/B switch CSDR_CHAN_ALT bit 0;
+// SD: rows hold s / d already (bit 1).
+template <int KP, bool SD, bool UNC>
+__device__ __forceinline__ void chan_p2_accumulate(const float4 *row, const int A, const int H, const float2 *__restrict__ w, const int PA,
+                                                   float2 (&P0)[KP], float2 (&Q0)[KP], float2 (&P1)[KP], float2 (&Q1)[KP]) {
+    float4 a = row[1], b = row[A - 1], a2 = a, b2 = b;
+    float2 eA[KP], eB[KP];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) { eA[j] = w[j]; eB[j] = eA[j]; }
+    int c = 1;
+    for (; c + 1 <= H; c += 2) {
+        w += PA;
+        a2 = row[c + 1]; b2 = row[A - c - 1];
+#pragma unroll
+        for (int j = 0; j < KP; ++j) eB[j] = w[j];
+        sched_fence();
+        chan_p2_term<KP, SD>(a, b, eA, P0, Q0, P1, Q1);
+        sched_fence();
+        if (UNC) {
+            const int cn = min(c + 2, H);
+            w += (c + 2 <= H) ? PA : 0;
+            a = row[cn]; b = row[A - cn];
+#pragma unroll
+            for (int j = 0; j < KP; ++j) eA[j] = w[j];
+        } else {
+            w += PA;
+            if (c + 2 <= H) {
+                a = row[c + 2]; b = row[A - c - 2];
+#pragma unroll
+                for (int j = 0; j < KP; ++j) eA[j] = w[j];
+            }
+        }
+        sched_fence();
+        chan_p2_term<KP, SD>(a2, b2, eB, P0, Q0, P1, Q1);
+        sched_fence();
+    }
+    if (c <= H) chan_p2_term<KP, SD>(a, b, eA, P0, Q0, P1, Q1);        // H odd: the last term
 }
 
 // request the input of `tile` (rows f0 - 7 .. f0 + nf - 1 as one flat run of float4) into registers.  Every element of `pre`
@@ -649,6 +692,7 @@ __global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
             const int ta = wave * kRange;
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
             float4 halo[kChanTaps - 1], w[kChanTaps];
+            const bool sd = !MX && (g.alt & 2) != 0;
 #pragma unroll
             for (int j = 0; j < kChanTaps - 1; ++j) halo[j] = col ? rows[(ta + kRange + j) * A + lane] : z4;
 #pragma unroll
@@ -662,6 +706,12 @@ __global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
                     const float4 v = w[kChanTaps - 1 - n];
                     acc.x = fmaf(h[n].x, v.x, acc.x); acc.y = fmaf(h[n].x, v.y, acc.y);
                     acc.z = fmaf(h[n].y, v.z, acc.z); acc.w = fmaf(h[n].y, v.w, acc.w);
+                }
+                if (sd) {                                     // columns c and A - c trade: s_c = x_c + x_{A-c} at row c, d_c = x_c - x_{A-c} at row A - c
+                    const int pl = (lane >= 1 && lane < A) ? A - lane : lane;
+                    const float4 pv = make_float4(__shfl(acc.x, pl, 64), __shfl(acc.y, pl, 64), __shfl(acc.z, pl, 64), __shfl(acc.w, pl, 64));
+                    if (lane >= 1 && lane <= H) acc = make_float4(acc.x + pv.x, acc.y + pv.y, acc.z + pv.z, acc.w + pv.w);
+                    else if (lane > H && lane < A) acc = make_float4(pv.x - acc.x, pv.y - acc.y, pv.z - acc.z, pv.w - acc.w);
                 }
                 if (col) rows[(ta + i) * A + lane] = acc;
 #pragma unroll
@@ -777,33 +827,12 @@ __global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
                     P0[j] = make_float2(x0.x, x0.y); P1[j] = make_float2(x0.z, x0.w);
                     Q0[j] = make_float2(0.f, 0.f); Q1[j] = make_float2(0.f, 0.f);
                 }
-                // software pipeline, two terms per trip with two register sets (no copies): the rows and the (cos, sin) row of the
-                // next term are requested before the current one is accumulated
-                const float2 *w = cs + q0;
-                float4 a = row[1], b = row[A - 1], a2 = a, b2 = b;
-                float2 eA[KP], eB[KP];
-    #pragma unroll
-                for (int j = 0; j < KP; ++j) { eA[j] = w[j]; eB[j] = eA[j]; }
-                int c = 1;
-                for (; c + 1 <= H; c += 2) {
-                    w += g.PA;
-                    a2 = row[c + 1]; b2 = row[A - c - 1];
-    #pragma unroll
-                    for (int j = 0; j < KP; ++j) eB[j] = w[j];
-                    sched_fence();
-                    chan_p2_term<KP>(a, b, eA, P0, Q0, P1, Q1);
-                    sched_fence();
-                    w += g.PA;
-                    if (c + 2 <= H) {
-                        a = row[c + 2]; b = row[A - c - 2];
-    #pragma unroll
-                        for (int j = 0; j < KP; ++j) eA[j] = w[j];
-                    }
-                    sched_fence();
-                    chan_p2_term<KP>(a2, b2, eB, P0, Q0, P1, Q1);
-                    sched_fence();
+                switch (g.alt & 3) {
+                    case 1: chan_p2_accumulate<KP, false, true>(row, A, H, cs + q0, g.PA, P0, Q0, P1, Q1); break;
+                    case 2: chan_p2_accumulate<KP, true, false>(row, A, H, cs + q0, g.PA, P0, Q0, P1, Q1); break;
+                    case 3: chan_p2_accumulate<KP, true, true>(row, A, H, cs + q0, g.PA, P0, Q0, P1, Q1); break;
+                    default: chan_p2_accumulate<KP, false, false>(row, A, H, cs + q0, g.PA, P0, Q0, P1, Q1); break;
                 }
-                if (c <= H) chan_p2_term<KP>(a, b, eA, P0, Q0, P1, Q1);        // H odd: the last term
                 float2 *ob = out + f0;                                  // wave-uniform row bases + a 32-bit lane offset: scalar-base stores
                 const unsigned tb = (unsigned)t * (unsigned)sizeof(float2);   // byte offset of this lane inside a channel row
     #pragma unroll

@@ -321,7 +321,8 @@ __global__ __launch_bounds__(kFftThreads) void spec_fft_small(FrameSrc fs, int N
 // The per-frame extrema the reference tracks are (float) max / min of maa; float rounding is monotonic, so each thread
 // forms (float max, float min) per frame and the wave (= 64 points of one frame) reduces them.
 constexpr int kAvgLanes = 64;
-constexpr int kAvgGroups = 16;
+constexpr int kAvgGroups = 16;             // most frame groups (waves) per workgroup
+constexpr int kAvgGroupsDefault = 8;       // what the host launches unless told otherwise: two workgroups share a CU (measured on C3: 16 / 8 / 4 groups = 0.213 / 0.186 / 0.189 ms)
 constexpr int kAvgThreads = kAvgLanes * kAvgGroups;
 constexpr int kAvgGMax = 16;               // frames per thread per round -> 256 frames per round
 
@@ -387,7 +388,10 @@ __device__ __forceinline__ void row16_max_min(float &mx, float &mn) {
 }
 
 constexpr int kAvgExtFrames = 4;           // frames whose per-lane extrema sit in LDS before one transposed reduction
-constexpr size_t kAvgLds = (size_t)(kAvgGroups + 1) * kAvgLanes * 4 * sizeof(double) + (size_t)kAvgGroups * 2 * kAvgExtFrames * kAvgLanes * sizeof(float) + 16;
+constexpr size_t kAvgLds = (size_t)(kAvgGroups + 1) * kAvgLanes * 4 * sizeof(double) + (size_t)kAvgGroups * 2 * kAvgExtFrames * kAvgLanes * sizeof(float) + 16;      // the largest request (hipFuncSetAttribute)
+__host__ __device__ constexpr size_t avg_lds_bytes(int ng) {      // dynamic LDS of a launch with ng frame groups
+    return (size_t)(ng + 1) * kAvgLanes * 4 * sizeof(double) + (size_t)ng * 2 * kAvgExtFrames * kAvgLanes * sizeof(float) + 16;
+}
 
 __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restrict__ mag, int nf, SpecGeom g, double rate,
                                                             double *__restrict__ ma, double *__restrict__ maa,
@@ -430,22 +434,32 @@ __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restr
     const unsigned off_a = (unsigned)t * 4u, off_b = (unsigned)(t + db) * 4u, off_p = (unsigned)pt * 4u;
     const bool adjacent = db == 1;                                       // (uniform) single-pass sizes: the two bins are one 8-byte load
     AvgState s0 = {ma[xs], maa[xs], ma[F + xs], maa[F + xs]};            // state entering the batch
-    int *s_flag = reinterpret_cast<int *>(s_ex_all + (size_t)kAvgGroups * 2 * kAvgExtFrames * kAvgLanes);   // [2] "this round needs the repairs", by round parity
+    int *s_flag = reinterpret_cast<int *>(s_ex_all + (size_t)ng * 2 * kAvgExtFrames * kAvgLanes);   // [2] "this round needs the repairs", by round parity
     if (threadIdx.x == 0) { s_flag[0] = 0; s_flag[1] = 0; }
     __syncthreads();
     int round = 0;
+    // magnitudes of my frames of a round (frames past the end read the round's last frame: loaded, never used); the NEXT round's are
+    // requested while this one is scanned
+    float2 mn[kAvgGMax];
+    auto request = [&](int fb) {
+        const int nfb = min(ng * kAvgGMax, nf - fb);
+        const int G = (nfb + ng - 1) / ng, fg = grp * G;
+#pragma unroll
+        for (int i = 0; i < kAvgGMax; ++i) {
+            const float *mf = mag + (int64_t)(fb + min(fg + i, nfb - 1)) * NN;      // wave-uniform base
+            mn[i] = adjacent ? ldf2(mf, off_a) : make_float2(ldf(mf, off_a), ldf(mf, off_b));
+        }
+    };
+    if (nf > 0) request(0);
     for (int fb = 0; fb < nf; fb += ng * kAvgGMax) {
         const int nfb = min(ng * kAvgGMax, nf - fb);
         const int G = (nfb + ng - 1) / ng;                               // frames per group (block-uniform)
         const int fg = grp * G;                                           // first frame of my group inside the round (wave-uniform)
         const int cnt = max(0, min(G, nfb - fg));                         // frames this wave really has (wave-uniform)
-        // magnitudes of my frames (frames past the end read the round's last frame: loaded, never used)
         float2 m[kAvgGMax];
 #pragma unroll
-        for (int i = 0; i < kAvgGMax; ++i) {
-            const float *mf = mag + (int64_t)(fb + min(fg + i, nfb - 1)) * NN;      // wave-uniform base
-            m[i] = adjacent ? ldf2(mf, off_a) : make_float2(ldf(mf, off_a), ldf(mf, off_b));
-        }
+        for (int i = 0; i < kAvgGMax; ++i) m[i] = mn[i];
+        if (fb + ng * kAvgGMax < nf) request(fb + ng * kAvgGMax);
         // M^G = [[aG, 0], [cG, aG]] with aG = a^G, cG = G rate a^(G-1)
         double aG = 1.0, aGm1 = 1.0;
         for (int i = 0; i < G; ++i) { aGm1 = aG; aG *= a; }
@@ -565,14 +579,6 @@ __global__ __launch_bounds__(256) void spec_extrema(const float2 *__restrict__ e
     }
 }
 
-// ---- K16 + floor / ceil trackers.  grid = (F / 512, frames), 256 threads -----------------------------------------
-// The trackers (SpectrumVisualProcessor.cpp:513-521) are short linear recurrences over the frames; every workgroup
-// evaluates them in closed form from the batch-entering state up to its own frame, the first workgroup of each frame
-// records them and that of the last frame publishes the end state (ping-pong copy).  Then two display points per
-// thread, full-span view (visualRatio = 1: two bins per point), :532-576:
-//     y = log10(acc / 2 + 0.25 - (floor - 0.75)) / log10(ceil + 0.25 - (floor - 0.75)) * scale
-// Both arguments are 1 + u with u formed in double; the logarithms are taken as log(1 + u) with the rounding of the sum
-// cancelled (log1p_fast: a few float ulps also when the dynamic range is tiny), their ratio needs no base conversion.
 // log(1 + u) for u > -1 from the hardware base-2 logarithm: log(w) u / (w - 1) with w = fl(1 + u) cancels the rounding of
 // the sum (the classic log1p identity), so the relative error stays at a few float ulps however small u is
 __device__ __forceinline__ float log1p_fast(float u) {
@@ -661,24 +667,26 @@ __global__ void spec_peak_trackers(const float2 *__restrict__ ext, int nf, int p
 }
 constexpr int kDispThreads = 256;
 constexpr int kDispTile = 2 * kDispThreads;   // display points per tile
-constexpr size_t kDispLds = (4 * (kDispThreads / 64) + 4) * sizeof(double) + 2 * kDispTile * sizeof(float);
+constexpr int kDispTpi = 4;                   // tiles one workgroup of the transposing path handles (all of its loads are in flight together)
+constexpr int kDispPad = kDispTile + kDispTile / 16;      // a tile in LDS: one float of padding per 16 (position p at p + p / 16)
+constexpr size_t kDispLds = 2 * (size_t)kDispTpi * kDispPad * sizeof(float);
+constexpr size_t kTrackLds = 4 * (kDispThreads / 64) * sizeof(double);
 
-__global__ __launch_bounds__(kDispThreads) void spec_display(const float *__restrict__ pairsum /* pair order: spec_pair_index */, const float *__restrict__ first_b,
-                                                             const float2 *__restrict__ ext, int nf, SpecGeom g, float sf,
-                                                             const SpecScalars *__restrict__ st_in, SpecScalars *__restrict__ st_out,
-                                                             SpecFrameOut *__restrict__ fo, float *__restrict__ points,
-                                                             int pk_from, const SpecFrameOut *__restrict__ pfo, const float *__restrict__ peaksum,
-                                                             const float *__restrict__ peak_b, float *__restrict__ hold_points,
-                                                             const int2 *__restrict__ vmap /* zoomed view: (first bin, bins) per point, else null */,
-                                                             const float2 *__restrict__ maaf, const float2 *__restrict__ peakf) {
+struct SpecFrameScal { double pc, pf, fl; };  // point_ceil, point_floor, fft_floor_maa of a frame
+
+// ---- floor / ceil trackers of every frame of the batch.  grid = frames, 256 threads --------------------------------
+// The trackers (SpectrumVisualProcessor.cpp:513-521) are short linear recurrences over the frames; workgroup f evaluates them in
+// closed form from the batch-entering state up to its own frame (a = 0.95, b = 0.05; c_i = float ceiling, d_i = float floor of
+// frame i):      ma_f  = a^(f+1) ma_in + b sum_i a^(f-i) c_i
+//                maa_f = a^(f+1) maa_in + b (f+1) a^(f+1) ma_in + b^2 sum_i (f-i+1) a^(f-i) c_i      (maa uses the NEW ma)
+// as parallel weighted sums over i <= f (double; equal to the serial loop to ~1e-15 relative); the last frame publishes the end
+// state (ping-pong copy).
+__global__ __launch_bounds__(kDispThreads) void spec_trackers(const float2 *__restrict__ ext, int nf, const SpecScalars *__restrict__ st_in,
+                                                              SpecScalars *__restrict__ st_out, SpecFrameOut *__restrict__ fo,
+                                                              SpecFrameScal *__restrict__ fsc, int pk_from, const SpecFrameOut *__restrict__ pfo) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *s_sum = reinterpret_cast<double *>(smem);          // reduction scratch [waves][4]
-    double *s_pc = s_sum + 4 * (kDispThreads / 64);            // [3] point_ceil, point_floor, fft_floor_maa of this frame
-    const int f = blockIdx.y, tid = threadIdx.x, F = g.F;
-    // trackers after frame f, closed form of the recurrences (a = 0.95, b = 0.05; c_i = float ceiling, d_i = float floor
-    // of frame i):   ma_f  = a^(f+1) ma_in + b sum_i a^(f-i) c_i
-    //                maa_f = a^(f+1) maa_in + b (f+1) a^(f+1) ma_in + b^2 sum_i (f-i+1) a^(f-i) c_i      (maa uses the NEW ma)
-    // evaluated as parallel weighted sums over i <= f (double; equal to the serial loop to ~1e-15 relative).
+    const int f = blockIdx.x, tid = threadIdx.x;
     const SpecScalars s_in = *st_in;
     double w_c = 0.0, w_c2 = 0.0, w_d = 0.0, w_d2 = 0.0;
     for (int i = tid; i <= f; i += kDispThreads) {
@@ -707,49 +715,90 @@ __global__ __launch_bounds__(kDispThreads) void spec_display(const float *__rest
         s.floor_maa = af * s_in.floor_maa + b * (double)(f + 1) * af * s_in.floor_ma + b * b * t3;
         // point_ceil / point_floor: the held extremes while peak hold is live (:539-540)
         const bool hold = f >= pk_from;
-        s_pc[0] = hold ? pfo[f].point_ceil : s.ceil_maa; s_pc[1] = hold ? pfo[f].point_floor : s.floor_maa;
-        s_pc[2] = s.floor_maa;
-        if (blockIdx.x == 0) {
-            fo[f].point_ceil = s_pc[0]; fo[f].point_floor = s_pc[1];
-            if (f == nf - 1) *st_out = s;
-        }
+        SpecFrameScal o;
+        o.pc = hold ? pfo[f].point_ceil : s.ceil_maa; o.pf = hold ? pfo[f].point_floor : s.floor_maa; o.fl = s.floor_maa;
+        fsc[f] = o;
+        fo[f].point_ceil = o.pc; fo[f].point_floor = o.pf;
+        if (f == nf - 1) *st_out = s;
     }
-    __syncthreads();
-    const double pc = s_pc[0], pf = s_pc[1], fl = s_pc[2];
+}
+
+// ---- K16.  Two display points per thread, full-span view (visualRatio = 1: two bins per point), :532-576:
+//     y = log10(acc / 2 + 0.25 - (floor - 0.75)) / log10(ceil + 0.25 - (floor - 0.75)) * scale
+// Both arguments are 1 + u with u formed in double; the logarithms are taken as log(1 + u) with the rounding of the sum
+// cancelled (log1p_fast: a few float ulps also when the dynamic range is tiny), their ratio needs no base conversion.
+// grid = (column blocks, frames): the transposing path takes kDispTpi tiles per workgroup (grid.x = F / kDispTile / kDispTpi or fewer: it
+// strides), the plain path 2 x 256 points per step.
+__global__ __launch_bounds__(kDispThreads) void spec_display(const float *__restrict__ pairsum /* pair order: spec_pair_index */, const float *__restrict__ first_b,
+                                                             const SpecFrameScal *__restrict__ fsc, SpecGeom g, float sf, float *__restrict__ points,
+                                                             int pk_from, const float *__restrict__ peaksum,
+                                                             const float *__restrict__ peak_b, float *__restrict__ hold_points,
+                                                             const int2 *__restrict__ vmap /* zoomed view: (first bin, bins) per point, else null */,
+                                                             const float2 *__restrict__ maaf, const float2 *__restrict__ peakf) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int f = blockIdx.y, tid = threadIdx.x, F = g.F;
+    const SpecFrameScal sc = fsc[f];
+    const double pc = sc.pc, pf = sc.pf, fl = sc.fl;
     const bool hold = f >= pk_from;
     const float inv_den = 1.0f / log1pf((float)(pc - pf));          // (pc + 0.25) - (pf - 0.75) = 1 + (pc - pf)
     // Full-span view of a multi-pass transform: the pair sums lie in PAIR order (spec_pair_index).  A tile of kDispTile
     // consecutive display points = nk3 consecutive k3 of every row pair: the threads read it row by row (runs of nk3 floats),
-    // form y, drop it at its display position in LDS and write the tile out as whole 16-byte (x, y, x, y) groups.
+    // form y, drop it at its display position in LDS (padded: a wave's stores are npairs floats apart) and write the tile out in display
+    // order.  All loads of the workgroup's kDispTpi tiles are issued before the first value is used.
     const int npairs = g.Ra == 1 ? 1 : (g.Ra >> 1) * g.Rb;           // row pairs = display points per k3
     if (!vmap && g.Ra > 1 && npairs <= kDispTile && F >= kDispTile) {
-        float *s_y = reinterpret_cast<float *>(s_pc + 4);            // [2][kDispTile]: y, held y
+        float *s_y = reinterpret_cast<float *>(smem);                // [kDispTpi][kDispPad] y, then the same for the held y
+        float *s_h = s_y + kDispTpi * kDispPad;
         const int nk3 = kDispTile / npairs, lg_nk3 = 31 - __clz(nk3), lg_half = g.lgRa - 1;
-        for (int tile = blockIdx.x; tile < F / kDispTile; tile += gridDim.x) {
-            const int k3base = tile * nk3;
-            const int x0 = (npairs * k3base - (g.N >> 2)) & (F - 1);       // display point of (row pair 0, k3base); tiles do not wrap
+        const int ntile = F / kDispTile;
+        for (int tile0 = blockIdx.x * kDispTpi; tile0 < ntile; tile0 += gridDim.x * kDispTpi) {
+            float a[kDispTpi][2], ph[kDispTpi][2];
 #pragma unroll
-            for (int u = 0; u < kDispTile / kDispThreads; ++u) {
-                const int i = tid + u * kDispThreads;
-                const int prow = i >> lg_nk3, k3i = i & (nk3 - 1);
-                const int k1h = prow >> g.lgRb, k2 = prow & (g.Rb - 1);
-                const int pos = k3i * npairs + k1h + (k2 << lg_half);      // position inside the tile, display order
-                const int x = x0 + pos;
-                const double acc = (x == 0) ? fl + (double)first_b[f]       // idx == 0 is replaced by fft_floor_maa (:546-556)
-                                            : (double)pairsum[(int64_t)f * F + (int64_t)prow * 4096 + k3base + k3i];
-                s_y[pos] = log1p_fast((float)(acc * 0.5 - pf)) * inv_den * sf;
-                if (hold) {
-                    const double pacc = (x == 0) ? fl + (double)peak_b[f] : (double)peaksum[(int64_t)f * F + x];
-                    s_y[kDispTile + pos] = log1p_fast((float)(pacc * 0.5 - pf)) * inv_den * sf;
+            for (int tt = 0; tt < kDispTpi; ++tt) {
+                const int tile = min(tile0 + tt, ntile - 1);               // (a tile past the end re-reads the last one: loaded, never stored)
+                const int k3base = tile * nk3;
+                const int x0 = (npairs * k3base - (g.N >> 2)) & (F - 1);   // display point of (row pair 0, k3base); tiles do not wrap
+#pragma unroll
+                for (int u = 0; u < kDispTile / kDispThreads; ++u) {
+                    const int i = tid + u * kDispThreads;
+                    const int prow = i >> lg_nk3, k3i = i & (nk3 - 1);
+                    const int k1h = prow >> g.lgRb, k2 = prow & (g.Rb - 1);
+                    const int pos = k3i * npairs + k1h + (k2 << lg_half);  // position inside the tile, display order
+                    a[tt][u] = pairsum[(int64_t)f * F + (int64_t)prow * 4096 + k3base + k3i];
+                    if (hold) ph[tt][u] = peaksum[(int64_t)f * F + x0 + pos];
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < kDispTpi; ++tt) {
+                const int tile = min(tile0 + tt, ntile - 1);
+                const int k3base = tile * nk3;
+                const int x0 = (npairs * k3base - (g.N >> 2)) & (F - 1);
+#pragma unroll
+                for (int u = 0; u < kDispTile / kDispThreads; ++u) {
+                    const int i = tid + u * kDispThreads;
+                    const int prow = i >> lg_nk3, k3i = i & (nk3 - 1);
+                    const int k1h = prow >> g.lgRb, k2 = prow & (g.Rb - 1);
+                    const int pos = k3i * npairs + k1h + (k2 << lg_half);
+                    const int x = x0 + pos;
+                    const double acc = (x == 0) ? fl + (double)first_b[f] : (double)a[tt][u];      // idx == 0 is replaced by fft_floor_maa (:546-556)
+                    s_y[tt * kDispPad + pos + (pos >> 4)] = log1p_fast((float)(acc * 0.5 - pf)) * inv_den * sf;
+                    if (hold) {
+                        const double pacc = (x == 0) ? fl + (double)peak_b[f] : (double)ph[tt][u];
+                        s_h[tt * kDispPad + pos + (pos >> 4)] = log1p_fast((float)(pacc * 0.5 - pf)) * inv_den * sf;
+                    }
                 }
             }
             __syncthreads();
-            {
-                const int j = 2 * tid, xo = x0 + j;
-                const float2 yy = *reinterpret_cast<const float2 *>(s_y + j);
-                // only y is stored: the x of point i is i / F for every frame (:562) and is filled in when a frame is fetched
-                *reinterpret_cast<float2 *>(points + (int64_t)f * F + xo) = yy;
-                if (hold) *reinterpret_cast<float2 *>(hold_points + (int64_t)f * F + xo) = *reinterpret_cast<const float2 *>(s_y + kDispTile + j);
+#pragma unroll
+            for (int tt = 0; tt < kDispTpi; ++tt) {
+                const int tile = tile0 + tt;
+                if (tile < ntile) {                                         // (block-uniform)
+                    const int x0 = (npairs * tile * nk3 - (g.N >> 2)) & (F - 1);
+                    const int j = 2 * tid, q = tt * kDispPad + j + (j >> 4);
+                    // only y is stored: the x of point i is i / F for every frame (:562) and is filled in when a frame is fetched
+                    *reinterpret_cast<float2 *>(points + (int64_t)f * F + x0 + j) = make_float2(s_y[q], s_y[q + 1]);
+                    if (hold) *reinterpret_cast<float2 *>(hold_points + (int64_t)f * F + x0 + j) = make_float2(s_h[q], s_h[q + 1]);
+                }
             }
             __syncthreads();
         }
