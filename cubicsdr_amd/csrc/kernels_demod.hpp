@@ -483,47 +483,6 @@ __device__ inline void fes_carry_tail(float2 *__restrict__ LE, float2 *__restric
     }
 }
 
-// mix the prefetched chunk (pair p = tid + q kFeThreads holds samples 2p, 2p + 1) and drop it into the stage-0 arrays.  All table
-// look-ups of the thread are issued before the first product needs one (one wait instead of one per sample); a chunk that lies wholly
-// inside the batch (rel0 >= 0, chunk-uniform) skips the per-sample "history samples are mixed already" tests.
-template <int NPF>
-__device__ __forceinline__ void fes_mix_store(const float4 (&pf)[NPF], const int tid, const int64_t rel0, const SlotDyn &dyn, const float sgn,
-                                              const float *__restrict__ tab, float2 *__restrict__ LEd, float2 *__restrict__ LOd) {
-    float2 a[NPF], b[NPF];
-#pragma unroll
-    for (int q = 0; q < NPF; ++q) { a[q] = make_float2(pf[q].x, pf[q].y); b[q] = make_float2(pf[q].z, pf[q].w); }
-    if (dyn.mixdir != 0) {
-        const uint32_t th0 = dyn.theta0 + (uint32_t)rel0 * dyn.dtheta;
-        float sa[NPF], ca[NPF], sb[NPF], cb[NPF];
-#pragma unroll
-        for (int q = 0; q < NPF; ++q) {
-            const int p = tid + q * kFeThreads;
-            const uint32_t tha = th0 + (uint32_t)(2 * p) * dyn.dtheta, thb = tha + dyn.dtheta;
-            const uint32_t ia = (tha + (1u << 21)) >> 22, ib = (thb + (1u << 21)) >> 22;      // 0 .. 1023
-            sa[q] = tab[ia]; ca[q] = tab[ia + 256]; sb[q] = tab[ib]; cb[q] = tab[ib + 256];
-        }
-        if (rel0 >= 0) {
-#pragma unroll
-            for (int q = 0; q < NPF; ++q) {
-                const float s0 = sa[q] * sgn, s1 = sb[q] * sgn;
-                a[q] = make_float2(fmaf(a[q].x, ca[q], -(a[q].y * s0)), fmaf(a[q].y, ca[q], a[q].x * s0));
-                b[q] = make_float2(fmaf(b[q].x, cb[q], -(b[q].y * s1)), fmaf(b[q].y, cb[q], b[q].x * s1));
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < NPF; ++q) {
-                const int p = tid + q * kFeThreads;
-                const float s0 = sa[q] * sgn, s1 = sb[q] * sgn;
-                // samples before the batch (rel < 0) come from the history and are mixed already
-                if (rel0 + 2 * p >= 0) a[q] = make_float2(fmaf(a[q].x, ca[q], -(a[q].y * s0)), fmaf(a[q].y, ca[q], a[q].x * s0));
-                if (rel0 + 2 * p + 1 >= 0) b[q] = make_float2(fmaf(b[q].x, cb[q], -(b[q].y * s1)), fmaf(b[q].y, cb[q], b[q].x * s1));
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NPF; ++q) { const int p = tid + q * kFeThreads; LEd[p] = a[q]; LOd[p] = b[q]; }
-}
-
 // Stages [0, fes_blk) run on the whole workgroup, one barrier each; when the remaining stages are small enough for
 // one wave (<= 64 output pairs, and <= 64 chain outputs for the resampler) they run on wave 0 alone with wave-level
 // hand-offs while the other waves already start on the next chunk.
@@ -658,7 +617,21 @@ __device__ __forceinline__ void fes_body(
             for (int k = 0; k < nch; ++k) {
                 const int64_t uc = u_lo + (int64_t)k * CH;
                 const int64_t rel0 = uc - (int64_t)dyn.buf0;
-                fes_mix_store<NPF>(pf, tid, rel0, dyn, sgn, tab, LE + kFeTail, LO + fes_offo<S, CH>(0) + kFeTail);
+                const bool do_mix = dyn.mixdir != 0;
+                const uint32_t th0 = dyn.theta0 + (uint32_t)rel0 * dyn.dtheta;
+#pragma unroll
+                for (int q = 0; q < NPF; ++q) {
+                    const int p = tid + q * kFeThreads;
+                    float2 a = make_float2(pf[q].x, pf[q].y), b = make_float2(pf[q].z, pf[q].w);
+                    if (do_mix) {
+                        const uint32_t tha = th0 + (uint32_t)(2 * p) * dyn.dtheta, thb = tha + dyn.dtheta;
+                        const uint32_t ia = (tha + (1u << 21)) >> 22, ib = (thb + (1u << 21)) >> 22;
+                        const float sa = tab[ia] * sgn, ca = tab[ia + 256], sb = tab[ib] * sgn, cb = tab[ib + 256];
+                        if (rel0 + 2 * p >= 0) a = make_float2(fmaf(a.x, ca, -(a.y * sa)), fmaf(a.y, ca, a.x * sa));
+                        if (rel0 + 2 * p + 1 >= 0) b = make_float2(fmaf(b.x, cb, -(b.y * sb)), fmaf(b.y, cb, b.x * sb));
+                    }
+                    LE[kFeTail + p] = a; LO[fes_offo<S, CH>(0) + kFeTail + p] = b;
+                }
                 if (k + 1 < nch) {
                     const int64_t reln = rel0 + CH;
                     const bool inside = reln >= 0 && reln + CH <= total;
@@ -735,7 +708,24 @@ __device__ __forceinline__ void fes_body(
     for (int64_t uc = u_lo; uc < u_stop; uc += CH) {
         const int64_t rel0 = uc - (int64_t)dyn.buf0;          // batch-relative index of the chunk's first input
         // ---- mix the prefetched chunk into the stage-0 arrays
-        fes_mix_store<NPF>(pf, tid, rel0, dyn, sgn, tab, LE + kFeTail, LO + fes_offo<S, CH>(0) + kFeTail);
+        {
+            const bool do_mix = dyn.mixdir != 0;
+            const uint32_t th0 = dyn.theta0 + (uint32_t)rel0 * dyn.dtheta;
+#pragma unroll
+            for (int q = 0; q < NPF; ++q) {
+                const int p = tid + q * kFeThreads;
+                float2 a = make_float2(pf[q].x, pf[q].y), b = make_float2(pf[q].z, pf[q].w);
+                if (do_mix) {
+                    const uint32_t tha = th0 + (uint32_t)(2 * p) * dyn.dtheta, thb = tha + dyn.dtheta;
+                    const uint32_t ia = (tha + (1u << 21)) >> 22, ib = (thb + (1u << 21)) >> 22;      // 0 .. 1023
+                    const float sa = tab[ia] * sgn, ca = tab[ia + 256], sb = tab[ib] * sgn, cb = tab[ib + 256];
+                    // samples before the batch (rel < 0) come from the history and are mixed already
+                    if (rel0 + 2 * p >= 0) a = make_float2(fmaf(a.x, ca, -(a.y * sa)), fmaf(a.y, ca, a.x * sa));
+                    if (rel0 + 2 * p + 1 >= 0) b = make_float2(fmaf(b.x, cb, -(b.y * sb)), fmaf(b.y, cb, b.x * sb));
+                }
+                LE[kFeTail + p] = a; LO[fes_offo<S, CH>(0) + kFeTail + p] = b;
+            }
+        }
         // ---- resampler outputs of this chunk: fetch their filter arms before the prefetch (vector-memory waits retire in order)
         const int64_t kz0 = uc >> S;
         int64_t jb = resamp_first_out(kz0 + CZ, dyn.phase0, step);

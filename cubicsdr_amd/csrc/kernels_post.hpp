@@ -209,7 +209,7 @@ struct ChanGeom {
     int threads;              // workgroup size (whole waves, 256..512): chosen so each phase splits evenly over the waves
     int p2;                   // 1: M = 2 A, A odd <= 63, critically sampled: chan_analyze_p2 (KA = slots per pass, nkA = passes, PA = row pitch)
     int mx;                   // p2 only: the A-point DFTs run on the fp32 matrix pipe (chan_analyze_p2<.., true>)
-    int alt;                  // p2 only: experiment switches of the vector form (CSDR_CHAN_ALT)
+    int alt;                  // p2 only, vector form: bit 0 = unconditional second request of a trip, bit 1 = s / d formed in the FIR phase (CSDR_CHAN_ALT; default 3)
 };
 __host__ __device__ inline size_t chan_zin_floats2(const ChanGeom &g) {      // Z array, or the staged input tile if larger
     const size_t z = (size_t)g.TF * g.S, in = g.stage_in ? (size_t)(g.TF - 1) * g.hop + (size_t)kChanTaps * g.M : 0;
