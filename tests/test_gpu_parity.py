@@ -137,20 +137,25 @@ def test_channelizer_matrix_pipe_equals_vector_form_bit_for_bit(ctx, M, frames):
     block = M * frames
     x = synth_iq_fast(3 * block, fs, center, [("NBFM", center + 123456), ("AM", center - 3 * (fs // M) + 999)], seed=5)
     outs = []
-    saved = os.environ.get("CSDR_CHAN_MX")
+    saved = {k: os.environ.get(k) for k in ("CSDR_CHAN_MX", "CSDR_CHAN_ALT")}
     try:
-        for mx in ("0", "1", "2", "3", "4"):                          # vector form, then the four matrix-pipe variants (csdr_api.hip: chan_geometry)
+        # the vector form as round 2 had it (s / d formed by every wave in its DFT pass, guarded second request), the four matrix-pipe
+        # variants, then the vector form's other three (s / d formed once in the FIR phase by a lane trade; unconditional request; both =
+        # the default): csdr_api.hip, chan_geometry
+        for mx, alt in (("0", "0"), ("1", "0"), ("2", "0"), ("3", "0"), ("4", "0"), ("0", "1"), ("0", "2"), ("0", "3")):
             os.environ["CSDR_CHAN_MX"] = mx
+            os.environ["CSDR_CHAN_ALT"] = alt
             p = SDRPost(ctx, fs, M, block, max_blocks=3)
             p.execute(x, 3, block, center)
             outs.append([p.read_channel(ch) for ch in range(M)])
             p.close()
     finally:
-        if saved is None:
-            os.environ.pop("CSDR_CHAN_MX", None)
-        else:
-            os.environ["CSDR_CHAN_MX"] = saved
-    for v in range(1, 5):
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for v in range(1, len(outs)):
         for ch, (a, b) in enumerate(zip(outs[0], outs[v])):
             assert a.size == 3 * frames and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (M, v, ch, float(np.max(np.abs(a - b))))
 
