@@ -155,6 +155,22 @@ __device__ inline float4 fe_fetch_pair(const float2 *__restrict__ chan, const fl
     return make_float4(a.x, a.y, b.x, b.y);
 }
 
+// the NPF pairs of a thread for one chunk (pair p = tid + q kFeThreads starts at rel_first + 2 q kFeThreads).  A chunk that lies wholly inside the
+// batch takes NPF independent 16-byte loads in a block of its own; routed pair by pair through fe_fetch_pair, every load was compiled
+// behind an s_waitcnt vmcnt(0) (its destination registers are also written on the history path): four serialised HBM round trips per chunk
+template <int NPF>
+__device__ __forceinline__ void fe_fetch_chunk(float4 (&pf)[NPF], const float2 *__restrict__ chan, const float2 *__restrict__ hist, int hist_len,
+                                               int64_t rel_first, int64_t total, bool inside /* chunk-uniform */) {
+    if (inside) {
+        const f4u *src = reinterpret_cast<const f4u *>(chan + rel_first);
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) { const f4u v = src[q * kFeThreads]; pf[q] = make_float4(v.x, v.y, v.z, v.w); }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) pf[q] = fe_fetch_pair(chan, hist, hist_len, rel_first + 2 * q * kFeThreads, total, false);
+    }
+}
+
 __device__ inline float2 fe_mix(float2 x, int64_t rel, const SlotDyn &dyn, const float *tab) {
     if (dyn.mixdir == 0 || rel < 0) return x;          // history samples are stored mixed
     float s, c;
@@ -609,8 +625,7 @@ __device__ __forceinline__ void fes_body(
         if (!tailw) {
             const int64_t rel0 = u_lo - (int64_t)dyn.buf0;
             const bool inside = rel0 >= 0 && rel0 + CH <= total;
-#pragma unroll
-            for (int q = 0; q < NPF; ++q) pf[q] = fe_fetch_pair(chan, hist, hist_len, rel0 + 2 * (tid + q * kFeThreads), total, inside);
+            fe_fetch_chunk<NPF>(pf, chan, hist, hist_len, rel0 + 2 * tid, total, inside);
         }
         __syncthreads();
         if (!tailw) {
@@ -635,8 +650,7 @@ __device__ __forceinline__ void fes_body(
                 if (k + 1 < nch) {
                     const int64_t reln = rel0 + CH;
                     const bool inside = reln >= 0 && reln + CH <= total;
-#pragma unroll
-                    for (int q = 0; q < NPF; ++q) pf[q] = fe_fetch_pair(chan, hist, hist_len, reln + 2 * (tid + q * kFeThreads), total, inside);
+                    fe_fetch_chunk<NPF>(pf, chan, hist, hist_len, reln + 2 * tid, total, inside);
                 }
                 __syncthreads();                                                        // B1
                 FesStages<S, CH, 0, BLK, false>::run(LE, LO, LZ, hb, zeta, tid);        // B2 .. B(BLK+1)
@@ -699,8 +713,7 @@ __device__ __forceinline__ void fes_body(
     {
         const int64_t rel0 = u_lo - (int64_t)dyn.buf0;
         const bool inside = rel0 >= 0 && rel0 + CH <= total;
-#pragma unroll
-        for (int q = 0; q < NPF; ++q) pf[q] = fe_fetch_pair(chan, hist, hist_len, rel0 + 2 * (tid + q * kFeThreads), total, inside);
+        fe_fetch_chunk<NPF>(pf, chan, hist, hist_len, rel0 + 2 * tid, total, inside);
     }
     int64_t ja = resamp_first_out(u_lo >> S, dyn.phase0, step);
     __syncthreads();
@@ -745,8 +758,7 @@ __device__ __forceinline__ void fes_body(
         if (uc + CH < u_stop) {
             const int64_t reln = rel0 + CH;
             const bool inside = reln >= 0 && reln + CH <= total;
-#pragma unroll
-            for (int q = 0; q < NPF; ++q) pf[q] = fe_fetch_pair(chan, hist, hist_len, reln + 2 * (tid + q * kFeThreads), total, inside);
+            fe_fetch_chunk<NPF>(pf, chan, hist, hist_len, reln + 2 * tid, total, inside);
         }
         __syncthreads();
         // the previous chunk's resampler is done (barrier above): its Z tail may move to the front now
