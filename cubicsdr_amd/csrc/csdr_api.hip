@@ -1272,29 +1272,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         CSDR_LAUNCH(c, LANE_FE, KID_FE_S56, demod_frontend_s56, dim3(std::max(P6, P5) + 1, grp_n[6] + grp_n[5]), dim3(kFeThreads + 64), (fes_lds_bytes<6, 2048>()),
                     b->cfgs.p, dyns_d, grp_d + grp_off[6], grp_n[6], P6, grp_d + grp_off[5], P5, chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
     }
-    // CSDR_FE_CH=1536: 1536-sample chunks for the two tail-wave depths (five resident workgroups per CU instead of four)
-    static const bool fe_ch1536 = getenv("CSDR_FE_CH") ? atoi(getenv("CSDR_FE_CH")) == 1536 : kFeChunk1536Default;
-    if (fe_ch1536 && !merged && tw6) {
-        const int slots15 = std::max(1, c->wg_slots(demod_frontend_s<5, 1536, true>, kFeThreads + 64, fes_lds_bytes<5, 1536>()) * fe_pct / 100);
-        auto ranges15 = [&](int n_slots) {
-            int P = (int)std::max<int64_t>(1, std::min<int64_t>(total / std::max<int64_t>(4096, 4 * (int64_t)warm_max), 4096));
-            const int per_slot = slots15 / std::max(1, n_slots) - 1;
-            if (per_slot >= 1) P = std::min(P, per_slot);
-            else {
-                const int rounds = (n_slots * 2 + slots15 - 1) / slots15;
-                P = std::max(1, std::min(P, rounds * slots15 / std::max(1, n_slots) - 1));
-            }
-            return P;
-        };
-        if (grp_n[6] > 0)
-            CSDR_LAUNCH(c, LANE_FE, KID_FE_S6, (demod_frontend_s<6, 1536, true>), dim3(ranges15(grp_n[6]) + 1, grp_n[6]), dim3(kFeThreads + 64), (fes_lds_bytes<6, 1536>()),
-                        b->cfgs.p, dyns_d, grp_d + grp_off[6], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
-        if (grp_n[5] > 0)
-            CSDR_LAUNCH(c, LANE_FE, KID_FE_S5, (demod_frontend_s<5, 1536, true>), dim3(ranges15(grp_n[5]) + 1, grp_n[5]), dim3(kFeThreads + 64), (fes_lds_bytes<5, 1536>()),
-                        b->cfgs.p, dyns_d, grp_d + grp_off[5], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
-    }
-    const bool done56 = fe_ch1536 && !merged && tw6;
-    if (grp_n[6] > 0 && !merged && !done56) {          // depth 6 (AM / SSB from ~500 kS/s channels): tail wave with three tail stages (CSDR_FE_TW6=0: without)
+    if (grp_n[6] > 0 && !merged) {          // depth 6 (AM / SSB from ~500 kS/s channels): tail wave with three tail stages (CSDR_FE_TW6=0: without)
         if (tw6)
             CSDR_LAUNCH(c, LANE_FE, KID_FE_S6, (demod_frontend_s<6, 2048, true>), dim3(ranges_for(grp_n[6]) + 1, grp_n[6]), dim3(kFeThreads + 64), (fes_lds_bytes<6, 2048>()),
                         b->cfgs.p, dyns_d, grp_d + grp_off[6], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
@@ -1307,7 +1285,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         CSDR_LAUNCH(c, LANE_FE, KID_FE_INTERP, demod_frontend_interp, dim3(nchunks + 1, grp_n[7]), dim3(kFeThreads), kFiLds, b->cfgs.p, dyns_d, grp_d + grp_off[7],
                     chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
     }
-    if (grp_n[5] > 0 && !merged && !done56)            // depth 5 (NBFM from ~500 kS/s channels): a fifth wave runs the one-wave tail one chunk behind
+    if (grp_n[5] > 0 && !merged)            // depth 5 (NBFM from ~500 kS/s channels): a fifth wave runs the one-wave tail one chunk behind
         CSDR_LAUNCH(c, LANE_FE, KID_FE_S5, (demod_frontend_s<5, 2048, true>), dim3(ranges_for(grp_n[5]) + 1, grp_n[5]), dim3(kFeThreads + 64), (fes_lds_bytes<5, 2048>()),
                     b->cfgs.p, dyns_d, grp_d + grp_off[5], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
 #undef CSDR_FE_S

@@ -29,7 +29,6 @@ constexpr int kScopeMax = 2048;   // DEMOD_VIS_SIZE (DemodulatorThread.h:15)
 constexpr int kFeThreads = 256;
 constexpr int kFeChunk = 2048;    // input samples one inner iteration of the front-end stages through LDS
 constexpr int kFePairs = kFeChunk / 2 / kFeThreads;   // 16-byte loads per thread per chunk
-constexpr bool kFeChunk1536Default = false;   // tail-wave depths (5, 6): 1536-sample chunks instead of 2048 (CSDR_FE_CH overrides)
 constexpr int kFeTail = 24;       // per-stage carried tail (>= 2 * kHbMaxM)
 constexpr int kFeZTail = 16;      // carried tail of the half-band chain output (>= 13)
 
@@ -783,9 +782,11 @@ __device__ __forceinline__ void fes_body(
     }
 }
 
-// (CH = 1536 with the tail wave: 31.5 KB of LDS and <= 72 registers, so that FIVE workgroups of five waves share a CU instead of four)
+// (Five waves per SIMD: the tail-wave form must stay at or below 80 registers -- four resident workgroups of five waves need five wave slots
+// on every SIMD; at 84 the fourth workgroup is lost and the kernel runs 60 % longer.  1536-sample chunks with five workgroups per CU were
+// measured too: 0.97 ms against 0.68 ms, the per-chunk barrier chain does not shrink with the chunk.)
 template <int S, int CH, bool TW = false>
-__global__ __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? (CH <= 1536 ? 7 : 5) : 4) void demod_frontend_s(
+__global__ __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? 5 : 4) void demod_frontend_s(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
     const float2 *__restrict__ chan_base, int64_t chan_stride, int64_t total, const float *__restrict__ arms_all, const float *__restrict__ sintab) {
     fes_body<S, CH, TW>(cfgs, dyns, slot_list[blockIdx.y], (int)blockIdx.x, (int)gridDim.x - 1, chan_base, chan_stride, total, arms_all, sintab);
