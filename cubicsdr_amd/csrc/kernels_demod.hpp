@@ -786,7 +786,7 @@ __device__ __forceinline__ void fes_body(
 // on every SIMD; at 84 the fourth workgroup is lost and the kernel runs 60 % longer.  1536-sample chunks with five workgroups per CU were
 // measured too: 0.97 ms against 0.68 ms, the per-chunk barrier chain does not shrink with the chunk.)
 template <int S, int CH, bool TW = false>
-__global__ __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? 5 : 4) void demod_frontend_s(
+__global__ __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? 6 : 4) void demod_frontend_s(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
     const float2 *__restrict__ chan_base, int64_t chan_stride, int64_t total, const float *__restrict__ arms_all, const float *__restrict__ sintab) {
     fes_body<S, CH, TW>(cfgs, dyns, slot_list[blockIdx.y], (int)blockIdx.x, (int)gridDim.x - 1, chan_base, chan_stride, total, arms_all, sintab);
