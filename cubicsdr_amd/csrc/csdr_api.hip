@@ -307,7 +307,7 @@ static int chan_geometry(int M, int hop, ChanGeom &g) {
         // vector form: s = x_c + x_{A-c} / d = x_c - x_{A-c} are formed once, in the FIR phase (a lane trade), instead of by all eight waves in
         // their DFT passes, and the second row request of a trip is unconditional (no register-set copies).  Same sums, same order: the
         // output is bit-identical.  Measured on C3: 0.581 -> 0.564 ms.  CSDR_CHAN_ALT=0 restores the round-2 form (A/B).
-        g.alt = getenv("CSDR_CHAN_ALT") ? (atoi(getenv("CSDR_CHAN_ALT")) & 3) : 3;
+        g.alt = getenv("CSDR_CHAN_ALT") ? (atoi(getenv("CSDR_CHAN_ALT")) != 0) : 1;
         if (g.mx >= 3) { g.TF = 32; g.lgTF = 5; g.threads = P2Tile<32>::threads; }
         return CSDR_OK;
     }

@@ -209,7 +209,7 @@ struct ChanGeom {
     int threads;              // workgroup size (whole waves, 256..512): chosen so each phase splits evenly over the waves
     int p2;                   // 1: M = 2 A, A odd <= 63, critically sampled: chan_analyze_p2 (KA = slots per pass, nkA = passes, PA = row pitch)
     int mx;                   // p2 only: the A-point DFTs run on the fp32 matrix pipe (chan_analyze_p2<.., true>)
-    int alt;                  // p2 only, vector form: bit 0 = unconditional second request of a trip, bit 1 = s / d formed in the FIR phase (CSDR_CHAN_ALT; default 3)
+    int alt;                  // p2 only, vector form: 1 = s / d formed in the FIR phase + unconditional second request of a trip (default), 0 = the round-2 form (CSDR_CHAN_ALT)
 };
 __host__ __device__ inline size_t chan_zin_floats2(const ChanGeom &g) {      // Z array, or the staged input tile if larger
     const size_t z = (size_t)g.TF * g.S, in = g.stage_in ? (size_t)(g.TF - 1) * g.hop + (size_t)kChanTaps * g.M : 0;
@@ -549,8 +549,9 @@ __device__ __forceinline__ void chan_p2_term(const float4 a, const float4 b, con
 
 // the conjugate-pair sums of one pass (KP slots, both c2) over the terms c = 1 .. H.  Software pipeline, two terms per trip with two
 // register sets: the rows and the (cos, sin) row of the next term are requested before the current one is accumulated.
-// UNC: the second request of a trip is unconditional (the last trip re-reads term H) instead of guarded -- A/B switch CSDR_CHAN_ALT bit 0;
-// SD: rows hold s / d already (bit 1).
+// UNC: the second request of a trip is unconditional (the last trip re-reads term H) instead of guarded; SD: rows hold s / d already.
+// (CSDR_CHAN_ALT=0 selects <false, false>, the round-2 form; all four combinations were measured: a four-way switch costs one more
+// spilled float4 in the tile loop.)
 template <int KP, bool SD, bool UNC>
 __device__ __forceinline__ void chan_p2_accumulate(const float4 *row, const int A, const int H, const float2 *__restrict__ w, const int PA,
                                                    float2 (&P0)[KP], float2 (&Q0)[KP], float2 (&P1)[KP], float2 (&Q1)[KP]) {
@@ -692,7 +693,7 @@ __global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
             const int ta = wave * kRange;
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
             float4 halo[kChanTaps - 1], w[kChanTaps];
-            const bool sd = !MX && (g.alt & 2) != 0;
+            const bool sd = !MX && g.alt != 0;
 #pragma unroll
             for (int j = 0; j < kChanTaps - 1; ++j) halo[j] = col ? rows[(ta + kRange + j) * A + lane] : z4;
 #pragma unroll
@@ -708,10 +709,14 @@ __global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
                     acc.z = fmaf(h[n].y, v.z, acc.z); acc.w = fmaf(h[n].y, v.w, acc.w);
                 }
                 if (sd) {                                     // columns c and A - c trade: s_c = x_c + x_{A-c} at row c, d_c = x_c - x_{A-c} at row A - c
+                    // (one component at a time: a float4 of partner values at once is one more spilled float4 in this phase)
                     const int pl = (lane >= 1 && lane < A) ? A - lane : lane;
-                    const float4 pv = make_float4(__shfl(acc.x, pl, 64), __shfl(acc.y, pl, 64), __shfl(acc.z, pl, 64), __shfl(acc.w, pl, 64));
-                    if (lane >= 1 && lane <= H) acc = make_float4(acc.x + pv.x, acc.y + pv.y, acc.z + pv.z, acc.w + pv.w);
-                    else if (lane > H && lane < A) acc = make_float4(pv.x - acc.x, pv.y - acc.y, pv.z - acc.z, pv.w - acc.w);
+                    const bool is_s = lane >= 1 && lane <= H, is_d = lane > H && lane < A;
+                    float p;
+                    p = __shfl(acc.x, pl, 64); acc.x = is_s ? acc.x + p : (is_d ? p - acc.x : acc.x);
+                    p = __shfl(acc.y, pl, 64); acc.y = is_s ? acc.y + p : (is_d ? p - acc.y : acc.y);
+                    p = __shfl(acc.z, pl, 64); acc.z = is_s ? acc.z + p : (is_d ? p - acc.z : acc.z);
+                    p = __shfl(acc.w, pl, 64); acc.w = is_s ? acc.w + p : (is_d ? p - acc.w : acc.w);
                 }
                 if (col) rows[(ta + i) * A + lane] = acc;
 #pragma unroll
@@ -827,12 +832,8 @@ __global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
                     P0[j] = make_float2(x0.x, x0.y); P1[j] = make_float2(x0.z, x0.w);
                     Q0[j] = make_float2(0.f, 0.f); Q1[j] = make_float2(0.f, 0.f);
                 }
-                switch (g.alt & 3) {
-                    case 1: chan_p2_accumulate<KP, false, true>(row, A, H, cs + q0, g.PA, P0, Q0, P1, Q1); break;
-                    case 2: chan_p2_accumulate<KP, true, false>(row, A, H, cs + q0, g.PA, P0, Q0, P1, Q1); break;
-                    case 3: chan_p2_accumulate<KP, true, true>(row, A, H, cs + q0, g.PA, P0, Q0, P1, Q1); break;
-                    default: chan_p2_accumulate<KP, false, false>(row, A, H, cs + q0, g.PA, P0, Q0, P1, Q1); break;
-                }
+                if (g.alt) chan_p2_accumulate<KP, true, true>(row, A, H, cs + q0, g.PA, P0, Q0, P1, Q1);
+                else chan_p2_accumulate<KP, false, false>(row, A, H, cs + q0, g.PA, P0, Q0, P1, Q1);      // the round-2 form (A/B, bit-identity test)
                 float2 *ob = out + f0;                                  // wave-uniform row bases + a 32-bit lane offset: scalar-base stores
                 const unsigned tb = (unsigned)t * (unsigned)sizeof(float2);   // byte offset of this lane inside a channel row
     #pragma unroll

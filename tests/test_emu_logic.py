@@ -225,7 +225,7 @@ def test_emu_spectrum_nan_repairs_frame_by_frame(ctx):
 
 
 def test_emu_channelizer_vector_forms_bit_identical(ctx):
-    """the vector form's request / trade variants (CSDR_CHAN_ALT 0..3: s / d formed per wave or once in the FIR phase) give the same bits"""
+    """the vector form's request / trade variants (CSDR_CHAN_ALT 0 / 1: s / d formed per wave or once in the FIR phase) give the same bits"""
     from cubicsdr_amd.engine import SDRPost
     from tests.util import synth_iq
     M, frames = 122, 150
@@ -234,7 +234,7 @@ def test_emu_channelizer_vector_forms_bit_identical(ctx):
     outs = []
     saved = os.environ.get("CSDR_CHAN_ALT")
     try:
-        for alt in ("0", "1", "2", "3"):
+        for alt in ("0", "1"):
             os.environ["CSDR_CHAN_ALT"] = alt
             p = SDRPost(ctx, fs, M, block, max_blocks=2)
             p.execute(x, 2, block, center)
@@ -245,6 +245,6 @@ def test_emu_channelizer_vector_forms_bit_identical(ctx):
             os.environ.pop("CSDR_CHAN_ALT", None)
         else:
             os.environ["CSDR_CHAN_ALT"] = saved
-    for v in range(1, 4):
+    for v in range(1, len(outs)):
         for ch, (a, b) in enumerate(zip(outs[0], outs[v])):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (v, ch)
