@@ -501,6 +501,7 @@ __global__ __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kP2Frames = 64;          // frames per tile of the vector form (lane = frame in its DFT phase)
 constexpr int kP2Waves = 8;
+constexpr int kP2EarlyRows = 8;          // rows of the next tile's FIR window requested before the DFT phase (the first frame's whole window); the other seven after it
 constexpr int kP2Threads = 64 * kP2Waves;
 constexpr int kP2MaxA = 63;
 // tile geometry as a function of the frames per tile TF (64, or 32 for the matrix-pipe form): eight frames per wave in the FIR phase
@@ -624,6 +625,27 @@ __device__ __forceinline__ void chan_p2_request(const float2 *__restrict__ x, co
     }
 }
 
+// the window of one wave's FIR range, straight into registers: the 8 frames [ta, ta + 8) of tile `tile` need the 15 input rows
+// f0 + ta - 7 .. f0 + ta + 7; lane = column pair, a row is 16 A contiguous bytes per wave.  Rows in front of the batch come from the carried
+// history, rows past its end are zero (their frames are never stored).  The row index and the source select are wave-uniform: fifteen
+// plain loads under one lane mask, nothing between them.
+template <int TF, int J0 = 0, int J1 = 2 * kChanTaps - 1>
+__device__ __forceinline__ void chan_p2_request_window(const float2 *__restrict__ x, const float2 *__restrict__ hist, int M, int A, int64_t n_frames,
+                                                       int64_t tile, bool valid, int wave, int lane, float4 (&win)[2 * kChanTaps - 1]) {
+    const int64_t r0 = tile * TF + (int64_t)wave * kChanTaps - (kChanTaps - 1);      // input row of win[0]
+    const bool col = lane < A;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = J0; j < J1; ++j) {
+        const int64_t r = r0 + j;                                                   // wave-uniform
+        const float2 *src = r >= 0 ? x + r * M : hist + (r + (kChanTaps - 1)) * M;
+        win[j] = z4;
+        if (valid && r < n_frames) {                                                // (wave-uniform)
+            if (col) { const f4u v = *reinterpret_cast<const f4u *>(src + 2 * lane); win[j] = make_float4(v.x, v.y, v.z, v.w); }
+        }
+    }
+}
+
 // MX = true: the DFT phase runs on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32), see "DFT on the matrix pipe" below; `cs` then is
 // the coefficient-fragment table of chan_mx_table().
 template <int KP, bool MX = false, int TF = 64>
@@ -667,44 +689,35 @@ __global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
             mx_on[r] = (active[k] ? 1 : 0) | (active[k + A] ? 2 : 0) | (active[kn] ? 4 : 0) | (active[kn + A] ? 8 : 0);
         }
     }
-    float4 pre[kP2Pre];
+    float4 win[2 * kChanTaps - 1];                              // this wave's FIR window of the tile: input rows f0 + ta - 7 .. f0 + ta + 7
     int64_t tile = blockIdx.x;
-    if (tile == 0) chan_p2_request<true, TF>(x, hist, M, n_frames, tile, true, pre);
-    else chan_p2_request<false, TF>(x, hist, M, n_frames, tile, tile < n_tiles, pre);
+    chan_p2_request_window<TF>(x, hist, M, A, n_frames, tile, tile < n_tiles, wave, lane0, win);
     for (; tile < n_tiles; tile += gridDim.x) {
         const int64_t f0 = tile * kP2Frames;
         const int nf = (int)min((int64_t)kP2Frames, n_frames - f0);
         int lane = lane0, tid = tid0;                         // per-tile copies: their address arithmetic is not worth carrying across tiles
         opaque(lane); opaque(tid);
-        {   // commit the prefetched rows
-            const int n_in2 = ((nf - 1) * M + kChanTaps * M) >> 1;
-#pragma unroll
-            for (int i = 0; i < kP2Pre; ++i) { const int p = tid + i * kP2Threads; if (p < n_in2) rows[p] = pre[i]; }
-        }
         const bool col = lane < A;
         float2 h[kChanTaps];
+        {   // (lanes past the last column read the last column's taps: nothing of theirs is stored, and a guarded load is compiled behind a
+            // wait for everything in flight -- eight serialised round trips per tile)
+            const int lc = min(lane, A - 1);
 #pragma unroll
-        for (int n = 0; n < kChanTaps; ++n) h[n] = col ? *reinterpret_cast<const float2 *>(tapsT + n * M + 2 * lane) : make_float2(0.f, 0.f);
-        lds_barrier();
-        // ---- FIR: frames [ta, ta + 8) of this wave, window rows t .. t + 7 in registers
+            for (int n = 0; n < kChanTaps; ++n) h[n] = *reinterpret_cast<const float2 *>(tapsT + n * M + 2 * lc);
+        }
+        // ---- FIR: frames [ta, ta + 8) of this wave from the window in registers (requested one tile ahead); X[t] goes to row t of the LDS array
         {
             constexpr int kRange = kP2Frames / kP2Waves;
-            static_assert(kRange == kChanTaps, "the window of a range is exactly its own rows; everything after comes from the halo");
+            static_assert(kRange == kChanTaps, "a wave's range is eight frames: its window is fifteen rows");
             const int ta = wave * kRange;
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 halo[kChanTaps - 1], w[kChanTaps];
             const bool sd = !MX && g.alt != 0;
-#pragma unroll
-            for (int j = 0; j < kChanTaps - 1; ++j) halo[j] = col ? rows[(ta + kRange + j) * A + lane] : z4;
-#pragma unroll
-            for (int j = 0; j < kChanTaps; ++j) w[j] = col ? rows[(ta + j) * A + lane] : z4;
-            lds_barrier();                                  // every wave holds its rows and its upper halo: rows may now be overwritten
 #pragma unroll
             for (int i = 0; i < kRange; ++i) {
                 float4 acc = z4;
 #pragma unroll
-                for (int n = 0; n < kChanTaps; ++n) {         // tap n multiplies input row t - n = window row 7 - n
-                    const float4 v = w[kChanTaps - 1 - n];
+                for (int n = 0; n < kChanTaps; ++n) {         // tap n multiplies input row t - n = window entry i + 7 - n
+                    const float4 v = win[i + kChanTaps - 1 - n];
                     acc.x = fmaf(h[n].x, v.x, acc.x); acc.y = fmaf(h[n].x, v.y, acc.y);
                     acc.z = fmaf(h[n].y, v.z, acc.z); acc.w = fmaf(h[n].y, v.w, acc.w);
                 }
@@ -719,15 +732,12 @@ __global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
                     p = __shfl(acc.w, pl, 64); acc.w = is_s ? acc.w + p : (is_d ? p - acc.w : acc.w);
                 }
                 if (col) rows[(ta + i) * A + lane] = acc;
-#pragma unroll
-                for (int j = 0; j < kChanTaps - 1; ++j) w[j] = w[j + 1];
-                if (i + 1 < kRange) w[kChanTaps - 1] = halo[i];
-                sched_fence();                                // frame after frame: interleaving all eight costs ~100 registers
+                sched_fence();                                // frame after frame
             }
         }
         lds_barrier();
-        // the next tile's input is on its way while this one is transformed
-        chan_p2_request<false, TF>(x, hist, M, n_frames, tile + gridDim.x, tile + gridDim.x < n_tiles, pre);
+        // the next tile's window is on its way while this one is transformed (into the registers the FIR has just finished with)
+        chan_p2_request_window<TF, 0, kP2EarlyRows>(x, hist, M, A, n_frames, tile + gridDim.x, tile + gridDim.x < n_tiles, wave, lane, win);
         if constexpr (MX) {
         // ---- DFT on the matrix pipe.  The conjugate-pair sums are two real matrix products per component:
         //        P[k][t] = sum_n Cos[k][n] s_n[t]      Q[k][t] = sum_n Sin[k][n] d_n[t]        k, n = 0 .. H   (s_0 = x_0, Cos[k][0] = 1, Sin[k][0] = 0)
@@ -869,6 +879,8 @@ __global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
                 }
             }
         }
+        // the rest of the next window (the transform above leaves no room for all fifteen rows: they would be spilled -- which waits for them)
+        chan_p2_request_window<TF, kP2EarlyRows, 2 * kChanTaps - 1>(x, hist, M, A, n_frames, tile + gridDim.x, tile + gridDim.x < n_tiles, wave, lane0, win);
         lds_barrier();                                      // the rows are free for the next tile
         if constexpr (MX) {
             if (dc_ends && tid0 == 0) {
