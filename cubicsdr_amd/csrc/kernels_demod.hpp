@@ -1340,6 +1340,27 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
         while (bb > 0 && j < pl[bb].j0) --bb;
         return cfg.d[j] * (0.5f / cfg.blockmaa[bb]);                  // block bb holds sample j, so it stepped the gain
     };
+    if (!plain && !autogain) {
+        // the FM discriminator's window, four samples of a lane at a time: all eight IQ loads are in flight before the first arctangent (the
+        // general form below is a load, a wait and an arctangent per sample).  Indices are clamped instead of guarded, the results selected.
+        const int64_t jmin = -(int64_t)(kIqHist - 1);
+        for (int i0 = tid; i0 < nwin; i0 += 4 * nthr) {
+            float2 c4[4], p4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t j = jlo + min(i0 + u * nthr, nwin - 1);
+                const int64_t jc = j < jmin ? jmin : j;
+                c4[u] = iq[jc]; p4[u] = iq[jc - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * nthr;
+                const float2 c = c4[u], pq = p4[u];
+                const float v = atan2f(c.y * pq.x - c.x * pq.y, c.x * pq.x + c.y * pq.y) * fm_ref;
+                if (i < nwin) s_d[i] = (jlo + i) < jmin ? 0.f : v;
+            }
+        }
+    } else
     for (int i = tid; i < nwin; i += nthr) s_d[i] = demod_sample(jlo + i);
     // the last block's own scaled samples are the scope tap (ModemAnalog::getDemodOutputData, DemodulatorThread.cpp:293-305): the WHOLE
     // block, up to DEMOD_VIS_SIZE -- those the cascade of this block already staged, and the trailing ones a decimating cascade leaves
@@ -1381,17 +1402,28 @@ __global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
             s_w0[i] = acc;
         }
     }
-    for (int i = tid + 2 * nthr; i < nv; i += nthr) {
-        const int64_t q = lo[0] + i;
-        const int64_t P = (int64_t)dyn.aphase0 + q * (int64_t)au.step;
-        const int64_t jq = P >> 24;
-        const int arm = (int)((P & 0xFFFFFF) >> 16);
-        const float *h = arms + arm * kArmTaps;
-        const float *z = s_d + (jq - (kArmTaps - 1) - jlo);
-        float acc = 0.f;
+    // the outputs after a thread's first two, two at a time: the filter arms of both are requested before either dot product
+    for (int i0 = tid + 2 * nthr; i0 < nv; i0 += 2 * nthr) {
+        float2 ha[2][kArmTaps / 2];
+        int zo[2];
 #pragma unroll
-        for (int t = 0; t < kArmTaps; ++t) acc = fmaf(h[t], z[t], acc);
-        s_w0[i] = acc;
+        for (int r = 0; r < 2; ++r) {
+            const int i = min(i0 + r * nthr, nv - 1);                       // (an index past the end re-reads the last output's arm: never stored)
+            const int64_t P = (int64_t)dyn.aphase0 + (lo[0] + i) * (int64_t)au.step;
+            zo[r] = (int)((P >> 24) - (kArmTaps - 1) - jlo);
+            const float2 *h2 = reinterpret_cast<const float2 *>(arms + (int)((P & 0xFFFFFF) >> 16) * kArmTaps);
+#pragma unroll
+            for (int t = 0; t < kArmTaps / 2; ++t) ha[r][t] = h2[t];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = i0 + r * nthr;
+            const float *z = s_d + zo[r];
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < kArmTaps / 2; ++t) { acc = fmaf(ha[r][t].x, z[2 * t], acc); acc = fmaf(ha[r][t].y, z[2 * t + 1], acc); }
+            if (i < nv) s_w0[i] = acc;
+        }
     }
     __syncthreads();
     // 2. x2 stages: w'[2q] = w[q - m], w'[2q+1] = sum_j h1[j] w[q - j]
