@@ -482,16 +482,17 @@ __global__ __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
 // ------------------------------------------------------------------------------------------------------------
 // K2 + K4 for M = 2 A with A odd (M = 6, 10, 14, 22, ... 122 = the 61.44 MS/s case, A <= 63): the Cooley-Tukey split has B = 2,
 // so the B-point pass is one butterfly and the whole transform of a frame stays inside one lane.
-// Persistent workgroups of eight waves (two per CU) walk over tiles of 64 consecutive frames; LDS holds ONE array of
-// (64 + 7) rows of M samples:
-//  prefetch the tile's input rows are requested as 16-byte coalesced loads into registers while the PREVIOUS tile's DFT runs
-//           (the two workgroups of a CU otherwise stay in lockstep -- loading together, computing together -- and the phases
-//           add up: measured 0.17 + 0.15 + 0.08 ms for load + FIR, DFT, stores against 0.34 ms in total), then committed to LDS
-//  FIR      lane = column pair (c1; c2 = 0, 1 = one float4), wave = 8 consecutive frames walked in ascending order with
-//           the eight rows of the window in REGISTERS: one ds_read_b128 + one ds_write_b128 per frame instead of eight
-//           reads (the taps live in registers too).  X[t] overwrites row t in place: a row is last needed by the frame
-//           that replaces it; the seven rows a wave needs from its upper neighbour's range are fetched before that
-//           neighbour starts writing (one barrier).
+// Persistent workgroups of eight waves (two per CU) walk over tiles of 64 consecutive frames; LDS holds ONE array of 64 rows
+// X[t][c] (the FIR's output; the array is sized 64 + 7 rows for the matrix-pipe form's staged stores):
+//  window   lane = column pair (c1; c2 = 0, 1 = one float4), wave = 8 consecutive frames: the fifteen input rows those frames
+//           reach (16 A contiguous bytes per wave and row) are loaded straight from global memory into the registers the FIR
+//           reads -- requested one tile ahead, eight rows before the DFT phase of the previous tile and seven after it (all
+//           fifteen at once do not fit next to the accumulators).  Until the middle of round 3 the tile went through a flat
+//           register stage, a commit to LDS and halo reads: two more barriers per tile, 36 registers, and a load skeleton that alone
+//           took half of the kernel.  Neighbouring waves read seven rows twice: cache hits, the HBM traffic is the same.
+//  FIR      the eight frames in ascending order from the window; the taps (a guarded load is compiled behind a wait for everything in
+//           flight: they are read without a lane guard) live in registers; then s = x_c + x_{A-c} / d = x_c - x_{A-c} by a lane trade,
+//           X[t] to LDS.
 //  DFT      lane = frame t, wave = KP of the (A - 1) / 2 conjugate output pairs (k, A - k) for BOTH c2 at once
 //           (4 KP accumulators): per term c one ds_read_b128 pair x_c, x_{A-c} (row stride 4 A dwords: conflict-free for
 //           odd A), the (cos, sin) rows are wave-uniform scalar loads, both requested one term ahead; then the radix-2
@@ -507,7 +508,6 @@ constexpr int kP2MaxA = 63;
 // tile geometry as a function of the frames per tile TF (64, or 32 for the matrix-pipe form): eight frames per wave in the FIR phase
 template <int TF> struct P2Tile {
     static constexpr int waves = TF / kChanTaps, threads = 64 * waves;
-    static constexpr int pre = ((TF + kChanTaps - 1) * kP2MaxA + threads - 1) / threads;     // float4 registers per thread holding a tile's input
     static constexpr int ctiles = TF / 16;                                                  // 16-frame column tiles of the matrix-pipe form
 };
 __host__ __device__ inline size_t chan_p2_lds_bytes(int M, int TF = kP2Frames) { return (size_t)(TF + kChanTaps - 1) * M * sizeof(float2) + 4 * 2 * sizeof(double); }
@@ -590,41 +590,6 @@ __device__ __forceinline__ void chan_p2_accumulate(const float4 *row, const int 
     if (c <= H) chan_p2_term<KP, SD>(a, b, eA, P0, Q0, P1, Q1);        // H odd: the last term
 }
 
-// request the input of `tile` (rows f0 - 7 .. f0 + nf - 1 as one flat run of float4) into registers.  Every element of `pre`
-// is assigned (zero where there is nothing to load) so that the registers are dead between a commit and the next request.
-template <bool FIRST /* the tile may reach back into the carried history (tile 0 only) */, int TF>
-__device__ __forceinline__ void chan_p2_request(const float2 *__restrict__ x, const float2 *__restrict__ hist, int M, int64_t n_frames, int64_t tile,
-                                                bool valid, float4 (&pre)[P2Tile<TF>::pre]) {
-    constexpr int kP2Frames = TF, kP2Threads = P2Tile<TF>::threads, kP2Pre = P2Tile<TF>::pre;
-    const int tid = threadIdx.x;
-    const int64_t f0 = tile * kP2Frames, Hs = (int64_t)(kChanTaps - 1) * M;
-    const int nf = (int)min((int64_t)kP2Frames, n_frames - f0);
-    const int n_in2 = valid ? ((nf - 1) * M + kChanTaps * M) >> 1 : 0;
-    const int64_t gbase = f0 * M - Hs;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!FIRST) {                                             // one wave-uniform base, 32-bit lane offsets
-        const float4 *src4 = reinterpret_cast<const float4 *>(x + gbase);
-#pragma unroll
-        for (int i = 0; i < kP2Pre; ++i) {
-            const unsigned p = tid + i * kP2Threads;
-            float4 v = z4;
-            if (p < (unsigned)n_in2) v = src4[p];
-            pre[i] = v;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < kP2Pre; ++i) {
-            const int p = tid + i * kP2Threads;
-            float4 v = z4;
-            if (p < n_in2) {
-                const int64_t gi = gbase + 2 * (int64_t)p;
-                v = *reinterpret_cast<const float4 *>(gi >= 0 ? x + gi : hist + (gi + Hs));
-            }
-            pre[i] = v;
-        }
-    }
-}
-
 // the window of one wave's FIR range, straight into registers: the 8 frames [ta, ta + 8) of tile `tile` need the 15 input rows
 // f0 + ta - 7 .. f0 + ta + 7; lane = column pair, a row is 16 A contiguous bytes per wave.  Rows in front of the batch come from the carried
 // history, rows past its end are zero (their frames are never stored).  The row index and the source select are wave-uniform: fifteen
@@ -657,7 +622,7 @@ __global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
     const int *__restrict__ active, ChanGeom g, int64_t n_frames,
     float2 *__restrict__ out, int64_t out_stride, d2 *__restrict__ dc_ends, double dc_c) {
     static_assert(TF == 64 || (MX && TF == 32), "the vector form's DFT phase has one frame per lane: 64-frame tiles");
-    constexpr int kP2Frames = TF, kP2Waves = P2Tile<TF>::waves, kP2Threads = P2Tile<TF>::threads, kP2Pre = P2Tile<TF>::pre, kCt = P2Tile<TF>::ctiles;
+    constexpr int kP2Frames = TF, kP2Waves = P2Tile<TF>::waves, kP2Threads = P2Tile<TF>::threads, kCt = P2Tile<TF>::ctiles;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *rows = reinterpret_cast<float4 *>(smem);          // row r (input row f0 + r - 7, later X[r]) at rows + r A
     const int M = g.M, A = g.A, H = (A - 1) >> 1;
