@@ -306,8 +306,11 @@ static int chan_geometry(int M, int hop, ChanGeom &g) {
         if (const char *e = getenv("CSDR_CHAN_MX")) g.mx = g.A >= 17 ? std::max(0, std::min(4, atoi(e))) : 0;
         // vector form: s = x_c + x_{A-c} / d = x_c - x_{A-c} are formed once, in the FIR phase (a lane trade), instead of by all eight waves in
         // their DFT passes, and the second row request of a trip is unconditional (no register-set copies).  Same sums, same order: the
-        // output is bit-identical.  Measured on C3: 0.581 -> 0.564 ms.  CSDR_CHAN_ALT=0 restores the round-2 form (A/B).
-        g.alt = getenv("CSDR_CHAN_ALT") ? (atoi(getenv("CSDR_CHAN_ALT")) != 0) : 1;
+        // output is bit-identical.  Measured on C3: 0.581 -> 0.564 ms (before the window went straight into registers; within noise after).
+        // CSDR_CHAN_ALT=0 selects the round-2 form of the DFT phase (A/B, bit-identity test).
+        // bit 1: the channel rows are stored with the streaming hint (nothing in this kernel reads them again): they stay out of the way of
+        // the window rows two waves share -- 12.6 -> 10.5 B/sample fetched on C3, same kernel time
+        g.alt = getenv("CSDR_CHAN_ALT") ? (atoi(getenv("CSDR_CHAN_ALT")) & 3) : 3;
         if (g.mx >= 3) { g.TF = 32; g.lgTF = 5; g.threads = P2Tile<32>::threads; }
         return CSDR_OK;
     }

@@ -209,7 +209,7 @@ struct ChanGeom {
     int threads;              // workgroup size (whole waves, 256..512): chosen so each phase splits evenly over the waves
     int p2;                   // 1: M = 2 A, A odd <= 63, critically sampled: chan_analyze_p2 (KA = slots per pass, nkA = passes, PA = row pitch)
     int mx;                   // p2 only: the A-point DFTs run on the fp32 matrix pipe (chan_analyze_p2<.., true>)
-    int alt;                  // p2 only, vector form: 1 = s / d formed in the FIR phase + unconditional second request of a trip (default), 0 = the round-2 form (CSDR_CHAN_ALT)
+    int alt;                  // p2 only, vector form: bit 0 = s / d formed in the FIR phase + unconditional second request of a trip, bit 1 = streaming-hint stores (CSDR_CHAN_ALT, default 3; 0 = the round-2 form)
 };
 __host__ __device__ inline size_t chan_zin_floats2(const ChanGeom &g) {      // Z array, or the staged input tile if larger
     const size_t z = (size_t)g.TF * g.S, in = g.stage_in ? (size_t)(g.TF - 1) * g.hop + (size_t)kChanTaps * g.M : 0;
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
 //           odd A), the (cos, sin) rows are wave-uniform scalar loads, both requested one term ahead; then the radix-2
 //           butterfly with W_M^k and four channel-major stores of 512 contiguous bytes per wave (scalar row base + lane
 //           offset).  k = 0 rides along as a pseudo pair with (cos, sin) = (1, 0).  No Z array, no third phase.
-// (v_pk_fma_f32 issues every ~5 clk per SIMD with >= 2 waves resident on it, 13 clk with one: measured, scratch/ubench.)
+// (v_pk_fma_f32 issues every ~5 clk per SIMD with >= 2 waves resident on it, 13 clk with one: measured with a micro-benchmark.)
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kP2Frames = 64;          // frames per tile of the vector form (lane = frame in its DFT phase)
 constexpr int kP2Waves = 8;
@@ -531,6 +531,16 @@ __host__ inline void chan_mx_table(int A, float *tab /* [2][2][kMxSteps][64] */)
 // store to a wave-uniform row base plus a 32-bit per-lane byte offset (scalar-base addressing: no 64-bit address arithmetic per lane)
 __device__ __forceinline__ void store_row(float2 *row_base, unsigned byte_off, float2 v) {
     *reinterpret_cast<float2 *>(reinterpret_cast<char *>(row_base) + byte_off) = v;
+}
+// the same with the streaming hint (the output is not read again by this kernel: kept out of the way of the window rows in L2)
+__device__ __forceinline__ void store_row_nt(float2 *row_base, unsigned byte_off, float2 v) {
+#if defined(__AMDGCN__)
+    typedef float csdr_v2f __attribute__((ext_vector_type(2)));
+    const csdr_v2f t = {v.x, v.y};
+    __builtin_nontemporal_store(t, reinterpret_cast<csdr_v2f *>(reinterpret_cast<char *>(row_base) + byte_off));
+#else
+    store_row(row_base, byte_off, v);
+#endif
 }
 // one term of the conjugate-pair sums for KP slots and both c2: s = x_c + x_{A-c}, d = x_c - x_{A-c}; e = (cos, sin) rows
 // (SD: the FIR phase already left s at row c and d at row A - c)
@@ -676,7 +686,7 @@ __global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
             static_assert(kRange == kChanTaps, "a wave's range is eight frames: its window is fifteen rows");
             const int ta = wave * kRange;
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            const bool sd = !MX && g.alt != 0;
+            const bool sd = !MX && (g.alt & 1) != 0;
 #pragma unroll
             for (int i = 0; i < kRange; ++i) {
                 float4 acc = z4;
@@ -807,7 +817,7 @@ __global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
                     P0[j] = make_float2(x0.x, x0.y); P1[j] = make_float2(x0.z, x0.w);
                     Q0[j] = make_float2(0.f, 0.f); Q1[j] = make_float2(0.f, 0.f);
                 }
-                if (g.alt) chan_p2_accumulate<KP, true, true>(row, A, H, cs + q0, g.PA, P0, Q0, P1, Q1);
+                if (g.alt & 1) chan_p2_accumulate<KP, true, true>(row, A, H, cs + q0, g.PA, P0, Q0, P1, Q1);
                 else chan_p2_accumulate<KP, false, false>(row, A, H, cs + q0, g.PA, P0, Q0, P1, Q1);      // the round-2 form (A/B, bit-identity test)
                 float2 *ob = out + f0;                                  // wave-uniform row bases + a 32-bit lane offset: scalar-base stores
                 const unsigned tb = (unsigned)t * (unsigned)sizeof(float2);   // byte offset of this lane inside a channel row
@@ -821,7 +831,12 @@ __global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
                         const float2 z0k = make_float2(P0[j].x + Q0[j].y, P0[j].y - Q0[j].x), z0n = make_float2(P0[j].x - Q0[j].y, P0[j].y + Q0[j].x);
                         const float2 u = cmul(make_float2(P1[j].x + Q1[j].y, P1[j].y - Q1[j].x), wk);
                         const float2 v = cmul(make_float2(P1[j].x - Q1[j].y, P1[j].y + Q1[j].x), wn);
-                        if (tv) {
+                        if (tv && (g.alt & 2)) {
+                            if (on0) store_row_nt(ob + (int64_t)k * out_stride, tb, make_float2(z0k.x + u.x, z0k.y + u.y));
+                            if (on1) store_row_nt(ob + (int64_t)(k + A) * out_stride, tb, make_float2(z0k.x - u.x, z0k.y - u.y));
+                            if (on2) store_row_nt(ob + (int64_t)kn * out_stride, tb, make_float2(z0n.x + v.x, z0n.y + v.y));
+                            if (on3) store_row_nt(ob + (int64_t)(kn + A) * out_stride, tb, make_float2(z0n.x - v.x, z0n.y - v.y));
+                        } else if (tv) {
                             if (on0) store_row(ob + (int64_t)k * out_stride, tb, make_float2(z0k.x + u.x, z0k.y + u.y));
                             if (on1) store_row(ob + (int64_t)(k + A) * out_stride, tb, make_float2(z0k.x - u.x, z0k.y - u.y));
                             if (on2) store_row(ob + (int64_t)kn * out_stride, tb, make_float2(z0n.x + v.x, z0n.y + v.y));

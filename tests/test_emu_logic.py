@@ -234,7 +234,7 @@ def test_emu_channelizer_vector_forms_bit_identical(ctx):
     outs = []
     saved = os.environ.get("CSDR_CHAN_ALT")
     try:
-        for alt in ("0", "1"):
+        for alt in ("0", "1", "3"):
             os.environ["CSDR_CHAN_ALT"] = alt
             p = SDRPost(ctx, fs, M, block, max_blocks=2)
             p.execute(x, 2, block, center)

@@ -141,7 +141,7 @@ def test_channelizer_matrix_pipe_equals_vector_form_bit_for_bit(ctx, M, frames):
     try:
         # the vector form as round 2 had it (s / d formed by every wave in its DFT pass, guarded second request), the four matrix-pipe
         # variants, then the vector form's default (s / d formed once in the FIR phase by a lane trade, unconditional request): csdr_api.hip, chan_geometry
-        for mx, alt in (("0", "0"), ("1", "0"), ("2", "0"), ("3", "0"), ("4", "0"), ("0", "1")):
+        for mx, alt in (("0", "0"), ("1", "0"), ("2", "0"), ("3", "0"), ("4", "0"), ("0", "1"), ("0", "3")):
             os.environ["CSDR_CHAN_MX"] = mx
             os.environ["CSDR_CHAN_ALT"] = alt
             p = SDRPost(ctx, fs, M, block, max_blocks=3)
