@@ -241,7 +241,7 @@ __global__ __launch_bounds__(kFftThreads) void spec_fft_radix(FrameSrc fs, int L
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < R; ++r) a[r] = x[(int64_t)r * Lr];
+        for (int r = 0; r < R; ++r) a[r] = ld_stream(x + (int64_t)r * Lr);
     }
     float2 leaf[5];
     dft_reg<R>(a);
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(kFftThreads) void spec_fft_radix(FrameSrc fs, int L
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < R; ++k) o[(int64_t)k * Lr] = a[k];
+        for (int k = 0; k < R; ++k) st_stream(o + (int64_t)k * Lr, a[k]);
     }
 }
 
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kFftThreads) void spec_fft_rows4096(FrameSrc fs, Sp
     if (mag) {
         float *o = mag + (int64_t)f * g.N + (int64_t)row * 4096;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[tid + 256 * r] = cabs_f(v[r]);
+        for (int r = 0; r < 16; ++r) st_stream(o + tid + 256 * r, cabs_f(v[r]));
     }
     if (raw_out) {   // natural-order complex output (parity tests of K13 alone)
         const int k1 = row >> g.lgRb, k2 = row & (g.Rb - 1);
@@ -369,7 +369,7 @@ __device__ __forceinline__ void avg_step_fast(AvgState &s, double xa, double xb,
 // loads / stores at a wave-uniform base plus a 32-bit per-lane byte offset (scalar-base addressing)
 __device__ __forceinline__ float ldf(const float *base, unsigned byte_off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off); }
 __device__ __forceinline__ float2 ldf2(const float *base, unsigned byte_off) { return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(base) + byte_off); }
-__device__ __forceinline__ void stf(float *base, unsigned byte_off, float v) { *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v; }
+__device__ __forceinline__ void stf(float *base, unsigned byte_off, float v) { st_stream(reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off), v); }
 // max / min over each row of 16 lanes (every lane of the row gets the result): four DPP steps, operands fused into the ALU op
 __device__ __forceinline__ void row16_max_min(float &mx, float &mn) {
 #if defined(__AMDGCN__)
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(kDispThreads) void spec_display(const float *__rest
                     const int x0 = (npairs * tile * nk3 - (g.N >> 2)) & (F - 1);
                     const int j = 2 * tid, q = tt * kDispPad + j + (j >> 4);
                     // only y is stored: the x of point i is i / F for every frame (:562) and is filled in when a frame is fetched
-                    *reinterpret_cast<float2 *>(points + (int64_t)f * F + x0 + j) = make_float2(s_y[q], s_y[q + 1]);
+                    st_stream(reinterpret_cast<float2 *>(points + (int64_t)f * F + x0 + j), make_float2(s_y[q], s_y[q + 1]));
                     if (hold) *reinterpret_cast<float2 *>(hold_points + (int64_t)f * F + x0 + j) = make_float2(s_h[q], s_h[q + 1]);
                 }
             }
