@@ -107,6 +107,13 @@ __device__ __forceinline__ void opaque(int &v) {
     asm volatile("" : "+v"(v));
 #endif
 }
+// pin loaded values where they are: without it a load whose result is only stored under a guard is sunk into the guarded block, behind its
+// own wait (one memory round trip per element instead of several loads in flight)
+__device__ __forceinline__ void pin_loaded(float4 &v) {
+#if defined(__AMDGCN__)
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+#endif
+}
 // a product (or sum) that must be rounded on its own: hipcc contracts a * b + c into one fused operation by default (and its
 // __fmul_rn / __fadd_rn are plain operators), which differs from the reference's separately rounded multiply and add in the last bit
 __device__ __forceinline__ float rounded(float v) {

@@ -349,15 +349,37 @@ __global__ __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
     if (STAGE_IN) {
         // one memory round trip: every input sample of the tile (the halo first) is loaded once, 16 bytes per lane
         const int n_in2 = ((nf - 1) * hop + kChanTaps * M + 1) >> 1;
-        for (int p = tid; p < n_in2; p += nthr) {
-            const int64_t gi = base - Hs + 2 * (int64_t)p;
-            const float2 *src = gi >= 0 ? x + gi : hist + (gi + H);
-            if (OS2) {                                    // M / 2 may be odd: 8-byte aligned pairs; the pair may straddle hist | x
+        if (OS2) {
+            for (int p = tid; p < n_in2; p += nthr) {
+                const int64_t gi = base - Hs + 2 * (int64_t)p;
+                const float2 *src = gi >= 0 ? x + gi : hist + (gi + H);
+                // M / 2 may be odd: 8-byte aligned pairs; the pair may straddle hist | x
                 const float2 a = src[0];
                 float2 b2 = make_float2(0.f, 0.f);                              // one sample past the batch (odd count): never read, never used
                 if (gi + 1 < n_frames * hop) b2 = (gi + 1 >= 0) ? x[gi + 1] : hist[gi + 1 + H];
                 s_z[2 * p] = a; s_z[2 * p + 1] = b2;
-            } else reinterpret_cast<float4 *>(s_z)[p] = *reinterpret_cast<const float4 *>(src);
+            }
+        } else {
+            // eight 16-byte loads of a thread in flight at a time (one load, one LDS store per trip was a memory round trip per trip: fourteen
+            // of them in a row at M = 200); indices past the end re-read the last pair and are not stored
+            if (base - Hs >= 0) {                          // (block-uniform: every tile but the first lies wholly inside the batch)
+                const float4 *src4 = reinterpret_cast<const float4 *>(x + (base - Hs));
+                for (int p0 = tid; p0 < n_in2; p0 += 8 * nthr) {
+                    float4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = src4[min(p0 + u * nthr, n_in2 - 1)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) pin_loaded(v[u]);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const int p = p0 + u * nthr; if (p < n_in2) reinterpret_cast<float4 *>(s_z)[p] = v[u]; }
+                }
+            } else {
+                for (int p = tid; p < n_in2; p += nthr) {
+                    const int64_t gi = base - Hs + 2 * (int64_t)p;
+                    const float2 *src = gi >= 0 ? x + gi : hist + (gi + H);
+                    reinterpret_cast<float4 *>(s_z)[p] = *reinterpret_cast<const float4 *>(src);
+                }
+            }
         }
     }
     if (TAPS_LDS) for (int i = tid; i < kChanTaps * M; i += nthr) s_taps[i] = tapsT[i];
