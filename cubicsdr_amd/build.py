@@ -47,6 +47,8 @@ def build(force=False, verbose=True):
         return OUT
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",
            "-Wno-unused-function", SRC, "-o", OUT]
+    if os.environ.get("CSDR_BUILD_LAB") == "1":      # measurement build: the A/B switches of common.hpp lab_int() read the environment
+        cmd.insert(1, "-DCSDR_LAB")
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

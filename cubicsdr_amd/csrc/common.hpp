@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -25,6 +26,17 @@ inline int fail(int code, const char *fmt, ...) {
     va_end(ap);
     last_error_ref() = buf;
     return code;
+}
+
+// measurement switches (A/B runs recorded under profiles/): compiled in only with -DCSDR_LAB (CSDR_BUILD_LAB=1 python -m cubicsdr_amd.build);
+// the shipping library reads none of them
+inline int lab_int(const char *name, int dflt) {
+#ifdef CSDR_LAB
+    if (const char *e = getenv(name)) return atoi(e);
+#else
+    (void)name;
+#endif
+    return dflt;
 }
 
 #define CSDR_HIP_TRY(expr)                                                                      \
@@ -238,6 +250,7 @@ enum CsdrLane { LANE_POST = 0, LANE_FE, LANE_AUDIO, LANE_FFT, LANE_AVG, LANE_COU
 struct csdr_ctx {
     int device = 0;
     int n_cu = 256;                          // compute units (grid sizing: whole rounds of resident workgroups)
+    int lds_per_cu = 160 * 1024;             // LDS of one compute unit (gfx950)
     hipStream_t stream = nullptr;            // boundary stream: the caller's producer / consumer work is ordered on it
     bool own_stream = false;
     hipStream_t lanes[LANE_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // logical stage -> physical stream

@@ -11,6 +11,7 @@
 #include "kernels_demod.hpp"
 #include "kernels_fms.hpp"
 #include "kernels_post.hpp"
+#include "kernels_chanfft.hpp"
 #include "kernels_spec.hpp"
 #include "kernels_io.hpp"
 
@@ -211,6 +212,9 @@ struct csdr_post {
     std::vector<int> active_host;            // sorted list of produced channels
     bool active_dirty = true;
     ChanGeom geom{};
+    bool use_fft = false;                    // critically sampled, M = 2^a 3^b 5^c 7^d 11^e 13^f: chan_analyze_fft (kernels_chanfft.hpp)
+    ChanFftGeom fgeom{};
+    DevBuf<int> perm;                        // chan_analyze_fft: position after the last pass -> channel
     // `out` holds kPostBufs batches in rotation: the channelizer fills the next one while the demodulators still read
     // the previous (the reference hands ReBuffer blocks through a queue, SDRPostThread.cpp:341-396)
     static constexpr int kPostBufs = 3, kMaxConsumers = 4;
@@ -264,7 +268,7 @@ extern "C" void csdr_post_destroy(csdr_post *p) {
         for (int c = 0; c < csdr_post::kMaxConsumers; ++c) if (p->ev_consumed[k][c]) (void)hipEventDestroy(p->ev_consumed[k][c]);
     }
     p->out.release(); p->hist0.release(); p->hist1.release(); p->stage_in.release();
-    p->twA.release(); p->twB.release(); p->twM.release(); p->post2.release();
+    p->twA.release(); p->twB.release(); p->twM.release(); p->post2.release(); p->perm.release();
     p->taps.release(); p->active.release(); p->dc_state.release(); p->tile_end.release();
     for (auto &kv : p->rowlists) (void)hipFree(kv.second);
     p->rowlists.clear();
@@ -392,6 +396,11 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
     if (mode != CSDR_POST_SINGLE) {
         if (int rc = chan_geometry(M, p->hop, p->geom)) return rc;
         const ChanGeom &g = p->geom;
+        // every channel count that is not 2 * odd and factors over the small radices takes the FFT kernel (kernels_chanfft.hpp);
+        // CSDR_CHAN_FFT=0 keeps the two-factor direct-DFT kernel (A/B measurements, bit-for-bit routing tests)
+        std::vector<int> fperm;
+        p->use_fft = mode == CSDR_POST_PFBCH && !g.p2 && lab_int("CSDR_CHAN_FFT", 1) != 0 &&
+                     chanfft_plan(M, (size_t)p->ctx->lds_per_cu, lab_int("CSDR_CHANFFT_TF", 0), lab_int("CSDR_CHANFFT_THREADS", 0), p->fgeom, fperm);
         // prototype taps transposed to [n][c]: tapsT[n M + c] multiplies x[(t - n) M + c]
         std::vector<float> taps = mode == CSDR_POST_PFBCH2 ? design::channelizer2_taps((unsigned)M, 4, 60.0f)      // initPFBCH2 :463
                                                            : design::channelizer_taps((unsigned)M, 4, 60.0f);      // initPFBCH :406
@@ -425,6 +434,12 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
         for (int c1 = 0; c1 < g.A; c1++) for (int k1 = 0; k1 < g.A; k1++) twA[(size_t)c1 * g.PA + k1] = W((int64_t)c1 * k1, g.A);
         for (int c2 = 0; c2 < g.B; c2++) for (int k2 = 0; k2 < g.B; k2++) twB[(size_t)c2 * g.PB + k2] = W((int64_t)c2 * k2, g.B);
         for (int k1 = 0; k1 < g.A; k1++) for (int c2 = 0; c2 < g.B; c2++) twM[(size_t)k1 * g.B + c2] = W((int64_t)k1 * c2, M);
+        if (p->use_fft) {        // one table W_M^i serves every pass: W_N^(j r) = W_M^(j r M / N)
+            twM.resize((size_t)M);
+            for (int i = 0; i < M; i++) twM[(size_t)i] = W(i, M);
+            if (int rc = p->perm.reserve(fperm.size())) return rc;
+            CSDR_HIP_TRY(hipMemcpyAsync(p->perm.p, fperm.data(), fperm.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        }
         if (int rc = p->taps.reserve(tapsT.size())) return rc;
         if (int rc = p->twA.reserve(twA.size())) return rc;
         if (int rc = p->twB.reserve(twB.size())) return rc;
@@ -439,8 +454,8 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
         CSDR_HIP_TRY(hipMemsetAsync(p->hist0.p, 0, H * sizeof(float2), st));
         CSDR_HIP_TRY(hipMemsetAsync(p->hist1.p, 0, H * sizeof(float2), st));
         CSDR_HIP_TRY(hipStreamSynchronize(st));   // host vectors above go out of scope
-        const size_t lds = g.p2 ? chan_p2_lds_bytes(M, g.TF) : chan_lds_bytes(g);
-        if (lds > 64 * 1024) CSDR_HIP_TRY(hipFuncSetAttribute(g.p2 ? (const void *)chan_p2_kernel(g) : (const void *)chan_kernel(g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const size_t lds = p->use_fft ? chanfft_lds_bytes(p->fgeom) : g.p2 ? chan_p2_lds_bytes(M, g.TF) : chan_lds_bytes(g);
+        if (lds > 64 * 1024) CSDR_HIP_TRY(hipFuncSetAttribute(p->use_fft ? (const void *)chan_analyze_fft : g.p2 ? (const void *)chan_p2_kernel(g) : (const void *)chan_kernel(g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     p->hist_parity = 0;
     p->active_host.resize(M);
@@ -529,13 +544,20 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
         const int64_t n_frames = n / p->hop;
         float2 *hist = p->hist_parity ? p->hist1.p : p->hist0.p, *hist_new = p->hist_parity ? p->hist0.p : p->hist1.p;
         ChanGeom g = p->geom;
-        g.fpw = g.TF;                         // frames per workgroup (full tiles measured fastest on MI355X)
+        g.fpw = p->use_fft ? p->fgeom.TF : g.TF;      // frames per workgroup (full tiles measured fastest on MI355X)
         const int ntiles = (int)((n_frames + g.fpw - 1) / g.fpw);
         // channel 0 carries the DC spike: it is blocked after de-interleave (:364-375); when the tile size allows, the
         // channelizer itself emits the per-tile end values the blocked scan needs
         const bool dc0 = p->dc_enabled && !p->active_host.empty() && p->active_host[0] == 0;
         const bool fused_ends = dc0 && g.fpw >= 16;
-        if (g.p2) {
+        if (p->use_fft) {
+            // persistent workgroups (as many as are resident at once) walk over the tiles
+            const ChanFftGeom &fg = p->fgeom;
+            const size_t lds = chanfft_lds_bytes(fg);
+            const int wgs = std::min(ntiles, std::max(1, c->wg_slots(chan_analyze_fft, fg.threads, lds) * lab_int("CSDR_CHANFFT_PCT", 100) / 100));
+            CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, chan_analyze_fft, dim3(wgs), dim3(fg.threads), lds, x, hist, hist_new, p->taps.p,
+                        p->twM.p, p->perm.p, p->active.p, fg, n_frames, out, p->chan_stride, fused_ends ? p->tile_end.p : (d2 *)nullptr, p->dc_c);
+        } else if (g.p2) {
             // persistent workgroups: as many as are resident at once, each walks over tiles blockIdx.x, + gridDim.x, ...
             const chan_p2_kernel_t k2 = chan_p2_kernel(g);
             static const int chan_pct = getenv("CSDR_CHAN_PCT") ? std::max(10, std::min(100, atoi(getenv("CSDR_CHAN_PCT")))) : 100;
@@ -562,6 +584,10 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
 extern "C" int64_t csdr_post_channel_bandwidth(const csdr_post *p) { return p ? (p->M == 1 ? p->sample_rate : p->chan_bw) : 0; }
 extern "C" int64_t csdr_post_channel_rate(const csdr_post *p) { return p ? p->chan_rate : 0; }
 extern "C" int csdr_post_num_channels(const csdr_post *p) { return p ? p->M : 0; }
+extern "C" const char *csdr_post_kernel_name(const csdr_post *p) {
+    if (!p || !p->configured) return "";
+    return p->mode == CSDR_POST_SINGLE ? "dc_blocker" : p->use_fft ? "chan_analyze_fft" : p->geom.p2 ? "chan_analyze_p2" : "chan_analyze";
+}
 extern "C" int64_t csdr_post_channel_center(const csdr_post *p, int i) {
     if (!p || i < 0 || i >= (int)p->centers.size()) return 0;
     return p->centers[i];

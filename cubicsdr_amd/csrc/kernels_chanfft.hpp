@@ -1,0 +1,370 @@
+// kernels_chanfft.hpp -- K2 + K4 for every even channel count whose factors are small (M = 4, 8, 20, 40, 112, 200, 1024 ...):
+// the critically sampled polyphase analysis bank with a real mixed-radix FFT.
+//
+// Replaces (reference file:line): firpfbch_crcf_analyzer_execute SDRPostThread.cpp:449-451 (liquid firpfbch: Kaiser prototype m = 4,
+// As = 60, :406; its M-point transform is liquid's own mixed-radix FFT plan) and the strided channel gather :364-381.
+//
+//   X_t[c] = sum_{n<8} taps[c][n] x[(t-n) M + c];   y_t[k] = sum_c X_t[c] exp(-j 2 pi k c / M);   out[k][t]
+//
+// Until round 4 these channel counts ran chan_analyze (kernels_post.hpp): ONE Cooley-Tukey split M = A B with direct A- and B-point
+// DFTs, M (A + B) complex MACs per frame -- 64 per sample at M = 1024, 0.11 of the HBM roofline.  Here the transform is an in-place
+// decimation-in-frequency FFT over radices 16 / 8 / 4 / 2 and odd 3 / 5 / 7 / 9 / 11 / 13 (M = 1024 = 16 * 8 * 8: ~9 real operations per
+// sample and pass), and the tile is TRANSPOSED in LDS: X[c][t], t contiguous.
+//  * Persistent workgroups walk over tiles of TF consecutive frames (TF a power of two, 8 .. 256: the largest whose tile fits the LDS budget).
+//  * FIR: a work item owns a column PAIR (one float4) and eight consecutive frames; the fifteen input rows they reach go straight
+//    from global memory into registers (lanes along the columns: every load of a wave is one contiguous run; neighbouring items share
+//    seven rows: cache hits), the taps of its two columns sit in registers, and each of its two rows of X receives 64 contiguous bytes
+//    (four ds_write_b128; row pitch TF + 2 samples: lanes two rows apart are 8 banks apart).
+//  * FFT pass p (radix R, span s, block N = R s): work item = (butterfly, frame), lanes along the frames, so the R operands of a lane
+//    are R row reads at a pitch of s rows, conflict-free, and with TF >= 64 the butterfly -- hence its twiddles W_N^(j r), read from an
+//    M-entry table in LDS -- is wave-uniform (a broadcast read).  The R-point DFT runs in registers; results go back in place.
+//  * The last pass does not write LDS: output r of the butterfly at position pos is channel k = perm[pos + r] (the mixed-radix digit
+//    reversal, a table) and goes straight to out[k][f0 + t]: with the lanes along t every store instruction writes runs of 8 TF bytes
+//    of one channel row.  Rows without consumers are skipped (SDRPostThread.cpp:336-339).
+//  * Channel 0 of the tile is left in LDS for the DC blocker's per-tile end value (as chan_analyze does).
+// LDS traffic per input sample: one 8-byte write + read per pass (three at M = 1024); arithmetic ~ 16 FIR + 9 * passes operations.
+#pragma once
+#include "common.hpp"
+#include "kernels_post.hpp"
+
+namespace csdr {
+
+constexpr int kCfMaxPasses = 8;
+constexpr int kCfSeg = 8;                 // frames one FIR work item produces
+constexpr int kCfMaxThreads = 1024;
+
+struct ChanFftGeom {
+    int M, TF, lgTF, TFs;                 // TFs: row pitch of X in samples (TF + 2)
+    int threads;                          // workgroup size (whole waves)
+    int npass;
+    int radix[kCfMaxPasses];              // R_p;  N_p = M / (R_0 .. R_{p-1}) is the block size of pass p
+    int span[kCfMaxPasses];               // s_p = N_p / R_p
+    unsigned magic_span[kCfMaxPasses];    // floor(2^32 / s_p) + 1 (s_p > 1)
+    int twstep[kCfMaxPasses];             // M / N_p: W_{N_p}^(j r) = W_M^(j r twstep)
+    unsigned magic_half;                  // floor(2^32 / (M / 2)) + 1 (M > 2)
+};
+
+__host__ __device__ inline size_t chanfft_lds_bytes(const ChanFftGeom &g) {
+    return ((size_t)g.M * g.TFs + g.M + g.TF) * sizeof(float2) + (size_t)g.M * sizeof(int);
+}
+
+// plan for M channels: radices (odd ones first, then the powers of two from the widest), tile size, workgroup size.
+// Returns false when M has a prime factor this kernel has no butterfly for (chan_analyze takes those).
+// (force_tf / force_threads: measurement overrides, 0 = automatic)
+__host__ inline bool chanfft_plan(int M, size_t lds_limit, int force_tf, int force_threads, ChanFftGeom &g, std::vector<int> &perm) {
+    memset(&g, 0, sizeof g);
+    g.M = M;
+    if (M < 2 || (M & 1) || M > 65536) return false;
+    std::vector<int> rad;
+    int m = M, e2 = 0, e3 = 0;
+    while (!(m & 1)) { m >>= 1; ++e2; }
+    while (m % 3 == 0) { m /= 3; ++e3; }
+    for (; e3 >= 2; e3 -= 2) rad.push_back(9);
+    if (e3) rad.push_back(3);
+    for (int p : {5, 7, 11, 13}) while (m % p == 0) { m /= p; rad.push_back(p); }
+    if (m != 1) return false;
+    const int n2 = (e2 + 3) / 4;                               // passes over the power of two: as even as possible, widest first
+    for (int i = 0; i < n2; ++i) rad.push_back(1 << (e2 / n2 + (i < e2 % n2 ? 1 : 0)));
+    if ((int)rad.size() > kCfMaxPasses) return false;
+    g.npass = (int)rad.size();
+    int N = M;
+    for (int p = 0; p < g.npass; ++p) {
+        g.radix[p] = rad[p]; g.span[p] = N / rad[p]; g.twstep[p] = M / N;
+        g.magic_span[p] = g.span[p] > 1 ? (unsigned)((1ull << 32) / (unsigned)g.span[p]) + 1u : 0u;
+        N /= rad[p];
+    }
+    g.magic_half = M > 2 ? (unsigned)((1ull << 32) / (unsigned)(M / 2)) + 1u : 0u;
+    // tile: two workgroups per CU when a 16-frame tile allows it, else the largest tile that fits at all; capped at 256 frames
+    auto fits = [&](int tf, size_t budget) { g.TF = tf; g.TFs = tf + 2; return chanfft_lds_bytes(g) <= budget; };
+    int tf = 256;
+    while (tf > 16 && !fits(tf, std::min<size_t>(lds_limit / 2, 64 * 1024))) tf >>= 1;
+    if (!fits(tf, lds_limit / 2)) { tf = 64; while (tf > 8 && !fits(tf, lds_limit)) tf >>= 1; }
+    if (force_tf >= kCfSeg && !(force_tf & (force_tf - 1)) && fits(force_tf, lds_limit)) tf = force_tf;
+    if (!fits(tf, lds_limit)) return false;
+    g.lgTF = 0; while ((1 << g.lgTF) < tf) ++g.lgTF;
+    const int fir_items = (M / 2) * (tf / kCfSeg);
+    g.threads = std::min(kCfMaxThreads, std::max(256, (fir_items + 63) / 64 * 64));
+    if (force_threads >= 64 && force_threads <= kCfMaxThreads && !(force_threads & 63)) g.threads = force_threads;
+    // pos = sum_p r_p s_p holds channel k = r_0 + R_0 (r_1 + R_1 (r_2 + ...)) after the last pass
+    perm.assign(M, 0);
+    for (int pos = 0; pos < M; ++pos) {
+        int k = 0, w = 1, rest = pos;
+        for (int p = 0; p < g.npass; ++p) { const int r = rest / g.span[p]; rest -= r * g.span[p]; k += r * w; w *= g.radix[p]; }
+        perm[pos] = k;
+    }
+    return true;
+}
+
+// ---- R-point forward DFTs in registers: v[r] <- sum_q v[q] exp(-j 2 pi q r / R)
+__device__ __forceinline__ float2 cf_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 cf_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cf_mj(float2 a) { return make_float2(a.y, -a.x); }        // a * (-j)
+__device__ __forceinline__ float2 cf_mulc(float2 a, float c, float s) {                      // a * (c + j s), constants
+    return make_float2(fmaf(a.x, c, -a.y * s), fmaf(a.x, s, a.y * c));
+}
+__device__ __forceinline__ void cf_dft2(float2 &a, float2 &b) { const float2 t = cf_sub(a, b); a = cf_add(a, b); b = t; }
+__device__ __forceinline__ void cf_dft4(float2 &a, float2 &b, float2 &c, float2 &d) {
+    const float2 t0 = cf_add(a, c), t1 = cf_sub(a, c), t2 = cf_add(b, d), t3 = cf_mj(cf_sub(b, d));
+    a = cf_add(t0, t2); c = cf_sub(t0, t2); b = cf_add(t1, t3); d = cf_sub(t1, t3);
+}
+template <int R> struct CfOdd;
+template <> struct CfOdd<3> {
+    static constexpr float c[3] = {1.000000000e+00f, -5.000000000e-01f, -5.000000000e-01f};
+    static constexpr float s[3] = {0.000000000e+00f, 8.660254038e-01f, -8.660254038e-01f};
+};
+template <> struct CfOdd<5> {
+    static constexpr float c[5] = {1.000000000e+00f, 3.090169944e-01f, -8.090169944e-01f, -8.090169944e-01f, 3.090169944e-01f};
+    static constexpr float s[5] = {0.000000000e+00f, 9.510565163e-01f, 5.877852523e-01f, -5.877852523e-01f, -9.510565163e-01f};
+};
+template <> struct CfOdd<7> {
+    static constexpr float c[7] = {1.000000000e+00f, 6.234898019e-01f, -2.225209340e-01f, -9.009688679e-01f, -9.009688679e-01f, -2.225209340e-01f, 6.234898019e-01f};
+    static constexpr float s[7] = {0.000000000e+00f, 7.818314825e-01f, 9.749279122e-01f, 4.338837391e-01f, -4.338837391e-01f, -9.749279122e-01f, -7.818314825e-01f};
+};
+template <> struct CfOdd<9> {
+    static constexpr float c[9] = {1.000000000e+00f, 7.660444431e-01f, 1.736481777e-01f, -5.000000000e-01f, -9.396926208e-01f, -9.396926208e-01f, -5.000000000e-01f, 1.736481777e-01f, 7.660444431e-01f};
+    static constexpr float s[9] = {0.000000000e+00f, 6.427876097e-01f, 9.848077530e-01f, 8.660254038e-01f, 3.420201433e-01f, -3.420201433e-01f, -8.660254038e-01f, -9.848077530e-01f, -6.427876097e-01f};
+};
+template <> struct CfOdd<11> {
+    static constexpr float c[11] = {1.000000000e+00f, 8.412535328e-01f, 4.154150130e-01f, -1.423148383e-01f, -6.548607339e-01f, -9.594929736e-01f, -9.594929736e-01f, -6.548607339e-01f, -1.423148383e-01f, 4.154150130e-01f, 8.412535328e-01f};
+    static constexpr float s[11] = {0.000000000e+00f, 5.406408175e-01f, 9.096319954e-01f, 9.898214419e-01f, 7.557495744e-01f, 2.817325568e-01f, -2.817325568e-01f, -7.557495744e-01f, -9.898214419e-01f, -9.096319954e-01f, -5.406408175e-01f};
+};
+template <> struct CfOdd<13> {
+    static constexpr float c[13] = {1.000000000e+00f, 8.854560257e-01f, 5.680647467e-01f, 1.205366803e-01f, -3.546048870e-01f, -7.485107482e-01f, -9.709418174e-01f, -9.709418174e-01f, -7.485107482e-01f, -3.546048870e-01f, 1.205366803e-01f, 5.680647467e-01f, 8.854560257e-01f};
+    static constexpr float s[13] = {0.000000000e+00f, 4.647231720e-01f, 8.229838659e-01f, 9.927088741e-01f, 9.350162427e-01f, 6.631226582e-01f, 2.393156643e-01f, -2.393156643e-01f, -6.631226582e-01f, -9.350162427e-01f, -9.927088741e-01f, -8.229838659e-01f, -4.647231720e-01f};
+};
+
+template <int R> struct CfDft {
+    // odd R, conjugate-pair form: s_c = v_c + v_{R-c}, d_c = v_c - v_{R-c};  P_k = v_0 + sum_c s_c cos(2 pi k c / R),
+    // Q_k = sum_c d_c sin(2 pi k c / R);  y_k = P_k - j Q_k,  y_{R-k} = P_k + j Q_k
+    static __device__ __forceinline__ void run(float2 (&v)[R]) {
+        static_assert(R & 1, "odd radix");
+        constexpr int H = (R - 1) / 2;
+        float2 s[H + 1], d[H + 1];
+        float2 y0 = v[0];
+#pragma unroll
+        for (int c = 1; c <= H; ++c) { s[c] = cf_add(v[c], v[R - c]); d[c] = cf_sub(v[c], v[R - c]); y0 = cf_add(y0, s[c]); }
+        const float2 x0 = v[0];
+        v[0] = y0;
+#pragma unroll
+        for (int k = 1; k <= H; ++k) {
+            float2 P = x0, Q = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int c = 1; c <= H; ++c) {
+                const float co = CfOdd<R>::c[(k * c) % R], si = CfOdd<R>::s[(k * c) % R];
+                P.x = fmaf(s[c].x, co, P.x); P.y = fmaf(s[c].y, co, P.y);
+                Q.x = fmaf(d[c].x, si, Q.x); Q.y = fmaf(d[c].y, si, Q.y);
+            }
+            v[k] = make_float2(P.x + Q.y, P.y - Q.x);
+            v[R - k] = make_float2(P.x - Q.y, P.y + Q.x);
+        }
+    }
+};
+template <> struct CfDft<2> { static __device__ __forceinline__ void run(float2 (&v)[2]) { cf_dft2(v[0], v[1]); } };
+template <> struct CfDft<4> { static __device__ __forceinline__ void run(float2 (&v)[4]) { cf_dft4(v[0], v[1], v[2], v[3]); } };
+template <> struct CfDft<8> {
+    // a_q = v_q + v_{q+4}, b_q = (v_q - v_{q+4}) W_8^q;  y_{2m} = DFT4(a)_m,  y_{2m+1} = DFT4(b)_m
+    static __device__ __forceinline__ void run(float2 (&v)[8]) {
+        constexpr float h = 7.071067812e-01f;
+        float2 a0 = cf_add(v[0], v[4]), a1 = cf_add(v[1], v[5]), a2 = cf_add(v[2], v[6]), a3 = cf_add(v[3], v[7]);
+        float2 b0 = cf_sub(v[0], v[4]), b1 = cf_sub(v[1], v[5]), b2 = cf_mj(cf_sub(v[2], v[6])), b3 = cf_sub(v[3], v[7]);
+        b1 = make_float2((b1.x + b1.y) * h, (b1.y - b1.x) * h);          // (1 - j) / sqrt 2
+        b3 = make_float2((b3.y - b3.x) * h, -(b3.x + b3.y) * h);         // (-1 - j) / sqrt 2
+        cf_dft4(a0, a1, a2, a3); cf_dft4(b0, b1, b2, b3);
+        v[0] = a0; v[2] = a1; v[4] = a2; v[6] = a3; v[1] = b0; v[3] = b1; v[5] = b2; v[7] = b3;
+    }
+};
+template <> struct CfDft<16> {
+    // v[4 a + b]: u_b = DFT4 over a, times W_16^(b r1); y[r1 + 4 r2] = DFT4 over b of u[r1][.]
+    static __device__ __forceinline__ void run(float2 (&v)[16]) {
+        constexpr float h = 7.071067812e-01f, c1 = 9.238795325e-01f, s1 = 3.826834324e-01f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) cf_dft4(v[b], v[b + 4], v[b + 8], v[b + 12]);      // v[4 r1 + b] now holds u[r1][b]
+        // W_16^m = (cos(m pi / 8), -sin(m pi / 8)):  m = b r1
+        v[5] = cf_mulc(v[5], c1, -s1);                                                 // m = 1
+        v[6] = make_float2((v[6].x + v[6].y) * h, (v[6].y - v[6].x) * h);              // m = 2
+        v[7] = cf_mulc(v[7], s1, -c1);                                                 // m = 3
+        v[9] = make_float2((v[9].x + v[9].y) * h, (v[9].y - v[9].x) * h);              // m = 2
+        v[10] = cf_mj(v[10]);                                                          // m = 4
+        v[11] = make_float2((v[11].y - v[11].x) * h, -(v[11].x + v[11].y) * h);        // m = 6
+        v[13] = cf_mulc(v[13], s1, -c1);                                               // m = 3
+        v[14] = make_float2((v[14].y - v[14].x) * h, -(v[14].x + v[14].y) * h);        // m = 6
+        v[15] = cf_mulc(v[15], -c1, s1);                                               // m = 9
+        float2 y[16];
+#pragma unroll
+        for (int r1 = 0; r1 < 4; ++r1) {
+            cf_dft4(v[4 * r1], v[4 * r1 + 1], v[4 * r1 + 2], v[4 * r1 + 3]);
+#pragma unroll
+            for (int r2 = 0; r2 < 4; ++r2) y[r1 + 4 * r2] = v[4 * r1 + r2];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = y[i];
+    }
+};
+
+__device__ __forceinline__ unsigned cf_div(unsigned n, int d, unsigned magic) { return d == 1 ? n : __umulhi(n, magic); }
+
+// one butterfly of a pass that stays in LDS: R rows at pitch `pitch` samples, twiddles W_M^(r jj), in place
+template <int R>
+__device__ __forceinline__ void cf_pass_item(float2 *px, int pitch, const float2 *s_tw, int jj) {
+    float2 v[R], w[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = px[(size_t)q * pitch];
+#pragma unroll
+    for (int r = 1; r < R; ++r) w[r] = s_tw[r * jj];
+    CfDft<R>::run(v);
+    px[0] = v[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) px[(size_t)r * pitch] = cmul(v[r], w[r]);
+}
+// one butterfly of the last pass (span 1): results go to their channel rows
+template <int R>
+__device__ __forceinline__ void cf_last_item(const float2 *px, int pitch, const int *s_pa, float2 *s_dc, int t, bool live, float2 *__restrict__ o /* out + f0 + t */,
+                                             int64_t out_stride) {
+    float2 v[R];
+    int k[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) { v[q] = px[(size_t)q * pitch]; k[q] = s_pa[q]; }
+    CfDft<R>::run(v);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (k[r] == 0 && s_dc) s_dc[t] = v[r];
+        if (k[r] >= 0 && live) st_stream(o + (int64_t)k[r] * out_stride, v[r]);
+    }
+}
+
+__global__ __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
+    const float2 *__restrict__ x,        // batch input, n_frames * M samples
+    const float2 *__restrict__ hist,     // 7 * M samples preceding x
+    float2 *__restrict__ hist_new,       // receives the last 7 * M samples of (hist ++ x)
+    const float *__restrict__ tapsT,     // [8][M]  tapsT[n M + c] multiplies x[(t - n) M + c]
+    const float2 *__restrict__ twM,      // [M] exp(-j 2 pi i / M)
+    const int *__restrict__ perm,        // [M] position after the last pass -> channel
+    const int *__restrict__ active,      // [M] 1: store channel row k
+    ChanFftGeom g, int64_t n_frames,
+    float2 *__restrict__ out, int64_t out_stride,
+    d2 *__restrict__ dc_ends, double dc_c /* DC blocker of channel 0: end value of each tile's recurrence (zero entering state) */) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int M = g.M, TF = g.TF, TFs = g.TFs;
+    float2 *s_x = reinterpret_cast<float2 *>(smem);                  // X[c][t], pitch TFs
+    float2 *s_tw = s_x + (size_t)M * TFs;                            // W_M^i
+    float2 *s_dc = s_tw + M;                                         // channel 0 of the tile
+    int *s_pa = reinterpret_cast<int *>(s_dc + TF);                  // position -> channel, or -1 when the row has no consumer
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    for (int i = tid; i < M; i += nthr) { s_tw[i] = twM[i]; const int k = perm[i]; s_pa[i] = active[k] ? k : -1; }
+
+    const int64_t ntiles = (n_frames + TF - 1) >> g.lgTF;
+    const int half = M >> 1, nfir = half * (TF / kCfSeg);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t f0 = tile << g.lgTF;
+        const int nf = (int)min((int64_t)TF, n_frames - f0);
+        // ---- FIR: item = (column pair cp, segment of 8 frames); input row r of the batch is x[r M ..], rows -7 .. -1 are the history
+        const bool inside = f0 >= kChanTaps - 1 && f0 + TF <= n_frames;          // (tile-uniform) every row any item reaches lies in x
+        for (int it = tid; it < nfir; it += nthr) {
+            const int seg = (int)cf_div((unsigned)it, half, g.magic_half), cp = it - seg * half;
+            const int64_t r0 = f0 + seg * kCfSeg - (kChanTaps - 1);
+            float4 win[kCfSeg + kChanTaps - 1];
+            if (inside) {
+                const float4 *src = reinterpret_cast<const float4 *>(x + r0 * M) + cp;
+#pragma unroll
+                for (int j = 0; j < kCfSeg + kChanTaps - 1; ++j) win[j] = src[(size_t)j * half];
+            } else {
+#pragma unroll
+                for (int j = 0; j < kCfSeg + kChanTaps - 1; ++j) {
+                    const int64_t r = r0 + j;
+                    win[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (r < n_frames) win[j] = reinterpret_cast<const float4 *>(r >= 0 ? x + r * M : hist + (r + kChanTaps - 1) * M)[cp];
+                }
+            }
+            float2 h[kChanTaps];
+#pragma unroll
+            for (int n = 0; n < kChanTaps; ++n) h[n] = *reinterpret_cast<const float2 *>(tapsT + (size_t)n * M + 2 * cp);
+            float4 *d0 = reinterpret_cast<float4 *>(s_x + (size_t)(2 * cp) * TFs + seg * kCfSeg);
+            float4 *d1 = reinterpret_cast<float4 *>(s_x + (size_t)(2 * cp + 1) * TFs + seg * kCfSeg);
+#pragma unroll
+            for (int tt = 0; tt < kCfSeg; tt += 2) {
+                float2 a[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)}, b[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                    for (int n = 0; n < kChanTaps; ++n) {
+                        const float4 v = win[kChanTaps - 1 + tt + u - n];
+                        a[u].x = fmaf(h[n].x, v.x, a[u].x); a[u].y = fmaf(h[n].x, v.y, a[u].y);
+                        b[u].x = fmaf(h[n].y, v.z, b[u].x); b[u].y = fmaf(h[n].y, v.w, b[u].y);
+                    }
+                }
+                d0[tt >> 1] = make_float4(a[0].x, a[0].y, a[1].x, a[1].y);
+                d1[tt >> 1] = make_float4(b[0].x, b[0].y, b[1].x, b[1].y);
+            }
+        }
+        // the workgroup that owns the last tile also writes the new input history (the launch runs even with no consumers)
+        if (tile == ntiles - 1) {
+            const int64_t n = n_frames * M, H = (int64_t)(kChanTaps - 1) * M;
+            for (int64_t j = tid; j < H; j += nthr) {
+                const int64_t gsrc = n - H + j;
+                hist_new[j] = gsrc >= 0 ? x[gsrc] : hist[gsrc + H];
+            }
+        }
+        lds_barrier();
+
+        // ---- FFT passes: item = (butterfly bf, frame t), lanes along t
+        for (int p = 0; p < g.npass; ++p) {
+            const int R = g.radix[p], s = g.span[p], items = (M / R) << g.lgTF, pitch = s * TFs;
+            const bool lastp = p == g.npass - 1;
+            for (int it = tid; it < items; it += nthr) {
+                const int t = it & (TF - 1);
+                const unsigned bf = (unsigned)it >> g.lgTF;
+                const unsigned b = cf_div(bf, s, g.magic_span[p]);
+                const int j = (int)(bf - b * (unsigned)s), pos0 = (int)b * R * s + j;
+                float2 *px = s_x + (size_t)pos0 * TFs + t;
+                if (!lastp) {
+                    const int jj = j * g.twstep[p];
+                    switch (R) {
+                        case 2: cf_pass_item<2>(px, pitch, s_tw, jj); break;
+                        case 3: cf_pass_item<3>(px, pitch, s_tw, jj); break;
+                        case 4: cf_pass_item<4>(px, pitch, s_tw, jj); break;
+                        case 5: cf_pass_item<5>(px, pitch, s_tw, jj); break;
+                        case 7: cf_pass_item<7>(px, pitch, s_tw, jj); break;
+                        case 8: cf_pass_item<8>(px, pitch, s_tw, jj); break;
+                        case 9: cf_pass_item<9>(px, pitch, s_tw, jj); break;
+                        case 11: cf_pass_item<11>(px, pitch, s_tw, jj); break;
+                        case 13: cf_pass_item<13>(px, pitch, s_tw, jj); break;
+                        default: cf_pass_item<16>(px, pitch, s_tw, jj); break;
+                    }
+                } else {
+                    float2 *o = out + f0 + t;
+                    float2 *dcp = dc_ends ? s_dc : nullptr;
+                    const int *pa = s_pa + pos0;
+                    const bool live = t < nf;
+                    switch (R) {
+                        case 2: cf_last_item<2>(px, pitch, pa, dcp, t, live, o, out_stride); break;
+                        case 3: cf_last_item<3>(px, pitch, pa, dcp, t, live, o, out_stride); break;
+                        case 4: cf_last_item<4>(px, pitch, pa, dcp, t, live, o, out_stride); break;
+                        case 5: cf_last_item<5>(px, pitch, pa, dcp, t, live, o, out_stride); break;
+                        case 7: cf_last_item<7>(px, pitch, pa, dcp, t, live, o, out_stride); break;
+                        case 8: cf_last_item<8>(px, pitch, pa, dcp, t, live, o, out_stride); break;
+                        case 9: cf_last_item<9>(px, pitch, pa, dcp, t, live, o, out_stride); break;
+                        case 11: cf_last_item<11>(px, pitch, pa, dcp, t, live, o, out_stride); break;
+                        case 13: cf_last_item<13>(px, pitch, pa, dcp, t, live, o, out_stride); break;
+                        default: cf_last_item<16>(px, pitch, pa, dcp, t, live, o, out_stride); break;
+                    }
+                }
+            }
+            lds_barrier();
+        }
+        if (dc_ends) {
+            // v_end = sum_t c^(nf-1-t) y0[t]: the DC blocker's state after this tile if it entered with zero (iirfilt, :375)
+            if (tid < 64) {
+                double vx = 0.0, vy = 0.0;
+                for (int t = tid; t < nf; t += 64) {
+                    const double wgt = dc_pow(dc_c, nf - 1 - t);
+                    const float2 v = s_dc[t];
+                    vx += wgt * (double)v.x; vy += wgt * (double)v.y;
+                }
+                for (int o = 32; o > 0; o >>= 1) { vx += __shfl_down(vx, o, 64); vy += __shfl_down(vy, o, 64); }
+                if (tid == 0) dc_ends[tile] = d2{vx, vy};
+            }
+        }
+    }
+}
+
+}  // namespace csdr

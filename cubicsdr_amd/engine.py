@@ -138,6 +138,11 @@ class SDRPost:
         return C.c_void_p(buf.data_ptr())
 
     @property
+    def kernel_name(self):
+        """which kernel the channel count maps to (csdr_post_kernel_name)"""
+        return self._l.csdr_post_kernel_name(self.h).decode()
+
+    @property
     def history_length(self):
         return self._l.csdr_post_history_length(self.h)
 

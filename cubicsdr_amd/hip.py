@@ -74,6 +74,7 @@ ABI = {
     "csdr_post_channel_bandwidth": (_i64, [_p]),
     "csdr_post_channel_rate": (_i64, [_p]),
     "csdr_post_num_channels": (_i, [_p]),
+    "csdr_post_kernel_name": (C.c_char_p, [_p]),
     "csdr_post_channel_center": (_i64, [_p, _i]),
     "csdr_post_channel_at": (_i, [_p, _i64]),
     "csdr_post_read_channel": (_i, [_p, _i, _p, _i, C.POINTER(_i)]),

@@ -195,6 +195,12 @@ def test_emu_channelizer_m_twice_odd(ctx, fs, M, block):
     G.test_channelizer_m_twice_odd(ctx, fs, M, block)
 
 
+@pytest.mark.parametrize("M,frames", [pytest.param(M, fr, marks=() if M in (4, 20, 200, 56, 32) and fr != 3 else full) for M, fr in G.FFT_SIZES])
+def test_emu_channelizer_fft_sizes(ctx, M, frames):
+    """the mixed-radix FFT channelizer (kernels_chanfft.hpp): tile walk, FIR windows across the history, every pass's indexing"""
+    G.test_channelizer_fft_sizes(ctx, M, frames)
+
+
 def test_emu_spectrum_contiguous_batches_multi_row(ctx):
     """the control flow of the headline spectrum test (carry across calls, > 256-frame rounds, row-pair tiles) at a size the emulation finishes"""
     G._spectrum_contiguous_batches(ctx, 4096, 2400000, (8, 20, 5))

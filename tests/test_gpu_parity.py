@@ -88,21 +88,20 @@ def test_channelizer2_matches_firpfbch2(ctx, fs, M, block):
     batch.close()
 
 
-@pytest.mark.parametrize("fs,M,block", [(5000000, 10, 83340), (7000000, 14, 14 * 70), (61440000, 122, 122 * 150), (61440000, 122, 1024068)])
-def test_channelizer_m_twice_odd(ctx, fs, M, block):
-    """M = 2 A with A odd (10, 14, 122 = the 61.44 MS/s channel count, SoapySDRThread.cpp:676-693) runs the one-lane-per-frame
-    kernel (chan_analyze_p2): whole and ragged 64-frame tiles, three blocks one at a time (carried history), then the same
-    three in one batch.  Tolerance relative to the strongest channel of the block (a DFT's rounding error scales with the
-    frame's energy; the reference's own mixed-radix / Rader FFT is no closer to the exact transform in the quiet channels)."""
+def _channelizer_case(ctx, fs, M, block, chans=None, nblocks=3):
+    """`nblocks` blocks one at a time (carried history), then the same blocks in one batch, every channel (or `chans`) against the
+    reference's firpfbch.  Tolerance relative to the strongest channel of the block (a DFT's rounding error scales with the frame's
+    energy; the reference's own mixed-radix / Rader FFT is no closer to the exact transform in the quiet channels)."""
     from cubicsdr_amd.engine import SDRPost
     from oracle.cubicsdr_chain import RefSDRPost
     center = 100000000
-    x = [synth_iq(block, fs, center, [("NBFM", center + 123456), ("AM", center - 7 * (fs // M) + 999)], seed=71 + b, t0=b * block) for b in range(3)]
+    x = [synth_iq(block, fs, center, [("NBFM", center + 123456), ("AM", center - 7 * (fs // M) + 999)], seed=71 + b, t0=b * block) for b in range(nblocks)]
     ref = RefSDRPost(_backend(), fs, M)
     post = SDRPost(ctx, fs, M, block, max_blocks=1)
-    chans = list(range(M + 1))
+    chans = list(range(M + 1)) if chans is None else list(chans)
     want_all = {ch: [] for ch in chans}
-    for b in range(3):
+    worst = 0.0
+    for b in range(nblocks):
         ref.run_block(x[b], center)
         post.execute(x[b], 1, block, center)
         peak = float(np.max(np.abs(ref.data_out)))
@@ -112,17 +111,46 @@ def test_channelizer_m_twice_odd(ctx, fs, M, block):
             assert got.size == want.size == block // M
             assert post.channel_center(ch) == fc
             noise = 4 * np.spacing(np.float32(0.01 * M / 0.0005)) if ch == 0 else 0.0     # DC-blocker state noise (see C4 test)
-            assert np.max(np.abs(got - want)) < TOL * peak + noise, (b, ch)
+            err = float(np.max(np.abs(got - want)))
+            assert err < TOL * peak + noise, (b, ch, err / peak)
+            if ch:
+                worst = max(worst, err / peak)
             want_all[ch].append(want)
     post.close()
-    batch = SDRPost(ctx, fs, M, block, max_blocks=3)
-    batch.execute(np.concatenate(x), 3, block, center)
+    batch = SDRPost(ctx, fs, M, block, max_blocks=nblocks)
+    batch.execute(np.concatenate(x), nblocks, block, center)
     peak = max(float(np.max(np.abs(np.concatenate(want_all[ch])))) for ch in chans)
     for ch in chans:
         want = np.concatenate(want_all[ch])
         noise = 4 * np.spacing(np.float32(0.01 * M / 0.0005)) if ch == 0 else 0.0
         assert np.max(np.abs(batch.read_channel(ch) - want)) < TOL * peak + noise, ch
     batch.close()
+    return worst
+
+
+@pytest.mark.parametrize("fs,M,block", [(5000000, 10, 83340), (7000000, 14, 14 * 70), (61440000, 122, 122 * 150), (61440000, 122, 1024068)])
+def test_channelizer_m_twice_odd(ctx, fs, M, block):
+    """M = 2 A with A odd (10, 14, 122 = the 61.44 MS/s channel count, SoapySDRThread.cpp:676-693) runs the one-lane-per-frame
+    kernel (chan_analyze_p2): whole and ragged 64-frame tiles."""
+    _channelizer_case(ctx, fs, M, block)
+
+
+# (M, frames per block): every butterfly of chan_analyze_fft (16 / 8 / 4 / 2, 3 / 5 / 7 / 9 / 11 / 13), one to four passes, tiles of 16 .. 256
+# frames whole and ragged, blocks shorter than one tile and shorter than the FIR's reach; 68 = 4 * 17 and 2048 (no 8-frame tile in 160 KB) stay on chan_analyze
+FFT_SIZES = [(2, 700), (4, 1000), (8, 515), (12, 300), (16, 260), (20, 777), (24, 130), (28, 100), (36, 70), (40, 300), (44, 65), (52, 40), (56, 66),
+             (72, 50), (80, 129), (100, 90), (112, 33), (126 * 2, 20), (200, 100), (256, 37), (360, 20), (1024, 40), (2048, 19), (68, 30), (32, 5), (200, 3)]
+
+
+@pytest.mark.parametrize("M,frames", FFT_SIZES)
+def test_channelizer_fft_sizes(ctx, M, frames):
+    """SDRPostThread::runPFBCH (SDRPostThread.cpp:416-455) for the channel counts getOptimalChannelCount can return
+    (SoapySDRThread.cpp:676-693: any even number): mixed-radix FFT kernel against the reference's firpfbch_crcf."""
+    chans = None if M <= 256 else sorted({c for c in (0, 1, 2, 3, M // 4 - 1, M // 4, M // 2 - 1, M // 2, M // 2 + 1, M - 2, M - 1, M, 77, 500, 333) if c <= M})
+    from cubicsdr_amd.engine import SDRPost
+    probe = SDRPost(ctx, 500000 * M, M, M * frames)
+    assert probe.kernel_name == ("chan_analyze" if M in (68, 2048) else "chan_analyze_fft"), probe.kernel_name
+    probe.close()
+    _channelizer_case(ctx, 500000 * M, M, M * frames, chans=chans)
 
 
 @pytest.mark.parametrize("M,frames", [(122, 8394), (126, 300), (62, 1000), (34, 64)])
