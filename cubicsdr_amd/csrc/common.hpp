@@ -126,6 +126,14 @@ __device__ __forceinline__ void pin_loaded(float4 &v) {
     asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
 #endif
 }
+// a value whose computation (the loads feeding it) must not be removed although nothing reads it
+__device__ __forceinline__ void keep_alive(float v) {
+#if defined(__AMDGCN__)
+    asm volatile("" :: "v"(v));
+#else
+    (void)v;
+#endif
+}
 // a product (or sum) that must be rounded on its own: hipcc contracts a * b + c into one fused operation by default (and its
 // __fmul_rn / __fadd_rn are plain operators), which differs from the reference's separately rounded multiply and add in the last bit
 __device__ __forceinline__ float rounded(float v) {

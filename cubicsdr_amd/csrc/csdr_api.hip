@@ -353,6 +353,9 @@ static chan_p2_kernel_t chan_p2_kernel(const ChanGeom &g) {
     }
 #undef CSDR_P2_CASE
 }
+typedef void (*chanfft_kernel_t)(const float2 *, const float2 *, float2 *, const float *, const float2 *, const int *, const int *, ChanFftGeom, int64_t,
+                                 float2 *, int64_t, d2 *, double);
+static chanfft_kernel_t chanfft_kernel(const ChanFftGeom &) { return chan_analyze_fft; }
 static chan_kernel_t chan_kernel(const ChanGeom &g) {
     if (g.oddA) {
         if (g.hop != g.M) return g.stage_in ? chan_analyze<1, 1, 1, 1> : g.taps_lds ? chan_analyze<0, 1, 1, 1> : chan_analyze<0, 0, 1, 1>;
@@ -455,7 +458,7 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
         CSDR_HIP_TRY(hipMemsetAsync(p->hist1.p, 0, H * sizeof(float2), st));
         CSDR_HIP_TRY(hipStreamSynchronize(st));   // host vectors above go out of scope
         const size_t lds = p->use_fft ? chanfft_lds_bytes(p->fgeom) : g.p2 ? chan_p2_lds_bytes(M, g.TF) : chan_lds_bytes(g);
-        if (lds > 64 * 1024) CSDR_HIP_TRY(hipFuncSetAttribute(p->use_fft ? (const void *)chan_analyze_fft : g.p2 ? (const void *)chan_p2_kernel(g) : (const void *)chan_kernel(g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 64 * 1024) CSDR_HIP_TRY(hipFuncSetAttribute(p->use_fft ? (const void *)chanfft_kernel(p->fgeom) : g.p2 ? (const void *)chan_p2_kernel(g) : (const void *)chan_kernel(g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     p->hist_parity = 0;
     p->active_host.resize(M);
@@ -552,10 +555,12 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
         const bool fused_ends = dc0 && g.fpw >= 16;
         if (p->use_fft) {
             // persistent workgroups (as many as are resident at once) walk over the tiles
-            const ChanFftGeom &fg = p->fgeom;
+            ChanFftGeom fg = p->fgeom;
+            fg.xcd = lab_int("CSDR_CHANFFT_XCD", fg.xcd);
             const size_t lds = chanfft_lds_bytes(fg);
-            const int wgs = std::min(ntiles, std::max(1, c->wg_slots(chan_analyze_fft, fg.threads, lds) * lab_int("CSDR_CHANFFT_PCT", 100) / 100));
-            CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, chan_analyze_fft, dim3(wgs), dim3(fg.threads), lds, x, hist, hist_new, p->taps.p,
+            const chanfft_kernel_t kf = chanfft_kernel(fg);
+            const int wgs = std::min(ntiles, std::max(1, c->wg_slots(kf, fg.threads, lds) * lab_int("CSDR_CHANFFT_PCT", 100) / 100));
+            CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, kf, dim3(wgs), dim3(fg.threads), lds, x, hist, hist_new, p->taps.p,
                         p->twM.p, p->perm.p, p->active.p, fg, n_frames, out, p->chan_stride, fused_ends ? p->tile_end.p : (d2 *)nullptr, p->dc_c);
         } else if (g.p2) {
             // persistent workgroups: as many as are resident at once, each walks over tiles blockIdx.x, + gridDim.x, ...

@@ -42,6 +42,7 @@ struct ChanFftGeom {
     unsigned magic_span[kCfMaxPasses];    // floor(2^32 / s_p) + 1 (s_p > 1)
     int twstep[kCfMaxPasses];             // M / N_p: W_{N_p}^(j r) = W_M^(j r twstep)
     unsigned magic_half;                  // floor(2^32 / (M / 2)) + 1 (M > 2)
+    int xcd;                              // 1: workgroups of one XCD (blockIdx.x % 8) take CONSECUTIVE tiles (grid a multiple of 8)
 };
 
 __host__ __device__ inline size_t chanfft_lds_bytes(const ChanFftGeom &g) {
@@ -74,17 +75,23 @@ __host__ inline bool chanfft_plan(int M, size_t lds_limit, int force_tf, int for
         N /= rad[p];
     }
     g.magic_half = M > 2 ? (unsigned)((1ull << 32) / (unsigned)(M / 2)) + 1u : 0u;
-    // tile: two workgroups per CU when a 16-frame tile allows it, else the largest tile that fits at all; capped at 256 frames
-    auto fits = [&](int tf, size_t budget) { g.TF = tf; g.TFs = tf + 2; return chanfft_lds_bytes(g) <= budget; };
-    int tf = 256;
-    while (tf > 16 && !fits(tf, std::min<size_t>(lds_limit / 2, 64 * 1024))) tf >>= 1;
-    if (!fits(tf, lds_limit / 2)) { tf = 64; while (tf > 8 && !fits(tf, lds_limit)) tf >>= 1; }
-    if (force_tf >= kCfSeg && !(force_tf & (force_tf - 1)) && fits(force_tf, lds_limit)) tf = force_tf;
-    if (!fits(tf, lds_limit)) return false;
+    // tile and workgroup size, from the sweep in profiles/r04_chan_geometry.txt (11 channel counts x 15 geometries on MI355X, working sets beyond the
+    // Infinity Cache): about 5 K samples per tile up to M = 200 (several workgroups per CU overlap their phases), 16 K samples from M = 256 on (the
+    // runs a store instruction writes are 8 TF bytes: 512 at M = 256, 128 at M = 1024, where the 160 KB of LDS end the choice); one thread per FIR
+    // work item, a power of two (320- and 448-thread workgroups measured 10 - 25 % slower than 256 / 512)
+    auto fits = [&](int tf) { g.TF = tf; g.TFs = tf + 2; return chanfft_lds_bytes(g) <= lds_limit; };
+    const int target = M >= 256 ? 16384 : 5120;
+    int tf = 16;
+    while (tf < 256 && 141 * tf * M <= 100 * target) tf <<= 1;    // the power of two nearest target / M (on a log scale)
+    while (tf > kCfSeg && !fits(tf)) tf >>= 1;
+    if (force_tf >= kCfSeg && !(force_tf & (force_tf - 1)) && fits(force_tf)) tf = force_tf;
+    if (!fits(tf)) return false;
     g.lgTF = 0; while ((1 << g.lgTF) < tf) ++g.lgTF;
     const int fir_items = (M / 2) * (tf / kCfSeg);
-    g.threads = std::min(kCfMaxThreads, std::max(256, (fir_items + 63) / 64 * 64));
+    g.threads = 256;
+    while (g.threads < kCfMaxThreads && g.threads < fir_items) g.threads <<= 1;
     if (force_threads >= 64 && force_threads <= kCfMaxThreads && !(force_threads & 63)) g.threads = force_threads;
+    g.xcd = M >= 64;             // (C4: + 5 %, M = 20: nothing)
     // pos = sum_p r_p s_p holds channel k = r_0 + R_0 (r_1 + R_1 (r_2 + ...)) after the last pass
     perm.assign(M, 0);
     for (int pos = 0; pos < M; ++pos) {
@@ -232,6 +239,47 @@ __device__ __forceinline__ void cf_last_item(const float2 *px, int pitch, const 
     }
 }
 
+// the fifteen input rows the eight frames [f0 + 8 seg, + 8) reach, column pair cp: row r of the batch is x[r M ..], rows -7 .. -1 are the
+// carried history, rows past the end are zero (their frames are never stored).  `inside` (tile-uniform): every row lies in x -- fifteen
+// plain loads with nothing between them (a guarded load is compiled behind a wait of its own).
+__device__ __forceinline__ void cf_load_window(const float2 *__restrict__ x, const float2 *__restrict__ hist, int M, int half, int64_t n_frames,
+                                               int64_t f0, bool inside, int seg, int cp, float4 (&win)[kCfSeg + kChanTaps - 1]) {
+    const int64_t r0 = f0 + seg * kCfSeg - (kChanTaps - 1);
+    if (inside) {
+        const float4 *src = reinterpret_cast<const float4 *>(x + r0 * M) + cp;
+#pragma unroll
+        for (int j = 0; j < kCfSeg + kChanTaps - 1; ++j) win[j] = src[(size_t)j * half];
+    } else {
+#pragma unroll
+        for (int j = 0; j < kCfSeg + kChanTaps - 1; ++j) {
+            const int64_t r = r0 + j;
+            win[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < n_frames) win[j] = reinterpret_cast<const float4 *>(r >= 0 ? x + r * M : hist + (r + kChanTaps - 1) * M)[cp];
+        }
+    }
+}
+// eight frames of the two columns of a pair from the window; each row of X receives 64 contiguous bytes
+__device__ __forceinline__ void cf_fir(const float4 (&win)[kCfSeg + kChanTaps - 1], const float *__restrict__ tapsT, int M, int cp, float4 *d0, float4 *d1) {
+    float2 h[kChanTaps];
+#pragma unroll
+    for (int n = 0; n < kChanTaps; ++n) h[n] = *reinterpret_cast<const float2 *>(tapsT + (size_t)n * M + 2 * cp);
+#pragma unroll
+    for (int tt = 0; tt < kCfSeg; tt += 2) {
+        float2 a[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)}, b[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int n = 0; n < kChanTaps; ++n) {
+                const float4 v = win[kChanTaps - 1 + tt + u - n];
+                a[u].x = fmaf(h[n].x, v.x, a[u].x); a[u].y = fmaf(h[n].x, v.y, a[u].y);
+                b[u].x = fmaf(h[n].y, v.z, b[u].x); b[u].y = fmaf(h[n].y, v.w, b[u].y);
+            }
+        }
+        d0[tt >> 1] = make_float4(a[0].x, a[0].y, a[1].x, a[1].y);
+        d1[tt >> 1] = make_float4(b[0].x, b[0].y, b[1].x, b[1].y);
+    }
+}
+
 __global__ __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
     const float2 *__restrict__ x,        // batch input, n_frames * M samples
     const float2 *__restrict__ hist,     // 7 * M samples preceding x
@@ -254,46 +302,23 @@ __global__ __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
 
     const int64_t ntiles = (n_frames + TF - 1) >> g.lgTF;
     const int half = M >> 1, nfir = half * (TF / kCfSeg);
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // tile walk: workgroup b takes tiles b, b + grid, ...; with `xcd` the workgroups that share an L2 (b % 8, the dispatcher's round robin: a
+    // speed assumption only) take consecutive tiles of every round, so that the window rows two neighbouring tiles share and the pieces of a
+    // channel row they write meet in ONE L2
+    int64_t tile0 = blockIdx.x;
+    if (g.xcd && !(gridDim.x & 7)) tile0 = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    for (int64_t tile = tile0; tile < ntiles; tile += gridDim.x) {
         const int64_t f0 = tile << g.lgTF;
         const int nf = (int)min((int64_t)TF, n_frames - f0);
-        // ---- FIR: item = (column pair cp, segment of 8 frames); input row r of the batch is x[r M ..], rows -7 .. -1 are the history
-        const bool inside = f0 >= kChanTaps - 1 && f0 + TF <= n_frames;          // (tile-uniform) every row any item reaches lies in x
-        for (int it = tid; it < nfir; it += nthr) {
-            const int seg = (int)cf_div((unsigned)it, half, g.magic_half), cp = it - seg * half;
-            const int64_t r0 = f0 + seg * kCfSeg - (kChanTaps - 1);
-            float4 win[kCfSeg + kChanTaps - 1];
-            if (inside) {
-                const float4 *src = reinterpret_cast<const float4 *>(x + r0 * M) + cp;
-#pragma unroll
-                for (int j = 0; j < kCfSeg + kChanTaps - 1; ++j) win[j] = src[(size_t)j * half];
-            } else {
-#pragma unroll
-                for (int j = 0; j < kCfSeg + kChanTaps - 1; ++j) {
-                    const int64_t r = r0 + j;
-                    win[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (r < n_frames) win[j] = reinterpret_cast<const float4 *>(r >= 0 ? x + r * M : hist + (r + kChanTaps - 1) * M)[cp];
-                }
-            }
-            float2 h[kChanTaps];
-#pragma unroll
-            for (int n = 0; n < kChanTaps; ++n) h[n] = *reinterpret_cast<const float2 *>(tapsT + (size_t)n * M + 2 * cp);
-            float4 *d0 = reinterpret_cast<float4 *>(s_x + (size_t)(2 * cp) * TFs + seg * kCfSeg);
-            float4 *d1 = reinterpret_cast<float4 *>(s_x + (size_t)(2 * cp + 1) * TFs + seg * kCfSeg);
-#pragma unroll
-            for (int tt = 0; tt < kCfSeg; tt += 2) {
-                float2 a[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)}, b[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-#pragma unroll
-                    for (int n = 0; n < kChanTaps; ++n) {
-                        const float4 v = win[kChanTaps - 1 + tt + u - n];
-                        a[u].x = fmaf(h[n].x, v.x, a[u].x); a[u].y = fmaf(h[n].x, v.y, a[u].y);
-                        b[u].x = fmaf(h[n].y, v.z, b[u].x); b[u].y = fmaf(h[n].y, v.w, b[u].y);
-                    }
-                }
-                d0[tt >> 1] = make_float4(a[0].x, a[0].y, a[1].x, a[1].y);
-                d1[tt >> 1] = make_float4(b[0].x, b[0].y, b[1].x, b[1].y);
+        // ---- FIR: item = (column pair cp, segment of 8 frames)
+        {
+            const bool inside = f0 >= kChanTaps - 1 && f0 + TF <= n_frames;      // (tile-uniform) every row any item of the tile reaches lies in x
+            for (int it = tid; it < nfir; it += nthr) {
+                const int seg = (int)cf_div((unsigned)it, half, g.magic_half), cp = it - seg * half;
+                float4 win[kCfSeg + kChanTaps - 1];
+                cf_load_window(x, hist, M, half, n_frames, f0, inside, seg, cp, win);
+                cf_fir(win, tapsT, M, cp, reinterpret_cast<float4 *>(s_x + (size_t)(2 * cp) * TFs + seg * kCfSeg),
+                       reinterpret_cast<float4 *>(s_x + (size_t)(2 * cp + 1) * TFs + seg * kCfSeg));
             }
         }
         // the workgroup that owns the last tile also writes the new input history (the launch runs even with no consumers)

@@ -21,7 +21,7 @@ from cubicsdr_amd.engine import Context, SDRPost  # noqa: E402
 
 CASES = {"C2": (10_000_000, 20, 166_680, 256), "C3": (61_440_000, 122, 1_024_068, 128), "C5": (100_000_000, 200, 1_666_800, 32),
          "C4": (100_000_000, 1024, 1_667_072, 16)}
-ITERS = int(os.environ.get("CHAN_BENCH_ITERS", "30"))
+ITERS = int(os.environ.get("CHAN_BENCH_ITERS", "100"))
 
 
 def run(name, fs, M, block, nb, variants):
@@ -61,7 +61,7 @@ def main():
             fs = 500_000 * M
             block = -(-fs // 60 // M) * M
             nb = max(1, (1 << 26) // block)
-        variants = [("direct-dft", {"CSDR_CHAN_FFT": "0"}), ("default", {})]
+        variants = [("direct-dft", {"CSDR_CHAN_FFT": "0"}), ("default", {})] if os.environ.get("CHAN_BENCH_BASE", "1") == "1" else [("default", {})]
         extra = os.environ.get("CHAN_BENCH_VARIANTS", "")     # e.g. "tf32:CSDR_CHANFFT_TF=32;tf64:CSDR_CHANFFT_TF=64"
         for item in filter(None, extra.split(";")):
             label, kv = item.split(":", 1)

@@ -21,7 +21,8 @@ def lib_path(flavor=""):
 def build(flavor="", force=False, verbose=False):
     """flavor: "" (plain -O2), "asan", "tsan" """
     os.makedirs(OUT_DIR, exist_ok=True)
-    out = lib_path(flavor)
+    lab = os.environ.get("CSDR_BUILD_LAB") == "1"       # the measurement switches of common.hpp lab_int() compiled in
+    out = lib_path(flavor + ("lab" if lab else ""))
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "hip", "hip_runtime.h"),
                                                                 os.path.join(HERE, "hip_emu_runtime.cpp"),
                                                                 os.path.join(ROOT, "include", "csdr_hip.h")]
@@ -30,7 +31,7 @@ def build(flavor="", force=False, verbose=False):
     san = {"": ["-O2"], "asan": ["-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer"],
            "tsan": ["-O1", "-g", "-fsanitize=thread"]}[flavor]
     cmd = ["g++", "-std=c++20", "-shared", "-fPIC", "-pthread", "-w", "-ffp-contract=off", "-I", HERE] + san + \
-          ["-x", "c++", os.path.join(CSRC, "csdr_api.hip"), os.path.join(HERE, "hip_emu_runtime.cpp"), "-o", out]
+          (["-DCSDR_LAB"] if lab else []) + ["-x", "c++", os.path.join(CSRC, "csdr_api.hip"), os.path.join(HERE, "hip_emu_runtime.cpp"), "-o", out]
     if verbose:
         print("[emu build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
