@@ -64,6 +64,9 @@ extern "C" int csdr_scope_setup(csdr_scope *s, int fft_size, int max_frames, int
     if (int rc = s->spec_pts.reserve((size_t)max_frames * fft_size)) return rc;
     if (int rc = s->wave_meta.reserve((size_t)max_frames)) return rc;
     if (int rc = s->spec_meta.reserve((size_t)max_frames)) return rc;
+    // the spectrum kernel's two L-point arrays + its reduction scratch pass the 64 KB default at fftSize 4096
+    const size_t lds = (size_t)2 * fft_size * sizeof(float2) + 8 * sizeof(double);
+    if (lds > 64 * 1024) CSDR_HIP_TRY(hipFuncSetAttribute((const void *)scope_spectrum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     s->nf_last = 0;
     s->ready = true;
     return CSDR_OK;
@@ -252,6 +255,7 @@ extern "C" int csdr_mix_set_source(csdr_mix *m, int source, int bound, int activ
 }
 static int mix_enqueue(csdr_mix *m, MixSource &s, int n, int channels, int rate) {
     if (s.queue_cap && s.queue.size() >= s.queue_cap) return 1;                    // try_push on a full queue: the block is dropped
+    if (s.queue.size() + (s.have_cur ? 1 : 0) >= (size_t)s.pmask) return 1;         // one peak slot per queued block: an unbounded queue (queue_blocks 0) is full here
     if ((int64_t)n + s.buffered > (int64_t)s.mask + 1) return fail(CSDR_ERANGE, "mixer ring overrun: render before pushing more");
     s.queue.push_back(MixSeg{s.wpos, n, channels, rate, s.pwpos});
     s.wpos = (s.wpos + (uint32_t)n) & s.mask; s.pwpos = (s.pwpos + 1) & s.pmask; s.buffered += n;
@@ -267,12 +271,22 @@ extern "C" int csdr_mix_push(csdr_mix *m, int source, const float *audio, int is
     hipStream_t st = m->ctx->lanes[LANE_AUDIO];
     const uint32_t w0 = s.wpos, pw0 = s.pwpos;
     if (int rc = mix_enqueue(m, s, n_floats, channels, sample_rate)) return rc;
+    if (is_dev) {
+        // device audio may have been produced on any lane of this context or on the boundary stream: the copy starts behind all of them
+        csdr_ctx *c = m->ctx;
+        for (int l = 0; l < c->n_phys; ++l) {
+            if (c->phys[l] == st) continue;
+            CSDR_HIP_TRY(hipEventRecord(c->ev_lane[l], c->phys[l]));
+            CSDR_HIP_TRY(hipStreamWaitEvent(st, c->ev_lane[l], 0));
+        }
+        if (int rc = c->lane_begin(LANE_AUDIO)) return rc;
+    }
     const hipMemcpyKind k = is_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     const uint32_t first = std::min<uint32_t>((uint32_t)n_floats, s.mask + 1 - w0);
     if (first) CSDR_HIP_TRY(hipMemcpyAsync(s.ring.p + w0, audio, (size_t)first * sizeof(float), k, st));
     if ((uint32_t)n_floats > first) CSDR_HIP_TRY(hipMemcpyAsync(s.ring.p, audio + first, ((size_t)n_floats - first) * sizeof(float), k, st));
     CSDR_HIP_TRY(hipMemcpyAsync(s.peaks.p + pw0, &peak, sizeof(float), hipMemcpyHostToDevice, st));
-    if (!is_dev) CSDR_HIP_TRY(hipStreamSynchronize(st));                          // pageable source: the caller may reuse it on return
+    CSDR_HIP_TRY(hipStreamSynchronize(st));                                       // `peak` lives on this stack frame, a pageable source may be reused on return
     return CSDR_OK;
 }
 // The audio of EVERY block of the bank's last execute, for n (slot, source) pairs, appended in HBM by ONE kernel: samples and
@@ -283,20 +297,28 @@ extern "C" int csdr_mix_push_bank(csdr_mix *m, csdr_bank *b, const int *slots, c
     if (b->ctx != m->ctx) return fail(CSDR_EINVAL, "bank and mixer belong to different contexts");
     std::vector<RingPush> jobs;
     int max_n = 0;
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; ++i) {                    // every pair is checked before anything is enqueued: a bad pair leaves no half-pushed queue entries
         if (slots[i] < 0 || slots[i] >= b->max_demods || sources[i] < 0 || sources[i] >= (int)m->src.size()) return fail(CSDR_EINVAL, "pair %d", i);
+        if (!m->src[(size_t)sources[i]].bound) return fail(CSDR_ESTATE, "source %d is not bound", sources[i]);
+    }
+    struct Undo { MixSource *s; uint32_t wpos, pwpos; size_t qsize; int64_t buffered; };
+    std::vector<Undo> undo;
+    for (int i = 0; i < n; ++i) {
         const SlotHost &sl = b->slots[(size_t)slots[i]];
         MixSource &s = m->src[(size_t)sources[i]];
-        if (!s.bound) return fail(CSDR_ESTATE, "source %d is not bound", sources[i]);
         if (!sl.configured || sl.results.empty() || sl.results[0].skipped || is_fe_only(sl.prm.modem)) continue;
         const int channels = (sl.prm.modem == CSDR_MODEM_IQ || sl.prm.modem == CSDR_MODEM_FMS) ? 2 : 1;
         RingPush jb{};
         jb.src = sl.cfg.audio; jb.ring = s.ring.p; jb.mask = s.mask; jb.wpos = s.wpos; jb.n = 0;
         jb.peaks_src = sl.cfg.bout; jb.peaks_dst = s.peaks.p; jb.peaks_mask = s.pmask; jb.peaks_wpos = s.pwpos; jb.n_peaks = 0;
+        undo.push_back(Undo{&s, s.wpos, s.pwpos, s.queue.size(), s.buffered});
         // blocks the queue refuses (full) still occupy ring space of this copy: simplest is to stop at the first refusal
         for (const csdr_block_result &r : sl.results) {
             const int rc = mix_enqueue(m, s, r.n_audio, channels, sl.prm.audio_sample_rate);
-            if (rc < 0) return rc;
+            if (rc < 0) {                             // ring overrun: the copy kernel will not run, so nothing of this call may stay queued
+                for (const Undo &u : undo) { u.s->queue.resize(u.qsize); u.s->wpos = u.wpos; u.s->pwpos = u.pwpos; u.s->buffered = u.buffered; }
+                return rc;
+            }
             if (rc == 1) break;
             jb.n += r.n_audio; jb.n_peaks += 1;
         }
@@ -478,23 +500,29 @@ struct csdr_ingest {
     std::vector<std::vector<hipEvent_t>> ev_done;                        // [slot][physical stream]: its consumers enqueued up to the next commit
     std::vector<char> copied_valid, done_valid;
 };
+extern "C" void csdr_ingest_destroy(csdr_ingest *g);
 extern "C" int csdr_ingest_create(csdr_ctx *ctx, int64_t max_samples, int depth, csdr_ingest **out) {
     DeviceScope dev__(ctx);
     if (!ctx || !out || max_samples <= 0 || depth < 2 || depth > 16) return fail(CSDR_EINVAL, "bad argument (depth 2..16)");
-    std::unique_ptr<csdr_ingest> g(new csdr_ingest());
+    csdr_ingest *g = new csdr_ingest();
     g->ctx = ctx; g->depth = depth; g->cap = max_samples;
-    CSDR_HIP_TRY(hipStreamCreateWithFlags(&g->copy, hipStreamNonBlocking));
     g->host.assign((size_t)depth, nullptr); g->dev.assign((size_t)depth, nullptr);
     g->ev_copied.assign((size_t)depth, nullptr); g->ev_done.assign((size_t)depth, std::vector<hipEvent_t>());
     g->copied_valid.assign((size_t)depth, 0); g->done_valid.assign((size_t)depth, 0);
-    for (int k = 0; k < depth; ++k) {
-        if (hipHostMalloc((void **)&g->host[(size_t)k], (size_t)max_samples * sizeof(float2), hipHostMallocDefault) != hipSuccess) return fail(CSDR_ENOMEM, "pinned ingest slot of %lld samples", (long long)max_samples);
-        if (hipMalloc((void **)&g->dev[(size_t)k], (size_t)max_samples * sizeof(float2)) != hipSuccess) return fail(CSDR_ENOMEM, "device ingest slot");
-        CSDR_HIP_TRY(hipEventCreateWithFlags(&g->ev_copied[(size_t)k], hipEventDisableTiming));
-        g->ev_done[(size_t)k].assign((size_t)ctx->n_phys + 1, nullptr);
-        for (auto &e : g->ev_done[(size_t)k]) CSDR_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-    *out = g.release();
+    // a failure anywhere below tears down what was built so far (pinned slots are large: nothing may leak under memory pressure)
+    auto build = [&]() -> int {
+        CSDR_HIP_TRY(hipStreamCreateWithFlags(&g->copy, hipStreamNonBlocking));
+        for (int k = 0; k < depth; ++k) {
+            if (hipHostMalloc((void **)&g->host[(size_t)k], (size_t)max_samples * sizeof(float2), hipHostMallocDefault) != hipSuccess) return fail(CSDR_ENOMEM, "pinned ingest slot of %lld samples", (long long)max_samples);
+            if (hipMalloc((void **)&g->dev[(size_t)k], (size_t)max_samples * sizeof(float2)) != hipSuccess) return fail(CSDR_ENOMEM, "device ingest slot");
+            CSDR_HIP_TRY(hipEventCreateWithFlags(&g->ev_copied[(size_t)k], hipEventDisableTiming));
+            g->ev_done[(size_t)k].assign((size_t)ctx->n_phys + 1, nullptr);
+            for (auto &e : g->ev_done[(size_t)k]) CSDR_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        return CSDR_OK;
+    };
+    if (int rc = build()) { const std::string why = last_error_ref(); csdr_ingest_destroy(g); last_error_ref() = why; return rc; }
+    *out = g;
     return CSDR_OK;
 }
 extern "C" void csdr_ingest_destroy(csdr_ingest *g) {
@@ -561,6 +589,14 @@ extern "C" int csdr_ingest_commit(csdr_ingest *g, int64_t n_samples, int iq_swap
     const int k = g->acquired;
     g->acquired = -1;
     return ingest_transfer(g, k, g->host[(size_t)k], true, n_samples, iq_swap, dev_iq);
+}
+// blocks until the last transfer has left its source buffer (a caller that is about to rewrite or recycle the block it just uploaded)
+extern "C" int csdr_ingest_wait(csdr_ingest *g) {
+    DeviceScope dev__(g ? g->ctx : nullptr);
+    if (!g) return fail(CSDR_EINVAL, "ingest is null");
+    const int last = (g->next + g->depth - 1) % g->depth;
+    if (g->copied_valid[(size_t)last]) CSDR_HIP_TRY(hipEventSynchronize(g->ev_copied[(size_t)last]));
+    return CSDR_OK;
 }
 // the slot the next commit / upload will use (a caller that ties a slot's lifetime to its own block objects asks before it transfers)
 extern "C" int csdr_ingest_next_slot(const csdr_ingest *g) { return g ? g->next : -1; }

@@ -143,6 +143,7 @@ ABI = {
     "csdr_ingest_acquire": (_i, [_p, _pp]),
     "csdr_ingest_commit": (_i, [_p, _i64, _i, _pp]),
     "csdr_ingest_upload": (_i, [_p, _p, _i64, _i, _pp]),
+    "csdr_ingest_wait": (_i, [_p]),
     "csdr_ingest_next_slot": (_i, [_p]),
 }
 

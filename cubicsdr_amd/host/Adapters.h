@@ -67,6 +67,7 @@ public:
     ~DeviceIngest() { if (ing_) csdr_ingest_destroy(ing_); }
     // Moves blk.data over the link (exchanging I and Q on the way when blk.iqSwapPending) and records the HBM address in the block.
     // false: the slot that is next in the ring is still held by a consumer (or the transfer failed) -- the block stays host-only.
+    // The transfer is a DMA from blk.data that may still be running on return: wait() before the buffer is rewritten or recycled.
     bool upload(SDRThreadIQData &blk) {
         const int k = csdr_ingest_next_slot(ing_);
         if (k < 0 || (holds_[(size_t)k] && holds_[(size_t)k].use_count() > 1)) return false;
@@ -76,6 +77,7 @@ public:
         blk.deviceData = dev; blk.deviceSamples = blk.data.size(); blk.deviceHold = holds_[(size_t)k];
         return true;
     }
+    void wait() { (void)csdr_ingest_wait(ing_); }
 
 private:
     csdr_ingest *ing_ = nullptr;
@@ -145,13 +147,16 @@ public:
         blk->frequency = freq_.load(); blk->sampleRate = rate_.load(); blk->numChannels = channels_.load(); blk->dcCorrected = false;
         blk->iqSwapPending = swapped;
         blk->dropDeviceCopy();
-        // with an ingest bound the block crosses the link ONCE, here, and the exchange rides along; host readers of `data` get the
-        // same orientation afterwards (one pass over the host copy, only while the option is on)
-        const bool inHbm = ingest_ && ingest_->upload(*blk);
+        // host readers of `data` need the exchanged orientation anyway (one pass over the host copy, only while the option is on): it is made
+        // BEFORE the transfer -- the DMA reads this buffer asynchronously, an exchange issued behind it would race with it -- and the block then
+        // crosses the link ONCE, as it is
         if (blk->iqSwapPending) exchange(blk->data.data(), have);
         blk->iqSwapPending = false;
-        (void)inHbm;
-        if (!out->try_push(blk)) return 0;
+        const bool inHbm = ingest_ && ingest_->upload(*blk);
+        if (!out->try_push(blk)) {
+            if (inHbm) ingest_->wait();          // the block goes back to the pool: its transfer must not be reading it when the next read refills it
+            return 0;
+        }
         return code;
     }
     void bindIngest(DeviceIngest *ing) { ingest_ = ing; }

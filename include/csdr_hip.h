@@ -336,6 +336,7 @@ int  csdr_ingest_commit(csdr_ingest *ing, int64_t n_samples, int iq_swap, const 
  * csdr_host_register); waits for the previous upload first.  csdr_ingest_next_slot: the ring slot the next transfer will overwrite. */
 int  csdr_ingest_upload(csdr_ingest *ing, const float *host_iq, int64_t n_samples, int iq_swap, const float **dev_iq);
 int  csdr_ingest_next_slot(const csdr_ingest *ing);
+int  csdr_ingest_wait(csdr_ingest *ing);             /* blocks until the last transfer has left its source buffer: call before rewriting or recycling the block just uploaded */
 
 #ifdef __cplusplus
 }

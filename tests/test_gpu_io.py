@@ -62,14 +62,14 @@ def _compare_scope_item(got, want, tag):
     return 0.0
 
 
-def scope_scenario(ctx, per_call=(1, 1, 3, 2, 5, 4)):
+def scope_scenario(ctx, per_call=(1, 1, 3, 2, 5, 4), fft_size=1024):
     import oracle.ref_modems as RM
     from cubicsdr_amd.engine import ScopeProcessor
     _need(RM.scope_available(), "libref_scope.so")
     rng = np.random.default_rng(5)
     frames = _scope_frames(rng)
-    ref = RM.RefScopeCpp(1024)
-    sp = ScopeProcessor(ctx, 1024, max_frames=8, max_samples=4096)
+    ref = RM.RefScopeCpp(fft_size)
+    sp = ScopeProcessor(ctx, fft_size, max_frames=8, max_samples=4096)
     worst = 0.0
     k = 0
     for n in per_call:
@@ -99,9 +99,11 @@ def scope_scenario(ctx, per_call=(1, 1, 3, 2, 5, 4)):
     return worst
 
 
-def test_scope_matches_reference_processor(ctx):
-    """waveform items bit for bit, spectrum items at 1e-5, floor / ceil trackers, item sizes (decimated taps), over 16 frames in calls of 1..5"""
-    print("audio scope against the reference's ScopeVisualProcessor: worst %.3g" % scope_scenario(ctx))
+@pytest.mark.parametrize("fft_size", [1024, 256, 4096])
+def test_scope_matches_reference_processor(ctx, fft_size):
+    """waveform items bit for bit, spectrum items at 1e-5, floor / ceil trackers, item sizes (decimated taps), over 16 frames in calls of 1..5;
+    fftSize 4096 is the largest csdr_scope_setup accepts (its LDS request passes the 64 KB default)"""
+    print("audio scope (fftSize %d) against the reference's ScopeVisualProcessor: worst %.3g" % (fft_size, scope_scenario(ctx, fft_size=fft_size)))
 
 
 def test_scope_tap_is_the_modems_demod_output(ctx):
