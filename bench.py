@@ -103,7 +103,7 @@ def cascade_depth(bw, chan_rate):
 
 
 def frontend_groups(cfg):
-    """demodulators per front-end kernel instance (one launch per cascade depth, csdr_api.hip: csdr_bank_execute)"""
+    """demodulators per front-end kernel instance (one launch per cascade depth, csdr_bank.hip: csdr_bank_execute)"""
     out = {}
     for i in range(cfg["n_demods"]):
         kind = cfg["kinds"][i % len(cfg["kinds"])]
@@ -135,9 +135,6 @@ def algorithmic_bytes_per_sample(kernel, cfg):
         "spec_average": 0.0,
         "spec_display": 4.0,
     }
-    if kernel == "demod_frontend_s56":                                        # the depth-5 and depth-6 groups in one launch
-        g = frontend_groups(cfg)
-        return 8.0 * (g.get("demod_frontend_s5", 0) + g.get("demod_frontend_s6", 0)) / cfg["M"]
     if kernel.startswith("demod_frontend"):
         return 8.0 * frontend_groups(cfg).get(kernel, 0) / cfg["M"]          # each demodulator reads its channel once
     return table.get(kernel, 0.0)
@@ -164,11 +161,9 @@ def measured_traffic(cfg_name):
     for name, v in t.items():
         if "FETCH_SIZE_KiB_avg_per_launch" in v and "WRITE_SIZE_KiB_avg_per_launch" in v:
             base = name.split("<")[0]
-            if base == "demod_frontend_s56":
-                pass
-            elif base == "demod_frontend_s" and "<" in name:
+            if base == "demod_frontend_s" and "<" in name:
                 base = "demod_frontend_s" + name.split("<")[1].split(",")[0].strip()          # demod_frontend_s<6, 2048, true> -> demod_frontend_s6
-            base = {"demod_frontend": "demod_frontend_generic", "spec_fft_rows4096": "spec_fft_rows", "chan_analyze_p2": "chan_analyze", "chan_analyze_mx": "chan_analyze"}.get(base, base)
+            base = {"demod_frontend": "demod_frontend_generic", "spec_fft_rows4096": "spec_fft_rows", "chan_analyze_p2": "chan_analyze", "chan_analyze_fft": "chan_analyze"}.get(base, base)
             out[base] = out.get(base, 0.0) + (2.0 * v["FETCH_SIZE_KiB_avg_per_launch"] + v["WRITE_SIZE_KiB_avg_per_launch"]) * 1024.0 / blocks
     return out, os.path.relpath(files[-1], ROOT)
 

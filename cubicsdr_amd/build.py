@@ -5,10 +5,11 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "csdr_api.hip")
+# one translation unit per object of include/csdr_hip.h (an edit rebuilds its own unit; the units compile in parallel)
+UNITS = ["csdr_ctx", "csdr_post", "csdr_bank", "csdr_spec", "csdr_io"]
+SRCS = [os.path.join(HERE, "csrc", u + ".hip") for u in UNITS]
+OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
 OUT = os.path.join(HERE, "libcsdr_hip.so")
-DEPS = [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))] + [
-    os.path.join(HERE, "..", "include", "csdr_hip.h")]
 
 
 def hipcc():
@@ -34,21 +35,49 @@ def build_design(force=False, verbose=True):
     return DESIGN_OUT
 
 
-def needs_build():
-    if not os.path.exists(OUT):
-        return True
-    t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(d) > t for d in DEPS if os.path.exists(d))
+def _unit_deps(src):
+    """the unit itself plus every header of csrc/ it includes, transitively"""
+    import re
+    seen, todo = set(), [src]
+    while todo:
+        f = todo.pop()
+        if f in seen or not os.path.exists(f):
+            continue
+        seen.add(f)
+        for inc in re.findall(r'^#include "([^"]+)"', open(f).read(), re.M):
+            todo.append(os.path.normpath(os.path.join(os.path.dirname(f), inc)))
+    return seen
 
 
 def build(force=False, verbose=True):
     build_design(force, verbose)
-    if not force and not needs_build():
+    lab = os.environ.get("CSDR_BUILD_LAB") == "1"      # measurement build: the A/B switches of common.hpp lab_int() read the environment
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + (["-DCSDR_LAB"] if lab else [])
+    stamp = os.path.join(OBJ_DIR, "flavor")
+    flavor = "lab" if lab else "ship"
+    if not os.path.exists(stamp) or open(stamp).read() != flavor:
+        force = True
+    jobs = []
+    for src in SRCS:
+        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _unit_deps(src)):
+            jobs.append((src, obj))
+    objs = [os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o") for src in SRCS]
+    if not jobs and os.path.exists(OUT) and all(os.path.getmtime(o) <= os.path.getmtime(OUT) for o in objs):
         return OUT
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",
-           "-Wno-unused-function", SRC, "-o", OUT]
-    if os.environ.get("CSDR_BUILD_LAB") == "1":      # measurement build: the A/B switches of common.hpp lab_int() read the environment
-        cmd.insert(1, "-DCSDR_LAB")
+    cc = hipcc()
+
+    def compile_one(job):
+        cmd = [cc] + flags + ["-c", job[0], "-o", job[1]]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(compile_one, jobs))
+    open(stamp, "w").write(flavor)
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

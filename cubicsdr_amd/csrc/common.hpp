@@ -12,6 +12,9 @@
 
 #include "../../include/csdr_hip.h"
 
+// every kernel has internal linkage: the kernel headers are included by several translation units (each uses, and emits, its own subset)
+#define CSDR_KERNEL static __global__
+
 namespace csdr {
 
 inline std::string &last_error_ref() {
@@ -77,6 +80,9 @@ struct PinBuf {
     }
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
+
+// one AudioThreadInput (a block) of the float -> 16-bit PCM conversion (kernels_io.hpp: pcm16_convert)
+struct PcmJob { const float *src; int16_t *dst; int32_t n; int32_t pad; const float *peak; };
 
 // ---- small device helpers shared by the kernel headers ----
 __device__ inline float2 cmul(float2 a, float2 b) { return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x)); }
@@ -195,15 +201,6 @@ __device__ __forceinline__ float wave_min_to_lane63(float v) {
     return v;
 }
 #endif
-// fp32 matrix pipe: D[16][16] += A[16][4] B[4][16] on one wave (v_mfma_f32_16x16x4_f32, 32 cycles, exact f32: a k-ordered fmaf chain).
-// lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15] and holds D[4 (l >> 4) + r][l & 15] in element r.
-#if defined(__AMDGCN__) || defined(__HIP__)
-typedef float csdr_f32x4 __attribute__((ext_vector_type(4)));
-#else
-typedef float csdr_f32x4 __attribute__((vector_size(16)));
-#endif
-__device__ __forceinline__ csdr_f32x4 csdr_mfma16(float a, float b, csdr_f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-
 // 16 bytes that are only guaranteed 8-byte aligned (two adjacent complex samples at an odd sample offset)
 struct __attribute__((aligned(8))) f4u { float x, y, z, w; };
 
@@ -245,7 +242,7 @@ template <int N> __device__ __forceinline__ void lds_read128(const float2 *pe, c
 // always be sampled at the same phase of the sampling period and the per-stage sums would miss the other instance)
 enum CsdrKernelId {
     KID_CHAN_ANALYZE = 0, KID_DC_ENDS, KID_DC_APPLY, KID_ROWS_COPY,
-    KID_FE_GENERIC, KID_FE_S3, KID_FE_S4, KID_FE_S5, KID_FE_S6, KID_FE_S56, KID_FE_INTERP,
+    KID_FE_GENERIC, KID_FE_S3, KID_FE_S4, KID_FE_S5, KID_FE_S6, KID_FE_INTERP,
     KID_MODEM, KID_GAIN_SCAN, KID_FMS, KID_AUDIO, KID_FMS_OUT, KID_MIX,
     KID_FFT_COLS, KID_FFT_ROWS, KID_SPEC_AVG, KID_SPEC_TRACK, KID_SPEC_DISPLAY, KID_SPEC_MISC,
     KID_COUNT

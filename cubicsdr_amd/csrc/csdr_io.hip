@@ -1,12 +1,18 @@
-// csdr_io_api.hpp -- C ABI of the path's edges (included at the end of csdr_api.hip: it uses the bank's internals).
+// csdr_io.hip -- C ABI of the path's edges (it uses the bank's internals: csdr_objects.hpp).
 //   csdr_scope   ScopeVisualProcessor's arithmetic                      (src/process/ScopeVisualProcessor.cpp:24-217)
 //   csdr_mix     AudioThread's mixing callback                          (src/audio/AudioThread.cpp:88-240)
 //   PCM16        AudioFileWAV's payload conversion                      (src/audio/AudioFileWAV.cpp:133-157)
 //   csdr_ingest  SDRThread's block buffers -> HBM, one transfer per block (src/sdr/SoapySDRThread.cpp:221-225, :258-266; SDRPostThread.cpp:227-245)
-#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
 #include <deque>
+#include <memory>
 
+#include "csdr_objects.hpp"
 #include "kernels_io.hpp"
+
+using namespace csdr;
 
 // =================================================================================================== audio scope
 struct csdr_scope {

@@ -1,0 +1,112 @@
+// csdr_objects.hpp -- the object layouts behind the opaque handles of include/csdr_hip.h that more than one translation unit looks into
+// (the demodulator bank reads the channelizer's output rotation; the audio / scope edges read the bank's slots).
+#pragma once
+#include <map>
+#include <vector>
+
+#include "common.hpp"
+#include "design.hpp"
+#include "kernels_post.hpp"
+#include "kernels_chanfft.hpp"
+#include "kernels_demod.hpp"
+
+using namespace csdr;      // (this header is only included by the library's own translation units, all of which do the same)
+
+// =================================================================================================== SDRPostThread
+struct csdr_post {
+    csdr_ctx *ctx = nullptr;
+    bool configured = false;
+    int mode = CSDR_POST_SINGLE, M = 1;
+    int64_t sample_rate = 0, chan_bw = 0, chan_rate = 0, frequency = 0;
+    int hop = 1;                             // input samples per output sample of a channel: M, M / 2 (PFBCH2) or 1 (single)
+    int max_block_len = 0, max_blocks = 0;
+    int64_t chan_stride = 0;                 // samples per channel row in `out` (even: rows stay 16-byte aligned)
+    int n_blocks = 0, block_len = 0;         // of the last execute
+    std::vector<int64_t> centers;            // chanCenters[M + 1]
+    std::vector<int> active_host;            // sorted list of produced channels
+    bool active_dirty = true;
+    ChanGeom geom{};
+    bool use_fft = false;                    // critically sampled, M = 2^a 3^b 5^c 7^d 11^e 13^f: chan_analyze_fft (kernels_chanfft.hpp)
+    ChanFftGeom fgeom{};
+    DevBuf<int> perm;                        // chan_analyze_fft: position after the last pass -> channel
+    // `out` holds kPostBufs batches in rotation: the channelizer fills the next one while the demodulators still read
+    // the previous (the reference hands ReBuffer blocks through a queue, SDRPostThread.cpp:341-396)
+    static constexpr int kPostBufs = 3, kMaxConsumers = 4;
+    int cur = 0;                             // buffer of the last execute
+    uint64_t seq = 0;
+    hipEvent_t ev_ready[kPostBufs] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_consumed[kPostBufs][kMaxConsumers] = {};
+    int n_consumed[kPostBufs] = {0, 0, 0};
+    DevBuf<float2> out, hist0, hist1, stage_in, twA, twB, twM, post2;
+    DevBuf<float> taps;
+    DevBuf<int> active;                      // [M] flags
+    DevBuf<d2> dc_state, tile_end;           // dc_state[2]: ping-pong carried state
+    int hist_parity = 0, dc_parity = 0;
+    double dc_c = 0.0;                       // feedback coefficient of the DC blocker recurrence
+    bool raw = false;                        // internal (zoomed spectrum view): SINGLE mode hands the input on unfiltered
+    bool dc_enabled = true;                  // csdr_post_set_dc_blocker: a time-slab producer leaves channel 0 to the rank that owns it
+    int import_k = -1;                       // buffer being assembled by csdr_post_import_begin .. commit
+    std::map<std::vector<int>, int *> rowlists;   // device copies of the channel lists export / import calls name (a handful, reused every batch)
+};
+static inline float2 *post_buf(const csdr_post *p, int k) { return p->out.p + (size_t)k * p->chan_stride * p->M; }
+
+// =================================================================================================== demodulator bank
+namespace csdr {
+struct SlotHost {
+    bool configured = false, active = false;
+    csdr_demod_params prm{};
+    design::MsresampPlan iq, au;
+    int64_t chan_rate = 0;
+    // integer state mirrored on the host (closed-form bookkeeping)
+    uint32_t theta = 0, dtheta = 0, buf_idx = 0, phase = 0, aphase = 0, abuf = 0, ssb_theta = 0, cw_dtheta = 0;
+    long long shift_frequency = 0;
+    bool shift_valid = false;
+    int hist_parity = 0, last_parity = 0;
+    int prev_J = 0;                          // resampled-IQ samples of the previous executed batch
+    int warm = 0;                            // cascade span in input samples (+ one output period)
+    bool fms_sos_set = false;                // csdr_bank_set_fms_pilot: caller-supplied pilot band-pass sections
+    float fms_b[15] = {0}, fms_a[15] = {0};
+    void *slab = nullptr;
+    SlotCfg cfg{};
+    // results of the last execute
+    std::vector<csdr_block_result> results;
+    int last_J = 0, last_A = 0;
+};
+constexpr int kStageRing = 4;                // pinned staging sets for the per-batch uploads
+}  // namespace csdr
+
+struct csdr_bank {
+    csdr_ctx *ctx = nullptr;
+    int max_demods = 0, max_blocks = 0;
+    std::vector<SlotHost> slots;
+    DevBuf<SlotCfg> cfgs;
+    // per-batch device tables, two copies: the front-end of batch i+1 uploads its set while the audio kernels of batch i
+    // still read theirs
+    DevBuf<SlotDyn> dyns;                    // [2][max_demods]
+    DevBuf<int> slot_list;                   // [2][3][max_demods]: all running slots | running auto-gain slots | grouped by front-end kernel
+    DevBuf<BlockPlan> plans;                 // [2][max_demods][max_blocks + 1]
+    uint64_t seq = 0;
+    hipEvent_t ev_fe_done[2] = {nullptr, nullptr}, ev_audio_done[2] = {nullptr, nullptr};
+    bool audio_pending[2] = {false, false};
+    DevBuf<float> arms;
+    DevBuf<ModemConsts> mconsts;
+    PinBuf<SlotDyn> dyns_h[kStageRing];
+    PinBuf<int> slot_list_h[kStageRing];
+    PinBuf<BlockPlan> plans_h[kStageRing];
+    hipEvent_t stage_ev[kStageRing] = {nullptr, nullptr, nullptr, nullptr};
+    bool stage_used[kStageRing] = {false, false, false, false};
+    int stage_next = 0;
+    PinBuf<BlockOut> bout_h;
+    std::map<uint32_t, int> arm_index;       // key: bit pattern of rate_arb
+    std::vector<float> arms_host;
+    int n_run = 0, last_nb = 0;
+    size_t lds_attr[7] = {0, 0, 0, 0, 0, 0, 0};
+    DevBuf<int16_t> pcm;                     // csdr_bank_fetch_pcm16: the converted audio of one slot
+    DevBuf<PcmJob> pcm_jobs;
+};
+
+// internal modem id: NCO + msresamp only, no modem / audio stage (the zoomed spectrum view's shift + resample, SpectrumVisualProcessor.cpp:306-379)
+#define CSDR_MODEM_FRONTEND_ONLY 100
+// csdr_bank_configure_slot without the public entry point's modem-range check (csdr_bank.hip; the zoomed view configures a front-end-only slot)
+int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *prm, const csdr_post *post);
+static inline bool is_fe_only(int modem) { return modem == CSDR_MODEM_FRONTEND_ONLY || modem == CSDR_MODEM_HOST; }

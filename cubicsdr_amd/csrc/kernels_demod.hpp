@@ -225,7 +225,7 @@ __device__ inline void fe_stage_any(int m, const float2 *__restrict__ Ein, const
     }
 }
 
-__global__ __launch_bounds__(kFeThreads, 4) void demod_frontend(
+CSDR_KERNEL __launch_bounds__(kFeThreads, 4) void demod_frontend(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
     const float2 *__restrict__ chan_base, int64_t chan_stride, int64_t total /* batch samples per channel */,
     const float *__restrict__ arms_all, const float *__restrict__ sintab) {
@@ -786,28 +786,13 @@ __device__ __forceinline__ void fes_body(
 // on every SIMD; at 84 the fourth workgroup is lost and the kernel runs 60 % longer.  1536-sample chunks with five workgroups per CU were
 // measured too: 0.97 ms against 0.68 ms, the per-chunk barrier chain does not shrink with the chunk.)
 template <int S, int CH, bool TW = false>
-__global__ __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? 6 : 4) void demod_frontend_s(
+CSDR_KERNEL __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? 6 : 4) void demod_frontend_s(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
     const float2 *__restrict__ chan_base, int64_t chan_stride, int64_t total, const float *__restrict__ arms_all, const float *__restrict__ sintab) {
     fes_body<S, CH, TW>(cfgs, dyns, slot_list[blockIdx.y], (int)blockIdx.x, (int)gridDim.x - 1, chan_base, chan_stride, total, arms_all, sintab);
 }
-// Depth 6 (AM / SSB from ~500 kS/s channels) and depth 5 (NBFM) demodulators in ONE launch: rows [0, n6) of the grid run the depth-6
-// body on list6 with P6 ranges, the rest the depth-5 body on list5 with P5 ranges (grid.x = max(P6, P5) + 1; a column past a row's own
-// range count returns at once).  As two launches on one stream the second waits for the slowest workgroup of the first; here the
-// depth-5 workgroups fill the slots the depth-6 stragglers leave.
-__global__ __launch_bounds__(kFeThreads + 64, 5) void demod_frontend_s56(
-    const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ list6, int n6, int P6,
-    const int *__restrict__ list5, int P5, const float2 *__restrict__ chan_base, int64_t chan_stride, int64_t total,
-    const float *__restrict__ arms_all, const float *__restrict__ sintab) {
-    const int y = (int)blockIdx.y, x = (int)blockIdx.x;
-    if (y < n6) {
-        if (x > P6) return;
-        fes_body<6, 2048, true>(cfgs, dyns, list6[y], x, P6, chan_base, chan_stride, total, arms_all, sintab);
-    } else {
-        if (x > P5) return;
-        fes_body<5, 2048, true>(cfgs, dyns, list5[y - n6], x, P5, chan_base, chan_stride, total, arms_all, sintab);
-    }
-}
+// (Depths 5 and 6 in ONE launch were measured in round 3: 0.749 ms against 0.440 + 0.231 ms for the two launches -- the depth-5 workgroups
+// then carry the depth-6 LDS carve and fewer of them are resident; that kernel is gone.)
 
 // ------------------------------------------------------------------------------------------------------------
 // D1i: NCO shift + INTERPOLATING msresamp_crcf (demodulator bandwidth above the channel rate: DemodulatorWorkerThread.cpp:97-101
@@ -821,7 +806,7 @@ constexpr int kFiChunk = 2048;
 constexpr int kFiArr = kFiChunk + 256;        // LDS array length (outputs of a stage + half-band reach)
 constexpr size_t kFiLds = (size_t)3 * kFiArr * sizeof(float2);
 
-__global__ __launch_bounds__(kFeThreads) void demod_frontend_interp(
+CSDR_KERNEL __launch_bounds__(kFeThreads) void demod_frontend_interp(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
     const float2 *__restrict__ chan_base, int64_t chan_stride, int64_t total /* batch samples per channel */,
     const float *__restrict__ arms_all, const float *__restrict__ sintab) {
@@ -953,7 +938,7 @@ __device__ inline float block_max_float(float v, float *lds) {
     return r;   // valid in thread 0
 }
 
-__global__ __launch_bounds__(kModemThreads) void demod_modem(
+CSDR_KERNEL __launch_bounds__(kModemThreads) void demod_modem(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
     const BlockPlan *__restrict__ plans, int NB, int cap_stream, const ModemConsts *__restrict__ mc, const float *__restrict__ sintab,
     const float *__restrict__ arms_all, int cap_cw) {
@@ -1178,7 +1163,7 @@ __global__ __launch_bounds__(kModemThreads) void demod_modem(
 // blockmaa[b] = MAA in force for block b; the end state goes to the other parity copy.  (Every audio workgroup used to replay the
 // recurrence up to its own block: quadratic in the blocks per batch.)   grid = auto-gain slots, 64 threads
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void demod_gain_scan(const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
+CSDR_KERNEL __launch_bounds__(64) void demod_gain_scan(const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
                                                       const BlockPlan *__restrict__ plans, int NB) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_max = reinterpret_cast<float *>(smem);             // [NB] block maxima (one coalesced read instead of NB dependent ones)
@@ -1214,7 +1199,7 @@ __global__ __launch_bounds__(64) void demod_gain_scan(const SlotCfg *__restrict_
 constexpr int kAudioMaxOut = 16384;        // audio samples of one block handled by one workgroup (likewise bounded by the LDS request)
 // dynamic LDS: two ping-pong arrays of `cap_out` floats, `cap_win` staged demodulator samples, 64 bytes of scratch
 
-__global__ __launch_bounds__(kModemThreads) void demod_audio_interp(
+CSDR_KERNEL __launch_bounds__(kModemThreads) void demod_audio_interp(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
     const BlockPlan *__restrict__ plans, int NB, int cap_out, int cap_win, const float *__restrict__ arms_all, int pass) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -31,7 +31,7 @@ __device__ inline float fms_freqdem(const float2 *iq, int64_t j) {
 
 // ---- fms_pre: x[j] = firhilbf_r2c_execute(d[j]) = d[j - 2m] + i sum_t hq[t] d[j - (2t + 1)]      grid = (slot, block)
 // dynamic LDS: (cap_blk + 4 m) floats
-__global__ __launch_bounds__(64) void fms_pre(const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
+CSDR_KERNEL __launch_bounds__(64) void fms_pre(const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
                                               const BlockPlan *__restrict__ plans, int NB, const ModemConsts *__restrict__ mc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_d = reinterpret_cast<float *>(smem);
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64) void fms_pre(const SlotCfg *__restrict__ cfgs, 
 
 // ---- fms_pll: the pilot band-pass and the phase-locked loop, one thread per demodulator over the whole batch.   grid = slots
 // dynamic LDS: 1024-entry sine table, one block of x (float2) and of theta (uint32)
-__global__ __launch_bounds__(kModemThreads) void fms_pll(const SlotCfg *__restrict__ cfgs, const int *__restrict__ slot_list,
+CSDR_KERNEL __launch_bounds__(kModemThreads) void fms_pll(const SlotCfg *__restrict__ cfgs, const int *__restrict__ slot_list,
                                                          const BlockPlan *__restrict__ plans, int NB, int cap_blk, const float *__restrict__ sintab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_tab = reinterpret_cast<float *>(smem);
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kModemThreads) void fms_pll(const SlotCfg *__restri
 
 // ---- fms_mix: y = (x conj w) conj w with w of the stepped oscillator, s = lower-sideband output of firhilbf_c2r_execute   grid = (slot, block)
 // dynamic LDS: 2 (cap_blk + 4 m) floats.  s goes to cfg.d (the stream the audio kernel's second pass resamples).
-__global__ __launch_bounds__(64) void fms_mix(const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
+CSDR_KERNEL __launch_bounds__(64) void fms_mix(const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
                                               const BlockPlan *__restrict__ plans, int NB, int cap_blk, const ModemConsts *__restrict__ mc,
                                               const float *__restrict__ sintab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64) void fms_mix(const SlotCfg *__restrict__ cfgs, 
 
 // ---- fms_out: left / right = FIR(0.568 (mono -/+ stereo)), interleaved; audio peak of the block      grid = (slot, block)
 // dynamic LDS: 2 (cap_au + kFmsFirMax) floats + the taps + 64 bytes
-__global__ __launch_bounds__(64) void fms_out(const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
+CSDR_KERNEL __launch_bounds__(64) void fms_out(const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
                                               const BlockPlan *__restrict__ plans, int NB, int cap_au) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int slot = slot_list[blockIdx.x], b = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;

@@ -6,7 +6,7 @@
 //   audioCallback                      src/audio/AudioThread.cpp:88-240              (per-source gain, mono fan-out, sum, peak normalisation)
 //   AudioFileWAV::writePayloadToFileStream  src/audio/AudioFileWAV.cpp:133-157       (anti-clipping scale, float -> int16)
 //   SDRThread::readStream IQ swap      src/sdr/SoapySDRThread.cpp:258-266, :300-308  (applied while the block crosses the link)
-// Host control flow (which block is current, queue rules, file headers) lives in csdr_io_api.hpp; only arithmetic is here.
+// Host control flow (which block is current, queue rules, file headers) lives in csdr_io.hip; only arithmetic is here.
 // All LDS is dynamic (`smem`).
 #pragma once
 #include "common.hpp"
@@ -52,7 +52,7 @@ struct ScopeMeta {               // per produced item
 constexpr int kScopeThreads = 256;
 
 // ---- waveform (:64-117).  grid = frames.  points[f] has room for 2 * max_n floats ------------------------------------------------
-__global__ __launch_bounds__(kScopeThreads) void scope_wave(const ScopeFrame *__restrict__ frames, int max_scope_samples, int max_n,
+CSDR_KERNEL __launch_bounds__(kScopeThreads) void scope_wave(const ScopeFrame *__restrict__ frames, int max_scope_samples, int max_n,
                                                             float *__restrict__ points, ScopeMeta *__restrict__ meta) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_red = reinterpret_cast<float *>(smem);
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kScopeThreads) void scope_wave(const ScopeFrame *__
 // ---- audio spectrum (:119-214).  ONE workgroup walks the frames in order: the averagers and trackers are recurrences over them.
 // L = fftSize <= 4096 complex points through the in-LDS transform of the main spectrum; bins [0, L/2) are kept.
 // state: ma / maa double[L/2], trk = {ceil_ma, ceil_maa, floor_ma, floor_maa}.  points[f] has room for L floats.
-__global__ __launch_bounds__(kFftThreads) void scope_spectrum(const ScopeFrame *__restrict__ frames, int nf, int L, double rate,
+CSDR_KERNEL __launch_bounds__(kFftThreads) void scope_spectrum(const ScopeFrame *__restrict__ frames, int nf, int L, double rate,
                                                              const float2 *__restrict__ tw4096, double *__restrict__ ma, double *__restrict__ maa,
                                                              double *__restrict__ trk, float *__restrict__ points, ScopeMeta *__restrict__ meta) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kFftThreads) void scope_spectrum(const ScopeFrame *
 }
 
 // ---- audio mix-down (audioCallback) ---------------------------------------------------------------------------------------
-// The host walks the sources' block queues (which block is current, when the next one is taken: csdr_io_api.hpp) and describes
+// The host walks the sources' block queues (which block is current, when the next one is taken: csdr_io.hip) and describes
 // every callback buffer as a list of PIECES: a run of one source's stream that lands on a run of the buffer's interleaved stereo
 // floats.  The kernel does the arithmetic in the callback's own order -- sources in binding order, v = sample * gain, out += v,
 // then the whole buffer times (float)(1 / peak) when the summed peaks exceed 1 -- with explicitly rounded operations, so that the
@@ -183,7 +183,7 @@ struct MixBuffer { int32_t piece0, piece1, ref0, ref1, n_sources, pad; };
 constexpr int kMixThreads = 256;
 constexpr int kMixMaxSources = 1024;       // per buffer (LDS: one double each)
 
-__global__ __launch_bounds__(kMixThreads) void audio_mix(const MixBuffer *__restrict__ bufs, const MixPiece *__restrict__ pieces,
+CSDR_KERNEL __launch_bounds__(kMixThreads) void audio_mix(const MixBuffer *__restrict__ bufs, const MixPiece *__restrict__ pieces,
                                                         const MixPeakRef *__restrict__ refs, int frames, float *__restrict__ out,
                                                         float *__restrict__ out_peak /* per buffer: the summed peak (diagnostic / PCM scale) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kMixThreads) void audio_mix(const MixBuffer *__rest
 // append `n` floats at src to a ring at write position wpos (ring of mask + 1 floats); grid-stride.  One launch moves the batch audio
 // of many demodulators: job j = blockIdx.y.
 struct RingPush { const float *src; float *ring; uint32_t mask, wpos; int32_t n; int32_t n_peaks; const void *peaks_src /* BlockOut[n_peaks] */; float *peaks_dst; uint32_t peaks_mask, peaks_wpos; };
-__global__ __launch_bounds__(256) void ring_push(const RingPush *__restrict__ jobs, int peak_stride_bytes, int peak_offset_bytes) {
+CSDR_KERNEL __launch_bounds__(256) void ring_push(const RingPush *__restrict__ jobs, int peak_stride_bytes, int peak_offset_bytes) {
     const RingPush jb = jobs[blockIdx.y];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < jb.n; i += 256 * gridDim.x) jb.ring[(jb.wpos + (uint32_t)i) & jb.mask] = jb.src[i];
     if (blockIdx.x == 0)
@@ -235,8 +235,7 @@ __global__ __launch_bounds__(256) void ring_push(const RingPush *__restrict__ jo
 
 // ---- float -> 16-bit PCM with the WAV writer's anti-clipping scale (:136): int(x * (peak < 1 ? 32767 : 32767 / peak)), low 16 bits.
 // job = one AudioThreadInput (a block): grid = (chunks, jobs)
-struct PcmJob { const float *src; int16_t *dst; int32_t n; int32_t pad; const float *peak; };
-__global__ __launch_bounds__(256) void pcm16_convert(const PcmJob *__restrict__ jobs) {
+CSDR_KERNEL __launch_bounds__(256) void pcm16_convert(const PcmJob *__restrict__ jobs) {
     const PcmJob jb = jobs[blockIdx.y];
     const float pk = *jb.peak;
     const float scale = pk < 1.0f ? 32767.0f : __fdiv_rn(32767.0f, pk);
@@ -246,7 +245,7 @@ __global__ __launch_bounds__(256) void pcm16_convert(const PcmJob *__restrict__ 
 
 // ---- ingest: host block -> HBM with I and Q exchanged on the way (the reference swaps while it copies the block together).
 // `src` is page-locked host memory mapped into the device's address space: the kernel IS the transfer over the link.
-__global__ __launch_bounds__(256) void ingest_swap(const float2 *src, float2 *dst /* may be src: exchange in place */, int64_t n) {
+CSDR_KERNEL __launch_bounds__(256) void ingest_swap(const float2 *src, float2 *dst /* may be src: exchange in place */, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)256 * gridDim.x) {
         const float2 v = src[i];
         dst[i] = make_float2(v.y, v.x);

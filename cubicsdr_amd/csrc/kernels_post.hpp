@@ -69,7 +69,7 @@ __device__ inline void dc_stage_in(const float2 *__restrict__ x, int64_t n, int6
 }
 
 // pass 1: each tile computes its end value assuming zero entering state
-__global__ __launch_bounds__(kDcThreads) void dc_tile_ends(const float2 *__restrict__ x, int64_t n, double c, d2 *__restrict__ tile_end) {
+CSDR_KERNEL __launch_bounds__(kDcThreads) void dc_tile_ends(const float2 *__restrict__ x, int64_t n, double c, d2 *__restrict__ tile_end) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *sx = reinterpret_cast<float2 *>(smem);
     d2 *sb = reinterpret_cast<d2 *>(smem + kDcTile * sizeof(float2));
@@ -119,7 +119,7 @@ __device__ inline d2 dc_scan256(d2 b, double a, d2 v_in, d2 *lds4) {
 //     v_in(n0) = c^n0 state + sum_{i < n0 / tile_len} c^(n0 - (i+1) tile_len) e_i
 // (terms older than ~80000 samples are below 1e-17 of the newest and are dropped), then the recurrence is re-run with
 // that state and y is written (in place allowed); the block holding the last sample stores the new carried state.
-__global__ __launch_bounds__(kDcThreads) void dc_apply(const float2 *x, float2 *y, int64_t n, double c, int tile_len,
+CSDR_KERNEL __launch_bounds__(kDcThreads) void dc_apply(const float2 *x, float2 *y, int64_t n, double c, int tile_len,
                                                        const d2 *__restrict__ tile_end, const d2 *__restrict__ state_in,
                                                        d2 *__restrict__ state_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -208,8 +208,6 @@ struct ChanGeom {
     int oddA;                 // 1: A is odd (>= 3) and phase 1 uses the conjugate-pair form: KA / nkA / PA then count output PAIRS (k, A - k)
     int threads;              // workgroup size (whole waves, 256..512): chosen so each phase splits evenly over the waves
     int p2;                   // 1: M = 2 A, A odd <= 63, critically sampled: chan_analyze_p2 (KA = slots per pass, nkA = passes, PA = row pitch)
-    int mx;                   // p2 only: the A-point DFTs run on the fp32 matrix pipe (chan_analyze_p2<.., true>)
-    int alt;                  // p2 only, vector form: bit 0 = s / d formed in the FIR phase + unconditional second request of a trip, bit 1 = streaming-hint stores (CSDR_CHAN_ALT, default 3; 0 = the round-2 form)
 };
 __host__ __device__ inline size_t chan_zin_floats2(const ChanGeom &g) {      // Z array, or the staged input tile if larger
     const size_t z = (size_t)g.TF * g.S, in = g.stage_in ? (size_t)(g.TF - 1) * g.hop + (size_t)kChanTaps * g.M : 0;
@@ -320,7 +318,7 @@ __device__ __forceinline__ void chan_phase2(const ChanGeom &g, float2 *s_x, cons
 
 template <int STAGE_IN, int TAPS_LDS, int OS2 /* 1: frames hop by M / 2 and may start at odd sample offsets */,
           int ODDA /* 1: phase 1 in the conjugate-pair form (its own variant: the registers it needs would cost the others occupancy) */>
-__global__ __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
+CSDR_KERNEL __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
     const float2 *__restrict__ x,        // batch input, n_frames * M samples
     const float2 *__restrict__ hist,     // 8 * M - hop samples preceding x
     float2 *__restrict__ hist_new,       // receives the last 8 * M - hop samples of (hist ++ x)
@@ -505,7 +503,7 @@ __global__ __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
 // K2 + K4 for M = 2 A with A odd (M = 6, 10, 14, 22, ... 122 = the 61.44 MS/s case, A <= 63): the Cooley-Tukey split has B = 2,
 // so the B-point pass is one butterfly and the whole transform of a frame stays inside one lane.
 // Persistent workgroups of eight waves (two per CU) walk over tiles of 64 consecutive frames; LDS holds ONE array of 64 rows
-// X[t][c] (the FIR's output; the array is sized 64 + 7 rows for the matrix-pipe form's staged stores):
+// X[t][c] (the FIR's output):
 //  window   lane = column pair (c1; c2 = 0, 1 = one float4), wave = 8 consecutive frames: the fifteen input rows those frames
 //           reach (16 A contiguous bytes per wave and row) are loaded straight from global memory into the registers the FIR
 //           reads -- requested one tile ahead, eight rows before the DFT phase of the previous tile and seven after it (all
@@ -522,34 +520,12 @@ __global__ __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
 //           offset).  k = 0 rides along as a pseudo pair with (cos, sin) = (1, 0).  No Z array, no third phase.
 // (v_pk_fma_f32 issues every ~5 clk per SIMD with >= 2 waves resident on it, 13 clk with one: measured with a micro-benchmark.)
 // ------------------------------------------------------------------------------------------------------------
-constexpr int kP2Frames = 64;          // frames per tile of the vector form (lane = frame in its DFT phase)
+constexpr int kP2Frames = 64;          // frames per tile (lane = frame in the DFT phase)
 constexpr int kP2Waves = 8;
 constexpr int kP2EarlyRows = 8;          // rows of the next tile's FIR window requested before the DFT phase (the first frame's whole window); the other seven after it
 constexpr int kP2Threads = 64 * kP2Waves;
 constexpr int kP2MaxA = 63;
-// tile geometry as a function of the frames per tile TF (64, or 32 for the matrix-pipe form): eight frames per wave in the FIR phase
-template <int TF> struct P2Tile {
-    static constexpr int waves = TF / kChanTaps, threads = 64 * waves;
-    static constexpr int ctiles = TF / 16;                                                  // 16-frame column tiles of the matrix-pipe form
-};
-__host__ __device__ inline size_t chan_p2_lds_bytes(int M, int TF = kP2Frames) { return (size_t)(TF + kChanTaps - 1) * M * sizeof(float2) + 4 * 2 * sizeof(double); }
-// matrix-pipe form: K steps of 4 terms cover n = 0 .. 31 (H <= 31), two row tiles of 16 outputs cover k = 0 .. 31
-constexpr int kMxSteps = 8;
-// coefficient fragments, [2 (cos | sin)][2 row tiles][kMxSteps][64 lanes]: lane l of step J holds the coefficient of output
-// k = 16 rt + (l & 15) and term n = 4 J + (l >> 4) -- the A operand of v_mfma_f32_16x16x4_f32 (A[i = l & 15][k = l >> 4])
-__host__ inline void chan_mx_table(int A, float *tab /* [2][2][kMxSteps][64] */) {
-    const int H = (A - 1) / 2;
-    for (int kind = 0; kind < 2; ++kind) for (int rt = 0; rt < 2; ++rt) for (int J = 0; J < kMxSteps; ++J) for (int l = 0; l < 64; ++l) {
-        const int k = 16 * rt + (l & 15), n = 4 * J + (l >> 4);
-        float v = 0.f;
-        if (k <= H && n <= H) {
-            const double ang = 2.0 * M_PI * (double)(((long long)n * k) % A) / (double)A;      // the same expression as the vector form's (cos, sin) rows
-            if (kind == 0) v = n == 0 ? 1.0f : (float)std::cos(ang);
-            else v = n == 0 ? 0.0f : (float)std::sin(ang);
-        }
-        tab[(((size_t)kind * 2 + rt) * kMxSteps + J) * 64 + l] = v;
-    }
-}
+__host__ __device__ inline size_t chan_p2_lds_bytes(int M) { return (size_t)kP2Frames * M * sizeof(float2); }
 // store to a wave-uniform row base plus a 32-bit per-lane byte offset (scalar-base addressing: no 64-bit address arithmetic per lane)
 __device__ __forceinline__ void store_row(float2 *row_base, unsigned byte_off, float2 v) {
     *reinterpret_cast<float2 *>(reinterpret_cast<char *>(row_base) + byte_off) = v;
@@ -564,13 +540,11 @@ __device__ __forceinline__ void store_row_nt(float2 *row_base, unsigned byte_off
     store_row(row_base, byte_off, v);
 #endif
 }
-// one term of the conjugate-pair sums for KP slots and both c2: s = x_c + x_{A-c}, d = x_c - x_{A-c}; e = (cos, sin) rows
-// (SD: the FIR phase already left s at row c and d at row A - c)
-template <int KP, bool SD = false>
-__device__ __forceinline__ void chan_p2_term(const float4 a, const float4 b, const float2 (&e)[KP], float2 (&P0)[KP], float2 (&Q0)[KP],
+// one term of the conjugate-pair sums for KP slots and both c2: s = x_c + x_{A-c} (the FIR phase left it at row c), d = x_c - x_{A-c}
+// (at row A - c); e = (cos, sin) rows
+template <int KP>
+__device__ __forceinline__ void chan_p2_term(const float4 s, const float4 d, const float2 (&e)[KP], float2 (&P0)[KP], float2 (&Q0)[KP],
                                              float2 (&P1)[KP], float2 (&Q1)[KP]) {
-    const float4 s = SD ? a : make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-    const float4 d = SD ? b : make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
 #pragma unroll
     for (int j = 0; j < KP; ++j) {
         P0[j].x = fmaf(s.x, e[j].x, P0[j].x); P0[j].y = fmaf(s.y, e[j].x, P0[j].y);
@@ -581,11 +555,10 @@ __device__ __forceinline__ void chan_p2_term(const float4 a, const float4 b, con
 }
 
 // the conjugate-pair sums of one pass (KP slots, both c2) over the terms c = 1 .. H.  Software pipeline, two terms per trip with two
-// register sets: the rows and the (cos, sin) row of the next term are requested before the current one is accumulated.
-// UNC: the second request of a trip is unconditional (the last trip re-reads term H) instead of guarded; SD: rows hold s / d already.
-// (CSDR_CHAN_ALT=0 selects <false, false>, the round-2 form; all four combinations were measured: a four-way switch costs one more
-// spilled float4 in the tile loop.)
-template <int KP, bool SD, bool UNC>
+// register sets: the rows and the (cos, sin) row of the next term are requested before the current one is accumulated; the second request
+// of a trip is unconditional (the last trip re-reads term H).  (Round 3 measured the guarded request and s / d formed here, in every wave's
+// passes, as well: 3 % slower before the window went straight into registers, bit-identical results; those forms are gone.)
+template <int KP>
 __device__ __forceinline__ void chan_p2_accumulate(const float4 *row, const int A, const int H, const float2 *__restrict__ w, const int PA,
                                                    float2 (&P0)[KP], float2 (&Q0)[KP], float2 (&P1)[KP], float2 (&Q1)[KP]) {
     float4 a = row[1], b = row[A - 1], a2 = a, b2 = b;
@@ -599,37 +572,28 @@ __device__ __forceinline__ void chan_p2_accumulate(const float4 *row, const int 
 #pragma unroll
         for (int j = 0; j < KP; ++j) eB[j] = w[j];
         sched_fence();
-        chan_p2_term<KP, SD>(a, b, eA, P0, Q0, P1, Q1);
+        chan_p2_term<KP>(a, b, eA, P0, Q0, P1, Q1);
         sched_fence();
-        if (UNC) {
-            const int cn = min(c + 2, H);
-            w += (c + 2 <= H) ? PA : 0;
-            a = row[cn]; b = row[A - cn];
+        const int cn = min(c + 2, H);
+        w += (c + 2 <= H) ? PA : 0;
+        a = row[cn]; b = row[A - cn];
 #pragma unroll
-            for (int j = 0; j < KP; ++j) eA[j] = w[j];
-        } else {
-            w += PA;
-            if (c + 2 <= H) {
-                a = row[c + 2]; b = row[A - c - 2];
-#pragma unroll
-                for (int j = 0; j < KP; ++j) eA[j] = w[j];
-            }
-        }
+        for (int j = 0; j < KP; ++j) eA[j] = w[j];
         sched_fence();
-        chan_p2_term<KP, SD>(a2, b2, eB, P0, Q0, P1, Q1);
+        chan_p2_term<KP>(a2, b2, eB, P0, Q0, P1, Q1);
         sched_fence();
     }
-    if (c <= H) chan_p2_term<KP, SD>(a, b, eA, P0, Q0, P1, Q1);        // H odd: the last term
+    if (c <= H) chan_p2_term<KP>(a, b, eA, P0, Q0, P1, Q1);        // H odd: the last term
 }
 
 // the window of one wave's FIR range, straight into registers: the 8 frames [ta, ta + 8) of tile `tile` need the 15 input rows
 // f0 + ta - 7 .. f0 + ta + 7; lane = column pair, a row is 16 A contiguous bytes per wave.  Rows in front of the batch come from the carried
 // history, rows past its end are zero (their frames are never stored).  The row index and the source select are wave-uniform: fifteen
 // plain loads under one lane mask, nothing between them.
-template <int TF, int J0 = 0, int J1 = 2 * kChanTaps - 1>
+template <int J0 = 0, int J1 = 2 * kChanTaps - 1>
 __device__ __forceinline__ void chan_p2_request_window(const float2 *__restrict__ x, const float2 *__restrict__ hist, int M, int A, int64_t n_frames,
                                                        int64_t tile, bool valid, int wave, int lane, float4 (&win)[2 * kChanTaps - 1]) {
-    const int64_t r0 = tile * TF + (int64_t)wave * kChanTaps - (kChanTaps - 1);      // input row of win[0]
+    const int64_t r0 = tile * kP2Frames + (int64_t)wave * kChanTaps - (kChanTaps - 1);      // input row of win[0]
     const bool col = lane < A;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -643,22 +607,17 @@ __device__ __forceinline__ void chan_p2_request_window(const float2 *__restrict_
     }
 }
 
-// MX = true: the DFT phase runs on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32), see "DFT on the matrix pipe" below; `cs` then is
-// the coefficient-fragment table of chan_mx_table().
-template <int KP, bool MX = false, int TF = 64>
-__global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
+template <int KP>
+CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
     const float2 *__restrict__ x, const float2 *__restrict__ hist, float2 *__restrict__ hist_new,
     const float *__restrict__ tapsT,      // [8][M]
     const float2 *__restrict__ cs,        // [(A-1)/2][PA]: (cos, sin)(2 pi k(q) c / A) at [(c - 1) PA + q]; slot q: k = q + 1 (q < H), k = 0 (q == H), else (0, 0)
     const float2 *__restrict__ twM,       // [A][2]: exp(-j 2 pi k1 c2 / M) at [2 k1 + c2]
     const int *__restrict__ active, ChanGeom g, int64_t n_frames,
     float2 *__restrict__ out, int64_t out_stride, d2 *__restrict__ dc_ends, double dc_c) {
-    static_assert(TF == 64 || (MX && TF == 32), "the vector form's DFT phase has one frame per lane: 64-frame tiles");
-    constexpr int kP2Frames = TF, kP2Waves = P2Tile<TF>::waves, kP2Threads = P2Tile<TF>::threads, kCt = P2Tile<TF>::ctiles;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4 *rows = reinterpret_cast<float4 *>(smem);          // row r (input row f0 + r - 7, later X[r]) at rows + r A
+    float4 *rows = reinterpret_cast<float4 *>(smem);          // X[t] at rows + t A
     const int M = g.M, A = g.A, H = (A - 1) >> 1;
-    d2 *dc_part = reinterpret_cast<d2 *>(smem + (size_t)(kP2Frames + kChanTaps - 1) * M * sizeof(float2));      // [4] per-column-tile partial sums (MX)
     const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = wave_uniform(tid0 >> 6);
     const int64_t n_tiles = (n_frames + kP2Frames - 1) / kP2Frames;
     const int64_t Hs = (int64_t)(kChanTaps - 1) * M;          // samples in front of a tile's own first row = carried history length
@@ -671,24 +630,9 @@ __global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
             hist_new[j] = gsrc >= 0 ? x[gsrc] : hist[gsrc + Hs];
         }
     }
-    // MX: this wave's coefficient fragments stay in registers for the whole launch (persistent workgroup)
-    float mxc[kMxSteps], mxs[kMxSteps];
-    float2 mx_wk[4], mx_wn[4];                                  // W_M^k of this lane's four outputs k and of their partners A - k
-    int mx_on[4];                                               // consumer flags of rows k, k + A, A - k, 2 A - k (bits 0..3)
-    if constexpr (MX) {
-        const float *tab = reinterpret_cast<const float *>(cs) + (size_t)(wave / kCt) * kMxSteps * 64 + lane0;
-#pragma unroll
-        for (int J = 0; J < kMxSteps; ++J) { mxc[J] = tab[J * 64]; mxs[J] = tab[(2 * kMxSteps + J) * 64]; }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = min(16 * (wave / kCt) + 4 * (lane0 >> 4) + r, H), kn = k ? A - k : 0;
-            mx_wk[r] = twM[2 * k + 1]; mx_wn[r] = twM[2 * kn + 1];
-            mx_on[r] = (active[k] ? 1 : 0) | (active[k + A] ? 2 : 0) | (active[kn] ? 4 : 0) | (active[kn + A] ? 8 : 0);
-        }
-    }
     float4 win[2 * kChanTaps - 1];                              // this wave's FIR window of the tile: input rows f0 + ta - 7 .. f0 + ta + 7
     int64_t tile = blockIdx.x;
-    chan_p2_request_window<TF>(x, hist, M, A, n_frames, tile, tile < n_tiles, wave, lane0, win);
+    chan_p2_request_window<>(x, hist, M, A, n_frames, tile, tile < n_tiles, wave, lane0, win);
     for (; tile < n_tiles; tile += gridDim.x) {
         const int64_t f0 = tile * kP2Frames;
         const int nf = (int)min((int64_t)kP2Frames, n_frames - f0);
@@ -708,7 +652,6 @@ __global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
             static_assert(kRange == kChanTaps, "a wave's range is eight frames: its window is fifteen rows");
             const int ta = wave * kRange;
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            const bool sd = !MX && (g.alt & 1) != 0;
 #pragma unroll
             for (int i = 0; i < kRange; ++i) {
                 float4 acc = z4;
@@ -718,7 +661,7 @@ __global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
                     acc.x = fmaf(h[n].x, v.x, acc.x); acc.y = fmaf(h[n].x, v.y, acc.y);
                     acc.z = fmaf(h[n].y, v.z, acc.z); acc.w = fmaf(h[n].y, v.w, acc.w);
                 }
-                if (sd) {                                     // columns c and A - c trade: s_c = x_c + x_{A-c} at row c, d_c = x_c - x_{A-c} at row A - c
+                {                                             // columns c and A - c trade: s_c = x_c + x_{A-c} at row c, d_c = x_c - x_{A-c} at row A - c
                     // (one component at a time: a float4 of partner values at once is one more spilled float4 in this phase)
                     const int pl = (lane >= 1 && lane < A) ? A - lane : lane;
                     const bool is_s = lane >= 1 && lane <= H, is_d = lane > H && lane < A;
@@ -734,99 +677,8 @@ __global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
         }
         lds_barrier();
         // the next tile's window is on its way while this one is transformed (into the registers the FIR has just finished with)
-        chan_p2_request_window<TF, 0, kP2EarlyRows>(x, hist, M, A, n_frames, tile + gridDim.x, tile + gridDim.x < n_tiles, wave, lane, win);
-        if constexpr (MX) {
-        // ---- DFT on the matrix pipe.  The conjugate-pair sums are two real matrix products per component:
-        //        P[k][t] = sum_n Cos[k][n] s_n[t]      Q[k][t] = sum_n Sin[k][n] d_n[t]        k, n = 0 .. H   (s_0 = x_0, Cos[k][0] = 1, Sin[k][0] = 0)
-        //      for the four components (c2 = 0 / 1) x (re / im) of s and d: eight products, tiled 16 (k) x 16 (t) x 4 (n) on
-        //      v_mfma_f32_16x16x4_f32.  Wave = (row tile rt = wave >> 2: k = 16 rt .. 16 rt + 15, column tile ct = wave & 3: frames
-        //      16 ct .. 16 ct + 15); lane (q = lane >> 4, j = lane & 15) feeds term n = 4 J + q of frame t = 16 ct + j in step J -- the
-        //      float4 sums / differences of ONE ds_read_b128 pair are the B operands of all eight products -- and receives outputs
-        //      k = 16 rt + 4 q + r (r = 0..3) of that frame for all eight, so the radix-2 butterfly and the stores stay in-lane.
-        //      An MFMA is a k-ordered fmaf chain: the accumulation order (n ascending, starting from x_0) is the VALU form's, and so
-        //      are the results, bit for bit.  64 MFMAs (2048 matrix-pipe cycles) per wave and tile against ~70 VALU instructions.
-        const int q = lane >> 4, t = 16 * (wave % kCt) + (lane & 15), rt = wave / kCt;
-        const float4 *row = rows + t * A;
-        const bool tv = t < nf;
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        csdr_f32x4 P0r = {0.f, 0.f, 0.f, 0.f}, P0i = P0r, P1r = P0r, P1i = P0r, Q0r = P0r, Q0i = P0r, Q1r = P0r, Q1i = P0r;
-        float4 a = q <= H ? row[q] : z4, b = (q >= 1 && q <= H) ? row[A - q] : z4;     // step 0: n = q
-#pragma unroll
-        for (int J = 0; J < kMxSteps; ++J) {
-            float4 a2 = z4, b2 = z4;
-            if (J + 1 < kMxSteps) {                                  // the next step's rows are requested ahead of this step's products
-                const int n2 = 4 * (J + 1) + q;
-                if (n2 <= H) { a2 = row[n2]; b2 = row[A - n2]; }
-            }
-            const float4 sv = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-            const float4 dv = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
-            P0r = csdr_mfma16(mxc[J], sv.x, P0r); P0i = csdr_mfma16(mxc[J], sv.y, P0i);
-            P1r = csdr_mfma16(mxc[J], sv.z, P1r); P1i = csdr_mfma16(mxc[J], sv.w, P1i);
-            Q0r = csdr_mfma16(mxs[J], dv.x, Q0r); Q0i = csdr_mfma16(mxs[J], dv.y, Q0i);
-            Q1r = csdr_mfma16(mxs[J], dv.z, Q1r); Q1i = csdr_mfma16(mxs[J], dv.w, Q1i);
-            a = a2; b = b2;
-        }
-        // Epilogue.  The radix-2 butterfly is in-lane; the stores are not lane-friendly as they stand: a lane group holds 16 frames of
-        // FOUR different channel rows, i.e. 128-byte pieces 8 MB apart.  g.mx == 2 (default) passes the tile through the (now free)
-        // row array so that every store instruction writes 512 contiguous bytes of ONE channel row, as the vector form does;
-        // g.mx == 1 stores straight from the accumulators (measured slower: scattered partial rows).
-        const bool staged = (g.mx & 1) == 0;                         // mx = 2 / 4
-        if (staged) lds_barrier();                                  // every wave has read its last input rows: the array is free
-        float2 *stage = reinterpret_cast<float2 *>(rows);           // [k][64 frames]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = 16 * rt + 4 * q + r;
-            if (k <= H) {
-                const int kn = A - k;
-                const float2 P0 = make_float2(P0r[r], P0i[r]), Q0 = make_float2(Q0r[r], Q0i[r]), P1 = make_float2(P1r[r], P1i[r]), Q1 = make_float2(Q1r[r], Q1i[r]);
-                const float2 wk = mx_wk[r], wn = mx_wn[r];
-                const float2 z0k = make_float2(P0.x + Q0.y, P0.y - Q0.x), z0n = make_float2(P0.x - Q0.y, P0.y + Q0.x);
-                const float2 u = cmul(make_float2(P1.x + Q1.y, P1.y - Q1.x), wk);
-                const float2 v = cmul(make_float2(P1.x - Q1.y, P1.y + Q1.x), wn);
-                const float2 y0 = make_float2(z0k.x + u.x, z0k.y + u.y), y1 = make_float2(z0k.x - u.x, z0k.y - u.y);
-                const float2 y2 = make_float2(z0n.x + v.x, z0n.y + v.y), y3 = make_float2(z0n.x - v.x, z0n.y - v.y);
-                if (staged) {
-                    stage[k * kP2Frames + t] = y0; stage[(k + A) * kP2Frames + t] = y1;
-                    if (k > 0) { stage[kn * kP2Frames + t] = y2; stage[(kn + A) * kP2Frames + t] = y3; }      // k = 0 has no conjugate partner
-                } else if (tv) {
-                    float2 *ob = out + f0 + t;
-                    const int on = mx_on[r];
-                    if (on & 1) ob[(int64_t)k * out_stride] = y0;
-                    if (on & 2) ob[(int64_t)(k + A) * out_stride] = y1;
-                    if (k > 0) {
-                        if (on & 4) ob[(int64_t)kn * out_stride] = y2;
-                        if (on & 8) ob[(int64_t)(kn + A) * out_stride] = y3;
-                    }
-                }
-            }
-        }
-        if (staged) {
-            lds_barrier();
-            // rows wave, wave + 8, ...: lane = frame, one 512-byte run per row (scalar row base + lane offset)
-            float2 *ob = out + f0;
-            constexpr int kRowsPer = 64 / TF;                         // channel rows one store instruction covers (lanes run along the frames)
-            const int tl = lane % TF, kofs = lane / TF;
-            const unsigned tb = (unsigned)tl * (unsigned)sizeof(float2);
-            const bool lv = tl < nf;
-            for (int k0 = wave * kRowsPer; k0 < M; k0 += kP2Waves * kRowsPer) {
-                const int k = k0 + kofs;
-                if (k < M) {
-                    const float2 yv = stage[k * kP2Frames + tl];
-                    if (active[k] && lv) store_row(ob + (int64_t)k * out_stride, tb, yv);
-                }
-            }
-        }
-        if (dc_ends && rt == 0) {
-            // v_end = sum_t c^(nf-1-t) y0[t] over the tile (the DC blocker's state after it from a zero state, iirfilt :375): channel 0
-            // sits in r = 0 of the lanes with q = 0; each column tile contributes a partial sum, added up after the tile's last barrier
-            const bool mine = q == 0 && tv;
-            const double wgt = mine ? dc_pow(dc_c, nf - 1 - t) : 0.0;
-            double vx = mine ? wgt * (double)(P0r[0] + P1r[0]) : 0.0, vy = mine ? wgt * (double)(P0i[0] + P1i[0]) : 0.0;
-            for (int s2 = 8; s2 > 0; s2 >>= 1) { vx += __shfl_down(vx, s2, 64); vy += __shfl_down(vy, s2, 64); }
-            if (lane == 0) dc_part[wave % kCt] = d2{vx, vy};
-        }
-        } else {
-        // ---- DFT: lane = frame t; wave = pass of KP output-pair slots
+        chan_p2_request_window<0, kP2EarlyRows>(x, hist, M, A, n_frames, tile + gridDim.x, tile + gridDim.x < n_tiles, wave, lane, win);
+        {   // ---- DFT: lane = frame t; wave = pass of KP output-pair slots
             const int t = lane;
             const float4 *row = rows + t * A;
             const bool tv = t < nf;
@@ -834,16 +686,15 @@ __global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
                 const int q0 = p * KP;
                 const float4 x0 = row[0];
                 float2 P0[KP], Q0[KP], P1[KP], Q1[KP];
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < KP; ++j) {
                     P0[j] = make_float2(x0.x, x0.y); P1[j] = make_float2(x0.z, x0.w);
                     Q0[j] = make_float2(0.f, 0.f); Q1[j] = make_float2(0.f, 0.f);
                 }
-                if (g.alt & 1) chan_p2_accumulate<KP, true, true>(row, A, H, cs + q0, g.PA, P0, Q0, P1, Q1);
-                else chan_p2_accumulate<KP, false, false>(row, A, H, cs + q0, g.PA, P0, Q0, P1, Q1);      // the round-2 form (A/B, bit-identity test)
+                chan_p2_accumulate<KP>(row, A, H, cs + q0, g.PA, P0, Q0, P1, Q1);
                 float2 *ob = out + f0;                                  // wave-uniform row bases + a 32-bit lane offset: scalar-base stores
                 const unsigned tb = (unsigned)t * (unsigned)sizeof(float2);   // byte offset of this lane inside a channel row
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < KP; ++j) {
                     const int q = q0 + j;                               // wave-uniform
                     if (q < H) {
@@ -853,16 +704,11 @@ __global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
                         const float2 z0k = make_float2(P0[j].x + Q0[j].y, P0[j].y - Q0[j].x), z0n = make_float2(P0[j].x - Q0[j].y, P0[j].y + Q0[j].x);
                         const float2 u = cmul(make_float2(P1[j].x + Q1[j].y, P1[j].y - Q1[j].x), wk);
                         const float2 v = cmul(make_float2(P1[j].x - Q1[j].y, P1[j].y + Q1[j].x), wn);
-                        if (tv && (g.alt & 2)) {
+                        if (tv) {                                       // streaming-hint stores: nothing in this kernel reads the rows again, they stay out of the way of the window rows two waves share (12.6 -> 10.5 B/sample fetched on C3)
                             if (on0) store_row_nt(ob + (int64_t)k * out_stride, tb, make_float2(z0k.x + u.x, z0k.y + u.y));
                             if (on1) store_row_nt(ob + (int64_t)(k + A) * out_stride, tb, make_float2(z0k.x - u.x, z0k.y - u.y));
                             if (on2) store_row_nt(ob + (int64_t)kn * out_stride, tb, make_float2(z0n.x + v.x, z0n.y + v.y));
                             if (on3) store_row_nt(ob + (int64_t)(kn + A) * out_stride, tb, make_float2(z0n.x - v.x, z0n.y - v.y));
-                        } else if (tv) {
-                            if (on0) store_row(ob + (int64_t)k * out_stride, tb, make_float2(z0k.x + u.x, z0k.y + u.y));
-                            if (on1) store_row(ob + (int64_t)(k + A) * out_stride, tb, make_float2(z0k.x - u.x, z0k.y - u.y));
-                            if (on2) store_row(ob + (int64_t)kn * out_stride, tb, make_float2(z0n.x + v.x, z0n.y + v.y));
-                            if (on3) store_row(ob + (int64_t)(kn + A) * out_stride, tb, make_float2(z0n.x - v.x, z0n.y - v.y));
                         }
                     } else if (q == H) {                                // k = 0: P = sum of the column, Q = 0
                         const float2 y0 = make_float2(P0[j].x + P1[j].x, P0[j].y + P1[j].y);
@@ -882,15 +728,8 @@ __global__ __launch_bounds__(P2Tile<TF>::threads, 4) void chan_analyze_p2(
             }
         }
         // the rest of the next window (the transform above leaves no room for all fifteen rows: they would be spilled -- which waits for them)
-        chan_p2_request_window<TF, kP2EarlyRows, 2 * kChanTaps - 1>(x, hist, M, A, n_frames, tile + gridDim.x, tile + gridDim.x < n_tiles, wave, lane0, win);
+        chan_p2_request_window<kP2EarlyRows, 2 * kChanTaps - 1>(x, hist, M, A, n_frames, tile + gridDim.x, tile + gridDim.x < n_tiles, wave, lane0, win);
         lds_barrier();                                      // the rows are free for the next tile
-        if constexpr (MX) {
-            if (dc_ends && tid0 == 0) {
-                d2 v = dc_part[0];
-                for (int i = 1; i < kCt; ++i) { v.x += dc_part[i].x; v.y += dc_part[i].y; }
-                dc_ends[tile] = v;
-            }
-        }
     }
 }
 

@@ -216,7 +216,7 @@ __device__ inline float cabs_f(float2 v) { return sqrtf(v.x * v.x + v.y * v.y); 
 // ---- radix pass: R-point column DFTs over stride Lr = L / R, times W_L^(k c); grid = (Lr / (256 COLS), sequences) --
 // W_L^q = exp(-2 pi i q tw_scale / N) is looked up in the split tables of the full transform.
 template <int R, int COLS>
-__global__ __launch_bounds__(kFftThreads) void spec_fft_radix(FrameSrc fs, int L, unsigned tw_scale,
+CSDR_KERNEL __launch_bounds__(kFftThreads) void spec_fft_radix(FrameSrc fs, int L, unsigned tw_scale,
                                                               const float2 *__restrict__ tw_hi, const float2 *__restrict__ tw_lo,
                                                               float2 *dst) {
     const int Lr = L / R;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(kFftThreads) void spec_fft_radix(FrameSrc fs, int L
 // ---- 4096-point row FFTs + magnitude.  grid = (rows = Ra Rb, frames) ---------------------------------------------
 // row r = k1 Rb + k2 of frame f in `fs` ([f][r][4096]; the frame itself when there is a single row) holds the bins
 // k = k1 + Ra (k2 + Rb k3); |X| is stored as mag[f][r][k3] (float), i.e. natural bin order when there is one row.
-__global__ __launch_bounds__(kFftThreads) void spec_fft_rows4096(FrameSrc fs, SpecGeom g, const float2 *__restrict__ tw4096,
+CSDR_KERNEL __launch_bounds__(kFftThreads) void spec_fft_rows4096(FrameSrc fs, SpecGeom g, const float2 *__restrict__ tw4096,
                                                                  float *__restrict__ mag, float2 *__restrict__ raw_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *lds = reinterpret_cast<float2 *>(smem);
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kFftThreads) void spec_fft_rows4096(FrameSrc fs, Sp
 }
 
 // ---- small transforms (N <= 2048): one frame per workgroup, Stockham through LDS.  grid = (1, frames) ----------
-__global__ __launch_bounds__(kFftThreads) void spec_fft_small(FrameSrc fs, int N, const float2 *__restrict__ tw4096,
+CSDR_KERNEL __launch_bounds__(kFftThreads) void spec_fft_small(FrameSrc fs, int N, const float2 *__restrict__ tw4096,
                                                               float *__restrict__ mag, float2 *__restrict__ raw_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *sa = reinterpret_cast<float2 *>(smem), *sb = sa + N;
@@ -393,7 +393,7 @@ __host__ __device__ constexpr size_t avg_lds_bytes(int ng) {      // dynamic LDS
     return (size_t)(ng + 1) * kAvgLanes * 4 * sizeof(double) + (size_t)ng * 2 * kAvgExtFrames * kAvgLanes * sizeof(float) + 16;
 }
 
-__global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restrict__ mag, int nf, SpecGeom g, double rate,
+CSDR_KERNEL __launch_bounds__(kAvgThreads) void spec_average(const float *__restrict__ mag, int nf, SpecGeom g, double rate,
                                                             double *__restrict__ ma, double *__restrict__ maa,
                                                             float *__restrict__ pairsum /* pair order */, float *__restrict__ first_b,
                                                             float2 *__restrict__ ext_w,
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(kAvgThreads) void spec_average(const float *__restr
 }
 
 // ---- per-frame extrema over the tiles of spec_average.  grid = frames, 256 threads -------------------------------
-__global__ __launch_bounds__(256) void spec_extrema(const float2 *__restrict__ ext_w, int ntiles, float2 *__restrict__ ext) {
+CSDR_KERNEL __launch_bounds__(256) void spec_extrema(const float2 *__restrict__ ext_w, int ntiles, float2 *__restrict__ ext) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *s_r = reinterpret_cast<float2 *>(smem);
     const int f = blockIdx.x, tid = threadIdx.x;
@@ -589,7 +589,7 @@ struct SpecPeakScalars { double ceil_peak, floor_peak; };
 
 // ---- peak hold (SpectrumVisualProcessor.cpp:247-273, :506-510, :523-530) --------------------------------------------
 // reset: fft_result_peak[i] = fft_floor_maa, fft_ceil_peak = fft_floor_maa, fft_floor_peak = fft_ceil_maa (:266-272)
-__global__ __launch_bounds__(256) void spec_peak_reset(const SpecScalars *__restrict__ st, double *__restrict__ peak, int n2f,
+CSDR_KERNEL __launch_bounds__(256) void spec_peak_reset(const SpecScalars *__restrict__ st, double *__restrict__ peak, int n2f,
                                                        SpecPeakScalars *__restrict__ pk) {
     const SpecScalars s = *st;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n2f; i += 256 * gridDim.x) peak[i] = s.floor_maa;
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void spec_peak_reset(const SpecScalars *__rest
 }
 // running maximum of the averaged bins over the frames [pk_from, nf) of a batch, one thread per display point (both of
 // its bins); peaksum[f][x] = peak[2x] + peak[2x+1] after frame f, peak_b[f] = the second bin of point 0 (:546-556)
-__global__ __launch_bounds__(256) void spec_peak_track(const float2 *__restrict__ maaf, int nf, int pk_from, int F,
+CSDR_KERNEL __launch_bounds__(256) void spec_peak_track(const float2 *__restrict__ maaf, int nf, int pk_from, int F,
                                                        double *__restrict__ peak, float *__restrict__ peaksum, float *__restrict__ peak_b,
                                                        float2 *__restrict__ peakf /* zoomed view: both held bins per frame, else null */) {
     const int x = blockIdx.x * 256 + threadIdx.x;
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256) void spec_peak_track(const float2 *__restrict_
 // zoomed view: the averagers follow a retune or a zoom step (SpectrumVisualProcessor.cpp:316-331, :454-492).  Display-order
 // bin i lives at [(i & 1) F + (i >> 1)] (pair layout).  mode 0/1: memmove left / right by n bins (the vacated end keeps its
 // old values); 2: zoom in, dst[i] = src[N/4 + i/2]; 3: zoom out, dst[i] = src[(i - N/4) 2] inside the middle half, else 0.
-__global__ __launch_bounds__(256) void spec_avg_remap(const double *__restrict__ ma, const double *__restrict__ maa,
+CSDR_KERNEL __launch_bounds__(256) void spec_avg_remap(const double *__restrict__ ma, const double *__restrict__ maa,
                                                       double *__restrict__ ma_o, double *__restrict__ maa_o, int N, int mode, int n) {
     const int F = N >> 1;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += 256 * gridDim.x) {
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void spec_avg_remap(const double *__restrict__
 
 // the four trackers frame by frame (the reference's statements, :513-521) and their held extremes (:523-530) for the
 // frames [pk_from, nf): pfo[f] = {fft_ceil_peak, fft_floor_peak} after frame f.  One thread: nf short double recurrences.
-__global__ void spec_peak_trackers(const float2 *__restrict__ ext, int nf, int pk_from, const SpecScalars *__restrict__ st_in,
+CSDR_KERNEL void spec_peak_trackers(const float2 *__restrict__ ext, int nf, int pk_from, const SpecScalars *__restrict__ st_in,
                                    SpecPeakScalars *__restrict__ pk, SpecFrameOut *__restrict__ pfo) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     SpecScalars s = *st_in;
@@ -672,7 +672,7 @@ struct SpecFrameScal { double pc, pf, fl; };  // point_ceil, point_floor, fft_fl
 //                maa_f = a^(f+1) maa_in + b (f+1) a^(f+1) ma_in + b^2 sum_i (f-i+1) a^(f-i) c_i      (maa uses the NEW ma)
 // as parallel weighted sums over i <= f (double; equal to the serial loop to ~1e-15 relative); the last frame publishes the end
 // state (ping-pong copy).
-__global__ __launch_bounds__(kDispThreads) void spec_trackers(const float2 *__restrict__ ext, int nf, const SpecScalars *__restrict__ st_in,
+CSDR_KERNEL __launch_bounds__(kDispThreads) void spec_trackers(const float2 *__restrict__ ext, int nf, const SpecScalars *__restrict__ st_in,
                                                               SpecScalars *__restrict__ st_out, SpecFrameOut *__restrict__ fo,
                                                               SpecFrameScal *__restrict__ fsc, int pk_from, const SpecFrameOut *__restrict__ pfo) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(kDispThreads) void spec_trackers(const float2 *__re
 // cancelled (log1p_fast: a few float ulps also when the dynamic range is tiny), their ratio needs no base conversion.
 // grid = (column blocks, frames): the transposing path takes kDispTpi tiles per workgroup (grid.x = F / kDispTile / kDispTpi or fewer: it
 // strides), the plain path 2 x 256 points per step.
-__global__ __launch_bounds__(kDispThreads) void spec_display(const float *__restrict__ pairsum /* pair order: spec_pair_index */, const float *__restrict__ first_b,
+CSDR_KERNEL __launch_bounds__(kDispThreads) void spec_display(const float *__restrict__ pairsum /* pair order: spec_pair_index */, const float *__restrict__ first_b,
                                                              const SpecFrameScal *__restrict__ fsc, SpecGeom g, float sf, float *__restrict__ points,
                                                              int pk_from, const float *__restrict__ peaksum,
                                                              const float *__restrict__ peak_b, float *__restrict__ hold_points,

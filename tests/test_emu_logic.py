@@ -228,29 +228,3 @@ def test_emu_ingest_shared_device_buffer(ctx):
 
 def test_emu_spectrum_nan_repairs_frame_by_frame(ctx):
     G.test_spectrum_nan_samples_recover_frame_by_frame(ctx, 2048, (40, 23), ((5, 100), (38, 7), (41, 3000)))
-
-
-def test_emu_channelizer_vector_forms_bit_identical(ctx):
-    """the vector form's request / trade variants (CSDR_CHAN_ALT 0 / 1: s / d formed per wave or once in the FIR phase) give the same bits"""
-    from cubicsdr_amd.engine import SDRPost
-    from tests.util import synth_iq
-    M, frames = 122, 150
-    fs, center, block = M * 50000, 100000000, M * frames
-    x = synth_iq(2 * block, fs, center, [("NBFM", center + 123456)], seed=5)
-    outs = []
-    saved = os.environ.get("CSDR_CHAN_ALT")
-    try:
-        for alt in ("0", "1", "3"):
-            os.environ["CSDR_CHAN_ALT"] = alt
-            p = SDRPost(ctx, fs, M, block, max_blocks=2)
-            p.execute(x, 2, block, center)
-            outs.append([p.read_channel(ch) for ch in range(M)])
-            p.close()
-    finally:
-        if saved is None:
-            os.environ.pop("CSDR_CHAN_ALT", None)
-        else:
-            os.environ["CSDR_CHAN_ALT"] = saved
-    for v in range(1, len(outs)):
-        for ch, (a, b) in enumerate(zip(outs[0], outs[v])):
-            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (v, ch)

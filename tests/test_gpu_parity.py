@@ -153,40 +153,6 @@ def test_channelizer_fft_sizes(ctx, M, frames):
     _channelizer_case(ctx, 500000 * M, M, M * frames, chans=chans)
 
 
-@pytest.mark.parametrize("M,frames", [(122, 8394), (126, 300), (62, 1000), (34, 64)])
-def test_channelizer_matrix_pipe_equals_vector_form_bit_for_bit(ctx, M, frames):
-    """M = 2 A with A odd >= 17 runs its A-point DFTs on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: a k-ordered fmaf chain per output);
-    the vector form (CSDR_CHAN_MX=0) accumulates the same terms in the same order, so every channel sample -- the DC-blocked channel 0
-    included -- must be IDENTICAL.  M = 122 at the headline block length (8394 frames: whole and ragged 64-frame tiles), A = 63 (all
-    32 x 32 coefficient slots in use), A = 31, A = 17."""
-    import os
-    from cubicsdr_amd.engine import SDRPost
-    fs, center = M * 50000, 100000000
-    block = M * frames
-    x = synth_iq_fast(3 * block, fs, center, [("NBFM", center + 123456), ("AM", center - 3 * (fs // M) + 999)], seed=5)
-    outs = []
-    saved = {k: os.environ.get(k) for k in ("CSDR_CHAN_MX", "CSDR_CHAN_ALT")}
-    try:
-        # the vector form as round 2 had it (s / d formed by every wave in its DFT pass, guarded second request), the four matrix-pipe
-        # variants, then the vector form's default (s / d formed once in the FIR phase by a lane trade, unconditional request): csdr_api.hip, chan_geometry
-        for mx, alt in (("0", "0"), ("1", "0"), ("2", "0"), ("3", "0"), ("4", "0"), ("0", "1"), ("0", "3")):
-            os.environ["CSDR_CHAN_MX"] = mx
-            os.environ["CSDR_CHAN_ALT"] = alt
-            p = SDRPost(ctx, fs, M, block, max_blocks=3)
-            p.execute(x, 3, block, center)
-            outs.append([p.read_channel(ch) for ch in range(M)])
-            p.close()
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-    for v in range(1, len(outs)):
-        for ch, (a, b) in enumerate(zip(outs[0], outs[v])):
-            assert a.size == 3 * frames and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (M, v, ch, float(np.max(np.abs(a - b))))
-
-
 def test_channelizer_batched_equals_blockwise(ctx):
     from cubicsdr_amd.engine import SDRPost
     fs, M, block, center = 2400000, 4, 40000, 100000000
