@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 # one translation unit per object of include/csdr_hip.h (an edit rebuilds its own unit; the units compile in parallel)
-UNITS = ["csdr_ctx", "csdr_post", "csdr_bank", "csdr_spec", "csdr_io"]
+UNITS = ["csdr_ctx", "csdr_post", "csdr_bank", "csdr_spec", "csdr_io", "csdr_comm"]
 SRCS = [os.path.join(HERE, "csrc", u + ".hip") for u in UNITS]
 OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
 OUT = os.path.join(HERE, "libcsdr_hip.so")
@@ -77,7 +77,7 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
         list(ex.map(compile_one, jobs))
     open(stamp, "w").write(flavor)
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", OUT]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

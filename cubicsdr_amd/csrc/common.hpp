@@ -258,6 +258,7 @@ struct csdr_ctx {
     int lds_per_cu = 160 * 1024;             // LDS of one compute unit (gfx950)
     hipStream_t stream = nullptr;            // boundary stream: the caller's producer / consumer work is ordered on it
     bool own_stream = false;
+    bool boundary_shared = false;            // a csdr_comm enqueues collectives on the boundary stream: the lanes order against it even when the library created it
     hipStream_t lanes[LANE_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // logical stage -> physical stream
     hipStream_t phys[LANE_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};    // streams this ctx created
     int n_phys = 0;
@@ -283,7 +284,7 @@ struct csdr_ctx {
     }
     // work the caller enqueued on the boundary stream (e.g. the producer of a device IQ buffer) precedes this lane's next work
     int lane_begin(int lane) {
-        if (own_stream) return CSDR_OK;      // nobody else can enqueue on a stream we created
+        if (own_stream && !boundary_shared) return CSDR_OK;      // nobody else can enqueue on a stream we created
         CSDR_HIP_TRY(hipEventRecord(ev_in[lane], stream));
         CSDR_HIP_TRY(hipStreamWaitEvent(lanes[lane], ev_in[lane], 0));
         return CSDR_OK;

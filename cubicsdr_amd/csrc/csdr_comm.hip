@@ -1,0 +1,245 @@
+// csdr_comm.hip -- implementation of include/csdr_hip.h (gfx950): csdr_comm, ONE IQ stream over the GPUs of a node (RCCL over xGMI).
+//
+// Replaces the fan-out point of SDRPostThread::runDemodChannels (SDRPostThread.cpp:389-396: one ReBuffer block pushed to every demodulator's
+// queue) when the DemodulatorInstances of one stream are spread over several GPUs (BASELINE config 4):
+//   * csdr_comm_broadcast      the ingest rank's raw IQ batch to every rank (8 B / sample; every rank then channelizes for ITS channels);
+//   * csdr_comm_scatter        time slabs [history | the rank's blocks] from the ingest rank (the time-slab variant: the channelizer's work is divided too);
+//   * csdr_comm_all_to_all     the rows of each owner's channels for each producer's frames: every channel sample crosses a link once;
+//   * csdr_post_exchange_rows  export -> all-to-all -> import -> commit of one batch, between a producer and an owner csdr_post.
+// One process per GPU; the communicator is created from a 128-byte id that rank 0 makes and the HOST distributes (a pipe, a socket, MPI, a
+// torch.distributed store: csdr_hip.h does not care).  Every collective is enqueued on the context's BOUNDARY stream, behind every lane of
+// the library (csdr_ctx::join), and the lanes' next work starts behind it (lane_begin): no host synchronisation on the data path.
+//
+// RCCL is loaded at the first csdr_comm_unique_id / csdr_comm_create (dlopen: a single-GPU user of the library never maps it).  xGMI is
+// point-to-point: the all-to-all is one grouped send / receive per peer pair, sized by the caller's channel plan.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "csdr_objects.hpp"
+
+using namespace csdr;
+
+namespace {
+// the few declarations of <rccl/rccl.h> this file needs (the header drags the whole HIP surface in; the ABI below is stable since NCCL 2.x)
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+enum { kNcclSuccess = 0, kNcclFloat = 7, kNcclDouble = 8, kNcclMax = 2 };
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl &rccl() { static Rccl r; return r; }
+int rccl_load() {
+    Rccl &r = rccl();
+    if (r.lib) return CSDR_OK;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (r.lib) return CSDR_OK;
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) return fail(CSDR_EUNSUPPORTED, "RCCL is not available: %s", dlerror());
+#define CSDR_SYM(field_, sym_) \
+    if (!(*(void **)(&r.field_) = dlsym(h, sym_))) { dlclose(h); return fail(CSDR_EUNSUPPORTED, "librccl lacks %s", sym_); }
+    CSDR_SYM(GetUniqueId, "ncclGetUniqueId"); CSDR_SYM(CommInitRank, "ncclCommInitRank"); CSDR_SYM(CommDestroy, "ncclCommDestroy");
+    CSDR_SYM(Broadcast, "ncclBroadcast"); CSDR_SYM(AllReduce, "ncclAllReduce"); CSDR_SYM(Send, "ncclSend"); CSDR_SYM(Recv, "ncclRecv");
+    CSDR_SYM(GroupStart, "ncclGroupStart"); CSDR_SYM(GroupEnd, "ncclGroupEnd"); CSDR_SYM(GetErrorString, "ncclGetErrorString");
+#undef CSDR_SYM
+    r.lib = h;
+    return CSDR_OK;
+}
+#define CSDR_RCCL_TRY(expr)                                                                                               \
+    do {                                                                                                                  \
+        const int e__ = (expr);                                                                                           \
+        if (e__ != kNcclSuccess) return ::csdr::fail(CSDR_EHIP, "%s failed: %s", #expr, rccl().GetErrorString(e__));      \
+    } while (0)
+}  // namespace
+
+struct csdr_comm {
+    csdr_ctx *ctx = nullptr;
+    int rank = 0, world = 1;
+    bool loopback = false;                   // one rank without RCCL (the host-executing test build): collectives are copies on the boundary stream
+    ncclComm_t nc = nullptr;
+    DevBuf<float2> send, recv;               // csdr_post_exchange_rows
+    DevBuf<double> scalar;                   // barrier / max over ranks
+};
+
+extern "C" int csdr_comm_unique_id(char *id_out) {
+    if (!id_out) return fail(CSDR_EINVAL, "null argument");
+    memset(id_out, 0, CSDR_COMM_ID_BYTES);
+#if !defined(CSDR_HIP_EMULATION)
+    if (int rc = rccl_load()) return rc;
+    ncclUniqueId id;
+    CSDR_RCCL_TRY(rccl().GetUniqueId(&id));
+    memcpy(id_out, id.internal, sizeof id.internal);
+#endif
+    return CSDR_OK;
+}
+
+extern "C" int csdr_comm_create(csdr_ctx *ctx, const char *unique_id, int rank, int world, csdr_comm **out) {
+    DeviceScope dev__(ctx);
+    if (!ctx || !out || !unique_id) return fail(CSDR_EINVAL, "null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(CSDR_EINVAL, "rank %d of %d", rank, world);
+    std::unique_ptr<csdr_comm> m(new csdr_comm());
+    m->ctx = ctx; m->rank = rank; m->world = world;
+#if defined(CSDR_HIP_EMULATION)
+    if (world != 1) return fail(CSDR_EUNSUPPORTED, "the host-executing test build has no RCCL: one rank only");
+    m->loopback = true;
+#else
+    if (int rc = rccl_load()) return rc;
+    ncclUniqueId id;
+    memcpy(id.internal, unique_id, sizeof id.internal);
+    CSDR_RCCL_TRY(rccl().CommInitRank(&m->nc, world, id, rank));      // collective: every rank of the node calls it with the same id
+#endif
+    if (int rc = m->scalar.reserve(2)) return rc;
+    ctx->boundary_shared = true;              // the library itself enqueues on the boundary stream from now on: the lanes must order against it
+    *out = m.release();
+    return CSDR_OK;
+}
+extern "C" void csdr_comm_destroy(csdr_comm *m) {
+    DeviceScope dev__(m ? m->ctx : nullptr);
+    if (!m) return;
+    (void)m->ctx->sync_all();
+    if (m->nc) (void)rccl().CommDestroy(m->nc);
+    m->send.release(); m->recv.release(); m->scalar.release();
+    delete m;
+}
+extern "C" int csdr_comm_rank(const csdr_comm *m) { return m ? m->rank : -1; }
+extern "C" int csdr_comm_world(const csdr_comm *m) { return m ? m->world : 0; }
+
+// every collective: behind all the library's lanes (they may still read or write the buffers), on the boundary stream
+static int comm_begin(csdr_comm *m) { return m->ctx->join(); }
+
+extern "C" int csdr_comm_broadcast(csdr_comm *m, float *iq_dev, int64_t n_samples, int root) {
+    DeviceScope dev__(m ? m->ctx : nullptr);
+    if (!m || !iq_dev || n_samples < 0 || root < 0 || root >= m->world) return fail(CSDR_EINVAL, "bad argument");
+    if (int rc = comm_begin(m)) return rc;
+    if (m->loopback || n_samples == 0) return CSDR_OK;
+    CSDR_RCCL_TRY(rccl().Broadcast(iq_dev, iq_dev, (size_t)2 * (size_t)n_samples, kNcclFloat, root, m->nc, m->ctx->stream));
+    return CSDR_OK;
+}
+
+// rank `root` holds world x n_samples samples (rank r's part at send_dev + 2 * r * n_samples floats); every rank receives its part
+extern "C" int csdr_comm_scatter(csdr_comm *m, const float *send_dev, float *recv_dev, int64_t n_samples, int root) {
+    DeviceScope dev__(m ? m->ctx : nullptr);
+    if (!m || !recv_dev || n_samples < 0 || root < 0 || root >= m->world || (m->rank == root && !send_dev)) return fail(CSDR_EINVAL, "bad argument");
+    if (int rc = comm_begin(m)) return rc;
+    if (n_samples == 0) return CSDR_OK;
+    hipStream_t st = m->ctx->stream;
+    const size_t cnt = (size_t)2 * (size_t)n_samples;
+    if (m->loopback) {
+        CSDR_HIP_TRY(hipMemcpyAsync(recv_dev, send_dev, cnt * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return CSDR_OK;
+    }
+    CSDR_RCCL_TRY(rccl().GroupStart());
+    if (m->rank == root)
+        for (int r = 0; r < m->world; ++r) CSDR_RCCL_TRY(rccl().Send(send_dev + (size_t)r * cnt, cnt, kNcclFloat, r, m->nc, st));
+    CSDR_RCCL_TRY(rccl().Recv(recv_dev, cnt, kNcclFloat, root, m->nc, st));
+    CSDR_RCCL_TRY(rccl().GroupEnd());
+    return CSDR_OK;
+}
+
+// send_samples[q] samples to rank q (consecutive in send_dev), recv_samples[p] from rank p (consecutive in recv_dev): one grouped
+// send / receive per peer pair -- xGMI is point-to-point, every pair has its own link
+extern "C" int csdr_comm_all_to_all(csdr_comm *m, const float *send_dev, const int64_t *send_samples, float *recv_dev, const int64_t *recv_samples) {
+    DeviceScope dev__(m ? m->ctx : nullptr);
+    if (!m || !send_samples || !recv_samples) return fail(CSDR_EINVAL, "null argument");
+    int64_t ts = 0, tr = 0;
+    for (int q = 0; q < m->world; ++q) {
+        if (send_samples[q] < 0 || recv_samples[q] < 0) return fail(CSDR_EINVAL, "negative count");
+        ts += send_samples[q]; tr += recv_samples[q];
+    }
+    if ((ts && !send_dev) || (tr && !recv_dev)) return fail(CSDR_EINVAL, "null buffer");
+    if (int rc = comm_begin(m)) return rc;
+    hipStream_t st = m->ctx->stream;
+    if (m->loopback) {
+        if (send_samples[0] != recv_samples[0]) return fail(CSDR_EINVAL, "one rank: send and receive counts differ");
+        if (ts) CSDR_HIP_TRY(hipMemcpyAsync(recv_dev, send_dev, (size_t)ts * sizeof(float2), hipMemcpyDeviceToDevice, st));
+        return CSDR_OK;
+    }
+    CSDR_RCCL_TRY(rccl().GroupStart());
+    size_t so = 0, ro = 0;
+    for (int q = 0; q < m->world; ++q) {
+        if (send_samples[q]) CSDR_RCCL_TRY(rccl().Send(send_dev + 2 * so, (size_t)2 * (size_t)send_samples[q], kNcclFloat, q, m->nc, st));
+        if (recv_samples[q]) CSDR_RCCL_TRY(rccl().Recv(recv_dev + 2 * ro, (size_t)2 * (size_t)recv_samples[q], kNcclFloat, q, m->nc, st));
+        so += (size_t)send_samples[q]; ro += (size_t)recv_samples[q];
+    }
+    CSDR_RCCL_TRY(rccl().GroupEnd());
+    return CSDR_OK;
+}
+
+// max over the ranks of a host scalar (a timing: bench.py takes the slowest rank), which is also a barrier: returns when every rank has
+// reached it and everything this rank enqueued before it has finished
+extern "C" int csdr_comm_max(csdr_comm *m, double *value) {
+    DeviceScope dev__(m ? m->ctx : nullptr);
+    if (!m || !value) return fail(CSDR_EINVAL, "null argument");
+    if (int rc = comm_begin(m)) return rc;
+    hipStream_t st = m->ctx->stream;
+    CSDR_HIP_TRY(hipMemcpyAsync(m->scalar.p, value, sizeof(double), hipMemcpyHostToDevice, st));
+    if (!m->loopback) CSDR_RCCL_TRY(rccl().AllReduce(m->scalar.p, m->scalar.p, 1, kNcclDouble, kNcclMax, m->nc, st));
+    CSDR_HIP_TRY(hipMemcpyAsync(value, m->scalar.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    CSDR_HIP_TRY(hipStreamSynchronize(st));
+    return CSDR_OK;
+}
+extern "C" int csdr_comm_barrier(csdr_comm *m) { double v = 0.0; return csdr_comm_max(m, &v); }
+
+// One batch of the time-slab variant between this rank's producer post (it has just executed ITS blocks for all channels) and its owner
+// post (the rows of ITS channels for the whole batch, read by its demodulator bank):
+//   export: the rows each peer owns, packed [peer q][q's channels][this rank's frames]      (csdr_post_export_rows)
+//   all-to-all over RCCL
+//   import: [peer p][my channels][p's frames] into the owner's rows at p's frame offset      (csdr_post_import_begin / _rows / _commit)
+// channels: the ranks' channel lists one after the other (n_channels[q] entries for rank q); frame0[p] / frames[p]: rank p's slab inside the
+// batch, in frames (samples per channel).
+extern "C" int csdr_post_exchange_rows(csdr_comm *m, csdr_post *producer, csdr_post *owner, const int *channels, const int *n_channels,
+                                       const int64_t *frame0, const int64_t *frames, int n_blocks, int block_len, int64_t frequency) {
+    DeviceScope dev__(m ? m->ctx : nullptr);
+    if (!m || !producer || !owner || !channels || !n_channels || !frame0 || !frames) return fail(CSDR_EINVAL, "null argument");
+    if (producer->ctx != m->ctx || owner->ctx != m->ctx) return fail(CSDR_EINVAL, "posts and communicator belong to different contexts");
+    const int W = m->world, me = m->rank;
+    std::vector<const int *> list((size_t)W);
+    int64_t total_ch = 0;
+    for (int q = 0; q < W; ++q) {
+        if (n_channels[q] < 0 || frames[q] < 0) return fail(CSDR_EINVAL, "negative count");
+        list[(size_t)q] = channels + total_ch;
+        total_ch += n_channels[q];
+    }
+    const int64_t mine_f = frames[me];
+    std::vector<int64_t> sc((size_t)W), rc_((size_t)W);
+    int64_t ts = 0, tr = 0;
+    for (int q = 0; q < W; ++q) {
+        sc[(size_t)q] = (int64_t)n_channels[q] * mine_f; rc_[(size_t)q] = (int64_t)n_channels[me] * frames[q];
+        ts += sc[(size_t)q]; tr += rc_[(size_t)q];
+    }
+    if (int rc = m->send.reserve((size_t)std::max<int64_t>(ts, 1))) return rc;
+    if (int rc = m->recv.reserve((size_t)std::max<int64_t>(tr, 1))) return rc;
+    if (mine_f) {
+        int64_t off = 0;
+        for (int q = 0; q < W; ++q) {
+            if (n_channels[q])
+                if (int rc = csdr_post_export_rows(producer, list[(size_t)q], n_channels[q], (float *)(m->send.p + off), mine_f)) return rc;
+            off += sc[(size_t)q];
+        }
+    }
+    if (int rc = csdr_comm_all_to_all(m, (const float *)m->send.p, sc.data(), (float *)m->recv.p, rc_.data())) return rc;
+    if (int rc = csdr_post_import_begin(owner, n_blocks, block_len, frequency)) return rc;      // (lane_begin: the owner's lane starts behind the all-to-all)
+    int64_t off = 0;
+    for (int p = 0; p < W; ++p) {
+        if (n_channels[me] && frames[p])
+            if (int rc = csdr_post_import_rows(owner, list[(size_t)me], n_channels[me], (const float *)(m->recv.p + off), frames[p], frame0[p], frames[p])) return rc;
+        off += rc_[(size_t)p];
+    }
+    return csdr_post_import_commit(owner);
+}

@@ -463,6 +463,73 @@ class AudioMixer:
             self.h = C.c_void_p()
 
 
+class Comm:
+    """csdr_comm: the collectives of ONE stream over the GPUs of a node, RCCL over xGMI behind the C ABI (csdr_comm.hip).  Every rank
+    creates one on its own Context with the same 128-byte id (rank 0 makes it: Comm.unique_id(); how it reaches the other ranks is the
+    host's business -- parallel.exchange_id uses a TCP store).  Buffers are device memory (torch CUDA tensors / DevicePointer; numpy
+    arrays with the host-executing test build); counts are complex samples."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(Comm.ID_BYTES)
+        H.check(H.lib().csdr_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, ctx, unique_id, rank, world):
+        self._l = H.lib()
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        self.h = C.c_void_p()
+        assert len(unique_id) == Comm.ID_BYTES
+        H.check(self._l.csdr_comm_create(ctx.h, C.c_char_p(bytes(unique_id)), self.rank, self.world, C.byref(self.h)))
+
+    @staticmethod
+    def _ptr(buf):
+        if buf is None:
+            return None
+        if isinstance(buf, np.ndarray):
+            return buf.ctypes.data_as(C.c_void_p)
+        if isinstance(buf, DevicePointer):
+            return C.c_void_p(buf.ptr)
+        return C.c_void_p(buf.data_ptr())
+
+    def broadcast(self, iq, n_samples, root=0):
+        H.check(self._l.csdr_comm_broadcast(self.h, self._ptr(iq), int(n_samples), int(root)))
+
+    def scatter(self, send, recv, n_samples, root=0):
+        H.check(self._l.csdr_comm_scatter(self.h, self._ptr(send), self._ptr(recv), int(n_samples), int(root)))
+
+    def all_to_all(self, send, send_samples, recv, recv_samples):
+        a = np.ascontiguousarray(send_samples, dtype=np.int64)
+        b = np.ascontiguousarray(recv_samples, dtype=np.int64)
+        assert a.size == self.world and b.size == self.world
+        H.check(self._l.csdr_comm_all_to_all(self.h, self._ptr(send), a.ctypes.data_as(C.c_void_p), self._ptr(recv), b.ctypes.data_as(C.c_void_p)))
+
+    def max(self, value):
+        v = C.c_double(float(value))
+        H.check(self._l.csdr_comm_max(self.h, C.byref(v)))
+        return v.value
+
+    def barrier(self):
+        H.check(self._l.csdr_comm_barrier(self.h))
+
+    def exchange_rows(self, producer, owner, owned, frame0, frames, n_blocks, block_len, frequency):
+        """owned: per-rank channel lists; frame0 / frames: per-rank slab position inside the batch (frames = samples per channel)"""
+        ch = np.ascontiguousarray([c for o in owned for c in o] or [0], dtype=np.int32)
+        nch = np.ascontiguousarray([len(o) for o in owned], dtype=np.int32)
+        f0 = np.ascontiguousarray(frame0, dtype=np.int64)
+        fr = np.ascontiguousarray(frames, dtype=np.int64)
+        assert nch.size == self.world and f0.size == self.world and fr.size == self.world
+        H.check(self._l.csdr_post_exchange_rows(self.h, producer.h, owner.h, ch.ctypes.data_as(C.c_void_p), nch.ctypes.data_as(C.c_void_p),
+                                                f0.ctypes.data_as(C.c_void_p), fr.ctypes.data_as(C.c_void_p), int(n_blocks), int(block_len), int(frequency)))
+
+    def close(self):
+        if self.h:
+            self._l.csdr_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 class Ingest:
     """page-locked block ring -> HBM, ONE transfer per block (csdr_ingest); commit returns the device pointer as an integer"""
 

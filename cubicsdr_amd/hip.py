@@ -144,6 +144,17 @@ ABI = {
     "csdr_ingest_commit": (_i, [_p, _i64, _i, _pp]),
     "csdr_ingest_upload": (_i, [_p, _p, _i64, _i, _pp]),
     "csdr_ingest_wait": (_i, [_p]),
+    "csdr_comm_unique_id": (_i, [_p]),
+    "csdr_comm_create": (_i, [_p, _p, _i, _i, _pp]),
+    "csdr_comm_destroy": (None, [_p]),
+    "csdr_comm_rank": (_i, [_p]),
+    "csdr_comm_world": (_i, [_p]),
+    "csdr_comm_broadcast": (_i, [_p, _p, _i64, _i]),
+    "csdr_comm_scatter": (_i, [_p, _p, _p, _i64, _i]),
+    "csdr_comm_all_to_all": (_i, [_p, _p, _p, _p, _p]),
+    "csdr_comm_max": (_i, [_p, C.POINTER(_d)]),
+    "csdr_comm_barrier": (_i, [_p]),
+    "csdr_post_exchange_rows": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64]),
     "csdr_ingest_next_slot": (_i, [_p]),
 }
 

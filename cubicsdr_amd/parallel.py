@@ -1,5 +1,7 @@
-"""Multi-GPU partitioning of the hot path: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on
-the GPU box, "gloo" in CPU tests).
+"""Multi-GPU partitioning of the hot path: one process per GPU.  The collectives of a sharded stream go through the C ABI's communicator
+(csdr_comm: RCCL over xGMI, include/csdr_hip.h "one stream over several GPUs") when the stream is given an engine.Comm -- that is what
+bench.py --config C4 runs on a GPU node; without one they go through torch.distributed ("gloo" in the CPU tests, where no RCCL exists).
+This module only plans (who owns which channel) and calls; the data path is the library's.
 
 The path shards two ways:
   * by IQ stream  -- independent receivers, one per GPU, no data-path collective (BASELINE config 5; bench.py default);
@@ -132,8 +134,10 @@ class ShardedStream:
     No reduction exists on this path: audio stays on the owning rank.  `group=False` skips the collective (single process
     driving several "virtual ranks" on one GPU: the sharded-equals-unsharded test)."""
 
-    def __init__(self, device_index, rank, world, fs, M, block, demods, center, max_blocks, group=None, oversampled=False):
-        from .engine import Context, DemodBank, SDRPost
+    def __init__(self, device_index, rank, world, fs, M, block, demods, center, max_blocks, group=None, oversampled=False, comm_id=None):
+        """comm_id: the 128-byte id of engine.Comm.unique_id() (same on every rank): the broadcast then runs through the C ABI's
+        communicator (RCCL) instead of torch.distributed"""
+        from .engine import Comm, Context, DemodBank, SDRPost
         self.rank, self.world, self.group = rank, world, group
         self.fs, self.M, self.block, self.center, self.max_blocks = fs, M, block, center, max_blocks
         self.demods = list(demods)                               # (kind, bandwidth, frequency) of EVERY demodulator of the stream
@@ -145,6 +149,7 @@ class ShardedStream:
         self.boundary = _Boundary(device_index)
         self.ctx = Context(device_index, stream=self.boundary.handle)
         assert self.boundary.handle is None or not self.ctx.owns_stream
+        self.comm = Comm(self.ctx, comm_id, rank, world) if comm_id is not None else None
         self.post = SDRPost(self.ctx, fs, M, block, max_blocks=max_blocks, oversampled=oversampled)
         self.post.set_active_channels(self.plan.active_channels)
         self.bank = DemodBank(self.ctx, max(1, len(self.plan.demods)), max_blocks=max_blocks)
@@ -157,7 +162,9 @@ class ShardedStream:
     def step(self, iq, n_blocks, src=0):
         """iq: the batch tensor, pre-allocated on every rank (valid on `src`); returns after the work is enqueued"""
         with self.boundary.on():
-            if self.world > 1 and self.group is not False:
+            if self.comm is not None:
+                self.comm.broadcast(iq, n_blocks * self.block, src)        # (joins the lanes itself: csdr_comm.hip)
+            elif self.world > 1 and self.group is not False:
                 self.ctx.join()                                  # the previous batch's kernels have read `iq` before it is overwritten
                 broadcast_iq(iq, src=src, group=self.group)
             self.post.execute(iq, n_blocks, self.block, self.center)
@@ -180,6 +187,8 @@ class ShardedStream:
         self.ctx.synchronize()
 
     def close(self):
+        if self.comm is not None:
+            self.comm.close()
         self.bank.close(); self.post.close(); self.ctx.close()
 
 
@@ -210,8 +219,9 @@ class SlabStream:
     GPU and do the exchange by slicing (local_exchange): the sharded-equals-unsharded test.  Buffers are torch tensors on the GPU
     (float32 [n, 2]); with use_torch=False (a host-executing test build of the library) they are numpy arrays."""
 
-    def __init__(self, device_index, rank, world, fs, M, block, demods, center, max_blocks, group=None, use_torch=True):
-        from .engine import Context, DemodBank, SDRPost
+    def __init__(self, device_index, rank, world, fs, M, block, demods, center, max_blocks, group=None, use_torch=True, comm_id=None):
+        """comm_id: see ShardedStream: scatter and the row exchange then run through the C ABI (csdr_comm_scatter, csdr_post_exchange_rows)"""
+        from .engine import Comm, Context, DemodBank, SDRPost
         self.rank, self.world, self.group, self.use_torch = rank, world, group, use_torch
         self.fs, self.M, self.block, self.center, self.max_blocks = fs, M, block, center, max_blocks
         self.bc = block // M                                       # frames (samples per channel) of one block
@@ -225,6 +235,7 @@ class SlabStream:
         self.boundary = _Boundary(device_index, use_torch)
         self.ctx = Context(device_index, stream=self.boundary.handle)
         assert self.boundary.handle is None or not self.ctx.owns_stream
+        self.comm = Comm(self.ctx, comm_id, rank, world) if comm_id is not None else None
         self.producer = SDRPost(self.ctx, fs, M, block, max_blocks=max(1, -(-max_blocks // world)))
         self.producer.set_dc_blocker(False)
         self.rows = SDRPost(self.ctx, fs, M, block, max_blocks=max_blocks)
@@ -291,12 +302,22 @@ class SlabStream:
             raise ValueError("scatter needs the batch's blocks to divide evenly over the ranks")
         with self.boundary.on():
             self.ctx.join()                                         # the previous batch's kernels have read the window buffer
-            mine = self._empty(self.hist + (n_blocks // self.world) * self.block)
+            each = self.hist + (n_blocks // self.world) * self.block
+            mine = self._empty(each)
             parts = None
             if self.rank == src:
                 ext = self.extended(batch, n_blocks)
                 parts = [self._t(self.window(ext, n_blocks, r)).contiguous() for r in range(self.world)]
-            dist.scatter(self._t(mine), parts, src=src, group=self.group)
+            if self.comm is not None:
+                packed = None
+                if self.rank == src:                                # the overlapping windows, one after the other
+                    packed = self._empty(each * self.world)
+                    for r in range(self.world):
+                        packed[r * each:(r + 1) * each] = self.window(ext, n_blocks, r)
+                self.comm.scatter(packed, mine, each, src)
+                self._keep_scatter = packed
+            else:
+                dist.scatter(self._t(mine), parts, src=src, group=self.group)
         return mine
 
     # ---- the three phases
@@ -351,7 +372,22 @@ class SlabStream:
                 self.bank.execute(self.rows)
 
     def step(self, window, n_blocks):
-        self.consume(self.exchange(self.produce(window, n_blocks), n_blocks), n_blocks)
+        if self.comm is None:
+            self.consume(self.exchange(self.produce(window, n_blocks), n_blocks), n_blocks)
+            return
+        # through the C ABI: producer execute, then export -> all-to-all (RCCL) -> import -> commit in ONE call
+        sl = slab_blocks(n_blocks, self.world)
+        start, cnt = sl[self.rank]
+        with self.boundary.on():
+            self.ctx.join()
+            if cnt:
+                self.producer.set_history(window, self.hist)
+                self.producer.execute(window[self.hist:], cnt, self.block, self.center)
+            self.comm.exchange_rows(self.producer, self.rows, self.owned, [b * self.bc for b, _ in sl], [c * self.bc for _, c in sl],
+                                    n_blocks, self.block, self.center)
+            self._keep = [window]
+            if self.plan.demods:
+                self.bank.execute(self.rows)
 
     def audio(self, demod_index):
         return self.bank.audio(self.slot_of[demod_index])
@@ -363,6 +399,8 @@ class SlabStream:
         self.ctx.synchronize()
 
     def close(self):
+        if self.comm is not None:
+            self.comm.close()
         self.bank.close(); self.rows.close(); self.producer.close(); self.ctx.close()
 
 
@@ -384,6 +422,23 @@ def local_exchange(streams, sends, n_blocks):
                 off += outs[p]
         recvs.append(recv)
     return recvs
+
+
+def exchange_id(rank: int, world: int, host: str = None, port: int = None, timeout_s: float = 120.0) -> bytes:
+    """the 128-byte communicator id: rank 0 makes it (csdr_comm_unique_id), the others read it from a TCP key-value store on
+    MASTER_ADDR : MASTER_PORT + 1 (no process group, no collective library involved)"""
+    import datetime
+    import os
+    from torch.distributed import TCPStore
+    from .engine import Comm
+    if world == 1:
+        return Comm.unique_id()
+    host = host or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = port or int(os.environ.get("MASTER_PORT", "29500")) + 1
+    store = TCPStore(host, port, world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=timeout_s))
+    if rank == 0:
+        store.set("csdr_comm_id", Comm.unique_id())
+    return bytes(store.get("csdr_comm_id"))
 
 
 def broadcast_iq(batch, src: int = 0, group=None):

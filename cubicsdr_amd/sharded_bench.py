@@ -23,13 +23,21 @@ def main(args):
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # transport of the collectives: the library's own communicator (csdr_comm: RCCL behind the C ABI, no torch.distributed process group; the
+    # id travels over a TCP store on MASTER_PORT + 1), or CSDR_C4_TRANSPORT=torch: torch.distributed ("nccl" is RCCL; CSDR_DIST_BACKEND overrides
+    # it for one-GPU dry runs of the multi-rank control flow)
     dist = None
+    cid = None
     if world > 1:
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("CSDR_DIST_BACKEND", "nccl"), rank=rank, world_size=world)   # ("nccl" is RCCL; the override exists for one-GPU dry runs of the multi-rank control flow)
-        dist.barrier()
-    NB = args.blocks or 16
+        if os.environ.get("CSDR_C4_TRANSPORT", "abi") == "abi":
+            from cubicsdr_amd.parallel import exchange_id
+            cid = exchange_id(rank, world)
+        else:
+            import torch.distributed as dist
+            dist.init_process_group(os.environ.get("CSDR_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+            dist.barrier()
+    NB = args.blocks or 32          # 32 blocks = 427 MB of input per batch: beyond the 256 MB Infinity Cache (16 blocks fit in it and measure 0.39 instead of 0.27 of peak on the channelizer)
     NBATCH = args.batches or 24
     cc = channel_centers(CENTER, FS, M)
     demods = [("NBFM", NBFM_BW, cc[ch] + 3700) for ch in range(M)]          # one per channel, 3.7 kHz off the channel centre (forces the NCO)
@@ -39,9 +47,9 @@ def main(args):
     if slab and NB % world:
         raise SystemExit("--shard slab needs --blocks divisible by the number of GPUs")
     if slab:
-        st = SlabStream(local_rank, rank, world, FS, M, BLOCK, demods, CENTER, NB)
+        st = SlabStream(local_rank, rank, world, FS, M, BLOCK, demods, CENTER, NB, comm_id=cid)
     else:
-        st = ShardedStream(local_rank, rank, world, FS, M, BLOCK, demods, CENTER, NB)
+        st = ShardedStream(local_rank, rank, world, FS, M, BLOCK, demods, CENTER, NB, comm_id=cid)
 
     def step():
         for _ in range(NBATCH):
@@ -58,6 +66,8 @@ def main(args):
     st.synchronize(); torch.cuda.synchronize()
     if dist:
         dist.barrier()
+    elif st.comm is not None:
+        st.comm.barrier()
     profile_period = 4
     if not args.no_profile:
         st.ctx.profile_enable(profile_period)
@@ -75,6 +85,8 @@ def main(args):
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    elif st.comm is not None:
+        elapsed = st.comm.max(elapsed)                   # max over the ranks (also a barrier)
     samples = args.steps * NBATCH * NB * BLOCK                                   # ONE stream: not multiplied by the world size
     value = samples / elapsed / 1e6
     bytes_per_sample = 8 + 8 + 8.0 * 1.0 + 4.0 * M * AUDIO / FS                  # SURVEY.md 8d, C4 (no FFT): 26.0
@@ -87,7 +99,8 @@ def main(args):
                       "batches_per_step": NBATCH, "blocks_per_batch": NB, "block_len": BLOCK, "n_demods": M, "demods_on_rank0": len(st.plan.demods),
                       "channels_on_rank0": len(st.plan.active_channels), "realtime_multiple": value / (FS / 1e6), "timed_region_s": elapsed,
                       "parallelism": ("time slabs -> per-rank channelizer -> all-to-all of channel rows -> per-rank bank" if slab else
-                                      "dp over demodulators (one IQ stream): broadcast + per-rank channel subset + per-rank bank")},
+                                      "dp over demodulators (one IQ stream): broadcast + per-rank channel subset + per-rank bank"),
+                      "transport": "torch.distributed" if dist else "csdr_comm (RCCL through the C ABI)" if cid is not None else "none (one rank)"},
            "roofline": {"bound": "hbm", "whole_path": {"bytes_per_sample": round(bytes_per_sample, 1), "achieved": bytes_per_sample * value * 1e6 / 1e9,
                                                        "frac": bytes_per_sample * value * 1e6 / 1e9 / 8000.0 / world}}}
     if prof:

@@ -39,6 +39,7 @@ typedef struct csdr_spec  csdr_spec;   /* SpectrumVisualProcessor's arithmetic *
 typedef struct csdr_scope csdr_scope;  /* ScopeVisualProcessor's arithmetic (audio scope + audio spectrum) */
 typedef struct csdr_mix   csdr_mix;    /* AudioThread's mixing callback, PCM conversion */
 typedef struct csdr_ingest csdr_ingest; /* page-locked block ring -> HBM, one transfer per block */
+typedef struct csdr_comm  csdr_comm;   /* one IQ stream over the GPUs of a node: RCCL over xGMI */
 
 /* ------------------------------------------------------------------ context */
 int         csdr_abi_version(void);
@@ -337,6 +338,34 @@ int  csdr_ingest_commit(csdr_ingest *ing, int64_t n_samples, int iq_swap, const 
 int  csdr_ingest_upload(csdr_ingest *ing, const float *host_iq, int64_t n_samples, int iq_swap, const float **dev_iq);
 int  csdr_ingest_next_slot(const csdr_ingest *ing);
 int  csdr_ingest_wait(csdr_ingest *ing);             /* blocks until the last transfer has left its source buffer: call before rewriting or recycling the block just uploaded */
+
+/* ------------------------------------------------------------------ one stream over several GPUs
+ * Replaces the fan-out point SDRPostThread.cpp:389-396 (one block pushed to every demodulator's queue) when the DemodulatorInstances
+ * of ONE stream are spread over the GPUs of a node: one process per GPU, each with its own csdr_ctx.  Rank 0 makes the 128-byte id
+ * (csdr_comm_unique_id) and the HOST hands it to every rank (pipe, socket, MPI ...); csdr_comm_create is collective.  Every call below
+ * is collective too and is enqueued on the context's boundary stream: behind all the library's earlier work on this context, and the
+ * library's next work starts behind it -- no host synchronisation on the data path.  RCCL is loaded on first use (dlopen): a
+ * single-GPU user never maps it.  Buffers are device memory; counts are complex samples.
+ *   broadcast     the ingest rank's raw IQ batch (then csdr_post_set_active_channels + csdr_post_execute on every rank: SURVEY 8e option 1)
+ *   scatter       root holds world x n_samples (rank r's part at 2 * r * n_samples floats); every rank receives its part (time slabs)
+ *   all_to_all    send_samples[q] to rank q, recv_samples[p] from rank p, consecutive in the buffers: one send / receive per xGMI peer pair
+ *   max           max over the ranks of a host scalar; also a barrier (returns when this rank's enqueued work is done and all ranks arrived)
+ *   csdr_post_exchange_rows  one batch of the time-slab variant: export of the rows every peer owns from `producer` (which has just
+ *                 executed this rank's blocks for all channels), all-to-all, import into `owner` at each peer's frame offset, commit.
+ *                 channels: the ranks' channel lists one after the other (n_channels[q] entries for rank q); frame0 / frames [world]. */
+#define CSDR_COMM_ID_BYTES 128
+int  csdr_comm_unique_id(char *id_out /* [CSDR_COMM_ID_BYTES] */);
+int  csdr_comm_create(csdr_ctx *ctx, const char *unique_id, int rank, int world, csdr_comm **out);
+void csdr_comm_destroy(csdr_comm *comm);
+int  csdr_comm_rank(const csdr_comm *comm);
+int  csdr_comm_world(const csdr_comm *comm);
+int  csdr_comm_broadcast(csdr_comm *comm, float *iq_dev, int64_t n_samples, int root);
+int  csdr_comm_scatter(csdr_comm *comm, const float *send_dev, float *recv_dev, int64_t n_samples, int root);
+int  csdr_comm_all_to_all(csdr_comm *comm, const float *send_dev, const int64_t *send_samples, float *recv_dev, const int64_t *recv_samples);
+int  csdr_comm_max(csdr_comm *comm, double *value);
+int  csdr_comm_barrier(csdr_comm *comm);
+int  csdr_post_exchange_rows(csdr_comm *comm, csdr_post *producer, csdr_post *owner, const int *channels, const int *n_channels,
+                             const int64_t *frame0, const int64_t *frames, int n_blocks, int block_len, int64_t frequency);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,7 @@
 // that returns from the kernel drops out of the barrier (as an exited wave does on the hardware); dynamic LDS is one
 // global buffer; wave64 cross-lane ops go through an exchange buffer and a per-wave barrier (wave-uniform control flow).
 #pragma once
+#define CSDR_HIP_EMULATION 1      /* host-executing test build: no RCCL, no device */
 #include <algorithm>
 #include <barrier>
 #include <cmath>

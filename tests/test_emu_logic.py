@@ -228,3 +228,21 @@ def test_emu_ingest_shared_device_buffer(ctx):
 
 def test_emu_spectrum_nan_repairs_frame_by_frame(ctx):
     G.test_spectrum_nan_samples_recover_frame_by_frame(ctx, 2048, (40, 23), ((5, 100), (38, 7), (41, 3000)))
+
+
+def test_emu_comm_one_rank(ctx):
+    """csdr_comm's entry points and the drivers' ABI transport with the one-rank loopback of the host-executing build"""
+    G._comm_one_rank_case(ctx, False)
+
+
+def test_emu_cpp_comm_ranks(ctx):
+    """tests/cpp/comm_ranks.cpp (the C++ host of a sharded stream, C ABI only) linked against the host-executing build: one rank, loopback"""
+    import subprocess
+    import build_emu
+    lib = build_emu.build(os.environ.get("CSDR_EMU_FLAVOR", ""))
+    exe = os.path.join(os.path.dirname(lib), "comm_ranks_emu")
+    src = os.path.join(HERE, "cpp", "comm_ranks.cpp")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-pthread", src, "-o", exe, "-L" + os.path.dirname(lib), "-l:" + os.path.basename(lib), "-ldl",
+                    "-Wl,-rpath," + os.path.dirname(lib)], check=True)
+    r = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sharded rows: ok" in r.stdout, r.stdout + r.stderr

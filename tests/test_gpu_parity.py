@@ -1233,6 +1233,81 @@ def test_time_slab_sharding_equals_unsharded(ctx):
           _slab_case(ctx, 6400000, 64, 106688, 24, 2, 4, 3, True))
 
 
+def _comm_one_rank_case(ctx, use_torch):
+    """The C ABI's communicator (csdr_comm: RCCL, loaded on first use) with ONE rank: every collective entry point runs on the boundary stream
+    (ncclCommInitRank with one rank; the host-executing test build copies instead) and the two sharded drivers, given a communicator id,
+    go through csdr_comm_broadcast / csdr_comm_scatter / csdr_post_exchange_rows: audio and counts equal the unsharded path's."""
+    from cubicsdr_amd.engine import Comm, Context, DemodBank, SDRPost
+    from cubicsdr_amd.parallel import ShardedStream, SlabStream, exchange_id
+    fs, M, block, nd, nb, n_batches, center = 6400000, 64, 64 * 417, 12, 4, 2, 400000000
+    freqs = demod_frequencies(center, fs, nd)
+    freqs[0] = center + 1500
+    kinds = ("NBFM", "AM", "USB")
+    bw = {"NBFM": 12500, "AM": 6000, "USB": 5400}
+    demods = [(kinds[i % 3], bw[kinds[i % 3]], f) for i, f in enumerate(freqs)]
+    x = synth_iq(n_batches * nb * block, fs, center, [(k, f) for k, _, f in demods[:6]], seed=197)
+    xf = x.view(np.float32).reshape(-1, 2)
+
+    def dev(a):
+        if not use_torch:
+            return a.copy()
+        import torch
+        return torch.from_numpy(a.copy()).cuda()
+
+    def host(t):
+        return t.cpu().numpy() if hasattr(t, "cpu") else np.asarray(t)
+    post = SDRPost(ctx, fs, M, block, max_blocks=nb)
+    bank = DemodBank(ctx, nd, max_blocks=nb)
+    for i, (k, b, f) in enumerate(demods):
+        bank.configure(i, post, k, b, f)
+    whole, counts = [], []
+    for t in range(n_batches):
+        post.execute(x[t * nb * block:(t + 1) * nb * block], nb, block, center)
+        bank.execute(post)
+        whole.append([bank.audio(i) for i in range(nd)])
+        counts.append([[(r.n_iq, r.n_audio, r.nco_theta, r.resamp_phase) for r in bank.results(i)] for i in range(nd)])
+    bank.close(); post.close()
+    cid = exchange_id(0, 1)
+    assert len(cid) == Comm.ID_BYTES
+    # the bare collectives
+    c2 = Context(0)
+    comm = Comm(c2, cid, 0, 1)
+    assert (comm.rank, comm.world) == (0, 1)
+    a = dev(xf[:5000]); b = dev(np.zeros((5000, 2), np.float32)); c = dev(np.zeros((5000, 2), np.float32))
+    comm.broadcast(a, 5000, 0)
+    comm.scatter(a, b, 5000, 0)
+    comm.all_to_all(b, [5000], c, [5000])
+    assert comm.max(3.25) == 3.25
+    comm.barrier()
+    assert np.array_equal(host(a), xf[:5000]) and np.array_equal(host(b), xf[:5000]) and np.array_equal(host(c), xf[:5000])
+    comm.close(); c2.close()
+    # broadcast variant
+    sh = ShardedStream(0, 0, 1, fs, M, block, demods, center, nb, comm_id=cid)
+    for t in range(n_batches):
+        sh.step(dev(xf[t * nb * block:(t + 1) * nb * block]), nb, src=0)
+        for i in range(nd):
+            assert np.array_equal(sh.audio(i), whole[t][i]), (t, i)
+            assert [(q.n_iq, q.n_audio, q.nco_theta, q.resamp_phase) for q in sh.results(i)] == counts[t][i], (t, i)
+    sh.close()
+    # time-slab variant: scatter + export / all-to-all / import in one ABI call
+    sl = SlabStream(0, 0, 1, fs, M, block, demods, center, nb, use_torch=use_torch, comm_id=cid)
+    worst = 0.0
+    for t in range(n_batches):
+        sl.step(sl.scatter(dev(xf[t * nb * block:(t + 1) * nb * block]), nb, src=0), nb)
+        for i in range(nd):
+            got = sl.audio(i)
+            assert [(q.n_iq, q.n_audio, q.nco_theta, q.resamp_phase) for q in sl.results(i)] == counts[t][i], (t, i)
+            if not np.array_equal(got, whole[t][i]):
+                worst = max(worst, rel_err(got, whole[t][i]))
+    sl.close()
+    assert worst < 1e-6, worst
+    return worst
+
+
+def test_comm_one_rank_through_the_abi(ctx):
+    print("communicator, one rank: slab worst", _comm_one_rank_case(ctx, True))
+
+
 def test_c2_full_size_batching_invariance(ctx):
     """Size-independent property at the full C2 size: 64 NBFM demodulators, 16 blocks -- the audio, the resampled IQ and
     the per-block counts of one 16-block batch equal, bit for bit, those of 16 one-block batches."""

@@ -1,4 +1,6 @@
-"""The N > 1 path over RCCL on real GPUs: two ranks, one GPU each (backend "nccl" = RCCL over xGMI).  Skipped where fewer than two GPUs
+"""The N > 1 path over RCCL on real GPUs: two ranks, one GPU each -- through the C ABI's communicator (csdr_comm: no torch.distributed
+process group at all, the id travels over a TCP store) and through torch.distributed (backend "nccl" = RCCL over xGMI); plus the C++
+example tests/cpp/comm_ranks.cpp (one rank where one GPU is visible: the same RCCL calls).  Skipped where fewer than two GPUs
 are visible (RCCL refuses two ranks on one device); the same stream classes run on CPU over gloo in tests/test_parallel_gloo.py and as
 virtual ranks on one GPU in tests/test_gpu_parity.py.  What this adds: the collectives, the library's kernels and torch's allocator
 really are ordered by the dedicated boundary stream (cubicsdr_amd/parallel.py: _Boundary) -- every sharded demodulator's audio must equal
@@ -18,14 +20,19 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, mode, q):
+def _worker(rank, world, port, mode, q, transport="torch"):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world)
+    cid = None
+    if transport == "abi":
+        from cubicsdr_amd.parallel import exchange_id
+        cid = exchange_id(rank, world)                        # no process group: the collectives are the library's own
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
     try:
         from cubicsdr_amd.engine import Context, DemodBank, SDRPost
         from cubicsdr_amd.parallel import ShardedStream, SlabStream
@@ -47,10 +54,10 @@ def _worker(rank, world, port, mode, q):
             bank.execute(post)
             want.append({i: bank.audio(i) for i in range(nd)})
         if mode == "broadcast":
-            st = ShardedStream(rank, rank, world, fs, M, block, demods, center, nb)
+            st = ShardedStream(rank, rank, world, fs, M, block, demods, center, nb, comm_id=cid)
             batch = torch.empty(nb * block, 2, dtype=torch.float32, device=dev)
         else:
-            st = SlabStream(rank, rank, world, fs, M, block, demods, center, nb)
+            st = SlabStream(rank, rank, world, fs, M, block, demods, center, nb, comm_id=cid)
         # batches back to back: only the LAST one is inspected after a synchronise, the earlier ones must have been ordered by the streams
         got_last = None
         for t in range(nbat):
@@ -67,11 +74,13 @@ def _worker(rank, world, port, mode, q):
         q.put((rank, ok, list(st.plan.demods)))
         st.close(); bank.close(); post.close(); ctx.close()
     finally:
-        dist.destroy_process_group()
+        if transport != "abi":
+            dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("transport", ["abi", "torch"])
 @pytest.mark.parametrize("mode", ["broadcast", "slab"])
-def test_sharded_streams_over_rccl_equal_unsharded(mode):
+def test_sharded_streams_over_rccl_equal_unsharded(mode, transport):
     import torch
     if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
@@ -79,7 +88,7 @@ def test_sharded_streams_over_rccl_equal_unsharded(mode):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q, transport)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in range(world)]
@@ -91,3 +100,25 @@ def test_sharded_streams_over_rccl_equal_unsharded(mode):
         assert ok, (mode, rank)
         owned += mine
     assert sorted(owned) == list(range(6))
+
+
+def test_cpp_ranks_through_the_c_abi():
+    """tests/cpp/comm_ranks.cpp: one process per GPU in C++ against include/csdr_hip.h alone -- csdr_comm_broadcast / _scatter / _all_to_all /
+    _max on known patterns, then both sharded variants (csdr_post_exchange_rows) against an unsharded channelizer.  Two ranks where two
+    GPUs are visible, else one (the same RCCL entry points with a one-rank communicator)."""
+    import subprocess
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from cubicsdr_amd import build
+    build.build(verbose=False)
+    exe = os.path.join(ROOT, "tests", "cpp", "comm_ranks")
+    src = exe + ".cpp"
+    if not os.path.exists(exe) or os.path.getmtime(src) > os.path.getmtime(exe):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", src, "-o", exe, "-L" + os.path.join(ROOT, "cubicsdr_amd"), "-lcsdr_hip", "-ldl",
+                        "-Wl,-rpath," + os.path.join(ROOT, "cubicsdr_amd")], check=True)
+    world = min(2, torch.cuda.device_count())
+    r = subprocess.run([exe, str(world)], capture_output=True, text=True, timeout=600)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("sharded rows: ok") == world
