@@ -148,7 +148,18 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
     p->chan_rate = mode == CSDR_POST_SINGLE ? sample_rate : (mode == CSDR_POST_PFBCH2 ? 2 * p->chan_bw : p->chan_bw);
     p->max_block_len = max_block_len; p->max_blocks = max_blocks;
     const int M = p->M;
-    p->chan_stride = ((int64_t)max_blocks * (max_block_len / p->hop) + 1) & ~(int64_t)1;
+    // Row pitch of the channel-major output: a multiple of 16 samples (128 bytes, one cache line), so that every row starts on a line: a
+    // 16-frame tile of the M = 1024 channelizer then stores exactly one whole line per channel row, where an unaligned pitch splits every such
+    // store into two partial lines.  Measured on the M = 1024 channelizer, 60 M samples per launch (profiles/r04_row_pitch.txt): pitch 58338
+    // samples (16-byte aligned rows) 0.25 of the HBM roofline, any multiple of 16 .. 2048 samples 0.38.  (The multiple is made odd as well: a
+    // pitch that is a multiple of a large power of two could land the rows a workgroup writes together on few memory channels; on MI355X
+    // that was measured NOT to matter -- 52096 = 2^7 * 407 samples runs at 0.38 too -- so this costs 16 samples per row and buys insurance.)
+    {
+        int64_t q = ((int64_t)max_blocks * (max_block_len / p->hop) + 15) / 16;
+        if (!(q & 1)) ++q;
+        p->chan_stride = q * 16;
+    }
+    if (lab_int("CSDR_ROW_PAD", 1) == 0) p->chan_stride = ((int64_t)max_blocks * (max_block_len / p->hop) + 1) & ~(int64_t)1;      // the round-3 pitch (A/B)
     if (int rc = p->out.reserve((size_t)p->chan_stride * M * csdr_post::kPostBufs)) return rc;
     if (int rc = p->dc_state.reserve(2)) return rc;
     CSDR_HIP_TRY(hipMemsetAsync(p->dc_state.p, 0, 2 * sizeof(d2), st));

@@ -37,6 +37,11 @@ def main(args):
             import torch.distributed as dist
             dist.init_process_group(os.environ.get("CSDR_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
             dist.barrier()
+    # the timed pipeline runs its stages on ONE HIP stream unless told otherwise (as bench.py's default configuration does): every kernel runs
+    # alone, so the live per-kernel durations are the kernels' own; the library's default folding (three streams) overlaps the channelizer of
+    # batch i + 1 with the demodulators of batch i: higher throughput, stretched kernel durations
+    streams = int(os.environ.get("CSDR_STREAMS", getattr(args, "streams", 1)))
+    os.environ["CSDR_STREAMS"] = str(streams)
     NB = args.blocks or 32          # 32 blocks = 427 MB of input per batch: beyond the 256 MB Infinity Cache (16 blocks fit in it and measure 0.39 instead of 0.27 of peak on the channelizer)
     NBATCH = args.batches or 24
     cc = channel_centers(CENTER, FS, M)
@@ -100,7 +105,7 @@ def main(args):
                       "channels_on_rank0": len(st.plan.active_channels), "realtime_multiple": value / (FS / 1e6), "timed_region_s": elapsed,
                       "parallelism": ("time slabs -> per-rank channelizer -> all-to-all of channel rows -> per-rank bank" if slab else
                                       "dp over demodulators (one IQ stream): broadcast + per-rank channel subset + per-rank bank"),
-                      "transport": "torch.distributed" if dist else "csdr_comm (RCCL through the C ABI)" if cid is not None else "none (one rank)"},
+                      "streams": streams, "transport": "torch.distributed" if dist else "csdr_comm (RCCL through the C ABI)" if cid is not None else "none (one rank)"},
            "roofline": {"bound": "hbm", "whole_path": {"bytes_per_sample": round(bytes_per_sample, 1), "achieved": bytes_per_sample * value * 1e6 / 1e9,
                                                        "frac": bytes_per_sample * value * 1e6 / 1e9 / 8000.0 / world}}}
     if prof:

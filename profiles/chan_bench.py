@@ -20,7 +20,7 @@ import bench  # noqa: E402
 from cubicsdr_amd.engine import Context, SDRPost  # noqa: E402
 
 CASES = {"C2": (10_000_000, 20, 166_680, 256), "C3": (61_440_000, 122, 1_024_068, 128), "C5": (100_000_000, 200, 1_666_800, 32),
-         "C4": (100_000_000, 1024, 1_667_072, 16)}
+         "C4": (100_000_000, 1024, 1_667_072, 16), "C4L": (100_000_000, 1024, 1_667_072, 32), "C4X": (100_000_000, 1024, 1_667_072, 35)}
 ITERS = int(os.environ.get("CHAN_BENCH_ITERS", "100"))
 
 

@@ -1267,6 +1267,7 @@ def _comm_one_rank_case(ctx, use_torch):
         whole.append([bank.audio(i) for i in range(nd)])
         counts.append([[(r.n_iq, r.n_audio, r.nco_theta, r.resamp_phase) for r in bank.results(i)] for i in range(nd)])
     bank.close(); post.close()
+    # (a communicator id serves ONE communicator: each object below gets its own)
     cid = exchange_id(0, 1)
     assert len(cid) == Comm.ID_BYTES
     # the bare collectives
@@ -1282,7 +1283,7 @@ def _comm_one_rank_case(ctx, use_torch):
     assert np.array_equal(host(a), xf[:5000]) and np.array_equal(host(b), xf[:5000]) and np.array_equal(host(c), xf[:5000])
     comm.close(); c2.close()
     # broadcast variant
-    sh = ShardedStream(0, 0, 1, fs, M, block, demods, center, nb, comm_id=cid)
+    sh = ShardedStream(0, 0, 1, fs, M, block, demods, center, nb, comm_id=exchange_id(0, 1))
     for t in range(n_batches):
         sh.step(dev(xf[t * nb * block:(t + 1) * nb * block]), nb, src=0)
         for i in range(nd):
@@ -1290,7 +1291,7 @@ def _comm_one_rank_case(ctx, use_torch):
             assert [(q.n_iq, q.n_audio, q.nco_theta, q.resamp_phase) for q in sh.results(i)] == counts[t][i], (t, i)
     sh.close()
     # time-slab variant: scatter + export / all-to-all / import in one ABI call
-    sl = SlabStream(0, 0, 1, fs, M, block, demods, center, nb, use_torch=use_torch, comm_id=cid)
+    sl = SlabStream(0, 0, 1, fs, M, block, demods, center, nb, use_torch=use_torch, comm_id=exchange_id(0, 1))
     worst = 0.0
     for t in range(n_batches):
         sl.step(sl.scatter(dev(xf[t * nb * block:(t + 1) * nb * block]), nb, src=0), nb)
