@@ -42,6 +42,22 @@ inline int lab_int(const char *name, int dflt) {
     return dflt;
 }
 
+// roctx ranges around the stage calls of the C ABI (csdr_post_execute, csdr_bank_execute, csdr_spec_process, the collectives): named spans
+// on the host timeline next to the kernel trace (rocprofv3 --marker-trace --kernel-trace).  Off unless CSDR_ROCTX=1 is set when the first
+// context is created: the tracing library (rocprofiler-sdk's roctx, else roctracer's) is then loaded with dlopen; nothing is linked.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+};
+Roctx &roctx();            // csdr_ctx.hip
+struct RangeScope {
+    bool on;
+    explicit RangeScope(const char *name) : on(roctx().push != nullptr) { if (on) (void)roctx().push(name); }
+    ~RangeScope() { if (on) (void)roctx().pop(); }
+    RangeScope(const RangeScope &) = delete;
+    RangeScope &operator=(const RangeScope &) = delete;
+};
+
 #define CSDR_HIP_TRY(expr)                                                                      \
     do {                                                                                        \
         hipError_t e__ = (expr);                                                                \

@@ -250,6 +250,7 @@ static inline int64_t first_out(int64_t K, uint32_t phase0, uint32_t step) {
 }
 
 extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
+    RangeScope range__("csdr_bank_execute");
     DeviceScope dev__(b ? b->ctx : nullptr);
     if (!b || !post) return fail(CSDR_EINVAL, "null argument");
     if (!post->configured || post->n_blocks <= 0) return fail(CSDR_ESTATE, "post has no data");

@@ -124,6 +124,7 @@ extern "C" int csdr_comm_world(const csdr_comm *m) { return m ? m->world : 0; }
 static int comm_begin(csdr_comm *m) { return m->ctx->join(); }
 
 extern "C" int csdr_comm_broadcast(csdr_comm *m, float *iq_dev, int64_t n_samples, int root) {
+    RangeScope range__("csdr_comm_broadcast");
     DeviceScope dev__(m ? m->ctx : nullptr);
     if (!m || !iq_dev || n_samples < 0 || root < 0 || root >= m->world) return fail(CSDR_EINVAL, "bad argument");
     if (int rc = comm_begin(m)) return rc;
@@ -155,6 +156,7 @@ extern "C" int csdr_comm_scatter(csdr_comm *m, const float *send_dev, float *rec
 // send_samples[q] samples to rank q (consecutive in send_dev), recv_samples[p] from rank p (consecutive in recv_dev): one grouped
 // send / receive per peer pair -- xGMI is point-to-point, every pair has its own link
 extern "C" int csdr_comm_all_to_all(csdr_comm *m, const float *send_dev, const int64_t *send_samples, float *recv_dev, const int64_t *recv_samples) {
+    RangeScope range__("csdr_comm_all_to_all");
     DeviceScope dev__(m ? m->ctx : nullptr);
     if (!m || !send_samples || !recv_samples) return fail(CSDR_EINVAL, "null argument");
     int64_t ts = 0, tr = 0;
@@ -205,6 +207,7 @@ extern "C" int csdr_comm_barrier(csdr_comm *m) { double v = 0.0; return csdr_com
 // batch, in frames (samples per channel).
 extern "C" int csdr_post_exchange_rows(csdr_comm *m, csdr_post *producer, csdr_post *owner, const int *channels, const int *n_channels,
                                        const int64_t *frame0, const int64_t *frames, int n_blocks, int block_len, int64_t frequency) {
+    RangeScope range__("csdr_post_exchange_rows");
     DeviceScope dev__(m ? m->ctx : nullptr);
     if (!m || !producer || !owner || !channels || !n_channels || !frame0 || !frames) return fail(CSDR_EINVAL, "null argument");
     if (producer->ctx != m->ctx || owner->ctx != m->ctx) return fail(CSDR_EINVAL, "posts and communicator belong to different contexts");

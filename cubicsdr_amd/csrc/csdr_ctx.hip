@@ -9,7 +9,30 @@
 #include "common.hpp"
 #include "design.hpp"
 
+#include <dlfcn.h>
+
 using namespace csdr;
+
+namespace csdr {
+Roctx &roctx() { static Roctx r; return r; }
+static void roctx_load_once() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *e = getenv("CSDR_ROCTX");
+        if (!e || atoi(e) == 0) return;
+        for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            void *h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (!h) continue;
+            Roctx &r = roctx();
+            *(void **)(&r.push) = dlsym(h, "roctxRangePushA");
+            *(void **)(&r.pop) = dlsym(h, "roctxRangePop");
+            if (r.push && r.pop) return;
+            r.push = nullptr; r.pop = nullptr;
+            dlclose(h);
+        }
+    });
+}
+}  // namespace csdr
 
 // =================================================================================================== context
 extern "C" int csdr_abi_version(void) { return 1; }
@@ -31,6 +54,7 @@ extern "C" const char *csdr_last_error(void) { return last_error_ref().c_str(); 
 extern "C" int csdr_ctx_create(int device, void *hip_stream, csdr_ctx **out) {
     if (!out) return fail(CSDR_EINVAL, "out is null");
     *out = nullptr;
+    roctx_load_once();
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(CSDR_EHIP, "no HIP device available: the HIP path cannot run (there is no CPU fallback)");

@@ -88,6 +88,7 @@ extern "C" int csdr_scope_set_average_rate(csdr_scope *s, float r) { if (!s) ret
 // n_frames AudioThreadInputs through process() (:45-217), in order: each yields a waveform item (scope enabled) and a spectrum
 // item (spectrum enabled).  Frame data is host memory (staged with ONE copy per call) or device memory read in place.
 extern "C" int csdr_scope_process(csdr_scope *s, const csdr_scope_frame *frames, int n_frames, int data_is_dev) {
+    RangeScope range__("csdr_scope_process");
     DeviceScope dev__(s ? s->ctx : nullptr);
     if (!s || !s->ready) return fail(CSDR_ESTATE, "scope not set up");
     if (!frames || n_frames <= 0) return fail(CSDR_EINVAL, "no frames");
@@ -351,6 +352,7 @@ extern "C" int csdr_mix_queued(const csdr_mix *m, int source) {
 // and hands the arithmetic to audio_mix as pieces.  out_host (may be null: csdr_mix_fetch_pcm16 / a later render read the device
 // copy) receives n_buffers * frames * 2 floats.
 extern "C" int csdr_mix_render(csdr_mix *m, int frames, int n_buffers, float *out_host) {
+    RangeScope range__("csdr_mix_render");
     DeviceScope dev__(m ? m->ctx : nullptr);
     if (!m || frames <= 0 || n_buffers <= 0) return fail(CSDR_EINVAL, "bad argument");
     csdr_ctx *c = m->ctx;
@@ -610,6 +612,7 @@ extern "C" int csdr_ingest_next_slot(const csdr_ingest *g) { return g ? g->next 
 // csdr_host_register and the transfer is a DMA).  The previous upload is waited for first, so at most one is in flight and a caller that
 // alternates between at least two buffers never rewrites one that is still being read.
 extern "C" int csdr_ingest_upload(csdr_ingest *g, const float *host_iq, int64_t n_samples, int iq_swap, const float **dev_iq) {
+    RangeScope range__("csdr_ingest_upload");
     DeviceScope dev__(g ? g->ctx : nullptr);
     if (!g || !host_iq || !dev_iq) return fail(CSDR_EINVAL, "bad argument");
     if (n_samples <= 0 || n_samples > g->cap) return fail(CSDR_ERANGE, "%lld samples (slot holds %lld)", (long long)n_samples, (long long)g->cap);

@@ -278,6 +278,7 @@ static int run_dc_blocker(csdr_post *p, const float2 *x, float2 *y, int64_t n, b
 
 
 extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, int n_blocks, int block_len, int64_t frequency) {
+    RangeScope range__("csdr_post_execute");
     DeviceScope dev__(p ? p->ctx : nullptr);
     if (!p || !p->configured) return fail(CSDR_ESTATE, "post not configured");
     if (!iq || n_blocks <= 0 || block_len <= 0) return fail(CSDR_EINVAL, "bad block arguments");

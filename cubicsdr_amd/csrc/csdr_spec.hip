@@ -512,6 +512,7 @@ static int spec_process_view(csdr_spec *s, const float *iq, int iq_is_dev, int b
 }
 
 extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, int n_blocks, int block_len, int mode) {
+    RangeScope range__("csdr_spec_process");
     DeviceScope dev__(s ? s->ctx : nullptr);
     if (!s || !s->ready) return fail(CSDR_ESTATE, "spec not set up");
     if (!iq || n_blocks <= 0 || block_len <= 0) return fail(CSDR_EINVAL, "bad block arguments");

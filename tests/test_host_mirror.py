@@ -103,6 +103,26 @@ def test_level_squelch_state_machine_matches_oracle():
     assert n == 400 and flips >= 2            # the sequence really opens and closes the squelch
 
 
+@pytest.mark.parametrize("san", ["thread", "address"])
+def test_host_mirror_under_sanitizers(san):
+    """SURVEY 5 (race detection): the C++ host mirror's threads / queues / buffer pools / visual processors (test_host "cpu" mode: every
+    IOThread, ThreadBlockingQueue, ReBuffer and VisualProcessor scenario) built with ThreadSanitizer and with AddressSanitizer and run to a clean exit"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    lib = build_emu.build("")                                  # the host-executing library only resolves the symbols: "cpu" mode never calls into it
+    exe = os.path.join(os.path.dirname(lib), "test_host_" + san)
+    src = os.path.join(ROOT, "tests", "cpp", "test_host.cpp")
+    deps = [src] + [os.path.join(ROOT, "cubicsdr_amd", "host", f) for f in os.listdir(os.path.join(ROOT, "cubicsdr_amd", "host"))]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=" + san, "-fno-omit-frame-pointer", src, "-o", exe, "-L" + os.path.dirname(lib),
+                        "-l:" + os.path.basename(lib), "-ldl", "-Wl,-rpath," + os.path.dirname(lib)], check=True)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66", ASAN_OPTIONS="detect_leaks=0 exitcode=66")
+    r = subprocess.run([exe, "cpu"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "host test ok" in r.stdout and "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr
+
+
 @pytest.mark.gpu
 def test_threaded_pipeline_on_gpu():
     """SDRThreadIQData blocks -> SDRPostThread (HIP) -> NBFM audio queue + spectrum queue, through real threads/queues"""
