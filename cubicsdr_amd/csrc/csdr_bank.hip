@@ -126,6 +126,7 @@ int bank_configure_slot(csdr_bank *b, int slot, const csdr_demod_params *prm, co
     if (!b || !prm || !post) return fail(CSDR_EINVAL, "null argument");
     if (slot < 0 || slot >= b->max_demods) return fail(CSDR_EINVAL, "slot out of range");
     if (!post->configured) return fail(CSDR_ESTATE, "post not configured");
+    if (!post->row_order.empty()) return fail(CSDR_ESTATE, "the post has packed rows (a time-slab producer): demodulators read the owner's post");
     if (prm->bandwidth <= 0 || prm->audio_sample_rate <= 0) return fail(CSDR_EINVAL, "bad rates");
     SlotHost &s = b->slots[slot];
     if (int rc = b->ctx->sync_all()) return rc;
@@ -254,6 +255,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     DeviceScope dev__(b ? b->ctx : nullptr);
     if (!b || !post) return fail(CSDR_EINVAL, "null argument");
     if (!post->configured || post->n_blocks <= 0) return fail(CSDR_ESTATE, "post has no data");
+    if (!post->row_order.empty()) return fail(CSDR_ESTATE, "the post has packed rows (a time-slab producer): demodulators read the owner's post");
     csdr_ctx *c = b->ctx;
     hipStream_t st = c->lanes[LANE_FE], st_a = c->lanes[LANE_AUDIO];
     const int NB = post->n_blocks, M = post->M, Bc = post->block_len / post->hop;

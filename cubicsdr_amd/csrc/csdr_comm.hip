@@ -172,12 +172,38 @@ extern "C" int csdr_comm_all_to_all(csdr_comm *m, const float *send_dev, const i
         if (ts) CSDR_HIP_TRY(hipMemcpyAsync(recv_dev, send_dev, (size_t)ts * sizeof(float2), hipMemcpyDeviceToDevice, st));
         return CSDR_OK;
     }
+    if (send_samples[m->rank] != recv_samples[m->rank]) return fail(CSDR_EINVAL, "a rank's counts to and from itself differ");
     CSDR_RCCL_TRY(rccl().GroupStart());
-    size_t so = 0, ro = 0;
+    size_t so = 0, ro = 0, self_so = 0, self_ro = 0;
     for (int q = 0; q < m->world; ++q) {
-        if (send_samples[q]) CSDR_RCCL_TRY(rccl().Send(send_dev + 2 * so, (size_t)2 * (size_t)send_samples[q], kNcclFloat, q, m->nc, st));
-        if (recv_samples[q]) CSDR_RCCL_TRY(rccl().Recv(recv_dev + 2 * ro, (size_t)2 * (size_t)recv_samples[q], kNcclFloat, q, m->nc, st));
+        if (q == m->rank) { self_so = so; self_ro = ro; }                 // the part that stays on this GPU is a device copy, not a transfer
+        else {
+            if (send_samples[q]) CSDR_RCCL_TRY(rccl().Send(send_dev + 2 * so, (size_t)2 * (size_t)send_samples[q], kNcclFloat, q, m->nc, st));
+            if (recv_samples[q]) CSDR_RCCL_TRY(rccl().Recv(recv_dev + 2 * ro, (size_t)2 * (size_t)recv_samples[q], kNcclFloat, q, m->nc, st));
+        }
         so += (size_t)send_samples[q]; ro += (size_t)recv_samples[q];
+    }
+    CSDR_RCCL_TRY(rccl().GroupEnd());
+    if (send_samples[m->rank])
+        CSDR_HIP_TRY(hipMemcpyAsync(recv_dev + 2 * self_ro, send_dev + 2 * self_so, (size_t)send_samples[m->rank] * sizeof(float2), hipMemcpyDeviceToDevice, st));
+    return CSDR_OK;
+}
+
+// n point-to-point transfers as ONE group (what a scatter of overlapping windows, or any irregular exchange, is made of): op i sends
+// n_samples from `buf` to `peer` (recv == 0) or receives them into `buf` from `peer`.  A rank's own part needs no transfer: peer == rank is refused.
+extern "C" int csdr_comm_p2p(csdr_comm *m, const csdr_p2p_op *ops, int n) {
+    DeviceScope dev__(m ? m->ctx : nullptr);
+    if (!m || n < 0 || (n && !ops)) return fail(CSDR_EINVAL, "bad argument");
+    for (int i = 0; i < n; ++i)
+        if (ops[i].peer < 0 || ops[i].peer >= m->world || ops[i].peer == m->rank || ops[i].n_samples < 0 || (ops[i].n_samples && !ops[i].buf)) return fail(CSDR_EINVAL, "operation %d", i);
+    if (int rc = comm_begin(m)) return rc;
+    if (m->loopback || n == 0) return CSDR_OK;
+    hipStream_t st = m->ctx->stream;
+    CSDR_RCCL_TRY(rccl().GroupStart());
+    for (int i = 0; i < n; ++i) {
+        if (!ops[i].n_samples) continue;
+        if (ops[i].recv) CSDR_RCCL_TRY(rccl().Recv(ops[i].buf, (size_t)2 * (size_t)ops[i].n_samples, kNcclFloat, ops[i].peer, m->nc, st));
+        else CSDR_RCCL_TRY(rccl().Send(ops[i].buf, (size_t)2 * (size_t)ops[i].n_samples, kNcclFloat, ops[i].peer, m->nc, st));
     }
     CSDR_RCCL_TRY(rccl().GroupEnd());
     return CSDR_OK;
@@ -220,28 +246,54 @@ extern "C" int csdr_post_exchange_rows(csdr_comm *m, csdr_post *producer, csdr_p
         total_ch += n_channels[q];
     }
     const int64_t mine_f = frames[me];
-    std::vector<int64_t> sc((size_t)W), rc_((size_t)W);
+    // Producers whose rows are packed in this very order (csdr_post_set_row_order with the concatenated lists) send their output buffer as it
+    // stands: rows at the producer's pitch, the few padding samples of a row travel along (every rank's producer is configured alike, so the
+    // pitch is the same everywhere).  Otherwise the rows each peer owns are packed by a copy first (csdr_post_export_rows).
+    const bool direct = producer->row_order.size() == (size_t)total_ch && std::equal(producer->row_order.begin(), producer->row_order.end(), channels);
+    const int64_t pitch = producer->chan_stride;
+    // the part of this rank's own rows stays on the GPU: it is imported straight from where it lies, not sent to itself
+    std::vector<int64_t> sc((size_t)W), rc_((size_t)W), rstride((size_t)W), soff((size_t)W);
     int64_t ts = 0, tr = 0;
     for (int q = 0; q < W; ++q) {
-        sc[(size_t)q] = (int64_t)n_channels[q] * mine_f; rc_[(size_t)q] = (int64_t)n_channels[me] * frames[q];
+        const int64_t row_len = direct ? pitch : mine_f;
+        soff[(size_t)q] = ts;
+        sc[(size_t)q] = (int64_t)n_channels[q] * row_len;
+        rstride[(size_t)q] = direct ? pitch : frames[q];
+        rc_[(size_t)q] = q == me ? 0 : (int64_t)n_channels[me] * rstride[(size_t)q];
+        if (direct && frames[q] > pitch) return fail(CSDR_ERANGE, "rank %d's slab of %lld frames exceeds the producers' row pitch %lld", q, (long long)frames[q], (long long)pitch);
         ts += sc[(size_t)q]; tr += rc_[(size_t)q];
     }
-    if (int rc = m->send.reserve((size_t)std::max<int64_t>(ts, 1))) return rc;
     if (int rc = m->recv.reserve((size_t)std::max<int64_t>(tr, 1))) return rc;
-    if (mine_f) {
-        int64_t off = 0;
-        for (int q = 0; q < W; ++q) {
-            if (n_channels[q])
-                if (int rc = csdr_post_export_rows(producer, list[(size_t)q], n_channels[q], (float *)(m->send.p + off), mine_f)) return rc;
-            off += sc[(size_t)q];
-        }
+    const float2 *send = nullptr;
+    if (direct) {
+        if (mine_f && producer->n_blocks <= 0) return fail(CSDR_ESTATE, "the producer has not executed");
+        send = post_buf(producer, producer->cur);
+    } else {
+        if (int rc = m->send.reserve((size_t)std::max<int64_t>(ts, 1))) return rc;
+        if (mine_f)
+            for (int q = 0; q < W; ++q)
+                if (n_channels[q])
+                    if (int rc = csdr_post_export_rows(producer, list[(size_t)q], n_channels[q], (float *)(m->send.p + soff[(size_t)q]), mine_f)) return rc;
+        send = m->send.p;
     }
-    if (int rc = csdr_comm_all_to_all(m, (const float *)m->send.p, sc.data(), (float *)m->recv.p, rc_.data())) return rc;
-    if (int rc = csdr_post_import_begin(owner, n_blocks, block_len, frequency)) return rc;      // (lane_begin: the owner's lane starts behind the all-to-all)
+    {   // the transfers: one send / receive per peer pair (nothing to itself)
+        std::vector<csdr_p2p_op> ops;
+        int64_t ro = 0;
+        for (int q = 0; q < W; ++q) {
+            if (q == me) continue;
+            if (sc[(size_t)q] && mine_f) ops.push_back(csdr_p2p_op{q, 0, (float *)(send + soff[(size_t)q]), sc[(size_t)q]});
+            if (rc_[(size_t)q] && frames[q]) ops.push_back(csdr_p2p_op{q, 1, (float *)(m->recv.p + ro), rc_[(size_t)q]});
+            ro += rc_[(size_t)q];
+        }
+        if (int rc = csdr_comm_p2p(m, ops.data(), (int)ops.size())) return rc;          // (joins the lanes: the producer's kernels / export copies are done)
+    }
+    if (int rc = csdr_post_import_begin(owner, n_blocks, block_len, frequency)) return rc;      // (lane_begin: the owner's lane starts behind the transfers)
     int64_t off = 0;
     for (int p = 0; p < W; ++p) {
-        if (n_channels[me] && frames[p])
-            if (int rc = csdr_post_import_rows(owner, list[(size_t)me], n_channels[me], (const float *)(m->recv.p + off), frames[p], frame0[p], frames[p])) return rc;
+        if (n_channels[me] && frames[p]) {
+            const float2 *src = p == me ? send + soff[(size_t)me] : m->recv.p + off;
+            if (int rc = csdr_post_import_rows(owner, list[(size_t)me], n_channels[me], (const float *)src, rstride[(size_t)p], frame0[p], frames[p])) return rc;
+        }
         off += rc_[(size_t)p];
     }
     return csdr_post_import_commit(owner);

@@ -24,6 +24,8 @@ struct csdr_post {
     int n_blocks = 0, block_len = 0;         // of the last execute
     std::vector<int64_t> centers;            // chanCenters[M + 1]
     std::vector<int> active_host;            // sorted list of produced channels
+    std::vector<int> row_order;              // csdr_post_set_row_order: channel of output row i (empty: row = channel).  A post with packed rows is a
+                                             // time-slab PRODUCER: its buffer is the all-to-all's send buffer; no bank reads it, no DC blocker runs on it
     bool active_dirty = true;
     ChanGeom geom{};
     bool use_fft = false;                    // critically sampled, M = 2^a 3^b 5^c 7^d 11^e 13^f: chan_analyze_fft (kernels_chanfft.hpp)

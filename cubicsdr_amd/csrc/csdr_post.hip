@@ -255,8 +255,30 @@ extern "C" int csdr_post_set_active_channels(csdr_post *p, const int *channels, 
         std::sort(v.begin(), v.end());
         v.erase(std::unique(v.begin(), v.end()), v.end());
     }
+    if (!p->row_order.empty()) { p->row_order.clear(); p->active_dirty = true; }
     if (v != p->active_host) { p->active_host = v; p->active_dirty = true; }
     return CSDR_OK;
+}
+// Time-slab producers: store the rows of the listed channels one after the other IN THIS ORDER (row i = channels[i]; the other channels are
+// not produced) -- with the channels grouped by owning rank the output buffer is the all-to-all's send buffer as it stands
+// (csdr_post_exchange_rows then skips the export copy).  n = 0 returns to "row = channel".
+extern "C" int csdr_post_set_row_order(csdr_post *p, const int *channels, int n) {
+    if (!p || !p->configured || p->mode == CSDR_POST_SINGLE) return fail(CSDR_ESTATE, "post is not a configured channelizer");
+    if (n < 0 || n > p->M || (n && !channels)) return fail(CSDR_EINVAL, "bad channel count");
+    std::vector<int> order(channels, channels + n), sorted;
+    for (int c : order) if (c < 0 || c >= p->M) return fail(CSDR_EINVAL, "channel %d out of range", c);
+    sorted = order;
+    std::sort(sorted.begin(), sorted.end());
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return fail(CSDR_EINVAL, "a channel is listed twice");
+    if (n == 0) { sorted.resize(p->M); for (int i = 0; i < p->M; i++) sorted[i] = i; }
+    p->row_order = order; p->active_host = sorted; p->active_dirty = true;
+    return CSDR_OK;
+}
+// output row of channel ch (-1: not produced)
+static int post_row_of(const csdr_post *p, int ch) {
+    if (p->row_order.empty()) return std::binary_search(p->active_host.begin(), p->active_host.end(), ch) ? ch : -1;
+    for (size_t i = 0; i < p->row_order.size(); ++i) if (p->row_order[i] == ch) return (int)i;
+    return -1;
 }
 
 // DC blocker over n samples: `have_ends` = the mini-tile end values (tile_len samples each) are already in tile_end
@@ -309,8 +331,9 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
     else {
         const int M = p->M;
         if (p->active_dirty) {
-            std::vector<int> flags(M, 0);
-            for (int ch : p->active_host) flags[ch] = 1;
+            std::vector<int> flags(M, 0);                                        // output row of the channel + 1; 0 = not produced
+            if (p->row_order.empty()) for (int ch : p->active_host) flags[ch] = ch + 1;
+            else for (size_t i = 0; i < p->row_order.size(); ++i) flags[p->row_order[i]] = (int)i + 1;
             CSDR_HIP_TRY(hipStreamSynchronize(st));                              // earlier launches still read the old flags
             CSDR_HIP_TRY(hipMemcpy(p->active.p, flags.data(), flags.size() * sizeof(int), hipMemcpyHostToDevice));
             p->active_dirty = false;
@@ -323,6 +346,7 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
         // channel 0 carries the DC spike: it is blocked after de-interleave (:364-375); when the tile size allows, the
         // channelizer itself emits the per-tile end values the blocked scan needs
         const bool dc0 = p->dc_enabled && !p->active_host.empty() && p->active_host[0] == 0;
+        if (dc0 && !p->row_order.empty()) return fail(CSDR_ESTATE, "packed rows are for time-slab producers: csdr_post_set_dc_blocker(0) first (channel 0's owner runs the DC blocker)");
         const bool fused_ends = dc0 && g.fpw >= 16;
         if (p->use_fft) {
             // persistent workgroups (as many as are resident at once) walk over the tiles
@@ -387,7 +411,9 @@ extern "C" int csdr_post_read_channel(csdr_post *p, int ch, float *host_out, int
     const int64_t cnt = (int64_t)p->n_blocks * (p->block_len / p->hop);
     if (cnt > cap_samples) return fail(CSDR_ERANGE, "need %lld samples", (long long)cnt);
     hipStream_t st = p->ctx->lanes[LANE_POST];
-    CSDR_HIP_TRY(hipMemcpyAsync(host_out, post_buf(p, p->cur) + (int64_t)ch * p->chan_stride, (size_t)cnt * sizeof(float2), hipMemcpyDeviceToHost, st));
+    const int row = p->row_order.empty() ? ch : post_row_of(p, ch);
+    if (row < 0) return fail(CSDR_EINVAL, "channel %d is not produced", ch);
+    CSDR_HIP_TRY(hipMemcpyAsync(host_out, post_buf(p, p->cur) + (int64_t)row * p->chan_stride, (size_t)cnt * sizeof(float2), hipMemcpyDeviceToHost, st));
     CSDR_HIP_TRY(hipStreamSynchronize(st));
     *n = (int)cnt;
     return CSDR_OK;
@@ -451,7 +477,13 @@ extern "C" int csdr_post_export_rows(csdr_post *p, const int *channels, int n, f
     const int64_t nf = (int64_t)p->n_blocks * (p->block_len / p->hop);
     if (dst_stride < nf) return fail(CSDR_EINVAL, "destination stride %lld below %lld frames", (long long)dst_stride, (long long)nf);
     const int *rows = nullptr;
-    if (int rc = post_row_list(p, channels, n, &rows)) return rc;
+    if (p->row_order.empty()) {
+        if (int rc = post_row_list(p, channels, n, &rows)) return rc;
+    } else {                                                     // packed rows: the listed channels' positions
+        std::vector<int> pos((size_t)std::max(n, 0));
+        for (int i = 0; i < n; ++i) if ((pos[(size_t)i] = post_row_of(p, channels[i])) < 0) return fail(CSDR_EINVAL, "channel %d is not produced", channels[i]);
+        if (int rc = post_row_list(p, pos.data(), n, &rows)) return rc;
+    }
     CSDR_LAUNCH(p->ctx, LANE_POST, KID_ROWS_COPY, rows_copy, dim3((unsigned)std::min<int64_t>(64, (nf + 255) / 256), n), dim3(256), 0,
                 post_buf(p, p->cur), p->chan_stride, rows, (float2 *)dst_dev, dst_stride, (const int *)nullptr, nf);
     CSDR_HIP_TRY(hipGetLastError());
@@ -460,6 +492,7 @@ extern "C" int csdr_post_export_rows(csdr_post *p, const int *channels, int n, f
 extern "C" int csdr_post_import_begin(csdr_post *p, int n_blocks, int block_len, int64_t frequency) {
     DeviceScope dev__(p ? p->ctx : nullptr);
     if (!p || !p->configured || p->mode == CSDR_POST_SINGLE) return fail(CSDR_ESTATE, "post is not a configured channelizer");
+    if (!p->row_order.empty()) return fail(CSDR_ESTATE, "a post with packed rows is a producer: import into a second post object");
     if (n_blocks <= 0 || n_blocks > p->max_blocks || block_len <= 0 || block_len > p->max_block_len || block_len % p->M) return fail(CSDR_ERANGE, "bad batch %d x %d", n_blocks, block_len);
     csdr_ctx *c = p->ctx;
     hipStream_t st = c->lanes[LANE_POST];

@@ -225,8 +225,8 @@ __device__ __forceinline__ void cf_pass_item(float2 *px, int pitch, const float2
 }
 // one butterfly of the last pass (span 1): results go to their channel rows
 template <int R>
-__device__ __forceinline__ void cf_last_item(const float2 *px, int pitch, const int *s_pa, float2 *s_dc, int t, bool live, float2 *__restrict__ o /* out + f0 + t */,
-                                             int64_t out_stride) {
+__device__ __forceinline__ void cf_last_item(const float2 *px, int pitch, const int *s_pa, float2 *s_dc /* non-null: this butterfly holds channel 0 (position 0) and its tile values are wanted */,
+                                             int t, bool live, float2 *__restrict__ o /* out + f0 + t */, int64_t out_stride) {
     float2 v[R];
     int k[R];
 #pragma unroll
@@ -234,7 +234,7 @@ __device__ __forceinline__ void cf_last_item(const float2 *px, int pitch, const 
     CfDft<R>::run(v);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        if (k[r] == 0 && s_dc) s_dc[t] = v[r];
+        if (r == 0 && s_dc) s_dc[t] = v[0];
         if (k[r] >= 0 && live) st_stream(o + (int64_t)k[r] * out_stride, v[r]);
     }
 }
@@ -287,7 +287,7 @@ CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
     const float *__restrict__ tapsT,     // [8][M]  tapsT[n M + c] multiplies x[(t - n) M + c]
     const float2 *__restrict__ twM,      // [M] exp(-j 2 pi i / M)
     const int *__restrict__ perm,        // [M] position after the last pass -> channel
-    const int *__restrict__ active,      // [M] 1: store channel row k
+    const int *__restrict__ active,      // [M] output row of channel k + 1; 0: not stored
     ChanFftGeom g, int64_t n_frames,
     float2 *__restrict__ out, int64_t out_stride,
     d2 *__restrict__ dc_ends, double dc_c /* DC blocker of channel 0: end value of each tile's recurrence (zero entering state) */) {
@@ -296,9 +296,9 @@ CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
     float2 *s_x = reinterpret_cast<float2 *>(smem);                  // X[c][t], pitch TFs
     float2 *s_tw = s_x + (size_t)M * TFs;                            // W_M^i
     float2 *s_dc = s_tw + M;                                         // channel 0 of the tile
-    int *s_pa = reinterpret_cast<int *>(s_dc + TF);                  // position -> channel, or -1 when the row has no consumer
+    int *s_pa = reinterpret_cast<int *>(s_dc + TF);                  // position -> output row of its channel (the channel itself unless the rows are packed), or -1 when it has no consumer
     const int tid = threadIdx.x, nthr = blockDim.x;
-    for (int i = tid; i < M; i += nthr) { s_tw[i] = twM[i]; const int k = perm[i]; s_pa[i] = active[k] ? k : -1; }
+    for (int i = tid; i < M; i += nthr) { s_tw[i] = twM[i]; s_pa[i] = active[perm[i]] - 1; }          // active[k] = output row of channel k + 1, 0 = not stored
 
     const int64_t ntiles = (n_frames + TF - 1) >> g.lgTF;
     const int half = M >> 1, nfir = half * (TF / kCfSeg);
@@ -357,7 +357,7 @@ CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
                     }
                 } else {
                     float2 *o = out + f0 + t;
-                    float2 *dcp = dc_ends ? s_dc : nullptr;
+                    float2 *dcp = (dc_ends && pos0 == 0) ? s_dc : nullptr;          // position 0 is channel 0 in every digit order
                     const int *pa = s_pa + pos0;
                     const bool live = t < nf;
                     switch (R) {

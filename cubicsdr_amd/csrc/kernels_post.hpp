@@ -310,10 +310,10 @@ __device__ __forceinline__ void chan_phase2(const ChanGeom &g, float2 *s_x, cons
 #pragma unroll
         for (int j = 0; j < K; ++j) acc[j] = cmul(acc[j], pr[min(k + j * A, M - 1)]);
     }
-    float2 *o = out + (int64_t)k * out_stride + f0 + t;
+    float2 *o = out + f0 + t;
     if (k == 0 && keep0) s_x[t] = acc[0];                 // channel 0 of this tile (s_x is free after phase 1)
 #pragma unroll
-    for (int j = 0; j < K; ++j) if (k2b + j < B && on[j]) o[(int64_t)j * A * out_stride] = acc[j];
+    for (int j = 0; j < K; ++j) if (k2b + j < B && on[j]) o[(int64_t)(on[j] - 1) * out_stride] = acc[j];      // on = output row of the channel + 1
 }
 
 template <int STAGE_IN, int TAPS_LDS, int OS2 /* 1: frames hop by M / 2 and may start at odd sample offsets */,
@@ -326,7 +326,7 @@ CSDR_KERNEL __launch_bounds__(64 * kChanMaxWaves) void chan_analyze(
     const float2 *__restrict__ twA,      // [A][PA] exp(-j 2 pi k1 c1 / A) at [c1 PA + k1], zero padded
     const float2 *__restrict__ twB,      // [B][PB] exp(-j 2 pi k2 c2 / B) at [c2 PB + k2], zero padded
     const float2 *__restrict__ twM,      // [A][B]  exp(-j 2 pi k1 c2 / M) at [k1 B + c2]
-    const int *__restrict__ active,      // [M] 1: store channel row k
+    const int *__restrict__ active,      // [M] output row of channel k + 1 (the channel itself unless the rows are packed); 0: not stored
     ChanGeom g, int64_t n_frames,
     float2 *__restrict__ out, int64_t out_stride,
     d2 *__restrict__ dc_ends, double dc_c /* DC blocker of channel 0: end value of this tile's recurrence (zero entering state) */,
@@ -705,16 +705,18 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
                         const float2 u = cmul(make_float2(P1[j].x + Q1[j].y, P1[j].y - Q1[j].x), wk);
                         const float2 v = cmul(make_float2(P1[j].x - Q1[j].y, P1[j].y + Q1[j].x), wn);
                         if (tv) {                                       // streaming-hint stores: nothing in this kernel reads the rows again, they stay out of the way of the window rows two waves share (12.6 -> 10.5 B/sample fetched on C3)
-                            if (on0) store_row_nt(ob + (int64_t)k * out_stride, tb, make_float2(z0k.x + u.x, z0k.y + u.y));
-                            if (on1) store_row_nt(ob + (int64_t)(k + A) * out_stride, tb, make_float2(z0k.x - u.x, z0k.y - u.y));
-                            if (on2) store_row_nt(ob + (int64_t)kn * out_stride, tb, make_float2(z0n.x + v.x, z0n.y + v.y));
-                            if (on3) store_row_nt(ob + (int64_t)(kn + A) * out_stride, tb, make_float2(z0n.x - v.x, z0n.y - v.y));
+                            // (on = output row of the channel + 1: the channel itself unless the rows are packed, csdr_post_set_row_order)
+                            if (on0) store_row_nt(ob + (int64_t)(on0 - 1) * out_stride, tb, make_float2(z0k.x + u.x, z0k.y + u.y));
+                            if (on1) store_row_nt(ob + (int64_t)(on1 - 1) * out_stride, tb, make_float2(z0k.x - u.x, z0k.y - u.y));
+                            if (on2) store_row_nt(ob + (int64_t)(on2 - 1) * out_stride, tb, make_float2(z0n.x + v.x, z0n.y + v.y));
+                            if (on3) store_row_nt(ob + (int64_t)(on3 - 1) * out_stride, tb, make_float2(z0n.x - v.x, z0n.y - v.y));
                         }
                     } else if (q == H) {                                // k = 0: P = sum of the column, Q = 0
                         const float2 y0 = make_float2(P0[j].x + P1[j].x, P0[j].y + P1[j].y);
                         if (tv) {
-                            if (active[0]) store_row(ob, tb, y0);
-                            if (active[A]) store_row(ob + (int64_t)A * out_stride, tb, make_float2(P0[j].x - P1[j].x, P0[j].y - P1[j].y));
+                            const int r0 = active[0], rA = active[A];
+                            if (r0) store_row(ob + (int64_t)(r0 - 1) * out_stride, tb, y0);
+                            if (rA) store_row(ob + (int64_t)(rA - 1) * out_stride, tb, make_float2(P0[j].x - P1[j].x, P0[j].y - P1[j].y));
                         }
                         if (dc_ends) {
                             // v_end = sum_t c^(nf-1-t) y0[t]: the DC blocker's state after this tile if it entered with zero (iirfilt, :375)

@@ -121,6 +121,11 @@ class SDRPost:
             a = np.ascontiguousarray(channels, dtype=np.int32)
             H.check(self._l.csdr_post_set_active_channels(self.h, a.ctypes.data_as(C.c_void_p), a.size))
 
+    def set_row_order(self, channels=None):
+        """time-slab producers: rows stored in this channel order (csdr_post_set_row_order); None = row is the channel"""
+        a = np.ascontiguousarray(channels if channels is not None else [], dtype=np.int32)
+        H.check(self._l.csdr_post_set_row_order(self.h, a.ctypes.data_as(C.c_void_p) if a.size else None, a.size))
+
     def execute(self, iq, n_blocks, block_len, frequency):
         p, is_dev, n, keep = _as_iq_arg(iq)
         if n < n_blocks * block_len:
@@ -505,6 +510,14 @@ class Comm:
         b = np.ascontiguousarray(recv_samples, dtype=np.int64)
         assert a.size == self.world and b.size == self.world
         H.check(self._l.csdr_comm_all_to_all(self.h, self._ptr(send), a.ctypes.data_as(C.c_void_p), self._ptr(recv), b.ctypes.data_as(C.c_void_p)))
+
+    def p2p(self, ops):
+        """ops: [(peer, recv, buffer, byte_offset_in_samples, n_samples)] -- one grouped set of sends (recv False) and receives"""
+        arr = (H.P2pOp * max(1, len(ops)))()
+        for i, (peer, recv, buf, off, n) in enumerate(ops):
+            base = self._ptr(buf).value or 0
+            arr[i] = H.P2pOp(int(peer), 1 if recv else 0, base + 8 * int(off), int(n))
+        H.check(self._l.csdr_comm_p2p(self.h, arr, len(ops)))
 
     def max(self, value):
         v = C.c_double(float(value))

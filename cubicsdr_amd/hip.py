@@ -29,6 +29,10 @@ class BlockResult(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
+class P2pOp(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("recv", C.c_int32), ("buf", C.c_void_p), ("n_samples", C.c_int64)]
+
+
 class ScopeFrame(C.Structure):
     _fields_ = [("data", C.c_void_p), ("n_dev", C.c_void_p), ("n", C.c_int32), ("channels", C.c_int32), ("type", C.c_int32),
                 ("sample_rate", C.c_int32), ("input_rate", C.c_int32), ("layout", C.c_int32), ("scale", C.c_float)]
@@ -75,6 +79,7 @@ ABI = {
     "csdr_post_channel_rate": (_i64, [_p]),
     "csdr_post_num_channels": (_i, [_p]),
     "csdr_post_kernel_name": (C.c_char_p, [_p]),
+    "csdr_post_set_row_order": (_i, [_p, _p, _i]),
     "csdr_post_channel_center": (_i64, [_p, _i]),
     "csdr_post_channel_at": (_i, [_p, _i64]),
     "csdr_post_read_channel": (_i, [_p, _i, _p, _i, C.POINTER(_i)]),
@@ -152,6 +157,7 @@ ABI = {
     "csdr_comm_broadcast": (_i, [_p, _p, _i64, _i]),
     "csdr_comm_scatter": (_i, [_p, _p, _p, _i64, _i]),
     "csdr_comm_all_to_all": (_i, [_p, _p, _p, _p, _p]),
+    "csdr_comm_p2p": (_i, [_p, _p, _i]),
     "csdr_comm_max": (_i, [_p, C.POINTER(_d)]),
     "csdr_comm_barrier": (_i, [_p]),
     "csdr_post_exchange_rows": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64]),

@@ -238,6 +238,9 @@ class SlabStream:
         self.comm = Comm(self.ctx, comm_id, rank, world) if comm_id is not None else None
         self.producer = SDRPost(self.ctx, fs, M, block, max_blocks=max(1, -(-max_blocks // world)))
         self.producer.set_dc_blocker(False)
+        if self.comm is not None:
+            # the producer writes its rows grouped by owning rank: its output buffer is the all-to-all's send buffer (no export copy)
+            self.producer.set_row_order([c for o in self.owned for c in o])
         self.rows = SDRPost(self.ctx, fs, M, block, max_blocks=max_blocks)
         self.rows.set_active_channels(self.owned[rank] if self.owned[rank] else [0])
         self.hist = self.producer.history_length
@@ -296,7 +299,10 @@ class SlabStream:
         return ext[start * self.block: start * self.block + self.hist + cnt * self.block]
 
     def scatter(self, batch, n_blocks, src=0):
-        """collective: every rank gets its window [history | its blocks]; needs n_blocks % world == 0 (equal windows)"""
+        """collective: every rank gets its window [history | its blocks].  Through torch.distributed: one buffer, needs n_blocks % world == 0
+        (equal windows).  Through the C ABI (comm_id given): returns (history, blocks) -- see _scatter_abi."""
+        if self.comm is not None:
+            return self._scatter_abi(batch, n_blocks, src)
         import torch.distributed as dist
         if n_blocks % self.world:
             raise ValueError("scatter needs the batch's blocks to divide evenly over the ranks")
@@ -308,17 +314,52 @@ class SlabStream:
             if self.rank == src:
                 ext = self.extended(batch, n_blocks)
                 parts = [self._t(self.window(ext, n_blocks, r)).contiguous() for r in range(self.world)]
-            if self.comm is not None:
-                packed = None
-                if self.rank == src:                                # the overlapping windows, one after the other
-                    packed = self._empty(each * self.world)
-                    for r in range(self.world):
-                        packed[r * each:(r + 1) * each] = self.window(ext, n_blocks, r)
-                self.comm.scatter(packed, mine, each, src)
-                self._keep_scatter = packed
-            else:
-                dist.scatter(self._t(mine), parts, src=src, group=self.group)
+            dist.scatter(self._t(mine), parts, src=src, group=self.group)
         return mine
+
+    def _scatter_abi(self, batch, n_blocks, src):
+        """The ingest rank sends every OTHER rank its window straight out of the batch -- a window starts `hist` samples in front of the rank's
+        first block: inside the batch for every slab but the first, whose history is the tail of the previous batch -- as one group of
+        point-to-point transfers (csdr_comm_p2p); its own slab is used where it lies.  No packing, no copy of the batch on the ingest rank.
+        Returns (history, blocks): `hist` samples and the rank's slab (uneven slabs are fine)."""
+        sl = slab_blocks(n_blocks, self.world)
+        start, cnt = sl[self.rank]
+        n = n_blocks * self.block
+        if any(s and s * self.block < self.hist for s, _ in sl):
+            raise ValueError("blocks shorter than the channelizer's history: use torch.distributed's scatter path")
+        with self.boundary.on():
+            if self.rank == src:
+                ops = []
+                for r, (s0, c) in enumerate(sl):
+                    if r == src or c == 0:
+                        continue
+                    if s0 == 0:
+                        ops += [(r, False, self._tail, 0, self.hist), (r, False, batch, 0, c * self.block)]
+                    else:
+                        ops.append((r, False, batch, s0 * self.block - self.hist, self.hist + c * self.block))
+                self.comm.p2p(ops)                                   # (joins the library's lanes first)
+                tail = self._tail if start == 0 else batch[start * self.block - self.hist: start * self.block]
+                blocks = batch[start * self.block:(start + cnt) * self.block]
+                new_tail = self._empty(self.hist)                    # the input in front of the NEXT batch
+                if n >= self.hist:
+                    new_tail[...] = batch[n - self.hist:n]
+                else:
+                    new_tail[:self.hist - n] = self._tail[n:]
+                    new_tail[self.hist - n:] = batch[:n]
+                self._keep_scatter = (self._tail, batch)
+                self._tail = new_tail
+            else:
+                recv = self._empty(self.hist + cnt * self.block)
+                if cnt == 0:
+                    ops = []
+                elif start == 0:
+                    ops = [(src, True, recv, 0, self.hist), (src, True, recv, self.hist, cnt * self.block)]
+                else:
+                    ops = [(src, True, recv, 0, self.hist + cnt * self.block)]
+                self.comm.p2p(ops)
+                tail, blocks = recv[:self.hist], recv[self.hist:]
+                self._keep_scatter = recv
+        return tail, blocks
 
     # ---- the three phases
     def produce(self, window, n_blocks):
@@ -375,14 +416,15 @@ class SlabStream:
         if self.comm is None:
             self.consume(self.exchange(self.produce(window, n_blocks), n_blocks), n_blocks)
             return
-        # through the C ABI: producer execute, then export -> all-to-all (RCCL) -> import -> commit in ONE call
+        # through the C ABI: producer execute, then the row exchange (RCCL) -> import -> commit in ONE call
         sl = slab_blocks(n_blocks, self.world)
         start, cnt = sl[self.rank]
+        tail, blocks = window if isinstance(window, tuple) else (window[:self.hist], window[self.hist:])
         with self.boundary.on():
             self.ctx.join()
             if cnt:
-                self.producer.set_history(window, self.hist)
-                self.producer.execute(window[self.hist:], cnt, self.block, self.center)
+                self.producer.set_history(tail, self.hist)
+                self.producer.execute(blocks, cnt, self.block, self.center)
             self.comm.exchange_rows(self.producer, self.rows, self.owned, [b * self.bc for b, _ in sl], [c * self.bc for _, c in sl],
                                     n_blocks, self.block, self.center)
             self._keep = [window]

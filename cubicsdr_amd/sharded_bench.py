@@ -49,6 +49,9 @@ def main(args):
     g = torch.Generator(device=device); g.manual_seed(0xC0B1C5D2)
     ring = torch.randn(NB * BLOCK, 2, generator=g, device=device, dtype=torch.float32) * 0.05 + 0.01
     slab = getattr(args, "shard", "broadcast") == "slab"
+    if slab and cid is None and dist is None and os.environ.get("CSDR_C4_TRANSPORT", "abi") == "abi":
+        from cubicsdr_amd.parallel import exchange_id
+        cid = exchange_id(rank, world)              # one rank: the same calls (scatter, packed producer rows, csdr_post_exchange_rows) on a one-rank communicator
     if slab and NB % world:
         raise SystemExit("--shard slab needs --blocks divisible by the number of GPUs")
     if slab:
@@ -60,7 +63,7 @@ def main(args):
         for _ in range(NBATCH):
             if not slab:
                 st.step(ring, NB, src=0)
-            elif world > 1:
+            elif world > 1 or st.comm is not None:
                 st.step(st.scatter(ring if rank == 0 else None, NB, src=0), NB)
             else:
                 ext = st.extended(ring, NB)

@@ -130,6 +130,10 @@ int  csdr_post_read_channel(csdr_post *post, int ch, float *host_out, int cap_sa
  * channels of the last execute -> dst_dev[i * dst_stride + frame], complex float).  Owner side, on a second post object configured alike:
  * csdr_post_import_begin, csdr_post_import_rows per peer (its frames at frame0), csdr_post_import_commit; then csdr_bank_execute. */
 int  csdr_post_history_length(const csdr_post *post);
+/* producer only: store the rows of the listed channels one after the other in THIS order (row i = channels[i]; other channels are not
+ * produced; n = 0: back to "row = channel").  With the channels grouped by owning rank the output buffer IS the all-to-all's send buffer:
+ * csdr_post_exchange_rows then sends it as it stands (no export copy).  Such a post cannot feed a bank or run the DC blocker. */
+int  csdr_post_set_row_order(csdr_post *post, const int *channels, int n);
 int  csdr_post_set_history(csdr_post *post, const float *dev_tail, int64_t n_samples);
 int  csdr_post_set_dc_blocker(csdr_post *post, int enabled);
 int  csdr_post_export_rows(csdr_post *post, const int *channels, int n, float *dst_dev, int64_t dst_stride);
@@ -362,6 +366,10 @@ int  csdr_comm_world(const csdr_comm *comm);
 int  csdr_comm_broadcast(csdr_comm *comm, float *iq_dev, int64_t n_samples, int root);
 int  csdr_comm_scatter(csdr_comm *comm, const float *send_dev, float *recv_dev, int64_t n_samples, int root);
 int  csdr_comm_all_to_all(csdr_comm *comm, const float *send_dev, const int64_t *send_samples, float *recv_dev, const int64_t *recv_samples);
+typedef struct csdr_p2p_op { int32_t peer; int32_t recv; float *buf; int64_t n_samples; } csdr_p2p_op;
+/* n point-to-point transfers as one group (a scatter of overlapping windows, any irregular exchange): op i sends n_samples from buf to peer
+ * (recv == 0) or receives them into buf; peer == this rank is refused (a rank's own part needs no transfer) */
+int  csdr_comm_p2p(csdr_comm *comm, const csdr_p2p_op *ops, int n);
 int  csdr_comm_max(csdr_comm *comm, double *value);
 int  csdr_comm_barrier(csdr_comm *comm);
 int  csdr_post_exchange_rows(csdr_comm *comm, csdr_post *producer, csdr_post *owner, const int *channels, const int *n_channels,

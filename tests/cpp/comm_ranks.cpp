@@ -104,6 +104,7 @@ static int run_rank(int rank, int world, const char *id) {
     CHECK(csdr_post_set_active_channels(shard, mine.data(), (int)mine.size()));
     CHECK(csdr_post_set_active_channels(owner, mine.data(), (int)mine.size()));
     CHECK(csdr_post_set_dc_blocker(producer, 0));
+    CHECK(csdr_post_set_row_order(producer, all_ch.data(), (int)all_ch.size()));      // rows grouped by owner: the output buffer is the send buffer
     const int H = csdr_post_history_length(producer);
     const size_t batch = (size_t)nb * block, each = (size_t)H + 2 * (size_t)block;
     void *d_batch = nullptr, *d_packed = nullptr, *d_win = nullptr;

@@ -246,3 +246,8 @@ def test_emu_cpp_comm_ranks(ctx):
                     "-Wl,-rpath," + os.path.dirname(lib)], check=True)
     r = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "sharded rows: ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("M", [10, 20, 68])
+def test_emu_packed_row_order(ctx, M):
+    G.test_packed_row_order_holds_the_same_rows(ctx, M)

@@ -1317,6 +1317,35 @@ def _comm_one_rank_case(ctx, use_torch):
     return worst
 
 
+@pytest.mark.parametrize("M", [10, 20, 68, 122])
+def test_packed_row_order_holds_the_same_rows(ctx, M):
+    """csdr_post_set_row_order (time-slab producers: rows grouped by owning rank, so that the output buffer is the all-to-all's send buffer):
+    for a three-rank channel plan the packed post's rows -- read back by channel, and exported -- equal the plain post's bit for bit, in all
+    three channelizer kernels (M = 10 / 122: chan_analyze_p2, 20: chan_analyze_fft, 68: chan_analyze); unlisted channels are refused."""
+    from cubicsdr_amd.engine import SDRPost
+    from cubicsdr_amd.hip import CsdrError
+    fs, block, center = 500000 * M, M * 150, 100000000
+    x = [synth_iq(block, fs, center, [("NBFM", center + 123456)], seed=5 + b, t0=b * block) for b in range(2)]
+    plain = SDRPost(ctx, fs, M, block)
+    packed = SDRPost(ctx, fs, M, block)
+    plain.set_dc_blocker(False); packed.set_dc_blocker(False)
+    owned = [[k for k in range(M) if k % 3 == q and k != 5] for q in range(3)]        # channel 5 has no owner
+    order = [c for o in owned for c in o]
+    packed.set_row_order(order)
+    for b in range(2):
+        plain.execute(x[b], 1, block, center)
+        packed.execute(x[b], 1, block, center)
+        for ch in order:
+            assert np.array_equal(packed.read_channel(ch), plain.read_channel(ch)), (b, ch)
+    with pytest.raises(CsdrError):
+        packed.read_channel(5)
+    packed.set_row_order(None)                                                       # back to row = channel, every channel produced
+    packed.execute(x[1], 1, block, center)
+    plain.execute(x[1], 1, block, center)
+    assert np.array_equal(packed.read_channel(5), plain.read_channel(5))
+    plain.close(); packed.close()
+
+
 def test_comm_one_rank_through_the_abi(ctx):
     print("communicator, one rank: slab worst", _comm_one_rank_case(ctx, True))
 
