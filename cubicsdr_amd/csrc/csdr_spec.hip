@@ -8,6 +8,7 @@
 
 #include "csdr_objects.hpp"
 #include "kernels_spec.hpp"
+#include "kernels_spec2.hpp"
 
 using namespace csdr;
 
@@ -61,6 +62,8 @@ struct csdr_spec {
     long vmap_bw = -1, vmap_rbw = -1;
     DevBuf<float2> peakf;
     bool view_frame = false;                 // the frames being post-processed belong to the zoomed view
+    bool fused_ok = false;                   // N = 2^17: the 512 x 256 factorisation with the averaging fused into the row pass exists (kernels_spec2.hpp)
+    bool fused_now = false;                  // ... and this batch takes it (full-span view, no peak hold pending)
 };
 
 extern "C" int csdr_spec_create(csdr_ctx *ctx, csdr_spec **out) {
@@ -127,6 +130,11 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     CSDR_HIP_TRY(hipMemcpy(s->tw_lo.p, lo.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
     CSDR_HIP_TRY(hipMemcpy(s->tw_hi.p, hi.data(), hi.size() * sizeof(float2), hipMemcpyHostToDevice));
     const size_t nfN = (size_t)max_frames * N, F = (size_t)g.F;
+    // (measurement builds only, CSDR_SPEC_FUSED=1: parity-green against the reference's class over 953 frames, but first measured at 0.47 + 0.77 ms
+    // per C3 batch against 0.34 + 0.28 + 0.18 ms for radix pass + row pass + averaging kernel: one four-wave workgroup per CU cannot hide the
+    // dependent chain of its row transforms -- DESIGN 12)
+    s->fused_ok = N == kC512 * kR2 && lab_int("CSDR_SPEC_FUSED", 0) != 0;
+    if (s->fused_ok) CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_cols512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC512Lds));
     if (g.Ra > 1) if (int rc = s->tmp.reserve(nfN)) return rc;
     if (int rc = s->mag.reserve(2 * nfN)) return rc;
     s->n_avg_tiles = (g.F + kAvgLanes - 1) / kAvgLanes;
@@ -193,6 +201,12 @@ static void launch_radix(csdr_ctx *c, int R, const FrameSrc &fs, int L, unsigned
 static int spec_run_fft(csdr_spec *s, const FrameSrc &fs, int nf, float *mag, float2 *raw) {
     const SpecGeom &g = s->g;
     csdr_ctx *c = s->ctx;
+    if (s->fused_now && !raw) {
+        // pass 1 of the 512 x 256 factorisation: Z[f][k1][n2] into `tmp`; pass 2 runs fused with the averaging (spec_post_range)
+        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_COLS, spec_cols512, dim3(g.N / kC512 / kC512Cols, nf), dim3(kFftThreads), kC512Lds, fs, g.N, s->tw4096.p, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
+        CSDR_HIP_TRY(hipGetLastError());
+        return CSDR_OK;
+    }
     if (g.N < 4096) {
         CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_small, dim3(1, nf), dim3(kFftThreads), (size_t)2 * g.N * sizeof(float2), fs, g.N, s->tw4096.p, mag, raw);
     } else if (g.Ra == 1) {
@@ -225,6 +239,21 @@ static int spec_post_range(csdr_spec *s, const float *mag, int f0, int cnt, int 
     // frame groups per workgroup: up to 16 frames each, so a short batch does not pay the set-up of sixteen groups
     // (CSDR_AVG_GROUPS = 4 | 8 | 16 caps the groups: fewer, smaller workgroups let two of them share a CU -- one loads its round while the
     // other scans)
+    if (s->fused_now) {
+        if (hold || view) return fail(CSDR_ESTATE, "internal: the fused spectrum pass was chosen for a batch that holds peaks");
+        const int npairs = kC512 / 2;
+        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_rows256_avg, dim3(npairs), dim3(kFftThreads), kR2Lds, s->tmp.p + (size_t)f0 * g.N, cnt, g, (double)s->avg_rate, s->tw4096.p,
+                    s->ma.p, s->maa.p, s->pairsum.p + f0 * F, s->first_b.p + f0, s->ext_w.p + (size_t)f0 * npairs);
+        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_extrema, dim3(cnt), dim3(256), 64, s->ext_w.p + (size_t)f0 * npairs, npairs, s->ext.p + f0);
+        const SpecScalars *st_in = s->scal.p + s->scal_parity;
+        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_trackers, dim3(cnt), dim3(kDispThreads), kTrackLds, s->ext.p + f0, cnt, st_in, s->scal.p + (s->scal_parity ^ 1),
+                    s->fo.p + f0, s->fsc.p + f0, cnt, (const SpecFrameOut *)nullptr);
+        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_DISPLAY, spec_display_rows256, dim3(64, cnt), dim3(kDispThreads), 32 * 33 * sizeof(float),
+                    s->pairsum.p + f0 * F, s->first_b.p + f0, s->fsc.p + f0, g, s->scale, s->points.p + f0 * F);
+        s->scal_parity ^= 1;
+        CSDR_HIP_TRY(hipGetLastError());
+        return CSDR_OK;
+    }
     static const int avg_cap = std::max(1, std::min(kAvgGroups, lab_int("CSDR_AVG_GROUPS", kAvgGroupsDefault)));
     const int avg_groups = std::max(1, std::min(avg_cap, (cnt + kAvgGMax - 1) / kAvgGMax));
     CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_average, dim3(s->n_avg_tiles), dim3(kAvgLanes * avg_groups), avg_lds_bytes(avg_groups), mag + (size_t)f0 * g.N, cnt, g, (double)s->avg_rate,
@@ -351,7 +380,7 @@ template <typename PostFn>
 static int spec_fft_then(csdr_spec *s, const FrameSrc &fs, int nf, PostFn post) {
     csdr_ctx *c = s->ctx;
     // lane FFT fills magnitude copy `mp`; its previous reader was the averaging kernel two batches ago
-    const int mp = c->same(LANE_FFT, LANE_AVG) ? 0 : (int)(s->seq & 1);
+    const int mp = (c->same(LANE_FFT, LANE_AVG) || s->fused_now) ? 0 : (int)(s->seq & 1);      // (fused: the one intermediate buffer is the hand-off)
     float *mag = s->mag.p + (size_t)mp * s->max_frames * s->g.N;
     if (s->avg_pending[mp]) if (int rc = c->wait(s->ev_avg_done[mp], LANE_AVG, LANE_FFT)) return rc;
     if (int rc = spec_run_fft(s, fs, nf, mag, nullptr)) return rc;
@@ -372,6 +401,7 @@ static int spec_process_view(csdr_spec *s, const float *iq, int iq_is_dev, int b
     csdr_ctx *c = s->ctx;
     const int N = s->g.N, F = s->g.F;
     const int64_t rate = s->input_rate;
+    s->fused_now = false;                                                        // the zoomed view keeps per-bin values: the general kernels
     s->nf_last = 0;
     s->hold_valid.clear();
     // head of process() (:247, :264-273): doPeak is taken before the countdown moves; a reset uses the trackers as they stand
@@ -526,6 +556,8 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
     const int N = g.N;
     const int64_t n = (int64_t)n_blocks * block_len;
     const float2 *x = (const float2 *)iq;
+    // full-span view, no peak hold set or pending: the 512 x 256 factorisation with the averaging fused into its row pass
+    s->fused_now = s->fused_ok && !s->peak_hold && s->peak_reset == 0;
     if (int rc = c->lane_begin(LANE_FFT)) return rc;
     if (!iq_is_dev) {
         if (int rc = s->stage_in.reserve((size_t)n)) return rc;

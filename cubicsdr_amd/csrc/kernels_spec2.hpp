@@ -1,0 +1,212 @@
+// kernels_spec2.hpp -- the spectrum chain on the N = 512 x R factorisation (headline size N = 2^17: R = 256), with the averaging fused into the
+// second transform pass.
+//
+// Replaces (reference file:line): fft_execute SpectrumVisualProcessor.cpp:439, magnitude + fftshift :441-452, the double EMA and the running
+// extrema :494-511 -- for the full-span view without peak hold (the other cases run the kernels of kernels_spec.hpp).
+//
+// Why another factorisation.  The averagers recur over FRAMES per bin; a transform pass that is to carry them in registers has to own its
+// bins for the whole batch and walk the frames in order.  With 4096-point rows (kernels_spec.hpp) a frame of 2^17 points has 16 row pairs:
+// sixteen workgroups.  With N = 512 x 256 the second pass has 512 rows of 256 points: 256 row PAIRS (rows k1 even and k1 + 1 hold the two
+// adjacent bins k1 + 512 k2, k1 + 1 + 512 k2 of one display point), one workgroup each, every thread owning ONE display point's two bins:
+// four doubles of averager state, the reference's statements as they are (NaN repairs included), no frame groups, no blocked scan.  The
+// magnitudes never leave the CU: 8 B/sample of traffic less than row FFT -> magnitudes -> averaging kernel.
+//   spec_cols512      pass 1: 512-point column transforms (radix 32 in registers, an LDS exchange, radix 16), times W_N^(n2 k1); 16 adjacent
+//                     columns per workgroup (128-byte runs on both sides).  Z[f][k1][n2].
+//   spec_rows256_avg  pass 2 + K15: workgroup = row pair, four waves take four consecutive frames (two 256-point transforms each, Stockham
+//                     radix 4 in wave-private LDS), then every thread runs its two bins through the four frames in order; pair sums in
+//                     pair-row order [f][row pair][k2], per-frame extrema per row pair.
+//   spec_display_rows256  K16 for that order: 32 x 32 tiles transposed through LDS (128-byte runs on both sides).
+#pragma once
+#include "kernels_spec.hpp"
+
+namespace csdr {
+
+constexpr int kC512 = 512, kC512Cols = 16;
+constexpr int kC512KaPitch = 16 * 16 + 16;                       // [k_a][v][col] with 16 float2 of padding per k_a: two k_a of a half-wave hit different bank halves
+constexpr size_t kC512Lds = (size_t)32 * kC512KaPitch * sizeof(float2);
+
+// pass 1.  Frame f, columns n2 in [16 blockIdx.x, + 16): X[k1][n2] = W_N^(n2 k1) sum_n1 x[n1 R + n2] W_512^(n1 k1), n1 = 16 u + v, k1 = k_a + 32 k_b.
+// thread = (v = tid >> 4, col = tid & 15): radix 32 over u in registers, times W_512^(v k_a); exchange; thread = (k_a = tid >> 4 and + 16, col):
+// radix 16 over v, times W_N^(n2 k1); stores Z[f][k1][n2] (16 columns = 128 contiguous bytes per k1).
+CSDR_KERNEL __launch_bounds__(kFftThreads) void spec_cols512(FrameSrc fs, int N, const float2 *__restrict__ tw4096, const float2 *__restrict__ tw_hi,
+                                                             const float2 *__restrict__ tw_lo, float2 *__restrict__ dst) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *s_x = reinterpret_cast<float2 *>(smem);
+    const int R = N / kC512;
+    const int f = blockIdx.y, tid = threadIdx.x, col = tid & 15, hi = tid >> 4;
+    const int n2 = blockIdx.x * kC512Cols + col;
+    const float2 *xb = frame_ptr(fs, f);
+    float2 a[32];
+    {
+        const int v = hi;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) a[u] = frame_at(fs, f, xb, (int64_t)(16 * u + v) * R + n2);
+        dft_reg<32>(a);
+        float2 leaf[5];
+#pragma unroll
+        for (int l = 0; l < 5; ++l) leaf[l] = tw4096[(8 * v) << l];              // W_512^(v 2^l) = exp(-2 pi i 8 v 2^l / 4096), 8 * 15 * 16 < 4096
+        twiddle_powers<32>(a, leaf);
+#pragma unroll
+        for (int ka = 0; ka < 32; ++ka) s_x[ka * kC512KaPitch + v * 16 + col] = a[ka];
+    }
+    __syncthreads();
+    float2 *o = dst + (int64_t)f * N + n2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int ka = hi + 16 * h;
+        float2 b[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) b[v] = s_x[ka * kC512KaPitch + v * 16 + col];
+        dft_reg<16>(b);
+        // W_N^(n2 (ka + 32 kb)) = W_N^(n2 ka) (W_N^(32 n2))^kb
+        float2 leaf[5];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) leaf[l] = tw_split(tw_hi, tw_lo, (unsigned)(32 * n2) << l);      // 32 n2 8 < N (n2 < R = N / 512)
+        leaf[4] = leaf[3];
+        twiddle_powers<16>(b, leaf);
+        const float2 w0 = tw_split(tw_hi, tw_lo, (unsigned)(n2 * ka));
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) st_stream(o + (int64_t)(ka + 32 * kb) * R, cmul(b[kb], w0));
+    }
+}
+
+// ---- pass 2 + averaging, R = 256
+constexpr int kR2 = 256;
+constexpr int kR2Frames = 4;                                      // frames per round = waves per workgroup
+constexpr size_t kR2Lds = (size_t)kR2Frames * 4 * kR2 * sizeof(float2) /* per wave: two rows, ping + pong */ + (size_t)kR2Frames * 2 * kR2 * sizeof(float) /* magnitudes */ +
+                          (size_t)kR2Frames * 4 * 2 * sizeof(float) /* per-frame extrema of the four waves */;
+
+// one radix-4 Stockham pass over BOTH rows of a wave (64 butterflies per row, one per lane): src -> dst
+__device__ __forceinline__ void r2_pass(const float2 *sa, const float2 *sb, float2 *da, float2 *db, int Ns, int lane, const float2 *__restrict__ tw4096) {
+    constexpr int q = kR2 / 4;
+    const int j = lane, k = j & (Ns - 1);
+    float2 a0 = sa[j], a1 = sa[j + q], a2 = sa[j + 2 * q], a3 = sa[j + 3 * q];
+    float2 b0 = sb[j], b1 = sb[j + q], b2 = sb[j + 2 * q], b3 = sb[j + 3 * q];
+    if (Ns > 1) {
+        const int ts = kTwTab / (Ns * 4);
+        const float2 w1 = tw4096[k * ts], w2 = tw4096[2 * k * ts], w3 = tw4096[3 * k * ts];
+        a1 = cmul(a1, w1); a2 = cmul(a2, w2); a3 = cmul(a3, w3);
+        b1 = cmul(b1, w1); b2 = cmul(b2, w2); b3 = cmul(b3, w3);
+    }
+    const int j0 = ((j - k) << 2) + k;
+    {
+        const float2 p0 = make_float2(a0.x + a2.x, a0.y + a2.y), p1 = make_float2(a0.x - a2.x, a0.y - a2.y);
+        const float2 p2 = make_float2(a1.x + a3.x, a1.y + a3.y), p3 = make_float2(a1.x - a3.x, a1.y - a3.y);
+        da[j0] = make_float2(p0.x + p2.x, p0.y + p2.y);
+        da[j0 + Ns] = make_float2(p1.x + p3.y, p1.y - p3.x);           // p1 - j p3
+        da[j0 + 2 * Ns] = make_float2(p0.x - p2.x, p0.y - p2.y);
+        da[j0 + 3 * Ns] = make_float2(p1.x - p3.y, p1.y + p3.x);       // p1 + j p3
+    }
+    {
+        const float2 p0 = make_float2(b0.x + b2.x, b0.y + b2.y), p1 = make_float2(b0.x - b2.x, b0.y - b2.y);
+        const float2 p2 = make_float2(b1.x + b3.x, b1.y + b3.y), p3 = make_float2(b1.x - b3.x, b1.y - b3.y);
+        db[j0] = make_float2(p0.x + p2.x, p0.y + p2.y);
+        db[j0 + Ns] = make_float2(p1.x + p3.y, p1.y - p3.x);
+        db[j0 + 2 * Ns] = make_float2(p0.x - p2.x, p0.y - p2.y);
+        db[j0 + 3 * Ns] = make_float2(p1.x - p3.y, p1.y + p3.x);
+    }
+}
+
+// grid = 256 row pairs (N / 512 / 2 ... for N = 2^17), 256 threads.  Z: [frames][512][256].  Frames [0, nf).
+// pairsum[f][pair][k2] (float), ext_w[f][pair] = (max, min) of the float-rounded averaged bins, first_b[f] = bin 1's maa for display point 0.
+CSDR_KERNEL __launch_bounds__(kFftThreads) void spec_rows256_avg(const float2 *__restrict__ Z, int nf, SpecGeom g, double rate, const float2 *__restrict__ tw4096,
+                                                                 double *__restrict__ ma, double *__restrict__ maa, float *__restrict__ pairsum,
+                                                                 float *__restrict__ first_b, float2 *__restrict__ ext_w) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6);
+    float2 *s_w = reinterpret_cast<float2 *>(smem) + (size_t)w * 4 * kR2;          // this wave's [row a ping | row a pong | row b ping | row b pong]
+    float *s_mag = reinterpret_cast<float *>(reinterpret_cast<float2 *>(smem) + (size_t)kR2Frames * 4 * kR2);      // [frame of the round][row][k2]
+    float *s_ex = s_mag + kR2Frames * 2 * kR2;                                      // [frame][wave][max | min]
+    const int pair = blockIdx.x, npairs = gridDim.x, F = g.F;
+    const int64_t N = g.N;
+    // this thread's display point: bins ka = 2 pair + 512 tid and ka + 1
+    const int ka = 2 * pair + kC512 * tid;
+    const int x = (int)(((ka - N / 2) & (N - 1)) >> 1);
+    AvgState s = {ma[x], maa[x], ma[F + x], maa[F + x]};
+    const float2 *za = Z + (int64_t)(2 * pair) * kR2, *zb = za + kR2;               // rows 2 pair and 2 pair + 1 of frame 0
+    // the wave's rows of its frame of the first round
+    float2 ra[4], rb[4];
+    {
+        const int f = min(w, nf - 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ra[i] = za[(int64_t)f * N + lane + 64 * i]; rb[i] = zb[(int64_t)f * N + lane + 64 * i]; }
+    }
+    for (int fb = 0; fb < nf; fb += kR2Frames) {
+        const int nfr = min(kR2Frames, nf - fb);
+        // ---- transforms: wave w takes frame fb + w
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s_w[lane + 64 * i] = ra[i]; s_w[2 * kR2 + lane + 64 * i] = rb[i]; }
+        {   // the next round's rows are requested before this round's arithmetic (frames past the end re-read the last one)
+            const int fn = min(fb + kR2Frames + w, nf - 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ra[i] = za[(int64_t)fn * N + lane + 64 * i]; rb[i] = zb[(int64_t)fn * N + lane + 64 * i]; }
+        }
+        wave_sync();
+        r2_pass(s_w, s_w + 2 * kR2, s_w + kR2, s_w + 3 * kR2, 1, lane, tw4096);   wave_sync();
+        r2_pass(s_w + kR2, s_w + 3 * kR2, s_w, s_w + 2 * kR2, 4, lane, tw4096);   wave_sync();
+        r2_pass(s_w, s_w + 2 * kR2, s_w + kR2, s_w + 3 * kR2, 16, lane, tw4096);  wave_sync();
+        r2_pass(s_w + kR2, s_w + 3 * kR2, s_w, s_w + 2 * kR2, 64, lane, tw4096);  wave_sync();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s_mag[(w * 2 + 0) * kR2 + lane + 64 * i] = cabs_f(s_w[lane + 64 * i]);
+            s_mag[(w * 2 + 1) * kR2 + lane + 64 * i] = cabs_f(s_w[2 * kR2 + lane + 64 * i]);
+        }
+        __syncthreads();
+        // ---- averaging: this thread's two bins through the frames of the round, in order (the reference's statements: avg_step)
+#pragma unroll
+        for (int i = 0; i < kR2Frames; ++i) {
+            if (i < nfr) {                                         // (block-uniform)
+                const int f = fb + i;
+                avg_step(s, (double)s_mag[(i * 2 + 0) * kR2 + tid], (double)s_mag[(i * 2 + 1) * kR2 + tid], rate);
+                const float fa = (float)s.maa_a, fbb = (float)s.maa_b;             // float rounding is monotonic: extrema of the rounded values
+                stf(pairsum + (int64_t)f * F, (unsigned)(pair * kR2 + tid) * 4u, (float)(s.maa_a + s.maa_b));
+                if (x == 0) first_b[f] = fbb;
+                float mx = wave_max_to_lane63(fmaxf(fa, fbb)), mn = wave_min_to_lane63(fminf(fa, fbb));      // (fmaxf / fminf skip a NaN operand, as the reference's comparisons do)
+                if (lane == 63) { s_ex[(i * 4 + w) * 2] = mx; s_ex[(i * 4 + w) * 2 + 1] = mn; }
+            }
+        }
+        __syncthreads();
+        if (tid < nfr) {
+            float mx = 0.f, mn = 3.0e38f;                                          // the starting values of spec_average's tiles
+            for (int q = 0; q < 4; ++q) { mx = fmaxf(mx, s_ex[(tid * 4 + q) * 2]); mn = fminf(mn, s_ex[(tid * 4 + q) * 2 + 1]); }
+            ext_w[(int64_t)(fb + tid) * npairs + pair] = make_float2(mx, mn);
+        }
+    }
+    ma[x] = s.ma_a; maa[x] = s.maa_a; ma[F + x] = s.ma_b; maa[F + x] = s.maa_b;
+}
+
+// ---- K16 for the pair-row order of spec_rows256_avg: pairsum[f][pair][k2], display point x = (pair + 256 k2 - N / 4) mod F.
+// grid = (8 x 8 tiles of 32 pairs x 32 k2, frames); reads 32 runs of 128 bytes, writes 32 runs of 128 bytes.
+CSDR_KERNEL __launch_bounds__(kDispThreads) void spec_display_rows256(const float *__restrict__ pairsum, const float *__restrict__ first_b,
+                                                                     const SpecFrameScal *__restrict__ fsc, SpecGeom g, float sf, float *__restrict__ points) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_y = reinterpret_cast<float *>(smem);                    // [32 k2][33]
+    const int f = blockIdx.y, tid = threadIdx.x, F = g.F;
+    const int npairs = kC512 / 2;
+    const int p0 = (blockIdx.x & 7) * 32, t0 = (blockIdx.x >> 3) * 32;
+    const SpecFrameScal sc = fsc[f];
+    const double pf = sc.pf, fl = sc.fl;
+    const float inv_den = 1.0f / log1pf((float)(sc.pc - pf));
+    float a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = (tid >> 5) + 8 * u, j = tid & 31;              // pair p0 + i, k2 t0 + j
+        a[u] = pairsum[(int64_t)f * F + (int64_t)(p0 + i) * kR2 + t0 + j];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = (tid >> 5) + 8 * u, j = tid & 31;
+        const int x = (p0 + i + npairs * (t0 + j) - (int)(g.N >> 2)) & (F - 1);
+        const double acc = (x == 0) ? fl + (double)first_b[f] : (double)a[u];      // idx == 0 is replaced by fft_floor_maa (:546-556)
+        s_y[j * 33 + i] = log1p_fast((float)(acc * 0.5 - pf)) * inv_den * sf;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = (tid >> 5) + 8 * u, i = tid & 31;              // 32 consecutive display points per k2
+        const int x = (p0 + i + npairs * (t0 + j) - (int)(g.N >> 2)) & (F - 1);
+        st_stream(points + (int64_t)f * F + x, s_y[j * 33 + i]);
+    }
+}
+
+}  // namespace csdr
