@@ -130,11 +130,13 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     CSDR_HIP_TRY(hipMemcpy(s->tw_lo.p, lo.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
     CSDR_HIP_TRY(hipMemcpy(s->tw_hi.p, hi.data(), hi.size() * sizeof(float2), hipMemcpyHostToDevice));
     const size_t nfN = (size_t)max_frames * N, F = (size_t)g.F;
-    // (measurement builds only, CSDR_SPEC_FUSED=1: parity-green against the reference's class over 953 frames, but first measured at 0.47 + 0.77 ms
-    // per C3 batch against 0.34 + 0.28 + 0.18 ms for radix pass + row pass + averaging kernel: one four-wave workgroup per CU cannot hide the
-    // dependent chain of its row transforms -- DESIGN 12)
+    // (measurement builds only, CSDR_SPEC_FUSED=1: parity-green against the reference's class over 953 frames, but 0.47 + 0.42 ms per C3 batch
+    // after three iterations against 0.34 + 0.28 + 0.18 ms for radix pass + row pass + averaging kernel: DESIGN 12)
     s->fused_ok = N == kC512 * kR2 && lab_int("CSDR_SPEC_FUSED", 0) != 0;
-    if (s->fused_ok) CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_cols512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC512Lds));
+    if (s->fused_ok) {
+        CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_cols512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC512Lds));
+        CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_rows256_avg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kR2Lds));
+    }
     if (g.Ra > 1) if (int rc = s->tmp.reserve(nfN)) return rc;
     if (int rc = s->mag.reserve(2 * nfN)) return rc;
     s->n_avg_tiles = (g.F + kAvgLanes - 1) / kAvgLanes;
@@ -242,7 +244,7 @@ static int spec_post_range(csdr_spec *s, const float *mag, int f0, int cnt, int 
     if (s->fused_now) {
         if (hold || view) return fail(CSDR_ESTATE, "internal: the fused spectrum pass was chosen for a batch that holds peaks");
         const int npairs = kC512 / 2;
-        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_rows256_avg, dim3(npairs), dim3(kFftThreads), kR2Lds, s->tmp.p + (size_t)f0 * g.N, cnt, g, (double)s->avg_rate, s->tw4096.p,
+        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_rows256_avg, dim3(npairs), dim3(kR2Threads), kR2Lds, s->tmp.p + (size_t)f0 * g.N, cnt, g, (double)s->avg_rate, s->tw4096.p,
                     s->ma.p, s->maa.p, s->pairsum.p + f0 * F, s->first_b.p + f0, s->ext_w.p + (size_t)f0 * npairs);
         CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_extrema, dim3(cnt), dim3(256), 64, s->ext_w.p + (size_t)f0 * npairs, npairs, s->ext.p + f0);
         const SpecScalars *st_in = s->scal.p + s->scal_parity;
@@ -255,7 +257,7 @@ static int spec_post_range(csdr_spec *s, const float *mag, int f0, int cnt, int 
         return CSDR_OK;
     }
     static const int avg_cap = std::max(1, std::min(kAvgGroups, lab_int("CSDR_AVG_GROUPS", kAvgGroupsDefault)));
-    const int avg_groups = std::max(1, std::min(avg_cap, (cnt + kAvgGMax - 1) / kAvgGMax));
+    const int avg_groups = std::max(1, std::min(avg_cap, (cnt + kAvgGMax - 1) / kAvgGMax));      // (fewer frames per group -- 8 / 4 / 2 -- measured on C5's 25-frame batches: 0.22 -> 0.25 - 0.27 ms)
     CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_average, dim3(s->n_avg_tiles), dim3(kAvgLanes * avg_groups), avg_lds_bytes(avg_groups), mag + (size_t)f0 * g.N, cnt, g, (double)s->avg_rate,
                 s->ma.p, s->maa.p, s->pairsum.p + f0 * F, s->first_b.p + f0, s->ext_w.p + (size_t)f0 * s->n_avg_tiles,
                 bins ? s->maaf.p + f0 * F : (float2 *)nullptr, view ? 0 : (hold ? pk_from : cnt));

@@ -12,9 +12,9 @@
 // magnitudes never leave the CU: 8 B/sample of traffic less than row FFT -> magnitudes -> averaging kernel.
 //   spec_cols512      pass 1: 512-point column transforms (radix 32 in registers, an LDS exchange, radix 16), times W_N^(n2 k1); 16 adjacent
 //                     columns per workgroup (128-byte runs on both sides).  Z[f][k1][n2].
-//   spec_rows256_avg  pass 2 + K15: workgroup = row pair, four waves take four consecutive frames (two 256-point transforms each, Stockham
-//                     radix 4 in wave-private LDS), then every thread runs its two bins through the four frames in order; pair sums in
-//                     pair-row order [f][row pair][k2], per-frame extrema per row pair.
+//   spec_rows256_avg  pass 2 + K15: workgroup = row pair; eight waves transform eight consecutive frames (two 256-point rows each, Stockham radix 4
+//                     in wave-private LDS) while four waves run their display points' bins through the eight frames before, in order; pair sums
+//                     in pair-row order [f][row pair][k2], per-frame extrema per row pair.
 //   spec_display_rows256  K16 for that order: 32 x 32 tiles transposed through LDS (128-byte runs on both sides).
 #pragma once
 #include "kernels_spec.hpp"
@@ -72,21 +72,23 @@ CSDR_KERNEL __launch_bounds__(kFftThreads) void spec_cols512(FrameSrc fs, int N,
 
 // ---- pass 2 + averaging, R = 256
 constexpr int kR2 = 256;
-constexpr int kR2Frames = 4;                                      // frames per round = waves per workgroup
-constexpr size_t kR2Lds = (size_t)kR2Frames * 4 * kR2 * sizeof(float2) /* per wave: two rows, ping + pong */ + (size_t)kR2Frames * 2 * kR2 * sizeof(float) /* magnitudes */ +
-                          (size_t)kR2Frames * 4 * 2 * sizeof(float) /* per-frame extrema of the four waves */;
+constexpr int kR2Frames = 8;                                      // frames per round = transforming waves per workgroup
+constexpr int kR2AvgWaves = kR2 / 64;                             // waves 0 .. 3 own the 256 display points of the row pair and only average
+constexpr int kR2Threads = 64 * (kR2AvgWaves + kR2Frames);
+constexpr size_t kR2Lds = (size_t)kR2Frames * 4 * kR2 * sizeof(float2) /* per transforming wave: two rows, ping + pong */ +
+                          (size_t)2 * kR2Frames * 2 * kR2 * sizeof(float) /* magnitudes of two rounds */ +
+                          (size_t)2 * kR2Frames * kR2AvgWaves * 2 * sizeof(float) /* per-frame extrema of the averaging waves, two rounds */;
 
 // one radix-4 Stockham pass over BOTH rows of a wave (64 butterflies per row, one per lane): src -> dst
-__device__ __forceinline__ void r2_pass(const float2 *sa, const float2 *sb, float2 *da, float2 *db, int Ns, int lane, const float2 *__restrict__ tw4096) {
+// (the lane's three twiddles of the pass sit in registers for the whole launch: w = null for the first pass, whose twiddles are 1)
+__device__ __forceinline__ void r2_pass(const float2 *sa, const float2 *sb, float2 *da, float2 *db, int Ns, int lane, const float2 *w) {
     constexpr int q = kR2 / 4;
     const int j = lane, k = j & (Ns - 1);
     float2 a0 = sa[j], a1 = sa[j + q], a2 = sa[j + 2 * q], a3 = sa[j + 3 * q];
     float2 b0 = sb[j], b1 = sb[j + q], b2 = sb[j + 2 * q], b3 = sb[j + 3 * q];
-    if (Ns > 1) {
-        const int ts = kTwTab / (Ns * 4);
-        const float2 w1 = tw4096[k * ts], w2 = tw4096[2 * k * ts], w3 = tw4096[3 * k * ts];
-        a1 = cmul(a1, w1); a2 = cmul(a2, w2); a3 = cmul(a3, w3);
-        b1 = cmul(b1, w1); b2 = cmul(b2, w2); b3 = cmul(b3, w3);
+    if (w) {
+        a1 = cmul(a1, w[0]); a2 = cmul(a2, w[1]); a3 = cmul(a3, w[2]);
+        b1 = cmul(b1, w[0]); b2 = cmul(b2, w[1]); b3 = cmul(b3, w[2]);
     }
     const int j0 = ((j - k) << 2) + k;
     {
@@ -107,71 +109,109 @@ __device__ __forceinline__ void r2_pass(const float2 *sa, const float2 *sb, floa
     }
 }
 
-// grid = 256 row pairs (N / 512 / 2 ... for N = 2^17), 256 threads.  Z: [frames][512][256].  Frames [0, nf).
-// pairsum[f][pair][k2] (float), ext_w[f][pair] = (max, min) of the float-rounded averaged bins, first_b[f] = bin 1's maa for display point 0.
-CSDR_KERNEL __launch_bounds__(kFftThreads) void spec_rows256_avg(const float2 *__restrict__ Z, int nf, SpecGeom g, double rate, const float2 *__restrict__ tw4096,
+// grid = 256 row pairs (N = 2^17), twelve waves: eight transform (wave 4 + q takes frame 8 r + q of round r: its two rows, magnitudes into LDS),
+// four average (thread = display point: the frames of round r - 1 in order) -- both at once, one workgroup barrier per round.
+// Z: [frames][512][256].  pairsum[f][pair][k2] (float), ext_w[f][pair] = (max, min) of the float-rounded averaged bins, first_b[f] = bin 1's maa
+// (display point 0).
+CSDR_KERNEL __launch_bounds__(kR2Threads) void spec_rows256_avg(const float2 *__restrict__ Z, int nf, SpecGeom g, double rate, const float2 *__restrict__ tw4096,
                                                                  double *__restrict__ ma, double *__restrict__ maa, float *__restrict__ pairsum,
                                                                  float *__restrict__ first_b, float2 *__restrict__ ext_w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6);
-    float2 *s_w = reinterpret_cast<float2 *>(smem) + (size_t)w * 4 * kR2;          // this wave's [row a ping | row a pong | row b ping | row b pong]
-    float *s_mag = reinterpret_cast<float *>(reinterpret_cast<float2 *>(smem) + (size_t)kR2Frames * 4 * kR2);      // [frame of the round][row][k2]
-    float *s_ex = s_mag + kR2Frames * 2 * kR2;                                      // [frame][wave][max | min]
+    float2 *s_rows = reinterpret_cast<float2 *>(smem);                                   // [transforming wave][row a ping | row a pong | row b ping | row b pong]
+    float *s_mag = reinterpret_cast<float *>(s_rows + (size_t)kR2Frames * 4 * kR2);      // [round parity][frame of the round][row][k2]
+    float *s_ex = s_mag + 2 * kR2Frames * 2 * kR2;                                       // [round parity][frame][averaging wave][max | min]
     const int pair = blockIdx.x, npairs = gridDim.x, F = g.F;
     const int64_t N = g.N;
-    // this thread's display point: bins ka = 2 pair + 512 tid and ka + 1
+    const int nrounds = (nf + kR2Frames - 1) / kR2Frames;
+    if (w >= kR2AvgWaves) {
+        // ================= transforming waves
+        const int pw = w - kR2AvgWaves;
+        float2 *s_w = s_rows + (size_t)pw * 4 * kR2;
+        float2 tw[3][3];                                           // passes Ns = 4, 16, 64: W^(k), W^(2k), W^(3k), k = lane & (Ns - 1)
+#pragma unroll
+        for (int ps = 0; ps < 3; ++ps) {
+            const int Ns = 4 << (2 * ps), k = lane & (Ns - 1), ts = kTwTab / (Ns * 4);
+            tw[ps][0] = tw4096[k * ts]; tw[ps][1] = tw4096[2 * k * ts]; tw[ps][2] = tw4096[3 * k * ts];
+        }
+        const float2 *za = Z + (int64_t)(2 * pair) * kR2, *zb = za + kR2;           // rows 2 pair and 2 pair + 1 of frame 0
+        float2 ra[4], rb[4];
+        {
+            const int f = min(pw, nf - 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ra[i] = za[(int64_t)f * N + lane + 64 * i]; rb[i] = zb[(int64_t)f * N + lane + 64 * i]; }
+        }
+        for (int it = 0; it <= nrounds; ++it) {
+            if (it < nrounds) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { s_w[lane + 64 * i] = ra[i]; s_w[2 * kR2 + lane + 64 * i] = rb[i]; }
+                {   // the next round's rows are requested before this round's arithmetic (frames past the end re-read the last one)
+                    const int fn = min((it + 1) * kR2Frames + pw, nf - 1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { ra[i] = za[(int64_t)fn * N + lane + 64 * i]; rb[i] = zb[(int64_t)fn * N + lane + 64 * i]; }
+                }
+                wave_sync();
+                r2_pass(s_w, s_w + 2 * kR2, s_w + kR2, s_w + 3 * kR2, 1, lane, nullptr);   wave_sync();
+                r2_pass(s_w + kR2, s_w + 3 * kR2, s_w, s_w + 2 * kR2, 4, lane, tw[0]);     wave_sync();
+                r2_pass(s_w, s_w + 2 * kR2, s_w + kR2, s_w + 3 * kR2, 16, lane, tw[1]);    wave_sync();
+                r2_pass(s_w + kR2, s_w + 3 * kR2, s_w, s_w + 2 * kR2, 64, lane, tw[2]);    wave_sync();
+                float *mg = s_mag + (size_t)((it & 1) * kR2Frames + pw) * 2 * kR2;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    mg[lane + 64 * i] = cabs_f(s_w[lane + 64 * i]);
+                    mg[kR2 + lane + 64 * i] = cabs_f(s_w[2 * kR2 + lane + 64 * i]);
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // ================= averaging waves: this thread's display point, bins ka = 2 pair + 512 tid and ka + 1
     const int ka = 2 * pair + kC512 * tid;
     const int x = (int)(((ka - N / 2) & (N - 1)) >> 1);
     AvgState s = {ma[x], maa[x], ma[F + x], maa[F + x]};
-    const float2 *za = Z + (int64_t)(2 * pair) * kR2, *zb = za + kR2;               // rows 2 pair and 2 pair + 1 of frame 0
-    // the wave's rows of its frame of the first round
-    float2 ra[4], rb[4];
-    {
-        const int f = min(w, nf - 1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { ra[i] = za[(int64_t)f * N + lane + 64 * i]; rb[i] = zb[(int64_t)f * N + lane + 64 * i]; }
-    }
-    for (int fb = 0; fb < nf; fb += kR2Frames) {
-        const int nfr = min(kR2Frames, nf - fb);
-        // ---- transforms: wave w takes frame fb + w
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { s_w[lane + 64 * i] = ra[i]; s_w[2 * kR2 + lane + 64 * i] = rb[i]; }
-        {   // the next round's rows are requested before this round's arithmetic (frames past the end re-read the last one)
-            const int fn = min(fb + kR2Frames + w, nf - 1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { ra[i] = za[(int64_t)fn * N + lane + 64 * i]; rb[i] = zb[(int64_t)fn * N + lane + 64 * i]; }
+    auto publish = [&](int r) {                                    // the per-frame extrema of round r, left in LDS one barrier ago
+        const int nfr = min(kR2Frames, nf - r * kR2Frames);
+        if (tid < nfr) {
+            const float *e = s_ex + (size_t)((r & 1) * kR2Frames + tid) * kR2AvgWaves * 2;
+            float mx = 0.f, mn = 3.0e38f;                          // the starting values of spec_average's tiles
+            for (int q = 0; q < kR2AvgWaves; ++q) { mx = fmaxf(mx, e[2 * q]); mn = fminf(mn, e[2 * q + 1]); }
+            ext_w[(int64_t)(r * kR2Frames + tid) * npairs + pair] = make_float2(mx, mn);
         }
-        wave_sync();
-        r2_pass(s_w, s_w + 2 * kR2, s_w + kR2, s_w + 3 * kR2, 1, lane, tw4096);   wave_sync();
-        r2_pass(s_w + kR2, s_w + 3 * kR2, s_w, s_w + 2 * kR2, 4, lane, tw4096);   wave_sync();
-        r2_pass(s_w, s_w + 2 * kR2, s_w + kR2, s_w + 3 * kR2, 16, lane, tw4096);  wave_sync();
-        r2_pass(s_w + kR2, s_w + 3 * kR2, s_w, s_w + 2 * kR2, 64, lane, tw4096);  wave_sync();
+    };
+    for (int it = 0; it <= nrounds; ++it) {
+        if (it >= 2) publish(it - 2);
+        if (it >= 1) {
+            const int r = it - 1, fb = r * kR2Frames, nfr = min(kR2Frames, nf - fb);
+            const float *mg = s_mag + (size_t)(r & 1) * kR2Frames * 2 * kR2;
+            float *ex = s_ex + (size_t)(r & 1) * kR2Frames * kR2AvgWaves * 2;
+            // the magnitudes of the whole round first (independent loads), then the recurrence -- the only serial chain -- frame after frame; the
+            // stores and the extrema hang off it and are folded for all frames together at the end (eight independent reductions in flight)
+            float xa[kR2Frames], xb[kR2Frames], mxs[kR2Frames], mns[kR2Frames];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            s_mag[(w * 2 + 0) * kR2 + lane + 64 * i] = cabs_f(s_w[lane + 64 * i]);
-            s_mag[(w * 2 + 1) * kR2 + lane + 64 * i] = cabs_f(s_w[2 * kR2 + lane + 64 * i]);
-        }
-        __syncthreads();
-        // ---- averaging: this thread's two bins through the frames of the round, in order (the reference's statements: avg_step)
+            for (int i = 0; i < kR2Frames; ++i) { xa[i] = mg[(i * 2 + 0) * kR2 + tid]; xb[i] = mg[(i * 2 + 1) * kR2 + tid]; }
 #pragma unroll
-        for (int i = 0; i < kR2Frames; ++i) {
-            if (i < nfr) {                                         // (block-uniform)
-                const int f = fb + i;
-                avg_step(s, (double)s_mag[(i * 2 + 0) * kR2 + tid], (double)s_mag[(i * 2 + 1) * kR2 + tid], rate);
-                const float fa = (float)s.maa_a, fbb = (float)s.maa_b;             // float rounding is monotonic: extrema of the rounded values
-                stf(pairsum + (int64_t)f * F, (unsigned)(pair * kR2 + tid) * 4u, (float)(s.maa_a + s.maa_b));
-                if (x == 0) first_b[f] = fbb;
-                float mx = wave_max_to_lane63(fmaxf(fa, fbb)), mn = wave_min_to_lane63(fminf(fa, fbb));      // (fmaxf / fminf skip a NaN operand, as the reference's comparisons do)
-                if (lane == 63) { s_ex[(i * 4 + w) * 2] = mx; s_ex[(i * 4 + w) * 2 + 1] = mn; }
+            for (int i = 0; i < kR2Frames; ++i) {
+                mxs[i] = 0.f; mns[i] = 3.0e38f;
+                if (i < nfr) {                                     // (block-uniform)
+                    const int f = fb + i;
+                    avg_step(s, (double)xa[i], (double)xb[i], rate);           // the reference's statements, NaN repairs included
+                    const float fa = (float)s.maa_a, fbb = (float)s.maa_b;         // float rounding is monotonic: extrema of the rounded values
+                    stf(pairsum + (int64_t)f * F, (unsigned)(pair * kR2 + tid) * 4u, (float)(s.maa_a + s.maa_b));
+                    if (x == 0) first_b[f] = fbb;
+                    mxs[i] = fmaxf(fa, fbb); mns[i] = fminf(fa, fbb);            // (fmaxf / fminf skip a NaN operand, as the reference's comparisons do)
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < kR2Frames; ++i) { mxs[i] = wave_max_to_lane63(mxs[i]); mns[i] = wave_min_to_lane63(mns[i]); }
+            if (lane == 63) {
+#pragma unroll
+                for (int i = 0; i < kR2Frames; ++i) { ex[(i * kR2AvgWaves + w) * 2] = mxs[i]; ex[(i * kR2AvgWaves + w) * 2 + 1] = mns[i]; }
             }
         }
         __syncthreads();
-        if (tid < nfr) {
-            float mx = 0.f, mn = 3.0e38f;                                          // the starting values of spec_average's tiles
-            for (int q = 0; q < 4; ++q) { mx = fmaxf(mx, s_ex[(tid * 4 + q) * 2]); mn = fminf(mn, s_ex[(tid * 4 + q) * 2 + 1]); }
-            ext_w[(int64_t)(fb + tid) * npairs + pair] = make_float2(mx, mn);
-        }
     }
+    publish(nrounds - 1);
     ma[x] = s.ma_a; maa[x] = s.maa_a; ma[F + x] = s.ma_b; maa[F + x] = s.maa_b;
 }
 
