@@ -211,7 +211,15 @@ __device__ inline float2 frame_at(const FrameSrc &fs, int f, const float2 *base,
     return base[i];
 }
 
-__device__ inline float cabs_f(float2 v) { return sqrtf(v.x * v.x + v.y * v.y); }
+// |v|: the hardware square root (v_sqrt_f32, one ulp) -- the library sqrtf wraps it in a range-scaling sequence of seven instructions per value,
+// which at sixteen magnitudes per thread was a tenth of the row pass's instruction stream (the pass is issue-bound: DESIGN 12)
+__device__ inline float cabs_f(float2 v) {
+#if defined(__AMDGCN__)
+    return __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y);
+#else
+    return sqrtf(v.x * v.x + v.y * v.y);
+#endif
+}
 
 // ---- radix pass: R-point column DFTs over stride Lr = L / R, times W_L^(k c); grid = (Lr / (256 COLS), sequences) --
 // W_L^q = exp(-2 pi i q tw_scale / N) is looked up in the split tables of the full transform.
@@ -580,7 +588,11 @@ __device__ __forceinline__ float log1p_fast(float u) {
     const float l = log2f(w) * 0.69314718055994530942f;
 #endif
     const float d = w - 1.0f;
+#if defined(__AMDGCN__)
+    return d == 0.0f ? u : l * (u * __builtin_amdgcn_rcpf(d));         // (v_rcp_f32, one ulp: the full-precision quotient is ten instructions per point)
+#else
     return d == 0.0f ? u : l * (u / d);
+#endif
 }
 
 struct SpecFrameOut { double point_ceil, point_floor; };
