@@ -20,6 +20,8 @@ struct csdr_spec {
     int max_frames = 0, nf_last = 0;
     float avg_rate = 0.65f, scale = 1.0f;
     DevBuf<float2> tw4096, tw_hi, tw_lo, tmp, carry, stage_in, raw;
+    DevBuf<float2> blue_w, blue_B;           // sizes that are not powers of two: chirp w[N] and the transformed chirp filter Bf[L]
+    int blue_L = 0;
     DevBuf<float> mag;                       // [2][max_frames][N]: the FFT lane fills one copy while the averaging lane reads the other
     DevBuf<float> pairsum, first_b, points;
     uint64_t seq = 0;
@@ -87,6 +89,7 @@ extern "C" void csdr_spec_destroy(csdr_spec *s) {
         if (s->ev_avg_done[k]) (void)hipEventDestroy(s->ev_avg_done[k]);
     }
     s->tw4096.release(); s->tw_hi.release(); s->tw_lo.release(); s->tmp.release(); s->carry.release();
+    s->blue_w.release(); s->blue_B.release();
     s->stage_in.release(); s->raw.release(); s->mag.release(); s->ext_w.release(); s->ext.release(); s->pairsum.release(); s->first_b.release(); s->points.release();
     s->ma.release(); s->maa.release(); s->fo.release(); s->fsc.release(); s->scal.release();
     s->last[0].release(); s->last[1].release(); s->lines.release();
@@ -102,7 +105,9 @@ static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     DeviceScope dev__(s ? s->ctx : nullptr);
     if (!s) return fail(CSDR_EINVAL, "spec is null");
-    if (fft_size < 2 || (fft_size & (fft_size - 1))) return fail(CSDR_EUNSUPPORTED, "fft_size %d: only powers of two are built", fft_size);
+    if (fft_size < 2) return fail(CSDR_EINVAL, "fft_size %d", fft_size);
+    const bool npot = (fft_size & (fft_size - 1)) != 0;
+    if (npot && fft_size > 1024) return fail(CSDR_EUNSUPPORTED, "fft_size %d: sizes that are not powers of two are built up to 1024 (the GUI sets 512 / 1024 / 2048)", fft_size);
     if (max_frames <= 0) return fail(CSDR_EINVAL, "max_frames");
     const int N = 2 * fft_size;                                      // SPECTRUM_VZM 2, SpectrumVisualProcessor.h:11, .cpp:145
     if (N > (1 << 22)) return fail(CSDR_EUNSUPPORTED, "internal FFT of %d points exceeds 2^22", N);
@@ -110,8 +115,41 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     s->ready = false;
     s->seq = 0; s->avg_pending[0] = s->avg_pending[1] = false;
     SpecGeom &g = s->g;
-    g.N = N; g.F = fft_size; g.Ra = 1; g.Rb = 1; g.N2 = N;
-    if (N >= 4096) {
+    g.N = N; g.F = fft_size; g.Ra = 1; g.Rb = 1; g.N2 = N; g.npot = npot ? 1 : 0;
+    s->blue_L = 0;
+    if (npot) {
+        // chirp-z tables, in double: w[n] = exp(-i pi n^2 / N) (n^2 taken mod 2 N, exactly) and Bf = FFT_L(b), b[m mod L] = conj(w[|m|]), |m| < N
+        int L = 1;
+        while (L < 2 * N - 1) L <<= 1;
+        s->blue_L = L;
+        std::vector<std::pair<double, double>> w((size_t)N), b((size_t)L, {0.0, 0.0});
+        for (int n = 0; n < N; ++n) {
+            const long long q = ((long long)n * n) % (2LL * N);
+            const double a = -M_PI * (double)q / (double)N;
+            w[(size_t)n] = {std::cos(a), std::sin(a)};
+        }
+        for (int m = 0; m < N; ++m) { b[(size_t)m] = {w[(size_t)m].first, -w[(size_t)m].second}; if (m) b[(size_t)(L - m)] = b[(size_t)m]; }
+        // iterative radix-2 transform of b (one-time, L <= 4096)
+        for (int i = 1, j = 0; i < L; ++i) { int bit = L >> 1; for (; j & bit; bit >>= 1) j ^= bit; j ^= bit; if (i < j) std::swap(b[(size_t)i], b[(size_t)j]); }
+        for (int len = 2; len <= L; len <<= 1)
+            for (int i = 0; i < L; i += len)
+                for (int k = 0; k < len / 2; ++k) {
+                    const double a = -2.0 * M_PI * k / len, c = std::cos(a), sn = std::sin(a);
+                    const auto u = b[(size_t)(i + k)], v = b[(size_t)(i + k + len / 2)];
+                    const double vr = v.first * c - v.second * sn, vi = v.first * sn + v.second * c;
+                    b[(size_t)(i + k)] = {u.first + vr, u.second + vi}; b[(size_t)(i + k + len / 2)] = {u.first - vr, u.second - vi};
+                }
+        std::vector<float2> wf((size_t)N), bf((size_t)L);
+        for (int n = 0; n < N; ++n) wf[(size_t)n] = make_float2((float)w[(size_t)n].first, (float)w[(size_t)n].second);
+        for (int i = 0; i < L; ++i) bf[(size_t)i] = make_float2((float)b[(size_t)i].first, (float)b[(size_t)i].second);
+        if (int rc = s->blue_w.reserve((size_t)N)) return rc;
+        if (int rc = s->blue_B.reserve((size_t)L)) return rc;
+        CSDR_HIP_TRY(hipMemcpy(s->blue_w.p, wf.data(), wf.size() * sizeof(float2), hipMemcpyHostToDevice));
+        CSDR_HIP_TRY(hipMemcpy(s->blue_B.p, bf.data(), bf.size() * sizeof(float2), hipMemcpyHostToDevice));
+        if ((size_t)2 * L * sizeof(float2) > 64 * 1024)
+            CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_fft_bluestein, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * L * sizeof(float2))));
+    }
+    if (N >= 4096 && !npot) {
         g.N2 = 4096;
         const int R = N / 4096;                                       // 1 .. 1024
         g.Ra = std::min(R, 32); g.Rb = R / g.Ra;
@@ -209,7 +247,10 @@ static int spec_run_fft(csdr_spec *s, const FrameSrc &fs, int nf, float *mag, fl
         CSDR_HIP_TRY(hipGetLastError());
         return CSDR_OK;
     }
-    if (g.N < 4096) {
+    if (g.npot) {
+        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_bluestein, dim3(1, nf), dim3(kFftThreads), (size_t)2 * s->blue_L * sizeof(float2), fs, g.N, s->blue_L, s->tw4096.p,
+                    s->blue_w.p, s->blue_B.p, mag, raw);
+    } else if (g.N < 4096) {
         CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_small, dim3(1, nf), dim3(kFftThreads), (size_t)2 * g.N * sizeof(float2), fs, g.N, s->tw4096.p, mag, raw);
     } else if (g.Ra == 1) {
         CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_rows4096, dim3(1, nf), dim3(kFftThreads), kRowLdsBytes, fs, g, s->tw4096.p, mag, raw);
@@ -549,6 +590,7 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
     if (!s || !s->ready) return fail(CSDR_ESTATE, "spec not set up");
     if (!iq || n_blocks <= 0 || block_len <= 0) return fail(CSDR_EINVAL, "bad block arguments");
     if (s->is_view) {
+        if (s->g.npot) return fail(CSDR_EUNSUPPORTED, "the zoomed view is built for power-of-two sizes");
         if (n_blocks != 1) return fail(CSDR_EINVAL, "the zoomed view takes one process() input per call");
         return spec_process_view(s, iq, iq_is_dev, block_len);
     }

@@ -32,6 +32,7 @@ struct SpecGeom {
     int N, F;                 // internal FFT size, display points (= N / 2)
     int Ra, Rb, lgRa, lgRb;   // radix passes in front of the 4096-point rows (1 = absent)
     int N2;                   // row length: 4096 when N >= 4096, else N
+    int npot;                 // 1: N is not a power of two (N <= 2048: chirp-z transform, spec_fft_bluestein); the fftshift then is a modulo, not a mask
 };
 
 // ---- twiddle table lookups ----------------------------------------------------------------------------------
@@ -315,6 +316,31 @@ CSDR_KERNEL __launch_bounds__(kFftThreads) void spec_fft_small(FrameSrc fs, int 
     if (raw_out) for (int i = tid; i < N; i += kFftThreads) raw_out[(int64_t)f * N + i] = r[i];
 }
 
+// ---- any even N <= 2048 (setFFTSize takes any size, SpectrumVisualProcessor.cpp:180-190; liquid plans a mixed-radix / Rader transform): the
+// chirp-z transform.  With w[n] = exp(-i pi n^2 / N):  X[k] = w[k] sum_n (x[n] w[n]) conj(w[k - n]) -- a circular convolution of length
+// L = 2^p >= 2 N - 1 with the (precomputed, transformed in double on the host) chirp filter Bf.  One frame per workgroup, both L-point
+// transforms in LDS (the inverse one as conj(FFT(conj(.))) / L).  grid = (1, frames), LDS 2 L float2.
+CSDR_KERNEL __launch_bounds__(kFftThreads) void spec_fft_bluestein(FrameSrc fs, int N, int L, const float2 *__restrict__ tw4096, const float2 *__restrict__ chirp /* [N] w */,
+                                                                  const float2 *__restrict__ Bf /* [L] */, float *__restrict__ mag, float2 *__restrict__ raw_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *sa = reinterpret_cast<float2 *>(smem), *sb = sa + L;
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const float2 *x = frame_ptr(fs, f);
+    for (int i = tid; i < L; i += kFftThreads) sa[i] = i < N ? cmul(frame_at(fs, f, x, i), chirp[i]) : make_float2(0.f, 0.f);
+    __syncthreads();
+    float2 *r = lds_fft(sa, sb, L, tw4096);
+    float2 *o = r == sa ? sb : sa;
+    for (int i = tid; i < L; i += kFftThreads) { const float2 v = cmul(r[i], Bf[i]); o[i] = make_float2(v.x, -v.y); }
+    __syncthreads();
+    const float2 *y = lds_fft(o, r, L, tw4096);
+    const float inv = 1.0f / (float)L;
+    for (int k = tid; k < N; k += kFftThreads) {
+        const float2 v = cmul(chirp[k], make_float2(y[k].x * inv, -y[k].y * inv));
+        if (mag) mag[(int64_t)f * N + k] = cabs_f(v);
+        if (raw_out) raw_out[(int64_t)f * N + k] = v;
+    }
+}
+
 // ---- K15: averaging recurrences, display order -----------------------------------------------------------------
 // Display point x owns the two adjacent shifted bins ka = (2 x + N / 2) mod N and ka + 1; fft_result_ma / _maa (double)
 // are kept per point as [2][F] arrays.  The reference runs, per bin and per frame,
@@ -336,6 +362,11 @@ constexpr int kAvgGMax = 16;               // frames per thread per round -> 256
 
 // offsets (in floats, inside one frame of `mag`) of the two bins of display point x; db = distance between them
 __device__ inline int64_t spec_pair_offset(const SpecGeom &g, int x, int64_t &db) {
+    if (g.npot) {                                                     // any even N: bins (2 x + N / 2) mod N and (2 x + 1 + N / 2) mod N (:441-452, :532-560)
+        const int ka = (2 * x + g.N / 2) % g.N, kb = (2 * x + 1 + g.N / 2) % g.N;
+        db = kb - ka;
+        return ka;
+    }
     const int ka = (2 * x + g.N / 2) & (g.N - 1);
     if (g.Ra == 1) { db = 1; return ka; }
     const int k1 = ka & (g.Ra - 1), rest = ka >> g.lgRa;
@@ -347,6 +378,7 @@ __device__ inline int64_t spec_pair_offset(const SpecGeom &g, int x, int64_t &db
 // reads the magnitudes and writes the averaged pair sums in this order (whole 256-byte runs per wave; display-order stores were
 // 8 bytes per 64: measured 4.2 x the bytes as 32-byte partial writes); the display kernel permutes on its read side
 __device__ inline int64_t spec_pair_index(const SpecGeom &g, int x) {
+    if (g.npot) return ((2 * x + g.N / 2) % g.N) >> 1;
     const int ka = (2 * x + g.N / 2) & (g.N - 1);
     if (g.Ra == 1) return ka >> 1;
     const int k1 = ka & (g.Ra - 1), rest = ka >> g.lgRa;
@@ -440,7 +472,7 @@ CSDR_KERNEL __launch_bounds__(kAvgThreads) void spec_average(const float *__rest
     const int ntiles = gridDim.x;
     const double a = 1.0 - rate;
     const unsigned off_a = (unsigned)t * 4u, off_b = (unsigned)(t + db) * 4u, off_p = (unsigned)pt * 4u;
-    const bool adjacent = db == 1;                                       // (uniform) single-pass sizes: the two bins are one 8-byte load
+    const bool adjacent = g.Ra == 1 && !g.npot;                          // (uniform) single-pass power-of-two sizes: the two bins are one 8-byte load
     AvgState s0 = {ma[xs], maa[xs], ma[F + xs], maa[F + xs]};            // state entering the batch
     int *s_flag = reinterpret_cast<int *>(s_ex_all + (size_t)ng * 2 * kAvgExtFrames * kAvgLanes);   // [2] "this round needs the repairs", by round parity
     if (threadIdx.x == 0) { s_flag[0] = 0; s_flag[1] = 0; }

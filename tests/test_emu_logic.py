@@ -257,3 +257,10 @@ def test_emu_packed_row_order(ctx, M):
 def test_emu_spectrum_headline_size_fused_rows(ctx):
     """N = 2^17: the 512 x 256 factorisation with the averaging fused into the row pass (kernels_spec2.hpp), a few frames over three calls"""
     G._spectrum_contiguous_batches(ctx, 65536, 61440000, (5, 3, 6))
+
+
+def test_emu_spectrum_sizes_that_are_not_powers_of_two(ctx):
+    for F in (600, 37, 3):
+        G.test_fft_matches_liquid(ctx, F)
+    G.test_spectrum_points_first_frame_mode(ctx, 375, 4000)
+    G._spectrum_contiguous_batches(ctx, 375, 2400000, (5, 3, 4))

@@ -634,8 +634,10 @@ def test_single_channel_mode_demod(ctx):
 
 
 # ----------------------------------------------------------------------------------------------- spectrum
-@pytest.mark.parametrize("F", [512, 2048, 16384, 65536])
+@pytest.mark.parametrize("F", [512, 2048, 16384, 65536, 600, 1000, 750, 37, 3, 1023])
 def test_fft_matches_liquid(ctx, F):
+    """fft_execute (SpectrumVisualProcessor.cpp:439) at the sizes the GUI sets and -- setFFTSize takes any size (:180-190) -- at sizes that are
+    not powers of two (chirp-z transform, up to fftSize 1024: internal 2 x fftSize points, odd fftSize included)"""
     from cubicsdr_amd.engine import SpectrumProcessor
     from oracle.cubicsdr_chain import RefSpectrum
     x = synth_iq(2 * F, 2.4e6, 0, [("NBFM", 300000.0)], seed=77)
@@ -645,11 +647,11 @@ def test_fft_matches_liquid(ctx, F):
     sp.close()
 
 
-@pytest.mark.parametrize("F,block", [(2048, 40000), (16384, 166680)])
+@pytest.mark.parametrize("F,block", [(2048, 40000), (16384, 166680), (600, 40000), (375, 4000)])
 def test_spectrum_points_first_frame_mode(ctx, F, block):
     from cubicsdr_amd.engine import SpectrumProcessor
     from oracle.cubicsdr_chain import RefSpectrum
-    fs = 2400000 if F == 2048 else 10000000
+    fs = 10000000 if F == 16384 else 2400000
     nb = 5
     x = synth_iq(nb * block, fs, 0, [("NBFM", 300000.0), ("AM", -500000.0)], seed=9)
     sp = SpectrumProcessor(ctx, F, max_frames=nb)
@@ -860,6 +862,13 @@ def test_spectrum_headline_shape_contiguous_batches(ctx, F, fs, frames_per_batch
     _spectrum_contiguous_batches(ctx, F, fs, frames_per_batch)
 
 
+def test_spectrum_size_that_is_not_a_power_of_two_contiguous_batches(ctx):
+    """fftSize 600 (1200-point transforms) and 375 (odd: the two bins of a display point straddle the fftshift's wrap), contiguous frames over
+    three calls against the reference's own class: averagers, trackers, carry"""
+    _spectrum_contiguous_batches(ctx, 600, 2400000, (30, 22, 25))
+    _spectrum_contiguous_batches(ctx, 375, 2400000, (12, 9, 14))
+
+
 def _spectrum_contiguous_batches(ctx, F, fs, frames_per_batch, against_exact=False):
     """The BASELINE spectrum shapes as the bench runs them: F = 65536 (C3: 32 rows of 4096 behind a radix-32 pass) and F = 16384 (C2),
     CSDR_SPEC_CONTIGUOUS, >= 300 frames per call (several 256-frame rounds of the averaging scan, multi-row tiles), three consecutive
@@ -873,9 +882,9 @@ def _spectrum_contiguous_batches(ctx, F, fs, frames_per_batch, against_exact=Fal
     except Exception:
         dev = None
     N = 2 * F
-    odd = (1000, 77, N - 1077)                                        # samples left over after the last whole frame of each call
+    odd = (1000 % N, 77 % N, (N - 1077) % N)                           # samples left over after the last whole frame of each call
     lens = [nf * N + o for nf, o in zip(frames_per_batch, odd)]
-    lens[1] -= 1000; lens[2] -= 77                                     # call k starts with the carry of call k - 1
+    lens[1] -= odd[0]; lens[2] -= odd[1]                               # call k starts with the carry of call k - 1
     total = sum(lens)
     carriers = [("NBFM", 0.21 * fs), ("AM", -0.33 * fs), ("USB", 0.05 * fs), ("NBFM", -0.07 * fs)]
     x = synth_iq_fast(total, fs, 0, carriers, seed=4242)
