@@ -153,6 +153,9 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
         g.N2 = 4096;
         const int R = N / 4096;                                       // 1 .. 1024
         g.Ra = std::min(R, 32); g.Rb = R / g.Ra;
+        // 2^21 points: ONE 512-point column pass through LDS (spec_cols512, kernels_spec2.hpp) instead of a radix-32 and a radix-16 pass through
+        // HBM -- 16 instead of 32 B/sample in front of the 4096-point rows; bins k = k1 + 512 k3, row = k1 (the layout of Ra = 512, Rb = 1)
+        if (N == kC512 * 4096 && lab_int("CSDR_SPEC_COLS512", 1) != 0) { g.Ra = kC512; g.Rb = 1; }
     }
     g.lgRa = ilog2(g.Ra); g.lgRb = ilog2(g.Rb);
     s->max_frames = max_frames;
@@ -171,10 +174,8 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     // (measurement builds only, CSDR_SPEC_FUSED=1: parity-green against the reference's class over 953 frames, but 0.47 + 0.42 ms per C3 batch
     // after three iterations against 0.34 + 0.28 + 0.18 ms for radix pass + row pass + averaging kernel: DESIGN 12)
     s->fused_ok = N == kC512 * kR2 && lab_int("CSDR_SPEC_FUSED", 0) != 0;
-    if (s->fused_ok) {
-        CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_cols512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC512Lds));
-        CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_rows256_avg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kR2Lds));
-    }
+    if (s->fused_ok) CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_rows256_avg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kR2Lds));
+    if (s->fused_ok || g.Ra == kC512) CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_cols512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC512Lds));
     if (g.Ra > 1) if (int rc = s->tmp.reserve(nfN)) return rc;
     if (int rc = s->mag.reserve(2 * nfN)) return rc;
     s->n_avg_tiles = (g.F + kAvgLanes - 1) / kAvgLanes;
@@ -254,6 +255,10 @@ static int spec_run_fft(csdr_spec *s, const FrameSrc &fs, int nf, float *mag, fl
         CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_small, dim3(1, nf), dim3(kFftThreads), (size_t)2 * g.N * sizeof(float2), fs, g.N, s->tw4096.p, mag, raw);
     } else if (g.Ra == 1) {
         CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_rows4096, dim3(1, nf), dim3(kFftThreads), kRowLdsBytes, fs, g, s->tw4096.p, mag, raw);
+    } else if (g.Ra == kC512) {
+        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_COLS, spec_cols512, dim3(g.N / kC512 / kC512Cols, nf), dim3(kFftThreads), kC512Lds, fs, g.N, s->tw4096.p, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
+        FrameSrc rows{s->tmp.p, nullptr, s->tmp.p + g.N, g.N, 1 << 30};
+        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_rows4096, dim3(g.Ra, nf), dim3(kFftThreads), kRowLdsBytes, rows, g, s->tw4096.p, mag, raw);
     } else {
         // radix passes: Ra-point columns of each frame, then (optionally) Rb-point columns inside each of the Ra sub-sequences
         if (g.Ra <= 16) launch_radix<2>(c, g.Ra, fs, g.N, 1u, nf, s->tw_hi.p, s->tw_lo.p, s->tmp.p);

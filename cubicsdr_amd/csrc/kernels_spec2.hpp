@@ -1,5 +1,10 @@
-// kernels_spec2.hpp -- the spectrum chain on the N = 512 x R factorisation (headline size N = 2^17: R = 256), with the averaging fused into the
-// second transform pass.
+// kernels_spec2.hpp -- the 512-point column pass of the N = 512 x R factorisation, and (an experiment of the measurement build) the spectrum chain
+// of the headline size N = 2^17 = 512 x 256 with the averaging fused into the second transform pass.
+//
+// IN THE PRODUCT: spec_cols512 is pass 1 of every 2^21-point frame (BASELINE config 5: fftSize 1 048 576): one 512-point column pass through LDS
+// in front of the 4096-point rows of kernels_spec.hpp, instead of a radix-32 and a radix-16 pass through HBM -- 16 instead of 32 B/sample
+// (C5: 0.31 -> 0.19 ms per batch, and the rows / averaging kernels gain from the one-level row layout: 35.0 -> 38.6 GS/s; against a float64
+// transform the 2^21-point display values are 9.5e-6 off where the two-pass form was 2.2e-5 and the reference's own class is 1.8e-5).
 //
 // Replaces (reference file:line): fft_execute SpectrumVisualProcessor.cpp:439, magnitude + fftshift :441-452, the double EMA and the running
 // extrema :494-511 -- for the full-span view without peak hold (the other cases run the kernels of kernels_spec.hpp).
