@@ -115,7 +115,7 @@ def frontend_groups(cfg):
 
 STAGE_OF = {"chan_analyze": "channelizer", "dc_tile_ends": "channelizer", "dc_apply": "channelizer",
             "demod_modem": "modem+audio", "demod_gain_scan": "modem+audio", "demod_audio_interp": "modem+audio", "fms_stages": "modem+audio", "fms_out": "modem+audio",
-            "spec_fft_radix": "spectrum", "spec_fft_rows": "spectrum", "spec_fused": "spectrum", "spec_average": "spectrum", "spec_extrema": "spectrum",
+            "spec_fft_radix": "spectrum", "spec_fft_rows": "spectrum", "spec_average": "spectrum", "spec_extrema": "spectrum",
             "spec_display": "spectrum", "spec_misc": "spectrum"}
 
 
@@ -131,7 +131,6 @@ def algorithmic_bytes_per_sample(kernel, cfg):
         "demod_audio_interp": audio,
         "spec_fft_radix": 8.0,         # the frame is read once from HBM ...
         "spec_fft_rows": 0.0,          # ... later passes re-read intermediates that are not algorithmic traffic
-        "spec_fused": 8.0,
         "spec_average": 0.0,
         "spec_display": 4.0,
     }

@@ -64,8 +64,6 @@ struct csdr_spec {
     long vmap_bw = -1, vmap_rbw = -1;
     DevBuf<float2> peakf;
     bool view_frame = false;                 // the frames being post-processed belong to the zoomed view
-    bool fused_ok = false;                   // N = 2^17: the 512 x 256 factorisation with the averaging fused into the row pass exists (kernels_spec2.hpp)
-    bool fused_now = false;                  // ... and this batch takes it (full-span view, no peak hold pending)
 };
 
 extern "C" int csdr_spec_create(csdr_ctx *ctx, csdr_spec **out) {
@@ -171,11 +169,9 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     CSDR_HIP_TRY(hipMemcpy(s->tw_lo.p, lo.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
     CSDR_HIP_TRY(hipMemcpy(s->tw_hi.p, hi.data(), hi.size() * sizeof(float2), hipMemcpyHostToDevice));
     const size_t nfN = (size_t)max_frames * N, F = (size_t)g.F;
-    // (measurement builds only, CSDR_SPEC_FUSED=1: parity-green against the reference's class over 953 frames, but 0.47 + 0.42 ms per C3 batch
-    // after three iterations against 0.34 + 0.28 + 0.18 ms for radix pass + row pass + averaging kernel: DESIGN 12)
-    s->fused_ok = N == kC512 * kR2 && lab_int("CSDR_SPEC_FUSED", 0) != 0;
-    if (s->fused_ok) CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_rows256_avg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kR2Lds));
-    if (s->fused_ok || g.Ra == kC512) CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_cols512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC512Lds));
+    if (g.Ra == kC512) CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_cols512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC512Lds));
+    if (g.Ra > 1 && disp_lds_bytes((g.Ra >> 1) * g.Rb, ilog2(g.Ra) - 1 + ilog2(g.Rb), true) > 64 * 1024)      // the display tiles of 2^21-point frames with peak hold
+        CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_display<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)disp_lds_bytes((g.Ra >> 1) * g.Rb, ilog2(g.Ra) - 1 + ilog2(g.Rb), true)));
     if (g.Ra > 1) if (int rc = s->tmp.reserve(nfN)) return rc;
     if (int rc = s->mag.reserve(2 * nfN)) return rc;
     s->n_avg_tiles = (g.F + kAvgLanes - 1) / kAvgLanes;
@@ -242,12 +238,6 @@ static void launch_radix(csdr_ctx *c, int R, const FrameSrc &fs, int L, unsigned
 static int spec_run_fft(csdr_spec *s, const FrameSrc &fs, int nf, float *mag, float2 *raw) {
     const SpecGeom &g = s->g;
     csdr_ctx *c = s->ctx;
-    if (s->fused_now && !raw) {
-        // pass 1 of the 512 x 256 factorisation: Z[f][k1][n2] into `tmp`; pass 2 runs fused with the averaging (spec_post_range)
-        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_COLS, spec_cols512, dim3(g.N / kC512 / kC512Cols, nf), dim3(kFftThreads), kC512Lds, fs, g.N, s->tw4096.p, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
-        CSDR_HIP_TRY(hipGetLastError());
-        return CSDR_OK;
-    }
     if (g.npot) {
         CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_bluestein, dim3(1, nf), dim3(kFftThreads), (size_t)2 * s->blue_L * sizeof(float2), fs, g.N, s->blue_L, s->tw4096.p,
                     s->blue_w.p, s->blue_B.p, mag, raw);
@@ -287,45 +277,36 @@ static int spec_post_range(csdr_spec *s, const float *mag, int f0, int cnt, int 
     // frame groups per workgroup: up to 16 frames each, so a short batch does not pay the set-up of sixteen groups
     // (CSDR_AVG_GROUPS = 4 | 8 | 16 caps the groups: fewer, smaller workgroups let two of them share a CU -- one loads its round while the
     // other scans)
-    if (s->fused_now) {
-        if (hold || view) return fail(CSDR_ESTATE, "internal: the fused spectrum pass was chosen for a batch that holds peaks");
-        const int npairs = kC512 / 2;
-        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_rows256_avg, dim3(npairs), dim3(kR2Threads), kR2Lds, s->tmp.p + (size_t)f0 * g.N, cnt, g, (double)s->avg_rate, s->tw4096.p,
-                    s->ma.p, s->maa.p, s->pairsum.p + f0 * F, s->first_b.p + f0, s->ext_w.p + (size_t)f0 * npairs);
-        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_extrema, dim3(cnt), dim3(256), 64, s->ext_w.p + (size_t)f0 * npairs, npairs, s->ext.p + f0);
-        const SpecScalars *st_in = s->scal.p + s->scal_parity;
-        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_trackers, dim3(cnt), dim3(kDispThreads), kTrackLds, s->ext.p + f0, cnt, st_in, s->scal.p + (s->scal_parity ^ 1),
-                    s->fo.p + f0, s->fsc.p + f0, cnt, (const SpecFrameOut *)nullptr);
-        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_DISPLAY, spec_display_rows256, dim3(64, cnt), dim3(kDispThreads), 32 * 33 * sizeof(float),
-                    s->pairsum.p + f0 * F, s->first_b.p + f0, s->fsc.p + f0, g, s->scale, s->points.p + f0 * F);
-        s->scal_parity ^= 1;
-        CSDR_HIP_TRY(hipGetLastError());
-        return CSDR_OK;
-    }
     static const int avg_cap = std::max(1, std::min(kAvgGroups, lab_int("CSDR_AVG_GROUPS", kAvgGroupsDefault)));
     const int avg_groups = std::max(1, std::min(avg_cap, (cnt + kAvgGMax - 1) / kAvgGMax));      // (fewer frames per group -- 8 / 4 / 2 -- measured on C5's 25-frame batches: 0.22 -> 0.25 - 0.27 ms)
     CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_average, dim3(s->n_avg_tiles), dim3(kAvgLanes * avg_groups), avg_lds_bytes(avg_groups), mag + (size_t)f0 * g.N, cnt, g, (double)s->avg_rate,
                 s->ma.p, s->maa.p, s->pairsum.p + f0 * F, s->first_b.p + f0, s->ext_w.p + (size_t)f0 * s->n_avg_tiles,
                 bins ? s->maaf.p + f0 * F : (float2 *)nullptr, view ? 0 : (hold ? pk_from : cnt));
-    CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_extrema, dim3(cnt), dim3(256), 64, s->ext_w.p + (size_t)f0 * s->n_avg_tiles, s->n_avg_tiles, s->ext.p + f0);
+    const int ext_threads = s->n_avg_tiles >= 4096 ? kExtMaxThreads : 256;
+    CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_extrema, dim3(cnt), dim3(ext_threads), (size_t)(ext_threads / 64) * sizeof(float2), s->ext_w.p + (size_t)f0 * s->n_avg_tiles, s->n_avg_tiles, s->ext.p + f0);
     const SpecScalars *st_in = s->scal.p + s->scal_parity;
     if (hold) {
         CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_MISC, spec_peak_track, dim3((g.F + 255) / 256), dim3(256), 0, s->maaf.p + f0 * F, cnt, pk_from, g.F, s->peak.p,
                     s->peaksum.p + f0 * F, s->peak_b.p + f0, view ? s->peakf.p + f0 * F : (float2 *)nullptr);
         CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_MISC, spec_peak_trackers, dim3(1), dim3(64), 0, s->ext.p + f0, cnt, pk_from, st_in, s->pk.p, s->pfo.p + f0);
     }
-    // trackers of every frame (closed form, one workgroup per frame), then the display: the transposing path takes kDispTpi tiles per workgroup
+    // trackers of every frame (closed form, one workgroup per frame), then the display: the transposing path takes one tile per workgroup
     CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_trackers, dim3(cnt), dim3(kDispThreads), kTrackLds, s->ext.p + f0, cnt, st_in, s->scal.p + (s->scal_parity ^ 1),
                 s->fo.p + f0, s->fsc.p + f0, hold ? pk_from : cnt, hold ? s->pfo.p + f0 : (const SpecFrameOut *)nullptr);
-    const bool transposing = !view && g.Ra > 1 && (g.Ra >> 1) * g.Rb <= kDispTile && g.F >= kDispTile;
-    const int disp_gx = transposing ? std::max(1, (g.F / kDispTile + kDispTpi - 1) / kDispTpi)
-                                    : std::max(1, std::min((g.F / 2 + kDispThreads - 1) / kDispThreads, c->wg_slots(spec_display, kDispThreads, kDispLds) / std::max(1, cnt)));
-    CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_DISPLAY, spec_display, dim3(disp_gx, cnt), dim3(kDispThreads), kDispLds,
-                s->pairsum.p + f0 * F, s->first_b.p + f0, s->fsc.p + f0, g, s->scale, s->points.p + f0 * F, hold ? pk_from : cnt,
-                hold ? s->peaksum.p + f0 * F : (const float *)nullptr, hold ? s->peak_b.p + f0 : (const float *)nullptr,
-                hold ? s->hold_points.p + f0 * F : (float *)nullptr,
-                view ? s->vmap.p : (const int2 *)nullptr, view ? s->maaf.p + f0 * F : (const float2 *)nullptr,
-                view && hold ? s->peakf.p + f0 * F : (const float2 *)nullptr);
+    const int npairs = g.Ra == 1 ? 1 : (g.Ra >> 1) * g.Rb;
+    const bool transposing = !view && g.Ra > 1 && npairs <= kDispMaxPairs;
+    const size_t disp_lds = transposing ? disp_lds_bytes(npairs, g.lgRa - 1 + g.lgRb, hold) : kDispLdsPlain;
+    const int disp_gx = transposing ? std::max(1, g.F / disp_tile_points(npairs))
+                                    : std::max(1, std::min((g.F / 2 + kDispThreads - 1) / kDispThreads, c->wg_slots(spec_display<false>, kDispThreads, kDispLdsPlain) / std::max(1, cnt)));
+#define CSDR_DISPLAY(T_)                                                                                                                   \
+    CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_DISPLAY, spec_display<T_>, dim3(disp_gx, cnt), dim3(kDispThreads), disp_lds,                         \
+                s->pairsum.p + f0 * F, s->first_b.p + f0, s->fsc.p + f0, g, s->scale, s->points.p + f0 * F, hold ? pk_from : cnt,           \
+                hold ? s->peaksum.p + f0 * F : (const float *)nullptr, hold ? s->peak_b.p + f0 : (const float *)nullptr,                    \
+                hold ? s->hold_points.p + f0 * F : (float *)nullptr,                                                                        \
+                view ? s->vmap.p : (const int2 *)nullptr, view ? s->maaf.p + f0 * F : (const float2 *)nullptr,                              \
+                view && hold ? s->peakf.p + f0 * F : (const float2 *)nullptr)
+    if (transposing) CSDR_DISPLAY(true); else CSDR_DISPLAY(false);
+#undef CSDR_DISPLAY
     s->scal_parity ^= 1;
     CSDR_HIP_TRY(hipGetLastError());
     return CSDR_OK;
@@ -428,7 +409,7 @@ template <typename PostFn>
 static int spec_fft_then(csdr_spec *s, const FrameSrc &fs, int nf, PostFn post) {
     csdr_ctx *c = s->ctx;
     // lane FFT fills magnitude copy `mp`; its previous reader was the averaging kernel two batches ago
-    const int mp = (c->same(LANE_FFT, LANE_AVG) || s->fused_now) ? 0 : (int)(s->seq & 1);      // (fused: the one intermediate buffer is the hand-off)
+    const int mp = c->same(LANE_FFT, LANE_AVG) ? 0 : (int)(s->seq & 1);
     float *mag = s->mag.p + (size_t)mp * s->max_frames * s->g.N;
     if (s->avg_pending[mp]) if (int rc = c->wait(s->ev_avg_done[mp], LANE_AVG, LANE_FFT)) return rc;
     if (int rc = spec_run_fft(s, fs, nf, mag, nullptr)) return rc;
@@ -449,7 +430,6 @@ static int spec_process_view(csdr_spec *s, const float *iq, int iq_is_dev, int b
     csdr_ctx *c = s->ctx;
     const int N = s->g.N, F = s->g.F;
     const int64_t rate = s->input_rate;
-    s->fused_now = false;                                                        // the zoomed view keeps per-bin values: the general kernels
     s->nf_last = 0;
     s->hold_valid.clear();
     // head of process() (:247, :264-273): doPeak is taken before the countdown moves; a reset uses the trackers as they stand
@@ -479,7 +459,7 @@ static int spec_process_view(csdr_spec *s, const float *iq, int iq_is_dev, int b
     if (int rc = s->maa2.reserve((size_t)2 * F)) return rc;
     auto remap = [&](int mode, int n) -> int {
         CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_MISC, spec_avg_remap, dim3(std::max(1, std::min(512, (N + 255) / 256))), dim3(256), 0,
-                    s->ma.p, s->maa.p, s->ma2.p, s->maa2.p, N, mode, n);
+                    s->ma.p, s->maa.p, s->ma2.p, s->maa2.p, N, mode, n, s->g);
         CSDR_HIP_TRY(hipGetLastError());
         std::swap(s->ma.p, s->ma2.p); std::swap(s->maa.p, s->maa2.p);
         return CSDR_OK;
@@ -605,8 +585,6 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
     const int N = g.N;
     const int64_t n = (int64_t)n_blocks * block_len;
     const float2 *x = (const float2 *)iq;
-    // full-span view, no peak hold set or pending: the 512 x 256 factorisation with the averaging fused into its row pass
-    s->fused_now = s->fused_ok && !s->peak_hold && s->peak_reset == 0;
     if (int rc = c->lane_begin(LANE_FFT)) return rc;
     if (!iq_is_dev) {
         if (int rc = s->stage_in.reserve((size_t)n)) return rc;

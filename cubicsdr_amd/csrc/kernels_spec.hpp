@@ -385,6 +385,9 @@ __device__ inline int64_t spec_pair_index(const SpecGeom &g, int x) {
     const int k2 = rest & (g.Rb - 1), k3 = rest >> g.lgRb;
     return ((int64_t)(k1 >> 1) * g.Rb + k2) * 4096 + k3;
 }
+// where the averagers of display point x live in ma / maa (bin a at [i], bin b at [F + i]): display order for the single-pass sizes,
+// pair order behind a multi-pass transform
+__device__ inline int64_t spec_state_index(const SpecGeom &g, int x) { return (g.Ra == 1 || g.npot) ? (int64_t)x : spec_pair_index(g, x); }
 __device__ inline float2 spec_load_pair(const float *__restrict__ mag, int64_t off, int64_t db) {
     if (db == 1) return *reinterpret_cast<const float2 *>(mag + off);   // ka is even: 8-byte aligned
     return make_float2(mag[off], mag[off + db]);
@@ -473,7 +476,10 @@ CSDR_KERNEL __launch_bounds__(kAvgThreads) void spec_average(const float *__rest
     const double a = 1.0 - rate;
     const unsigned off_a = (unsigned)t * 4u, off_b = (unsigned)(t + db) * 4u, off_p = (unsigned)pt * 4u;
     const bool adjacent = g.Ra == 1 && !g.npot;                          // (uniform) single-pass power-of-two sizes: the two bins are one 8-byte load
-    AvgState s0 = {ma[xs], maa[xs], ma[F + xs], maa[F + xs]};            // state entering the batch
+    // the averagers of a multi-pass transform live in PAIR order like the pair sums (spec_state_index): a tile's 64 points are 64 consecutive
+    // doubles, not one cache line each (display order: 2^21-point frames moved 2.5 x their magnitudes in state lines per 25-frame batch)
+    const int64_t si = g.Ra == 1 ? (int64_t)xs : pt;
+    AvgState s0 = {ma[si], maa[si], ma[F + si], maa[F + si]};            // state entering the batch
     int *s_flag = reinterpret_cast<int *>(s_ex_all + (size_t)ng * 2 * kAvgExtFrames * kAvgLanes);   // [2] "this round needs the repairs", by round parity
     if (threadIdx.x == 0) { s_flag[0] = 0; s_flag[1] = 0; }
     __syncthreads();
@@ -591,21 +597,29 @@ CSDR_KERNEL __launch_bounds__(kAvgThreads) void spec_average(const float *__rest
         s0 = s_carry[lane];
         ++round;
     }
-    if (grp == 0 && valid) { ma[x] = s0.ma_a; maa[x] = s0.maa_a; ma[F + x] = s0.ma_b; maa[F + x] = s0.maa_b; }
+    if (grp == 0 && valid) { ma[si] = s0.ma_a; maa[si] = s0.maa_a; ma[F + si] = s0.ma_b; maa[F + si] = s0.maa_b; }
 }
 
-// ---- per-frame extrema over the tiles of spec_average.  grid = frames, 256 threads -------------------------------
-CSDR_KERNEL __launch_bounds__(256) void spec_extrema(const float2 *__restrict__ ext_w, int ntiles, float2 *__restrict__ ext) {
+// ---- per-frame extrema over the tiles of spec_average.  grid = frames, 256 threads (1024 when a frame has thousands of tiles: a 2^21-point
+// frame has 16384 and a batch only a few dozen frames = workgroups) -------------------------------
+constexpr int kExtMaxThreads = 1024;
+CSDR_KERNEL __launch_bounds__(kExtMaxThreads) void spec_extrema(const float2 *__restrict__ ext_w, int ntiles, float2 *__restrict__ ext) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2 *s_r = reinterpret_cast<float2 *>(smem);
-    const int f = blockIdx.x, tid = threadIdx.x;
+    float2 *s_r = reinterpret_cast<float2 *>(smem);              // [waves]
+    const int f = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     float mx = 0.f, mn = 3.0e38f;
-    for (int w = tid; w < ntiles; w += 256) { const float2 v = ext_w[(int64_t)f * ntiles + w]; mx = fmaxf(mx, v.x); mn = fminf(mn, v.y); }
+    for (int w0 = tid; w0 < ntiles; w0 += 8 * nthr) {               // eight loads in flight (an index past the end re-reads the last tile: extrema do not mind)
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ext_w[(int64_t)f * ntiles + min(w0 + u * nthr, ntiles - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { mx = fmaxf(mx, v[u].x); mn = fminf(mn, v[u].y); }
+    }
     for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_down(mx, o, 64)); mn = fminf(mn, __shfl_down(mn, o, 64)); }
     if ((tid & 63) == 0) s_r[tid >> 6] = make_float2(mx, mn);
     __syncthreads();
     if (tid == 0) {
-        for (int i = 1; i < 4; ++i) { mx = fmaxf(mx, s_r[i].x); mn = fminf(mn, s_r[i].y); }
+        for (int i = 1; i < (nthr >> 6); ++i) { mx = fmaxf(mx, s_r[i].x); mn = fminf(mn, s_r[i].y); }
         ext[f] = make_float2(mx, mn);
     }
 }
@@ -661,7 +675,7 @@ CSDR_KERNEL __launch_bounds__(256) void spec_peak_track(const float2 *__restrict
 // bin i lives at [(i & 1) F + (i >> 1)] (pair layout).  mode 0/1: memmove left / right by n bins (the vacated end keeps its
 // old values); 2: zoom in, dst[i] = src[N/4 + i/2]; 3: zoom out, dst[i] = src[(i - N/4) 2] inside the middle half, else 0.
 CSDR_KERNEL __launch_bounds__(256) void spec_avg_remap(const double *__restrict__ ma, const double *__restrict__ maa,
-                                                      double *__restrict__ ma_o, double *__restrict__ maa_o, int N, int mode, int n) {
+                                                      double *__restrict__ ma_o, double *__restrict__ maa_o, int N, int mode, int n, SpecGeom g) {
     const int F = N >> 1;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += 256 * gridDim.x) {
         int src = i;
@@ -670,7 +684,7 @@ CSDR_KERNEL __launch_bounds__(256) void spec_avg_remap(const double *__restrict_
         else if (mode == 1) src = i >= n ? i - n : i;
         else if (mode == 2) src = N / 4 + i / 2;
         else { zero = i < N / 4 || i >= N - N / 4; src = zero ? 0 : (i - N / 4) * 2; }
-        const int so = (src & 1) * F + (src >> 1), dn = (i & 1) * F + (i >> 1);
+        const int64_t so = (int64_t)(src & 1) * F + spec_state_index(g, src >> 1), dn = (int64_t)(i & 1) * F + spec_state_index(g, i >> 1);
         ma_o[dn] = zero ? 0.0 : ma[so];
         maa_o[dn] = zero ? 0.0 : maa[so];
     }
@@ -701,10 +715,18 @@ CSDR_KERNEL void spec_peak_trackers(const float2 *__restrict__ ext, int nf, int 
     *pk = p;
 }
 constexpr int kDispThreads = 256;
-constexpr int kDispTile = 2 * kDispThreads;   // display points per tile
-constexpr int kDispTpi = 4;                   // tiles one workgroup of the transposing path handles (all of its loads are in flight together)
-constexpr int kDispPad = kDispTile + kDispTile / 16;      // a tile in LDS: one float of padding per 16 (position p at p + p / 16)
-constexpr size_t kDispLds = 2 * (size_t)kDispTpi * kDispPad * sizeof(float);
+constexpr int kDispTile = 2 * kDispThreads;   // display points per step of the plain path
+// the transposing path: a tile is W = U x 256 consecutive display points = W / npairs consecutive k3 of EVERY row pair.  W = 2048 up to 64 row
+// pairs; 32 k3 per row pair (128-byte runs on the read side) beyond: 4096 / 8192 points for 128 / 256 row pairs (2^20 / 2^21-point frames --
+// with 512-point tiles their runs were 16 / 8 bytes: 0.103 ms per C5 batch)
+constexpr int kDispRun = 32;
+__host__ __device__ constexpr int disp_tile_points(int npairs) { return npairs * kDispRun > 2048 ? npairs * kDispRun : 2048; }
+__host__ __device__ constexpr int disp_lg_pad(int lg_npairs) { return lg_npairs > 4 ? lg_npairs : 4; }      // one float of padding per max(16, npairs): a wave's stores are npairs floats apart
+__host__ __device__ constexpr size_t disp_lds_bytes(int npairs, int lg_npairs, bool hold) {
+    return (size_t)(hold ? 2 : 1) * (size_t)(disp_tile_points(npairs) + (disp_tile_points(npairs) >> disp_lg_pad(lg_npairs))) * sizeof(float);
+}
+constexpr int kDispMaxPairs = 256;
+constexpr size_t kDispLdsPlain = 16;
 constexpr size_t kTrackLds = 4 * (kDispThreads / 64) * sizeof(double);
 
 struct SpecFrameScal { double pc, pf, fl; };  // point_ceil, point_floor, fft_floor_maa of a frame
@@ -758,12 +780,70 @@ CSDR_KERNEL __launch_bounds__(kDispThreads) void spec_trackers(const float2 *__r
     }
 }
 
+// the transposing path of spec_display for one frame.  A tile of W points is read in passes of 2048 (eight loads per thread in flight together:
+// all of a wide tile's at once cost 16 registers a point -- 482 at W = 8192), formed, dropped at its display position in LDS; one barrier; written out
+constexpr int kDispPass = 8;                  // points per thread and pass
+__device__ __forceinline__ void spec_display_tiles(const float *__restrict__ pairsum, const float *__restrict__ first_b, const SpecGeom &g, float sf,
+                                                   float *__restrict__ points, bool hold, const float *__restrict__ peaksum, const float *__restrict__ peak_b,
+                                                   float *__restrict__ hold_points, int f, double pf, double fl, float inv_den, int npairs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int W = disp_tile_points(npairs);
+    const int tid = threadIdx.x, F = g.F;
+    const int lg_np = g.lgRa - 1 + g.lgRb, lg_pad = disp_lg_pad(lg_np);
+    float *s_y = reinterpret_cast<float *>(smem);                    // [W + W >> lg_pad] y, then the same for the held y
+    float *s_h = s_y + W + (W >> lg_pad);
+    const int nk3 = W >> lg_np, lg_nk3 = 31 - __clz(nk3), lg_half = g.lgRa - 1;
+    const int ntile = F / W;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int k3base = tile * nk3;
+        const int x0 = (npairs * k3base - (g.N >> 2)) & (F - 1);     // display point of (row pair 0, k3base); tiles do not wrap (nk3 divides 2048)
+#pragma unroll 1
+        for (int i0 = 0; i0 < W; i0 += kDispPass * kDispThreads) {
+            float a[kDispPass], ph[kDispPass];
+#pragma unroll
+            for (int u = 0; u < kDispPass; ++u) {
+                const int i = i0 + tid + u * kDispThreads;
+                const int prow = i >> lg_nk3, k3i = i & (nk3 - 1);
+                a[u] = pairsum[(int64_t)f * F + (int64_t)prow * 4096 + k3base + k3i];
+                if (hold) {
+                    const int k1h = prow >> g.lgRb, k2 = prow & (g.Rb - 1);
+                    ph[u] = peaksum[(int64_t)f * F + x0 + k3i * npairs + k1h + (k2 << lg_half)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kDispPass; ++u) {
+                const int i = i0 + tid + u * kDispThreads;
+                const int prow = i >> lg_nk3, k3i = i & (nk3 - 1);
+                const int k1h = prow >> g.lgRb, k2 = prow & (g.Rb - 1);
+                const int pos = k3i * npairs + k1h + (k2 << lg_half);    // position inside the tile, display order
+                const int x = x0 + pos;
+                const double acc = (x == 0) ? fl + (double)first_b[f] : (double)a[u];      // idx == 0 is replaced by fft_floor_maa (:546-556)
+                s_y[pos + (pos >> lg_pad)] = log1p_fast((float)(acc * 0.5 - pf)) * inv_den * sf;
+                if (hold) {
+                    const double pacc = (x == 0) ? fl + (double)peak_b[f] : (double)ph[u];
+                    s_h[pos + (pos >> lg_pad)] = log1p_fast((float)(pacc * 0.5 - pf)) * inv_den * sf;
+                }
+            }
+        }
+        __syncthreads();
+        for (int j = 2 * tid; j < W; j += 2 * kDispThreads) {
+            const int q = j + (j >> lg_pad);
+            // only y is stored: the x of point i is i / F for every frame (:562) and is filled in when a frame is fetched
+            st_stream(reinterpret_cast<float2 *>(points + (int64_t)f * F + x0 + j), make_float2(s_y[q], s_y[q + 1]));
+            if (hold) *reinterpret_cast<float2 *>(hold_points + (int64_t)f * F + x0 + j) = make_float2(s_h[q], s_h[q + 1]);
+        }
+        __syncthreads();
+    }
+}
+
 // ---- K16.  Two display points per thread, full-span view (visualRatio = 1: two bins per point), :532-576:
 //     y = log10(acc / 2 + 0.25 - (floor - 0.75)) / log10(ceil + 0.25 - (floor - 0.75)) * scale
 // Both arguments are 1 + u with u formed in double; the logarithms are taken as log(1 + u) with the rounding of the sum
 // cancelled (log1p_fast: a few float ulps also when the dynamic range is tiny), their ratio needs no base conversion.
-// grid = (column blocks, frames): the transposing path takes kDispTpi tiles per workgroup (grid.x = F / kDispTile / kDispTpi or fewer: it
-// strides), the plain path 2 x 256 points per step.
+// grid = (column blocks, frames): the transposing path takes one tile per workgroup (grid.x = F / W or fewer: it strides), the plain path
+// 2 x 256 points per step.
+// TILES: the transposing path (full-span view behind a multi-pass transform) or the plain one -- two kernels, the registers of one are not the other's
+template <bool TILES>
 CSDR_KERNEL __launch_bounds__(kDispThreads) void spec_display(const float *__restrict__ pairsum /* pair order: spec_pair_index */, const float *__restrict__ first_b,
                                                              const SpecFrameScal *__restrict__ fsc, SpecGeom g, float sf, float *__restrict__ points,
                                                              int pk_from, const float *__restrict__ peaksum,
@@ -776,67 +856,13 @@ CSDR_KERNEL __launch_bounds__(kDispThreads) void spec_display(const float *__res
     const double pc = sc.pc, pf = sc.pf, fl = sc.fl;
     const bool hold = f >= pk_from;
     const float inv_den = 1.0f / log1pf((float)(pc - pf));          // (pc + 0.25) - (pf - 0.75) = 1 + (pc - pf)
-    // Full-span view of a multi-pass transform: the pair sums lie in PAIR order (spec_pair_index).  A tile of kDispTile
-    // consecutive display points = nk3 consecutive k3 of every row pair: the threads read it row by row (runs of nk3 floats),
-    // form y, drop it at its display position in LDS (padded: a wave's stores are npairs floats apart) and write the tile out in display
-    // order.  All loads of the workgroup's kDispTpi tiles are issued before the first value is used.
+    // Full-span view of a multi-pass transform: the pair sums lie in PAIR order (spec_pair_index).  A tile of W consecutive display
+    // points = nk3 consecutive k3 of every row pair: the threads read it row by row (runs of nk3 floats), form y, drop it at its display
+    // position in LDS (padded: a wave's stores are npairs floats apart) and write the tile out in display order.  All loads of a tile are
+    // issued before the first value is used.
     const int npairs = g.Ra == 1 ? 1 : (g.Ra >> 1) * g.Rb;           // row pairs = display points per k3
-    if (!vmap && g.Ra > 1 && npairs <= kDispTile && F >= kDispTile) {
-        float *s_y = reinterpret_cast<float *>(smem);                // [kDispTpi][kDispPad] y, then the same for the held y
-        float *s_h = s_y + kDispTpi * kDispPad;
-        const int nk3 = kDispTile / npairs, lg_nk3 = 31 - __clz(nk3), lg_half = g.lgRa - 1;
-        const int ntile = F / kDispTile;
-        for (int tile0 = blockIdx.x * kDispTpi; tile0 < ntile; tile0 += gridDim.x * kDispTpi) {
-            float a[kDispTpi][2], ph[kDispTpi][2];
-#pragma unroll
-            for (int tt = 0; tt < kDispTpi; ++tt) {
-                const int tile = min(tile0 + tt, ntile - 1);               // (a tile past the end re-reads the last one: loaded, never stored)
-                const int k3base = tile * nk3;
-                const int x0 = (npairs * k3base - (g.N >> 2)) & (F - 1);   // display point of (row pair 0, k3base); tiles do not wrap
-#pragma unroll
-                for (int u = 0; u < kDispTile / kDispThreads; ++u) {
-                    const int i = tid + u * kDispThreads;
-                    const int prow = i >> lg_nk3, k3i = i & (nk3 - 1);
-                    const int k1h = prow >> g.lgRb, k2 = prow & (g.Rb - 1);
-                    const int pos = k3i * npairs + k1h + (k2 << lg_half);  // position inside the tile, display order
-                    a[tt][u] = pairsum[(int64_t)f * F + (int64_t)prow * 4096 + k3base + k3i];
-                    if (hold) ph[tt][u] = peaksum[(int64_t)f * F + x0 + pos];
-                }
-            }
-#pragma unroll
-            for (int tt = 0; tt < kDispTpi; ++tt) {
-                const int tile = min(tile0 + tt, ntile - 1);
-                const int k3base = tile * nk3;
-                const int x0 = (npairs * k3base - (g.N >> 2)) & (F - 1);
-#pragma unroll
-                for (int u = 0; u < kDispTile / kDispThreads; ++u) {
-                    const int i = tid + u * kDispThreads;
-                    const int prow = i >> lg_nk3, k3i = i & (nk3 - 1);
-                    const int k1h = prow >> g.lgRb, k2 = prow & (g.Rb - 1);
-                    const int pos = k3i * npairs + k1h + (k2 << lg_half);
-                    const int x = x0 + pos;
-                    const double acc = (x == 0) ? fl + (double)first_b[f] : (double)a[tt][u];      // idx == 0 is replaced by fft_floor_maa (:546-556)
-                    s_y[tt * kDispPad + pos + (pos >> 4)] = log1p_fast((float)(acc * 0.5 - pf)) * inv_den * sf;
-                    if (hold) {
-                        const double pacc = (x == 0) ? fl + (double)peak_b[f] : (double)ph[tt][u];
-                        s_h[tt * kDispPad + pos + (pos >> 4)] = log1p_fast((float)(pacc * 0.5 - pf)) * inv_den * sf;
-                    }
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int tt = 0; tt < kDispTpi; ++tt) {
-                const int tile = tile0 + tt;
-                if (tile < ntile) {                                         // (block-uniform)
-                    const int x0 = (npairs * tile * nk3 - (g.N >> 2)) & (F - 1);
-                    const int j = 2 * tid, q = tt * kDispPad + j + (j >> 4);
-                    // only y is stored: the x of point i is i / F for every frame (:562) and is filled in when a frame is fetched
-                    st_stream(reinterpret_cast<float2 *>(points + (int64_t)f * F + x0 + j), make_float2(s_y[q], s_y[q + 1]));
-                    if (hold) *reinterpret_cast<float2 *>(hold_points + (int64_t)f * F + x0 + j) = make_float2(s_h[q], s_h[q + 1]);
-                }
-            }
-            __syncthreads();
-        }
+    if constexpr (TILES) {
+        spec_display_tiles(pairsum, first_b, g, sf, points, hold, peaksum, peak_b, hold_points, f, pf, fl, inv_den, npairs);
         return;
     }
     for (int x0 = 2 * (blockIdx.x * kDispThreads + tid); x0 < F; x0 += 2 * kDispThreads * gridDim.x) {

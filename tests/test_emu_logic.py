@@ -253,12 +253,6 @@ def test_emu_packed_row_order(ctx, M):
     G.test_packed_row_order_holds_the_same_rows(ctx, M)
 
 
-@pytest.mark.skipif(os.environ.get("CSDR_BUILD_LAB") != "1" or os.environ.get("CSDR_SPEC_FUSED") != "1", reason="the fused spectrum pass is an experiment of the measurement build: CSDR_BUILD_LAB=1 CSDR_SPEC_FUSED=1")
-def test_emu_spectrum_headline_size_fused_rows(ctx):
-    """N = 2^17: the 512 x 256 factorisation with the averaging fused into the row pass (kernels_spec2.hpp), a few frames over three calls"""
-    G._spectrum_contiguous_batches(ctx, 65536, 61440000, (5, 3, 6))
-
-
 def test_emu_spectrum_sizes_that_are_not_powers_of_two(ctx):
     for F in (600, 37, 3):
         G.test_fft_matches_liquid(ctx, F)
