@@ -54,18 +54,17 @@ extern "C" int csdr_bank_create(csdr_ctx *ctx, int max_demods, int max_blocks, c
     b->ctx = ctx; b->max_demods = max_demods; b->max_blocks = max_blocks;
     b->slots.resize(max_demods);
     if (int rc = b->cfgs.reserve(max_demods)) return rc;
-    if (int rc = b->dyns.reserve(2 * (size_t)max_demods)) return rc;
-    if (int rc = b->slot_list.reserve(2 * 3 * (size_t)max_demods)) return rc;
-    if (int rc = b->plans.reserve(2 * (size_t)max_demods * (max_blocks + 1))) return rc;
+    b->off_lists = ((size_t)max_demods * sizeof(SlotDyn) + 15) & ~(size_t)15;
+    b->off_plans = (b->off_lists + 3 * (size_t)max_demods * sizeof(int) + 15) & ~(size_t)15;
+    b->table_bytes = (b->off_plans + (size_t)max_demods * (max_blocks + 1) * sizeof(BlockPlan) + 255) & ~(size_t)255;
+    if (int rc = b->tables.reserve(2 * b->table_bytes)) return rc;
     for (int k = 0; k < 2; ++k) {
         CSDR_HIP_TRY(hipEventCreateWithFlags(&b->ev_fe_done[k], hipEventDisableTiming));
         CSDR_HIP_TRY(hipEventCreateWithFlags(&b->ev_audio_done[k], hipEventDisableTiming));
     }
     if (int rc = b->mconsts.reserve(1)) return rc;
     for (int r = 0; r < kStageRing; ++r) {
-        if (int rc = b->dyns_h[r].reserve(max_demods)) return rc;
-        if (int rc = b->slot_list_h[r].reserve(3 * (size_t)max_demods)) return rc;
-        if (int rc = b->plans_h[r].reserve((size_t)max_demods * (max_blocks + 1))) return rc;
+        if (int rc = b->tables_h[r].reserve(b->table_bytes)) return rc;
         CSDR_HIP_TRY(hipEventCreate(&b->stage_ev[r]));
     }
     if (int rc = b->bout_h.reserve(max_blocks)) return rc;
@@ -97,9 +96,9 @@ extern "C" void csdr_bank_destroy(csdr_bank *b) {
         if (b->ev_audio_done[k]) (void)hipEventDestroy(b->ev_audio_done[k]);
     }
     for (auto &s : b->slots) if (s.slab) (void)hipFree(s.slab);
-    b->cfgs.release(); b->dyns.release(); b->slot_list.release(); b->plans.release(); b->arms.release(); b->mconsts.release();
+    b->cfgs.release(); b->tables.release(); b->arms.release(); b->mconsts.release();
     for (int r = 0; r < kStageRing; ++r) {
-        b->dyns_h[r].release(); b->slot_list_h[r].release(); b->plans_h[r].release();
+        b->tables_h[r].release();
         if (b->stage_ev[r]) (void)hipEventDestroy(b->stage_ev[r]);
     }
     b->bout_h.release();
@@ -261,17 +260,19 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     const int NB = post->n_blocks, M = post->M, Bc = post->block_len / post->hop;
     if (NB > b->max_blocks) return fail(CSDR_ERANGE, "batch of %d blocks exceeds bank capacity %d", NB, b->max_blocks);
     const int bpar = (int)(b->seq & 1);      // which copy of the per-batch device tables this batch uses
-    SlotDyn *dyns_d = b->dyns.p + (size_t)bpar * b->max_demods;
-    int *lists_d = b->slot_list.p + (size_t)bpar * 3 * b->max_demods;
-    BlockPlan *plans_d = b->plans.p + (size_t)bpar * b->max_demods * (b->max_blocks + 1);
+    char *table_d = b->tables.p + (size_t)bpar * b->table_bytes;
+    SlotDyn *dyns_d = b->dyns_of(table_d);
+    int *lists_d = b->lists_of(table_d);
+    BlockPlan *plans_d = b->plans_of(table_d);
     const int64_t rate = csdr_post_channel_rate(post);
     // pinned staging set for this batch: wait only for the upload that last used it (kStageRing batches ago)
     const int ring = b->stage_next;
     b->stage_next = (b->stage_next + 1) % kStageRing;
     if (b->stage_used[ring]) CSDR_HIP_TRY(hipEventSynchronize(b->stage_ev[ring]));
-    SlotDyn *dyns_h = b->dyns_h[ring].p;
-    int *slot_list_h = b->slot_list_h[ring].p;
-    BlockPlan *plans_h = b->plans_h[ring].p;
+    char *table_h = b->tables_h[ring].p;
+    SlotDyn *dyns_h = b->dyns_of(table_h);
+    int *slot_list_h = b->lists_of(table_h);
+    BlockPlan *plans_h = b->plans_of(table_h);
     int n_run = 0, n_ag = 0, max_n_iq = 0, max_n_iq_ag = 0, max_n_audio = 0, warm_max = 0, max_aS = 0, max_cw_audio = 0;
     int max_n_iq_fms = 0, max_n_au_fms = 0;
     std::vector<int> fms_slots;              // FM-stereo slots of this batch (their list shares the auto-gain list's region, from its end)
@@ -303,7 +304,13 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         if (!s.configured || !s.active) continue;
         if (s.chan_rate != rate) return reject(fail(CSDR_ESTATE, "slot %d was built for channel rate %lld, post now runs %lld: reconfigure", si, (long long)s.chan_rate, (long long)rate));
         // channel routing: runDemodChannels, SDRPostThread.cpp:317-323 (nearest centre; M == wrap channel = M/2)
-        int ch = csdr_post_channel_at(post, s.prm.frequency);
+        int ch;
+        if (s.route_ch != -2 && s.route_freq == (int64_t)s.prm.frequency && s.route_post_freq == (int64_t)post->frequency && s.route_post_rate == (int64_t)post->sample_rate && s.route_M == M)
+            ch = s.route_ch;
+        else {
+            ch = csdr_post_channel_at(post, s.prm.frequency);
+            s.route_freq = (int64_t)s.prm.frequency; s.route_post_freq = (int64_t)post->frequency; s.route_post_rate = (int64_t)post->sample_rate; s.route_M = M; s.route_ch = ch;
+        }
         if (ch < 0) continue;
         const int64_t centre = (M == 1) ? post->frequency : post->centers[ch];
         const int data_ch = (M > 1 && ch == M) ? M / 2 : ch;
@@ -425,9 +432,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         CSDR_HIP_TRY(hipStreamWaitEvent(st, post->ev_ready[pk], 0));
     }
     if (b->audio_pending[bpar]) if (int rc = c->wait(b->ev_audio_done[bpar], LANE_AUDIO, LANE_FE)) return rc;
-    CSDR_HIP_TRY(hipMemcpyAsync(dyns_d, dyns_h, b->max_demods * sizeof(SlotDyn), hipMemcpyHostToDevice, st));
-    CSDR_HIP_TRY(hipMemcpyAsync(lists_d, slot_list_h, 3 * (size_t)b->max_demods * sizeof(int), hipMemcpyHostToDevice, st));
-    CSDR_HIP_TRY(hipMemcpyAsync(plans_d, plans_h, (size_t)b->max_demods * (NB + 1) * sizeof(BlockPlan), hipMemcpyHostToDevice, st));
+    CSDR_HIP_TRY(hipMemcpyAsync(table_d, table_h, b->off_plans + (size_t)b->max_demods * (NB + 1) * sizeof(BlockPlan), hipMemcpyHostToDevice, st));
     CSDR_HIP_TRY(hipEventRecord(b->stage_ev[ring], st));
     b->stage_used[ring] = true;
     // front-end geometry: every slot's batch is cut into P ranges; a range re-runs `warm` inputs in front of it.

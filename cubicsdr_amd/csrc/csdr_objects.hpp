@@ -65,6 +65,10 @@ struct SlotHost {
     bool shift_valid = false;
     int hist_parity = 0, last_parity = 0;
     int prev_J = 0;                          // resampled-IQ samples of the previous executed batch
+    // routing of the last batch: getChannelAt is a scan over M + 1 centres (1 M comparisons per batch with 1024 demodulators behind M = 1024);
+    // the centres are a function of (post frequency, sample rate, M): same key, same channel
+    int64_t route_freq = 0, route_post_freq = 0, route_post_rate = 0;
+    int route_M = 0, route_ch = -2;          // -2: nothing cached
     int warm = 0;                            // cascade span in input samples (+ one output period)
     bool fms_sos_set = false;                // csdr_bank_set_fms_pilot: caller-supplied pilot band-pass sections
     float fms_b[15] = {0}, fms_a[15] = {0};
@@ -84,17 +88,19 @@ struct csdr_bank {
     DevBuf<SlotCfg> cfgs;
     // per-batch device tables, two copies: the front-end of batch i+1 uploads its set while the audio kernels of batch i
     // still read theirs
-    DevBuf<SlotDyn> dyns;                    // [2][max_demods]
-    DevBuf<int> slot_list;                   // [2][3][max_demods]: all running slots | running auto-gain slots | grouped by front-end kernel
-    DevBuf<BlockPlan> plans;                 // [2][max_demods][max_blocks + 1]
+    // ONE table per copy, uploaded by one transfer per batch (three transfers were three stream round trips: 75 us of a 0.65 ms C4 batch):
+    //   SlotDyn [max_demods] | int [3][max_demods]: all running slots | running auto-gain slots | grouped by front-end kernel | BlockPlan [max_demods][blocks + 1]
+    DevBuf<char> tables;                     // [2][table_bytes]
+    size_t table_bytes = 0, off_lists = 0, off_plans = 0;
+    SlotDyn *dyns_of(char *t) const { return reinterpret_cast<SlotDyn *>(t); }
+    int *lists_of(char *t) const { return reinterpret_cast<int *>(t + off_lists); }
+    BlockPlan *plans_of(char *t) const { return reinterpret_cast<BlockPlan *>(t + off_plans); }
     uint64_t seq = 0;
     hipEvent_t ev_fe_done[2] = {nullptr, nullptr}, ev_audio_done[2] = {nullptr, nullptr};
     bool audio_pending[2] = {false, false};
     DevBuf<float> arms;
     DevBuf<ModemConsts> mconsts;
-    PinBuf<SlotDyn> dyns_h[kStageRing];
-    PinBuf<int> slot_list_h[kStageRing];
-    PinBuf<BlockPlan> plans_h[kStageRing];
+    PinBuf<char> tables_h[kStageRing];
     hipEvent_t stage_ev[kStageRing] = {nullptr, nullptr, nullptr, nullptr};
     bool stage_used[kStageRing] = {false, false, false, false};
     int stage_next = 0;
