@@ -80,6 +80,10 @@ def test_emu_nbfm_c1(ctx):
     G.test_nbfm_c1_config(ctx)
 
 
+def test_emu_depth_two_cascade(ctx):
+    G.test_nbfm_from_100k_channels_depth_two_cascade(ctx)
+
+
 @full
 def test_emu_mixed_modems(ctx):
     G.test_mixed_modems_streaming(ctx)

@@ -377,6 +377,14 @@ def test_nbfm_c1_config(ctx):
     print(_compare(got, want, "c1"))
 
 
+def test_nbfm_from_100k_channels_depth_two_cascade(ctx):
+    """the C4 channel rate (100 MS/s / 1024 = 97 656.25 S/s) in a small frame: NBFM behind it is a TWO-stage half-band cascade (m = 5, 10) and the
+    arbitrary stage at 0.512 -- the generic front-end kernel (a specialised depth-2 instance with 1024-sample chunks was measured in round 4:
+    0.28 against 0.23 ms per C4 batch, not kept); AM next to it runs depth 4.  6 blocks in batches of 2."""
+    got, want = _run_demods(ctx, 781250, 8, 8 * 1628, ["NBFM", "AM", "NBFM"], 6, 2, seed=23)
+    print(_compare(got, want, "depth2"))
+
+
 def test_mixed_modems_streaming(ctx):
     got, want = _run_demods(ctx, 2400000, 4, 40000, ["NBFM", "AM", "USB", "LSB", "NBFM", "AM", "USB"], 6, 1)
     print(_compare(got, want, "mixed"))
