@@ -166,6 +166,10 @@ def test_emu_spectrum_many_frames(ctx):
     G.test_spectrum_many_frames_one_batch(ctx)
 
 
+def test_emu_routing_follows_retunes(ctx):
+    G.test_routing_follows_centre_and_demodulator_retunes(ctx)
+
+
 @full
 def test_emu_retune_skip_inactive(ctx):
     G.test_retune_skip_and_inactive(ctx)

@@ -1446,6 +1446,55 @@ def test_retune_skip_and_inactive(ctx):
     post.close(); bank.close()
 
 
+def test_routing_follows_centre_and_demodulator_retunes(ctx):
+    """getChannelAt per block (SDRPostThread.cpp:128-139, :317-323) behind M = 4: the channel of a demodulator changes when the stream's centre
+    frequency moves (every channel centre moves with it) and when the demodulator itself is retuned across channels; between such steps the
+    routing of a batch is the cached one.  Each step against the reference's post thread + pre-thread + modem, one block per batch.  (No step
+    lands on channel 0: its DC-blocker state noise has its own tests.)"""
+    from cubicsdr_amd.engine import DemodBank, SDRPost
+    from oracle.cubicsdr_chain import RefDemod, RefSDRPost
+    fs, M, block, center = 2400000, 4, 40000, 100000000
+    be = _backend()
+    cw = fs // M
+    f_a, f_b = center + 450000, center - 1050000
+    # a carrier at every offset from the stream centre a demodulator is ever tuned to (+-450 k, +-1050 k): no step demodulates bare noise
+    x = synth_iq(8 * block, fs, center, [("NBFM", f_a), ("AM", f_b), ("NBFM", center + 1050000), ("AM", center - 450000)], seed=91)
+    post, ref_post = SDRPost(ctx, fs, M, block, max_blocks=1), RefSDRPost(be, fs, M)
+    bank = DemodBank(ctx, 2, max_blocks=1)
+    steps = [  # (stream centre, frequency of demod 0, frequency of demod 1)        channels
+        (center, f_a, f_b), (center, f_a, f_b),                                    # 1, 2 (cached on the second block)
+        (center - cw, f_a, f_b), (center - cw, f_a, f_b),                          # the centre moves by one channel: 2 (the wrap channel), 3
+        (center - cw, f_a - cw, f_b), (center - cw, f_a - cw, f_b),                # demod 0 retuned into the next channel: 1, 3
+        (center, f_a, f_b + cw), (center, f_a, f_b)]                               # centre and both demodulators at once: 1, 3; then the first routing
+    kinds, bws = ["NBFM", "AM"], [12500, 6000]
+    refs = []
+    for i, k in enumerate(kinds):
+        bank.configure(i, post, k, bws[i], steps[0][1 + i])
+        refs.append(RefDemod(be, k, bws[i], steps[0][1 + i], ref_post.chan_bw))
+    seen = set()
+    for b, (c0, f0, f1) in enumerate(steps):
+        xb = x[b * block:(b + 1) * block]
+        for i, f in enumerate((f0, f1)):
+            bank.set_frequency(i, f); refs[i].frequency = f
+        post.execute(xb, 1, block, c0)
+        bank.execute(post)
+        ref_post.run_block(xb, c0)
+        for i, f in enumerate((f0, f1)):
+            ch = ref_post.channel_at(f)
+            assert ch != 0, (b, i)
+            seen.add((i, ch))
+            data, fc, rate = ref_post.channel_data(ch)
+            res = bank.results(i)
+            riq = refs[i].pre(data, fc, rate)
+            assert riq is not None and len(res) == 1 and res[0].skipped == 0, (b, i)
+            want = refs[i].demodulate(riq)
+            assert res[0].n_iq == riq.size and res[0].n_audio == want["audio"].size, (b, i, res[0].n_iq, riq.size)
+            assert rel_err(bank.iq(i), riq) < TOL, (b, i, ch)
+            assert rel_err(bank.audio(i), want["audio"]) < TOL, (b, i, ch)
+    assert len({c for i, c in seen if i == 0}) >= 2 and len({c for i, c in seen if i == 1}) >= 2, seen      # the routing really moved
+    post.close(); bank.close()
+
+
 # ----------------------------------------------------------------------------------------------- error behaviour
 def test_error_codes_and_edge_inputs(ctx):
     """The ABI never throws and never falls back: bad arguments, state errors, capacity overruns and not-built features come
