@@ -467,6 +467,11 @@ __host__ __device__ constexpr size_t fes_lds_bytes() {
 constexpr int fes_m(int S, int e) { return e == S - 1 ? 10 : (e == S - 2 ? 5 : 3); }
 // the odd-sample array of a stage with odd m starts one entry later, so that the pair O[2t - m], O[2t - m + 1] a thread
 // reads is 16-byte aligned like its even-sample window
+// (Where an odd-m stage is followed by an even-m one -- m = 5 then m = 10 -- the shifted region's last odd sample and the next region's tail
+// entry 0 are ONE address.  Tail entry 0 is never read (the deepest reach is 19 of the 24 entries); it is WRITTEN by the tail carry, which runs
+// after the stage that read the shifted region and a barrier before the stage that refills it, so the refill always lands last.  A depth-2
+// instance would break that order -- its mix refills the region right behind the carry with no barrier between, safe only inside one wave:
+// measured in round 4, slower than the generic kernel, not instantiated.)
 template <int S, int CH>
 __host__ __device__ constexpr int fes_offo(int e) { return fes_off<CH>(e) + (fes_m(S, e) & 1); }
 
