@@ -45,9 +45,8 @@ struct Rccl {
 Rccl &rccl() { static Rccl r; return r; }
 int rccl_load() {
     Rccl &r = rccl();
-    if (r.lib) return CSDR_OK;
     static std::mutex mu;
-    std::lock_guard<std::mutex> lk(mu);
+    std::lock_guard<std::mutex> lk(mu);          // (taken on every call: communicators are created once per process, collectives do not come here)
     if (r.lib) return CSDR_OK;
     void *h = nullptr;
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
@@ -66,6 +65,13 @@ int rccl_load() {
         const int e__ = (expr);                                                                                           \
         if (e__ != kNcclSuccess) return ::csdr::fail(CSDR_EHIP, "%s failed: %s", #expr, rccl().GetErrorString(e__));      \
     } while (0)
+// a group of sends / receives: closed on every path out of the scope (an early error return must not leave the communicator inside an open group)
+struct GroupScope {
+    bool open = false;
+    int start() { const int e = rccl().GroupStart(); open = e == kNcclSuccess; return e; }
+    int end() { open = false; return rccl().GroupEnd(); }
+    ~GroupScope() { if (open) (void)rccl().GroupEnd(); }
+};
 }  // namespace
 
 struct csdr_comm {
@@ -104,7 +110,10 @@ extern "C" int csdr_comm_create(csdr_ctx *ctx, const char *unique_id, int rank, 
     memcpy(id.internal, unique_id, sizeof id.internal);
     CSDR_RCCL_TRY(rccl().CommInitRank(&m->nc, world, id, rank));      // collective: every rank of the node calls it with the same id
 #endif
-    if (int rc = m->scalar.reserve(2)) return rc;
+    if (int rc = m->scalar.reserve(2)) {
+        if (m->nc) (void)rccl().CommDestroy(m->nc);
+        return rc;
+    }
     ctx->boundary_shared = true;              // the library itself enqueues on the boundary stream from now on: the lanes must order against it
     *out = m.release();
     return CSDR_OK;
@@ -145,11 +154,12 @@ extern "C" int csdr_comm_scatter(csdr_comm *m, const float *send_dev, float *rec
         CSDR_HIP_TRY(hipMemcpyAsync(recv_dev, send_dev, cnt * sizeof(float), hipMemcpyDeviceToDevice, st));
         return CSDR_OK;
     }
-    CSDR_RCCL_TRY(rccl().GroupStart());
+    GroupScope grp;
+    CSDR_RCCL_TRY(grp.start());
     if (m->rank == root)
         for (int r = 0; r < m->world; ++r) CSDR_RCCL_TRY(rccl().Send(send_dev + (size_t)r * cnt, cnt, kNcclFloat, r, m->nc, st));
     CSDR_RCCL_TRY(rccl().Recv(recv_dev, cnt, kNcclFloat, root, m->nc, st));
-    CSDR_RCCL_TRY(rccl().GroupEnd());
+    CSDR_RCCL_TRY(grp.end());
     return CSDR_OK;
 }
 
@@ -173,7 +183,8 @@ extern "C" int csdr_comm_all_to_all(csdr_comm *m, const float *send_dev, const i
         return CSDR_OK;
     }
     if (send_samples[m->rank] != recv_samples[m->rank]) return fail(CSDR_EINVAL, "a rank's counts to and from itself differ");
-    CSDR_RCCL_TRY(rccl().GroupStart());
+    GroupScope grp;
+    CSDR_RCCL_TRY(grp.start());
     size_t so = 0, ro = 0, self_so = 0, self_ro = 0;
     for (int q = 0; q < m->world; ++q) {
         if (q == m->rank) { self_so = so; self_ro = ro; }                 // the part that stays on this GPU is a device copy, not a transfer
@@ -183,7 +194,7 @@ extern "C" int csdr_comm_all_to_all(csdr_comm *m, const float *send_dev, const i
         }
         so += (size_t)send_samples[q]; ro += (size_t)recv_samples[q];
     }
-    CSDR_RCCL_TRY(rccl().GroupEnd());
+    CSDR_RCCL_TRY(grp.end());
     if (send_samples[m->rank])
         CSDR_HIP_TRY(hipMemcpyAsync(recv_dev + 2 * self_ro, send_dev + 2 * self_so, (size_t)send_samples[m->rank] * sizeof(float2), hipMemcpyDeviceToDevice, st));
     return CSDR_OK;
@@ -199,13 +210,14 @@ extern "C" int csdr_comm_p2p(csdr_comm *m, const csdr_p2p_op *ops, int n) {
     if (int rc = comm_begin(m)) return rc;
     if (m->loopback || n == 0) return CSDR_OK;
     hipStream_t st = m->ctx->stream;
-    CSDR_RCCL_TRY(rccl().GroupStart());
+    GroupScope grp;
+    CSDR_RCCL_TRY(grp.start());
     for (int i = 0; i < n; ++i) {
         if (!ops[i].n_samples) continue;
         if (ops[i].recv) CSDR_RCCL_TRY(rccl().Recv(ops[i].buf, (size_t)2 * (size_t)ops[i].n_samples, kNcclFloat, ops[i].peer, m->nc, st));
         else CSDR_RCCL_TRY(rccl().Send(ops[i].buf, (size_t)2 * (size_t)ops[i].n_samples, kNcclFloat, ops[i].peer, m->nc, st));
     }
-    CSDR_RCCL_TRY(rccl().GroupEnd());
+    CSDR_RCCL_TRY(grp.end());
     return CSDR_OK;
 }
 
