@@ -131,8 +131,19 @@ def main(args):
             bps = 0.0
         units = (nb_rank if dom == "chan_analyze" else NB) * BLOCK
         alg = bps * units / lpb
+        traffic, traffic_file = None, None
+        if world == 1 and not slab:
+            # HBM bytes of the dominant kernel from the committed PMC pass of this command (profiles/collect.sh; one rank, broadcast variant)
+            try:
+                import bench
+                per_block, traffic_file = bench.measured_traffic("C4")
+                if dom in per_block:
+                    traffic = per_block[dom] * (units / BLOCK) / lpb
+            except Exception:
+                traffic = None
         out["roofline"].update({"kernel": dom, "achieved": alg / (avg[dom] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / (avg[dom] * 1e-3) / 1e9 / 8000.0,
-                                "traffic": None, "avg_launch_ms": avg[dom], "launches_per_batch": lpb, "algorithmic_bytes_per_launch": alg,
+                                "traffic": traffic, "traffic_unit": ("HBM bytes per launch of the dominant kernel (PMC pass %s)" % traffic_file) if traffic is not None else None,
+                                "avg_launch_ms": avg[dom], "launches_per_batch": lpb, "algorithmic_bytes_per_launch": alg,
                                 "profile_sampling": "HIP events around every %d-th launch of each kernel id on rank 0, inside the timed region" % profile_period,
                                 "kernels_ms_per_batch": {k: per_batch[k] for k in sorted(per_batch, key=lambda k: -per_batch[k])}})
     st.close()
