@@ -243,11 +243,9 @@ extern "C" int csdr_bank_set_active(csdr_bank *b, int slot, int active) {
     return CSDR_OK;
 }
 
-static inline int64_t first_out(int64_t K, uint32_t phase0, uint32_t step) {
-    const int64_t lim = K * (int64_t)(1 << 24) - (int64_t)phase0;
-    if (lim <= 0) return -((-lim) / (int64_t)step);
-    return (lim + step - 1) / step;
-}
+// the smallest j with j * step >= K 2^24 - phase0 (K may be negative): the device's closed form (kernels_demod.hpp: a double quotient and two
+// integer corrections -- exact, and a third of the cost of the 64-bit division this walk used to pay twice per demodulator and block)
+static inline int64_t first_out(int64_t K, uint32_t phase0, uint32_t step) { return resamp_first_out(K, phase0, step); }
 
 extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     RangeScope range__("csdr_bank_execute");
