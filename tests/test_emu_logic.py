@@ -238,6 +238,10 @@ def test_emu_spectrum_nan_repairs_frame_by_frame(ctx):
     G.test_spectrum_nan_samples_recover_frame_by_frame(ctx, 2048, (40, 23), ((5, 100), (38, 7), (41, 3000)))
 
 
+def test_emu_comm_refusals(ctx):
+    G.test_comm_refuses_bad_arguments(ctx)
+
+
 def test_emu_comm_one_rank(ctx):
     """csdr_comm's entry points and the drivers' ABI transport with the one-rank loopback of the host-executing build"""
     G._comm_one_rank_case(ctx, False)

@@ -1334,6 +1334,62 @@ def _comm_one_rank_case(ctx, use_torch):
     return worst
 
 
+def test_comm_refuses_bad_arguments(ctx):
+    """the communicator's entry points never half-apply a bad call: ranks outside the world, a rank's own part as a transfer, counts that do
+    not match, null buffers and posts of another context come back as negative codes; the communicator keeps working afterwards."""
+    import ctypes as C
+    import cubicsdr_amd.hip as H
+    from cubicsdr_amd.engine import Context, SDRPost
+    from cubicsdr_amd.parallel import exchange_id
+    L = H.lib()
+    EINVAL = -1
+    cid = exchange_id(0, 1)
+    comm = C.c_void_p()
+    assert L.csdr_comm_create(ctx.h, cid, 1, 1, C.byref(comm)) == EINVAL           # rank outside the world
+    assert L.csdr_comm_create(ctx.h, cid, 0, 0, C.byref(comm)) == EINVAL
+    assert L.csdr_comm_create(None, cid, 0, 1, C.byref(comm)) == EINVAL
+    assert L.csdr_comm_create(ctx.h, cid, 0, 1, C.byref(comm)) == 0
+    assert L.csdr_comm_rank(comm) == 0 and L.csdr_comm_world(comm) == 1 and L.csdr_comm_rank(None) == -1 and L.csdr_comm_world(None) == 0
+    n = 4096
+    buf = C.c_void_p(); out = C.c_void_p()
+    assert L.csdr_dev_alloc(ctx.h, n * 8, C.byref(buf)) == 0 and L.csdr_dev_alloc(ctx.h, n * 8, C.byref(out)) == 0
+    x = (np.arange(2 * n, dtype=np.float32) / n).astype(np.float32)
+    assert L.csdr_dev_upload(ctx.h, buf, x.ctypes.data_as(C.c_void_p), x.nbytes) == 0
+    assert L.csdr_comm_broadcast(comm, buf, n, 1) == EINVAL                        # root outside the world
+    assert L.csdr_comm_broadcast(comm, None, n, 0) == EINVAL
+    assert L.csdr_comm_broadcast(comm, buf, -1, 0) == EINVAL
+    assert L.csdr_comm_scatter(comm, None, out, n, 0) == EINVAL                    # the root has nothing to send
+    assert L.csdr_comm_scatter(comm, buf, out, n, 3) == EINVAL
+    cnt = (C.c_int64 * 1)(n); other = (C.c_int64 * 1)(n - 1); neg = (C.c_int64 * 1)(-1)
+    assert L.csdr_comm_all_to_all(comm, buf, cnt, out, other) == EINVAL            # a rank's counts to and from itself differ
+    assert L.csdr_comm_all_to_all(comm, buf, neg, out, cnt) == EINVAL
+    assert L.csdr_comm_all_to_all(comm, None, cnt, out, cnt) == EINVAL
+    op = (H.P2pOp * 1)(H.P2pOp(0, 0, buf.value, n))
+    assert L.csdr_comm_p2p(comm, op, 1) == EINVAL                                  # a rank's own part is never a transfer
+    op[0].peer = 2
+    assert L.csdr_comm_p2p(comm, op, 1) == EINVAL
+    assert L.csdr_comm_p2p(comm, None, 1) == EINVAL and L.csdr_comm_p2p(comm, None, 0) == 0
+    assert L.csdr_comm_max(comm, None) == EINVAL
+    # posts of another context
+    c2 = Context(0)
+    p1, p2 = SDRPost(ctx, 800000, 8, 8 * 64, max_blocks=1), SDRPost(c2, 800000, 8, 8 * 64, max_blocks=1)
+    chans = (C.c_int * 8)(*range(8)); nch = (C.c_int * 1)(8); f0 = (C.c_int64 * 1)(0); fr = (C.c_int64 * 1)(64)
+    assert L.csdr_post_exchange_rows(comm, p1.h, p2.h, chans, nch, f0, fr, 1, 8 * 64, 100000000) == EINVAL
+    assert L.csdr_post_exchange_rows(comm, p1.h, None, chans, nch, f0, fr, 1, 8 * 64, 100000000) == EINVAL
+    nneg = (C.c_int * 1)(-8)
+    assert L.csdr_post_exchange_rows(comm, p1.h, p1.h, chans, nneg, f0, fr, 1, 8 * 64, 100000000) == EINVAL
+    p1.close(); p2.close(); c2.close()
+    # ... and a valid call still works
+    assert L.csdr_comm_scatter(comm, buf, out, n, 0) == 0
+    v = C.c_double(2.5)
+    assert L.csdr_comm_max(comm, C.byref(v)) == 0 and v.value == 2.5
+    y = np.zeros_like(x)
+    assert L.csdr_dev_download(ctx.h, y.ctypes.data_as(C.c_void_p), out, y.nbytes) == 0
+    assert np.array_equal(x, y)
+    L.csdr_comm_destroy(comm)
+    assert L.csdr_dev_free(ctx.h, buf) == 0 and L.csdr_dev_free(ctx.h, out) == 0
+
+
 @pytest.mark.parametrize("M", [10, 20, 68, 122])
 def test_packed_row_order_holds_the_same_rows(ctx, M):
     """csdr_post_set_row_order (time-slab producers: rows grouped by owning rank, so that the output buffer is the all-to-all's send buffer):
