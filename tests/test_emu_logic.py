@@ -161,6 +161,10 @@ def test_emu_spectrum_zoomed_view(ctx):
     G.test_spectrum_zoomed_view(ctx)
 
 
+def test_emu_spectrum_zoomed_view_two_pass(ctx):
+    G.test_spectrum_zoomed_view_behind_a_two_pass_transform(ctx)
+
+
 @full
 def test_emu_spectrum_many_frames(ctx):
     G.test_spectrum_many_frames_one_batch(ctx)

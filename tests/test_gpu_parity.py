@@ -820,6 +820,53 @@ def test_spectrum_zoomed_view(ctx):
     sp.close()
 
 
+def test_spectrum_zoomed_view_behind_a_two_pass_transform(ctx):
+    """the zoomed view at fftSize 4096 (8192-point transform = a radix-2 column pass + 4096-point rows): behind a multi-pass transform the
+    averagers live in PAIR order (spec_state_index), so a retune (shift), a zoom step in and one out have to move them through that order
+    (SpectrumVisualProcessor.cpp:316-331, :454-492); peak hold across the steps."""
+    from cubicsdr_amd.engine import SpectrumProcessor
+    from oracle.cubicsdr_chain import RefSpectrum
+    F, fs, center = 4096, 2400000, 100000000
+    block = 40000
+    steps = [  # (view centre, view bandwidth, peak-hold toggle)
+        (center + 200000, 500000, None), (center + 200000, 500000, None), (center + 200000, 500000, True), (center + 200000, 500000, None),
+        (center + 230000, 500000, None), (center + 230000, 500000, None),              # retune: the averagers shift
+        (center + 230000, 1000000, None), (center + 230000, 1000000, None),            # zoom out
+        (center + 170000, 500000, None), (center + 170000, 500000, None),              # zoom in and shift
+        (center, 1000000, None), (center, 1000000, None)]                              # centred on the input: no mixing
+    x = synth_iq(len(steps) * block, fs, center, [("NBFM", center + 200000.0), ("AM", center + 100000.0), ("NBFM", center - 310000.0)], seed=53)
+    sp = SpectrumProcessor(ctx, F, max_frames=1)
+    ref = RefSpectrum(_backend(), F)
+    ref.set_hide_dc(True, 0, 0, 0)
+    sp.set_hide_dc(True)
+    frames = held = 0
+    for k, (vc, vbw, toggle) in enumerate(steps):
+        if toggle is not None:
+            sp.set_peak_hold(toggle)
+            ref.set_peak_hold(toggle)
+        sp.set_view(True, vc, vbw)
+        ref.set_view(True, vc, vbw)
+        xin = x[k * block:(k + 1) * block]
+        want = ref.process_input(xin, center, fs)
+        nf = sp.process_view_input(xin, center, fs)
+        assert sp.desired_input_size == ref.desired_input_size, k
+        assert nf == (0 if want is None else 1), k
+        if want is None:
+            continue
+        wp, wce, wfl, whold = want
+        pts, ce, fl = sp.fetch(0)
+        hold = sp.fetch_hold(0)
+        assert rel_err(pts, wp) < TOL, (k, rel_err(pts, wp))
+        assert abs(ce - wce) <= TOL * abs(wce) and abs(fl - wfl) <= TOL * abs(wce), k
+        assert (hold is None) == (whold is None), k
+        if hold is not None:
+            assert rel_err(hold, whold) < TOL, k
+            held += 1
+        frames += 1
+    assert frames >= len(steps) - 2 and held >= 1, (frames, held)      # (a view change restarts the peak countdown: few held frames in twelve steps)
+    sp.close()
+
+
 def test_spectrum_many_frames_one_batch(ctx):
     """300 frames in ONE process() call (the averaging kernel splits a batch into 16 frame groups per round of 256
     frames and chains rounds): every frame must equal the frame-at-a-time reference."""
