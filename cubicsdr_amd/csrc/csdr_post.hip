@@ -445,7 +445,10 @@ static int post_row_list(csdr_post *p, const int *channels, int n, const int **d
         if (p->rowlists.size() >= 64) return fail(CSDR_ERANGE, "too many distinct channel lists");
         int *d = nullptr;
         if (hipMalloc((void **)&d, (size_t)n * sizeof(int)) != hipSuccess) return fail(CSDR_ENOMEM, "channel list");
-        CSDR_HIP_TRY(hipMemcpy(d, channels, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        if (hipMemcpy(d, channels, (size_t)n * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d);
+            return fail(CSDR_EHIP, "channel list upload");
+        }
         it = p->rowlists.emplace(std::move(key), d).first;
     }
     *dev_list = it->second;
