@@ -269,6 +269,82 @@ def parity_sample(cfg, ring_host, make_pipeline, n_check=12, n_blocks=2):
             "full_suite": "tests/test_gpu_parity.py compares every demodulator x 3 blocks and ~1000 spectrum frames of this configuration (DESIGN.md 2)"}
 
 
+class Sensors:
+    """core / memory clock, package power and junction temperature of ONE GPU, read from the amdgpu hwmon files of its PCI device
+    (/sys/bus/pci/devices/<bdf>/hwmon/hwmon*/{freq1,freq2,power1,temp2}_input) by a sampling thread while the timed region runs: the
+    kernels on this path are bound by instruction issue, so their durations follow the core clock -- which differs from box to box and
+    ramps for ~40 ms after the GPU was idle (profiles/r05_variance.txt).  Best effort: {} where the files do not exist."""
+
+    def __init__(self, device_index, period_s=0.1):
+        import glob
+        self.files, self.samples, self.period, self._stop, self._th = {}, [], period_s, False, None
+        try:
+            hip = C.CDLL("libamdhip64.so")
+            buf = C.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) != 0:
+                return
+            bdf = buf.value.decode().lower()
+            for d in glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bdf):
+                for key, name in (("sclk_MHz", "freq1_input"), ("mclk_MHz", "freq2_input"), ("power_W", "power1_input"), ("junction_C", "temp2_input")):
+                    f = os.path.join(d, name)
+                    if os.path.exists(f):
+                        self.files[key] = f
+        except Exception:
+            self.files = {}
+
+    def read(self):
+        out = {}
+        for key, f in self.files.items():
+            try:
+                v = float(open(f).read().strip())
+                out[key] = v / 1e6 if key != "junction_C" else v / 1e3
+            except Exception:
+                pass
+        return out
+
+    def start(self):
+        if not self.files:
+            return
+        import threading
+
+        def loop():
+            while not self._stop:
+                self.samples.append(self.read())
+                time.sleep(self.period)
+        self._th = threading.Thread(target=loop, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        """-> {sensor: {min, median, max}} over the samples taken since start()"""
+        self._stop = True
+        if self._th:
+            self._th.join()
+        out = {"samples": len(self.samples)}
+        for key in self.files:
+            v = sorted(x[key] for x in self.samples if key in x)
+            if v:
+                out[key] = {"min": round(v[0], 1), "median": round(v[len(v) // 2], 1), "max": round(v[-1], 1)}
+        return out
+
+
+def spread(v):
+    s = sorted(v)
+    return {"n": len(s), "min": s[0], "median": s[len(s) // 2], "max": s[-1]} if s else {}
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line under torch.distributed.run, one rank per GPU of this node
+    (rendezvous on 127.0.0.1, a free port); rank 0 prints the one JSON line.  Never returns."""
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -291,7 +367,10 @@ def main():
     ap.add_argument("--ring", default="signal", choices=["signal", "noise"],
                     help="signal: noise + one modulated carrier per demodulator + DC (default, SURVEY.md 8d); noise: the noise and DC only "
                          "(counter-collection passes: rocprofv3 --pmc does not survive the thousands of small torch launches of the synthesis)")
+    ap.add_argument("--no-strong", action="store_true", help="--gpus N > 1, default configuration: skip the strong-scaling leg (C4, time slabs) that follows the timed region")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)                         # (does not return)
     if args.config == "C4":
         from cubicsdr_amd import sharded_bench
         return sharded_bench.main(args)
@@ -311,6 +390,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     dist = None
+    local_rank = local_rank % torch.cuda.device_count()          # (more ranks than GPUs: the one-GPU dry run of the multi-rank control flow, CSDR_DIST_BACKEND=gloo)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -320,6 +400,7 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    sensors = Sensors(local_rank)
 
     from cubicsdr_amd.engine import Context, DemodBank, SDRPost, SpectrumProcessor
     if args.ring == "noise":
@@ -362,6 +443,7 @@ def main():
         dist.barrier()
     if not args.no_profile:
         ctx.profile_enable(PROFILE_PERIOD)
+    sensors.start()
     ctx.timer_start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -370,16 +452,25 @@ def main():
     ctx.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    clocks = sensors.stop()
     if dist:
         dist.barrier()
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    prof = {}
+    prof, prof_rng = {}, {}
     if not args.no_profile:
         prof.update(ctx.profile())
+        prof_rng = ctx.profile_range()
         ctx.profile_enable(False)
     audio_total = bank.total_audio()
+    # the spread behind the mean: the same steps once more, each synchronised and timed on its own (after the timed region, which runs unbroken)
+    step_ms = []
+    for _ in range(min(args.steps, 10)):
+        ts = time.perf_counter()
+        step()
+        ctx.synchronize()
+        step_ms.append(1e3 * (time.perf_counter() - ts))
 
     samples = args.steps * NBATCH * NB * BLOCK * world
     value = samples / elapsed / 1e6
@@ -394,6 +485,9 @@ def main():
                    "timed_region_s": elapsed, "event_ms_per_step": ev_ms / args.steps,
                    "error_metric": "parity tests hold |gpu - reference| <= 1e-5 of the reference's peak magnitude per compared array (tests/util.py rel_err); integer items bit-exact",
                    "streams": streams,
+                   "step_ms": dict(spread(step_ms), note="the same step run again after the timed region, each synchronised on its own"),
+                   "clocks": dict(clocks, note="amdgpu hwmon of this GPU sampled every 0.1 s inside the timed region (the kernels are issue-bound: their durations follow sclk, "
+                                               "which differs from box to box and ramps for ~40 ms after idle: profiles/r05_variance.txt)"),
                    "parallelism": "one independent IQ stream per GPU; stages of the timed pipeline on %d HIP stream(s)" % streams},
     }
     if prof:
@@ -423,7 +517,7 @@ def main():
                            "frac": achieved / HBM_PEAK_GBS,
                            "traffic": (traffic[dom] * NB / launches_dom if dom in traffic else None),
                            "traffic_unit": "HBM bytes per launch of the dominant kernel (PMC pass %s: per IQ block, times the blocks of this launch)" % traffic_file,
-                           "avg_launch_ms": avg_ms, "launches_per_batch": launches_dom,
+                           "avg_launch_ms": avg_ms, "launch_ms_range": list(prof_rng.get(dom, (None, None))), "launches_per_batch": launches_dom,
                            "algorithmic_bytes_per_launch": alg_launch,
                            "whole_path": {"bytes_per_sample": round(bytes_per_sample, 1), "achieved": bytes_per_sample * value / world * 1e6 / 1e9,
                                           "frac": bytes_per_sample * value / world * 1e6 / 1e9 / HBM_PEAK_GBS,
@@ -539,6 +633,23 @@ def main():
                     out["cpu_baseline"]["parity"] = {"ok": None, "note": repr(e)}
         except Exception as e:  # the baseline is reported, never required for the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "MS/s", "cores": 0, "kind": "unavailable", "sample": repr(e)}
+    if world > 1 and not args.no_strong:
+        # Strong scaling next to the weak (replica) value: ONE 100 MS/s stream, M = 1024 channelizer + 1024 NBFM demodulators (BASELINE config 4),
+        # time slabs scattered from rank 0 and channel rows exchanged all-to-all (SURVEY 8e option 2; cubicsdr_amd/sharded_bench.py).  Collective:
+        # every rank runs it; a short, untimed-by-the-contract leg after the timed region.
+        del ring
+        torch.cuda.empty_cache()
+        try:
+            from cubicsdr_amd import sharded_bench
+            sargs = argparse.Namespace(**vars(args))
+            sargs.shard, sargs.blocks, sargs.batches, sargs.steps, sargs.warmup = "slab", 32, 6, max(2, min(args.steps, 5)), 1
+            sargs.no_profile, sargs.cpu_seconds, sargs.streams = True, 0.0, 3
+            so = sharded_bench.measure(sargs, dist=dist)
+            out["strong"] = {"workload": so["config"]["workload"], "value": so["value"], "unit": "MS/s", "scaling": "strong", "n_gpus": world,
+                             "ms_per_step": so["ms_per_step"], "steps": sargs.steps, "transport": so["config"]["transport"], "rccl_ranks": so["config"]["rccl_ranks"],
+                             "note": "one stream over all ranks (total work fixed); `value` above is the replica (weak) figure of the default configuration"}
+        except Exception as e:      # reported, never required for the headline number
+            out["strong"] = {"value": None, "note": repr(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist:

@@ -291,6 +291,7 @@ struct csdr_ctx {
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> prof_pool;
     double prof_ms[KID_COUNT] = {0};
+    double prof_min[KID_COUNT] = {0}, prof_max[KID_COUNT] = {0};    // shortest / longest bracketed launch
     long long prof_n[KID_COUNT] = {0};
     hipEvent_t prof_event() {                // (callers hold prof_mu)
         if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }

@@ -148,7 +148,11 @@ static int prof_drain(csdr_ctx *c) {
     std::lock_guard<std::mutex> lk(c->prof_mu);
     for (auto &r : c->prof_pending) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->prof_ms[r.id] += ms; c->prof_n[r.id] += 1; }
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            if (c->prof_n[r.id] == 0 || ms < c->prof_min[r.id]) c->prof_min[r.id] = ms;
+            if (c->prof_n[r.id] == 0 || ms > c->prof_max[r.id]) c->prof_max[r.id] = ms;
+            c->prof_ms[r.id] += ms; c->prof_n[r.id] += 1;
+        }
         c->prof_pool.push_back(r.a); c->prof_pool.push_back(r.b);
     }
     c->prof_pending.clear();
@@ -160,13 +164,20 @@ extern "C" int csdr_ctx_profile_enable(csdr_ctx *c, int on) {
     if (int rc = prof_drain(c)) return rc;
     c->prof_on = on != 0;
     c->prof_period = on > 1 ? on : 1;
-    if (on) for (int i = 0; i < KID_COUNT; i++) { c->prof_ms[i] = 0.0; c->prof_n[i] = 0; c->prof_seen[i] = 0; }
+    if (on) for (int i = 0; i < KID_COUNT; i++) { c->prof_ms[i] = 0.0; c->prof_min[i] = 0.0; c->prof_max[i] = 0.0; c->prof_n[i] = 0; c->prof_seen[i] = 0; }
     return CSDR_OK;
 }
 extern "C" int csdr_ctx_profile_launches(csdr_ctx *c, int id, int64_t *launches) {
     if (!c || id < 0 || id >= KID_COUNT || !launches) return fail(CSDR_EINVAL, "bad argument");
     std::lock_guard<std::mutex> lk(c->prof_mu);
     *launches = (int64_t)c->prof_seen[id];
+    return CSDR_OK;
+}
+extern "C" int csdr_ctx_profile_range(csdr_ctx *c, int id, double *min_ms, double *max_ms) {
+    DeviceScope dev__(c);
+    if (!c || id < 0 || id >= KID_COUNT || !min_ms || !max_ms) return fail(CSDR_EINVAL, "bad argument");
+    if (int rc = prof_drain(c)) return rc;
+    *min_ms = c->prof_n[id] ? c->prof_min[id] : 0.0; *max_ms = c->prof_n[id] ? c->prof_max[id] : 0.0;
     return CSDR_OK;
 }
 extern "C" int csdr_ctx_profile_num_kernels(void) { return KID_COUNT; }

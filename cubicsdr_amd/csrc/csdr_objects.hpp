@@ -47,10 +47,11 @@ struct csdr_post {
     double dc_c = 0.0;                       // feedback coefficient of the DC blocker recurrence
     bool raw = false;                        // internal (zoomed spectrum view): SINGLE mode hands the input on unfiltered
     bool dc_enabled = true;                  // csdr_post_set_dc_blocker: a time-slab producer leaves channel 0 to the rank that owns it
+    size_t out_off = 0;                      // samples between the allocation's base and the first output buffer (0 unless the measurement build moves it: CSDR_OUT_OFFSET_KB)
     int import_k = -1;                       // buffer being assembled by csdr_post_import_begin .. commit
     std::map<std::vector<int>, int *> rowlists;   // device copies of the channel lists export / import calls name (a handful, reused every batch)
 };
-static inline float2 *post_buf(const csdr_post *p, int k) { return p->out.p + (size_t)k * p->chan_stride * p->M; }
+static inline float2 *post_buf(const csdr_post *p, int k) { return p->out.p + p->out_off + (size_t)k * p->chan_stride * p->M; }
 
 // =================================================================================================== demodulator bank
 namespace csdr {

@@ -160,7 +160,9 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
         p->chan_stride = q * 16;
     }
     if (lab_int("CSDR_ROW_PAD", 1) == 0) p->chan_stride = ((int64_t)max_blocks * (max_block_len / p->hop) + 1) & ~(int64_t)1;      // the round-3 pitch (A/B)
-    if (int rc = p->out.reserve((size_t)p->chan_stride * M * csdr_post::kPostBufs)) return rc;
+    const int out_off_kb = lab_int("CSDR_OUT_OFFSET_KB", -1);                                  // (measurement build: where the output starts inside its allocation;
+    p->out_off = (size_t)std::max(0, out_off_kb) * 128;                                        //  the allocation itself is the same for every offset up to 8 MB)
+    if (int rc = p->out.reserve((size_t)p->chan_stride * M * csdr_post::kPostBufs + (out_off_kb >= 0 ? (size_t)1 << 20 : 0))) return rc;
     if (int rc = p->dc_state.reserve(2)) return rc;
     CSDR_HIP_TRY(hipMemsetAsync(p->dc_state.p, 0, 2 * sizeof(d2), st));
     p->dc_parity = 0;
@@ -362,6 +364,8 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
             const chan_p2_kernel_t k2 = chan_p2_kernel(g);
             const int chan_pct = std::max(10, std::min(100, lab_int("CSDR_CHAN_PCT", 100)));
             const int wgs = std::min(ntiles, std::max(1, c->wg_slots(k2, g.threads, chan_p2_lds_bytes(M)) * chan_pct / 100));
+            g.xcd = lab_int("CSDR_CHAN_XCD", g.xcd);
+            if (lab_int("CSDR_LAB_TRACE", 0)) fprintf(stderr, "[csdr lab] chan_analyze_p2 x=%p out=%p hist=%p taps=%p cs=%p twM=%p wgs=%d xcd=%d\n", (const void *)x, (void *)out, (void *)hist, (void *)p->taps.p, (void *)p->twA.p, (void *)p->twM.p, wgs, g.xcd);
             CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, k2, dim3(wgs), dim3(g.threads), chan_p2_lds_bytes(M), x, hist, hist_new, p->taps.p,
                         p->twA.p, p->twM.p, p->active.p, g, n_frames, out, p->chan_stride, fused_ends ? p->tile_end.p : (d2 *)nullptr, p->dc_c);
         } else {

@@ -208,6 +208,7 @@ struct ChanGeom {
     int oddA;                 // 1: A is odd (>= 3) and phase 1 uses the conjugate-pair form: KA / nkA / PA then count output PAIRS (k, A - k)
     int threads;              // workgroup size (whole waves, 256..512): chosen so each phase splits evenly over the waves
     int p2;                   // 1: M = 2 A, A odd <= 63, critically sampled: chan_analyze_p2 (KA = slots per pass, nkA = passes, PA = row pitch)
+    int xcd;                  // chan_analyze_p2: 1 = the workgroups of one XCD (blockIdx.x % 8) take CONSECUTIVE tiles of a round (grid a multiple of 8)
 };
 __host__ __device__ inline size_t chan_zin_floats2(const ChanGeom &g) {      // Z array, or the staged input tile if larger
     const size_t z = (size_t)g.TF * g.S, in = g.stage_in ? (size_t)(g.TF - 1) * g.hop + (size_t)kChanTaps * g.M : 0;
@@ -631,7 +632,10 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
         }
     }
     float4 win[2 * kChanTaps - 1];                              // this wave's FIR window of the tile: input rows f0 + ta - 7 .. f0 + ta + 7
+    // tile walk: workgroup b takes tiles b, b + grid, ...; with `xcd` the workgroups that share an L2 (b % 8: the dispatcher's round robin over the
+    // XCDs) take consecutive tiles of the round, so that the seven window rows two neighbouring tiles share meet in one L2
     int64_t tile = blockIdx.x;
+    if (g.xcd && !(gridDim.x & 7)) tile = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     chan_p2_request_window<>(x, hist, M, A, n_frames, tile, tile < n_tiles, wave, lane0, win);
     for (; tile < n_tiles; tile += gridDim.x) {
         const int64_t f0 = tile * kP2Frames;

@@ -87,6 +87,16 @@ class Context:
                 out[self._l.csdr_ctx_profile_kernel_name(i).decode()] = (ms.value, n.value, seen.value)
         return out
 
+    def profile_range(self):
+        """-> {kernel name: (shortest, longest) bracketed launch in ms} since profile_enable(...)"""
+        out = {}
+        for i in range(self._l.csdr_ctx_profile_num_kernels()):
+            lo, hi = C.c_double(), C.c_double()
+            H.check(self._l.csdr_ctx_profile_range(self.h, i, C.byref(lo), C.byref(hi)))
+            if hi.value > 0.0:
+                out[self._l.csdr_ctx_profile_kernel_name(i).decode()] = (lo.value, hi.value)
+        return out
+
     def close(self):
         if self.h:
             self._l.csdr_ctx_destroy(self.h)
@@ -488,6 +498,11 @@ class Comm:
         self.h = C.c_void_p()
         assert len(unique_id) == Comm.ID_BYTES
         H.check(self._l.csdr_comm_create(ctx.h, C.c_char_p(bytes(unique_id)), self.rank, self.world, C.byref(self.h)))
+
+    @property
+    def world_size(self):
+        """ranks of the communicator as the library reports them (csdr_comm_world)"""
+        return int(self._l.csdr_comm_world(self.h))
 
     @staticmethod
     def _ptr(buf):

@@ -64,6 +64,7 @@ ABI = {
     "csdr_ctx_profile_kernel_name": (C.c_char_p, [_i]),
     "csdr_ctx_profile_fetch": (_i, [_p, _i, C.POINTER(_d), C.POINTER(_i64)]),
     "csdr_ctx_profile_launches": (_i, [_p, _i, C.POINTER(_i64)]),
+    "csdr_ctx_profile_range": (_i, [_p, _i, C.POINTER(_d), C.POINTER(_d)]),
     "csdr_dev_alloc": (_i, [_p, C.c_uint64, _pp]),
     "csdr_dev_free": (_i, [_p, _p]),
     "csdr_dev_upload": (_i, [_p, _p, _p, C.c_uint64]),

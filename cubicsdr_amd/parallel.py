@@ -314,8 +314,19 @@ class SlabStream:
             if self.rank == src:
                 ext = self.extended(batch, n_blocks)
                 parts = [self._t(self.window(ext, n_blocks, r)).contiguous() for r in range(self.world)]
-            dist.scatter(self._t(mine), parts, src=src, group=self.group)
+            if self._host_staged():
+                # gloo moves host memory only (the one-GPU dry run of the multi-rank control flow): stage the windows through the host
+                mine_h = self._t(mine).cpu()
+                dist.scatter(mine_h, [p.cpu() for p in parts] if parts is not None else None, src=src, group=self.group)
+                self._t(mine).copy_(mine_h)
+            else:
+                dist.scatter(self._t(mine), parts, src=src, group=self.group)
         return mine
+
+    def _host_staged(self):
+        """True when the collectives of this stream run through a gloo group while the buffers are device memory"""
+        import torch.distributed as dist
+        return bool(self.use_torch and self.boundary.ts is not None and dist.get_backend(self.group) == "gloo")
 
     def _scatter_abi(self, batch, n_blocks, src):
         """The ingest rank sends every OTHER rank its window straight out of the batch -- a window starts `hist` samples in front of the rank's
@@ -393,7 +404,21 @@ class SlabStream:
         with self.boundary.on():
             self.ctx.join()                                         # the export kernels have filled `send`
             recv = self._empty(sum(outs))
-            dist.all_to_all_single(self._t(recv)[:sum(outs)].view(-1), self._t(send)[:sum(ins)].view(-1), [2 * v for v in outs], [2 * v for v in ins], group=self.group)
+            if self._host_staged():
+                # (gloo has no all-to-all either: one broadcast per source rank of its whole send buffer, every rank keeps its part)
+                import torch
+                sizes = [None] * self.world
+                dist.all_gather_object(sizes, int(sum(ins)), group=self.group)
+                off = 0
+                for p in range(self.world):
+                    buf = self._t(send)[:sizes[p]].cpu().contiguous() if p == self.rank else torch.empty((max(1, sizes[p]), 2), dtype=torch.float32)
+                    dist.broadcast(buf, src=p, group=self.group)
+                    mine_from_p = outs[p]
+                    o = sum(len(self.owned[q]) for q in range(self.rank)) * (slab_blocks(n_blocks, self.world)[p][1] * self.bc)
+                    self._t(recv)[off:off + mine_from_p].copy_(buf[o:o + mine_from_p])
+                    off += mine_from_p
+            else:
+                dist.all_to_all_single(self._t(recv)[:sum(outs)].view(-1), self._t(send)[:sum(ins)].view(-1), [2 * v for v in outs], [2 * v for v in ins], group=self.group)
         return recv
 
     def consume(self, recv, n_blocks):

@@ -13,6 +13,15 @@ NBFM_BW, AUDIO = 12_500, 48_000
 
 
 def main(args):
+    out = measure(args)
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps(out), flush=True)
+
+
+def measure(args, dist=None):
+    """one C4 measurement; collective over the ranks of the job, returns the bench line as a dict (rank 0's is the one that counts).
+    `dist`: an initialised torch.distributed module (bench.py's strong-scaling leg calls with its own process group): "nccl" (= RCCL) -> the
+    library's own communicator is used next to it; "gloo" (the one-GPU dry run) -> the collectives go through that group, staged on the host."""
     import torch
     from cubicsdr_amd import build as cbuild
     from cubicsdr_amd.parallel import ShardedStream, SlabStream, channel_centers
@@ -21,22 +30,29 @@ def main(args):
         cbuild.build(verbose=False)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # transport of the collectives: the library's own communicator (csdr_comm: RCCL behind the C ABI, no torch.distributed process group; the
     # id travels over a TCP store on MASTER_PORT + 1), or CSDR_C4_TRANSPORT=torch: torch.distributed ("nccl" is RCCL; CSDR_DIST_BACKEND overrides
     # it for one-GPU dry runs of the multi-rank control flow)
-    dist = None
+    own_group = False
     cid = None
-    if world > 1:
+    if dist is not None:
+        if dist.get_backend() == "nccl" and os.environ.get("CSDR_C4_TRANSPORT", "abi") == "abi":
+            from cubicsdr_amd.parallel import exchange_id
+            cid = exchange_id(rank, world)
+            dist = None
+    elif world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("CSDR_C4_TRANSPORT", "abi") == "abi":
+        if os.environ.get("CSDR_C4_TRANSPORT", "abi") == "abi" and os.environ.get("CSDR_DIST_BACKEND", "nccl") == "nccl":
             from cubicsdr_amd.parallel import exchange_id
             cid = exchange_id(rank, world)
         else:
             import torch.distributed as dist
             dist.init_process_group(os.environ.get("CSDR_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
             dist.barrier()
+            own_group = True
     # the timed pipeline runs its stages on ONE HIP stream unless told otherwise (as bench.py's default configuration does): every kernel runs
     # alone, so the live per-kernel durations are the kernels' own; the library's default folding (three streams) overlaps the channelizer of
     # batch i + 1 with the demodulators of batch i: higher throughput, stretched kernel durations
@@ -108,7 +124,8 @@ def main(args):
                       "channels_on_rank0": len(st.plan.active_channels), "realtime_multiple": value / (FS / 1e6), "timed_region_s": elapsed,
                       "parallelism": ("time slabs -> per-rank channelizer -> all-to-all of channel rows -> per-rank bank" if slab else
                                       "dp over demodulators (one IQ stream): broadcast + per-rank channel subset + per-rank bank"),
-                      "streams": streams, "transport": "torch.distributed" if dist else "csdr_comm (RCCL through the C ABI)" if cid is not None else "none (one rank)"},
+                      "streams": streams, "transport": ("torch.distributed (%s)" % dist.get_backend()) if dist else "csdr_comm (RCCL through the C ABI)" if cid is not None else "none (one rank)",
+                      "rccl_ranks": st.comm.world_size if st.comm is not None else 0},
            "roofline": {"bound": "hbm", "whole_path": {"bytes_per_sample": round(bytes_per_sample, 1), "achieved": bytes_per_sample * value * 1e6 / 1e9,
                                                        "frac": bytes_per_sample * value * 1e6 / 1e9 / 8000.0 / world}}}
     if prof:
@@ -158,7 +175,6 @@ def main(args):
             out["cpu_baseline"] = cb
         except Exception as e:
             out["cpu_baseline"] = {"value": None, "unit": "MS/s", "cores": 0, "kind": "unavailable", "sample": repr(e)}
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if dist:
+    if dist and own_group:
         dist.destroy_process_group()
+    return out

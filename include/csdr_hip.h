@@ -77,6 +77,9 @@ const char *csdr_ctx_profile_kernel_name(int id);
 int  csdr_ctx_profile_fetch(csdr_ctx *ctx, int id, double *total_ms, int64_t *launches);
 /* ALL launches of kernel `id` since the profile was enabled, bracketed or not (launches per batch = this / batches) */
 int  csdr_ctx_profile_launches(csdr_ctx *ctx, int id, int64_t *launches);
+/* shortest / longest bracketed launch of kernel `id` since the profile was enabled (the spread behind csdr_ctx_profile_fetch's mean: a kernel
+   whose duration moves with the clocks or the placement of its buffers shows it here); both 0 when nothing was bracketed */
+int  csdr_ctx_profile_range(csdr_ctx *ctx, int id, double *min_ms, double *max_ms);
 /* raw device memory for callers without a GPU array library (tests written in C/C++) */
 int  csdr_dev_alloc(csdr_ctx *ctx, uint64_t bytes, void **dev);
 int  csdr_dev_free(csdr_ctx *ctx, void *dev);
