@@ -9,6 +9,7 @@
 #include "csdr_objects.hpp"
 #include "kernels_spec.hpp"
 #include "kernels_spec2.hpp"
+#include "kernels_spec3.hpp"
 
 using namespace csdr;
 
@@ -64,6 +65,8 @@ struct csdr_spec {
     long vmap_bw = -1, vmap_rbw = -1;
     DevBuf<float2> peakf;
     bool view_frame = false;                 // the frames being post-processed belong to the zoomed view
+    bool fused_ok = false;                   // N = 2^17: the 512 x 256 chain with the averaging fused into the row pass exists (kernels_spec3.hpp)
+    bool fused_now = false;                  // ... and this batch takes it (full-span view, no peak hold set or pending)
 };
 
 extern "C" int csdr_spec_create(csdr_ctx *ctx, csdr_spec **out) {
@@ -170,6 +173,13 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     CSDR_HIP_TRY(hipMemcpy(s->tw_hi.p, hi.data(), hi.size() * sizeof(float2), hipMemcpyHostToDevice));
     const size_t nfN = (size_t)max_frames * N, F = (size_t)g.F;
     if (g.Ra == kC512) CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_cols512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC512Lds));
+    // the headline size: two passes with the averaging fused into the second (30 instead of 38 B per sample; CSDR_SPEC_FUSED=0 of the measurement
+    // build keeps the three-kernel chain for A/B runs)
+    s->fused_ok = N == kS3N && !npot && lab_int("CSDR_SPEC_FUSED", 1) != 0;
+    if (s->fused_ok) {
+        CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_cols512p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kP1Lds));
+        CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_rows256_ema, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kR2Lds));
+    }
     if (g.Ra > 1 && disp_lds_bytes((g.Ra >> 1) * g.Rb, ilog2(g.Ra) - 1 + ilog2(g.Rb), true) > 64 * 1024)      // the display tiles of 2^21-point frames with peak hold
         CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_display<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)disp_lds_bytes((g.Ra >> 1) * g.Rb, ilog2(g.Ra) - 1 + ilog2(g.Rb), true)));
     if (g.Ra > 1) if (int rc = s->tmp.reserve(nfN)) return rc;
@@ -238,6 +248,15 @@ static void launch_radix(csdr_ctx *c, int R, const FrameSrc &fs, int L, unsigned
 static int spec_run_fft(csdr_spec *s, const FrameSrc &fs, int nf, float *mag, float2 *raw) {
     const SpecGeom &g = s->g;
     csdr_ctx *c = s->ctx;
+    if (s->fused_now && !raw) {
+        // pass 1 of the 512 x 256 chain: Z[f][k1][n2] into `tmp`; pass 2 runs fused with the averaging (spec_post_range).  Persistent
+        // workgroups: 16 column tiles x as many frame groups as are resident at once, each walking its frames
+        const int ntile = kS3R / kP1Cols;
+        const int groups = std::max(1, std::min(nf, c->wg_slots(spec_cols512p, kP1Threads, kP1Lds) / ntile));
+        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_COLS, spec_cols512p, dim3(ntile * groups), dim3(kP1Threads), kP1Lds, fs, nf, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
+        CSDR_HIP_TRY(hipGetLastError());
+        return CSDR_OK;
+    }
     if (g.npot) {
         CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_bluestein, dim3(1, nf), dim3(kFftThreads), (size_t)2 * s->blue_L * sizeof(float2), fs, g.N, s->blue_L, s->tw4096.p,
                     s->blue_w.p, s->blue_B.p, mag, raw);
@@ -274,6 +293,21 @@ static int spec_post_range(csdr_spec *s, const float *mag, int f0, int cnt, int 
     const size_t F = (size_t)g.F;
     const bool hold = pk_from < cnt, view = s->view_frame;
     const bool bins = hold || view;                                  // per-bin averaged values are kept (maaf)
+    if (s->fused_now) {
+        if (hold || view) return fail(CSDR_ESTATE, "internal: the fused spectrum pass was chosen for a batch that holds peaks");
+        const int npairs = kS3C / 2;
+        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_rows256_ema, dim3(npairs), dim3(kR2Threads), kR2Lds, s->tmp.p + (size_t)f0 * g.N, cnt, g, (double)s->avg_rate, s->tw4096.p,
+                    s->ma.p, s->maa.p, s->pairsum.p + f0 * F, s->first_b.p + f0, s->ext_w.p + (size_t)f0 * npairs);
+        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_extrema, dim3(cnt), dim3(256), (size_t)(256 / 64) * sizeof(float2), s->ext_w.p + (size_t)f0 * npairs, npairs, s->ext.p + f0);
+        const SpecScalars *st_in = s->scal.p + s->scal_parity;
+        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_trackers, dim3(cnt), dim3(kDispThreads), kTrackLds, s->ext.p + f0, cnt, st_in, s->scal.p + (s->scal_parity ^ 1),
+                    s->fo.p + f0, s->fsc.p + f0, cnt, (const SpecFrameOut *)nullptr);
+        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_DISPLAY, spec_display_p256, dim3(64, cnt), dim3(kDispThreads), 32 * 33 * sizeof(float),
+                    s->pairsum.p + f0 * F, s->first_b.p + f0, s->fsc.p + f0, g, s->scale, s->points.p + f0 * F);
+        s->scal_parity ^= 1;
+        CSDR_HIP_TRY(hipGetLastError());
+        return CSDR_OK;
+    }
     // frame groups per workgroup: up to 16 frames each, so a short batch does not pay the set-up of sixteen groups
     // (CSDR_AVG_GROUPS = 4 | 8 | 16 caps the groups: fewer, smaller workgroups let two of them share a CU -- one loads its round while the
     // other scans)
@@ -409,7 +443,7 @@ template <typename PostFn>
 static int spec_fft_then(csdr_spec *s, const FrameSrc &fs, int nf, PostFn post) {
     csdr_ctx *c = s->ctx;
     // lane FFT fills magnitude copy `mp`; its previous reader was the averaging kernel two batches ago
-    const int mp = c->same(LANE_FFT, LANE_AVG) ? 0 : (int)(s->seq & 1);
+    const int mp = (c->same(LANE_FFT, LANE_AVG) || s->fused_now) ? 0 : (int)(s->seq & 1);      // (fused: the one intermediate buffer is the hand-off)
     float *mag = s->mag.p + (size_t)mp * s->max_frames * s->g.N;
     if (s->avg_pending[mp]) if (int rc = c->wait(s->ev_avg_done[mp], LANE_AVG, LANE_FFT)) return rc;
     if (int rc = spec_run_fft(s, fs, nf, mag, nullptr)) return rc;
@@ -430,6 +464,7 @@ static int spec_process_view(csdr_spec *s, const float *iq, int iq_is_dev, int b
     csdr_ctx *c = s->ctx;
     const int N = s->g.N, F = s->g.F;
     const int64_t rate = s->input_rate;
+    s->fused_now = false;                                                        // the zoomed view keeps per-bin values: the general kernels
     s->nf_last = 0;
     s->hold_valid.clear();
     // head of process() (:247, :264-273): doPeak is taken before the countdown moves; a reset uses the trackers as they stand
@@ -583,6 +618,8 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
     hipStream_t st = c->lanes[LANE_FFT];
     const SpecGeom &g = s->g;
     const int N = g.N;
+    // full-span view, no peak hold set or pending: the 512 x 256 chain with the averaging fused into its row pass
+    s->fused_now = s->fused_ok && !s->peak_hold && s->peak_reset == 0;
     const int64_t n = (int64_t)n_blocks * block_len;
     const float2 *x = (const float2 *)iq;
     if (int rc = c->lane_begin(LANE_FFT)) return rc;
