@@ -175,14 +175,15 @@ extern "C" int csdr_comm_all_to_all(csdr_comm *m, const float *send_dev, const i
         ts += send_samples[q]; tr += recv_samples[q];
     }
     if ((ts && !send_dev) || (tr && !recv_dev)) return fail(CSDR_EINVAL, "null buffer");
+    // every rank-local check comes BEFORE the first call the peers take part in: a rank that returned from here after the others had entered
+    // the grouped transfers would leave them waiting for good
+    if (send_samples[m->rank] != recv_samples[m->rank]) return fail(CSDR_EINVAL, "a rank's counts to and from itself differ");
     if (int rc = comm_begin(m)) return rc;
     hipStream_t st = m->ctx->stream;
     if (m->loopback) {
-        if (send_samples[0] != recv_samples[0]) return fail(CSDR_EINVAL, "one rank: send and receive counts differ");
         if (ts) CSDR_HIP_TRY(hipMemcpyAsync(recv_dev, send_dev, (size_t)ts * sizeof(float2), hipMemcpyDeviceToDevice, st));
         return CSDR_OK;
     }
-    if (send_samples[m->rank] != recv_samples[m->rank]) return fail(CSDR_EINVAL, "a rank's counts to and from itself differ");
     GroupScope grp;
     CSDR_RCCL_TRY(grp.start());
     size_t so = 0, ro = 0, self_so = 0, self_ro = 0;
@@ -278,7 +279,10 @@ extern "C" int csdr_post_exchange_rows(csdr_comm *m, csdr_post *producer, csdr_p
     if (int rc = m->recv.reserve((size_t)std::max<int64_t>(tr, 1))) return rc;
     const float2 *send = nullptr;
     if (direct) {
-        if (mine_f && producer->n_blocks <= 0) return fail(CSDR_ESTATE, "the producer has not executed");
+        // the batch the producer holds must be the slab this call hands out (csdr_post_export_rows checks the same on the packing path): a stale or
+        // short batch would be sent as it stands
+        if (mine_f && (producer->n_blocks <= 0 || (int64_t)producer->n_blocks * (producer->block_len / producer->hop) != mine_f))
+            return fail(CSDR_ESTATE, "the producer holds %lld frames, this rank's slab has %lld", (long long)producer->n_blocks * (producer->block_len / std::max(1, producer->hop)), (long long)mine_f);
         send = post_buf(producer, producer->cur);
     } else {
         if (int rc = m->send.reserve((size_t)std::max<int64_t>(ts, 1))) return rc;

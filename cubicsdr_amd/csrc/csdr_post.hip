@@ -308,6 +308,9 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
     if (!iq || n_blocks <= 0 || block_len <= 0) return fail(CSDR_EINVAL, "bad block arguments");
     if (n_blocks > p->max_blocks || block_len > p->max_block_len) return fail(CSDR_ERANGE, "batch %d x %d exceeds configured %d x %d", n_blocks, block_len, p->max_blocks, p->max_block_len);
     if (block_len % p->M) return fail(CSDR_EINVAL, "block_len %d is not a multiple of numChannels %d", block_len, p->M);
+    // (refused before anything of the object changes: a failed call leaves the post holding its previous batch)
+    if (p->mode != CSDR_POST_SINGLE && !p->row_order.empty() && p->dc_enabled && !p->active_host.empty() && p->active_host[0] == 0)
+        return fail(CSDR_ESTATE, "packed rows are for time-slab producers: csdr_post_set_dc_blocker(0) first (channel 0's owner runs the DC blocker)");
     csdr_ctx *c = p->ctx;
     hipStream_t st = c->lanes[LANE_POST];
     const int64_t n = (int64_t)n_blocks * block_len;
@@ -348,7 +351,6 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
         // channel 0 carries the DC spike: it is blocked after de-interleave (:364-375); when the tile size allows, the
         // channelizer itself emits the per-tile end values the blocked scan needs
         const bool dc0 = p->dc_enabled && !p->active_host.empty() && p->active_host[0] == 0;
-        if (dc0 && !p->row_order.empty()) return fail(CSDR_ESTATE, "packed rows are for time-slab producers: csdr_post_set_dc_blocker(0) first (channel 0's owner runs the DC blocker)");
         const bool fused_ends = dc0 && g.fpw >= 16;
         if (p->use_fft) {
             // persistent workgroups (as many as are resident at once) walk over the tiles

@@ -706,8 +706,9 @@ static void spec_hide_dc(const csdr_spec *s, float *pts) {
 // the display kernel's stores and of the fetch's transfer were that constant).  pts[F .. 2F) holds the F values just fetched: interleave
 // in place, front to back (the value of point i is read before slots 2i, 2i + 1 <= F + i are written).
 static void spec_expand_points(float *pts, int F) {
-    const float inv_F = 1.0f / (float)F;                                  // F is a power of two: i * inv_F == i / F exactly
-    for (int i = 0; i < F; ++i) { const float y = pts[F + i]; pts[2 * i] = (float)i * inv_F; pts[2 * i + 1] = y; }
+    // the reference's own quotient, (float)x / (float)xMax (:563): a product with 1 / F is the same value only when F is a power of two, and
+    // setFFTSize takes any size
+    for (int i = 0; i < F; ++i) { const float y = pts[F + i]; pts[2 * i] = (float)i / (float)F; pts[2 * i + 1] = y; }
 }
 
 extern "C" int csdr_spec_fetch_hold(csdr_spec *s, int frame, float *hold_host, int cap_floats, int *n_floats) {

@@ -634,10 +634,14 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
     float4 win[2 * kChanTaps - 1];                              // this wave's FIR window of the tile: input rows f0 + ta - 7 .. f0 + ta + 7
     // tile walk: workgroup b takes tiles b, b + grid, ...; with `xcd` the workgroups that share an L2 (b % 8: the dispatcher's round robin over the
     // XCDs) take consecutive tiles of the round, so that the seven window rows two neighbouring tiles share meet in one L2
-    int64_t tile = blockIdx.x;
-    if (g.xcd && !(gridDim.x & 7)) tile = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    chan_p2_request_window<>(x, hist, M, A, n_frames, tile, tile < n_tiles, wave, lane0, win);
-    for (; tile < n_tiles; tile += gridDim.x) {
+    int64_t tile = blockIdx.x, tstep = gridDim.x, tend = n_tiles;
+    if (g.xcd == 1 && !(gridDim.x & 7)) tile = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (g.xcd == 2) {                                          // every workgroup takes a contiguous range of tiles: the seven window rows two consecutive tiles share are its own
+        const int64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
+        tile = (int64_t)blockIdx.x * per; tstep = 1; tend = min(n_tiles, tile + per);
+    }
+    chan_p2_request_window<>(x, hist, M, A, n_frames, tile, tile < tend, wave, lane0, win);
+    for (; tile < tend; tile += tstep) {
         const int64_t f0 = tile * kP2Frames;
         const int nf = (int)min((int64_t)kP2Frames, n_frames - f0);
         int lane = lane0, tid = tid0;                         // per-tile copies: their address arithmetic is not worth carrying across tiles
@@ -681,7 +685,7 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
         }
         lds_barrier();
         // the next tile's window is on its way while this one is transformed (into the registers the FIR has just finished with)
-        chan_p2_request_window<0, kP2EarlyRows>(x, hist, M, A, n_frames, tile + gridDim.x, tile + gridDim.x < n_tiles, wave, lane, win);
+        chan_p2_request_window<0, kP2EarlyRows>(x, hist, M, A, n_frames, tile + tstep, tile + tstep < tend, wave, lane, win);
         {   // ---- DFT: lane = frame t; wave = pass of KP output-pair slots
             const int t = lane;
             const float4 *row = rows + t * A;
@@ -734,7 +738,7 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
             }
         }
         // the rest of the next window (the transform above leaves no room for all fifteen rows: they would be spilled -- which waits for them)
-        chan_p2_request_window<kP2EarlyRows, 2 * kChanTaps - 1>(x, hist, M, A, n_frames, tile + gridDim.x, tile + gridDim.x < n_tiles, wave, lane0, win);
+        chan_p2_request_window<kP2EarlyRows, 2 * kChanTaps - 1>(x, hist, M, A, n_frames, tile + tstep, tile + tstep < tend, wave, lane0, win);
         lds_barrier();                                      // the rows are free for the next tile
     }
 }

@@ -112,6 +112,10 @@ public:
     // read with an empty block, stop request, saturated consumer), < 0 the stream's error code (what was read so far is still posted).
     int readStream(IQStreamSource &dev, const SDRThreadIQDataQueuePtr &out, const std::atomic_bool &stopping) {
         const int want = elems_.load(), mtu = std::max(1, mtu_.load());
+        // a pooled block may be one whose upload is still reading it (pushed, released early by its consumers, taken again): the one transfer
+        // in flight is waited for before any block is refilled
+        if (uploading_ && ingest_) ingest_->wait();
+        uploading_ = false;
         SDRThreadIQDataPtr blk = pool_.getBuffer();
         reserve(*blk, (size_t)want + (size_t)mtu);
         liquid_float_complex_t *base = blk->data.data();
@@ -153,10 +157,8 @@ public:
         if (blk->iqSwapPending) exchange(blk->data.data(), have);
         blk->iqSwapPending = false;
         const bool inHbm = ingest_ && ingest_->upload(*blk);
-        if (!out->try_push(blk)) {
-            if (inHbm) ingest_->wait();          // the block goes back to the pool: its transfer must not be reading it when the next read refills it
-            return 0;
-        }
+        uploading_ = inHbm;
+        if (!out->try_push(blk)) return 0;       // (the block goes back to the pool; the next read waits for its transfer before refilling anything)
         return code;
     }
     void bindIngest(DeviceIngest *ing) { ingest_ = ing; }
@@ -178,6 +180,7 @@ private:
     ReBuffer<SDRThreadIQData> pool_;
     std::vector<liquid_float_complex_t> spill_;
     bool spillSwapped_ = false;
+    bool uploading_ = false;                      // the last block's asynchronous upload has not been waited for yet
     std::vector<void *> pinned_;
     std::atomic<long long> rate_{0}, freq_{0};
     std::atomic_int channels_{1}, elems_{0}, mtu_{0};

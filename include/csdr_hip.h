@@ -361,6 +361,11 @@ int  csdr_ingest_wait(csdr_ingest *ing);             /* blocks until the last tr
  *                 executed this rank's blocks for all channels), all-to-all, import into `owner` at each peer's frame offset, commit.
  *                 channels: the ranks' channel lists one after the other (n_channels[q] entries for rank q); frame0 / frames [world]. */
 #define CSDR_COMM_ID_BYTES 128
+/* Errors.  Every entry point validates its arguments and allocates before the first call the peers take part in, so a refused call (CSDR_EINVAL,
+ * CSDR_ENOMEM, CSDR_ESTATE) has enqueued nothing and the communicator stays usable -- provided EVERY rank is refused alike: the ranks of one
+ * collective must pass consistent arguments (the same channel lists and row order in csdr_post_exchange_rows; whether the producers' rows
+ * travel as they lie is decided from the producer's row order, which therefore has to be the same on every rank).  A CSDR_EHIP from inside a
+ * collective, or one rank failing while its peers proceed, leaves the peers waiting: destroy the communicator on every rank and make a new one. */
 int  csdr_comm_unique_id(char *id_out /* [CSDR_COMM_ID_BYTES] */);
 int  csdr_comm_create(csdr_ctx *ctx, const char *unique_id, int rank, int world, csdr_comm **out);
 void csdr_comm_destroy(csdr_comm *comm);

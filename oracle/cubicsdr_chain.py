@@ -103,6 +103,7 @@ class RefDemod:
         """demph / pilot_sos: FM stereo only -- the "demph" setting (microseconds, 0 = none) and, when given, (b15, a15) second-order
         sections to build the pilot band-pass from (iirfilt_crcf_create_sos) instead of the reference's own design call"""
         L = self.L = A.load(backend)
+        self.backend = backend
         self.modem = modem
         self.frequency = int(frequency)
         self.audio_rate = int(audio_rate)
@@ -180,6 +181,14 @@ class RefDemod:
             self.ssb_nco = L.nco_crcf_create(A.LIQUID_NCO)               # :9
             L.nco_crcf_set_frequency(self.ssb_nco, float(np.float32((2.0 * math.pi) * 0.25)))   # :10
             self.hilb = L.firhilbf_create(5, 90.0)                       # :11
+
+    def state(self):
+        """the integer state of the front-end as it stands (after the blocks run so far): the oscillator's phase word, the arbitrary
+        resampler's 24-bit phase and the half-band input fill of msresamp_crcf -- what the HIP path reports per block as bit-exact items"""
+        be = self.backend
+        th, _ = A.nco_state(be, self.nco)
+        m = A.msresamp_state(be, self.resamp)
+        return dict(nco_theta=th, resamp_phase=m["phase"], buffer_index=m["buffer_index"], S=m["S"], step=m["step"])
 
     def pre(self, data, in_freq, in_rate):
         """NCO shift + decimate; returns resampled IQ or None when the block is skipped (:154-165)."""

@@ -172,6 +172,49 @@ def ptr(a):
     return a.ctypes.data_as(c_p)
 
 
+# ---- integer state of the objects on the path (the bit-exact items the HIP path reports per block: csdr_block_result) ----------------------
+# The restatement has test hooks (port_nco_get_state, port_msresamp_get_state).  The reference binary has none: its words are read where they
+# lie in its own objects -- liquid 1.5.0's structures as the reference's libliquid.dll lays them out (x86-64, LLP64):
+#   nco_crcf   { int type; float sintab[1024]; uint32 theta @0x1004; uint32 d_theta @0x1008; ... }                  (disassembled)
+#   msresamp   { float rate, As; int type; uint num_halfband_stages @12; msresamp2 *halfband @16; float rate_halfband @24;
+#                resamp *arbitrary @32; float rate_arbitrary @40; uint buffer_len @44; T *buffer @48; uint buffer_index @56 }
+#   resamp     { uint m; float As, fc, rate; uint32 step @16; uint32 phase @20; uint bits_index @24; uint npfb @28; firpfb pfb }
+# tests/test_oracle_pin.py pins these offsets against the restatement's hooks on identical inputs.
+_REF_NCO_THETA, _REF_NCO_DTHETA = 0x1004, 0x1008
+_REF_MSR_S, _REF_MSR_ARB, _REF_MSR_BUFIDX = 12, 32, 56
+_REF_RES_STEP, _REF_RES_PHASE = 16, 20
+
+
+def _addr(q):
+    return q if isinstance(q, int) else q.value
+
+
+def nco_state(kind, q):
+    """-> (theta, d_theta): the oscillator's 32-bit phase and frequency words"""
+    if kind == "port":
+        th, dth = C.c_uint32(), C.c_uint32()
+        fn = load("port").port_nco_get_state
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        fn(C.c_void_p(_addr(q)), C.byref(th), C.byref(dth))
+        return th.value, dth.value
+    a = _addr(q)
+    return C.c_uint32.from_address(a + _REF_NCO_THETA).value, C.c_uint32.from_address(a + _REF_NCO_DTHETA).value
+
+
+def msresamp_state(kind, q):
+    """-> dict(S, buffer_index, phase, step) of a msresamp_crcf / _rrrf / _cccf object"""
+    if kind == "port":
+        S, bi, ph, st = C.c_uint(), C.c_uint(), C.c_uint32(), C.c_uint32()
+        fn = load("port").port_msresamp_get_state
+        fn.argtypes = [C.c_void_p] * 5
+        fn(C.c_void_p(_addr(q)), C.byref(S), C.byref(bi), C.byref(ph), C.byref(st))
+        return dict(S=S.value, buffer_index=bi.value, phase=ph.value, step=st.value)
+    a = _addr(q)
+    arb = C.c_uint64.from_address(a + _REF_MSR_ARB).value
+    return dict(S=C.c_uint32.from_address(a + _REF_MSR_S).value, buffer_index=C.c_uint32.from_address(a + _REF_MSR_BUFIDX).value,
+                phase=C.c_uint32.from_address(arb + _REF_RES_PHASE).value, step=C.c_uint32.from_address(arb + _REF_RES_STEP).value)
+
+
 def as_c64(a):
     return np.ascontiguousarray(a, dtype=np.complex64)
 

@@ -272,6 +272,7 @@ def _ref_demods(x, fs, M, block, demods, bws, n_blocks, oversampled=False, modem
             if riq is None:
                 want[i].append(None)
                 continue
+            words = rd.state()                       # the reference's own integer state after this block: oscillator phase word, resampler phase, half-band fill
             gpu_iq = modem_iq[i][b] if modem_iq and i in modem_iq else None
             miq = gpu_iq if gpu_iq is not None and gpu_iq.size == riq.size else riq
             out = rd.demodulate(miq)
@@ -281,6 +282,7 @@ def _ref_demods(x, fs, M, block, demods, bws, n_blocks, oversampled=False, modem
             if out is None:       # no samples in this block: demodulate() returns at once, no audio item, no state change
                 out = dict(audio=np.zeros(0, np.float32), level_accum=0.0, level_count=0, peak=0.0)
             out["iq"] = riq
+            out.update(nco_theta=words["nco_theta"], resamp_phase=words["resamp_phase"], buffer_index=words["buffer_index"])
             want[i].append(out)
     for m in cpp or []:
         m.close()
@@ -304,7 +306,7 @@ def _run_demods(ctx, fs, M, block, kinds, n_blocks, batch, bw=None, seed=3, over
     return got, want
 
 
-def _full_config(ctx, fs, M, block, kinds, n_blocks, seed, hist=None):
+def _full_config(ctx, fs, M, block, kinds, n_blocks, seed, hist=None, persample=None):
     """every demodulator of a BASELINE configuration over n_blocks consecutive blocks: one oracle run, the HIP path once as ONE
     batch and once block at a time; both must match the oracle (counts and phase words exact, samples within TOL) and each
     other bit for bit.  Returns the worst errors."""
@@ -320,7 +322,7 @@ def _full_config(ctx, fs, M, block, kinds, n_blocks, seed, hist=None):
     dc_floor = float(4 * np.spacing(np.float32(0.01 * M / 0.0005))) if M > 1 else 0.0
     floors = {i: dc_floor for i, ch in enumerate(_ref_demods.last_channels) if ch == 0 and M >= 100}
     batched = _gpu_demods(ctx, x, fs, M, block, demods, bws, n_blocks, n_blocks)
-    worst = _compare(batched, want, "batched", floors, hist)
+    worst = _compare(batched, want, "batched", floors, hist, persample)
     single = _gpu_demods(ctx, x, fs, M, block, demods, bws, n_blocks, 1)
     _compare(single, want, "blockwise", floors)
     for i in range(len(kinds)):
@@ -334,7 +336,7 @@ def _full_config(ctx, fs, M, block, kinds, n_blocks, seed, hist=None):
 _ERR_EDGES = np.array([0.0, 1e-7, 3e-7, 1e-6, 2e-6, 4e-6, 6e-6, 8e-6, 1e-5, 1e30])
 
 
-def _compare(got, want, label, floors=None, hist=None):
+def _compare(got, want, label, floors=None, hist=None, persample=None):
     """floors: {slot: absolute noise floor of that slot's channel samples} (channel 0 behind a wide channelizer, see _full_config):
     the slot's IQ may differ by that much on top of TOL, its audio / level / peak by the phase noise that implies."""
     worst = {}
@@ -348,10 +350,18 @@ def _compare(got, want, label, floors=None, hist=None):
             assert g["n_iq"] == w["iq"].size, (label, i, b, g["n_iq"], w["iq"].size)          # bit-exact decimation index
             assert g["n_audio"] == w["audio"].size, (label, i, b, g["n_audio"], w["audio"].size)
             assert g["level_count"] == w["level_count"], (label, i, b)
+            # the integer state after the block against the REFERENCE's own words (its oscillator / resampler objects, oracle/liquid_api.py:
+            # nco_state, msresamp_state), not only against another run of the HIP path
+            if "nco_theta" in w:
+                assert (g["nco_theta"], g["resamp_phase"], g["buffer_index"]) == (w["nco_theta"], w["resamp_phase"], w["buffer_index"]), \
+                    (label, i, b, (g["nco_theta"], g["resamp_phase"], g["buffer_index"]), (w["nco_theta"], w["resamp_phase"], w["buffer_index"]))
         e_iq, e_au = rel_err(gi, wi), rel_err(ga, wa)
         if hist is not None and wa.size and not (floors and i in floors):
             # EVERY audio sample's error in units of its demodulator's peak (the bound is on the maximum of these; this shows how few samples sit near it)
             hist += np.histogram(np.abs(ga - wa) / float(np.max(np.abs(wa))), bins=_ERR_EDGES)[0]
+            if persample is not None:
+                # ... and relative to the SAMPLE's own magnitude (not the stream's peak), floored at 1 % of the peak: a sample at a zero crossing has no scale of its own
+                persample.append(np.abs(ga - wa) / np.maximum(np.abs(wa), 0.01 * float(np.max(np.abs(wa)))))
         # per-block level sums and peaks, relative to the block's own value -- but not below 5 % of the stream's peak per
         # sample (a block of one or two quiet samples has no scale of its own)
         gpk = float(np.max(np.abs(wa))) if wa.size else 1.0
@@ -1076,12 +1086,16 @@ def test_c3_shape_mixed_m122(ctx):
     """BASELINE config 3 (the headline): 61.44 MS/s, M = 122 (channel rate 503606 by integer division), block 1 024 068, ALL 256
     mixed NBFM / AM / USB demodulators over 3 consecutive blocks against the oracle, as one batch and block at a time."""
     hist = np.zeros(_ERR_EDGES.size - 1, np.int64)
-    print("c3 worst errors", _full_config(ctx, 61440000, 122, 1024068, ["NBFM", "AM", "USB"] * 85 + ["NBFM"], 3, seed=41, hist=hist))
+    per = []
+    print("c3 worst errors", _full_config(ctx, 61440000, 122, 1024068, ["NBFM", "AM", "USB"] * 85 + ["NBFM"], 3, seed=41, hist=hist, persample=per))
     # the margin of the worst sample is thin (DESIGN 2: the reference's own sensitivity); the distribution behind that maximum:
     print("c3 audio, per-sample |gpu - reference| / peak of the demodulator, %d samples:" % hist.sum())
     for lo, hi, n in zip(_ERR_EDGES[:-1], _ERR_EDGES[1:], hist):
         print("   [%.0e, %s): %9d  (%.5f %%)" % (lo, "%.0e" % hi if hi < 1 else "inf", n, 100.0 * n / max(1, hist.sum())))
     assert hist[-1] == 0
+    per = np.concatenate(per)
+    print("c3 audio, per-sample |gpu - reference| / max(|reference sample|, 1 %% of the demodulator's peak): " +
+          ", ".join("p%s %.2e" % (q, np.percentile(per, float(q))) for q in ("50", "90", "99", "99.9", "99.99", "100")))
 
 
 def test_c3n_shape_all_nbfm_m122(ctx):

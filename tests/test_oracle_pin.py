@@ -222,6 +222,45 @@ def test_port_tracks_reference_on_fresh_inputs(P):
         assert ph.value < (1 << 25)
 
 
+@pytest.mark.skipif(not A.available("ref"), reason="reference DLL not staged (oracle/_ref/libliquid.dll)")
+def test_reference_state_words_are_where_the_accessors_read_them(P):
+    """oracle/liquid_api.py nco_state / msresamp_state read the reference binary's phase words at fixed offsets inside ITS objects (it has no
+    accessor for them): on identical inputs they must be the words the restatement's hooks return -- oscillator phase and frequency words after
+    mix_block_up / _down, half-band stage count, buffer_index, step and phase of msresamp_crcf / _rrrf after ragged blocks (decimating and
+    interpolating ratios)."""
+    R = A.load("ref")
+    rng = np.random.default_rng(2024)
+    for f in (0.0, 0.7123, 3.0001, 6.2):
+        qa, qb = R.nco_crcf_create(A.LIQUID_VCO), P.nco_crcf_create(A.LIQUID_VCO)
+        R.nco_crcf_set_frequency(qa, f); P.nco_crcf_set_frequency(qb, f)
+        for n, up in ((1000, False), (777, True), (8394, False)):
+            x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.3).astype(np.complex64)
+            ya, yb = np.empty_like(x), np.empty_like(x)
+            (R.nco_crcf_mix_block_up if up else R.nco_crcf_mix_block_down)(qa, A.ptr(x), A.ptr(ya), n)
+            (P.nco_crcf_mix_block_up if up else P.nco_crcf_mix_block_down)(qb, A.ptr(x), A.ptr(yb), n)
+            assert A.nco_state("ref", qa) == A.nco_state("port", qb), (f, n)
+    for r in (0.0248, 0.3, 0.0107, 0.62, 1.33, 2.5):
+        qa, qb = R.msresamp_crcf_create(r, 60.0), P.msresamp_crcf_create(r, 60.0)
+        for bs in (8394, 8394, 777, 1):
+            x = ((rng.standard_normal(bs) + 1j * rng.standard_normal(bs)) * 0.3).astype(np.complex64)
+            cap = int(bs * max(r, 1.0)) + 600
+            ya, yb = np.zeros(cap, np.complex64), np.zeros(cap, np.complex64)
+            na, nb = C.c_uint(), C.c_uint()
+            R.msresamp_crcf_execute(qa, A.ptr(x), bs, A.ptr(ya), C.byref(na)); P.msresamp_crcf_execute(qb, A.ptr(x), bs, A.ptr(yb), C.byref(nb))
+            assert na.value == nb.value
+            assert A.msresamp_state("ref", qa) == A.msresamp_state("port", qb), (r, bs)
+    for r in (48000 / 12500.0, 48000 / 200000.0):
+        qa, qb = R.msresamp_rrrf_create(r, 60.0), P.msresamp_rrrf_create(r, 60.0)
+        for bs in (208, 209, 3333):
+            x = (rng.standard_normal(bs) * 0.3).astype(np.float32)
+            cap = int(bs * max(r, 1.0)) + 600
+            ya, yb = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+            na, nb = C.c_uint(), C.c_uint()
+            R.msresamp_rrrf_execute(qa, A.ptr(x), bs, A.ptr(ya), C.byref(na)); P.msresamp_rrrf_execute(qb, A.ptr(x), bs, A.ptr(yb), C.byref(nb))
+            assert na.value == nb.value
+            assert A.msresamp_state("ref", qa) == A.msresamp_state("port", qb), (r, bs)
+
+
 _MODEM_CASES = [("NBFM", 12500, 48000, {}), ("FM", 200000, 48000, {}), ("AM", 6000, 48000, {}), ("USB", 5400, 48000, {}), ("LSB", 5401, 44100, {}),
                 ("DSB", 5400, 48000, {}), ("CW", 500, 48000, {}), ("I/Q", 12345, 48000, {}), ("FMS", 200000, 48000, {}),
                 ("FMS", 250000, 44100, {"demph": 50}), ("FMS", 50000, 48000, {"demph": 0}), ("FM", 400000, 48000, {}), ("AM", 300, 48000, {})]
