@@ -12,8 +12,28 @@
 
 #include "../../include/csdr_hip.h"
 
-// every kernel has internal linkage: the kernel headers are included by several translation units (each uses, and emits, its own subset)
+// every kernel has internal linkage: the kernel headers are included by several translation units (for the object layouts and constants next to
+// the kernels).  A kernel has ONE home unit, the one that launches it: csdr_post.hip (CSDR_TU_POST: channelizers, DC blocker), csdr_bank.hip
+// (CSDR_TU_BANK: front-ends, modems, audio), csdr_spec.hip (CSDR_TU_SPEC: the spectrum chain), csdr_io.hip (scope, mixer, ingest).  Elsewhere a
+// kernel that is not a template already is declared as one that is never instantiated: parsed, not compiled (round 4 built chan_analyze_fft and the
+// demodulator kernels three times and the spectrum chain twice).
 #define CSDR_KERNEL static __global__
+#define CSDR_KERNEL_ELSEWHERE template <typename CsdrNotEmittedHere_ = void> static __global__
+#if defined(CSDR_TU_POST)
+#define CSDR_KERNEL_POST CSDR_KERNEL
+#else
+#define CSDR_KERNEL_POST CSDR_KERNEL_ELSEWHERE
+#endif
+#if defined(CSDR_TU_BANK)
+#define CSDR_KERNEL_BANK CSDR_KERNEL
+#else
+#define CSDR_KERNEL_BANK CSDR_KERNEL_ELSEWHERE
+#endif
+#if defined(CSDR_TU_SPEC)
+#define CSDR_KERNEL_SPEC CSDR_KERNEL
+#else
+#define CSDR_KERNEL_SPEC CSDR_KERNEL_ELSEWHERE
+#endif
 
 namespace csdr {
 

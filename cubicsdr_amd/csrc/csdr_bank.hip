@@ -6,6 +6,7 @@
 #include <map>
 #include <memory>
 
+#define CSDR_TU_BANK 1          // this unit is the home of its kernels (common.hpp)
 #include "csdr_objects.hpp"
 #include "kernels_fms.hpp"
 
@@ -55,7 +56,7 @@ extern "C" int csdr_bank_create(csdr_ctx *ctx, int max_demods, int max_blocks, c
     b->slots.resize(max_demods);
     if (int rc = b->cfgs.reserve(max_demods)) return rc;
     b->off_lists = ((size_t)max_demods * sizeof(SlotDyn) + 15) & ~(size_t)15;
-    b->off_plans = (b->off_lists + 3 * (size_t)max_demods * sizeof(int) + 15) & ~(size_t)15;
+    b->off_plans = (b->off_lists + (6 * (size_t)max_demods + 8 * 32) * sizeof(int) + 15) & ~(size_t)15;      // all running | auto-gain | grouped by front-end kernel (the specialised kernels' lists in rows of 8 G positions, padded)
     b->table_bytes = (b->off_plans + (size_t)max_demods * (max_blocks + 1) * sizeof(BlockPlan) + 255) & ~(size_t)255;
     if (int rc = b->tables.reserve(2 * b->table_bytes)) return rc;
     for (int k = 0; k < 2; ++k) {
@@ -403,7 +404,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     for (int i = 0; i < n_fms; ++i) ag_list_h[fms_off + i] = fms_slots[i];
     // running slots grouped by front-end kernel (filled before the staging set is handed to the copy engine)
     int *grp_h = slot_list_h + 2 * (size_t)b->max_demods;
-    int grp_off[8] = {0}, grp_n[8] = {0};        // index 0: generic, 3..6: specialised by S
+    int grp_off[8] = {0}, grp_n[8] = {0}, grp_rows[8] = {0}, grp_g[8] = {0};        // index 0: generic, 3..6: specialised by S (their lists: grp_rows rows of 8 grp_g positions)
     {
         auto klass = [&](const SlotHost &s) {
             const int S = (int)s.iq.S;
@@ -413,10 +414,44 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
             return S;
         };
         int pos = 0;
+        std::vector<int> members;
+        std::vector<std::vector<int>> cols;
+        std::map<int, std::vector<int>> by_chan;
         for (int k = 0; k < 8; ++k) {
             grp_off[k] = pos;
-            for (int i = 0; i < n_run; ++i) if (klass(b->slots[slot_list_h[i]]) == k) grp_h[pos++] = slot_list_h[i];
-            grp_n[k] = pos - grp_off[k];
+            if (k < 3 || k > 6) {
+                for (int i = 0; i < n_run; ++i) if (klass(b->slots[slot_list_h[i]]) == k) grp_h[pos++] = slot_list_h[i];
+                grp_n[k] = pos - grp_off[k];
+                continue;
+            }
+            // the specialised kernels take their list in rows of sixteen positions: two demodulators of ONE channel at positions w and w + 8 of a
+            // row (demod_frontend_s: they then run on the same XCD at the same time and the channel row crosses the fabric once); -1 = empty
+            // (only the last row has any: demodulators alone on their channel pair up with each other).  Measured on MI355X, front-end ms per
+            // batch: C3N (256 NBFM, 2.1 per channel) 0.59 -> 0.47, C5 0.217 + 0.133 -> 0.209 + 0.109, C3 (its two demodulators of a channel
+            // mostly sit in DIFFERENT launches, depth 5 and depth 6) and C2 unchanged.  Rows of 32 with up to four of a channel together were
+            // measured as well and lose badly (C3N 0.89, C2 0.27 -> 0.43 ms): half of the grid is then empty positions and a second round.
+            members.clear(); cols.clear(); by_chan.clear();
+            for (int i = 0; i < n_run; ++i) if (klass(b->slots[slot_list_h[i]]) == k) members.push_back(slot_list_h[i]);
+            grp_n[k] = (int)members.size();
+            if (members.empty()) continue;
+            for (int si : members) by_chan[dyns_h[si].chan].push_back(si);
+            constexpr int G = 2;
+            std::vector<int> loose;
+            for (auto &kv : by_chan) {
+                auto &v = kv.second;
+                size_t i = 0;
+                for (; i + 1 < v.size(); i += (size_t)G) cols.push_back(std::vector<int>(v.begin() + (long)i, v.begin() + (long)std::min(v.size(), i + (size_t)G)));
+                if (i < v.size()) loose.push_back(v[i]);         // one left over: alone
+            }
+            std::sort(loose.begin(), loose.end());
+            for (size_t i = 0; i < loose.size(); i += (size_t)G) cols.push_back(std::vector<int>(loose.begin() + (long)i, loose.begin() + (long)std::min(loose.size(), i + (size_t)G)));
+            grp_g[k] = G;
+            grp_rows[k] = ((int)cols.size() + 7) / 8;
+            const int R = 8 * G;
+            for (int i = 0; i < R * grp_rows[k]; ++i) grp_h[pos + i] = -1;
+            for (size_t cidx = 0; cidx < cols.size(); ++cidx)
+                for (size_t u = 0; u < cols[cidx].size(); ++u) grp_h[pos + (int)(cidx / 8) * R + (int)(cidx % 8) + 8 * (int)u] = cols[cidx][u];
+            pos += R * grp_rows[k];
         }
     }
     // the audio stage runs the slots that have one: compact the head of the list (the front-end groups above are copies)
@@ -519,14 +554,14 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
                     chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
 #define CSDR_FE_S(S_, CH_)                                                                                                              \
     if (grp_n[S_] > 0)                                                                                                                  \
-        CSDR_LAUNCH(c, LANE_FE, KID_FE_S##S_, (demod_frontend_s<S_, CH_>), dim3(ranges_for(grp_n[S_]) + 1, grp_n[S_]), dim3(kFeThreads), (fes_lds_bytes<S_, CH_>()), \
-                    b->cfgs.p, dyns_d, grp_d + grp_off[S_], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p)
+        CSDR_LAUNCH(c, LANE_FE, KID_FE_S##S_, (demod_frontend_s<S_, CH_>), dim3(8 * grp_g[S_], grp_rows[S_] * (ranges_for(grp_n[S_]) + 1)), dim3(kFeThreads), (fes_lds_bytes<S_, CH_>()), \
+                    b->cfgs.p, dyns_d, grp_d + grp_off[S_], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p, grp_rows[S_])
     CSDR_FE_S(3, 2048); CSDR_FE_S(4, 2048);
     static const bool tw6 = lab_int("CSDR_FE_TW6", 1) != 0;
     if (grp_n[6] > 0) {          // depth 6 (AM / SSB from ~500 kS/s channels): tail wave with three tail stages (CSDR_FE_TW6=0: without)
         if (tw6)
-            CSDR_LAUNCH(c, LANE_FE, KID_FE_S6, (demod_frontend_s<6, 2048, true>), dim3(ranges_for(grp_n[6]) + 1, grp_n[6]), dim3(kFeThreads + 64), (fes_lds_bytes<6, 2048>()),
-                        b->cfgs.p, dyns_d, grp_d + grp_off[6], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
+            CSDR_LAUNCH(c, LANE_FE, KID_FE_S6, (demod_frontend_s<6, 2048, true>), dim3(8 * grp_g[6], grp_rows[6] * (ranges_for(grp_n[6]) + 1)), dim3(kFeThreads + 64), (fes_lds_bytes<6, 2048>()),
+                        b->cfgs.p, dyns_d, grp_d + grp_off[6], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p, grp_rows[6]);
         else CSDR_FE_S(6, 2048);
     }
     if (grp_n[7] > 0) {          // interpolating IQ resamplers: chunks of output samples
@@ -537,8 +572,8 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
                     chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
     }
     if (grp_n[5] > 0)                       // depth 5 (NBFM from ~500 kS/s channels): a fifth wave runs the one-wave tail one chunk behind
-        CSDR_LAUNCH(c, LANE_FE, KID_FE_S5, (demod_frontend_s<5, 2048, true>), dim3(ranges_for(grp_n[5]) + 1, grp_n[5]), dim3(kFeThreads + 64), (fes_lds_bytes<5, 2048>()),
-                    b->cfgs.p, dyns_d, grp_d + grp_off[5], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
+        CSDR_LAUNCH(c, LANE_FE, KID_FE_S5, (demod_frontend_s<5, 2048, true>), dim3(8 * grp_g[5], grp_rows[5] * (ranges_for(grp_n[5]) + 1)), dim3(kFeThreads + 64), (fes_lds_bytes<5, 2048>()),
+                    b->cfgs.p, dyns_d, grp_d + grp_off[5], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p, grp_rows[5]);
 #undef CSDR_FE_S
     CSDR_HIP_TRY(hipGetLastError());
     // the front-end was the only reader of the channelizer buffer: hand it back to the post object's rotation

@@ -6,6 +6,7 @@
 #include <map>
 #include <memory>
 
+#define CSDR_TU_POST 1          // this unit is the home of its kernels (common.hpp)
 #include "csdr_objects.hpp"
 
 using namespace csdr;

@@ -6,6 +6,7 @@
 #include <map>
 #include <memory>
 
+#define CSDR_TU_SPEC 1          // this unit is the home of its kernels (common.hpp)
 #include "csdr_objects.hpp"
 #include "kernels_spec.hpp"
 #include "kernels_spec2.hpp"

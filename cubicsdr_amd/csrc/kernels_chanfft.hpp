@@ -280,7 +280,7 @@ __device__ __forceinline__ void cf_fir(const float4 (&win)[kCfSeg + kChanTaps - 
     }
 }
 
-CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
+CSDR_KERNEL_POST __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
     const float2 *__restrict__ x,        // batch input, n_frames * M samples
     const float2 *__restrict__ hist,     // 7 * M samples preceding x
     float2 *__restrict__ hist_new,       // receives the last 7 * M samples of (hist ++ x)

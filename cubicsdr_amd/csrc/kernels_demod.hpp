@@ -243,7 +243,7 @@ __device__ inline void fe_stage_any(int m, const float2 *__restrict__ Ein, const
     }
 }
 
-CSDR_KERNEL __launch_bounds__(kFeThreads, 4) void demod_frontend(
+CSDR_KERNEL_BANK __launch_bounds__(kFeThreads, 4) void demod_frontend(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
     const float2 *__restrict__ chan_base, int64_t chan_stride, int64_t total /* batch samples per channel */,
     const float *__restrict__ arms_all, const float *__restrict__ sintab) {
@@ -820,8 +820,15 @@ __device__ __forceinline__ void fes_body(
 template <int S, int CH, bool TW = false>
 CSDR_KERNEL __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? 6 : 4) void demod_frontend_s(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
-    const float2 *__restrict__ chan_base, int64_t chan_stride, int64_t total, const float *__restrict__ arms_all, const float *__restrict__ sintab) {
-    fes_body<S, CH, TW>(cfgs, dyns, slot_list[blockIdx.y], (int)blockIdx.x, (int)gridDim.x - 1, chan_base, chan_stride, total, arms_all, sintab);
+    const float2 *__restrict__ chan_base, int64_t chan_stride, int64_t total, const float *__restrict__ arms_all, const float *__restrict__ sintab, int nq) {
+    // grid = (16, nq * (P + 1)): sixteen list positions per row, nq rows per range of the batch.  Workgroups are dispatched in linear order
+    // (x fastest) round robin over the eight XCDs, each with its own L2: the positions w and w + 8 of a row -- where the host puts two
+    // demodulators that share a CHANNEL (csdr_bank_execute) -- run on the same XCD at the same time over the same range of the batch, so
+    // the channel row crosses the fabric once instead of twice (C3N, 2.1 demodulators per channel: 0.59 -> 0.47 ms; a speed assumption
+    // only: any placement computes the same thing).  Positions without a demodulator hold -1.
+    const int q = (int)blockIdx.y, part = q / nq, slot = slot_list[(q - part * nq) * (int)gridDim.x + (int)blockIdx.x];
+    if (slot < 0) return;
+    fes_body<S, CH, TW>(cfgs, dyns, slot, part, (int)gridDim.y / nq - 1, chan_base, chan_stride, total, arms_all, sintab);
 }
 // (Depths 5 and 6 in ONE launch were measured in round 3: 0.749 ms against 0.440 + 0.231 ms for the two launches -- the depth-5 workgroups
 // then carry the depth-6 LDS carve and fewer of them are resident; that kernel is gone.)
@@ -838,7 +845,7 @@ constexpr int kFiChunk = 2048;
 constexpr int kFiArr = kFiChunk + 256;        // LDS array length (outputs of a stage + half-band reach)
 constexpr size_t kFiLds = (size_t)3 * kFiArr * sizeof(float2);
 
-CSDR_KERNEL __launch_bounds__(kFeThreads) void demod_frontend_interp(
+CSDR_KERNEL_BANK __launch_bounds__(kFeThreads) void demod_frontend_interp(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
     const float2 *__restrict__ chan_base, int64_t chan_stride, int64_t total /* batch samples per channel */,
     const float *__restrict__ arms_all, const float *__restrict__ sintab) {
@@ -970,7 +977,7 @@ __device__ inline float block_max_float(float v, float *lds) {
     return r;   // valid in thread 0
 }
 
-CSDR_KERNEL __launch_bounds__(kModemThreads) void demod_modem(
+CSDR_KERNEL_BANK __launch_bounds__(kModemThreads) void demod_modem(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
     const BlockPlan *__restrict__ plans, int NB, int cap_stream, const ModemConsts *__restrict__ mc, const float *__restrict__ sintab,
     const float *__restrict__ arms_all, int cap_cw) {
@@ -1195,7 +1202,7 @@ CSDR_KERNEL __launch_bounds__(kModemThreads) void demod_modem(
 // blockmaa[b] = MAA in force for block b; the end state goes to the other parity copy.  (Every audio workgroup used to replay the
 // recurrence up to its own block: quadratic in the blocks per batch.)   grid = auto-gain slots, 64 threads
 // ------------------------------------------------------------------------------------------------------------
-CSDR_KERNEL __launch_bounds__(64) void demod_gain_scan(const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
+CSDR_KERNEL_BANK __launch_bounds__(64) void demod_gain_scan(const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
                                                       const BlockPlan *__restrict__ plans, int NB) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_max = reinterpret_cast<float *>(smem);             // [NB] block maxima (one coalesced read instead of NB dependent ones)
@@ -1231,7 +1238,7 @@ CSDR_KERNEL __launch_bounds__(64) void demod_gain_scan(const SlotCfg *__restrict
 constexpr int kAudioMaxOut = 16384;        // audio samples of one block handled by one workgroup (likewise bounded by the LDS request)
 // dynamic LDS: two ping-pong arrays of `cap_out` floats, `cap_win` staged demodulator samples, 64 bytes of scratch
 
-CSDR_KERNEL __launch_bounds__(kModemThreads) void demod_audio_interp(
+CSDR_KERNEL_BANK __launch_bounds__(kModemThreads) void demod_audio_interp(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
     const BlockPlan *__restrict__ plans, int NB, int cap_out, int cap_win, const float *__restrict__ arms_all, int pass) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -69,7 +69,7 @@ __device__ inline void dc_stage_in(const float2 *__restrict__ x, int64_t n, int6
 }
 
 // pass 1: each tile computes its end value assuming zero entering state
-CSDR_KERNEL __launch_bounds__(kDcThreads) void dc_tile_ends(const float2 *__restrict__ x, int64_t n, double c, d2 *__restrict__ tile_end) {
+CSDR_KERNEL_POST __launch_bounds__(kDcThreads) void dc_tile_ends(const float2 *__restrict__ x, int64_t n, double c, d2 *__restrict__ tile_end) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *sx = reinterpret_cast<float2 *>(smem);
     d2 *sb = reinterpret_cast<d2 *>(smem + kDcTile * sizeof(float2));
@@ -119,7 +119,7 @@ __device__ inline d2 dc_scan256(d2 b, double a, d2 v_in, d2 *lds4) {
 //     v_in(n0) = c^n0 state + sum_{i < n0 / tile_len} c^(n0 - (i+1) tile_len) e_i
 // (terms older than ~80000 samples are below 1e-17 of the newest and are dropped), then the recurrence is re-run with
 // that state and y is written (in place allowed); the block holding the last sample stores the new carried state.
-CSDR_KERNEL __launch_bounds__(kDcThreads) void dc_apply(const float2 *x, float2 *y, int64_t n, double c, int tile_len,
+CSDR_KERNEL_POST __launch_bounds__(kDcThreads) void dc_apply(const float2 *x, float2 *y, int64_t n, double c, int tile_len,
                                                        const d2 *__restrict__ tile_end, const d2 *__restrict__ state_in,
                                                        d2 *__restrict__ state_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

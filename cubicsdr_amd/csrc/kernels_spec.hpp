@@ -276,7 +276,7 @@ CSDR_KERNEL __launch_bounds__(kFftThreads) void spec_fft_radix(FrameSrc fs, int 
 // ---- 4096-point row FFTs + magnitude.  grid = (rows = Ra Rb, frames) ---------------------------------------------
 // row r = k1 Rb + k2 of frame f in `fs` ([f][r][4096]; the frame itself when there is a single row) holds the bins
 // k = k1 + Ra (k2 + Rb k3); |X| is stored as mag[f][r][k3] (float), i.e. natural bin order when there is one row.
-CSDR_KERNEL __launch_bounds__(kFftThreads) void spec_fft_rows4096(FrameSrc fs, SpecGeom g, const float2 *__restrict__ tw4096,
+CSDR_KERNEL_SPEC __launch_bounds__(kFftThreads) void spec_fft_rows4096(FrameSrc fs, SpecGeom g, const float2 *__restrict__ tw4096,
                                                                  float *__restrict__ mag, float2 *__restrict__ raw_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *lds = reinterpret_cast<float2 *>(smem);
@@ -300,7 +300,7 @@ CSDR_KERNEL __launch_bounds__(kFftThreads) void spec_fft_rows4096(FrameSrc fs, S
 }
 
 // ---- small transforms (N <= 2048): one frame per workgroup, Stockham through LDS.  grid = (1, frames) ----------
-CSDR_KERNEL __launch_bounds__(kFftThreads) void spec_fft_small(FrameSrc fs, int N, const float2 *__restrict__ tw4096,
+CSDR_KERNEL_SPEC __launch_bounds__(kFftThreads) void spec_fft_small(FrameSrc fs, int N, const float2 *__restrict__ tw4096,
                                                               float *__restrict__ mag, float2 *__restrict__ raw_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *sa = reinterpret_cast<float2 *>(smem), *sb = sa + N;
@@ -320,7 +320,7 @@ CSDR_KERNEL __launch_bounds__(kFftThreads) void spec_fft_small(FrameSrc fs, int 
 // chirp-z transform.  With w[n] = exp(-i pi n^2 / N):  X[k] = w[k] sum_n (x[n] w[n]) conj(w[k - n]) -- a circular convolution of length
 // L = 2^p >= 2 N - 1 with the (precomputed, transformed in double on the host) chirp filter Bf.  One frame per workgroup, both L-point
 // transforms in LDS (the inverse one as conj(FFT(conj(.))) / L).  grid = (1, frames), LDS 2 L float2.
-CSDR_KERNEL __launch_bounds__(kFftThreads) void spec_fft_bluestein(FrameSrc fs, int N, int L, const float2 *__restrict__ tw4096, const float2 *__restrict__ chirp /* [N] w */,
+CSDR_KERNEL_SPEC __launch_bounds__(kFftThreads) void spec_fft_bluestein(FrameSrc fs, int N, int L, const float2 *__restrict__ tw4096, const float2 *__restrict__ chirp /* [N] w */,
                                                                   const float2 *__restrict__ Bf /* [L] */, float *__restrict__ mag, float2 *__restrict__ raw_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *sa = reinterpret_cast<float2 *>(smem), *sb = sa + L;
@@ -436,7 +436,7 @@ __host__ __device__ constexpr size_t avg_lds_bytes(int ng) {      // dynamic LDS
     return (size_t)(ng + 1) * kAvgLanes * 4 * sizeof(double) + (size_t)ng * 2 * kAvgExtFrames * kAvgLanes * sizeof(float) + 16;
 }
 
-CSDR_KERNEL __launch_bounds__(kAvgThreads) void spec_average(const float *__restrict__ mag, int nf, SpecGeom g, double rate,
+CSDR_KERNEL_SPEC __launch_bounds__(kAvgThreads) void spec_average(const float *__restrict__ mag, int nf, SpecGeom g, double rate,
                                                             double *__restrict__ ma, double *__restrict__ maa,
                                                             float *__restrict__ pairsum /* pair order */, float *__restrict__ first_b,
                                                             float2 *__restrict__ ext_w,
@@ -603,7 +603,7 @@ CSDR_KERNEL __launch_bounds__(kAvgThreads) void spec_average(const float *__rest
 // ---- per-frame extrema over the tiles of spec_average.  grid = frames, 256 threads (1024 when a frame has thousands of tiles: a 2^21-point
 // frame has 16384 and a batch only a few dozen frames = workgroups) -------------------------------
 constexpr int kExtMaxThreads = 1024;
-CSDR_KERNEL __launch_bounds__(kExtMaxThreads) void spec_extrema(const float2 *__restrict__ ext_w, int ntiles, float2 *__restrict__ ext) {
+CSDR_KERNEL_SPEC __launch_bounds__(kExtMaxThreads) void spec_extrema(const float2 *__restrict__ ext_w, int ntiles, float2 *__restrict__ ext) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *s_r = reinterpret_cast<float2 *>(smem);              // [waves]
     const int f = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -647,7 +647,7 @@ struct SpecPeakScalars { double ceil_peak, floor_peak; };
 
 // ---- peak hold (SpectrumVisualProcessor.cpp:247-273, :506-510, :523-530) --------------------------------------------
 // reset: fft_result_peak[i] = fft_floor_maa, fft_ceil_peak = fft_floor_maa, fft_floor_peak = fft_ceil_maa (:266-272)
-CSDR_KERNEL __launch_bounds__(256) void spec_peak_reset(const SpecScalars *__restrict__ st, double *__restrict__ peak, int n2f,
+CSDR_KERNEL_SPEC __launch_bounds__(256) void spec_peak_reset(const SpecScalars *__restrict__ st, double *__restrict__ peak, int n2f,
                                                        SpecPeakScalars *__restrict__ pk) {
     const SpecScalars s = *st;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n2f; i += 256 * gridDim.x) peak[i] = s.floor_maa;
@@ -655,7 +655,7 @@ CSDR_KERNEL __launch_bounds__(256) void spec_peak_reset(const SpecScalars *__res
 }
 // running maximum of the averaged bins over the frames [pk_from, nf) of a batch, one thread per display point (both of
 // its bins); peaksum[f][x] = peak[2x] + peak[2x+1] after frame f, peak_b[f] = the second bin of point 0 (:546-556)
-CSDR_KERNEL __launch_bounds__(256) void spec_peak_track(const float2 *__restrict__ maaf, int nf, int pk_from, int F,
+CSDR_KERNEL_SPEC __launch_bounds__(256) void spec_peak_track(const float2 *__restrict__ maaf, int nf, int pk_from, int F,
                                                        double *__restrict__ peak, float *__restrict__ peaksum, float *__restrict__ peak_b,
                                                        float2 *__restrict__ peakf /* zoomed view: both held bins per frame, else null */) {
     const int x = blockIdx.x * 256 + threadIdx.x;
@@ -674,7 +674,7 @@ CSDR_KERNEL __launch_bounds__(256) void spec_peak_track(const float2 *__restrict
 // zoomed view: the averagers follow a retune or a zoom step (SpectrumVisualProcessor.cpp:316-331, :454-492).  Display-order
 // bin i lives at [(i & 1) F + (i >> 1)] (pair layout).  mode 0/1: memmove left / right by n bins (the vacated end keeps its
 // old values); 2: zoom in, dst[i] = src[N/4 + i/2]; 3: zoom out, dst[i] = src[(i - N/4) 2] inside the middle half, else 0.
-CSDR_KERNEL __launch_bounds__(256) void spec_avg_remap(const double *__restrict__ ma, const double *__restrict__ maa,
+CSDR_KERNEL_SPEC __launch_bounds__(256) void spec_avg_remap(const double *__restrict__ ma, const double *__restrict__ maa,
                                                       double *__restrict__ ma_o, double *__restrict__ maa_o, int N, int mode, int n, SpecGeom g) {
     const int F = N >> 1;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += 256 * gridDim.x) {
@@ -692,7 +692,7 @@ CSDR_KERNEL __launch_bounds__(256) void spec_avg_remap(const double *__restrict_
 
 // the four trackers frame by frame (the reference's statements, :513-521) and their held extremes (:523-530) for the
 // frames [pk_from, nf): pfo[f] = {fft_ceil_peak, fft_floor_peak} after frame f.  One thread: nf short double recurrences.
-CSDR_KERNEL void spec_peak_trackers(const float2 *__restrict__ ext, int nf, int pk_from, const SpecScalars *__restrict__ st_in,
+CSDR_KERNEL_SPEC void spec_peak_trackers(const float2 *__restrict__ ext, int nf, int pk_from, const SpecScalars *__restrict__ st_in,
                                    SpecPeakScalars *__restrict__ pk, SpecFrameOut *__restrict__ pfo) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     SpecScalars s = *st_in;
@@ -738,7 +738,7 @@ struct SpecFrameScal { double pc, pf, fl; };  // point_ceil, point_floor, fft_fl
 //                maa_f = a^(f+1) maa_in + b (f+1) a^(f+1) ma_in + b^2 sum_i (f-i+1) a^(f-i) c_i      (maa uses the NEW ma)
 // as parallel weighted sums over i <= f (double; equal to the serial loop to ~1e-15 relative); the last frame publishes the end
 // state (ping-pong copy).
-CSDR_KERNEL __launch_bounds__(kDispThreads) void spec_trackers(const float2 *__restrict__ ext, int nf, const SpecScalars *__restrict__ st_in,
+CSDR_KERNEL_SPEC __launch_bounds__(kDispThreads) void spec_trackers(const float2 *__restrict__ ext, int nf, const SpecScalars *__restrict__ st_in,
                                                               SpecScalars *__restrict__ st_out, SpecFrameOut *__restrict__ fo,
                                                               SpecFrameScal *__restrict__ fsc, int pk_from, const SpecFrameOut *__restrict__ pfo) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
