@@ -110,6 +110,12 @@ def frontend_groups(cfg):
         S = cascade_depth(MODEM_BW[kind], cfg["fs"] // cfg["M"])
         name = "demod_frontend_s%d" % S if 3 <= S <= 6 else "demod_frontend_generic"
         out[name] = out.get(name, 0) + 1
+    # depths 5 and 6 share one launch (demod_frontend_s56) when together they still get three ranges per demodulator (csdr_bank_execute: 4 (n5 + n6)
+    # <= resident workgroups, 4 per CU x 256 CUs on MI355X)
+    n5, n6 = out.get("demod_frontend_s5", 0), out.get("demod_frontend_s6", 0)
+    if n5 and n6 and 4 * (n5 + n6) <= 1024:
+        out["demod_frontend_s56"] = n5 + n6
+        del out["demod_frontend_s5"], out["demod_frontend_s6"]
     return out
 
 
@@ -162,6 +168,8 @@ def measured_traffic(cfg_name):
             base = name.split("<")[0]
             if base == "demod_frontend_s" and "<" in name:
                 base = "demod_frontend_s" + name.split("<")[1].split(",")[0].strip()          # demod_frontend_s<6, 2048, true> -> demod_frontend_s6
+            if base == "demod_frontend_s56" or name.startswith("demod_frontend_s56"):
+                base = "demod_frontend_s56"
             base = {"demod_frontend": "demod_frontend_generic", "spec_fft_rows4096": "spec_fft_rows", "chan_analyze_p2": "chan_analyze", "chan_analyze_fft": "chan_analyze"}.get(base, base)
             out[base] = out.get(base, 0.0) + (2.0 * v["FETCH_SIZE_KiB_avg_per_launch"] + v["WRITE_SIZE_KiB_avg_per_launch"]) * 1024.0 / blocks
     return out, os.path.relpath(files[-1], ROOT)

@@ -406,11 +406,26 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     int *grp_h = slot_list_h + 2 * (size_t)b->max_demods;
     int grp_off[8] = {0}, grp_n[8] = {0}, grp_rows[8] = {0}, grp_g[8] = {0};        // index 0: generic, 3..6: specialised by S (their lists: grp_rows rows of 8 grp_g positions)
     {
+        // Depths 5 and 6 (NBFM beside AM / SSB on ~500 kS/s channels) share ONE launch when the two together still get three or more ranges per
+        // demodulator: the two demodulators of a channel usually differ in depth, and only inside one launch can they run side by side on one
+        // XCD and read the channel row once (below).  C3 (86 + 170 demodulators): 0.37 + 0.19 -> 0.51 ms per batch; C5 (171 + 341: one range
+        // each when merged) 0.318 -> 0.334 ms: not merged.  (Round 3's merged launch was slower: it had no pairing to pay for the two bodies.)
+        int n5 = 0, n6 = 0;
+        auto depth = [&](const SlotHost &s) {
+            const int S = (int)s.iq.S;
+            if (s.iq.interp || S < 5 || S > 6) return 0;
+            for (int e = 0; e < S; ++e) if ((int)s.iq.m[S - 1 - e] != fes_m(S, e)) return 0;
+            return S;
+        };
+        for (int i = 0; i < n_run; ++i) { const int d = depth(b->slots[slot_list_h[i]]); n5 += d == 5; n6 += d == 6; }
+        static const int fe_resident = std::max(1, c->wg_slots(demod_frontend_s56<2048>, kFeThreads + 64, fes_lds_bytes<6, 2048>()));      // (one device type per process)
+        const bool merge56 = n5 > 0 && n6 > 0 && 4 * (n5 + n6) <= fe_resident && lab_int("CSDR_FE_MERGE56", 1) != 0;
         auto klass = [&](const SlotHost &s) {
             const int S = (int)s.iq.S;
             if (s.iq.interp) return 7;
             if (S < 3 || S > 6) return 0;
             for (int e = 0; e < S; ++e) if ((int)s.iq.m[S - 1 - e] != fes_m(S, e)) return 0;
+            if (S == 5 && merge56) return 6;
             return S;
         };
         int pos = 0;
@@ -559,7 +574,12 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     CSDR_FE_S(3, 2048); CSDR_FE_S(4, 2048);
     static const bool tw6 = lab_int("CSDR_FE_TW6", 1) != 0;
     if (grp_n[6] > 0) {          // depth 6 (AM / SSB from ~500 kS/s channels): tail wave with three tail stages (CSDR_FE_TW6=0: without)
-        if (tw6)
+        bool any5 = false;
+        for (int i = 0; i < 16 * grp_rows[6]; ++i) { const int si = grp_h[grp_off[6] + i]; any5 = any5 || (si >= 0 && b->slots[si].iq.S == 5); }
+        if (any5)
+            CSDR_LAUNCH(c, LANE_FE, KID_FE_S56, (demod_frontend_s56<2048>), dim3(16, grp_rows[6] * (ranges_for(grp_n[6]) + 1)), dim3(kFeThreads + 64), (fes_lds_bytes<6, 2048>()),
+                        b->cfgs.p, dyns_d, grp_d + grp_off[6], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p, grp_rows[6]);
+        else if (tw6)
             CSDR_LAUNCH(c, LANE_FE, KID_FE_S6, (demod_frontend_s<6, 2048, true>), dim3(8 * grp_g[6], grp_rows[6] * (ranges_for(grp_n[6]) + 1)), dim3(kFeThreads + 64), (fes_lds_bytes<6, 2048>()),
                         b->cfgs.p, dyns_d, grp_d + grp_off[6], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p, grp_rows[6]);
         else CSDR_FE_S(6, 2048);

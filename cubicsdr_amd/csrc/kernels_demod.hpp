@@ -830,6 +830,17 @@ CSDR_KERNEL __launch_bounds__(kFeThreads + (TW ? 64 : 0), TW ? 6 : 4) void demod
     if (slot < 0) return;
     fes_body<S, CH, TW>(cfgs, dyns, slot, part, (int)gridDim.y / nq - 1, chan_base, chan_stride, total, arms_all, sintab);
 }
+// depths 5 and 6 in ONE launch (the NBFM and the AM / SSB demodulators of a ~500 kS/s channel): the two demodulators of a channel usually differ in
+// depth, and only inside one launch can they run side by side on one XCD and share the channel row (demod_frontend_s above)
+template <int CH>
+CSDR_KERNEL __launch_bounds__(kFeThreads + 64, 6) void demod_frontend_s56(
+    const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
+    const float2 *__restrict__ chan_base, int64_t chan_stride, int64_t total, const float *__restrict__ arms_all, const float *__restrict__ sintab, int nq) {
+    const int q = (int)blockIdx.y, part = q / nq, slot = slot_list[(q - part * nq) * (int)gridDim.x + (int)blockIdx.x];
+    if (slot < 0) return;
+    if (cfgs[slot].rs_iq.S == 5) fes_body<5, CH, true>(cfgs, dyns, slot, part, (int)gridDim.y / nq - 1, chan_base, chan_stride, total, arms_all, sintab);
+    else fes_body<6, CH, true>(cfgs, dyns, slot, part, (int)gridDim.y / nq - 1, chan_base, chan_stride, total, arms_all, sintab);
+}
 // (Depths 5 and 6 in ONE launch were measured in round 3: 0.749 ms against 0.440 + 0.231 ms for the two launches -- the depth-5 workgroups
 // then carry the depth-6 LDS carve and fewer of them are resident; that kernel is gone.)
 
