@@ -349,10 +349,18 @@ struct csdr_ctx {
         return CSDR_OK;
     }
     // workgroups of this kernel that are resident at once on the whole chip
+    // (the occupancy query is a runtime call of several microseconds and its answer never changes: asked once per (kernel, shape); a one-block call
+    // has ~100 us of host time in all)
+    struct SlotsKey { const void *k; int threads; size_t lds; int nb; };
+    mutable std::vector<SlotsKey> slots_cache;
+    mutable std::mutex slots_mu;
     template <typename K>
     int wg_slots(K kernel, int threads, size_t lds) const {
+        std::lock_guard<std::mutex> lk(slots_mu);
+        for (const SlotsKey &e : slots_cache) if (e.k == (const void *)kernel && e.threads == threads && e.lds == lds) return e.nb * n_cu;
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kernel, threads, lds) != hipSuccess || nb < 1) nb = 1;
+        slots_cache.push_back(SlotsKey{(const void *)kernel, threads, lds, nb});
         return nb * n_cu;
     }
     int sync_all() {

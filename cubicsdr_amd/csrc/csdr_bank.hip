@@ -280,7 +280,9 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     // parities).  A rejected batch must leave every slot as it was -- no kernel runs for it -- so the state is snapshotted and
     // put back on any error return of the walk.
     struct Snap { uint32_t theta, dtheta, buf_idx, phase, aphase, abuf, ssb_theta; long long shift_frequency; bool shift_valid; int hist_parity, last_parity, prev_J; };
-    std::vector<Snap> snap((size_t)b->max_demods);
+    static_assert(sizeof(Snap) <= sizeof(csdr_bank::SnapBytes), "snapshot record");
+    b->snap.resize((size_t)b->max_demods);
+    Snap *snap = reinterpret_cast<Snap *>(b->snap.data());
     for (int si = 0; si < b->max_demods; ++si) {
         const SlotHost &s = b->slots[si];
         snap[si] = Snap{s.theta, s.dtheta, s.buf_idx, s.phase, s.aphase, s.abuf, s.ssb_theta, s.shift_frequency, s.shift_valid, s.hist_parity, s.last_parity, s.prev_J};
@@ -402,72 +404,77 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     if (n_run == 0) return CSDR_OK;
     const int n_fms = (int)fms_slots.size(), fms_off = b->max_demods - n_fms;     // n_ag + n_fms <= n_run <= max_demods
     for (int i = 0; i < n_fms; ++i) ag_list_h[fms_off + i] = fms_slots[i];
-    // running slots grouped by front-end kernel (filled before the staging set is handed to the copy engine)
+    // running slots grouped by front-end kernel (filled before the staging set is handed to the copy engine).  The grouping is a function of
+    // (running slots, their channels, their cascade classes): rebuilt only when that key changes (a one-block call has ~100 us to spend)
     int *grp_h = slot_list_h + 2 * (size_t)b->max_demods;
-    int grp_off[8] = {0}, grp_n[8] = {0}, grp_rows[8] = {0}, grp_g[8] = {0};        // index 0: generic, 3..6: specialised by S (their lists: grp_rows rows of 8 grp_g positions)
+    int grp_off[8] = {0}, grp_n[8] = {0}, grp_rows[8] = {0};        // index 0: generic, 3..6: specialised by S (their lists: grp_rows rows of sixteen positions)
+    bool merged56 = false;
     {
-        // Depths 5 and 6 (NBFM beside AM / SSB on ~500 kS/s channels) share ONE launch when the two together still get three or more ranges per
-        // demodulator: the two demodulators of a channel usually differ in depth, and only inside one launch can they run side by side on one
-        // XCD and read the channel row once (below).  C3 (86 + 170 demodulators): 0.37 + 0.19 -> 0.51 ms per batch; C5 (171 + 341: one range
-        // each when merged) 0.318 -> 0.334 ms: not merged.  (Round 3's merged launch was slower: it had no pairing to pay for the two bodies.)
-        int n5 = 0, n6 = 0;
-        auto depth = [&](const SlotHost &s) {
-            const int S = (int)s.iq.S;
-            if (s.iq.interp || S < 5 || S > 6) return 0;
-            for (int e = 0; e < S; ++e) if ((int)s.iq.m[S - 1 - e] != fes_m(S, e)) return 0;
-            return S;
-        };
-        for (int i = 0; i < n_run; ++i) { const int d = depth(b->slots[slot_list_h[i]]); n5 += d == 5; n6 += d == 6; }
-        static const int fe_resident = std::max(1, c->wg_slots(demod_frontend_s56<2048>, kFeThreads + 64, fes_lds_bytes<6, 2048>()));      // (one device type per process)
-        const bool merge56 = n5 > 0 && n6 > 0 && 4 * (n5 + n6) <= fe_resident && lab_int("CSDR_FE_MERGE56", 1) != 0;
-        auto klass = [&](const SlotHost &s) {
+        auto depth = [](const SlotHost &s) {        // 3 .. 6: the reference's standard half-band pattern of that depth; 7: interpolating; 0: anything else
             const int S = (int)s.iq.S;
             if (s.iq.interp) return 7;
             if (S < 3 || S > 6) return 0;
             for (int e = 0; e < S; ++e) if ((int)s.iq.m[S - 1 - e] != fes_m(S, e)) return 0;
-            if (S == 5 && merge56) return 6;
             return S;
         };
-        int pos = 0;
-        std::vector<int> members;
-        std::vector<std::vector<int>> cols;
-        std::map<int, std::vector<int>> by_chan;
-        for (int k = 0; k < 8; ++k) {
-            grp_off[k] = pos;
-            if (k < 3 || k > 6) {
-                for (int i = 0; i < n_run; ++i) if (klass(b->slots[slot_list_h[i]]) == k) grp_h[pos++] = slot_list_h[i];
-                grp_n[k] = pos - grp_off[k];
-                continue;
+        std::vector<int> &key = b->grp_key_scratch;
+        key.clear();
+        for (int i = 0; i < n_run; ++i) { const int si = slot_list_h[i]; key.push_back(si); key.push_back(dyns_h[si].chan); key.push_back(depth(b->slots[si])); }
+        if (key != b->grp_key) {
+            b->grp_key = key;
+            // Depths 5 and 6 (NBFM beside AM / SSB on ~500 kS/s channels) share ONE launch when the two together still get three or more ranges per
+            // demodulator: the two demodulators of a channel usually differ in depth, and only inside one launch can they run side by side on one
+            // XCD and read the channel row once (below).  C3 (86 + 170 demodulators): 0.37 + 0.19 -> 0.51 ms per batch; C5 (171 + 341: one range
+            // each when merged) 0.318 -> 0.334 ms: not merged.  (Round 3's merged launch was slower: it had no pairing to pay for the two bodies.)
+            int n5 = 0, n6 = 0;
+            for (int i = 0; i < n_run; ++i) { const int d = key[3 * (size_t)i + 2]; n5 += d == 5; n6 += d == 6; }
+            static const int fe_resident = std::max(1, c->wg_slots(demod_frontend_s56<2048>, kFeThreads + 64, fes_lds_bytes<6, 2048>()));      // (one device type per process)
+            const bool merge56 = n5 > 0 && n6 > 0 && 4 * (n5 + n6) <= fe_resident && lab_int("CSDR_FE_MERGE56", 1) != 0;
+            b->grp_merged56 = merge56;
+            auto klass = [&](int i) { const int d = key[3 * (size_t)i + 2]; return (d == 5 && merge56) ? 6 : d; };
+            std::vector<int> &list = b->grp_list;
+            list.clear();
+            std::vector<int> members, loose;
+            std::vector<std::pair<int, int>> cols;
+            std::map<int, int> waiting;
+            for (int k = 0; k < 8; ++k) {
+                b->grp_off[k] = (int)list.size(); b->grp_rows[k] = 0;
+                if (k < 3 || k > 6) {
+                    for (int i = 0; i < n_run; ++i) if (klass(i) == k) list.push_back(key[3 * (size_t)i]);
+                    b->grp_n[k] = (int)list.size() - b->grp_off[k];
+                    continue;
+                }
+                // the specialised kernels take their list in rows of sixteen positions: two demodulators of ONE channel at positions w and w + 8 of a
+                // row (demod_frontend_s: they then run on the same XCD at the same time and the channel row crosses the fabric once); -1 = empty
+                // (only the last row has any: demodulators alone on their channel pair up with each other).  Measured on MI355X, front-end ms per
+                // batch: C3N (256 NBFM, 2.1 per channel) 0.59 -> 0.47, C5 0.217 + 0.133 -> 0.209 + 0.109, C2 unchanged.  Rows of 32 with up to
+                // four of a channel together were measured as well and lose badly (C3N 0.89, C2 0.27 -> 0.43 ms): half of the grid is then
+                // empty positions and a second round.
+                members.clear(); loose.clear(); cols.clear(); waiting.clear();
+                for (int i = 0; i < n_run; ++i) if (klass(i) == k) members.push_back(i);
+                b->grp_n[k] = (int)members.size();
+                if (members.empty()) continue;
+                for (int i : members) {
+                    const int si = key[3 * (size_t)i], ch = key[3 * (size_t)i + 1];
+                    auto it = waiting.find(ch);
+                    if (it == waiting.end()) waiting[ch] = si;
+                    else { cols.push_back({it->second, si}); waiting.erase(it); }
+                }
+                for (auto &kv : waiting) loose.push_back(kv.second);
+                std::sort(loose.begin(), loose.end());
+                for (size_t i = 0; i < loose.size(); i += 2) cols.push_back({loose[i], i + 1 < loose.size() ? loose[i + 1] : -1});
+                b->grp_rows[k] = ((int)cols.size() + 7) / 8;
+                const size_t base = list.size();
+                list.resize(base + (size_t)16 * b->grp_rows[k], -1);
+                for (size_t cidx = 0; cidx < cols.size(); ++cidx) {
+                    list[base + (cidx / 8) * 16 + (cidx % 8)] = cols[cidx].first;
+                    list[base + (cidx / 8) * 16 + (cidx % 8) + 8] = cols[cidx].second;
+                }
             }
-            // the specialised kernels take their list in rows of sixteen positions: two demodulators of ONE channel at positions w and w + 8 of a
-            // row (demod_frontend_s: they then run on the same XCD at the same time and the channel row crosses the fabric once); -1 = empty
-            // (only the last row has any: demodulators alone on their channel pair up with each other).  Measured on MI355X, front-end ms per
-            // batch: C3N (256 NBFM, 2.1 per channel) 0.59 -> 0.47, C5 0.217 + 0.133 -> 0.209 + 0.109, C3 (its two demodulators of a channel
-            // mostly sit in DIFFERENT launches, depth 5 and depth 6) and C2 unchanged.  Rows of 32 with up to four of a channel together were
-            // measured as well and lose badly (C3N 0.89, C2 0.27 -> 0.43 ms): half of the grid is then empty positions and a second round.
-            members.clear(); cols.clear(); by_chan.clear();
-            for (int i = 0; i < n_run; ++i) if (klass(b->slots[slot_list_h[i]]) == k) members.push_back(slot_list_h[i]);
-            grp_n[k] = (int)members.size();
-            if (members.empty()) continue;
-            for (int si : members) by_chan[dyns_h[si].chan].push_back(si);
-            constexpr int G = 2;
-            std::vector<int> loose;
-            for (auto &kv : by_chan) {
-                auto &v = kv.second;
-                size_t i = 0;
-                for (; i + 1 < v.size(); i += (size_t)G) cols.push_back(std::vector<int>(v.begin() + (long)i, v.begin() + (long)std::min(v.size(), i + (size_t)G)));
-                if (i < v.size()) loose.push_back(v[i]);         // one left over: alone
-            }
-            std::sort(loose.begin(), loose.end());
-            for (size_t i = 0; i < loose.size(); i += (size_t)G) cols.push_back(std::vector<int>(loose.begin() + (long)i, loose.begin() + (long)std::min(loose.size(), i + (size_t)G)));
-            grp_g[k] = G;
-            grp_rows[k] = ((int)cols.size() + 7) / 8;
-            const int R = 8 * G;
-            for (int i = 0; i < R * grp_rows[k]; ++i) grp_h[pos + i] = -1;
-            for (size_t cidx = 0; cidx < cols.size(); ++cidx)
-                for (size_t u = 0; u < cols[cidx].size(); ++u) grp_h[pos + (int)(cidx / 8) * R + (int)(cidx % 8) + 8 * (int)u] = cols[cidx][u];
-            pos += R * grp_rows[k];
         }
+        memcpy(grp_h, b->grp_list.data(), b->grp_list.size() * sizeof(int));
+        for (int k = 0; k < 8; ++k) { grp_off[k] = b->grp_off[k]; grp_n[k] = b->grp_n[k]; grp_rows[k] = b->grp_rows[k]; }
+        merged56 = b->grp_merged56;
     }
     // the audio stage runs the slots that have one: compact the head of the list (the front-end groups above are copies)
     int n_audio_run = 0;
@@ -569,18 +576,16 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
                     chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
 #define CSDR_FE_S(S_, CH_)                                                                                                              \
     if (grp_n[S_] > 0)                                                                                                                  \
-        CSDR_LAUNCH(c, LANE_FE, KID_FE_S##S_, (demod_frontend_s<S_, CH_>), dim3(8 * grp_g[S_], grp_rows[S_] * (ranges_for(grp_n[S_]) + 1)), dim3(kFeThreads), (fes_lds_bytes<S_, CH_>()), \
+        CSDR_LAUNCH(c, LANE_FE, KID_FE_S##S_, (demod_frontend_s<S_, CH_>), dim3(16, grp_rows[S_] * (ranges_for(grp_n[S_]) + 1)), dim3(kFeThreads), (fes_lds_bytes<S_, CH_>()), \
                     b->cfgs.p, dyns_d, grp_d + grp_off[S_], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p, grp_rows[S_])
     CSDR_FE_S(3, 2048); CSDR_FE_S(4, 2048);
     static const bool tw6 = lab_int("CSDR_FE_TW6", 1) != 0;
     if (grp_n[6] > 0) {          // depth 6 (AM / SSB from ~500 kS/s channels): tail wave with three tail stages (CSDR_FE_TW6=0: without)
-        bool any5 = false;
-        for (int i = 0; i < 16 * grp_rows[6]; ++i) { const int si = grp_h[grp_off[6] + i]; any5 = any5 || (si >= 0 && b->slots[si].iq.S == 5); }
-        if (any5)
+        if (merged56)
             CSDR_LAUNCH(c, LANE_FE, KID_FE_S56, (demod_frontend_s56<2048>), dim3(16, grp_rows[6] * (ranges_for(grp_n[6]) + 1)), dim3(kFeThreads + 64), (fes_lds_bytes<6, 2048>()),
                         b->cfgs.p, dyns_d, grp_d + grp_off[6], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p, grp_rows[6]);
         else if (tw6)
-            CSDR_LAUNCH(c, LANE_FE, KID_FE_S6, (demod_frontend_s<6, 2048, true>), dim3(8 * grp_g[6], grp_rows[6] * (ranges_for(grp_n[6]) + 1)), dim3(kFeThreads + 64), (fes_lds_bytes<6, 2048>()),
+            CSDR_LAUNCH(c, LANE_FE, KID_FE_S6, (demod_frontend_s<6, 2048, true>), dim3(16, grp_rows[6] * (ranges_for(grp_n[6]) + 1)), dim3(kFeThreads + 64), (fes_lds_bytes<6, 2048>()),
                         b->cfgs.p, dyns_d, grp_d + grp_off[6], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p, grp_rows[6]);
         else CSDR_FE_S(6, 2048);
     }
@@ -592,7 +597,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
                     chan_out, post->chan_stride, total, b->arms.p, c->sintab.p);
     }
     if (grp_n[5] > 0)                       // depth 5 (NBFM from ~500 kS/s channels): a fifth wave runs the one-wave tail one chunk behind
-        CSDR_LAUNCH(c, LANE_FE, KID_FE_S5, (demod_frontend_s<5, 2048, true>), dim3(8 * grp_g[5], grp_rows[5] * (ranges_for(grp_n[5]) + 1)), dim3(kFeThreads + 64), (fes_lds_bytes<5, 2048>()),
+        CSDR_LAUNCH(c, LANE_FE, KID_FE_S5, (demod_frontend_s<5, 2048, true>), dim3(16, grp_rows[5] * (ranges_for(grp_n[5]) + 1)), dim3(kFeThreads + 64), (fes_lds_bytes<5, 2048>()),
                     b->cfgs.p, dyns_d, grp_d + grp_off[5], chan_out, post->chan_stride, total, b->arms.p, c->sintab.p, grp_rows[5]);
 #undef CSDR_FE_S
     CSDR_HIP_TRY(hipGetLastError());

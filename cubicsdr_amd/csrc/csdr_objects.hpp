@@ -110,6 +110,12 @@ struct csdr_bank {
     std::vector<float> arms_host;
     int n_run = 0, last_nb = 0;
     size_t lds_attr[7] = {0, 0, 0, 0, 0, 0, 0};
+    // the front-end launch lists of the last batch and what they were built from (slot, channel, cascade class per running slot): csdr_bank_execute
+    std::vector<int> grp_key, grp_key_scratch, grp_list;
+    int grp_off[8] = {0}, grp_n[8] = {0}, grp_rows[8] = {0};
+    bool grp_merged56 = false;
+    struct SnapBytes { char b[64]; };
+    std::vector<SnapBytes> snap;             // host-state snapshot of a batch being planned (a rejected batch puts it back)
     DevBuf<int16_t> pcm;                     // csdr_bank_fetch_pcm16: the converted audio of one slot
     DevBuf<PcmJob> pcm_jobs;
 };
