@@ -20,9 +20,13 @@ NB=${2:-128}
 BENCH="python $REPO/bench.py --config $CFG --steps 2 --warmup 1 --batches 6 --cpu-seconds 0 --no-profile --no-latency --blocks $NB"
 # counter passes: the same command on a noise-only ring (the kernels' work does not depend on the sample values)
 PMCBENCH="$BENCH --ring noise"
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- $BENCH ) > $OUT/stats.log 2>&1
+# duration passes: a few hundred batches, so that the ~40 ms core-clock ramp after the idle start (profiles/r05_variance.txt: + 45 % on the issue-bound
+# kernels for the first ~20 batches) is a few per cent of the average and the summary agrees with bench.py's steady-state HIP-event figures
+# (rounds 1-4 timed 18 batches here: their averages carry the ramp)
+LONGBENCH="python $REPO/bench.py --config $CFG --steps 8 --warmup 4 --batches 24 --cpu-seconds 0 --no-profile --no-latency --no-strong --blocks $NB --ring noise"
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- $LONGBENCH ) > $OUT/stats.log 2>&1
 # the same command on the library's default three streams
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/solo -o b -- $BENCH --streams 3 ) > $OUT/solo.log 2>&1
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/solo -o b -- $LONGBENCH --streams 3 ) > $OUT/solo.log 2>&1
 ( cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o b -- $PMCBENCH ) > $OUT/fetch.log 2>&1
 ( cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o b -- $PMCBENCH ) > $OUT/write.log 2>&1
 python - "$OUT" "$DST" "$NB" "$CFG" <<'PY'
@@ -47,12 +51,14 @@ for name in ("fetch", "write"):
     for k, v in acc.items():
         traffic[k][name.upper() + "_SIZE_KiB_avg_per_launch"] = sum(v) / len(v)
         traffic[k]["launches_" + name] = len(v)
-traffic["_meta"] = {"blocks_per_launch": int(sys.argv[3]), "config": sys.argv[4], "command": "bench.py --config %s --steps 2 --warmup 1 --batches 6 --cpu-seconds 0 --no-profile --no-latency --blocks %s" % (sys.argv[4], sys.argv[3])}
+traffic["_meta"] = {"blocks_per_launch": int(sys.argv[3]), "config": sys.argv[4], "command": "bench.py --config %s --steps 2 --warmup 1 --batches 6 --cpu-seconds 0 --no-profile --no-latency --blocks %s --ring noise" % (sys.argv[4], sys.argv[3]),
+                    "duration_passes": "bench.py --config %s --steps 8 --warmup 4 --batches 24 --cpu-seconds 0 --no-profile --no-latency --no-strong --blocks %s --ring noise (kernel_stats*.csv)" % (sys.argv[4], sys.argv[3])}
 json.dump(traffic, open(dst + "/pmc_traffic.json", "w"), indent=1, sort_keys=True)
 print(open(dst + "/kernel_stats.csv").read())
 print(json.dumps(traffic, indent=1, sort_keys=True))
 PY
 for f in stats solo fetch write; do tail -3 $OUT/$f.log > $DST/$f.log.tail 2>/dev/null; done
+if [ "${COLLECT_STATS_ONLY:-0}" = "1" ]; then tail -2 $OUT/stats.log; exit 0; fi
 # SQ counters of every kernel (own passes, one stream: every kernel alone on the device)
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" \
