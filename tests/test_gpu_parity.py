@@ -1094,7 +1094,7 @@ def test_c3_shape_mixed_m122(ctx):
         print("   [%.0e, %s): %9d  (%.5f %%)" % (lo, "%.0e" % hi if hi < 1 else "inf", n, 100.0 * n / max(1, hist.sum())))
     assert hist[-1] == 0
     per = np.concatenate(per)
-    print("c3 audio, per-sample |gpu - reference| / max(|reference sample|, 1 %% of the demodulator's peak): " +
+    print("c3 audio, per-sample |gpu - reference| / max(|reference sample|, 1 % of the demodulator's peak): " +
           ", ".join("p%s %.2e" % (q, np.percentile(per, float(q))) for q in ("50", "90", "99", "99.9", "99.99", "100")))
 
 
