@@ -119,7 +119,7 @@ static chan_p2_kernel_t chan_p2_kernel(const ChanGeom &g) {
 }
 typedef void (*chanfft_kernel_t)(const float2 *, const float2 *, float2 *, const float *, const float2 *, const int *, const int *, ChanFftGeom, int64_t,
                                  float2 *, int64_t, d2 *, double);
-static chanfft_kernel_t chanfft_kernel(const ChanFftGeom &) { return chan_analyze_fft; }
+static chanfft_kernel_t chanfft_kernel(const ChanFftGeom &g) { return g.wide_odd ? chan_analyze_fft<true> : chan_analyze_fft<false>; }
 static chan_kernel_t chan_kernel(const ChanGeom &g) {
     if (g.oddA) {
         if (g.hop != g.M) return g.stage_in ? chan_analyze<1, 1, 1, 1> : g.taps_lds ? chan_analyze<0, 1, 1, 1> : chan_analyze<0, 0, 1, 1>;

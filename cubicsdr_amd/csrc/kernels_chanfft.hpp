@@ -8,7 +8,7 @@
 //
 // Until round 4 these channel counts ran chan_analyze (kernels_post.hpp): ONE Cooley-Tukey split M = A B with direct A- and B-point
 // DFTs, M (A + B) complex MACs per frame -- 64 per sample at M = 1024, 0.11 of the HBM roofline.  Here the transform is an in-place
-// decimation-in-frequency FFT over radices 16 / 8 / 4 / 2 and odd 3 / 5 / 7 / 9 / 11 / 13 (M = 1024 = 16 * 8 * 8: ~9 real operations per
+// decimation-in-frequency FFT over radices 16 / 8 / 4 / 2 and odd 3 / 5 / 7 / 9 / 11 / 13 (17 / 19 / 23 in a second instance; M = 1024 = 16 * 8 * 8: ~9 real operations per
 // sample and pass), and the tile is TRANSPOSED in LDS: X[c][t], t contiguous.
 //  * Persistent workgroups walk over tiles of TF consecutive frames (TF a power of two, 8 .. 256: the largest whose tile fits the LDS budget).
 //  * FIR: a work item owns a column PAIR (one float4) and eight consecutive frames; the fifteen input rows they reach go straight
@@ -43,6 +43,7 @@ struct ChanFftGeom {
     int twstep[kCfMaxPasses];             // M / N_p: W_{N_p}^(j r) = W_M^(j r twstep)
     unsigned magic_half;                  // floor(2^32 / (M / 2)) + 1 (M > 2)
     int xcd;                              // 1: workgroups of one XCD (blockIdx.x % 8) take CONSECUTIVE tiles (grid a multiple of 8)
+    int wide_odd;                         // 1: a radix of 17 / 19 / 23 is in the plan: the kernel instance that carries those butterflies
 };
 
 __host__ __device__ inline size_t chanfft_lds_bytes(const ChanFftGeom &g) {
@@ -62,7 +63,7 @@ __host__ inline bool chanfft_plan(int M, size_t lds_limit, int force_tf, int for
     while (m % 3 == 0) { m /= 3; ++e3; }
     for (; e3 >= 2; e3 -= 2) rad.push_back(9);
     if (e3) rad.push_back(3);
-    for (int p : {5, 7, 11, 13}) while (m % p == 0) { m /= p; rad.push_back(p); }
+    for (int p : {5, 7, 11, 13, 17, 19, 23}) while (m % p == 0) { m /= p; rad.push_back(p); if (p >= 17) g.wide_odd = 1; }
     if (m != 1) return false;
     const int n2 = (e2 + 3) / 4;                               // passes over the power of two: as even as possible, widest first
     for (int i = 0; i < n2; ++i) rad.push_back(1 << (e2 / n2 + (i < e2 % n2 ? 1 : 0)));
@@ -138,6 +139,20 @@ template <> struct CfOdd<11> {
 template <> struct CfOdd<13> {
     static constexpr float c[13] = {1.000000000e+00f, 8.854560257e-01f, 5.680647467e-01f, 1.205366803e-01f, -3.546048870e-01f, -7.485107482e-01f, -9.709418174e-01f, -9.709418174e-01f, -7.485107482e-01f, -3.546048870e-01f, 1.205366803e-01f, 5.680647467e-01f, 8.854560257e-01f};
     static constexpr float s[13] = {0.000000000e+00f, 4.647231720e-01f, 8.229838659e-01f, 9.927088741e-01f, 9.350162427e-01f, 6.631226582e-01f, 2.393156643e-01f, -2.393156643e-01f, -6.631226582e-01f, -9.350162427e-01f, -9.927088741e-01f, -8.229838659e-01f, -4.647231720e-01f};
+};
+// 17 / 19 / 23: the wide-odd instance of the kernel only (chan_analyze_fft<true>: M = 68, 76, 92, 136 ... -- channel counts getOptimalChannelCount
+// returns between 34 and 46 MS/s and their multiples); their 2 R registers of operands stay out of the instance every other count runs
+template <> struct CfOdd<17> {
+    static constexpr float c[17] = {1.000000000e+00f, 9.324722294e-01f, 7.390089172e-01f, 4.457383558e-01f, 9.226835946e-02f, -2.736629901e-01f, -6.026346364e-01f, -8.502171357e-01f, -9.829730997e-01f, -9.829730997e-01f, -8.502171357e-01f, -6.026346364e-01f, -2.736629901e-01f, 9.226835946e-02f, 4.457383558e-01f, 7.390089172e-01f, 9.324722294e-01f};
+    static constexpr float s[17] = {0.000000000e+00f, 3.612416662e-01f, 6.736956436e-01f, 8.951632914e-01f, 9.957341763e-01f, 9.618256432e-01f, 7.980172273e-01f, 5.264321629e-01f, 1.837495178e-01f, -1.837495178e-01f, -5.264321629e-01f, -7.980172273e-01f, -9.618256432e-01f, -9.957341763e-01f, -8.951632914e-01f, -6.736956436e-01f, -3.612416662e-01f};
+};
+template <> struct CfOdd<19> {
+    static constexpr float c[19] = {1.000000000e+00f, 9.458172417e-01f, 7.891405094e-01f, 5.469481581e-01f, 2.454854871e-01f, -8.257934547e-02f, -4.016954247e-01f, -6.772815716e-01f, -8.794737512e-01f, -9.863613034e-01f, -9.863613034e-01f, -8.794737512e-01f, -6.772815716e-01f, -4.016954247e-01f, -8.257934547e-02f, 2.454854871e-01f, 5.469481581e-01f, 7.891405094e-01f, 9.458172417e-01f};
+    static constexpr float s[19] = {0.000000000e+00f, 3.246994692e-01f, 6.142127127e-01f, 8.371664783e-01f, 9.694002659e-01f, 9.965844930e-01f, 9.157733267e-01f, 7.357239107e-01f, 4.759473930e-01f, 1.645945903e-01f, -1.645945903e-01f, -4.759473930e-01f, -7.357239107e-01f, -9.157733267e-01f, -9.965844930e-01f, -9.694002659e-01f, -8.371664783e-01f, -6.142127127e-01f, -3.246994692e-01f};
+};
+template <> struct CfOdd<23> {
+    static constexpr float c[23] = {1.000000000e+00f, 9.629172873e-01f, 8.544194045e-01f, 6.825531432e-01f, 4.600650377e-01f, 2.034560131e-01f, -6.824241336e-02f, -3.348796122e-01f, -5.766803221e-01f, -7.757112907e-01f, -9.172113015e-01f, -9.906859460e-01f, -9.906859460e-01f, -9.172113015e-01f, -7.757112907e-01f, -5.766803221e-01f, -3.348796122e-01f, -6.824241336e-02f, 2.034560131e-01f, 4.600650377e-01f, 6.825531432e-01f, 8.544194045e-01f, 9.629172873e-01f};
+    static constexpr float s[23] = {0.000000000e+00f, 2.697967712e-01f, 5.195839500e-01f, 7.308359643e-01f, 8.878852184e-01f, 9.790840877e-01f, 9.976687692e-01f, 9.422609221e-01f, 8.169698930e-01f, 6.310879443e-01f, 3.984010898e-01f, 1.361666491e-01f, -1.361666491e-01f, -3.984010898e-01f, -6.310879443e-01f, -8.169698930e-01f, -9.422609221e-01f, -9.976687692e-01f, -9.790840877e-01f, -8.878852184e-01f, -7.308359643e-01f, -5.195839500e-01f, -2.697967712e-01f};
 };
 
 template <int R> struct CfDft {
@@ -280,7 +295,8 @@ __device__ __forceinline__ void cf_fir(const float4 (&win)[kCfSeg + kChanTaps - 
     }
 }
 
-CSDR_KERNEL_POST __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
+template <bool WIDE>
+CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
     const float2 *__restrict__ x,        // batch input, n_frames * M samples
     const float2 *__restrict__ hist,     // 7 * M samples preceding x
     float2 *__restrict__ hist_new,       // receives the last 7 * M samples of (hist ++ x)
@@ -353,6 +369,9 @@ CSDR_KERNEL_POST __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
                         case 9: cf_pass_item<9>(px, pitch, s_tw, jj); break;
                         case 11: cf_pass_item<11>(px, pitch, s_tw, jj); break;
                         case 13: cf_pass_item<13>(px, pitch, s_tw, jj); break;
+                        case 17: if constexpr (WIDE) cf_pass_item<17>(px, pitch, s_tw, jj); break;
+                        case 19: if constexpr (WIDE) cf_pass_item<19>(px, pitch, s_tw, jj); break;
+                        case 23: if constexpr (WIDE) cf_pass_item<23>(px, pitch, s_tw, jj); break;
                         default: cf_pass_item<16>(px, pitch, s_tw, jj); break;
                     }
                 } else {
@@ -370,6 +389,9 @@ CSDR_KERNEL_POST __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
                         case 9: cf_last_item<9>(px, pitch, pa, dcp, t, live, o, out_stride); break;
                         case 11: cf_last_item<11>(px, pitch, pa, dcp, t, live, o, out_stride); break;
                         case 13: cf_last_item<13>(px, pitch, pa, dcp, t, live, o, out_stride); break;
+                        case 17: if constexpr (WIDE) cf_last_item<17>(px, pitch, pa, dcp, t, live, o, out_stride); break;
+                        case 19: if constexpr (WIDE) cf_last_item<19>(px, pitch, pa, dcp, t, live, o, out_stride); break;
+                        case 23: if constexpr (WIDE) cf_last_item<23>(px, pitch, pa, dcp, t, live, o, out_stride); break;
                         default: cf_last_item<16>(px, pitch, pa, dcp, t, live, o, out_stride); break;
                     }
                 }
