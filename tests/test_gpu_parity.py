@@ -667,7 +667,7 @@ def test_fft_matches_liquid(ctx, F):
     sp.close()
 
 
-@pytest.mark.parametrize("F,block", [(2048, 40000), (16384, 166680), (600, 40000), (375, 4000)])
+@pytest.mark.parametrize("F,block", [(2048, 40000), (16384, 166680), (600, 40000), (375, 4000), (65536, 1024068)])
 def test_spectrum_points_first_frame_mode(ctx, F, block):
     from cubicsdr_amd.engine import SpectrumProcessor
     from oracle.cubicsdr_chain import RefSpectrum
@@ -711,7 +711,7 @@ def test_spectrum_contiguous_mode(ctx):
     sp.close()
 
 
-@pytest.mark.parametrize("F,line", [(2048, 2048), (2048, 3000), (1024, 600), (16384, 16384)])
+@pytest.mark.parametrize("F,line", [(2048, 2048), (2048, 3000), (1024, 600), (16384, 16384), (65536, 65536), (65536, 100000)])
 def test_spectrum_line_cadence_overlapped_frames(ctx, F, line):
     """FFTDataDistributor hands the spectrum fftSize-sample lines (FFTDataDistributor.cpp:112-131), shorter than the
     2*fftSize transform: the first primes fftLastData, every later one is transformed together with the tail of the
@@ -723,21 +723,48 @@ def test_spectrum_line_cadence_overlapped_frames(ctx, F, line):
     sp = SpectrumProcessor(ctx, F, max_frames=8)
     ref = RefSpectrum(_backend(), F)
     want = []
+    exact = None
+    if F >= 65536:
+        class ExactSpectrum(RefSpectrum):                  # the same restatement with a float64 transform
+            def fft(self, frame):
+                return np.fft.fft(np.asarray(frame, dtype=np.complex128))
+        exact = ExactSpectrum(_backend(), F)
+    exact_all = []
     for k in range(nl):
         fr = ref.select_input(x[k * line:(k + 1) * line])
         want.append(None if fr is None else ref.process_frame(fr))
+        exact_all.append(None if (fr is None or exact is None) else exact.process_frame(np.array(fr)))
     assert want[0] is None and all(w is not None for w in want[1:])
+    worst_seen = [0.0, 0.0, 0.0]
     k = 0
     for per_call in (1, 1, 1, 3, 5):
         nf = sp.process(x[k * line:(k + per_call) * line], per_call, line, lines=True)
         expect = [w for w in want[k:k + per_call] if w is not None]
+        exact_frames = {k + j: ew for j, ew in enumerate([q for q, w in zip(exact_all[k:k + per_call], want[k:k + per_call]) if w is not None])}
         assert nf == len(expect), (k, nf)
         for j, (wp, wce, wfl) in enumerate(expect):
             pts, ce, fl = sp.fetch(j)
-            assert rel_err(pts, wp) < TOL, (k, j)
+            e = rel_err(pts, wp)
+            if exact is None:
+                assert e < TOL, (k, j)
+            else:
+                # 2^17-point frames of a SPARSE signal (two strong carriers over a noise floor: the float32 transform's rounding noise in the weak
+                # bins is set by the carriers) in the first inputs after the start, while the floor tracker is still ~ 5e-5: one point of 65536
+                # can sit 1e-5 of display value from the reference's own float32 result, on either side of the exact value
+                # (profiles/experiments/r05_lines_err.py: the reference is 5.2e-6 from a float64 transform of the same frame, the two HIP chains
+                # 5.5e-6 / 8.4e-6, with the same error distribution otherwise: rms 1.5e-7).  Held as the 2^21-point frames are (DESIGN 2,
+                # deviation 5): no further from the exact result than the tolerance or 1.5 x the reference's distance, and within the tolerance
+                # + both distances of the reference.
+                ew = exact_frames[k + j]
+                e_ref, e_hip = rel_err(wp, ew[0]), rel_err(pts, ew[0])
+                worst_seen[0] = max(worst_seen[0], e); worst_seen[1] = max(worst_seen[1], e_hip); worst_seen[2] = max(worst_seen[2], e_ref)
+                assert e_hip < max(TOL, 1.5 * e_ref), (k, j, e_hip, e_ref)
+                assert e < TOL + e_ref + e_hip, (k, j, e, e_ref, e_hip)
             assert abs(ce - wce) <= TOL * abs(wce) and abs(fl - wfl) <= TOL * abs(wce), (k, j)
         k += per_call
     assert k == nl
+    if exact is not None:
+        print("lines F=%d line=%d: worst |hip - ref| %.3g, |hip - exact| %.3g, |ref - exact| %.3g" % (F, line, *worst_seen))
     sp.close()
 
 
