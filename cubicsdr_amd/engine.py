@@ -315,6 +315,9 @@ class SpectrumProcessor:
     def set_average_rate(self, r):
         H.check(self._l.csdr_spec_set_average_rate(self.h, float(r)))
 
+    def set_scale_factor(self, f):
+        H.check(self._l.csdr_spec_set_scale_factor(self.h, float(f)))
+
     def set_peak_hold(self, enabled):
         H.check(self._l.csdr_spec_set_peak_hold(self.h, int(bool(enabled))))
 

@@ -1005,6 +1005,21 @@ def test_spectrum_headline_small_calls_and_chain_switch(ctx):
     print("headline spectrum across chain switches (%s): %d frames, worst points %.3g" % (label, k, worst))
     assert worst < TOL
     sp.close(); cpp.close()
+    # another averaging rate and scale factor through the fused chain (setFFTAverageRate / setScaleFactor)
+    cpp = RM.RefSpectrumCpp(F, fs)
+    cpp.set_center(0); cpp.set_bandwidth(fs); cpp.set_average_rate(0.3); cpp.set_scale(2.5)
+    sp = SpectrumProcessor(ctx, F, max_frames=20)
+    sp.set_average_rate(0.3); sp.set_scale_factor(2.5)
+    n = sp.process(x[:2 * block], 2, block, contiguous=True)
+    worst = 0.0
+    for i in range(n):
+        pts, ce, fl = sp.fetch(i)
+        wp, wce, wfl, _ = cpp.process(x[i * 2 * F:(i + 1) * 2 * F], 0, fs)
+        worst = max(worst, rel_err(pts, wp))
+        assert abs(ce - wce) <= TOL * abs(wce) and abs(fl - wfl) <= TOL * abs(wce), i
+    print("headline spectrum, rate 0.3, scale 2.5: %d frames, worst points %.3g" % (n, worst))
+    assert worst < TOL
+    sp.close(); cpp.close()
 
 
 def test_spectrum_size_that_is_not_a_power_of_two_contiguous_batches(ctx):
