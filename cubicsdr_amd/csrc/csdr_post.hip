@@ -118,8 +118,11 @@ static chan_p2_kernel_t chan_p2_kernel(const ChanGeom &g) {
 #undef CSDR_P2_CASE
 }
 typedef void (*chanfft_kernel_t)(const float2 *, const float2 *, float2 *, const float *, const float2 *, const int *, const int *, ChanFftGeom, int64_t,
-                                 float2 *, int64_t, d2 *, double);
-static chanfft_kernel_t chanfft_kernel(const ChanFftGeom &g) { return g.wide_odd ? chan_analyze_fft<true> : chan_analyze_fft<false>; }
+                                 float2 *, int64_t, d2 *, double, const float2 *);
+static chanfft_kernel_t chanfft_kernel(const ChanFftGeom &g) {
+    if (g.os2) return g.wide_odd ? chan_analyze_fft<true, true> : chan_analyze_fft<false, true>;
+    return g.wide_odd ? chan_analyze_fft<true, false> : chan_analyze_fft<false, false>;
+}
 static chan_kernel_t chan_kernel(const ChanGeom &g) {
     if (g.oddA) {
         if (g.hop != g.M) return g.stage_in ? chan_analyze<1, 1, 1, 1> : g.taps_lds ? chan_analyze<0, 1, 1, 1> : chan_analyze<0, 0, 1, 1>;
@@ -179,8 +182,9 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
         // every channel count that is not 2 * odd and factors over the small radices takes the FFT kernel (kernels_chanfft.hpp);
         // CSDR_CHAN_FFT=0 keeps the two-factor direct-DFT kernel (A/B measurements, bit-for-bit routing tests)
         std::vector<int> fperm;
-        p->use_fft = mode == CSDR_POST_PFBCH && !g.p2 && lab_int("CSDR_CHAN_FFT", 1) != 0 &&
-                     chanfft_plan(M, (size_t)p->ctx->lds_per_cu, lab_int("CSDR_CHANFFT_TF", 0), lab_int("CSDR_CHANFFT_THREADS", 0), p->fgeom, fperm);
+        // (firpfbch2 too, since round 5: the oversampled hop is two interleaved lattices of frames in the same kernel, M % 4 == 0)
+        p->use_fft = (mode == CSDR_POST_PFBCH || mode == CSDR_POST_PFBCH2) && !g.p2 && lab_int("CSDR_CHAN_FFT", 1) != 0 &&
+                     chanfft_plan(M, (size_t)p->ctx->lds_per_cu, lab_int("CSDR_CHANFFT_TF", 0), lab_int("CSDR_CHANFFT_THREADS", 0), p->fgeom, fperm, mode == CSDR_POST_PFBCH2);
         // prototype taps transposed to [n][c]: tapsT[n M + c] multiplies x[(t - n) M + c]
         std::vector<float> taps = mode == CSDR_POST_PFBCH2 ? design::channelizer2_taps((unsigned)M, 4, 60.0f)      // initPFBCH2 :463
                                                            : design::channelizer_taps((unsigned)M, 4, 60.0f);      // initPFBCH :406
@@ -361,7 +365,8 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
             const chanfft_kernel_t kf = chanfft_kernel(fg);
             const int wgs = std::min(ntiles, std::max(1, c->wg_slots(kf, fg.threads, lds) * lab_int("CSDR_CHANFFT_PCT", 100) / 100));
             CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, kf, dim3(wgs), dim3(fg.threads), lds, x, hist, hist_new, p->taps.p,
-                        p->twM.p, p->perm.p, p->active.p, fg, n_frames, out, p->chan_stride, fused_ends ? p->tile_end.p : (d2 *)nullptr, p->dc_c);
+                        p->twM.p, p->perm.p, p->active.p, fg, n_frames, out, p->chan_stride, fused_ends ? p->tile_end.p : (d2 *)nullptr, p->dc_c,
+                        p->mode == CSDR_POST_PFBCH2 ? p->post2.p : (const float2 *)nullptr);
         } else if (g.p2) {
             // persistent workgroups: as many as are resident at once, each walks over tiles blockIdx.x, + gridDim.x, ...
             const chan_p2_kernel_t k2 = chan_p2_kernel(g);

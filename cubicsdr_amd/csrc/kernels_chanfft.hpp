@@ -44,18 +44,20 @@ struct ChanFftGeom {
     unsigned magic_half;                  // floor(2^32 / (M / 2)) + 1 (M > 2)
     int xcd;                              // 1: workgroups of one XCD (blockIdx.x % 8) take CONSECUTIVE tiles (grid a multiple of 8)
     int wide_odd;                         // 1: a radix of 17 / 19 / 23 is in the plan: the kernel instance that carries those butterflies
+    int os2;                              // 1: firpfbch2 -- frames hop by M / 2 (two interleaved lattices of frames), outputs times the post factors
 };
 
 __host__ __device__ inline size_t chanfft_lds_bytes(const ChanFftGeom &g) {
-    return ((size_t)g.M * g.TFs + g.M + g.TF) * sizeof(float2) + (size_t)g.M * sizeof(int);
+    return ((size_t)g.M * g.TFs + g.M + g.TF + (g.os2 ? g.M : 0)) * sizeof(float2) + (size_t)g.M * sizeof(int);      // (oversampled: + the M post factors)
 }
 
 // plan for M channels: radices (odd ones first, then the powers of two from the widest), tile size, workgroup size.
 // Returns false when M has a prime factor this kernel has no butterfly for (chan_analyze takes those).
 // (force_tf / force_threads: measurement overrides, 0 = automatic)
-__host__ inline bool chanfft_plan(int M, size_t lds_limit, int force_tf, int force_threads, ChanFftGeom &g, std::vector<int> &perm) {
+__host__ inline bool chanfft_plan(int M, size_t lds_limit, int force_tf, int force_threads, ChanFftGeom &g, std::vector<int> &perm, bool os2 = false) {
     memset(&g, 0, sizeof g);
-    g.M = M;
+    g.M = M; g.os2 = os2 ? 1 : 0;
+    if (os2 && (M & 3)) return false;             // the half-frame offset M / 2 of the second lattice must keep the column pairs 16-byte aligned
     if (M < 2 || (M & 1) || M > 65536) return false;
     std::vector<int> rad;
     int m = M, e2 = 0, e3 = 0;
@@ -84,10 +86,11 @@ __host__ inline bool chanfft_plan(int M, size_t lds_limit, int force_tf, int for
     const int target = M >= 256 ? 16384 : 5120;
     int tf = 16;
     while (tf < 256 && 141 * tf * M <= 100 * target) tf <<= 1;    // the power of two nearest target / M (on a log scale)
-    while (tf > kCfSeg && !fits(tf)) tf >>= 1;
+    while (tf > (os2 ? 2 * kCfSeg : kCfSeg) && !fits(tf)) tf >>= 1;      // (oversampled: eight frames of EACH lattice per tile at least)
     if (force_tf >= kCfSeg && !(force_tf & (force_tf - 1)) && fits(force_tf)) tf = force_tf;
     if (!fits(tf)) return false;
     g.lgTF = 0; while ((1 << g.lgTF) < tf) ++g.lgTF;
+    if (os2 && tf < 2 * kCfSeg) return false;
     const int fir_items = (M / 2) * (tf / kCfSeg);
     g.threads = 256;
     while (g.threads < kCfMaxThreads && g.threads < fir_items) g.threads <<= 1;
@@ -239,14 +242,26 @@ __device__ __forceinline__ void cf_pass_item(float2 *px, int pitch, const float2
     for (int r = 1; r < R; ++r) px[(size_t)r * pitch] = cmul(v[r], w[r]);
 }
 // one butterfly of the last pass (span 1): results go to their channel rows
-template <int R>
+// (OS2, the oversampled bank: s_pa holds (row << 1) | (channel is odd) -- -1 stays -1 --, s_post the post factor W_M^k / M of firpfbch2 of the channel at
+//  each position; odd channels change sign in the frames of odd parity, design::channelizer2_post)
+template <int R, bool OS2 = false>
 __device__ __forceinline__ void cf_last_item(const float2 *px, int pitch, const int *s_pa, float2 *s_dc /* non-null: this butterfly holds channel 0 (position 0) and its tile values are wanted */,
-                                             int t, bool live, float2 *__restrict__ o /* out + f0 + t */, int64_t out_stride) {
+                                             int t, bool live, float2 *__restrict__ o /* out + f0 + t */, int64_t out_stride, const float2 *s_post = nullptr) {
     float2 v[R];
     int k[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) { v[q] = px[(size_t)q * pitch]; k[q] = s_pa[q]; }
     CfDft<R>::run(v);
+    if constexpr (OS2) {
+        const bool odd_frame = (t & 1) != 0;                       // tiles start on even frames
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float2 w = s_post[r];
+            if (odd_frame && (k[r] & 1)) w = make_float2(-w.x, -w.y);
+            v[r] = cmul(v[r], w);
+            k[r] >>= 1;                                            // (-1 stays -1)
+        }
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         if (r == 0 && s_dc) s_dc[t] = v[0];
@@ -273,7 +288,29 @@ __device__ __forceinline__ void cf_load_window(const float2 *__restrict__ x, con
         }
     }
 }
+// the same for the oversampled bank (firpfbch2): frames of parity `par` live on a lattice of rows of M samples whose row r starts at sample
+// r M - (par ? 0 : M / 2); the eight frames u0 .. u0 + 7 of that lattice reach rows u0 - 7 .. u0 + 7.  Samples before the batch come from the
+// carried history (H = 7.5 M of them), samples past its end are zero.
+__device__ __forceinline__ void cf_load_window_os2(const float2 *__restrict__ x, const float2 *__restrict__ hist, int M, int half, int64_t n_samples,
+                                                   int64_t u0, int par, bool inside, int cp, float4 (&win)[kCfSeg + kChanTaps - 1]) {
+    const int64_t s0 = (u0 - (kChanTaps - 1)) * M - (par ? 0 : half) + 2 * cp;       // sample index of win[0]'s first value
+    if (inside) {
+        const float4 *src = reinterpret_cast<const float4 *>(x + s0);                 // (M % 4 == 0: 16-byte aligned)
+#pragma unroll
+        for (int j = 0; j < kCfSeg + kChanTaps - 1; ++j) win[j] = src[(size_t)j * half];
+    } else {
+        const int64_t H = (int64_t)kChanTaps * M - half;
+#pragma unroll
+        for (int j = 0; j < kCfSeg + kChanTaps - 1; ++j) {
+            const int64_t si = s0 + (int64_t)j * M;
+            win[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (si + 1 < n_samples && si >= -H) win[j] = *reinterpret_cast<const float4 *>(si >= 0 ? x + si : hist + (si + H));      // (a pair never straddles the boundary: si and H are even)
+        }
+    }
+}
 // eight frames of the two columns of a pair from the window; each row of X receives 64 contiguous bytes
+// (STRIDE2: the eight frames are every other frame of the tile -- one lattice of the oversampled bank: 8-byte stores two frames apart)
+template <bool STRIDE2 = false>
 __device__ __forceinline__ void cf_fir(const float4 (&win)[kCfSeg + kChanTaps - 1], const float *__restrict__ tapsT, int M, int cp, float4 *d0, float4 *d1) {
     float2 h[kChanTaps];
 #pragma unroll
@@ -290,12 +327,17 @@ __device__ __forceinline__ void cf_fir(const float4 (&win)[kCfSeg + kChanTaps - 
                 b[u].x = fmaf(h[n].y, v.z, b[u].x); b[u].y = fmaf(h[n].y, v.w, b[u].y);
             }
         }
-        d0[tt >> 1] = make_float4(a[0].x, a[0].y, a[1].x, a[1].y);
-        d1[tt >> 1] = make_float4(b[0].x, b[0].y, b[1].x, b[1].y);
+        if (STRIDE2) {
+            float2 *e0 = reinterpret_cast<float2 *>(d0), *e1 = reinterpret_cast<float2 *>(d1);
+            e0[2 * tt] = a[0]; e0[2 * tt + 2] = a[1]; e1[2 * tt] = b[0]; e1[2 * tt + 2] = b[1];
+        } else {
+            d0[tt >> 1] = make_float4(a[0].x, a[0].y, a[1].x, a[1].y);
+            d1[tt >> 1] = make_float4(b[0].x, b[0].y, b[1].x, b[1].y);
+        }
     }
 }
 
-template <bool WIDE>
+template <bool WIDE, bool OS2 = false>
 CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
     const float2 *__restrict__ x,        // batch input, n_frames * M samples
     const float2 *__restrict__ hist,     // 7 * M samples preceding x
@@ -306,15 +348,23 @@ CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
     const int *__restrict__ active,      // [M] output row of channel k + 1; 0: not stored
     ChanFftGeom g, int64_t n_frames,
     float2 *__restrict__ out, int64_t out_stride,
-    d2 *__restrict__ dc_ends, double dc_c /* DC blocker of channel 0: end value of each tile's recurrence (zero entering state) */) {
+    d2 *__restrict__ dc_ends, double dc_c /* DC blocker of channel 0: end value of each tile's recurrence (zero entering state) */,
+    const float2 *__restrict__ post /* OS2 (firpfbch2): [M] output factors W_M^k / M of the even frames; odd channels change sign in odd frames */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = g.M, TF = g.TF, TFs = g.TFs;
     float2 *s_x = reinterpret_cast<float2 *>(smem);                  // X[c][t], pitch TFs
     float2 *s_tw = s_x + (size_t)M * TFs;                            // W_M^i
     float2 *s_dc = s_tw + M;                                         // channel 0 of the tile
-    int *s_pa = reinterpret_cast<int *>(s_dc + TF);                  // position -> output row of its channel (the channel itself unless the rows are packed), or -1 when it has no consumer
+    float2 *s_post = s_dc + TF;                                      // OS2: post factor of the channel at each position
+    int *s_pa = reinterpret_cast<int *>(s_post + (OS2 ? M : 0));     // position -> output row of its channel (the channel itself unless the rows are packed), or -1 when it has no consumer
     const int tid = threadIdx.x, nthr = blockDim.x;
-    for (int i = tid; i < M; i += nthr) { s_tw[i] = twM[i]; s_pa[i] = active[perm[i]] - 1; }          // active[k] = output row of channel k + 1, 0 = not stored
+    for (int i = tid; i < M; i += nthr) {
+        const int ch = perm[i];
+        const int row = active[ch] - 1;                              // active[k] = output row of channel k + 1, 0 = not stored
+        s_tw[i] = twM[i];
+        s_pa[i] = !OS2 ? row : (row < 0 ? -1 : ((row << 1) | (ch & 1)));      // (oversampled: the channel's parity rides along, cf_last_item)
+        if (OS2) s_post[i] = post[ch];
+    }
 
     const int64_t ntiles = (n_frames + TF - 1) >> g.lgTF;
     const int half = M >> 1, nfir = half * (TF / kCfSeg);
@@ -327,7 +377,7 @@ CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
         const int64_t f0 = tile << g.lgTF;
         const int nf = (int)min((int64_t)TF, n_frames - f0);
         // ---- FIR: item = (column pair cp, segment of 8 frames)
-        {
+        if constexpr (!OS2) {
             const bool inside = f0 >= kChanTaps - 1 && f0 + TF <= n_frames;      // (tile-uniform) every row any item of the tile reaches lies in x
             for (int it = tid; it < nfir; it += nthr) {
                 const int seg = (int)cf_div((unsigned)it, half, g.magic_half), cp = it - seg * half;
@@ -336,10 +386,23 @@ CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
                 cf_fir(win, tapsT, M, cp, reinterpret_cast<float4 *>(s_x + (size_t)(2 * cp) * TFs + seg * kCfSeg),
                        reinterpret_cast<float4 *>(s_x + (size_t)(2 * cp + 1) * TFs + seg * kCfSeg));
             }
+        } else {
+            // oversampled: frame f0 + t = frame u = (f0 + t) >> 1 of the lattice of its parity; a segment = eight frames of ONE lattice: tile positions
+            // t = 16 useg + par, + 2, ... (segment index = 2 useg + par)
+            const int64_t n_samples = n_frames * half;
+            const bool inside = (f0 >> 1) >= kChanTaps && f0 + TF <= n_frames;   // (tile-uniform) row u - 7 of the lattice that starts M / 2 early lies in x
+            for (int it = tid; it < nfir; it += nthr) {
+                const int seg = (int)cf_div((unsigned)it, half, g.magic_half), cp = it - seg * half;
+                const int par = seg & 1, useg = seg >> 1;
+                float4 win[kCfSeg + kChanTaps - 1];
+                cf_load_window_os2(x, hist, M, half, n_samples, (f0 >> 1) + (int64_t)useg * kCfSeg, par, inside, cp, win);
+                cf_fir<true>(win, tapsT, M, cp, reinterpret_cast<float4 *>(s_x + (size_t)(2 * cp) * TFs + 2 * useg * kCfSeg + par),
+                             reinterpret_cast<float4 *>(s_x + (size_t)(2 * cp + 1) * TFs + 2 * useg * kCfSeg + par));
+            }
         }
         // the workgroup that owns the last tile also writes the new input history (the launch runs even with no consumers)
         if (tile == ntiles - 1) {
-            const int64_t n = n_frames * M, H = (int64_t)(kChanTaps - 1) * M;
+            const int64_t n = n_frames * (OS2 ? half : M), H = (int64_t)kChanTaps * M - (OS2 ? half : M);
             for (int64_t j = tid; j < H; j += nthr) {
                 const int64_t gsrc = n - H + j;
                 hist_new[j] = gsrc >= 0 ? x[gsrc] : hist[gsrc + H];
@@ -380,19 +443,19 @@ CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
                     const int *pa = s_pa + pos0;
                     const bool live = t < nf;
                     switch (R) {
-                        case 2: cf_last_item<2>(px, pitch, pa, dcp, t, live, o, out_stride); break;
-                        case 3: cf_last_item<3>(px, pitch, pa, dcp, t, live, o, out_stride); break;
-                        case 4: cf_last_item<4>(px, pitch, pa, dcp, t, live, o, out_stride); break;
-                        case 5: cf_last_item<5>(px, pitch, pa, dcp, t, live, o, out_stride); break;
-                        case 7: cf_last_item<7>(px, pitch, pa, dcp, t, live, o, out_stride); break;
-                        case 8: cf_last_item<8>(px, pitch, pa, dcp, t, live, o, out_stride); break;
-                        case 9: cf_last_item<9>(px, pitch, pa, dcp, t, live, o, out_stride); break;
-                        case 11: cf_last_item<11>(px, pitch, pa, dcp, t, live, o, out_stride); break;
-                        case 13: cf_last_item<13>(px, pitch, pa, dcp, t, live, o, out_stride); break;
-                        case 17: if constexpr (WIDE) cf_last_item<17>(px, pitch, pa, dcp, t, live, o, out_stride); break;
-                        case 19: if constexpr (WIDE) cf_last_item<19>(px, pitch, pa, dcp, t, live, o, out_stride); break;
-                        case 23: if constexpr (WIDE) cf_last_item<23>(px, pitch, pa, dcp, t, live, o, out_stride); break;
-                        default: cf_last_item<16>(px, pitch, pa, dcp, t, live, o, out_stride); break;
+                        case 2: cf_last_item<2, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
+                        case 3: cf_last_item<3, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
+                        case 4: cf_last_item<4, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
+                        case 5: cf_last_item<5, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
+                        case 7: cf_last_item<7, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
+                        case 8: cf_last_item<8, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
+                        case 9: cf_last_item<9, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
+                        case 11: cf_last_item<11, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
+                        case 13: cf_last_item<13, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
+                        case 17: if constexpr (WIDE) cf_last_item<17, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
+                        case 19: if constexpr (WIDE) cf_last_item<19, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
+                        case 23: if constexpr (WIDE) cf_last_item<23, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
+                        default: cf_last_item<16, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
                     }
                 }
             }

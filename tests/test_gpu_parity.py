@@ -51,7 +51,11 @@ def test_channelizer_matches_firpfbch(ctx, fs, M, block):
 
 
 @pytest.mark.parametrize("fs,M,block", [(2400000, 4, 40000), (10000000, 20, 166680), (3000000, 6, 50004), (61440000, 122, 102480),
-                                         (100000000, 1024, 65536), (1000000, 2, 16668)])
+                                         (100000000, 1024, 65536), (1000000, 2, 16668),
+                                         # round 5: the oversampled hop inside the FFT channelizer (M % 4 == 0 and a 16-frame tile fits): whole and ragged tiles, one to
+                                         # three passes, a wide-odd factor, blocks shorter than a tile
+                                         (4000000, 8, 8 * 517), (20000000, 40, 40 * 301), (100000000, 200, 200 * 77), (128000000, 256, 256 * 53),
+                                         (34000000, 68, 68 * 45), (56000000, 112, 112 * 5)])
 def test_channelizer2_matches_firpfbch2(ctx, fs, M, block):
     """SDRPostPFBCH2 (runPFBCH2, SDRPostThread.cpp:472-512): firpfbch2 hands out M samples per M/2 inputs, every channel at
     twice the channel spacing; M/2 odd (6, 122) starts every other frame at an odd sample offset; M = 1024 takes the
@@ -62,7 +66,8 @@ def test_channelizer2_matches_firpfbch2(ctx, fs, M, block):
     x = [synth_iq(block, fs, center, [("NBFM", center + 123456)], seed=41 + b, t0=b * block) for b in range(3)]
     ref = RefSDRPost(_backend(), fs, M, oversampled=True)
     post = SDRPost(ctx, fs, M, block, max_blocks=1, oversampled=True)
-    chans = range(M + 1) if M <= 122 else [0, 1, 2, 511, 512, 513, 1023, 1024]
+    assert post.kernel_name == ("chan_analyze_fft" if M % 4 == 0 and M < 1024 else "chan_analyze"), post.kernel_name
+    chans = range(M + 1) if M <= 122 else sorted({c for c in (0, 1, 2, M // 2 - 1, M // 2, M // 2 + 1, M - 1, M, 77, 511, 512, 513, 1023, 1024) if c <= M})
     want_all = {ch: [] for ch in chans}
     for b in range(3):
         ref.run_block(x[b], center)
