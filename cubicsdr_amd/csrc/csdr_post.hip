@@ -121,7 +121,13 @@ typedef void (*chanfft_kernel_t)(const float2 *, const float2 *, float2 *, const
                                  float2 *, int64_t, d2 *, double, const float2 *);
 static chanfft_kernel_t chanfft_kernel(const ChanFftGeom &g) {
     if (g.os2) return g.wide_odd ? chan_analyze_fft<true, true> : chan_analyze_fft<false, true>;
-    return g.wide_odd ? chan_analyze_fft<true, false> : chan_analyze_fft<false, false>;
+    if (g.wide_odd) return chan_analyze_fft<true, false>;
+    switch (lab_int("CSDR_CHANFFT_PLAN", 1) ? cf_plan_of(g) : 0) {      // the BASELINE channel counts have an instance of their own (only their radices: fewer registers)
+        case 1: return chan_analyze_fft<false, false, 1>;
+        case 2: return chan_analyze_fft<false, false, 2>;
+        case 3: return chan_analyze_fft<false, false, 3>;
+        default: return chan_analyze_fft<false, false, 0>;
+    }
 }
 static chan_kernel_t chan_kernel(const ChanGeom &g) {
     if (g.oddA) {

@@ -337,7 +337,33 @@ __device__ __forceinline__ void cf_fir(const float4 (&win)[kCfSeg + kChanTaps - 
     }
 }
 
-template <bool WIDE, bool OS2 = false>
+// which radices an instance of the kernel carries: PLAN 0 = every small radix (+ 17 / 19 / 23 when WIDE); 1 = {16, 8} (M = 1024 = 16 * 8 * 8: BASELINE
+// config 4), 2 = {5, 8} (M = 200 = 5 * 5 * 8: config 5), 3 = {5, 4} (M = 20: config 2)
+__host__ __device__ constexpr bool cf_plan_has(int plan, int R, bool wide) {
+    return plan == 1 ? (R == 16 || R == 8) : plan == 2 ? (R == 5 || R == 8) : plan == 3 ? (R == 5 || R == 4) : (R < 17 || wide);
+}
+__host__ inline int cf_plan_of(const ChanFftGeom &g) {
+    if (g.os2 || g.wide_odd) return 0;
+    return g.M == 1024 ? 1 : g.M == 200 ? 2 : g.M == 20 ? 3 : 0;
+}
+// one pass over the tile: R is a compile-time constant of the call
+template <int R, bool LAST, bool OS2>
+__device__ __forceinline__ void cf_run_pass(const ChanFftGeom &g, int p, float2 *s_x, const float2 *s_tw, const int *s_pa, float2 *s_dc, const float2 *s_post,
+                                            int tid, int nthr, int nf, float2 *__restrict__ out_f0, int64_t out_stride) {
+    const int TF = g.TF, TFs = g.TFs, s = g.span[p], items = (g.M / R) << g.lgTF, pitch = s * TFs;
+    for (int it = tid; it < items; it += nthr) {
+        const int t = it & (TF - 1);
+        const unsigned bf = (unsigned)it >> g.lgTF;
+        const unsigned b = cf_div(bf, s, g.magic_span[p]);
+        const int j = (int)(bf - b * (unsigned)s), pos0 = (int)b * R * s + j;
+        float2 *px = s_x + (size_t)pos0 * TFs + t;
+        if constexpr (!LAST) cf_pass_item<R>(px, pitch, s_tw, j * g.twstep[p]);
+        else cf_last_item<R, OS2>(px, pitch, s_pa + pos0, (s_dc && pos0 == 0) ? s_dc : nullptr /* position 0 is channel 0 in every digit order */, t, t < nf,
+                                  out_f0 + t, out_stride, s_post + pos0);
+    }
+}
+
+template <bool WIDE, bool OS2 = false, int PLAN = 0>
 CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
     const float2 *__restrict__ x,        // batch input, n_frames * M samples
     const float2 *__restrict__ hist,     // 7 * M samples preceding x
@@ -410,55 +436,24 @@ CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
         }
         lds_barrier();
 
-        // ---- FFT passes: item = (butterfly bf, frame t), lanes along t
+        // ---- FFT passes: item = (butterfly bf, frame t), lanes along t.  The radix is a property of the PASS: one dispatch per pass, the item loop
+        // inside it has a compile-time radix (and an instance built for a plan -- PLAN != 0 -- carries only its own radices: registers sized by the plan)
         for (int p = 0; p < g.npass; ++p) {
-            const int R = g.radix[p], s = g.span[p], items = (M / R) << g.lgTF, pitch = s * TFs;
             const bool lastp = p == g.npass - 1;
-            for (int it = tid; it < items; it += nthr) {
-                const int t = it & (TF - 1);
-                const unsigned bf = (unsigned)it >> g.lgTF;
-                const unsigned b = cf_div(bf, s, g.magic_span[p]);
-                const int j = (int)(bf - b * (unsigned)s), pos0 = (int)b * R * s + j;
-                float2 *px = s_x + (size_t)pos0 * TFs + t;
-                if (!lastp) {
-                    const int jj = j * g.twstep[p];
-                    switch (R) {
-                        case 2: cf_pass_item<2>(px, pitch, s_tw, jj); break;
-                        case 3: cf_pass_item<3>(px, pitch, s_tw, jj); break;
-                        case 4: cf_pass_item<4>(px, pitch, s_tw, jj); break;
-                        case 5: cf_pass_item<5>(px, pitch, s_tw, jj); break;
-                        case 7: cf_pass_item<7>(px, pitch, s_tw, jj); break;
-                        case 8: cf_pass_item<8>(px, pitch, s_tw, jj); break;
-                        case 9: cf_pass_item<9>(px, pitch, s_tw, jj); break;
-                        case 11: cf_pass_item<11>(px, pitch, s_tw, jj); break;
-                        case 13: cf_pass_item<13>(px, pitch, s_tw, jj); break;
-                        case 17: if constexpr (WIDE) cf_pass_item<17>(px, pitch, s_tw, jj); break;
-                        case 19: if constexpr (WIDE) cf_pass_item<19>(px, pitch, s_tw, jj); break;
-                        case 23: if constexpr (WIDE) cf_pass_item<23>(px, pitch, s_tw, jj); break;
-                        default: cf_pass_item<16>(px, pitch, s_tw, jj); break;
-                    }
-                } else {
-                    float2 *o = out + f0 + t;
-                    float2 *dcp = (dc_ends && pos0 == 0) ? s_dc : nullptr;          // position 0 is channel 0 in every digit order
-                    const int *pa = s_pa + pos0;
-                    const bool live = t < nf;
-                    switch (R) {
-                        case 2: cf_last_item<2, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
-                        case 3: cf_last_item<3, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
-                        case 4: cf_last_item<4, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
-                        case 5: cf_last_item<5, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
-                        case 7: cf_last_item<7, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
-                        case 8: cf_last_item<8, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
-                        case 9: cf_last_item<9, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
-                        case 11: cf_last_item<11, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
-                        case 13: cf_last_item<13, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
-                        case 17: if constexpr (WIDE) cf_last_item<17, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
-                        case 19: if constexpr (WIDE) cf_last_item<19, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
-                        case 23: if constexpr (WIDE) cf_last_item<23, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
-                        default: cf_last_item<16, OS2>(px, pitch, pa, dcp, t, live, o, out_stride, s_post + pos0); break;
-                    }
-                }
+            float2 *dcs = dc_ends ? s_dc : nullptr;
+#define CSDR_CF_CASE(R_)                                                                                                                         \
+            case R_:                                                                                                                             \
+                if constexpr (cf_plan_has(PLAN, R_, WIDE)) {                                                                                     \
+                    if (lastp) cf_run_pass<R_, true, OS2>(g, p, s_x, s_tw, s_pa, dcs, s_post, tid, nthr, nf, out + f0, out_stride);               \
+                    else cf_run_pass<R_, false, OS2>(g, p, s_x, s_tw, s_pa, dcs, s_post, tid, nthr, nf, out + f0, out_stride);                    \
+                }                                                                                                                                \
+                break;
+            switch (g.radix[p]) {
+                CSDR_CF_CASE(2) CSDR_CF_CASE(3) CSDR_CF_CASE(4) CSDR_CF_CASE(5) CSDR_CF_CASE(7) CSDR_CF_CASE(8) CSDR_CF_CASE(9) CSDR_CF_CASE(11) CSDR_CF_CASE(13)
+                CSDR_CF_CASE(16) CSDR_CF_CASE(17) CSDR_CF_CASE(19) CSDR_CF_CASE(23)
+                default: break;
             }
+#undef CSDR_CF_CASE
             lds_barrier();
         }
         if (dc_ends) {
