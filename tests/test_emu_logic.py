@@ -207,10 +207,24 @@ def test_emu_channelizer_m_twice_odd(ctx, fs, M, block):
     G.test_channelizer_m_twice_odd(ctx, fs, M, block)
 
 
-@pytest.mark.parametrize("M,frames", [pytest.param(M, fr, marks=() if M in (4, 20, 200, 56, 32) and fr != 3 else full) for M, fr in G.FFT_SIZES])
+@pytest.mark.parametrize("M,frames", [pytest.param(M, fr, marks=() if M in (4, 20, 200, 56, 32, 68) and fr != 3 else full) for M, fr in G.FFT_SIZES])
 def test_emu_channelizer_fft_sizes(ctx, M, frames):
     """the mixed-radix FFT channelizer (kernels_chanfft.hpp): tile walk, FIR windows across the history, every pass's indexing"""
     G.test_channelizer_fft_sizes(ctx, M, frames)
+
+
+@pytest.mark.parametrize("fs,M,block", [(4000000, 8, 8 * 77), pytest.param(20000000, 40, 40 * 61, marks=full), pytest.param(34000000, 68, 68 * 45, marks=full)])
+def test_emu_channelizer2_fft(ctx, fs, M, block):
+    """firpfbch2 inside the FFT channelizer (round 5): the two lattices of frames, windows across the 7.5 M history, post factors and the sign of odd channels"""
+    G.test_channelizer2_matches_firpfbch2(ctx, fs, M, block)
+
+
+@full
+def test_emu_spectrum_headline_fused_chain(ctx):
+    """the two-pass chain of the headline size (kernels_spec3.hpp, round 5): 1024-thread column workgroups walking frames, the row pass's producer /
+    consumer waves over a partial round, a frame carried from call to call -- five frames of 2^17 points over three calls against the reference
+    (seven minutes of host threads: 256 row-pair workgroups of 768, 16 column workgroups of 1024; part of the full suite only)"""
+    G._spectrum_contiguous_batches(ctx, 65536, 61440000, (2, 2, 1))
 
 
 def test_emu_spectrum_contiguous_batches_multi_row(ctx):
