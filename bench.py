@@ -31,7 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-PROFILE_PERIOD = 8        # per-kernel HIP events bracket every 8th launch (bracketing all of them costs ~7 % of the throughput)
+PROFILE_PERIOD = 32       # per-kernel HIP events bracket every 32nd launch of each kernel id: 30 samples per kernel over the default timed region (bracketing every
+                          # launch costs ~7 % of the throughput, every 8th still 4.5 %: an event pair is two barrier packets between back-to-back kernels)
 CENTER = 100_000_000
 AUDIO_RATE = 48_000
 MODEM_BW = {"NBFM": 12_500, "AM": 6_000, "USB": 5_400}
