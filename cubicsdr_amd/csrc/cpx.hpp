@@ -37,6 +37,8 @@ __device__ __forceinline__ cpx cpx_add_ib(cpx a, cpx b) {
     return r;
 }
 __device__ __forceinline__ float cpx_abs(cpx v) { const cpx q = v * v; return __builtin_amdgcn_sqrtf(q.x + q.y); }      // v_sqrt_f32: one ulp (cabs_f, kernels_spec.hpp)
+// acc + s v, both components fused (one v_pk_fma_f32; s may be wave-uniform: a scalar operand): a real tap on a complex / two-stream sample
+__device__ __forceinline__ cpx cpx_fma_s(float s, cpx v, cpx acc) { return __builtin_elementwise_fma(cpx{s, s}, v, acc); }
 #else
 struct cpx { float x, y; };
 static inline cpx cpx_make(float re, float im) { return cpx{re, im}; }
@@ -47,6 +49,7 @@ static inline cpx cpx_mulc(cpx a, float wr, float wi) { return cpx_mul(a, cpx{wr
 static inline cpx cpx_sub_ib(cpx a, cpx b) { return cpx{a.x + b.y, a.y - b.x}; }
 static inline cpx cpx_add_ib(cpx a, cpx b) { return cpx{a.x - b.y, a.y + b.x}; }
 static inline float cpx_abs(cpx v) { return sqrtf(v.x * v.x + v.y * v.y); }
+static inline cpx cpx_fma_s(float s, cpx v, cpx acc) { return cpx{fmaf(s, v.x, acc.x), fmaf(s, v.y, acc.y)}; }
 #endif
 __device__ __forceinline__ cpx cpx_from(float2 v) { return cpx_make(v.x, v.y); }
 __device__ __forceinline__ float2 cpx_to(cpx v) { return make_float2(v.x, v.y); }

@@ -568,7 +568,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     const dim3 grid(std::max(1, n_audio_run), NB);
     // one wave per (demodulator, block): the block's few hundred samples pass through five barrier-separated stages, and a
     // single wave crosses a barrier without waiting for anyone (measured 30 us against 41 us with four waves, 64 x 64 blocks)
-    const int audio_threads = 64;
+    const int audio_threads = kAudioThreads;
     const float2 *chan_out = post_buf(post, pk);
     const int *grp_d = lists_d + 2 * (size_t)b->max_demods;
     if (grp_n[0] > 0)
@@ -612,11 +612,12 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     if (int rc = c->signal(b->ev_fe_done[bpar], LANE_FE, LANE_AUDIO)) return rc;
     // lane AUDIO: modem + audio kernels of this batch
     if (int rc = c->wait(b->ev_fe_done[bpar], LANE_FE, LANE_AUDIO)) return rc;
-    if (n_ag > 0)     // freqdem modems need no block-wide pre-pass: only the auto-gain modems run the modem kernel
-        CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, demod_modem, dim3(n_ag, NB), dim3(audio_threads) /* one wave per block, like the audio kernel */, modem_lds, b->cfgs.p, dyns_d, lists_d + b->max_demods,
+    // freqdem modems need no block-wide pre-pass: only the auto-gain modems run the modem kernel (grid: blocks first, see the kernel)
+    if (n_ag > 0)
+        CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, demod_modem, dim3(NB, n_ag), dim3(audio_threads) /* one wave per block, like the audio kernel */, modem_lds, b->cfgs.p, dyns_d, lists_d + b->max_demods,
                     plans_d, NB, cap_stream, b->mconsts.p, c->sintab.p, b->arms.p, cap_cw);
     if (n_ag > 0)     // the auto-gain recurrence over the blocks, once per demodulator
-        CSDR_LAUNCH(c, LANE_AUDIO, KID_GAIN_SCAN, demod_gain_scan, dim3(n_ag), dim3(64), (size_t)NB * sizeof(float), b->cfgs.p, dyns_d, lists_d + b->max_demods, plans_d, NB);
+        CSDR_LAUNCH(c, LANE_AUDIO, KID_GAIN_SCAN, demod_gain_scan, dim3(n_ag), dim3(64), (size_t)(2 * NB + 1) * sizeof(float), b->cfgs.p, dyns_d, lists_d + b->max_demods, plans_d, NB);
     const int *fms_d = lists_d + b->max_demods + fms_off;
     if (n_fms > 0) {  // FM stereo, ahead of the audio stage: Hilbert r2c of the discriminator output, the pilot loop, the 38 kHz down-mix
         CSDR_LAUNCH(c, LANE_AUDIO, KID_FMS, fms_pre, dim3(n_fms, NB), dim3(64), fms_pre_lds, b->cfgs.p, dyns_d, fms_d, plans_d, NB, b->mconsts.p);

@@ -15,6 +15,7 @@
 // All LDS is dynamic (`smem`).
 #pragma once
 #include "common.hpp"
+#include "cpx.hpp"
 
 namespace csdr {
 
@@ -951,6 +952,7 @@ CSDR_KERNEL_BANK __launch_bounds__(kFeThreads) void demod_frontend_interp(
 //   USB/LSB : fs/4 shift, 3 biquads, shift back, Hilbert c2r, keep upper/lower    (ModemUSB.cpp:54-61)
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kModemThreads = 256;
+constexpr int kAudioThreads = 64;          // demod_modem / demod_audio_interp: ONE wave per (demodulator, block) -- the barriers between their stages are wave-local
 constexpr int kModemMaxBlockIq = 16384;    // resampled samples of one block one workgroup may have to stage (the real bound is the LDS its kernels need: csdr_bank_execute)
 constexpr int kAmTaps = 51;
 constexpr int kSsbFir = 128;               // taps of the SSB low-pass run as an FIR filter (pole radius <= 0.77: 0.77^128 ~ 3e-15)
@@ -967,28 +969,17 @@ struct ModemConsts {
     float ssb_fir[kSsbFir];                // impulse response of the three sections (iirfilt_crcf_create_lowpass(6, 0.25), ModemUSB.cpp:8)
 };
 
-__device__ inline double block_sum_double(double v, double *lds) {
+// sum / maximum over the ONE wave of a modem / audio workgroup (kAudioThreads): valid in thread 0
+__device__ inline double block_sum_double(double v, double *) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) lds[w] = v;
-    __syncthreads();
-    double r = 0.0;
-    if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += lds[i];
-    __syncthreads();
-    return r;   // valid in thread 0
+    return v;
 }
-__device__ inline float block_max_float(float v, float *lds) {
+__device__ inline float block_max_float(float v, float *) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) lds[w] = v;
-    __syncthreads();
-    float r = lds[0];
-    if (threadIdx.x == 0) for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = fmaxf(r, lds[i]);
-    __syncthreads();
-    return r;   // valid in thread 0
+    return v;
 }
 
-CSDR_KERNEL_BANK __launch_bounds__(kModemThreads) void demod_modem(
+CSDR_KERNEL_BANK __launch_bounds__(kAudioThreads) void demod_modem(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
     const BlockPlan *__restrict__ plans, int NB, int cap_stream, const ModemConsts *__restrict__ mc, const float *__restrict__ sintab,
     const float *__restrict__ arms_all, int cap_cw) {
@@ -998,8 +989,10 @@ CSDR_KERNEL_BANK __launch_bounds__(kModemThreads) void demod_modem(
     double *s_red = reinterpret_cast<double *>(s_b + 3 * cap_stream);   // (CW carves the same memory differently, see below)
     float *s_redf = reinterpret_cast<float *>(s_red + 4);
 
-    const int slot = slot_list[blockIdx.x], b = blockIdx.y, tid = threadIdx.x;
-    const int nthr = blockDim.x;
+    // grid = (blocks, demodulators): the blocks of a demodulator are neighbours in dispatch order (measured on C3, ms per batch: 0.048; demodulators
+    // first 0.060; one XCD per demodulator -- id % 8 -- 0.061).  The audio kernel below is the other way round: 0.105 against 0.125.
+    const int slot = slot_list[blockIdx.y], b = blockIdx.x, tid = threadIdx.x;
+    constexpr int nthr = kAudioThreads;
     const SlotCfg &cfg = cfgs[slot];
     const SlotDyn dyn = dyns[slot];
     const BlockPlan *pl = plans + (size_t)slot * (NB + 1);
@@ -1019,11 +1012,15 @@ CSDR_KERNEL_BANK __launch_bounds__(kModemThreads) void demod_modem(
             s_a[i] = sqrtf(x.x * x.x + x.y * x.y);
         }
         __syncthreads();
-        for (int i = tid; i < n; i += nthr) {
-            float acc = 0.f;
-            for (int t = 0; t < kAmTaps; ++t) acc = fmaf(mc->am_taps[t], s_a[i + halo - t], acc);
-            d[j0 + i] = acc;
-            lmax = fmaxf(lmax, acc);
+        // outputs i and i + 64 of a lane as one pair: a two-address LDS read and one packed multiply-add per tap serve both (the partner past the
+        // block's end reads staged or stale LDS inside the carve -- cap_stream >= n + 127 + 64 -- and is never stored)
+        for (int i = tid; i < n; i += 2 * nthr) {
+            cpx acc = cpx_make(0.f, 0.f);
+#pragma unroll 17
+            for (int t = 0; t < kAmTaps; ++t) acc = cpx_fma_s(mc->am_taps[t], cpx_make(s_a[i + halo - t], s_a[i + nthr + halo - t]), acc);
+            d[j0 + i] = acc.x;
+            lmax = fmaxf(lmax, acc.x);
+            if (i + nthr < n) { d[j0 + i + nthr] = acc.y; lmax = fmaxf(lmax, acc.y); }
         }
     } else if (cfg.modem == CSDR_MODEM_DSB) {
         // ModemDSB::demodulate -> ampmodem_demodulate, DSB with suppressed carrier (liquid 1.5.0 ampmodem_demod_dsb_pll_costas):
@@ -1150,48 +1147,43 @@ CSDR_KERNEL_BANK __launch_bounds__(kModemThreads) void demod_modem(
         const int hh = 4 * kHilbM;                 // Hilbert span
         const int pre = kSsbWarm + hh;             // samples before j0 that are processed
         const int tot = n + pre;
+        // the two streams (real, imaginary) travel interleaved: one 8-byte LDS read and one packed multiply-add per tap serve both
+        cpx *s_ab = reinterpret_cast<cpx *>(smem), *s_cd = s_ab + cap_stream;
         // 1. shift by fs/4 (oscillator is stepped BEFORE use: theta_j = theta0 + (j+1) * 2^30)
         for (int i = tid; i < tot; i += nthr) {
             const int j = j0 - pre + i;
             const float2 x = iq[j];
             float s, c;
             nco_sincos(sintab, dyn.ssb_theta0 + (uint32_t)(j + 1) * (1u << 30), s, c);
-            float2 v = usb ? make_float2(x.x * c + x.y * s, x.y * c - x.x * s)      // mix down
-                           : make_float2(x.x * c - x.y * s, x.y * c + x.x * s);     // mix up
-            s_a[i] = v.x; s_b[i] = v.y;
+            s_ab[i] = usb ? cpx_make(x.x * c + x.y * s, x.y * c - x.x * s)      // mix down
+                          : cpx_make(x.x * c - x.y * s, x.y * c + x.x * s);     // mix up
         }
         __syncthreads();
         // 2. the three Butterworth sections (iirfilt_crcf_execute, ModemUSB.cpp:57) as their 128-tap impulse response: every
         //    output is an independent dot product (the recursion ran 300 dependent steps on two lanes), real taps on both streams
-        float *s_c = s_b + cap_stream, *s_d = s_c + cap_stream;
         for (int i = kSsbWarm + tid; i < tot; i += nthr) {
-            float ar = 0.f, ai = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < kSsbFir; ++k) {
-                const float gk = mc->ssb_fir[k];
-                ar = fmaf(gk, s_a[i - k], ar); ai = fmaf(gk, s_b[i - k], ai);
-            }
-            s_c[i] = ar; s_d[i] = ai;
+            cpx acc = cpx_make(0.f, 0.f);
+#pragma unroll 32
+            for (int k = 0; k < kSsbFir; ++k) acc = cpx_fma_s(mc->ssb_fir[k], s_ab[i - k], acc);
+            s_cd[i] = acc;
         }
         __syncthreads();
-        s_a = s_c; s_b = s_d;
         // 3. shift back (same oscillator phase), in place
         for (int i = kSsbWarm + tid; i < tot; i += nthr) {
             const int j = j0 - pre + i;
             float s, c;
             nco_sincos(sintab, dyn.ssb_theta0 + (uint32_t)(j + 1) * (1u << 30), s, c);
-            const float xr = s_a[i], xi = s_b[i];
-            float2 v = usb ? make_float2(xr * c - xi * s, xi * c + xr * s) : make_float2(xr * c + xi * s, xi * c - xr * s);
-            s_a[i] = v.x; s_b[i] = v.y;
+            const float xr = s_cd[i].x, xi = s_cd[i].y;
+            s_cd[i] = usb ? cpx_make(xr * c - xi * s, xi * c + xr * s) : cpx_make(xr * c + xi * s, xi * c - xr * s);
         }
         __syncthreads();
         // 4. Hilbert c2r: yi = re[k - 2m], yq = sum_{n odd} hq[(n-1)/2] im[k - n]; lower = yi + yq, upper = yi - yq
         for (int i = tid; i < n; i += nthr) {
             const int k = i + pre;
-            const float yi = s_a[k - 2 * kHilbM];
+            const float yi = s_cd[k - 2 * kHilbM].x;
             float yq = 0.f;
 #pragma unroll
-            for (int t = 0; t < 2 * kHilbM; ++t) yq = fmaf(mc->hilb[t], s_b[k - (2 * t + 1)], yq);
+            for (int t = 0; t < 2 * kHilbM; ++t) yq = fmaf(mc->hilb[t], s_cd[k - (2 * t + 1)].y, yq);
             const float v = usb ? (yi - yq) : (yi + yq);
             d[j0 + i] = v;
             lmax = fmaxf(lmax, v);
@@ -1216,24 +1208,30 @@ CSDR_KERNEL_BANK __launch_bounds__(kModemThreads) void demod_modem(
 CSDR_KERNEL_BANK __launch_bounds__(64) void demod_gain_scan(const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
                                                       const BlockPlan *__restrict__ plans, int NB) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *s_max = reinterpret_cast<float *>(smem);             // [NB] block maxima (one coalesced read instead of NB dependent ones)
+    float *s_max = reinterpret_cast<float *>(smem);             // [NB] block maxima, then the MAA per block (coalesced traffic on both sides of the serial walk)
+    int *s_j0 = reinterpret_cast<int *>(s_max + NB);            // [NB + 1] first resampled sample of every block
     const int slot = slot_list[blockIdx.x], tid = threadIdx.x;
     const SlotCfg &cfg = cfgs[slot];
     const SlotDyn dyn = dyns[slot];
     const BlockPlan *pl = plans + (size_t)slot * (NB + 1);
     for (int i = tid; i < NB; i += 64) s_max[i] = cfg.blockmax[i];
+    for (int i = tid; i <= NB; i += 64) s_j0[i] = pl[i].j0;
     __syncthreads();
-    if (tid != 0) return;
     const float *agc_in = cfg.agc + 4 * dyn.hist_parity;
     float ceil_ = agc_in[0], ma = agc_in[1], maa = agc_in[2];
-    for (int bb = 0; bb < NB; ++bb) {
-        if (pl[bb + 1].j0 != pl[bb].j0) {                       // a block without samples never reaches demodulate() (ModemAM.cpp:33-36)
-            ma = ma + (ceil_ - ma) * 0.025f;
-            maa = maa + (ma - maa) * 0.025f;
-            ceil_ = s_max[bb];
+    if (tid == 0)
+        for (int bb = 0; bb < NB; ++bb) {
+            const float mx = s_max[bb];
+            if (s_j0[bb + 1] != s_j0[bb]) {                     // a block without samples never reaches demodulate() (ModemAM.cpp:33-36)
+                ma = ma + (ceil_ - ma) * 0.025f;
+                maa = maa + (ma - maa) * 0.025f;
+                ceil_ = mx;
+            }
+            s_max[bb] = maa;
         }
-        cfg.blockmaa[bb] = maa;
-    }
+    __syncthreads();
+    for (int i = tid; i < NB; i += 64) cfg.blockmaa[i] = s_max[i];
+    if (tid != 0) return;
     float *agc_out = cfg.agc + 4 * (dyn.hist_parity ^ 1);
     agc_out[0] = ceil_; agc_out[1] = ma; agc_out[2] = maa;
 }
@@ -1246,10 +1244,33 @@ CSDR_KERNEL_BANK __launch_bounds__(64) void demod_gain_scan(const SlotCfg *__res
 // workgroup of the last block also carries the stream tails (resampled IQ, scaled demodulator output) to the
 // history regions for the next batch.
 // ------------------------------------------------------------------------------------------------------------
+// one x2 half-band stage of the audio interpolator on a single wave: a thread forms the output PAIR (2p, 2p + 1) relative to the even index at or
+// below the stage's first output: the delayed sample and the filtered one (one lane per output would have half of every wave copy while the other
+// half filters).  M = the stage's m when it is one of the reference's (taps in registers, straight-line); M = 0: any m <= kHbMaxM
+template <int M>
+__device__ __forceinline__ void audio_x2_stage(const float *__restrict__ h, const float *__restrict__ src, float *__restrict__ dst, int qoff, int par0, int nout, int tid,
+                                               int m_any = 0) {
+    constexpr int NT = M ? M : kHbMaxM;
+    const int m = M ? M : m_any;
+    float hs[NT];                                           // the stage's taps, fetched once (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) hs[j] = h[j];
+    for (int p = tid; 2 * p - par0 < nout; p += kAudioThreads) {
+        const int qi = qoff + p, i0 = 2 * p - par0;
+        const float ve = src[qi - m];
+        float vo = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            if (M || j < m) vo = fmaf(hs[j], src[qi - j] + src[qi - (2 * m - 1) + j], vo);
+        if (i0 >= 0) dst[i0] = ve;
+        if (i0 + 1 < nout) dst[i0 + 1] = vo;
+    }
+}
+
 constexpr int kAudioMaxOut = 16384;        // audio samples of one block handled by one workgroup (likewise bounded by the LDS request)
 // dynamic LDS: two ping-pong arrays of `cap_out` floats, `cap_win` staged demodulator samples, 64 bytes of scratch
 
-CSDR_KERNEL_BANK __launch_bounds__(kModemThreads) void demod_audio_interp(
+CSDR_KERNEL_BANK __launch_bounds__(kAudioThreads) void demod_audio_interp(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
     const BlockPlan *__restrict__ plans, int NB, int cap_out, int cap_win, const float *__restrict__ arms_all, int pass) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1259,8 +1280,8 @@ CSDR_KERNEL_BANK __launch_bounds__(kModemThreads) void demod_audio_interp(
     double *s_red = reinterpret_cast<double *>(s_d + cap_win);
     float *s_redf = reinterpret_cast<float *>(s_red + 4);
 
-    const int slot = slot_list[blockIdx.x], b = blockIdx.y, tid = threadIdx.x;
-    const int nthr = blockDim.x;                               // 64 .. kModemThreads (host: csdr_bank_execute)
+    const int slot = slot_list[blockIdx.x], b = blockIdx.y, tid = threadIdx.x;        // grid = (demodulators, blocks)
+    constexpr int nthr = kAudioThreads;
     const SlotCfg &cfg = cfgs[slot];
     const SlotDyn dyn = dyns[slot];
     const BlockPlan *pl = plans + (size_t)slot * (NB + 1);
@@ -1466,21 +1487,13 @@ CSDR_KERNEL_BANK __launch_bounds__(kModemThreads) void demod_audio_interp(
         const int m = au.m_x[s];
         const int64_t olo = lo[s + 1], ohi = hi[s + 1], ilo = lo[s];
         const int nout = (int)(ohi - olo);
-        float hs[kHbMaxM];                                       // the stage's taps, fetched once (wave-uniform)
-#pragma unroll
-        for (int j = 0; j < kHbMaxM; ++j) hs[j] = au.h_x[s][j];
         const int qoff = (int)((olo >> 1) - ilo), par0 = (int)(olo & 1);
-        // a thread forms the output PAIR (2p, 2p + 1) relative to the even index at or below olo: the delayed sample and the filtered one
-        // (one lane per output would have half of every wave copy while the other half filters)
-        for (int p = tid; 2 * p - par0 < nout; p += nthr) {
-            const int qi = qoff + p, i0 = 2 * p - par0;
-            const float ve = src[qi - m];
-            float vo = 0.f;
-#pragma unroll
-            for (int j = 0; j < kHbMaxM; ++j)
-                if (j < m) vo = fmaf(hs[j], src[qi - j] + src[qi - (2 * m - 1) + j], vo);
-            if (i0 >= 0) dst[i0] = ve;
-            if (i0 + 1 < nout) dst[i0 + 1] = vo;
+        // the reference's interpolators are m = 10, 5, 3, 3, ... (msresamp2 at 60 dB): those run with the tap count known to the compiler
+        switch (m) {
+            case 3: audio_x2_stage<3>(au.h_x[s], src, dst, qoff, par0, nout, tid); break;
+            case 5: audio_x2_stage<5>(au.h_x[s], src, dst, qoff, par0, nout, tid); break;
+            case 10: audio_x2_stage<10>(au.h_x[s], src, dst, qoff, par0, nout, tid); break;
+            default: audio_x2_stage<0>(au.h_x[s], src, dst, qoff, par0, nout, tid, m); break;
         }
         __syncthreads();
         float *t = src; src = dst; dst = t;

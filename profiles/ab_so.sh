@@ -1,0 +1,12 @@
+# A/B of whole library builds (measurement helper): bash profiles/ab_so.sh CONFIG lib1.so lib2.so ...   (variants built here, e.g. under _ab/)
+# each variant is copied over cubicsdr_amd/libcsdr_hip.so (newer than the objects: bench.py's build() leaves it alone), twice round-robin
+cfg=$1; shift
+cp cubicsdr_amd/libcsdr_hip.so /tmp/libcsdr_hip_orig.so
+for rep in 1 2; do
+for so in "$@"; do
+cp "$so" cubicsdr_amd/libcsdr_hip.so
+python bench.py --config $cfg --steps 6 --warmup 2 --cpu-seconds 0 --no-latency --no-strong > gpurun_out/bq.json 2> gpurun_out/bq.err; python -c "
+import json; d=json.load(open('gpurun_out/bq.json')); k=d['roofline']['kernels_ms_per_batch']; print('$cfg $so', round(d['value']), {n: round(v,4) for n,v in k.items() if n in ('demod_audio_interp','demod_modem','demod_gain_scan')})"
+done
+done
+cp /tmp/libcsdr_hip_orig.so cubicsdr_amd/libcsdr_hip.so
