@@ -4,9 +4,9 @@ cfg=$1; shift
 cp cubicsdr_amd/libcsdr_hip.so /tmp/libcsdr_hip_orig.so
 for rep in 1 2; do
 for so in "$@"; do
-cp "$so" cubicsdr_amd/libcsdr_hip.so
+cp "$so" cubicsdr_amd/libcsdr_hip.so || exit 1
 python bench.py --config $cfg --steps 6 --warmup 2 --cpu-seconds 0 --no-latency --no-strong > gpurun_out/bq.json 2> gpurun_out/bq.err; python -c "
-import json; d=json.load(open('gpurun_out/bq.json')); k=d['roofline']['kernels_ms_per_batch']; print('$cfg $so', round(d['value']), {n: round(v,4) for n,v in k.items() if n in ('demod_audio_interp','demod_modem','demod_gain_scan')})"
+import json; d=json.load(open('gpurun_out/bq.json')); k=d['roofline']['kernels_ms_per_batch']; print('$cfg $so', round(d['value']), {n: round(v,4) for n,v in k.items() if v > 0.03 or 'demod' in n})"
 done
 done
 cp /tmp/libcsdr_hip_orig.so cubicsdr_amd/libcsdr_hip.so
