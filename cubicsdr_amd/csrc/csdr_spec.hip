@@ -24,6 +24,10 @@ struct csdr_spec {
     DevBuf<float2> tw4096, tw_hi, tw_lo, tmp, carry, stage_in, raw;
     DevBuf<float2> blue_w, blue_B;           // sizes that are not powers of two: chirp w[N] and the transformed chirp filter Bf[L]
     int blue_L = 0;
+    // ... with a convolution longer than 4096 points (fftSize above 1024): the two L-point transforms run as the power-of-two chain of size L
+    bool blue_big = false;
+    SpecGeom gL{};
+    DevBuf<float2> blue_a, blue_b, twL_hi, twL_lo;
     DevBuf<float> mag;                       // [2][max_frames][N]: the FFT lane fills one copy while the averaging lane reads the other
     DevBuf<float> pairsum, first_b, points;
     uint64_t seq = 0;
@@ -109,10 +113,9 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     if (!s) return fail(CSDR_EINVAL, "spec is null");
     if (fft_size < 2) return fail(CSDR_EINVAL, "fft_size %d", fft_size);
     const bool npot = (fft_size & (fft_size - 1)) != 0;
-    if (npot && fft_size > 1024) return fail(CSDR_EUNSUPPORTED, "fft_size %d: sizes that are not powers of two are built up to 1024 (the GUI sets 512 / 1024 / 2048)", fft_size);
     if (max_frames <= 0) return fail(CSDR_EINVAL, "max_frames");
     const int N = 2 * fft_size;                                      // SPECTRUM_VZM 2, SpectrumVisualProcessor.h:11, .cpp:145
-    if (N > (1 << 22)) return fail(CSDR_EUNSUPPORTED, "internal FFT of %d points exceeds 2^22", N);
+    if (N > (1 << 22) || (npot && 2 * (int64_t)N - 1 > (1 << 22))) return fail(CSDR_EUNSUPPORTED, "internal FFT of %d points exceeds 2^22%s", N, npot ? " (the chirp-z convolution of a size that is not a power of two is twice as long)" : "");
     if (int rc = s->ctx->sync_all()) return rc;
     s->ready = false;
     s->seq = 0; s->avg_pending[0] = s->avg_pending[1] = false;
@@ -131,16 +134,22 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
             w[(size_t)n] = {std::cos(a), std::sin(a)};
         }
         for (int m = 0; m < N; ++m) { b[(size_t)m] = {w[(size_t)m].first, -w[(size_t)m].second}; if (m) b[(size_t)(L - m)] = b[(size_t)m]; }
-        // iterative radix-2 transform of b (one-time, L <= 4096)
-        for (int i = 1, j = 0; i < L; ++i) { int bit = L >> 1; for (; j & bit; bit >>= 1) j ^= bit; j ^= bit; if (i < j) std::swap(b[(size_t)i], b[(size_t)j]); }
-        for (int len = 2; len <= L; len <<= 1)
-            for (int i = 0; i < L; i += len)
-                for (int k = 0; k < len / 2; ++k) {
-                    const double a = -2.0 * M_PI * k / len, c = std::cos(a), sn = std::sin(a);
-                    const auto u = b[(size_t)(i + k)], v = b[(size_t)(i + k + len / 2)];
-                    const double vr = v.first * c - v.second * sn, vi = v.first * sn + v.second * c;
-                    b[(size_t)(i + k)] = {u.first + vr, u.second + vi}; b[(size_t)(i + k + len / 2)] = {u.first - vr, u.second - vi};
-                }
+        // iterative radix-2 transform of b in double (one-time; the twiddles from ONE table of L / 2 entries: L reaches 2^22)
+        {
+            std::vector<std::pair<double, double>> tw((size_t)L / 2);
+            for (int k = 0; k < L / 2; ++k) { const double a = -2.0 * M_PI * (double)k / (double)L; tw[(size_t)k] = {std::cos(a), std::sin(a)}; }
+            for (int i = 1, j = 0; i < L; ++i) { int bit = L >> 1; for (; j & bit; bit >>= 1) j ^= bit; j ^= bit; if (i < j) std::swap(b[(size_t)i], b[(size_t)j]); }
+            for (int len = 2; len <= L; len <<= 1) {
+                const int step = L / len;
+                for (int i = 0; i < L; i += len)
+                    for (int k = 0; k < len / 2; ++k) {
+                        const double c = tw[(size_t)k * step].first, sn = tw[(size_t)k * step].second;
+                        const auto u = b[(size_t)(i + k)], v = b[(size_t)(i + k + len / 2)];
+                        const double vr = v.first * c - v.second * sn, vi = v.first * sn + v.second * c;
+                        b[(size_t)(i + k)] = {u.first + vr, u.second + vi}; b[(size_t)(i + k + len / 2)] = {u.first - vr, u.second - vi};
+                    }
+            }
+        }
         std::vector<float2> wf((size_t)N), bf((size_t)L);
         for (int n = 0; n < N; ++n) wf[(size_t)n] = make_float2((float)w[(size_t)n].first, (float)w[(size_t)n].second);
         for (int i = 0; i < L; ++i) bf[(size_t)i] = make_float2((float)b[(size_t)i].first, (float)b[(size_t)i].second);
@@ -148,9 +157,30 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
         if (int rc = s->blue_B.reserve((size_t)L)) return rc;
         CSDR_HIP_TRY(hipMemcpy(s->blue_w.p, wf.data(), wf.size() * sizeof(float2), hipMemcpyHostToDevice));
         CSDR_HIP_TRY(hipMemcpy(s->blue_B.p, bf.data(), bf.size() * sizeof(float2), hipMemcpyHostToDevice));
-        if ((size_t)2 * L * sizeof(float2) > 64 * 1024)
+        s->blue_big = L > kTwTab;                                     // the LDS transforms of spec_fft_bluestein reach 4096 points
+        if (!s->blue_big && (size_t)2 * L * sizeof(float2) > 64 * 1024)
             CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_fft_bluestein, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * L * sizeof(float2))));
-    }
+        if (s->blue_big) {
+            // the L-point transforms as the power-of-two chain of that size (radix passes + 4096-point rows, natural-order complex output)
+            SpecGeom &q = s->gL;
+            q = SpecGeom{};
+            q.N = L; q.F = L / 2; q.N2 = 4096; q.npot = 0;
+            const int R = L / 4096;
+            q.Ra = std::min(R, 32); q.Rb = R / q.Ra;
+            q.lgRa = ilog2(q.Ra); q.lgRb = ilog2(q.Rb);
+            std::vector<float2> lo(1024), hi((size_t)L / 1024);
+            for (int i = 0; i < 1024; i++) { double a = -2.0 * M_PI * i / L; lo[i] = make_float2((float)std::cos(a), (float)std::sin(a)); }
+            for (size_t i = 0; i < hi.size(); i++) { double a = -2.0 * M_PI * (double)(i * 1024) / L; hi[i] = make_float2((float)std::cos(a), (float)std::sin(a)); }
+            if (int rc = s->twL_lo.reserve(1024)) return rc;
+            if (int rc = s->twL_hi.reserve(hi.size())) return rc;
+            CSDR_HIP_TRY(hipMemcpy(s->twL_lo.p, lo.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
+            CSDR_HIP_TRY(hipMemcpy(s->twL_hi.p, hi.data(), hi.size() * sizeof(float2), hipMemcpyHostToDevice));
+            const size_t nfL = (size_t)max_frames * (size_t)L;
+            if (int rc = s->blue_a.reserve(nfL)) return rc;
+            if (int rc = s->blue_b.reserve(nfL)) return rc;
+            if (int rc = s->tmp.reserve(nfL)) return rc;
+        }
+    } else { s->blue_big = false; s->blue_a.release(); s->blue_b.release(); }
     if (N >= 4096 && !npot) {
         g.N2 = 4096;
         const int R = N / 4096;                                       // 1 .. 1024
@@ -183,7 +213,7 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     }
     if (g.Ra > 1 && disp_lds_bytes((g.Ra >> 1) * g.Rb, ilog2(g.Ra) - 1 + ilog2(g.Rb), true) > 64 * 1024)      // the display tiles of 2^21-point frames with peak hold
         CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_display<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)disp_lds_bytes((g.Ra >> 1) * g.Rb, ilog2(g.Ra) - 1 + ilog2(g.Rb), true)));
-    if (g.Ra > 1) if (int rc = s->tmp.reserve(nfN)) return rc;
+    if (g.Ra > 1 && !s->blue_big) if (int rc = s->tmp.reserve(nfN)) return rc;
     if (int rc = s->mag.reserve(2 * nfN)) return rc;
     s->n_avg_tiles = (g.F + kAvgLanes - 1) / kAvgLanes;
     if (int rc = s->ext_w.reserve((size_t)max_frames * s->n_avg_tiles)) return rc;
@@ -246,6 +276,36 @@ static void launch_radix(csdr_ctx *c, int R, const FrameSrc &fs, int L, unsigned
     }
 }
 
+// the power-of-two transform chain of geometry `g` (the spectrum's own size, or the convolution length of a chirp-z transform) over `nf` frames
+static int spec_run_pow2(csdr_spec *s, const SpecGeom &g, const float2 *tw_hi, const float2 *tw_lo, const FrameSrc &fs, int nf, float *mag, float2 *raw) {
+    csdr_ctx *c = s->ctx;
+    if (g.N < 4096) {
+        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_small, dim3(1, nf), dim3(kFftThreads), (size_t)2 * g.N * sizeof(float2), fs, g.N, s->tw4096.p, mag, raw);
+    } else if (g.Ra == 1) {
+        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_rows4096, dim3(1, nf), dim3(kFftThreads), kRowLdsBytes, fs, g, s->tw4096.p, mag, raw);
+    } else if (g.Ra == kC512) {
+        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_COLS, spec_cols512, dim3(g.N / kC512 / kC512Cols, nf), dim3(kFftThreads), kC512Lds, fs, g.N, s->tw4096.p, tw_hi, tw_lo, s->tmp.p);
+        FrameSrc rows{s->tmp.p, nullptr, s->tmp.p + g.N, g.N, 1 << 30};
+        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_rows4096, dim3(g.Ra, nf), dim3(kFftThreads), kRowLdsBytes, rows, g, s->tw4096.p, mag, raw);
+    } else {
+        // radix passes: Ra-point columns of each frame, then (optionally) Rb-point columns inside each of the Ra sub-sequences
+        if (g.Ra <= 16) launch_radix<2>(c, g.Ra, fs, g.N, 1u, nf, tw_hi, tw_lo, s->tmp.p);
+        else launch_radix<1>(c, g.Ra, fs, g.N, 1u, nf, tw_hi, tw_lo, s->tmp.p);
+        if (g.Rb > 1) {
+            const int L2 = g.N / g.Ra;
+            FrameSrc sub{s->tmp.p, nullptr, s->tmp.p + L2, L2, 1 << 30};
+            if (g.Rb <= 16) launch_radix<2>(c, g.Rb, sub, L2, (unsigned)g.Ra, nf * g.Ra, tw_hi, tw_lo, s->tmp.p);
+            else launch_radix<1>(c, g.Rb, sub, L2, (unsigned)g.Ra, nf * g.Ra, tw_hi, tw_lo, s->tmp.p);
+        }
+        FrameSrc rows{s->tmp.p, nullptr, s->tmp.p + g.N, g.N, 1 << 30};
+        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_rows4096, dim3(g.Ra * g.Rb, nf), dim3(kFftThreads), kRowLdsBytes, rows, g,
+                    s->tw4096.p, mag, raw);
+    }
+    CSDR_HIP_TRY(hipGetLastError());
+    return CSDR_OK;
+}
+
+
 static int spec_run_fft(csdr_spec *s, const FrameSrc &fs, int nf, float *mag, float2 *raw) {
     const SpecGeom &g = s->g;
     csdr_ctx *c = s->ctx;
@@ -258,31 +318,20 @@ static int spec_run_fft(csdr_spec *s, const FrameSrc &fs, int nf, float *mag, fl
         CSDR_HIP_TRY(hipGetLastError());
         return CSDR_OK;
     }
-    if (g.npot) {
+    if (g.npot && s->blue_big) {
+        // chirp-z with a convolution longer than the LDS transforms: x w -> FFT_L -> times Bf, conjugated -> FFT_L -> conjugate, / L, times w
+        const int L = s->blue_L;
+        const dim3 ew((L + kFftThreads - 1) / kFftThreads, nf);
+        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_COLS, spec_blue_pre, ew, dim3(kFftThreads), 0, fs, g.N, L, s->blue_w.p, s->blue_a.p);
+        FrameSrc fa{s->blue_a.p, nullptr, s->blue_a.p + L, L, 1 << 30};
+        if (int rc = spec_run_pow2(s, s->gL, s->twL_hi.p, s->twL_lo.p, fa, nf, nullptr, s->blue_b.p)) return rc;
+        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_COLS, spec_blue_mid, ew, dim3(kFftThreads), 0, s->blue_b.p, s->blue_B.p, L, s->blue_a.p);
+        if (int rc = spec_run_pow2(s, s->gL, s->twL_hi.p, s->twL_lo.p, fa, nf, nullptr, s->blue_b.p)) return rc;
+        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_blue_post, dim3((g.N + kFftThreads - 1) / kFftThreads, nf), dim3(kFftThreads), 0, s->blue_b.p, s->blue_w.p, g.N, L, mag, raw);
+    } else if (g.npot) {
         CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_bluestein, dim3(1, nf), dim3(kFftThreads), (size_t)2 * s->blue_L * sizeof(float2), fs, g.N, s->blue_L, s->tw4096.p,
                     s->blue_w.p, s->blue_B.p, mag, raw);
-    } else if (g.N < 4096) {
-        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_small, dim3(1, nf), dim3(kFftThreads), (size_t)2 * g.N * sizeof(float2), fs, g.N, s->tw4096.p, mag, raw);
-    } else if (g.Ra == 1) {
-        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_rows4096, dim3(1, nf), dim3(kFftThreads), kRowLdsBytes, fs, g, s->tw4096.p, mag, raw);
-    } else if (g.Ra == kC512) {
-        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_COLS, spec_cols512, dim3(g.N / kC512 / kC512Cols, nf), dim3(kFftThreads), kC512Lds, fs, g.N, s->tw4096.p, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
-        FrameSrc rows{s->tmp.p, nullptr, s->tmp.p + g.N, g.N, 1 << 30};
-        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_rows4096, dim3(g.Ra, nf), dim3(kFftThreads), kRowLdsBytes, rows, g, s->tw4096.p, mag, raw);
-    } else {
-        // radix passes: Ra-point columns of each frame, then (optionally) Rb-point columns inside each of the Ra sub-sequences
-        if (g.Ra <= 16) launch_radix<2>(c, g.Ra, fs, g.N, 1u, nf, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
-        else launch_radix<1>(c, g.Ra, fs, g.N, 1u, nf, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
-        if (g.Rb > 1) {
-            const int L2 = g.N / g.Ra;
-            FrameSrc sub{s->tmp.p, nullptr, s->tmp.p + L2, L2, 1 << 30};
-            if (g.Rb <= 16) launch_radix<2>(c, g.Rb, sub, L2, (unsigned)g.Ra, nf * g.Ra, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
-            else launch_radix<1>(c, g.Rb, sub, L2, (unsigned)g.Ra, nf * g.Ra, s->tw_hi.p, s->tw_lo.p, s->tmp.p);
-        }
-        FrameSrc rows{s->tmp.p, nullptr, s->tmp.p + g.N, g.N, 1 << 30};
-        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_rows4096, dim3(g.Ra * g.Rb, nf), dim3(kFftThreads), kRowLdsBytes, rows, g,
-                    s->tw4096.p, mag, raw);
-    }
+    } else return spec_run_pow2(s, g, s->tw_hi.p, s->tw_lo.p, fs, nf, mag, raw);
     CSDR_HIP_TRY(hipGetLastError());
     return CSDR_OK;
 }
@@ -611,7 +660,6 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
     if (!s || !s->ready) return fail(CSDR_ESTATE, "spec not set up");
     if (!iq || n_blocks <= 0 || block_len <= 0) return fail(CSDR_EINVAL, "bad block arguments");
     if (s->is_view) {
-        if (s->g.npot) return fail(CSDR_EUNSUPPORTED, "the zoomed view is built for power-of-two sizes");
         if (n_blocks != 1) return fail(CSDR_EINVAL, "the zoomed view takes one process() input per call");
         return spec_process_view(s, iq, iq_is_dev, block_len);
     }

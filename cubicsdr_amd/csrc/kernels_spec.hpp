@@ -316,7 +316,7 @@ CSDR_KERNEL_SPEC __launch_bounds__(kFftThreads) void spec_fft_small(FrameSrc fs,
     if (raw_out) for (int i = tid; i < N; i += kFftThreads) raw_out[(int64_t)f * N + i] = r[i];
 }
 
-// ---- any even N <= 2048 (setFFTSize takes any size, SpectrumVisualProcessor.cpp:180-190; liquid plans a mixed-radix / Rader transform): the
+// ---- any even N (setFFTSize takes any size, SpectrumVisualProcessor.cpp:180-190; liquid plans a mixed-radix / Rader transform): the
 // chirp-z transform.  With w[n] = exp(-i pi n^2 / N):  X[k] = w[k] sum_n (x[n] w[n]) conj(w[k - n]) -- a circular convolution of length
 // L = 2^p >= 2 N - 1 with the (precomputed, transformed in double on the host) chirp filter Bf.  One frame per workgroup, both L-point
 // transforms in LDS (the inverse one as conj(FFT(conj(.))) / L).  grid = (1, frames), LDS 2 L float2.
@@ -339,6 +339,30 @@ CSDR_KERNEL_SPEC __launch_bounds__(kFftThreads) void spec_fft_bluestein(FrameSrc
         if (mag) mag[(int64_t)f * N + k] = cabs_f(v);
         if (raw_out) raw_out[(int64_t)f * N + k] = v;
     }
+}
+
+// ---- the same transform with a convolution longer than 4096 points (fftSize above 1024): the two L-point transforms run as the power-of-two chain
+// of size L (spec_run_pow2: natural-order complex output), these three kernels do the element-wise steps between them.  grid = (ceil(n / 256), frames)
+CSDR_KERNEL_SPEC __launch_bounds__(kFftThreads) void spec_blue_pre(FrameSrc fs, int N, int L, const float2 *__restrict__ chirp, float2 *__restrict__ a) {
+    const int f = blockIdx.y, i = blockIdx.x * kFftThreads + threadIdx.x;
+    if (i >= L) return;
+    a[(int64_t)f * L + i] = i < N ? cmul(frame_at(fs, f, frame_ptr(fs, f), i), chirp[i]) : make_float2(0.f, 0.f);
+}
+CSDR_KERNEL_SPEC __launch_bounds__(kFftThreads) void spec_blue_mid(const float2 *__restrict__ b, const float2 *__restrict__ Bf, int L, float2 *__restrict__ a) {
+    const int f = blockIdx.y, i = blockIdx.x * kFftThreads + threadIdx.x;
+    if (i >= L) return;
+    const float2 v = cmul(b[(int64_t)f * L + i], Bf[i]);
+    a[(int64_t)f * L + i] = make_float2(v.x, -v.y);               // the inverse transform as conj(FFT(conj(.))) / L
+}
+CSDR_KERNEL_SPEC __launch_bounds__(kFftThreads) void spec_blue_post(const float2 *__restrict__ y, const float2 *__restrict__ chirp, int N, int L,
+                                                              float *__restrict__ mag, float2 *__restrict__ raw_out) {
+    const int f = blockIdx.y, k = blockIdx.x * kFftThreads + threadIdx.x;
+    if (k >= N) return;
+    const float inv = 1.0f / (float)L;
+    const float2 q = y[(int64_t)f * L + k];
+    const float2 v = cmul(chirp[k], make_float2(q.x * inv, -q.y * inv));
+    if (mag) mag[(int64_t)f * N + k] = cabs_f(v);
+    if (raw_out) raw_out[(int64_t)f * N + k] = v;
 }
 
 // ---- K15: averaging recurrences, display order -----------------------------------------------------------------
@@ -683,7 +707,10 @@ CSDR_KERNEL_SPEC __launch_bounds__(256) void spec_avg_remap(const double *__rest
         if (mode == 0) src = i < N - n ? i + n : i;
         else if (mode == 1) src = i >= n ? i - n : i;
         else if (mode == 2) src = N / 4 + i / 2;
-        else { zero = i < N / 4 || i >= N - N / 4; src = zero ? 0 : (i - N / 4) * 2; }
+        else {
+            zero = i < N / 4 || i >= N - N / 4; src = zero ? 0 : (i - N / 4) * 2;
+            if (src >= N) { zero = true; src = 0; }      // N not a multiple of 4 (an odd fftSize): the reference reads one element past its vector here (:471); a zero instead
+        }
         const int64_t so = (int64_t)(src & 1) * F + spec_state_index(g, src >> 1), dn = (int64_t)(i & 1) * F + spec_state_index(g, i >> 1);
         ma_o[dn] = zero ? 0.0 : ma[so];
         maa_o[dn] = zero ? 0.0 : maa[so];

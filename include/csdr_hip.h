@@ -234,7 +234,7 @@ int  csdr_bank_total_audio(csdr_bank *bank, int64_t *n);
 
 int  csdr_spec_create(csdr_ctx *ctx, csdr_spec **out);
 void csdr_spec_destroy(csdr_spec *spec);
-int  csdr_spec_setup(csdr_spec *spec, int fft_size, int max_frames);      /* setup(fftSize_in): a power of two up to 2^21, or any size up to 1024 (setFFTSize :180-190 takes any) */
+int  csdr_spec_setup(csdr_spec *spec, int fft_size, int max_frames);      /* setup(fftSize_in): a power of two up to 2^21, or any other size up to 2^20 (setFFTSize :180-190 takes any) */
 int  csdr_spec_set_average_rate(csdr_spec *spec, float rate);             /* setFFTAverageRate, default 0.65 (:36) */
 int  csdr_spec_set_scale_factor(csdr_spec *spec, float sf);               /* setScaleFactor, default 1 */
 /* setPeakHold (:115-125): enabling starts a one-input countdown to the reset of fft_result_peak / fft_ceil_peak /

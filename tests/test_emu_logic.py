@@ -161,6 +161,10 @@ def test_emu_spectrum_zoomed_view(ctx):
     G.test_spectrum_zoomed_view(ctx)
 
 
+def test_emu_spectrum_zoomed_view_not_a_power_of_two(ctx):
+    G.test_spectrum_zoomed_view(ctx, 600)
+
+
 def test_emu_spectrum_zoomed_view_two_pass(ctx):
     G.test_spectrum_zoomed_view_behind_a_two_pass_transform(ctx)
 
@@ -284,7 +288,7 @@ def test_emu_packed_row_order(ctx, M):
 
 
 def test_emu_spectrum_sizes_that_are_not_powers_of_two(ctx):
-    for F in (600, 37, 3):
+    for F in (600, 37, 3, 1500):
         G.test_fft_matches_liquid(ctx, F)
     G.test_spectrum_points_first_frame_mode(ctx, 375, 4000)
     G._spectrum_contiguous_batches(ctx, 375, 2400000, (5, 3, 4))

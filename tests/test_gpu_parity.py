@@ -659,10 +659,11 @@ def test_single_channel_mode_demod(ctx):
 
 
 # ----------------------------------------------------------------------------------------------- spectrum
-@pytest.mark.parametrize("F", [512, 2048, 16384, 65536, 600, 1000, 750, 37, 3, 1023])
+@pytest.mark.parametrize("F", [512, 2048, 16384, 65536, 600, 1000, 750, 37, 3, 1023, 1025, 1500, 3000, 5000, 12345, 50000, 100001])
 def test_fft_matches_liquid(ctx, F):
     """fft_execute (SpectrumVisualProcessor.cpp:439) at the sizes the GUI sets and -- setFFTSize takes any size (:180-190) -- at sizes that are
-    not powers of two (chirp-z transform, up to fftSize 1024: internal 2 x fftSize points, odd fftSize included)"""
+    not powers of two (chirp-z transform; internal 2 x fftSize points, odd fftSize included; above fftSize 1024 the convolution runs as two
+    power-of-two transform chains of 8192 .. 2^19 points in HBM)"""
     from cubicsdr_amd.engine import SpectrumProcessor
     from oracle.cubicsdr_chain import RefSpectrum
     x = synth_iq(2 * F, 2.4e6, 0, [("NBFM", 300000.0)], seed=77)
@@ -812,7 +813,7 @@ def test_spectrum_peak_hold_and_hide_dc(ctx):
     sp.close()
 
 
-def test_spectrum_zoomed_view(ctx):
+def test_spectrum_zoomed_view(ctx, F=512):
     """setView: the input is shifted to the view centre and resampled to the smallest rate/2^k that still covers the view
     bandwidth, then transformed; the display walks bandwidth / resampleBw bins per point.  The scenario retunes the view
     (the averagers shift), zooms in and out (they are stretched / squeezed, the resampler is rebuilt while the NCO phase
@@ -820,7 +821,7 @@ def test_spectrum_zoomed_view(ctx):
     resampler needs (overlap rule)."""
     from cubicsdr_amd.engine import SpectrumProcessor
     from oracle.cubicsdr_chain import RefSpectrum
-    F, fs, center = 512, 2400000, 100000000
+    fs, center = 2400000, 100000000
     block = 40000
     steps = [  # (view centre, view bandwidth, samples of the block handed over, peak-hold toggle)
         (center + 200000, 500000, block, None), (center + 200000, 500000, block, None), (center + 200000, 500000, block, True),
@@ -862,6 +863,14 @@ def test_spectrum_zoomed_view(ctx):
         frames += 1
     assert frames >= len(steps) - 3 and held >= 3, (frames, held)
     sp.close()
+
+
+@pytest.mark.parametrize("F", [600, 1500])
+def test_spectrum_zoomed_view_at_sizes_that_are_not_powers_of_two(ctx, F):
+    """the same walk (retunes, zoom steps, short inputs, peak hold) at fftSize 600 (chirp-z in LDS) and 1500 (the convolution as two 8192-point chains).
+    (An odd fftSize is not walked: with 2 fftSize not a multiple of four the reference's zoom-out reads fft_result_ma one element past its end,
+    SpectrumVisualProcessor.cpp:471 -- the HIP path puts a zero there.)"""
+    test_spectrum_zoomed_view(ctx, F)
 
 
 def test_spectrum_zoomed_view_behind_a_two_pass_transform(ctx):
@@ -1032,6 +1041,14 @@ def test_spectrum_size_that_is_not_a_power_of_two_contiguous_batches(ctx):
     three calls against the reference's own class: averagers, trackers, carry"""
     _spectrum_contiguous_batches(ctx, 600, 2400000, (30, 22, 25))
     _spectrum_contiguous_batches(ctx, 375, 2400000, (12, 9, 14))
+
+
+def test_spectrum_large_size_that_is_not_a_power_of_two_contiguous_batches(ctx):
+    """fftSize 1500 and 3000 (3000- and 6000-point transforms: convolutions of 8192 and 16384 points, one and two radix passes in front of the
+    4096-point rows) and 20000 (40000 points through a 131072-point convolution), contiguous frames over three calls against the reference's class"""
+    _spectrum_contiguous_batches(ctx, 1500, 2400000, (14, 9, 11))
+    _spectrum_contiguous_batches(ctx, 3000, 2400000, (9, 7, 8))
+    _spectrum_contiguous_batches(ctx, 20000, 10000000, (4, 3, 5))
 
 
 def _spectrum_contiguous_batches(ctx, F, fs, frames_per_batch, against_exact=False):
