@@ -26,6 +26,7 @@ struct csdr_spec {
     int blue_L = 0;
     // ... with a convolution longer than 4096 points (fftSize above 1024): the two L-point transforms run as the power-of-two chain of size L
     bool blue_big = false;
+    int blue_chunk = 1;                      // frames per pass of the big path
     SpecGeom gL{};
     DevBuf<float2> blue_a, blue_b, twL_hi, twL_lo;
     DevBuf<float> mag;                       // [2][max_frames][N]: the FFT lane fills one copy while the averaging lane reads the other
@@ -175,7 +176,8 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
             if (int rc = s->twL_hi.reserve(hi.size())) return rc;
             CSDR_HIP_TRY(hipMemcpy(s->twL_lo.p, lo.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
             CSDR_HIP_TRY(hipMemcpy(s->twL_hi.p, hi.data(), hi.size() * sizeof(float2), hipMemcpyHostToDevice));
-            const size_t nfL = (size_t)max_frames * (size_t)L;
+            s->blue_chunk = std::max(1, std::min(max_frames, (1 << 26) / L));
+            const size_t nfL = (size_t)s->blue_chunk * (size_t)L;
             if (int rc = s->blue_a.reserve(nfL)) return rc;
             if (int rc = s->blue_b.reserve(nfL)) return rc;
             if (int rc = s->tmp.reserve(nfL)) return rc;
@@ -320,14 +322,19 @@ static int spec_run_fft(csdr_spec *s, const FrameSrc &fs, int nf, float *mag, fl
     }
     if (g.npot && s->blue_big) {
         // chirp-z with a convolution longer than the LDS transforms: x w -> FFT_L -> times Bf, conjugated -> FFT_L -> conjugate, / L, times w
+        // (the frames of a call in groups of blue_chunk: the three work arrays hold at most 2^26 complex each)
         const int L = s->blue_L;
-        const dim3 ew((L + kFftThreads - 1) / kFftThreads, nf);
-        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_COLS, spec_blue_pre, ew, dim3(kFftThreads), 0, fs, g.N, L, s->blue_w.p, s->blue_a.p);
         FrameSrc fa{s->blue_a.p, nullptr, s->blue_a.p + L, L, 1 << 30};
-        if (int rc = spec_run_pow2(s, s->gL, s->twL_hi.p, s->twL_lo.p, fa, nf, nullptr, s->blue_b.p)) return rc;
-        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_COLS, spec_blue_mid, ew, dim3(kFftThreads), 0, s->blue_b.p, s->blue_B.p, L, s->blue_a.p);
-        if (int rc = spec_run_pow2(s, s->gL, s->twL_hi.p, s->twL_lo.p, fa, nf, nullptr, s->blue_b.p)) return rc;
-        CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_blue_post, dim3((g.N + kFftThreads - 1) / kFftThreads, nf), dim3(kFftThreads), 0, s->blue_b.p, s->blue_w.p, g.N, L, mag, raw);
+        for (int f0 = 0; f0 < nf; f0 += s->blue_chunk) {
+            const int cnt = std::min(s->blue_chunk, nf - f0);
+            const dim3 ew((L + kFftThreads - 1) / kFftThreads, cnt);
+            CSDR_LAUNCH(c, LANE_FFT, KID_FFT_COLS, spec_blue_pre, ew, dim3(kFftThreads), 0, fs, f0, g.N, L, s->blue_w.p, s->blue_a.p);
+            if (int rc = spec_run_pow2(s, s->gL, s->twL_hi.p, s->twL_lo.p, fa, cnt, nullptr, s->blue_b.p)) return rc;
+            CSDR_LAUNCH(c, LANE_FFT, KID_FFT_COLS, spec_blue_mid, ew, dim3(kFftThreads), 0, s->blue_b.p, s->blue_B.p, L, s->blue_a.p);
+            if (int rc = spec_run_pow2(s, s->gL, s->twL_hi.p, s->twL_lo.p, fa, cnt, nullptr, s->blue_b.p)) return rc;
+            CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_blue_post, dim3((g.N + kFftThreads - 1) / kFftThreads, cnt), dim3(kFftThreads), 0, s->blue_b.p, s->blue_w.p, g.N, L,
+                        mag ? mag + (size_t)f0 * g.N : nullptr, raw ? raw + (size_t)f0 * g.N : nullptr);
+        }
     } else if (g.npot) {
         CSDR_LAUNCH(c, LANE_FFT, KID_FFT_ROWS, spec_fft_bluestein, dim3(1, nf), dim3(kFftThreads), (size_t)2 * s->blue_L * sizeof(float2), fs, g.N, s->blue_L, s->tw4096.p,
                     s->blue_w.p, s->blue_B.p, mag, raw);

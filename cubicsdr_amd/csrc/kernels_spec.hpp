@@ -343,10 +343,10 @@ CSDR_KERNEL_SPEC __launch_bounds__(kFftThreads) void spec_fft_bluestein(FrameSrc
 
 // ---- the same transform with a convolution longer than 4096 points (fftSize above 1024): the two L-point transforms run as the power-of-two chain
 // of size L (spec_run_pow2: natural-order complex output), these three kernels do the element-wise steps between them.  grid = (ceil(n / 256), frames)
-CSDR_KERNEL_SPEC __launch_bounds__(kFftThreads) void spec_blue_pre(FrameSrc fs, int N, int L, const float2 *__restrict__ chirp, float2 *__restrict__ a) {
-    const int f = blockIdx.y, i = blockIdx.x * kFftThreads + threadIdx.x;
+CSDR_KERNEL_SPEC __launch_bounds__(kFftThreads) void spec_blue_pre(FrameSrc fs, int f0, int N, int L, const float2 *__restrict__ chirp, float2 *__restrict__ a) {
+    const int f = blockIdx.y, i = blockIdx.x * kFftThreads + threadIdx.x;      // frame f0 + f of the call into slot f of the work array
     if (i >= L) return;
-    a[(int64_t)f * L + i] = i < N ? cmul(frame_at(fs, f, frame_ptr(fs, f), i), chirp[i]) : make_float2(0.f, 0.f);
+    a[(int64_t)f * L + i] = i < N ? cmul(frame_at(fs, f0 + f, frame_ptr(fs, f0 + f), i), chirp[i]) : make_float2(0.f, 0.f);
 }
 CSDR_KERNEL_SPEC __launch_bounds__(kFftThreads) void spec_blue_mid(const float2 *__restrict__ b, const float2 *__restrict__ Bf, int L, float2 *__restrict__ a) {
     const int f = blockIdx.y, i = blockIdx.x * kFftThreads + threadIdx.x;

@@ -292,3 +292,4 @@ def test_emu_spectrum_sizes_that_are_not_powers_of_two(ctx):
         G.test_fft_matches_liquid(ctx, F)
     G.test_spectrum_points_first_frame_mode(ctx, 375, 4000)
     G._spectrum_contiguous_batches(ctx, 375, 2400000, (5, 3, 4))
+    G._spectrum_contiguous_batches(ctx, 1500, 2400000, (5, 3, 4))
