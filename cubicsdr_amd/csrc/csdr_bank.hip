@@ -616,7 +616,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     if (n_ag > 0)
         CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, demod_modem, dim3(NB, n_ag), dim3(audio_threads) /* one wave per block, like the audio kernel */, modem_lds, b->cfgs.p, dyns_d, lists_d + b->max_demods,
                     plans_d, NB, cap_stream, b->mconsts.p, c->sintab.p, b->arms.p, cap_cw);
-    if (n_ag > 0)     // the auto-gain recurrence over the blocks, once per demodulator
+    if (n_ag > 0 && NB > 1)     // the auto-gain recurrence over the blocks, once per demodulator (a one-block batch: the modem workgroup takes the single step)
         CSDR_LAUNCH(c, LANE_AUDIO, KID_GAIN_SCAN, demod_gain_scan, dim3(n_ag), dim3(64), (size_t)(2 * NB + 1) * sizeof(float), b->cfgs.p, dyns_d, lists_d + b->max_demods, plans_d, NB);
     const int *fms_d = lists_d + b->max_demods + fms_off;
     if (n_fms > 0) {  // FM stereo, ahead of the audio stage: Hilbert r2c of the discriminator output, the pilot loop, the 38 kHz down-mix

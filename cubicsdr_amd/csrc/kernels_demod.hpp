@@ -979,6 +979,21 @@ __device__ inline float block_max_float(float v, float *) {
     return v;
 }
 
+// A ONE-block batch (the real-time shape): the auto-gain recurrence over the blocks is a single step, taken by the modem workgroup itself instead of a
+// demod_gain_scan launch behind it (one dependent kernel less in the chain of a call).  The statements of demod_gain_scan, below.
+__device__ inline void gain_step_single(const SlotCfg &cfg, const SlotDyn &dyn, const BlockPlan *pl, float block_max) {
+    const float *agc_in = cfg.agc + 4 * dyn.hist_parity;
+    float ceil_ = agc_in[0], ma = agc_in[1], maa = agc_in[2];
+    if (pl[1].j0 != pl[0].j0) {
+        ma = ma + (ceil_ - ma) * 0.025f;
+        maa = maa + (ma - maa) * 0.025f;
+        ceil_ = block_max;
+    }
+    cfg.blockmaa[0] = maa;
+    float *agc_out = cfg.agc + 4 * (dyn.hist_parity ^ 1);
+    agc_out[0] = ceil_; agc_out[1] = ma; agc_out[2] = maa;
+}
+
 CSDR_KERNEL_BANK __launch_bounds__(kAudioThreads) void demod_modem(
     const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
     const BlockPlan *__restrict__ plans, int NB, int cap_stream, const ModemConsts *__restrict__ mc, const float *__restrict__ sintab,
@@ -1057,6 +1072,7 @@ CSDR_KERNEL_BANK __launch_bounds__(kAudioThreads) void demod_modem(
                 }
                 cfg.blockmax[bb] = mx;
                 cfg.bout[bb].level_accum = 0.0; cfg.bout[bb].level_count = 0; cfg.bout[bb].audio_peak = 0.f;
+                if (NB == 1) gain_step_single(cfg, dyn, pl, mx);
             }
         }
         if (tid == 0) { cfg.pll[0] = th; cfg.pll[1] = dth; }
@@ -1196,6 +1212,7 @@ CSDR_KERNEL_BANK __launch_bounds__(kAudioThreads) void demod_modem(
         cfg.bout[b].level_accum = bs;
         cfg.bout[b].level_count = lcount;
         cfg.bout[b].audio_peak = 0.f;
+        if (NB == 1) gain_step_single(cfg, dyn, pl, bm);
     }
 }
 

@@ -1786,7 +1786,8 @@ def test_error_codes_and_edge_inputs(ctx):
     spec = C.c_void_p()
     assert L.csdr_spec_create(ctx.h, C.byref(spec)) == 0
     assert L.csdr_spec_process(spec, x.ctypes.data_as(C.c_void_p), 0, 1, 4096, 0) == ESTATE
-    assert L.csdr_spec_setup(spec, 3000, 4) == EUNSUP                                                  # not a power of two and above 1024 (chirp-z sizes end there)
+    assert L.csdr_spec_setup(spec, 3000000, 4) == EUNSUP                                               # not a power of two: the chirp-z convolution would exceed 2^22 points
+    assert L.csdr_spec_setup(spec, 1 << 22, 4) == EUNSUP                                               # internal transform above 2^22 points
     assert L.csdr_spec_setup(spec, 512, 0) == EINVAL
     assert L.csdr_spec_setup(spec, 512, 4) == 0
     assert L.csdr_spec_process(spec, x.ctypes.data_as(C.c_void_p), 0, 1, 4096, 9) == EINVAL            # unknown mode
