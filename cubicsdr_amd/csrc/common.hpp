@@ -279,7 +279,7 @@ template <int N> __device__ __forceinline__ void lds_read128(const float2 *pe, c
 enum CsdrKernelId {
     KID_CHAN_ANALYZE = 0, KID_DC_ENDS, KID_DC_APPLY, KID_ROWS_COPY,
     KID_FE_GENERIC, KID_FE_S3, KID_FE_S4, KID_FE_S5, KID_FE_S6, KID_FE_S56, KID_FE_INTERP,
-    KID_MODEM, KID_GAIN_SCAN, KID_FMS, KID_AUDIO, KID_FMS_OUT, KID_MIX,
+    KID_MODEM, KID_GAIN_SCAN, KID_FMS, KID_AUDIO, KID_FMS_OUT, KID_MIX, KID_TABLES,
     KID_FFT_COLS, KID_FFT_ROWS, KID_SPEC_AVG, KID_SPEC_TRACK, KID_SPEC_DISPLAY, KID_SPEC_MISC,
     KID_COUNT
 };

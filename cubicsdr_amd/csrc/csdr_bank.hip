@@ -487,7 +487,13 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         CSDR_HIP_TRY(hipStreamWaitEvent(st, post->ev_ready[pk], 0));
     }
     if (b->audio_pending[bpar]) if (int rc = c->wait(b->ev_audio_done[bpar], LANE_AUDIO, LANE_FE)) return rc;
-    CSDR_HIP_TRY(hipMemcpyAsync(table_d, table_h, b->off_plans + (size_t)b->max_demods * (NB + 1) * sizeof(BlockPlan), hipMemcpyHostToDevice, st));
+    {   // the tables of this batch: fetched from the page-locked staging slot by a kernel of this stream (bank_tables_fetch: why not a copy-engine transfer)
+        const size_t bytes = b->off_plans + (size_t)b->max_demods * (NB + 1) * sizeof(BlockPlan);
+        const int n16 = (int)((bytes + 15) / 16);                   // (the slot and the device table are whole multiples of 256 bytes)
+        CSDR_LAUNCH(c, LANE_FE, KID_TABLES, bank_tables_fetch, dim3(std::max(1, std::min(64, (n16 + 255) / 256))), dim3(256), 0,
+                    reinterpret_cast<const float4 *>(table_h), reinterpret_cast<float4 *>(table_d), n16);
+        CSDR_HIP_TRY(hipGetLastError());
+    }
     CSDR_HIP_TRY(hipEventRecord(b->stage_ev[ring], st));
     b->stage_used[ring] = true;
     // front-end geometry: every slot's batch is cut into P ranges; a range re-runs `warm` inputs in front of it.

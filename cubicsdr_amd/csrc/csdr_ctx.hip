@@ -141,7 +141,7 @@ extern "C" int csdr_ctx_timer_stop(csdr_ctx *c, float *ms) {
 static const char *kKernelNames[KID_COUNT] = {
     "chan_analyze", "dc_tile_ends", "dc_apply", "rows_copy",
     "demod_frontend_generic", "demod_frontend_s3", "demod_frontend_s4", "demod_frontend_s5", "demod_frontend_s6", "demod_frontend_s56", "demod_frontend_interp",
-    "demod_modem", "demod_gain_scan", "fms_stages", "demod_audio_interp", "fms_out", "audio_egress",
+    "demod_modem", "demod_gain_scan", "fms_stages", "demod_audio_interp", "fms_out", "audio_egress", "bank_tables",
     "spec_fft_radix", "spec_fft_rows", "spec_average", "spec_extrema", "spec_display", "spec_misc"};
 static int prof_drain(csdr_ctx *c) {
     if (int rc = c->sync_all()) return rc;

@@ -979,6 +979,14 @@ __device__ inline float block_max_float(float v, float *) {
     return v;
 }
 
+// The per-batch tables of a bank (slot dynamics, launch lists, block plans) from their page-locked staging slot into device memory, fetched BY A KERNEL of
+// the front-end's own stream.  A hipMemcpyAsync puts a copy-engine transfer into the dependent chain of a call: 6 us of transfer behind ~ 20 us of host
+// time inside the API call, and ~ 12 us until the compute queue sees the engine's completion signal (rocprofv3 traces of one-block calls, round 5) -- a
+// third of a one-block call.  The staging slot is host memory mapped into the device's address space (hipHostMalloc): n16 16-byte words.
+CSDR_KERNEL_BANK __launch_bounds__(256) void bank_tables_fetch(const float4 *__restrict__ staged, float4 *__restrict__ tables, int n16) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) tables[i] = staged[i];
+}
+
 // A ONE-block batch (the real-time shape): the auto-gain recurrence over the blocks is a single step, taken by the modem workgroup itself instead of a
 // demod_gain_scan launch behind it (one dependent kernel less in the chain of a call).  The statements of demod_gain_scan, below.
 __device__ inline void gain_step_single(const SlotCfg &cfg, const SlotDyn &dyn, const BlockPlan *pl, float block_max) {
