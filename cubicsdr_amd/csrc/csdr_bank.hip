@@ -508,7 +508,12 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     auto ranges_for = [&](int n_slots) {
         int P = (int)std::max<int64_t>(1, std::min<int64_t>(total / std::max<int64_t>(4096, 4 * (int64_t)warm_max), 4096));
         const int per_slot = fe_slots / std::max(1, n_slots) - 1;                          // one extra workgroup per slot carries the histories
-        if (per_slot >= 1) P = std::min(P, per_slot);
+        if (per_slot >= 1) {
+            // a batch too short to fill the resident workgroups at that length (the real-time shape: one block per call) is cut down to ONE warm-up
+            // span per range: the launch is then bound by the serial chunk chain of a workgroup, not by the work (one block, C3: 19 -> 12 us)
+            P = std::max(P, (int)std::min<int64_t>(total / std::max<int64_t>(2048, (int64_t)warm_max), 4096));
+            P = std::min(P, per_slot);
+        }
         else {                                                           // more slots than resident workgroups: whole rounds
             const int rounds = (n_slots * 2 + fe_slots - 1) / fe_slots;
             P = std::max(1, std::min(P, rounds * fe_slots / std::max(1, n_slots) - 1));
