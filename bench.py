@@ -354,6 +354,16 @@ def self_launch(n):
     os.execv(sys.executable, cmd)
 
 
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries under this process write there too (RCCL's version banner at communicator creation, gloo's
+    connection notes in the one-GPU dry run): file descriptor 1 is pointed at stderr for the whole run and the line goes to the descriptor that was
+    stdout.  Returns the stream to print the line on."""
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    return os.fdopen(keep, "w")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -380,9 +390,10 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)                         # (does not return)
+    line_out = claim_stdout()
     if args.config == "C4":
         from cubicsdr_amd import sharded_bench
-        return sharded_bench.main(args)
+        return sharded_bench.main(args, line_out)
 
     cfg = dict(CONFIGS[args.config]); cfg["name"] = args.config
     FS, M, BLOCK, N_DEMODS, FFT_SIZE, kinds = cfg["fs"], cfg["M"], cfg["block"], cfg["n_demods"], cfg["fft"], cfg["kinds"]
@@ -660,7 +671,7 @@ def main():
         except Exception as e:      # reported, never required for the headline number
             out["strong"] = {"value": None, "note": repr(e)}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        line_out.write(json.dumps(out) + "\n"); line_out.flush()
     if dist:
         dist.destroy_process_group()
 

@@ -6,16 +6,18 @@ cubicsdr_amd.parallel.SlabStream): scatter of [history | slab] windows, every ra
 all-to-all hands every rank the rows of its channels -- the channelizer's work is divided too."""
 import json
 import os
+import sys
 import time
 
 FS, M, BLOCK, CENTER = 100_000_000, 1024, 1_667_072, 400_000_000        # BASELINE config 4 names M = 1024; block = ceil(fs / 60 / M) M (SoapySDRThread.cpp:668-674)
 NBFM_BW, AUDIO = 12_500, 48_000
 
 
-def main(args):
+def main(args, line_out=None):
     out = measure(args)
     if int(os.environ.get("RANK", "0")) == 0:
-        print(json.dumps(out), flush=True)
+        line_out = line_out or sys.stdout
+        line_out.write(json.dumps(out) + "\n"); line_out.flush()
 
 
 def measure(args, dist=None):
