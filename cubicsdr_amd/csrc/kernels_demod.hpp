@@ -571,6 +571,64 @@ struct FesStages<S, CH, END, END, WAVE> {
     static __device__ inline void run(float2 *, float2 *, float2 *, const float *, float, int) {}
 };
 
+// The mix of one prefetched chunk into the stage-0 arrays: x (c + j sgn s) with (s, c) from the 1024-entry table at the oscillator's phase word
+// (nco_crcf_mix_down / _up, DemodulatorPreThread.cpp:186-199); pair p = tid + q kFeThreads holds the samples rel0 + 2 p, + 1.  Samples before the
+// batch (rel < 0) come from the carried history and are mixed already.  A chunk that lies wholly in the batch (rel0 >= 0: all but a range's first
+// chunks) takes a form without per-sample guards: the 4 NPF table reads issued together, the direction of the mix chosen once per chunk (its sign
+// rides on the multiply-adds); the products are formed exactly as in the guarded form: bit-identical.
+// What the mix costs (round 5, C3, ablations of the merged depth-5 / 6 launch): 0.51 ms as is, 0.40 without it, 0.45 with conflict-free table addresses --
+// the table gathers are arithmetic progressions of arbitrary stride over 64 banks (~ 4 bank cycles each where one would do: 16 gathers per wave and
+// chunk, 11 % of the kernel), and the reference's oscillator IS that table.  The unguarded form itself changed nothing measurable (0.513 -> 0.515 ms:
+// the LDS pipe's conflict cycles are the cost, not the waits between the reads).
+template <int S, int CH, int NPF>
+__device__ __forceinline__ void fes_mix_chunk(const float4 (&pf)[NPF], int64_t rel0, const SlotDyn &dyn, float sgn, const float *__restrict__ tab,
+                                              float2 *__restrict__ LE, float2 *__restrict__ LO, int tid) {
+    float2 *e0 = LE + kFeTail, *o0 = LO + fes_offo<S, CH>(0) + kFeTail;
+    const uint32_t th0 = dyn.theta0 + (uint32_t)rel0 * dyn.dtheta;
+    if (dyn.mixdir != 0 && rel0 >= 0) {                          // (chunk-uniform)
+        float ts[NPF][4];
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int p = tid + q * kFeThreads;
+            const uint32_t tha = th0 + (uint32_t)(2 * p) * dyn.dtheta, thb = tha + dyn.dtheta;
+            const uint32_t ia = (tha + (1u << 21)) >> 22, ib = (thb + (1u << 21)) >> 22;          // 0 .. 1023
+            ts[q][0] = tab[ia]; ts[q][1] = tab[ia + 256]; ts[q][2] = tab[ib]; ts[q][3] = tab[ib + 256];
+        }
+        if (dyn.mixdir < 0) {
+#pragma unroll
+            for (int q = 0; q < NPF; ++q) {
+                const int p = tid + q * kFeThreads;
+                const float4 v = pf[q];
+                e0[p] = make_float2(fmaf(v.x, ts[q][1], v.y * ts[q][0]), fmaf(v.y, ts[q][1], -(v.x * ts[q][0])));
+                o0[p] = make_float2(fmaf(v.z, ts[q][3], v.w * ts[q][2]), fmaf(v.w, ts[q][3], -(v.z * ts[q][2])));
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NPF; ++q) {
+                const int p = tid + q * kFeThreads;
+                const float4 v = pf[q];
+                e0[p] = make_float2(fmaf(v.x, ts[q][1], -(v.y * ts[q][0])), fmaf(v.y, ts[q][1], v.x * ts[q][0]));
+                o0[p] = make_float2(fmaf(v.z, ts[q][3], -(v.w * ts[q][2])), fmaf(v.w, ts[q][3], v.z * ts[q][2]));
+            }
+        }
+        return;
+    }
+    const bool do_mix = dyn.mixdir != 0;
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) {
+        const int p = tid + q * kFeThreads;
+        float2 a = make_float2(pf[q].x, pf[q].y), b = make_float2(pf[q].z, pf[q].w);
+        if (do_mix) {
+            const uint32_t tha = th0 + (uint32_t)(2 * p) * dyn.dtheta, thb = tha + dyn.dtheta;
+            const uint32_t ia = (tha + (1u << 21)) >> 22, ib = (thb + (1u << 21)) >> 22;
+            const float sa = tab[ia] * sgn, ca = tab[ia + 256], sb = tab[ib] * sgn, cb = tab[ib + 256];
+            if (rel0 + 2 * p >= 0) a = make_float2(fmaf(a.x, ca, -(a.y * sa)), fmaf(a.y, ca, a.x * sa));
+            if (rel0 + 2 * p + 1 >= 0) b = make_float2(fmaf(b.x, cb, -(b.y * sb)), fmaf(b.y, cb, b.x * sb));
+        }
+        e0[p] = a; o0[p] = b;
+    }
+}
+
 // TW (S = 5, 6): a FIFTH wave owns the one-wave tail (the last two -- depth 6: three -- stages and the arbitrary resampler).  It works one chunk behind
 // the four worker waves, one piece per barrier interval, so the workers never wait for the tail at the head of the next chunk:
 //   workers      mix k | B1 | stage 0 | B2 | stage 1 | B3 | stage 2 (writes the tail's input of chunk k) | B4
@@ -664,21 +722,7 @@ __device__ __forceinline__ void fes_body(
             for (int k = 0; k < nch; ++k) {
                 const int64_t uc = u_lo + (int64_t)k * CH;
                 const int64_t rel0 = uc - (int64_t)dyn.buf0;
-                const bool do_mix = dyn.mixdir != 0;
-                const uint32_t th0 = dyn.theta0 + (uint32_t)rel0 * dyn.dtheta;
-#pragma unroll
-                for (int q = 0; q < NPF; ++q) {
-                    const int p = tid + q * kFeThreads;
-                    float2 a = make_float2(pf[q].x, pf[q].y), b = make_float2(pf[q].z, pf[q].w);
-                    if (do_mix) {
-                        const uint32_t tha = th0 + (uint32_t)(2 * p) * dyn.dtheta, thb = tha + dyn.dtheta;
-                        const uint32_t ia = (tha + (1u << 21)) >> 22, ib = (thb + (1u << 21)) >> 22;
-                        const float sa = tab[ia] * sgn, ca = tab[ia + 256], sb = tab[ib] * sgn, cb = tab[ib + 256];
-                        if (rel0 + 2 * p >= 0) a = make_float2(fmaf(a.x, ca, -(a.y * sa)), fmaf(a.y, ca, a.x * sa));
-                        if (rel0 + 2 * p + 1 >= 0) b = make_float2(fmaf(b.x, cb, -(b.y * sb)), fmaf(b.y, cb, b.x * sb));
-                    }
-                    LE[kFeTail + p] = a; LO[fes_offo<S, CH>(0) + kFeTail + p] = b;
-                }
+                fes_mix_chunk<S, CH, NPF>(pf, rel0, dyn, sgn, tab, LE, LO, tid);
                 if (k + 1 < nch) {
                     const int64_t reln = rel0 + CH;
                     const bool inside = reln >= 0 && reln + CH <= total;
@@ -753,24 +797,7 @@ __device__ __forceinline__ void fes_body(
     for (int64_t uc = u_lo; uc < u_stop; uc += CH) {
         const int64_t rel0 = uc - (int64_t)dyn.buf0;          // batch-relative index of the chunk's first input
         // ---- mix the prefetched chunk into the stage-0 arrays
-        {
-            const bool do_mix = dyn.mixdir != 0;
-            const uint32_t th0 = dyn.theta0 + (uint32_t)rel0 * dyn.dtheta;
-#pragma unroll
-            for (int q = 0; q < NPF; ++q) {
-                const int p = tid + q * kFeThreads;
-                float2 a = make_float2(pf[q].x, pf[q].y), b = make_float2(pf[q].z, pf[q].w);
-                if (do_mix) {
-                    const uint32_t tha = th0 + (uint32_t)(2 * p) * dyn.dtheta, thb = tha + dyn.dtheta;
-                    const uint32_t ia = (tha + (1u << 21)) >> 22, ib = (thb + (1u << 21)) >> 22;      // 0 .. 1023
-                    const float sa = tab[ia] * sgn, ca = tab[ia + 256], sb = tab[ib] * sgn, cb = tab[ib + 256];
-                    // samples before the batch (rel < 0) come from the history and are mixed already
-                    if (rel0 + 2 * p >= 0) a = make_float2(fmaf(a.x, ca, -(a.y * sa)), fmaf(a.y, ca, a.x * sa));
-                    if (rel0 + 2 * p + 1 >= 0) b = make_float2(fmaf(b.x, cb, -(b.y * sb)), fmaf(b.y, cb, b.x * sb));
-                }
-                LE[kFeTail + p] = a; LO[fes_offo<S, CH>(0) + kFeTail + p] = b;
-            }
-        }
+        fes_mix_chunk<S, CH, NPF>(pf, rel0, dyn, sgn, tab, LE, LO, tid);
         // ---- resampler outputs of this chunk: fetch their filter arms before the prefetch (vector-memory waits retire in order)
         const int64_t kz0 = uc >> S;
         int64_t jb = resamp_first_out(kz0 + CZ, dyn.phase0, step);
