@@ -96,7 +96,7 @@ extern "C" void csdr_spec_destroy(csdr_spec *s) {
         if (s->ev_avg_done[k]) (void)hipEventDestroy(s->ev_avg_done[k]);
     }
     s->tw4096.release(); s->tw_hi.release(); s->tw_lo.release(); s->tmp.release(); s->carry.release();
-    s->blue_w.release(); s->blue_B.release();
+    s->blue_w.release(); s->blue_B.release(); s->blue_a.release(); s->blue_b.release(); s->twL_hi.release(); s->twL_lo.release();
     s->stage_in.release(); s->raw.release(); s->mag.release(); s->ext_w.release(); s->ext.release(); s->pairsum.release(); s->first_b.release(); s->points.release();
     s->ma.release(); s->maa.release(); s->fo.release(); s->fsc.release(); s->scal.release();
     s->last[0].release(); s->last[1].release(); s->lines.release();
@@ -122,7 +122,7 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     s->seq = 0; s->avg_pending[0] = s->avg_pending[1] = false;
     SpecGeom &g = s->g;
     g.N = N; g.F = fft_size; g.Ra = 1; g.Rb = 1; g.N2 = N; g.npot = npot ? 1 : 0;
-    s->blue_L = 0;
+    s->blue_L = 0; s->blue_big = false;
     if (npot) {
         // chirp-z tables, in double: w[n] = exp(-i pi n^2 / N) (n^2 taken mod 2 N, exactly) and Bf = FFT_L(b), b[m mod L] = conj(w[|m|]), |m| < N
         int L = 1;
@@ -182,7 +182,8 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
             if (int rc = s->blue_b.reserve(nfL)) return rc;
             if (int rc = s->tmp.reserve(nfL)) return rc;
         }
-    } else { s->blue_big = false; s->blue_a.release(); s->blue_b.release(); }
+    }
+    if (!s->blue_big) { s->blue_a.release(); s->blue_b.release(); }      // (a smaller size after a large one that was not a power of two)
     if (N >= 4096 && !npot) {
         g.N2 = 4096;
         const int R = N / 4096;                                       // 1 .. 1024
