@@ -479,13 +479,9 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     // the audio stage runs the slots that have one: compact the head of the list (the front-end groups above are copies)
     int n_audio_run = 0;
     for (int i = 0; i < n_run; ++i) if (!is_fe_only(b->slots[slot_list_h[i]].prm.modem)) slot_list_h[n_audio_run++] = slot_list_h[i];
-    // lane FE: the channelizer output of this batch must be complete; the tables and the resampled-IQ buffers of this
-    // parity were last read by the audio kernels two batches ago
+    // lane FE: the tables and the resampled-IQ buffers of this parity were last read by the audio kernels two batches ago; the tables are fetched
+    // BEFORE the lane waits for the channelizer (on separate streams the fetch runs beside it), the front-end kernels behind that wait
     const int pk = post->cur;
-    if (post->ctx != c || !c->same(LANE_POST, LANE_FE)) {
-        if (post->ctx != c) CSDR_HIP_TRY(hipEventRecord(post->ev_ready[pk], post->ctx->lanes[LANE_POST]));
-        CSDR_HIP_TRY(hipStreamWaitEvent(st, post->ev_ready[pk], 0));
-    }
     if (b->audio_pending[bpar]) if (int rc = c->wait(b->ev_audio_done[bpar], LANE_AUDIO, LANE_FE)) return rc;
     {   // the tables of this batch: fetched from the page-locked staging slot by a kernel of this stream (bank_tables_fetch: why not a copy-engine transfer)
         const size_t bytes = b->off_plans + (size_t)b->max_demods * (NB + 1) * sizeof(BlockPlan);
@@ -494,8 +490,12 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
                     reinterpret_cast<const float4 *>(table_h), reinterpret_cast<float4 *>(table_d), n16);
         CSDR_HIP_TRY(hipGetLastError());
     }
-    CSDR_HIP_TRY(hipEventRecord(b->stage_ev[ring], st));
+    CSDR_HIP_TRY(hipEventRecord(b->stage_ev[ring], st));           // the staging slot is free again once the fetch has run
     b->stage_used[ring] = true;
+    if (post->ctx != c || !c->same(LANE_POST, LANE_FE)) {           // the channelizer output of this batch must be complete
+        if (post->ctx != c) CSDR_HIP_TRY(hipEventRecord(post->ev_ready[pk], post->ctx->lanes[LANE_POST]));
+        CSDR_HIP_TRY(hipStreamWaitEvent(st, post->ev_ready[pk], 0));
+    }
     // front-end geometry: every slot's batch is cut into P ranges; a range re-runs `warm` inputs in front of it.
     // Slots whose cascade has the reference's standard shape (m = 3..3, 5, 10; 3 <= S <= 6) run the specialised kernel,
     // one launch per depth S; anything else runs the generic one.
