@@ -22,6 +22,19 @@ def test_spread_and_sensors_without_a_gpu():
     assert s.stop().get("samples", 0) == 0 or s.files
 
 
+def test_only_the_json_line_reaches_stdout():
+    """libraries under bench.py write to file descriptor 1 (RCCL's version banner, gloo's connection notes): after claim_stdout() such writes land
+    on stderr and the stream it returns is the only way to the caller's stdout"""
+    code = ("import os, sys; sys.path.insert(0, %r); import bench\n"
+            "out = bench.claim_stdout()\n"
+            "os.write(1, b'banner from a library\\n'); print('a stray print')\n"
+            "out.write('{\"ok\": 1}\\n'); out.flush()\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == '{"ok": 1}\n', r.stdout
+    assert "banner from a library" in r.stderr and "a stray print" in r.stderr
+
+
 @pytest.mark.gpu
 def test_bench_gpus_2_launches_its_own_ranks_dry_run():
     import torch
