@@ -606,6 +606,33 @@ def main():
             dt = time.perf_counter() - tl
             lat[str(nb)] = {"MS_per_s": calls * nb * BLOCK / dt / 1e6, "blocks_per_s": calls * nb / dt, "ms_per_call": 1e3 * dt / calls,
                             "streams_at_60_blocks_per_s": calls * nb / dt / 60.0}
+            if nb == 1:
+                # the same one-block calls from TWO host threads, the reference's own thread cut (SDRPostThread drives the channelizer and the
+                # demodulators, SpectrumVisualDataThread the spectrum: cubicsdr_amd/host/HipPipeline.h runs them that way): a one-block call is
+                # bound by the host's enqueue time, which the two threads spend side by side (the C ABI calls release the GIL)
+                import threading
+                errs = []
+
+                def demod_side():
+                    try:
+                        for _ in range(calls):
+                            p2.execute(sub, 1, BLOCK, CENTER); b2.execute(p2)
+                    except Exception as e:      # noqa: BLE001
+                        errs.append(repr(e))
+
+                def spec_side():
+                    try:
+                        for _ in range(calls):
+                            s2.process(sub, 1, BLOCK, contiguous=True)
+                    except Exception as e:      # noqa: BLE001
+                        errs.append(repr(e))
+                ta, tb = threading.Thread(target=demod_side), threading.Thread(target=spec_side)
+                tl = time.perf_counter()
+                ta.start(); tb.start(); ta.join(); tb.join()
+                c2.synchronize()
+                dt2 = time.perf_counter() - tl
+                lat["1"]["two_host_threads"] = {"blocks_per_s": calls / dt2, "ms_per_call": 1e3 * dt2 / calls, "errors": errs,
+                                                "note": "channelizer + demodulators on one host thread, spectrum on another (the reference's thread cut)"}
             s2.close(); b2.close(); p2.close(); c2.close()
         out["config"]["small_batches"] = lat
     if rank == 0 and world == 1 and not args.no_latency:

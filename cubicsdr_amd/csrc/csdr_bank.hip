@@ -569,10 +569,13 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
                  fms_out_lds = ((size_t)2 * (fms_au + kFmsFirMax) + kFmsFirMax) * sizeof(float) + 64;
     if (n_fms && std::max(std::max(fms_pre_lds, fms_pll_lds), std::max(fms_mix_lds, fms_out_lds)) > kLdsPerWorkgroup)
         return reject(fail(CSDR_EUNSUPPORTED, "FM stereo: %d IQ samples per block need more LDS than a workgroup has", max_n_iq_fms));
-    const size_t want[7] = {fe_lds, modem_lds, audio_lds, n_fms ? fms_pre_lds : 0, n_fms ? fms_pll_lds : 0, n_fms ? fms_mix_lds : 0, n_fms ? fms_out_lds : 0};
-    const void *fn[7] = {(const void *)demod_frontend, (const void *)demod_modem, (const void *)demod_audio_interp,
-                         (const void *)fms_pre, (const void *)fms_pll, (const void *)fms_mix, (const void *)fms_out};
-    for (int k = 0; k < 7; ++k)
+    // a one-block batch without FM stereo runs modem and audio of a demodulator in ONE launch (demod_modem_audio1: one dependent kernel less in the call's chain)
+    const bool fused1 = NB == 1 && n_fms == 0;
+    const size_t want[8] = {fe_lds, modem_lds, audio_lds, n_fms ? fms_pre_lds : 0, n_fms ? fms_pll_lds : 0, n_fms ? fms_mix_lds : 0, n_fms ? fms_out_lds : 0,
+                            fused1 ? std::max(modem_lds, audio_lds) : 0};
+    const void *fn[8] = {(const void *)demod_frontend, (const void *)demod_modem, (const void *)demod_audio_interp,
+                         (const void *)fms_pre, (const void *)fms_pll, (const void *)fms_mix, (const void *)fms_out, (const void *)demod_modem_audio1};
+    for (int k = 0; k < 8; ++k)
         if (want[k] > 64 * 1024 && want[k] > b->lds_attr[k]) {
             CSDR_HIP_TRY(hipFuncSetAttribute(fn[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)want[k]));
             b->lds_attr[k] = want[k];
@@ -624,6 +627,11 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     if (int rc = c->signal(b->ev_fe_done[bpar], LANE_FE, LANE_AUDIO)) return rc;
     // lane AUDIO: modem + audio kernels of this batch
     if (int rc = c->wait(b->ev_fe_done[bpar], LANE_FE, LANE_AUDIO)) return rc;
+    if (fused1) {
+        if (n_audio_run > 0)
+            CSDR_LAUNCH(c, LANE_AUDIO, KID_AUDIO, demod_modem_audio1, dim3(n_audio_run), dim3(audio_threads), std::max(modem_lds, audio_lds), b->cfgs.p, dyns_d, lists_d, plans_d,
+                        cap_stream, b->mconsts.p, c->sintab.p, b->arms.p, cap_cw, cap_out, cap_win);
+    } else {
     // freqdem modems need no block-wide pre-pass: only the auto-gain modems run the modem kernel (grid: blocks first, see the kernel)
     if (n_ag > 0)
         CSDR_LAUNCH(c, LANE_AUDIO, KID_MODEM, demod_modem, dim3(NB, n_ag), dim3(audio_threads) /* one wave per block, like the audio kernel */, modem_lds, b->cfgs.p, dyns_d, lists_d + b->max_demods,
@@ -643,6 +651,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         CSDR_LAUNCH(c, LANE_AUDIO, KID_AUDIO, demod_audio_interp, dim3(n_fms, NB), dim3(audio_threads), audio_lds, b->cfgs.p, dyns_d, fms_d, plans_d, NB,
                     cap_out, cap_win, b->arms.p, 1);
         CSDR_LAUNCH(c, LANE_AUDIO, KID_FMS_OUT, fms_out, dim3(n_fms, NB), dim3(64), fms_out_lds, b->cfgs.p, dyns_d, fms_d, plans_d, NB, fms_au);
+    }
     }
     CSDR_HIP_TRY(hipGetLastError());
     if (int rc = c->signal(b->ev_audio_done[bpar], LANE_AUDIO, LANE_FE)) return rc;

@@ -109,7 +109,7 @@ struct csdr_bank {
     std::map<uint32_t, int> arm_index;       // key: bit pattern of rate_arb
     std::vector<float> arms_host;
     int n_run = 0, last_nb = 0;
-    size_t lds_attr[7] = {0, 0, 0, 0, 0, 0, 0};
+    size_t lds_attr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // the front-end launch lists of the last batch and what they were built from (slot, channel, cascade class per running slot): csdr_bank_execute
     std::vector<int> grp_key, grp_key_scratch, grp_list;
     int grp_off[8] = {0}, grp_n[8] = {0}, grp_rows[8] = {0};

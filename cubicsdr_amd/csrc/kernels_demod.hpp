@@ -1029,8 +1029,9 @@ __device__ inline void gain_step_single(const SlotCfg &cfg, const SlotDyn &dyn, 
     agc_out[0] = ceil_; agc_out[1] = ma; agc_out[2] = maa;
 }
 
-CSDR_KERNEL_BANK __launch_bounds__(kAudioThreads) void demod_modem(
-    const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
+// (the work of one workgroup = one wave, as a function: the kernel below calls it, and so does the fused modem + audio kernel of a one-block batch)
+__device__ __forceinline__ void demod_modem_body(
+    const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int slot, const int b,
     const BlockPlan *__restrict__ plans, int NB, int cap_stream, const ModemConsts *__restrict__ mc, const float *__restrict__ sintab,
     const float *__restrict__ arms_all, int cap_cw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1039,9 +1040,7 @@ CSDR_KERNEL_BANK __launch_bounds__(kAudioThreads) void demod_modem(
     double *s_red = reinterpret_cast<double *>(s_b + 3 * cap_stream);   // (CW carves the same memory differently, see below)
     float *s_redf = reinterpret_cast<float *>(s_red + 4);
 
-    // grid = (blocks, demodulators): the blocks of a demodulator are neighbours in dispatch order (measured on C3, ms per batch: 0.048; demodulators
-    // first 0.060; one XCD per demodulator -- id % 8 -- 0.061).  The audio kernel below is the other way round: 0.105 against 0.125.
-    const int slot = slot_list[blockIdx.y], b = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     constexpr int nthr = kAudioThreads;
     const SlotCfg &cfg = cfgs[slot];
     const SlotDyn dyn = dyns[slot];
@@ -1250,6 +1249,14 @@ CSDR_KERNEL_BANK __launch_bounds__(kAudioThreads) void demod_modem(
         if (NB == 1) gain_step_single(cfg, dyn, pl, bm);
     }
 }
+// grid = (blocks, demodulators): the blocks of a demodulator are neighbours in dispatch order (measured on C3, ms per batch: 0.048; demodulators
+// first 0.060; one XCD per demodulator -- id % 8 -- 0.061).  The audio kernel below is the other way round: 0.105 against 0.125.
+CSDR_KERNEL_BANK __launch_bounds__(kAudioThreads) void demod_modem(
+    const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
+    const BlockPlan *__restrict__ plans, int NB, int cap_stream, const ModemConsts *__restrict__ mc, const float *__restrict__ sintab,
+    const float *__restrict__ arms_all, int cap_cw) {
+    demod_modem_body(cfgs, dyns, slot_list[blockIdx.y], (int)blockIdx.x, plans, NB, cap_stream, mc, sintab, arms_all, cap_cw);
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // D2a': the auto-gain recurrence over the blocks of the batch (ModemAnalog.cpp:70-77, ModemCW.cpp:181-190), once per demodulator:
@@ -1322,8 +1329,8 @@ __device__ __forceinline__ void audio_x2_stage(const float *__restrict__ h, cons
 constexpr int kAudioMaxOut = 16384;        // audio samples of one block handled by one workgroup (likewise bounded by the LDS request)
 // dynamic LDS: two ping-pong arrays of `cap_out` floats, `cap_win` staged demodulator samples, 64 bytes of scratch
 
-CSDR_KERNEL_BANK __launch_bounds__(kAudioThreads) void demod_audio_interp(
-    const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
+__device__ __forceinline__ void demod_audio_body(
+    const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int slot, const int b,
     const BlockPlan *__restrict__ plans, int NB, int cap_out, int cap_win, const float *__restrict__ arms_all, int pass) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_w0 = reinterpret_cast<float *>(smem);
@@ -1332,7 +1339,7 @@ CSDR_KERNEL_BANK __launch_bounds__(kAudioThreads) void demod_audio_interp(
     double *s_red = reinterpret_cast<double *>(s_d + cap_win);
     float *s_redf = reinterpret_cast<float *>(s_red + 4);
 
-    const int slot = slot_list[blockIdx.x], b = blockIdx.y, tid = threadIdx.x;        // grid = (demodulators, blocks)
+    const int tid = threadIdx.x;
     constexpr int nthr = kAudioThreads;
     const SlotCfg &cfg = cfgs[slot];
     const SlotDyn dyn = dyns[slot];
@@ -1635,6 +1642,32 @@ CSDR_KERNEL_BANK __launch_bounds__(kAudioThreads) void demod_audio_interp(
             (cfg.dh + (size_t)kDHist * (dyn.hist_parity ^ 1))[td] = dv;
         }
     }
+}
+// grid = (demodulators, blocks)
+CSDR_KERNEL_BANK __launch_bounds__(kAudioThreads) void demod_audio_interp(
+    const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list,
+    const BlockPlan *__restrict__ plans, int NB, int cap_out, int cap_win, const float *__restrict__ arms_all, int pass) {
+    demod_audio_body(cfgs, dyns, slot_list[blockIdx.x], (int)blockIdx.y, plans, NB, cap_out, cap_win, arms_all, pass);
+}
+
+// A ONE-block batch (the real-time shape): modem and audio of a demodulator in ONE launch -- its single block is one wave in either kernel, the
+// auto-gain of the block depends on the carried state alone (gain_step_single), and a call's time is the chain of its dependent launches (DESIGN 6:
+// front-end -> modem -> audio was 19 + 8 + 17 us).  The wave's own stores (the modem's output, the gain) are read back behind a workgroup fence.
+// grid = demodulators of the audio stage
+CSDR_KERNEL_BANK __launch_bounds__(kAudioThreads) void demod_modem_audio1(
+    const SlotCfg *__restrict__ cfgs, const SlotDyn *__restrict__ dyns, const int *__restrict__ slot_list, const BlockPlan *__restrict__ plans,
+    int cap_stream, const ModemConsts *__restrict__ mc, const float *__restrict__ sintab, const float *__restrict__ arms_all, int cap_cw,
+    int cap_out, int cap_win) {
+    const int slot = slot_list[blockIdx.x];
+    const int modem = cfgs[slot].modem;
+    if (modem == CSDR_MODEM_AM || modem == CSDR_MODEM_USB || modem == CSDR_MODEM_LSB || modem == CSDR_MODEM_DSB || modem == CSDR_MODEM_CW) {
+        demod_modem_body(cfgs, dyns, slot, 0, plans, 1, cap_stream, mc, sintab, arms_all, cap_cw);
+#if defined(__AMDGCN__)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // the wave's global stores (the modem's output, the gain) before its loads of them
+#endif
+        __syncthreads();
+    }
+    demod_audio_body(cfgs, dyns, slot, 0, plans, 1, cap_out, cap_win, arms_all, 0);
 }
 
 }  // namespace csdr
