@@ -5,7 +5,9 @@
  * (SURVEY.md section 8b).  This header is the boundary a maintainer binds from those classes; every entry
  * point names the reference code it replaces (file:line relative to the reference tree).  Plain pointers
  * and sizes only; every call returns 0 on success or a negative CSDR_E* code and never throws.  A handle
- * must be used from one thread at a time (same rule as the reference objects: one owning IOThread each).
+ * must be used from one thread at a time (same rule as the reference objects: one owning IOThread each); different
+ * handles of one context may be used from different threads at once -- the reference's thread cut: SDRPostThread with
+ * its demodulators (csdr_post + csdr_bank: a call that takes two handles uses both) beside the spectrum thread (csdr_spec).
  *
  * Sample format everywhere: interleaved complex float32 {re, im} (liquid_float_complex, liquid.h:149-157).
  * "dev" pointers are HIP device pointers resident in HBM; "host" pointers are ordinary host memory.
