@@ -671,13 +671,16 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
                 }
                 {                                             // columns c and A - c trade: s_c = x_c + x_{A-c} at row c, d_c = x_c - x_{A-c} at row A - c
                     // (one component at a time: a float4 of partner values at once is one more spilled float4 in this phase)
+                    // p + sg acc with sg = +1 on the s lanes, -1 on the d lanes: ONE multiply-add per component in place of two selects, an add and a subtract
+                    // (x + y and fma(1, x, y) are the same single rounding: bit-identical); the lanes outside 1 .. A - 1 keep their own value
                     const int pl = (lane >= 1 && lane < A) ? A - lane : lane;
-                    const bool is_s = lane >= 1 && lane <= H, is_d = lane > H && lane < A;
+                    const bool is_sd = lane >= 1 && lane < A;
+                    const float sg = lane <= H ? 1.0f : -1.0f;
                     float p;
-                    p = __shfl(acc.x, pl, 64); acc.x = is_s ? acc.x + p : (is_d ? p - acc.x : acc.x);
-                    p = __shfl(acc.y, pl, 64); acc.y = is_s ? acc.y + p : (is_d ? p - acc.y : acc.y);
-                    p = __shfl(acc.z, pl, 64); acc.z = is_s ? acc.z + p : (is_d ? p - acc.z : acc.z);
-                    p = __shfl(acc.w, pl, 64); acc.w = is_s ? acc.w + p : (is_d ? p - acc.w : acc.w);
+                    p = __shfl(acc.x, pl, 64); acc.x = is_sd ? fmaf(sg, acc.x, p) : acc.x;
+                    p = __shfl(acc.y, pl, 64); acc.y = is_sd ? fmaf(sg, acc.y, p) : acc.y;
+                    p = __shfl(acc.z, pl, 64); acc.z = is_sd ? fmaf(sg, acc.z, p) : acc.z;
+                    p = __shfl(acc.w, pl, 64); acc.w = is_sd ? fmaf(sg, acc.w, p) : acc.w;
                 }
                 if (col) rows[(ta + i) * A + lane] = acc;
                 sched_fence();                                // frame after frame
