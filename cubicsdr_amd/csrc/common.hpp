@@ -136,6 +136,14 @@ __device__ inline void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// issue priority of this wave among the waves of its SIMD (s_setprio 0 .. 3; 0 is what a wave starts with)
+__device__ __forceinline__ void wave_priority(const int p) {
+#if defined(__AMDGCN__)
+    if (p == 0) __builtin_amdgcn_s_setprio(0); else if (p == 1) __builtin_amdgcn_s_setprio(1); else if (p == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
+#else
+    (void)p;
+#endif
+}
 // keep the compiler's scheduler from moving instructions across this point (software-pipelined loops: requests for the next
 // iteration stay in front of the arithmetic of the current one instead of being sunk to their first use)
 __device__ __forceinline__ void sched_fence() {

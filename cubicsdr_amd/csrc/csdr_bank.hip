@@ -246,6 +246,37 @@ extern "C" int csdr_bank_set_active(csdr_bank *b, int slot, int active) {
 
 // the smallest j with j * step >= K 2^24 - phase0 (K may be negative): the device's closed form (kernels_demod.hpp: a double quotient and two
 // integer corrections -- exact, and a third of the cost of the 64-bit division this walk used to pay twice per demodulator and block)
+// The front-end's oscillator table in LDS (kernels_demod.hpp: fes_tab_slot): rows of 32 words, row r rotated by rot * r columns.  The table reads of
+// 32 consecutive lanes are the progression (theta0 + 2 p dtheta) >> 22: the rotation with the fewest addresses per bank, over a fixed set of starting
+// phases and both samples of a lane's pair.  A layout choice only: any value computes the same samples.
+static uint32_t fe_table_rotation(uint32_t dtheta) {
+#ifdef CSDR_FE_NOROT
+    return 0;                                                      // (A/B builds: the plain table order)
+#endif
+    if (!dtheta) return 0;
+    uint32_t best = 0;
+    int best_cost = 1 << 30;
+    for (uint32_t rot = 0; rot < 32; rot += 4) {       // multiples of 4: entry i + 256 (the cosine, eight rows on) then sits 256 words after entry i
+        int cost = 0;
+        for (uint32_t trial = 0; trial < 24; ++trial) {
+            const uint32_t th0 = 0x9E3779B9u * (trial + 1u) + (trial & 1u) * dtheta, base = 32u * (trial * 5u);     // lane group of 32 inside a chunk
+            uint16_t addr[32][32];
+            int cnt[32] = {0};
+            int worst = 0;
+            for (uint32_t l = 0; l < 32; ++l) {
+                const uint32_t th = th0 + 2u * (base + l) * dtheta, i = (th + (1u << 21)) >> 22;
+                const uint32_t a = ((i + rot * (i >> 5)) & 31u) | (i & ~31u), bk = a & 31u;
+                bool seen = false;
+                for (int k = 0; k < cnt[bk]; ++k) seen |= addr[bk][k] == (uint16_t)a;
+                if (!seen) { addr[bk][cnt[bk]++] = (uint16_t)a; worst = std::max(worst, cnt[bk]); }
+            }
+            cost += worst;
+        }
+        if (cost < best_cost) { best_cost = cost; best = rot; }
+    }
+    return best;
+}
+
 static inline int64_t first_out(int64_t K, uint32_t phase0, uint32_t step) { return resamp_first_out(K, phase0, step); }
 
 extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
@@ -322,8 +353,10 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         const int bound = (int)((double)(rate / 2) * 1.5);
         if (!s.shift_valid || shift != s.shift_frequency) {
             s.shift_frequency = shift; s.shift_valid = true;
-            if (std::llabs(shift) <= bound)
+            if (std::llabs(shift) <= bound) {
                 s.dtheta = design::nco_phase_word((float)((2.0 * M_PI) * (((double)std::llabs(shift)) / ((double)rate))));
+                s.tab_rot = fe_table_rotation(s.dtheta);
+            }
         }
         const bool skipped = std::llabs(shift) > bound;
         s.results.resize(NB);
@@ -333,7 +366,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
         }
         SlotDyn &d = dyns_h[si];
         memset(&d, 0, sizeof d);
-        d.active = 1; d.chan = data_ch; d.theta0 = s.theta; d.dtheta = s.dtheta;
+        d.active = 1; d.chan = data_ch; d.theta0 = s.theta; d.dtheta = s.dtheta; d.tab_rot = s.tab_rot;
         d.mixdir = shift == 0 ? 0 : (shift < 0 ? +1 : -1);          // :186-191: shift < 0 -> mix up
         d.buf0 = s.buf_idx; d.phase0 = s.phase; d.aphase0 = s.aphase; d.abuf0 = s.abuf; d.ssb_theta0 = s.ssb_theta; d.cw_dtheta = s.cw_dtheta; d.hist_parity = s.hist_parity;
         d.prev_j = s.prev_J;

@@ -62,6 +62,7 @@ struct SlotHost {
     int64_t chan_rate = 0;
     // integer state mirrored on the host (closed-form bookkeeping)
     uint32_t theta = 0, dtheta = 0, buf_idx = 0, phase = 0, aphase = 0, abuf = 0, ssb_theta = 0, cw_dtheta = 0;
+    uint32_t tab_rot = 0;                    // layout of the oscillator table in the front-end's LDS for this dtheta (fe_table_rotation)
     long long shift_frequency = 0;
     bool shift_valid = false;
     int hist_parity = 0, last_parity = 0;

@@ -85,6 +85,7 @@ struct SlotDyn {                  // per batch
     uint32_t cw_dtheta;           // CW beep oscillator increment per audio sample
     int32_t hist_parity;
     int32_t prev_j;               // resampled-IQ samples the previous batch produced (its tail is this batch's history)
+    uint32_t tab_rot;             // demod_frontend_s: column rotation per row of the oscillator table in LDS (fes_tab_slot; the host picks it for dtheta)
 };
 
 struct BlockPlan { int32_t j0, q0; };   // first IQ output / first audio-arbitrary output of the block (batch-relative)
@@ -458,6 +459,12 @@ CSDR_KERNEL_BANK __launch_bounds__(kFeThreads, 4) void demod_frontend(
 // grid = (P + 1, slots of this S).  Bit-identical to demod_frontend.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kFeTabLen = 1024 + 256;
+// Where entry i of the oscillator table sits in LDS: row i >> 5 keeps its 32 words, its columns are rotated by rot * row.  The table reads of a wave are
+// an arithmetic progression of the demodulator's phase increment over 32 banks: in the plain order thirty-two lanes meet 3.6 times per bank on average
+// (C3), with the rotation the host picks for the increment (csdr_bank.hip: fe_table_rotation: a multiple of 4, so that the cosine -- 256 entries = eight rows on -- keeps the sine's column and the
+// two come from one two-address read) 2.2 times.  Values and order of the
+// arithmetic are untouched: bit-identical.
+__device__ __forceinline__ uint32_t fes_tab_slot(uint32_t i, uint32_t t /* i + rot * (i >> 5) (+ a multiple of 32) */) { return (t & 31u) | (i & ~31u); }
 template <int CH>
 __host__ __device__ constexpr int fes_off(int e) { return e * kFeTail + CH - (CH >> e); }
 template <int S, int CH>
@@ -584,7 +591,7 @@ template <int S, int CH, int NPF>
 __device__ __forceinline__ void fes_mix_chunk(const float4 (&pf)[NPF], int64_t rel0, const SlotDyn &dyn, float sgn, const float *__restrict__ tab,
                                               float2 *__restrict__ LE, float2 *__restrict__ LO, int tid) {
     float2 *e0 = LE + kFeTail, *o0 = LO + fes_offo<S, CH>(0) + kFeTail;
-    const uint32_t th0 = dyn.theta0 + (uint32_t)rel0 * dyn.dtheta;
+    const uint32_t th0 = dyn.theta0 + (uint32_t)rel0 * dyn.dtheta, rot = dyn.tab_rot;
     if (dyn.mixdir != 0 && rel0 >= 0) {                          // (chunk-uniform)
         float ts[NPF][4];
 #pragma unroll
@@ -592,7 +599,8 @@ __device__ __forceinline__ void fes_mix_chunk(const float4 (&pf)[NPF], int64_t r
             const int p = tid + q * kFeThreads;
             const uint32_t tha = th0 + (uint32_t)(2 * p) * dyn.dtheta, thb = tha + dyn.dtheta;
             const uint32_t ia = (tha + (1u << 21)) >> 22, ib = (thb + (1u << 21)) >> 22;          // 0 .. 1023
-            ts[q][0] = tab[ia]; ts[q][1] = tab[ia + 256]; ts[q][2] = tab[ib]; ts[q][3] = tab[ib + 256];
+            const uint32_t sa = fes_tab_slot(ia, ia + rot * (ia >> 5)), sb = fes_tab_slot(ib, ib + rot * (ib >> 5));     // cosine: eight rows on, the same column (rot is a multiple of 4)
+            ts[q][0] = tab[sa]; ts[q][1] = tab[sa + 256]; ts[q][2] = tab[sb]; ts[q][3] = tab[sb + 256];
         }
         if (dyn.mixdir < 0) {
 #pragma unroll
@@ -621,7 +629,8 @@ __device__ __forceinline__ void fes_mix_chunk(const float4 (&pf)[NPF], int64_t r
         if (do_mix) {
             const uint32_t tha = th0 + (uint32_t)(2 * p) * dyn.dtheta, thb = tha + dyn.dtheta;
             const uint32_t ia = (tha + (1u << 21)) >> 22, ib = (thb + (1u << 21)) >> 22;
-            const float sa = tab[ia] * sgn, ca = tab[ia + 256], sb = tab[ib] * sgn, cb = tab[ib + 256];
+            const uint32_t ja = fes_tab_slot(ia, ia + rot * (ia >> 5)), jb = fes_tab_slot(ib, ib + rot * (ib >> 5));
+            const float sa = tab[ja] * sgn, ca = tab[ja + 256], sb = tab[jb] * sgn, cb = tab[jb + 256];
             if (rel0 + 2 * p >= 0) a = make_float2(fmaf(a.x, ca, -(a.y * sa)), fmaf(a.y, ca, a.x * sa));
             if (rel0 + 2 * p + 1 >= 0) b = make_float2(fmaf(b.x, cb, -(b.y * sb)), fmaf(b.y, cb, b.x * sb));
         }
@@ -663,7 +672,8 @@ __device__ __forceinline__ void fes_body(
     float2 *LZ = LO + ALEN + 2;
     float *tab = reinterpret_cast<float *>(LZ + kFeZTail + CZ);
     float *hb = tab + kFeTabLen;
-    for (int i = tid; i < kFeTabLen; i += kFeThreads) tab[i] = sintab[i & 1023];
+    const uint32_t rot = part == P ? 0u : dyn.tab_rot;            // (the carried-stream workgroup reads the table through nco_sincos: plain order)
+    for (int i = tid; i < kFeTabLen; i += kFeThreads) tab[fes_tab_slot((uint32_t)i, (uint32_t)i + rot * ((uint32_t)i >> 5))] = sintab[i & 1023];
 
     if (part == P) {
         // ---- carried streams of this demodulator (one workgroup): resampled-IQ history and mixed-input history

@@ -14,9 +14,13 @@ g = torch.Generator(device=dev); g.manual_seed(1)
 ring = torch.randn(NB * BLOCK, 2, generator=g, device=dev, dtype=torch.float32) * 0.05
 os.environ.setdefault("CSDR_STREAMS", "1")
 ctx = Context(0); post = SDRPost(ctx, FS, M, BLOCK, max_blocks=NB)
-for _ in range(100): post.execute(ring, NB, BLOCK, bench.CENTER)
+WARM, N = int(os.environ.get('CQ_WARM', 100)), int(os.environ.get('CQ_N', 200))
+for _ in range(WARM): post.execute(ring, NB, BLOCK, bench.CENTER)
 ctx.synchronize(); ctx.profile_enable(1)
-for _ in range(200): post.execute(ring, NB, BLOCK, bench.CENTER)
+for _ in range(N): post.execute(ring, NB, BLOCK, bench.CENTER)
 ctx.synchronize()
 ms, n, _ = ctx.profile()["chan_analyze"]; lo, hi = ctx.profile_range()["chan_analyze"]
-print(json.dumps({"args": sys.argv[1:], "kernel_ms_mean": round(ms / n, 4), "min": round(lo, 4), "max": round(hi, 4), "frac_of_8TBps": round(16 * NB * BLOCK / (ms / n * 1e-3) / 8e12, 3)}))
+import hashlib
+h = hashlib.sha256()
+for ch in (0, 1, 30, 60, 61, 62, 121): h.update(post.read_channel(ch).tobytes())       # the same input in every run: equal digests = bit-identical rows
+print(json.dumps({"args": sys.argv[1:], "rows_sha256": h.hexdigest()[:16], "kernel_ms_mean": round(ms / n, 4), "min": round(lo, 4), "max": round(hi, 4), "frac_of_8TBps": round(16 * NB * BLOCK / (ms / n * 1e-3) / 8e12, 3)}))
