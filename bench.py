@@ -103,6 +103,9 @@ def cascade_depth(bw, chan_rate):
     return S
 
 
+MERGED_56 = None     # set from the kernel ids the library really launched (main); None: the library's rule with MI355X's 1024 resident workgroups
+
+
 def frontend_groups(cfg):
     """demodulators per front-end kernel instance (one launch per cascade depth, csdr_bank.hip: csdr_bank_execute)"""
     out = {}
@@ -114,7 +117,7 @@ def frontend_groups(cfg):
     # depths 5 and 6 share one launch (demod_frontend_s56) when together they still get three ranges per demodulator (csdr_bank_execute: 4 (n5 + n6)
     # <= resident workgroups, 4 per CU x 256 CUs on MI355X)
     n5, n6 = out.get("demod_frontend_s5", 0), out.get("demod_frontend_s6", 0)
-    if n5 and n6 and 4 * (n5 + n6) <= 1024:
+    if n5 and n6 and (MERGED_56 if MERGED_56 is not None else 4 * (n5 + n6) <= 1024):
         out["demod_frontend_s56"] = n5 + n6
         del out["demod_frontend_s5"], out["demod_frontend_s6"]
     return out
@@ -376,8 +379,14 @@ def main():
     ap.add_argument("--blocks", type=int, default=0, help="IQ blocks per batch (HBM-resident ring); default per config")
     ap.add_argument("--batches", type=int, default=0, help="batches per step; default per config (a step is ~0.1-0.2 s of GPU work)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline sample budget per leg (0 disables)")
-    ap.add_argument("--shard", default="broadcast", choices=["broadcast", "slab"],
-                    help="--config C4 only: how the ONE stream is spread over the GPUs (broadcast + channel subsets, or time slabs + all-to-all)")
+    ap.add_argument("--shard", default="auto", choices=["auto", "broadcast", "slab"],
+                    help="--config C4 only: how the ONE stream is spread over the GPUs (broadcast + channel subsets, or time slabs + all-to-all); auto: "
+                         "parallel.strong_scaling_plan picks by the link model for this number of GPUs")
+    ap.add_argument("--ingest", default="distributed", choices=["distributed", "rank0"],
+                    help="--config C4 --shard slab: every rank holds its own time slab (its own reader; here the same synthetic ring on every rank) or "
+                         "rank 0 holds the stream and scatters windows over xGMI")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false",
+                    help="--config C4 --shard slab: row exchange of a batch NOT overlapped with the next batch's channelizer (the one-call form)")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2, 3, 5],
                     help="physical HIP streams the stages of the TIMED pipeline are folded onto (default 1: every kernel runs alone, so the live "
                          "per-kernel durations and roofline.frac are the kernel's own; the library's default folding is 3, measured next to it)")
@@ -515,9 +524,12 @@ def main():
         n_batches = args.steps * NBATCH
         # per kernel id: average launch duration (HIP events, every PROFILE_PERIOD-th launch) x the launches per batch the library
         # really made (all launches are counted, bracketed or not) = its time per batch
+        global MERGED_56
+        MERGED_56 = "demod_frontend_s56" in prof          # what the library launched, not a rule restated here
         avg = {k: v[0] / v[1] for k, v in prof.items()}
         per_batch = {k: avg[k] * (v[2] / n_batches) for k, v in prof.items()}
         dom = max(per_batch, key=lambda k: per_batch[k])
+        co_dominant = [k for k in sorted(per_batch, key=lambda k: -per_batch[k]) if k != dom and per_batch[k] >= 0.97 * per_batch[dom]]
         avg_ms = avg[dom]
         launches_dom = prof[dom][2] / n_batches
         bps = algorithmic_bytes_per_sample(dom, cfg)
@@ -533,10 +545,26 @@ def main():
         for st in stages.values():
             st["achieved_GBps"] = st["algorithmic_bytes_per_sample"] * units / (st["ms_per_batch"] * 1e-3) / 1e9 if st["ms_per_batch"] > 0 else None
             st["frac"] = st["achieved_GBps"] / HBM_PEAK_GBS if st["achieved_GBps"] is not None else None
+        # per kernel: time per batch, the fraction of the roofline by ALGORITHMIC bytes and by the bytes the counters saw it move
+        # (`frac_traffic`: committed PMC pass / this run's live time -- lower than `frac` where cache hits serve algorithmic bytes, higher where
+        # a kernel re-reads)
+        kernels = {}
+        for k in sorted(per_batch, key=lambda k: -per_batch[k]):
+            t_s = per_batch[k] * 1e-3
+            ab = algorithmic_bytes_per_sample(k, cfg)
+            kernels[k] = {"ms_per_batch": per_batch[k], "algorithmic_bytes_per_sample": ab,
+                          "frac": (ab * units / t_s / 1e9 / HBM_PEAK_GBS) if t_s > 0 and ab > 0 else None,
+                          "traffic_bytes_per_sample": (traffic[k] / BLOCK if k in traffic else None),
+                          "frac_traffic": (traffic[k] * NB / t_s / 1e9 / HBM_PEAK_GBS) if t_s > 0 and k in traffic else None}
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS,
+                           "frac_traffic": kernels[dom]["frac_traffic"],
+                           "co_dominant": {k: {"ms_per_batch": per_batch[k], "frac": kernels[k]["frac"], "frac_traffic": kernels[k]["frac_traffic"]} for k in co_dominant},
+                           "dominant_rule": "largest time per batch by this run's HIP events (agrees with rocprofv3: profiles/); kernels within 3 % of it are listed as co_dominant",
                            "traffic": (traffic[dom] * NB / launches_dom if dom in traffic else None),
                            "traffic_unit": "HBM bytes per launch of the dominant kernel (PMC pass %s: per IQ block, times the blocks of this launch)" % traffic_file,
+                           "traffic_source": "NOT measured in this run: read from the committed rocprofv3 counter pass %s (profiles/collect.sh: FETCH_SIZE x 2 + WRITE_SIZE, own passes, noise ring)" % traffic_file,
+                           "kernels": kernels,
                            "avg_launch_ms": avg_ms, "launch_ms_range": list(prof_rng.get(dom, (None, None))), "launches_per_batch": launches_dom,
                            "algorithmic_bytes_per_launch": alg_launch,
                            "whole_path": {"bytes_per_sample": round(bytes_per_sample, 1), "achieved": bytes_per_sample * value / world * 1e6 / 1e9,
@@ -689,7 +717,8 @@ def main():
         try:
             from cubicsdr_amd import sharded_bench
             sargs = argparse.Namespace(**vars(args))
-            sargs.shard, sargs.blocks, sargs.batches, sargs.steps, sargs.warmup = "slab", 32, 6, max(2, min(args.steps, 5)), 1
+            sargs.shard, sargs.blocks, sargs.batches, sargs.steps, sargs.warmup = "auto", 32, 6, max(2, min(args.steps, 5)), 1
+            sargs.ingest, sargs.overlap = "distributed", True
             sargs.no_profile, sargs.cpu_seconds, sargs.streams = True, 0.0, 3
             so = sharded_bench.measure(sargs, dist=dist)
             out["strong"] = {"workload": so["config"]["workload"], "value": so["value"], "unit": "MS/s", "scaling": "strong", "n_gpus": world,

@@ -49,6 +49,7 @@ struct csdr_post {
     bool dc_enabled = true;                  // csdr_post_set_dc_blocker: a time-slab producer leaves channel 0 to the rank that owns it
     size_t out_off = 0;                      // samples between the allocation's base and the first output buffer (0 unless the measurement build moves it: CSDR_OUT_OFFSET_KB)
     int import_k = -1;                       // buffer being assembled by csdr_post_import_begin .. commit
+    bool rotate = false;                     // the output is read from a stream that is no lane (csdr_post_exchange_rows_begin's transfers): the buffers rotate whatever the stream folding
     std::map<std::vector<int>, int *> rowlists;   // device copies of the channel lists export / import calls name (a handful, reused every batch)
 };
 static inline float2 *post_buf(const csdr_post *p, int k) { return p->out.p + p->out_off + (size_t)k * p->chan_stride * p->M; }

@@ -336,8 +336,9 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
     p->n_blocks = n_blocks; p->block_len = block_len;
     // next output buffer of the rotation: its previous readers (demodulator front-ends, three batches ago) must be done
     // (stages that share one stream are ordered by it: a single buffer keeps the working set inside the Infinity Cache)
-    const int k = c->same(LANE_POST, LANE_FE) ? 0 : (int)(p->seq % csdr_post::kPostBufs);
-    if (!c->same(LANE_FE, LANE_POST))
+    const bool rotating = p->rotate || !c->same(LANE_POST, LANE_FE);
+    const int k = rotating ? (int)(p->seq % csdr_post::kPostBufs) : 0;
+    if (rotating)
         for (int q = 0; q < p->n_consumed[k]; ++q) CSDR_HIP_TRY(hipStreamWaitEvent(st, p->ev_consumed[k][q], 0));
     p->n_consumed[k] = 0;
     float2 *out = post_buf(p, k);

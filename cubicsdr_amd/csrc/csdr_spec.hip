@@ -34,6 +34,7 @@ struct csdr_spec {
     uint64_t seq = 0;
     hipEvent_t ev_fft_done[2] = {nullptr, nullptr}, ev_avg_done[2] = {nullptr, nullptr};
     bool avg_pending[2] = {false, false};
+    int tmp_reader = -1;                     // magnitude copy whose ev_avg_done also covers a reader of `tmp` on lane AVG (the fused chain's row pass), -1: none
     DevBuf<double> ma, maa;
     DevBuf<float2> ext_w, ext;
     int n_avg_tiles = 0, scal_parity = 0;
@@ -119,7 +120,7 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     if (N > (1 << 22) || (npot && 2 * (int64_t)N - 1 > (1 << 22))) return fail(CSDR_EUNSUPPORTED, "internal FFT of %d points exceeds 2^22%s", N, npot ? " (the chirp-z convolution of a size that is not a power of two is twice as long)" : "");
     if (int rc = s->ctx->sync_all()) return rc;
     s->ready = false;
-    s->seq = 0; s->avg_pending[0] = s->avg_pending[1] = false;
+    s->seq = 0; s->avg_pending[0] = s->avg_pending[1] = false; s->tmp_reader = -1;
     SpecGeom &g = s->g;
     g.N = N; g.F = fft_size; g.Ra = 1; g.Rb = 1; g.N2 = N; g.npot = npot ? 1 : 0;
     s->blue_L = 0; s->blue_big = false;
@@ -504,6 +505,10 @@ static int spec_fft_then(csdr_spec *s, const FrameSrc &fs, int nf, PostFn post) 
     const int mp = (c->same(LANE_FFT, LANE_AVG) || s->fused_now) ? 0 : (int)(s->seq & 1);      // (fused: the one intermediate buffer is the hand-off)
     float *mag = s->mag.p + (size_t)mp * s->max_frames * s->g.N;
     if (s->avg_pending[mp]) if (int rc = c->wait(s->ev_avg_done[mp], LANE_AVG, LANE_FFT)) return rc;
+    // `tmp` is the fused chain's hand-off: its row pass reads it on lane AVG.  Whatever runs next on lane FFT rewrites it (a radix pass of the
+    // general chain as well, after peak hold was switched on), so that reader is waited for whichever magnitude copy this batch takes
+    if (s->tmp_reader >= 0 && s->tmp_reader != mp) if (int rc = c->wait(s->ev_avg_done[s->tmp_reader], LANE_AVG, LANE_FFT)) return rc;
+    s->tmp_reader = -1;
     if (int rc = spec_run_fft(s, fs, nf, mag, nullptr)) return rc;
     if (int rc = c->signal(s->ev_fft_done[mp], LANE_FFT, LANE_AVG)) return rc;
     // lane AVG: averaging, extrema, trackers + display points
@@ -511,6 +516,7 @@ static int spec_fft_then(csdr_spec *s, const FrameSrc &fs, int nf, PostFn post) 
     if (int rc = post(mag)) return rc;
     if (int rc = c->signal(s->ev_avg_done[mp], LANE_AVG, LANE_FFT)) return rc;
     s->avg_pending[mp] = true;
+    if (s->fused_now) s->tmp_reader = mp;
     s->seq++;
     return CSDR_OK;
 }
@@ -808,6 +814,7 @@ extern "C" int csdr_spec_fft_only(csdr_spec *s, const float *iq_host, float *out
     if (!s || !s->ready || !iq_host || !out_host) return fail(CSDR_EINVAL, "bad argument");
     hipStream_t st = s->ctx->lanes[LANE_FFT];
     const int N = s->g.N;
+    if (s->tmp_reader >= 0) { CSDR_HIP_TRY(hipStreamSynchronize(s->ctx->lanes[LANE_AVG])); s->tmp_reader = -1; }      // (a fused batch's row pass may still read the intermediate rows)
     if (int rc = s->stage_in.reserve((size_t)N)) return rc;
     if (int rc = s->raw.reserve((size_t)N)) return rc;
     CSDR_HIP_TRY(hipMemcpyAsync(s->stage_in.p, iq_host, (size_t)N * sizeof(float2), hipMemcpyHostToDevice, st));

@@ -555,6 +555,32 @@ class Comm:
         H.check(self._l.csdr_post_exchange_rows(self.h, producer.h, owner.h, ch.ctypes.data_as(C.c_void_p), nch.ctypes.data_as(C.c_void_p),
                                                 f0.ctypes.data_as(C.c_void_p), fr.ctypes.data_as(C.c_void_p), int(n_blocks), int(block_len), int(frequency)))
 
+    def exchange_rows_begin(self, producer, owned, frame0, frames):
+        """first half of exchange_rows: the transfers of the producer's current batch, on the communicator's own stream"""
+        ch = np.ascontiguousarray([c for o in owned for c in o] or [0], dtype=np.int32)
+        nch = np.ascontiguousarray([len(o) for o in owned], dtype=np.int32)
+        f0 = np.ascontiguousarray(frame0, dtype=np.int64)
+        fr = np.ascontiguousarray(frames, dtype=np.int64)
+        assert nch.size == self.world and f0.size == self.world and fr.size == self.world
+        H.check(self._l.csdr_post_exchange_rows_begin(self.h, producer.h, ch.ctypes.data_as(C.c_void_p), nch.ctypes.data_as(C.c_void_p),
+                                                      f0.ctypes.data_as(C.c_void_p), fr.ctypes.data_as(C.c_void_p)))
+
+    def exchange_rows_finish(self, owner, n_blocks, block_len, frequency):
+        """second half, for the oldest batch begun: import into the owner behind that batch's transfers, commit"""
+        H.check(self._l.csdr_post_exchange_rows_finish(self.h, owner.h, int(n_blocks), int(block_len), int(frequency)))
+        owner._last = (int(n_blocks), int(block_len))
+
+    @property
+    def exchanges_pending(self):
+        return int(self._l.csdr_comm_exchanges_pending(self.h))
+
+    def abort(self):
+        H.check(self._l.csdr_comm_abort(self.h))
+
+    def async_error(self):
+        """raises if a transfer of this communicator has failed (the communicator is then aborted on this rank too)"""
+        H.check(self._l.csdr_comm_async_error(self.h))
+
     def close(self):
         if self.h:
             self._l.csdr_comm_destroy(self.h)

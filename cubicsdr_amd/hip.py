@@ -162,6 +162,11 @@ ABI = {
     "csdr_comm_max": (_i, [_p, C.POINTER(_d)]),
     "csdr_comm_barrier": (_i, [_p]),
     "csdr_post_exchange_rows": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64]),
+    "csdr_post_exchange_rows_begin": (_i, [_p, _p, _p, _p, _p, _p]),
+    "csdr_post_exchange_rows_finish": (_i, [_p, _p, _i, _i, _i64]),
+    "csdr_comm_exchanges_pending": (_i, [_p]),
+    "csdr_comm_abort": (_i, [_p]),
+    "csdr_comm_async_error": (_i, [_p]),
     "csdr_ingest_next_slot": (_i, [_p]),
 }
 

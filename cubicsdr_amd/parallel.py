@@ -192,6 +192,34 @@ class ShardedStream:
         self.bank.close(); self.post.close(); self.ctx.close()
 
 
+def strong_scaling_plan(world: int, batch_bytes: float, kernels_ms_one_gpu: float, ingest: str = "distributed", link_GBps: float = 115.0,
+                        chan_share: float = 0.33, row_bytes: float = None):
+    """Which way to run ONE stream on `world` GPUs, from a link model (xGMI is point-to-point: one link per peer pair, ~115 GB/s sustained of
+    153 peak) and the one-GPU kernel time of a batch.  Returns {"choice", "ms": {variant: projected batch time}}; variants:
+      single     one GPU does everything (the others idle): kernels_ms_one_gpu
+      broadcast  ShardedStream: the raw batch crosses every link whole; each rank runs the channelizer's FIR over every frame (chan_share of
+                 the one-GPU kernels stays undivided) and 1 / world of the rest
+      slab       SlabStream with step(overlap=True): every rank channelizes 1 / world of the frames; rows_bytes / world^2 cross each link, hidden
+                 behind the next batch's kernels when shorter; ingest "rank0" adds the scatter of 1 / world of the batch over each link
+                 (the same links, in front of the kernels), "distributed" (every rank reads its own slab: local_window) adds nothing.
+    The choice is the smallest projected time: at world = 2 the one link carries a quarter of all channel samples (and, with rank-0 ingest,
+    half of the input): a free-running stream is then link-bound on two GPUs and `single` wins unless the demodulators do not FIT one GPU --
+    pass kernels_ms_one_gpu = inf in that case.  At real-time rates (0.8 GB/s per 100 MS/s stream) every variant is far inside one link and the
+    choice is by capacity only."""
+    if world < 1:
+        raise ValueError("world")
+    row_bytes = batch_bytes if row_bytes is None else row_bytes          # channel rows of a batch: 8 B per input sample, like the input
+    link = link_GBps * 1e6                                               # bytes per ms
+    ms = {"single": kernels_ms_one_gpu}
+    if world > 1:
+        ms["broadcast"] = max(batch_bytes / link, kernels_ms_one_gpu * (chan_share + (1.0 - chan_share) / world))
+        exch = row_bytes / (world * world) / link
+        scat = batch_bytes / world / link if ingest == "rank0" else 0.0
+        ms["slab"] = max(kernels_ms_one_gpu / world, exch + scat)
+    choice = min(ms, key=lambda k: (ms[k], k))
+    return {"choice": choice, "ms": ms, "speedup_over_one_gpu": kernels_ms_one_gpu / ms[choice] if ms[choice] > 0 else None}
+
+
 def slab_blocks(n_blocks: int, world: int):
     """[(first block, blocks)] per rank: contiguous, the remainder on the first ranks"""
     base, rem = divmod(n_blocks, world)
@@ -254,6 +282,7 @@ class SlabStream:
             self._tail = self._empty(self.hist)                     # ingest rank: the input in front of the next batch
             self._zero(self._tail)
         self._keep = []
+        self._pend = None                                           # step(overlap=True): the batch between the two halves of its exchange
 
     # ---- buffers
     def _empty(self, n_samples):
@@ -437,24 +466,71 @@ class SlabStream:
             if self.plan.demods:
                 self.bank.execute(self.rows)
 
-    def step(self, window, n_blocks):
+    def step(self, window, n_blocks, overlap=False):
+        """one batch.  overlap=True runs the software pipeline of csdr_hip.h "The same exchange in two halves": this batch is channelized and its
+        row transfers are started, THEN the previous batch is imported and demodulated -- the transfers of batch i run beside the channelizer of
+        batch i + 1.  The results of a batch (audio, results) are then complete after the NEXT step(overlap=True) or after flush(); they are the
+        sequential form's bit for bit."""
         if self.comm is None:
-            self.consume(self.exchange(self.produce(window, n_blocks), n_blocks), n_blocks)
+            if not overlap:
+                self.consume(self.exchange(self.produce(window, n_blocks), n_blocks), n_blocks)
+                return
+            recv = self.exchange(self.produce(window, n_blocks), n_blocks)     # (torch.distributed collectives return when they are done: the order is what this mode checks)
+            if self._pend is not None:
+                self.consume(*self._pend)
+            self._pend = (recv, n_blocks)
             return
-        # through the C ABI: producer execute, then the row exchange (RCCL) -> import -> commit in ONE call
+        # through the C ABI: producer execute, then the row exchange (RCCL) -> import -> commit
         sl = slab_blocks(n_blocks, self.world)
         start, cnt = sl[self.rank]
         tail, blocks = window if isinstance(window, tuple) else (window[:self.hist], window[self.hist:])
+        f0, fr = [b * self.bc for b, _ in sl], [c * self.bc for _, c in sl]
         with self.boundary.on():
             self.ctx.join()
             if cnt:
                 self.producer.set_history(tail, self.hist)
                 self.producer.execute(blocks, cnt, self.block, self.center)
-            self.comm.exchange_rows(self.producer, self.rows, self.owned, [b * self.bc for b, _ in sl], [c * self.bc for _, c in sl],
-                                    n_blocks, self.block, self.center)
+            if not overlap:
+                self.comm.exchange_rows(self.producer, self.rows, self.owned, f0, fr, n_blocks, self.block, self.center)
+                self._keep = [window]
+                if self.plan.demods:
+                    self.bank.execute(self.rows)
+                return
+            self.comm.exchange_rows_begin(self.producer, self.owned, f0, fr)
             self._keep = [window]
-            if self.plan.demods:
-                self.bank.execute(self.rows)
+            if self._pend is not None:
+                self._finish_pending()
+            self._pend = (n_blocks,)
+
+    def _finish_pending(self):
+        (n_blocks,) = self._pend
+        self.comm.exchange_rows_finish(self.rows, n_blocks, self.block, self.center)
+        if self.plan.demods:
+            self.bank.execute(self.rows)
+        self._pend = None
+
+    def flush(self):
+        """drain the pipeline of step(overlap=True): import and demodulate the batch whose transfers are still out"""
+        if self._pend is None:
+            return
+        with self.boundary.on():
+            if self.comm is None:
+                pend, self._pend = self._pend, None
+                self.consume(*pend)
+            else:
+                self._finish_pending()
+
+    def local_window(self, ring, n_blocks):
+        """distributed ingest: every rank already holds the stream's samples (its own reader, or -- the bench -- the same synthetic ring on every
+        rank) and takes ITS window where it lies: (history, blocks) views, nothing moves.  `ring` holds the batch; the history in front of slab 0
+        is the end of the previous batch, which for a ring that repeats is the ring's own end."""
+        start, cnt = slab_blocks(n_blocks, self.world)[self.rank]
+        n = n_blocks * self.block
+        if start == 0:
+            tail = ring[n - self.hist:n]
+        else:
+            tail = ring[start * self.block - self.hist: start * self.block]
+        return tail, ring[start * self.block:(start + cnt) * self.block]
 
     def audio(self, demod_index):
         return self.bank.audio(self.slot_of[demod_index])

@@ -366,8 +366,11 @@ int  csdr_ingest_wait(csdr_ingest *ing);             /* blocks until the last tr
 /* Errors.  Every entry point validates its arguments and allocates before the first call the peers take part in, so a refused call (CSDR_EINVAL,
  * CSDR_ENOMEM, CSDR_ESTATE) has enqueued nothing and the communicator stays usable -- provided EVERY rank is refused alike: the ranks of one
  * collective must pass consistent arguments (the same channel lists and row order in csdr_post_exchange_rows; whether the producers' rows
- * travel as they lie is decided from the producer's row order, which therefore has to be the same on every rank).  A CSDR_EHIP from inside a
- * collective, or one rank failing while its peers proceed, leaves the peers waiting: destroy the communicator on every rank and make a new one. */
+ * travel as they lie is decided from the producer's row order, which therefore has to be the same on every rank).  A rank that fails INSIDE a
+ * collective (CSDR_EHIP after its peers may have entered the matching calls) aborts its communicators (ncclCommAbort): its connections are torn
+ * down, so the peers' pending transfers end with an error instead of waiting for good -- they see it through csdr_comm_async_error (poll it where
+ * the host would otherwise block on the stream), which aborts theirs too.  An aborted communicator refuses every later call (CSDR_ESTATE): destroy
+ * it on every rank and make a new one.  csdr_comm_abort does the same on request (a rank that must leave for a reason of its own). */
 int  csdr_comm_unique_id(char *id_out /* [CSDR_COMM_ID_BYTES] */);
 int  csdr_comm_create(csdr_ctx *ctx, const char *unique_id, int rank, int world, csdr_comm **out);
 void csdr_comm_destroy(csdr_comm *comm);
@@ -384,6 +387,22 @@ int  csdr_comm_max(csdr_comm *comm, double *value);
 int  csdr_comm_barrier(csdr_comm *comm);
 int  csdr_post_exchange_rows(csdr_comm *comm, csdr_post *producer, csdr_post *owner, const int *channels, const int *n_channels,
                              const int64_t *frame0, const int64_t *frames, int n_blocks, int block_len, int64_t frequency);
+/* The same exchange in two halves, so that the transfers of batch i run beside the channelizer of batch i + 1 (SDRPostThread.cpp:389-396 hands a
+ * block to the demodulators' queues and goes straight on to the next one: the queue is the overlap there).  Host order per batch:
+ *     csdr_post_execute(producer, batch i + 1);  _begin(...batch i + 1...);  _finish(owner, batch i);  csdr_bank_execute(bank, owner);
+ *   _begin   enqueues the grouped sends / receives on the communicator's own transfer stream (and, where RCCL can split one off, its own
+ *            communicator), behind the producer's kernels only; no lane of the library waits for them.  From its first _begin on, the producer
+ *            rotates its output buffers whatever the stream folding and rewrites a buffer only behind the transfers that read it.
+ *   _finish  the oldest batch begun and not finished: the owner's lane waits for that batch's transfers, imports and commits (n_blocks,
+ *            block_len, frequency describe THAT batch).
+ * At most two batches may be between their halves (CSDR_ESTATE beyond); csdr_comm_exchanges_pending counts them.  The owner's rows -- and the
+ * audio behind them -- equal the one-call form's bit for bit. */
+int  csdr_post_exchange_rows_begin(csdr_comm *comm, csdr_post *producer, const int *channels, const int *n_channels,
+                                   const int64_t *frame0, const int64_t *frames);
+int  csdr_post_exchange_rows_finish(csdr_comm *comm, csdr_post *owner, int n_blocks, int block_len, int64_t frequency);
+int  csdr_comm_exchanges_pending(const csdr_comm *comm);
+int  csdr_comm_abort(csdr_comm *comm);
+int  csdr_comm_async_error(csdr_comm *comm);        /* CSDR_OK: no transfer of this communicator has failed; otherwise it has been aborted here too */
 
 #ifdef __cplusplus
 }

@@ -115,6 +115,7 @@ static int run_rank(int rank, int world, const char *id) {
     for (int q = 0; q < world; ++q) { frame0[(size_t)q] = (int64_t)q * 2 * frames_per_block; frames[(size_t)q] = 2 * frames_per_block; }
     const int nrow = nb * frames_per_block;
     std::vector<float> want((size_t)2 * nrow), row((size_t)2 * nrow);
+    std::vector<std::vector<float>> kept;                                   // [batch][my channel]: the unsharded rows, for the pipelined pass below
     for (int t = 0; t < n_batches; ++t) {
         const float *host_batch = stream.data() + (size_t)t * batch * 2;
         CHECK(csdr_post_execute(whole, host_batch, 0, nb, block, center));                        // the unsharded reference (every rank runs it)
@@ -138,6 +139,7 @@ static int run_rank(int rank, int world, const char *id) {
         for (int k : mine) {
             int got_n = 0;
             CHECK(csdr_post_read_channel(whole, k, want.data(), nrow, &got_n)); REQUIRE(got_n == nrow);
+            kept.push_back(want);
             CHECK(csdr_post_read_channel(shard, k, row.data(), nrow, &got_n)); REQUIRE(got_n == nrow);
             REQUIRE(std::memcmp(row.data(), want.data(), want.size() * 4) == 0);                   // broadcast variant: bit for bit
             CHECK(csdr_post_read_channel(owner, k, row.data(), nrow, &got_n)); REQUIRE(got_n == nrow);
@@ -148,6 +150,54 @@ static int run_rank(int rank, int world, const char *id) {
                 REQUIRE(worst <= 1e-6 * peak);
             }
         }
+    }
+    // 4. the same time-slab stream with the exchange in two halves (csdr_post_exchange_rows_begin / _finish): batch t is channelized and its row
+    //    transfers are started before batch t - 1 is imported -- the order in which the transfers run beside the next batch's channelizer
+    {
+        csdr_post *producer2 = nullptr, *owner2 = nullptr;
+        CHECK(csdr_post_create(ctx, &producer2)); CHECK(csdr_post_configure(producer2, fs, M, CSDR_POST_PFBCH, block, 2));
+        CHECK(csdr_post_create(ctx, &owner2)); CHECK(csdr_post_configure(owner2, fs, M, CSDR_POST_PFBCH, block, nb));
+        CHECK(csdr_post_set_active_channels(owner2, mine.data(), (int)mine.size()));
+        CHECK(csdr_post_set_dc_blocker(producer2, 0));
+        CHECK(csdr_post_set_row_order(producer2, all_ch.data(), (int)all_ch.size()));
+        auto check_batch = [&](int t) -> int {
+            for (size_t j = 0; j < mine.size(); ++j) {
+                int got_n = 0;
+                CHECK(csdr_post_read_channel(owner2, mine[j], row.data(), nrow, &got_n)); REQUIRE(got_n == nrow);
+                const std::vector<float> &w = kept[(size_t)t * mine.size() + j];
+                if (mine[j] != 0) REQUIRE(std::memcmp(row.data(), w.data(), w.size() * 4) == 0);
+                else {
+                    double worst = 0.0, peak = 1e-30;
+                    for (size_t i = 0; i < w.size(); ++i) { worst = std::fmax(worst, std::fabs((double)row[i] - (double)w[i])); peak = std::fmax(peak, std::fabs((double)w[i])); }
+                    REQUIRE(worst <= 1e-6 * peak);
+                }
+            }
+            return 0;
+        };
+        for (int t = 0; t < n_batches; ++t) {
+            if (rank == 0) {
+                std::vector<float> packed(each * 2 * (size_t)world, 0.0f);
+                for (int q = 0; q < world; ++q) {
+                    const long long first = ((long long)t * (long long)batch + (long long)q * 2 * block - H) * 2;
+                    for (size_t i = 0; i < each * 2; ++i) { const long long src = first + (long long)i; packed[(size_t)q * each * 2 + i] = src >= 0 ? stream[(size_t)src] : 0.0f; }
+                }
+                CHECK(csdr_dev_upload(ctx, d_packed, packed.data(), packed.size() * 4));
+            }
+            CHECK(csdr_comm_scatter(comm, (const float *)d_packed, (float *)d_win, (int64_t)each, 0));
+            CHECK(csdr_post_set_history(producer2, (const float *)d_win, H));
+            CHECK(csdr_post_execute(producer2, (const float *)d_win + 2 * (size_t)H, 1, 2, block, center));
+            CHECK(csdr_post_exchange_rows_begin(comm, producer2, all_ch.data(), n_ch.data(), frame0.data(), frames.data()));
+            if (t > 0) {
+                REQUIRE(csdr_comm_exchanges_pending(comm) == 2);
+                CHECK(csdr_post_exchange_rows_finish(comm, owner2, nb, block, center));
+                if (check_batch(t - 1)) return 1;
+            }
+        }
+        CHECK(csdr_post_exchange_rows_finish(comm, owner2, nb, block, center));
+        REQUIRE(csdr_comm_exchanges_pending(comm) == 0);
+        if (check_batch(n_batches - 1)) return 1;
+        REQUIRE(csdr_comm_async_error(comm) == CSDR_OK);
+        csdr_post_destroy(producer2); csdr_post_destroy(owner2);
     }
     CHECK(csdr_comm_barrier(comm));
     csdr_post_destroy(whole); csdr_post_destroy(shard); csdr_post_destroy(producer); csdr_post_destroy(owner);

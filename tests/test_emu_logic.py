@@ -269,6 +269,11 @@ def test_emu_comm_one_rank(ctx):
     G._comm_one_rank_case(ctx, False)
 
 
+def test_emu_slab_exchange_overlapped(ctx):
+    """the two-halves row exchange (begin / finish, the producer's rotating buffers, the two receive slots) against the one-call form: five batches"""
+    G._slab_overlap_case(False)
+
+
 def test_emu_cpp_comm_ranks(ctx):
     """tests/cpp/comm_ranks.cpp (the C++ host of a sharded stream, C ABI only) linked against the host-executing build: one rank, loopback"""
     import subprocess

@@ -970,6 +970,42 @@ def test_spectrum_headline_shape_contiguous_batches(ctx, F, fs, frames_per_batch
     _spectrum_contiguous_batches(ctx, F, fs, frames_per_batch)
 
 
+def test_spectrum_chain_switch_on_five_streams_without_host_waits():
+    """the fused chain's intermediate rows are read by its row pass on the averaging lane: with CSDR_STREAMS=5 (transform and averaging on streams of
+    their own) a batch of the three-kernel chain that follows a fused one -- peak hold switched on between two calls, nothing fetched in between --
+    must not start rewriting them early.  Back-to-back calls on five streams give the frames the one-stream context gives, bit for bit."""
+    import os
+    from cubicsdr_amd.engine import Context, SpectrumProcessor
+    F, fs, block, nb = 65536, 61440000, 1024068, 6
+    x = synth_iq(nb * block, fs, 100000000, [("NBFM", 100000000 + 1234567), ("AM", 100000000 - 20000000)], seed=78)
+    outs = []
+    for streams in ("1", "5"):
+        old = os.environ.get("CSDR_STREAMS")
+        os.environ["CSDR_STREAMS"] = streams
+        try:
+            c = Context(0)
+        finally:
+            if old is None:
+                os.environ.pop("CSDR_STREAMS", None)
+            else:
+                os.environ["CSDR_STREAMS"] = old
+        sp = SpectrumProcessor(c, F, max_frames=10)
+        res = []
+        for rep in range(3):                                   # the hazard is a timing one: a few rounds of fused, fused, held, held, fused, fused
+            for b in range(nb):
+                if b == 2:
+                    sp.set_peak_hold(True)
+                if b == 4:
+                    sp.set_peak_hold(False)
+                n = sp.process(x[b * block:(b + 1) * block], 1, block, contiguous=True)
+                if b in (3, 5):
+                    res.append(np.concatenate([sp.fetch(i)[0] for i in range(n)]))
+        sp.close(); c.close()
+        outs.append(res)
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
 def test_spectrum_headline_small_calls_and_chain_switch(ctx):
     """the fused two-pass chain of the headline size (N = 2^17) in the real-time shape: ONE 1/60 s block per call (7 or 8 frames: partial
     rounds of the row pass, one frame group per column workgroup, a partial frame carried from call to call) produces exactly the frames ONE
@@ -1510,6 +1546,64 @@ def _comm_one_rank_case(ctx, use_torch):
     sl.close()
     assert worst < 1e-6, worst
     return worst
+
+
+def _slab_overlap_case(use_torch, n_batches=5):
+    """step(overlap=True) of the time-slab stream -- csdr_post_exchange_rows_begin / _finish: the row transfers of a batch started before the
+    previous batch is imported and demodulated -- against the one-call form, over five back-to-back batches on a one-rank communicator (real
+    RCCL on the GPU box; the loopback of the host-executing build): audio and per-block counts bit for bit, with the windows scattered from the
+    ingest rank and with every rank taking its window where it lies (local_window)."""
+    from cubicsdr_amd.parallel import SlabStream, exchange_id
+    fs, M, block, nd, nb, center = 6400000, 64, 64 * 417, 12, 4, 400000000
+    freqs = demod_frequencies(center, fs, nd)
+    freqs[0] = center + 1500
+    kinds = ("NBFM", "AM", "USB")
+    bw = {"NBFM": 12500, "AM": 6000, "USB": 5400}
+    demods = [(kinds[i % 3], bw[kinds[i % 3]], f) for i, f in enumerate(freqs)]
+    x = synth_iq(n_batches * nb * block, fs, center, [(k, f) for k, _, f in demods[:6]], seed=211)
+    xf = x.view(np.float32).reshape(-1, 2)
+
+    def dev(a):
+        if not use_torch:
+            return a.copy()
+        import torch
+        return torch.from_numpy(a.copy()).cuda()
+
+    def run(overlap, local):
+        sl = SlabStream(0, 0, 1, fs, M, block, demods, center, nb, use_torch=use_torch, comm_id=exchange_id(0, 1))
+        out = []
+
+        def collect():
+            out.append(([sl.audio(i) for i in range(nd)], [[(q.n_iq, q.n_audio, q.nco_theta, q.resamp_phase) for q in sl.results(i)] for i in range(nd)]))
+        ring = dev(xf[:nb * block])
+        for t in range(n_batches):
+            if local:
+                window = sl.local_window(ring, nb)                  # the same batch again and again: its own end is the history in front of it
+            else:
+                window = sl.scatter(dev(xf[t * nb * block:(t + 1) * nb * block]), nb, src=0)
+            sl.step(window, nb, overlap=overlap)
+            if not overlap:
+                collect()
+            elif t > 0:
+                assert sl.comm.exchanges_pending == 1
+                collect()                                           # batch t - 1
+        if overlap:
+            sl.flush()
+            assert sl.comm.exchanges_pending == 0
+            collect()
+        sl.close()
+        return out
+    for local in (False, True):
+        a, b = run(False, local), run(True, local)
+        assert len(a) == len(b) == n_batches
+        for t in range(n_batches):
+            assert a[t][1] == b[t][1], (local, t)
+            for i in range(nd):
+                assert np.array_equal(a[t][0][i], b[t][0][i]), (local, t, i)
+
+
+def test_slab_exchange_overlapped_equals_one_call_form():
+    _slab_overlap_case(True)
 
 
 def test_comm_refuses_bad_arguments(ctx):

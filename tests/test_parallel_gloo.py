@@ -98,7 +98,7 @@ def test_channel_routing_twin_and_stream_plan():
             assert abs(len(p.demods) - M // world) <= 1
 
 
-def _slab_worker(rank, world, port, q):
+def _slab_worker(rank, world, port, q, overlap=False, nbat=2):
     """one rank of parallel.SlabStream over gloo, its kernels run by the host-thread emulation of tests/emu (numpy buffers)"""
     import ctypes as C
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
@@ -114,7 +114,7 @@ def _slab_worker(rank, world, port, q):
         from cubicsdr_amd.engine import Context, DemodBank, SDRPost
         from cubicsdr_amd.parallel import SlabStream
         from tests.util import demod_frequencies, synth_iq
-        fs, M, block, nd, nb, nbat, center = 480000, 8, 8000, 6, 4, 2, 400000000
+        fs, M, block, nd, nb, center = 480000, 8, 8000, 6, 4, 400000000
         freqs = demod_frequencies(center, fs, nd); freqs[0] = center + 1500
         demods = [("NBFM" if i % 2 == 0 else "AM", 12500 if i % 2 == 0 else 6000, f) for i, f in enumerate(freqs)]
         x = synth_iq(nbat * nb * block, fs, center, [(k, f) for k, _, f in demods], seed=97)
@@ -126,15 +126,27 @@ def _slab_worker(rank, world, port, q):
             bank.configure(i, post, k, b, f)
         ok, n_cmp = True, 0
         xf = x.view(np.float32).reshape(-1, 2)
+        want = []                                                  # the unsharded audio / counts of this rank's demodulators, batch by batch
+
+        def compare(t):
+            nonlocal ok, n_cmp
+            for i in stream.plan.demods:
+                ok = ok and np.array_equal(stream.audio(i), want[t][i][0])
+                ok = ok and [(r.n_iq, r.n_audio, r.nco_theta) for r in stream.results(i)] == want[t][i][1]
+                n_cmp += 1
         for t in range(nbat):
             post.execute(x[t * nb * block:(t + 1) * nb * block], nb, block, center)
             bank.execute(post)
+            want.append({i: (bank.audio(i), [(r.n_iq, r.n_audio, r.nco_theta) for r in bank.results(i)]) for i in stream.plan.demods})
             window = stream.scatter(xf[t * nb * block:(t + 1) * nb * block] if rank == 0 else None, nb, src=0)
-            stream.step(window, nb)
-            for i in stream.plan.demods:
-                ok = ok and np.array_equal(stream.audio(i), bank.audio(i))
-                ok = ok and [(r.n_iq, r.n_audio, r.nco_theta) for r in stream.results(i)] == [(r.n_iq, r.n_audio, r.nco_theta) for r in bank.results(i)]
-                n_cmp += 1
+            stream.step(window, nb, overlap=overlap)
+            if not overlap:
+                compare(t)
+            elif t > 0:
+                compare(t - 1)                                     # the pipeline is one batch deep: batch t - 1 is complete after step t
+        if overlap:
+            stream.flush()
+            compare(nbat - 1)
         stream.close(); bank.close(); post.close(); ctx.close()
         q.put((rank, ok, n_cmp, stream.plan.demods))
     finally:
@@ -160,3 +172,38 @@ def test_two_rank_time_slab_stream_over_gloo():
         assert ok and n_cmp == 2 * len(mine), (rank, ok, n_cmp)
         owned += mine
     assert sorted(owned) == list(range(6))
+
+
+def test_two_rank_time_slab_stream_overlapped_over_gloo():
+    """the same stream with step(overlap=True) -- batch i + 1 channelized and its rows exchanged BEFORE batch i is imported and demodulated
+    (the order the C ABI's begin / finish pair runs on a GPU node) -- over five back-to-back batches: every batch's audio still equals the
+    unsharded path's bit for bit."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_slab_worker, args=(r, world, port, q, True, 5)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, ok, n_cmp, mine in res:
+        assert ok and n_cmp == 5 * len(mine), (rank, ok, n_cmp)
+
+
+def test_strong_scaling_plan_picks_by_the_link_model():
+    """parallel.strong_scaling_plan: one C4 batch (32 blocks = 427 MB of input, 0.777 ms of kernels on one GPU).  Two GPUs: the one link binds
+    every sharded variant, one GPU alone is fastest -- unless the demodulators do not fit one GPU (infinite one-GPU time), then the time slabs;
+    four and eight GPUs: time slabs, and only with distributed ingest does eight reach the north star's 6 x (rank-0 ingest scatters 7 / 8 of
+    the input over rank 0's links)."""
+    from cubicsdr_amd.parallel import strong_scaling_plan as plan
+    b, k = 8.0 * 32 * 1667072, 0.777
+    assert plan(1, b, k)["choice"] == "single"
+    p2 = plan(2, b, k)
+    assert p2["choice"] == "single" and p2["ms"]["slab"] < p2["ms"]["broadcast"]
+    assert plan(2, b, float("inf"))["choice"] in ("slab", "broadcast")
+    for w in (4, 8):
+        assert plan(w, b, k)["choice"] == "slab"
+    assert plan(8, b, k)["speedup_over_one_gpu"] >= 6.0
+    assert plan(8, b, k, ingest="rank0")["speedup_over_one_gpu"] < 2.0
