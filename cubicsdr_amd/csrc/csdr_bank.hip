@@ -62,6 +62,7 @@ extern "C" int csdr_bank_create(csdr_ctx *ctx, int max_demods, int max_blocks, c
     for (int k = 0; k < 2; ++k) {
         CSDR_HIP_TRY(hipEventCreateWithFlags(&b->ev_fe_done[k], hipEventDisableTiming));
         CSDR_HIP_TRY(hipEventCreateWithFlags(&b->ev_audio_done[k], hipEventDisableTiming));
+        CSDR_HIP_TRY(hipEventCreateWithFlags(&b->ev_tables_read[k], hipEventDisableTiming));
     }
     if (int rc = b->mconsts.reserve(1)) return rc;
     for (int r = 0; r < kStageRing; ++r) {
@@ -95,6 +96,7 @@ extern "C" void csdr_bank_destroy(csdr_bank *b) {
     for (int k = 0; k < 2; ++k) {
         if (b->ev_fe_done[k]) (void)hipEventDestroy(b->ev_fe_done[k]);
         if (b->ev_audio_done[k]) (void)hipEventDestroy(b->ev_audio_done[k]);
+        if (b->ev_tables_read[k]) (void)hipEventDestroy(b->ev_tables_read[k]);
     }
     for (auto &s : b->slots) if (s.slab) (void)hipFree(s.slab);
     b->cfgs.release(); b->tables.release(); b->arms.release(); b->mconsts.release();
@@ -517,16 +519,24 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     // BEFORE the lane waits for the channelizer (on separate streams the fetch runs beside it), the front-end kernels behind that wait
     const int pk = post->cur;
     if (b->audio_pending[bpar]) if (int rc = c->wait(b->ev_audio_done[bpar], LANE_AUDIO, LANE_FE)) return rc;
-    {   // the tables of this batch: fetched from the page-locked staging slot by a kernel of this stream (bank_tables_fetch: why not a copy-engine transfer)
+    // Where the channelizer has a stream of its own, the fetch rides on THAT stream, behind the channelizer of this batch: a one-block call is bound by
+    // the chain of the demodulators' stream (tables 4 + front-end 19 + modem / audio 22 us and three gaps), the channelizer's stream has
+    // half of that; the front-end's wait for the channelizer becomes its wait for the fetch (one event either way).
+    const bool fetch_on_post = post->ctx == c && !c->same(LANE_POST, LANE_FE);
+    {   // the tables of this batch: fetched from the page-locked staging slot by a kernel (bank_tables_fetch: why not a copy-engine transfer)
         const size_t bytes = b->off_plans + (size_t)b->max_demods * (NB + 1) * sizeof(BlockPlan);
         const int n16 = (int)((bytes + 15) / 16);                   // (the slot and the device table are whole multiples of 256 bytes)
-        CSDR_LAUNCH(c, LANE_FE, KID_TABLES, bank_tables_fetch, dim3(std::max(1, std::min(64, (n16 + 255) / 256))), dim3(256), 0,
+        // (the device copy of this parity was last read by the audio kernels two batches ago: the demodulators' stream orders that by itself,
+        //  the channelizer's stream waits for the event recorded behind them)
+        if (fetch_on_post && b->tables_read_pending[bpar]) CSDR_HIP_TRY(hipStreamWaitEvent(c->lanes[LANE_POST], b->ev_tables_read[bpar], 0));
+        CSDR_LAUNCH(c, fetch_on_post ? LANE_POST : LANE_FE, KID_TABLES, bank_tables_fetch, dim3(std::max(1, std::min(64, (n16 + 255) / 256))), dim3(256), 0,
                     reinterpret_cast<const float4 *>(table_h), reinterpret_cast<float4 *>(table_d), n16);
         CSDR_HIP_TRY(hipGetLastError());
     }
-    CSDR_HIP_TRY(hipEventRecord(b->stage_ev[ring], st));           // the staging slot is free again once the fetch has run
+    CSDR_HIP_TRY(hipEventRecord(b->stage_ev[ring], fetch_on_post ? c->lanes[LANE_POST] : st));     // the staging slot is free again once the fetch has run
     b->stage_used[ring] = true;
-    if (post->ctx != c || !c->same(LANE_POST, LANE_FE)) {           // the channelizer output of this batch must be complete
+    if (fetch_on_post) CSDR_HIP_TRY(hipStreamWaitEvent(st, b->stage_ev[ring], 0));                  // (behind the channelizer of this batch on its stream)
+    else if (post->ctx != c || !c->same(LANE_POST, LANE_FE)) {      // the channelizer output of this batch must be complete
         if (post->ctx != c) CSDR_HIP_TRY(hipEventRecord(post->ev_ready[pk], post->ctx->lanes[LANE_POST]));
         CSDR_HIP_TRY(hipStreamWaitEvent(st, post->ev_ready[pk], 0));
     }
@@ -689,6 +699,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
     CSDR_HIP_TRY(hipGetLastError());
     if (int rc = c->signal(b->ev_audio_done[bpar], LANE_AUDIO, LANE_FE)) return rc;
     b->audio_pending[bpar] = true;
+    if (fetch_on_post) { CSDR_HIP_TRY(hipEventRecord(b->ev_tables_read[bpar], st_a)); b->tables_read_pending[bpar] = true; }      // the last reader of this parity's device tables
     (void)st_a;
     b->seq++;
     return CSDR_OK;

@@ -101,6 +101,8 @@ struct csdr_bank {
     uint64_t seq = 0;
     hipEvent_t ev_fe_done[2] = {nullptr, nullptr}, ev_audio_done[2] = {nullptr, nullptr};
     bool audio_pending[2] = {false, false};
+    hipEvent_t ev_tables_read[2] = {nullptr, nullptr};      // behind the audio kernels of a batch: the device tables of its parity may be refetched (by the channelizer's stream)
+    bool tables_read_pending[2] = {false, false};
     DevBuf<float> arms;
     DevBuf<ModemConsts> mconsts;
     PinBuf<char> tables_h[kStageRing];

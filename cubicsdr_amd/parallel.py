@@ -409,9 +409,10 @@ class SlabStream:
         with self.boundary.on():
             self.ctx.join()                                         # (see extended(): the previous batch's buffers are dropped below)
             send = self._empty(sum(len(o) for o in self.owned) * frames)
+            tail, blocks = window if isinstance(window, tuple) else (window, window[self.hist:])      # (history, blocks) views, or one buffer [history | blocks]
             if cnt:
-                self.producer.set_history(window, self.hist)
-                self.producer.execute(window[self.hist:], cnt, self.block, self.center)
+                self.producer.set_history(tail, self.hist)
+                self.producer.execute(blocks, cnt, self.block, self.center)
                 off = 0
                 for q in range(self.world):
                     if self.owned[q]:
