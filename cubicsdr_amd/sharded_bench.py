@@ -76,7 +76,7 @@ def measure(args, dist=None):
     if shard == "auto":
         from cubicsdr_amd.parallel import strong_scaling_plan
         policy = strong_scaling_plan(world, 8.0 * NB * BLOCK, 0.777 * NB / 32.0, ingest=ingest)
-        shard = "slab" if policy["choice"] in ("slab", "single") else "broadcast"
+        shard = "broadcast" if (world == 1 or policy["choice"] == "broadcast") else "slab"      # (one GPU: the unsharded path, which the broadcast driver with one rank is)
     slab = shard == "slab"
     overlap = slab and bool(getattr(args, "overlap", True))
     if slab and cid is None and dist is None and os.environ.get("CSDR_C4_TRANSPORT", "abi") == "abi":
