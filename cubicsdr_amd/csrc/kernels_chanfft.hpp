@@ -32,6 +32,13 @@ namespace csdr {
 constexpr int kCfMaxPasses = 8;
 constexpr int kCfSeg = 8;                 // frames one FIR work item produces
 constexpr int kCfMaxThreads = 1024;
+#ifndef CSDR_CF_PRIO_FIR
+#define CSDR_CF_PRIO_FIR 2
+#endif
+#ifndef CSDR_CF_PRIO_PASS
+#define CSDR_CF_PRIO_PASS 1
+#endif
+constexpr int kCfPrioFir = CSDR_CF_PRIO_FIR, kCfPrioPass = CSDR_CF_PRIO_PASS;      // (A/B builds: -DCSDR_CF_PRIO_FIR=0 -DCSDR_CF_PRIO_PASS=0 is the round-5 kernel)
 
 struct ChanFftGeom {
     int M, TF, lgTF, TFs;                 // TFs: row pitch of X in samples (TF + 2)
@@ -402,6 +409,10 @@ CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
     for (int64_t tile = tile0; tile < ntiles; tile += gridDim.x) {
         const int64_t f0 = tile << g.lgTF;
         const int nf = (int)min((int64_t)TF, n_frames - f0);
+        // wave priorities (round 6, profiles/r06_chanfft_priority.txt): the FIR phase -- global loads straight into the registers the taps read -- issues at
+        // priority 2, the passes at 1, whatever is left of a tile (set-up, the waits at the barriers) at 0: of the waves that share a SIMD the ones that
+        // can put loads in flight go first.  M = 200: 0.225 -> 0.204 ms (C5), M = 40 / 112: - 6 %, M = 20: - 2 %, M = 1024 (one workgroup per CU): - 1 %
+        wave_priority(kCfPrioFir);
         // ---- FIR: item = (column pair cp, segment of 8 frames)
         if constexpr (!OS2) {
             const bool inside = f0 >= kChanTaps - 1 && f0 + TF <= n_frames;      // (tile-uniform) every row any item of the tile reaches lies in x
@@ -435,6 +446,7 @@ CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
             }
         }
         lds_barrier();
+        wave_priority(kCfPrioPass);
 
         // ---- FFT passes: item = (butterfly bf, frame t), lanes along t.  The radix is a property of the PASS: one dispatch per pass, the item loop
         // inside it has a compile-time radix (and an instance built for a plan -- PLAN != 0 -- carries only its own radices: registers sized by the plan)
@@ -456,6 +468,7 @@ CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
 #undef CSDR_CF_CASE
             lds_barrier();
         }
+        wave_priority(0);
         if (dc_ends) {
             // v_end = sum_t c^(nf-1-t) y0[t]: the DC blocker's state after this tile if it entered with zero (iirfilt, :375)
             if (tid < 64) {

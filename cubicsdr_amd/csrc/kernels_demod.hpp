@@ -459,6 +459,13 @@ CSDR_KERNEL_BANK __launch_bounds__(kFeThreads, 4) void demod_frontend(
 // grid = (P + 1, slots of this S).  Bit-identical to demod_frontend.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kFeTabLen = 1024 + 256;
+#ifndef CSDR_FE_PRIO_STAGE
+#define CSDR_FE_PRIO_STAGE 1
+#endif
+#ifndef CSDR_FE_PRIO_TAIL
+#define CSDR_FE_PRIO_TAIL 2
+#endif
+constexpr int kFePrioStage = CSDR_FE_PRIO_STAGE, kFePrioTail = CSDR_FE_PRIO_TAIL;      // (A/B builds: both 0 is the round-5 kernel)
 // Where entry i of the oscillator table sits in LDS: row i >> 5 keeps its 32 words, its columns are rotated by rot * row.  The table reads of a wave are
 // an arithmetic progression of the demodulator's phase increment over 32 banks: in the plain order thirty-two lanes meet 3.6 times per bank on average
 // (C3), with the rotation the host picks for the increment (csdr_bank.hip: fe_table_rotation: a multiple of 4, so that the cosine -- 256 entries = eight rows on -- keeps the sine's column and the
@@ -720,6 +727,9 @@ __device__ __forceinline__ void fes_body(
         static_assert((NT == 2 || NT == 3) && BLK >= 1 && NT + 1 <= BLK + 1, "the tail wave schedule needs one barrier interval per tail piece");
         const bool tailw = tid >= kFeThreads;
         const int ltid = tid - kFeThreads;
+        // wave priorities (round 6): the tail wave -- one chunk behind, its pieces must fit the workers' barrier intervals -- at 2, the workers' stages at 1,
+        // their mix (LDS gathers, the next chunk's loads) and everything else at 0: 0.46 -> 0.42 - 0.43 ms on C3 / C3N (either alone: nothing / - 2 %)
+        if (tailw) wave_priority(kFePrioTail);
         const int nch = (int)((u_stop - u_lo) / CH);
         float4 pf[NPF];
         if (!tailw) {
@@ -739,7 +749,9 @@ __device__ __forceinline__ void fes_body(
                     fe_fetch_chunk<NPF>(pf, chan, hist, hist_len, reln + 2 * tid, total, inside);
                 }
                 __syncthreads();                                                        // B1
+                wave_priority(kFePrioStage);
                 FesStages<S, CH, 0, BLK, false>::run(LE, LO, LZ, hb, zeta, tid);        // B2 .. B(BLK+1)
+                wave_priority(0);
                 fes_carry_tail<(CH >> BLK)>(LE, LO, fes_off<CH>(BLK - 1), fes_offo<S, CH>(BLK - 1));
             }
         } else {

@@ -526,6 +526,10 @@ constexpr int kP2Waves = 8;
 #ifndef CSDR_P2_PRIO_DFT
 #define CSDR_P2_PRIO_DFT 1
 #endif
+#ifndef CSDR_P2_REQ_PRIO
+#define CSDR_P2_REQ_PRIO 2
+#endif
+constexpr int kP2ReqPrio = CSDR_P2_REQ_PRIO;
 constexpr int kP2DftPrio = CSDR_P2_PRIO_DFT;            // (A/B builds: -DCSDR_P2_PRIO_DFT=0 is the round-5 kernel)
 constexpr int kP2EarlyRows = 8;          // rows of the next tile's FIR window requested before the DFT phase (the first frame's whole window); the other seven after it
 constexpr int kP2Threads = 64 * kP2Waves;
@@ -693,10 +697,11 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
         lds_barrier();
         // the transform phase issues at raised priority: of the four waves of a SIMD (two workgroups) the ones inside their 480 packed multiply-adds
         // go first, the ones in the FIR / load / store phases fill in (0.504 -> 0.489 ms on C3, profiles/r06_p2_variants.txt; raising the FIR phase
-        // instead costs 1 %)
-        wave_priority(kP2DftPrio);
+        // instead costs 1 %); the window requests one step above it (- 1.5 %)
+        wave_priority(kP2ReqPrio);
         // the next tile's window is on its way while this one is transformed (into the registers the FIR has just finished with)
         chan_p2_request_window<0, kP2EarlyRows>(x, hist, M, A, n_frames, tile + tstep, tile + tstep < tend, wave, lane, win);
+        wave_priority(kP2DftPrio);
         {   // ---- DFT: lane = frame t; wave = pass of KP output-pair slots
             const int t = lane;
             const float4 *row = rows + t * A;
@@ -748,6 +753,7 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
                 }
             }
         }
+        wave_priority(kP2ReqPrio);
         // the rest of the next window (the transform above leaves no room for all fifteen rows: they would be spilled -- which waits for them)
         chan_p2_request_window<kP2EarlyRows, 2 * kChanTaps - 1>(x, hist, M, A, n_frames, tile + tstep, tile + tstep < tend, wave, lane0, win);
         wave_priority(0);
