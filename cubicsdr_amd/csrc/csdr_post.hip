@@ -111,9 +111,10 @@ typedef void (*chan_p2_kernel_t)(const float2 *, const float2 *, float2 *, const
                                  int64_t, float2 *, int64_t, d2 *, double);
 static chan_p2_kernel_t chan_p2_kernel(const ChanGeom &g) {
 #define CSDR_P2_CASE(K_) case K_: return chan_analyze_p2<K_>
+    // (A <= 63: at most 32 slots over eight waves = at most four per pass; wider passes were instances nothing ever launched -- one of them spilled)
     switch (g.KA) {
-        CSDR_P2_CASE(1); CSDR_P2_CASE(2); CSDR_P2_CASE(3); CSDR_P2_CASE(4); CSDR_P2_CASE(5); CSDR_P2_CASE(6); CSDR_P2_CASE(7);
-        default: return chan_analyze_p2<8>;
+        CSDR_P2_CASE(1); CSDR_P2_CASE(2); CSDR_P2_CASE(3);
+        default: return chan_analyze_p2<4>;
     }
 #undef CSDR_P2_CASE
 }

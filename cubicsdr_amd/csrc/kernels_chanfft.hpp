@@ -238,15 +238,25 @@ __device__ __forceinline__ unsigned cf_div(unsigned n, int d, unsigned magic) { 
 // one butterfly of a pass that stays in LDS: R rows at pitch `pitch` samples, twiddles W_M^(r jj), in place
 template <int R>
 __device__ __forceinline__ void cf_pass_item(float2 *px, int pitch, const float2 *s_tw, int jj) {
-    float2 v[R], w[R];
+    float2 v[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) v[q] = px[(size_t)q * pitch];
+    if constexpr (R >= 17) {
+        // the wide odd radices: 2 R operand registers and as many of sums and differences inside the butterfly already; the R - 1 twiddles are read
+        // one by one where they are used instead of up front (all in registers, the instance spilled 52 - 61 of them)
+        CfDft<R>::run(v);
+        px[0] = v[0];
 #pragma unroll
-    for (int r = 1; r < R; ++r) w[r] = s_tw[r * jj];
-    CfDft<R>::run(v);
-    px[0] = v[0];
+        for (int r = 1; r < R; ++r) px[(size_t)r * pitch] = cmul(v[r], s_tw[r * jj]);
+    } else {
+        float2 w[R];
 #pragma unroll
-    for (int r = 1; r < R; ++r) px[(size_t)r * pitch] = cmul(v[r], w[r]);
+        for (int r = 1; r < R; ++r) w[r] = s_tw[r * jj];
+        CfDft<R>::run(v);
+        px[0] = v[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) px[(size_t)r * pitch] = cmul(v[r], w[r]);
+    }
 }
 // one butterfly of the last pass (span 1): results go to their channel rows
 // (OS2, the oversampled bank: s_pa holds (row << 1) | (channel is odd) -- -1 stays -1 --, s_post the post factor W_M^k / M of firpfbch2 of the channel at
@@ -255,6 +265,28 @@ template <int R, bool OS2 = false>
 __device__ __forceinline__ void cf_last_item(const float2 *px, int pitch, const int *s_pa, float2 *s_dc /* non-null: this butterfly holds channel 0 (position 0) and its tile values are wanted */,
                                              int t, bool live, float2 *__restrict__ o /* out + f0 + t */, int64_t out_stride, const float2 *s_post = nullptr) {
     float2 v[R];
+    if constexpr (R >= 17) {
+        // (wide odd radices: the output rows -- and the oversampled bank's post factors -- are looked up one by one at the stores: R more live
+        //  registers spilled)
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = px[(size_t)q * pitch];
+        CfDft<R>::run(v);
+        const bool odd_frame = (t & 1) != 0;                       // tiles start on even frames
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int kr = s_pa[r];
+            float2 val = v[r];
+            if constexpr (OS2) {
+                float2 w = s_post[r];
+                if (odd_frame && (kr & 1)) w = make_float2(-w.x, -w.y);
+                val = cmul(val, w);
+                kr >>= 1;                                          // (-1 stays -1)
+            }
+            if (r == 0 && s_dc) s_dc[t] = val;
+            if (kr >= 0 && live) st_stream(o + (int64_t)kr * out_stride, val);
+        }
+        return;
+    }
     int k[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) { v[q] = px[(size_t)q * pitch]; k[q] = s_pa[q]; }
