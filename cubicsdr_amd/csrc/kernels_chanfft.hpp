@@ -52,10 +52,20 @@ struct ChanFftGeom {
     int xcd;                              // 1: workgroups of one XCD (blockIdx.x % 8) take CONSECUTIVE tiles (grid a multiple of 8)
     int wide_odd;                         // 1: a radix of 17 / 19 / 23 is in the plan: the kernel instance that carries those butterflies
     int os2;                              // 1: firpfbch2 -- frames hop by M / 2 (two interleaved lattices of frames), outputs times the post factors
+    // a prime factor >= 29 (M = 116, 134, 146 ... 398: a third of the even channel counts getOptimalChannelCount returns, SoapySDRThread.cpp:676-693):
+    // pass 0 is its bp-point transform, run as a chirp-z convolution of length bL (the power of two >= 2 bp - 1) in a work array beside the tile
+    int bp, bL, blgL;                     // 0: no such factor
+    int bnpass, bradix[4], bspan[4];      // the bL-point transform: radices 16 / 8 / 4 / 2, span of sub-pass k inside bL
 };
+// (measured, profiles/r06_chirpz_channel_counts.txt: the convolution costs 2.2 - 2.6 x the factor's own data in LDS work space and six to eight trips through
+//  it; against the two-factor direct-DFT kernel it wins from p ~ 100 on -- M = 202: 1.0 against 1.3 ms, M = 398: 1.2 against 3.6 ms -- and loses below
+//  -- M = 134: 1.5 against 0.7 ms; smaller primes stay on chan_analyze)
+constexpr int kCfBlueMinPrime = 97, kCfBlueMaxPrime = 509;
 
 __host__ __device__ inline size_t chanfft_lds_bytes(const ChanFftGeom &g) {
-    return ((size_t)g.M * g.TFs + g.M + g.TF + (g.os2 ? g.M : 0)) * sizeof(float2) + (size_t)g.M * sizeof(int);      // (oversampled: + the M post factors)
+    // (oversampled: + the M post factors; chirp-z pass: + the work array of M / bp transforms of bL points per frame, W_bL, the transformed chirp, the chirp)
+    const size_t blue = g.bp ? (size_t)(g.M / g.bp) * g.bL * g.TFs + 2 * (size_t)g.bL + g.bp : 0;
+    return ((size_t)g.M * g.TFs + g.M + g.TF + (g.os2 ? g.M : 0) + blue) * sizeof(float2) + (size_t)g.M * sizeof(int);
 }
 
 // plan for M channels: radices (odd ones first, then the powers of two from the widest), tile size, workgroup size.
@@ -73,7 +83,19 @@ __host__ inline bool chanfft_plan(int M, size_t lds_limit, int force_tf, int for
     for (; e3 >= 2; e3 -= 2) rad.push_back(9);
     if (e3) rad.push_back(3);
     for (int p : {5, 7, 11, 13, 17, 19, 23}) while (m % p == 0) { m /= p; rad.push_back(p); if (p >= 17) g.wide_odd = 1; }
-    if (m != 1) return false;
+    if (m != 1) {
+        // what is left: ONE prime >= 29 can go through the chirp-z pass (critically sampled bank, no 17 / 19 / 23 beside it: one kernel instance)
+        bool prime = m >= kCfBlueMinPrime && m <= kCfBlueMaxPrime;
+        for (int d = 3; prime && d * d <= m; d += 2) prime = m % d != 0;
+        if (!prime || os2 || g.wide_odd) return false;
+        g.bp = m;
+        g.blgL = 0; while ((1 << g.blgL) < 2 * m - 1) ++g.blgL;
+        g.bL = 1 << g.blgL;
+        g.bnpass = (g.blgL + 3) / 4;
+        int N = g.bL;
+        for (int k = 0; k < g.bnpass; ++k) { const int lg = g.blgL / g.bnpass + (k < g.blgL % g.bnpass ? 1 : 0); g.bradix[k] = 1 << lg; g.bspan[k] = N >> lg; N >>= lg; }
+        rad.insert(rad.begin(), m);               // pass 0
+    }
     const int n2 = (e2 + 3) / 4;                               // passes over the power of two: as even as possible, widest first
     for (int i = 0; i < n2; ++i) rad.push_back(1 << (e2 / n2 + (i < e2 % n2 ? 1 : 0)));
     if ((int)rad.size() > kCfMaxPasses) return false;
@@ -92,8 +114,10 @@ __host__ inline bool chanfft_plan(int M, size_t lds_limit, int force_tf, int for
     auto fits = [&](int tf) { g.TF = tf; g.TFs = tf + 2; return chanfft_lds_bytes(g) <= lds_limit; };
     const int target = M >= 256 ? 16384 : 5120;
     int tf = 16;
+    if (g.bp) { g.radix[0] = g.bp; g.span[0] = M / g.bp; }        // (chanfft_lds_bytes of a chirp-z plan)
     while (tf < 256 && 141 * tf * M <= 100 * target) tf <<= 1;    // the power of two nearest target / M (on a log scale)
     while (tf > (os2 ? 2 * kCfSeg : kCfSeg) && !fits(tf)) tf >>= 1;      // (oversampled: eight frames of EACH lattice per tile at least)
+    if (g.bp) { tf = M >= 280 ? 16 : 8; while (tf > kCfSeg && !fits(tf)) tf >>= 1; }      // chirp-z plans: small tiles, several workgroups per CU (sweep in profiles/r06_chirpz_channel_counts.txt)
     if (force_tf >= kCfSeg && !(force_tf & (force_tf - 1)) && fits(force_tf)) tf = force_tf;
     if (!fits(tf)) return false;
     g.lgTF = 0; while ((1 << g.lgTF) < tf) ++g.lgTF;
@@ -101,6 +125,7 @@ __host__ inline bool chanfft_plan(int M, size_t lds_limit, int force_tf, int for
     const int fir_items = (M / 2) * (tf / kCfSeg);
     g.threads = 256;
     while (g.threads < kCfMaxThreads && g.threads < fir_items) g.threads <<= 1;
+    if (g.bp) g.threads = M >= 280 ? 1024 : 512;
     if (force_threads >= 64 && force_threads <= kCfMaxThreads && !(force_threads & 63)) g.threads = force_threads;
     g.xcd = M >= 64;             // (C4: + 5 %, M = 20: nothing)
     // pos = sum_p r_p s_p holds channel k = r_0 + R_0 (r_1 + R_1 (r_2 + ...)) after the last pass
@@ -111,6 +136,33 @@ __host__ inline bool chanfft_plan(int M, size_t lds_limit, int force_tf, int for
         perm[pos] = k;
     }
     return true;
+}
+
+// tables of the chirp-z pass, in double on the host: W_L^i (L), the transformed chirp filter at the positions the forward sub-passes leave the
+// frequencies in, already divided by L (L), the chirp c[n] = exp(-j pi n^2 / p) (p)
+__host__ inline std::vector<float2> chanfft_blue_tables(const ChanFftGeom &g) {
+    const int p = g.bp, L = g.bL;
+    std::vector<float2> t((size_t)2 * L + p);
+    for (int i = 0; i < L; ++i) { const double a = -2.0 * M_PI * (double)i / (double)L; t[(size_t)i] = make_float2((float)std::cos(a), (float)std::sin(a)); }
+    std::vector<double> cr((size_t)p), ci((size_t)p);
+    for (int n = 0; n < p; ++n) {
+        const double a = -M_PI * (double)(((int64_t)n * n) % (2 * p)) / (double)p;
+        cr[(size_t)n] = std::cos(a); ci[(size_t)n] = std::sin(a);
+        t[(size_t)2 * L + n] = make_float2((float)cr[(size_t)n], (float)ci[(size_t)n]);
+    }
+    // b[m mod L] = conj(c[|m|]), |m| < p;  B = DFT_L(b): b is even, so B[k] = b[0] + 2 sum_{m=1}^{p-1} b[m] cos(2 pi k m / L)
+    std::vector<double> Br((size_t)L), Bi((size_t)L);
+    for (int k = 0; k < L; ++k) {
+        double sr = cr[0], si = -ci[0];
+        for (int m = 1; m < p; ++m) { const double w = 2.0 * std::cos(2.0 * M_PI * (double)(((int64_t)k * m) % L) / (double)L); sr += w * cr[(size_t)m]; si -= w * ci[(size_t)m]; }
+        Br[(size_t)k] = sr / L; Bi[(size_t)k] = si / L;
+    }
+    for (int pos = 0; pos < L; ++pos) {            // position after the forward sub-passes -> frequency (the digit reversal of the sub-plan)
+        int k = 0, w = 1, rest = pos;
+        for (int q = 0; q < g.bnpass; ++q) { const int r = rest / g.bspan[q]; rest -= r * g.bspan[q]; k += r * w; w *= g.bradix[q]; }
+        t[(size_t)L + pos] = make_float2((float)Br[(size_t)k], (float)Bi[(size_t)k]);
+    }
+    return t;
 }
 
 // ---- R-point forward DFTs in registers: v[r] <- sum_q v[q] exp(-j 2 pi q r / R)
@@ -258,6 +310,82 @@ __device__ __forceinline__ void cf_pass_item(float2 *px, int pitch, const float2
         for (int r = 1; r < R; ++r) px[(size_t)r * pitch] = cmul(v[r], w[r]);
     }
 }
+// one butterfly of an INVERSE sub-pass of the chirp-z convolution, on conjugated data (conj(IDFT(u)) = DFT(conj(u)): the array stays conjugated from
+// the first inverse sub-pass to the read-out): twiddle first, then the R-point transform -- the forward stage run backwards.  `bh` (first inverse
+// sub-pass only): the transformed chirp filter at these positions; its product with the transformed data is what gets conjugated.
+template <int R>
+__device__ __forceinline__ void cf_ipass_item(float2 *px, int pitch, const float2 *s_wl, int jj, const float2 *bh, int bh_pitch) {
+    float2 v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float2 u = px[(size_t)r * pitch];
+        if (bh) { u = cmul(u, bh[(size_t)r * bh_pitch]); u.y = -u.y; }
+        v[r] = r ? cmul(u, s_wl[r * jj]) : u;
+    }
+    CfDft<R>::run(v);
+#pragma unroll
+    for (int q = 0; q < R; ++q) px[(size_t)q * pitch] = v[q];
+}
+template <int R>
+__device__ __forceinline__ void cf_blue_subpass(const ChanFftGeom &g, int k, bool inverse, float2 *s_x, float2 *s_ws, const float2 *s_tw, const float2 *s_wl, const float2 *s_bh,
+                                                const float2 *s_c, int tid, int nthr) {
+    const int TF = g.TF, TFs = g.TFs, L = g.bL, p = g.bp, s0 = g.M / p, span = g.bspan[k], lgspan = __builtin_ctz((unsigned)span), lgR = __builtin_ctz((unsigned)R);
+    const int per = L >> lgR, lgper = g.blgL - lgR, items = (s0 * per) << g.lgTF, twstep = L / (R * span);
+    for (int it = tid; it < items; it += nthr) {
+        const int t = it & (TF - 1), rest = it >> g.lgTF, bf = rest & (per - 1), j = rest >> lgper;
+        const int b = bf >> lgspan, jj = bf & (span - 1), pos0 = b * R * span + jj;
+        float2 *px = s_ws + ((size_t)j * L + pos0) * TFs + t;
+        const int pitch = span * TFs;
+        if (k == 0 && !inverse) {
+            // first forward sub-pass (one block: pos0 = jj): its operands are the tile's rows times the chirp, zeros past the factor's length -- read in place
+            float2 v[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int n = jj + span * q;
+                v[q] = n < p ? cmul(s_x[(size_t)(j + s0 * n) * TFs + t], s_c[n]) : make_float2(0.f, 0.f);
+            }
+            CfDft<R>::run(v);
+            px[0] = v[0];
+#pragma unroll
+            for (int r = 1; r < R; ++r) px[(size_t)r * pitch] = cmul(v[r], s_wl[r * jj * twstep]);
+        } else if (k == 0) {
+            // last inverse sub-pass: its results are the convolution (conjugated): times the chirp and the pass's own twiddle, straight back into the tile
+            float2 v[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float2 u = px[(size_t)r * pitch];
+                if (g.bnpass == 1) { u = cmul(u, s_bh[pos0 + r * span]); u.y = -u.y; }
+                v[r] = r ? cmul(u, s_wl[r * jj * twstep]) : u;
+            }
+            CfDft<R>::run(v);
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int n = jj + span * q;
+                if (n < p) s_x[(size_t)(j + s0 * n) * TFs + t] = cmul(make_float2(v[q].x, -v[q].y), cmul(s_c[n], s_tw[j * n]));      // j n < M
+            }
+        } else if (!inverse) cf_pass_item<R>(px, pitch, s_wl, jj * twstep);
+        else cf_ipass_item<R>(px, pitch, s_wl, jj * twstep, k == g.bnpass - 1 ? s_bh + pos0 : nullptr, span);
+    }
+}
+__device__ __forceinline__ void cf_blue_dispatch(const ChanFftGeom &g, int k, bool inverse, float2 *s_x, float2 *s_ws, const float2 *s_tw, const float2 *s_wl, const float2 *s_bh,
+                                                 const float2 *s_c, int tid, int nthr) {
+    switch (g.bradix[k]) {
+        case 2: cf_blue_subpass<2>(g, k, inverse, s_x, s_ws, s_tw, s_wl, s_bh, s_c, tid, nthr); break;
+        case 4: cf_blue_subpass<4>(g, k, inverse, s_x, s_ws, s_tw, s_wl, s_bh, s_c, tid, nthr); break;
+        case 8: cf_blue_subpass<8>(g, k, inverse, s_x, s_ws, s_tw, s_wl, s_bh, s_c, tid, nthr); break;
+        default: cf_blue_subpass<16>(g, k, inverse, s_x, s_ws, s_tw, s_wl, s_bh, s_c, tid, nthr); break;
+    }
+}
+// pass 0 of a plan with a prime factor bp: y[r] = W_M^(j r) sum_q x[q] W_bp^(q r) for every column j < s0 = M / bp and frame, rows j + s0 q -> j + s0 r,
+// as the chirp-z convolution  y[r] = W_M^(j r) c[r] sum_q (x[q] c[q]) conj(c[r - q]),  c[n] = exp(-j pi n^2 / bp):
+//   forward bL-point sub-passes (the first reads the tile's rows times the chirp, zero padded) | times the transformed chirp filter, inverse sub-passes
+//   on conjugated data (the last writes the tile's rows: times the chirp and W_M^(j r))
+__device__ __forceinline__ void cf_blue_pass(const ChanFftGeom &g, float2 *s_x, float2 *s_ws, const float2 *s_tw, const float2 *s_wl, const float2 *s_bh, const float2 *s_c,
+                                             int tid, int nthr) {
+    for (int k = 0; k < g.bnpass; ++k) { cf_blue_dispatch(g, k, false, s_x, s_ws, s_tw, s_wl, s_bh, s_c, tid, nthr); lds_barrier(); }
+    for (int k = g.bnpass - 1; k >= 0; --k) { cf_blue_dispatch(g, k, true, s_x, s_ws, s_tw, s_wl, s_bh, s_c, tid, nthr); if (k) lds_barrier(); }
+}
+
 // one butterfly of the last pass (span 1): results go to their channel rows
 // (OS2, the oversampled bank: s_pa holds (row << 1) | (channel is odd) -- -1 stays -1 --, s_post the post factor W_M^k / M of firpfbch2 of the channel at
 //  each position; odd channels change sign in the frames of odd parity, design::channelizer2_post)
@@ -379,7 +507,7 @@ __device__ __forceinline__ void cf_fir(const float4 (&win)[kCfSeg + kChanTaps - 
 // which radices an instance of the kernel carries: PLAN 0 = every small radix (+ 17 / 19 / 23 when WIDE); 1 = {16, 8} (M = 1024 = 16 * 8 * 8: BASELINE
 // config 4), 2 = {5, 8} (M = 200 = 5 * 5 * 8: config 5), 3 = {5, 4} (M = 20: config 2)
 __host__ __device__ constexpr bool cf_plan_has(int plan, int R, bool wide) {
-    return plan == 1 ? (R == 16 || R == 8) : plan == 2 ? (R == 5 || R == 8) : plan == 3 ? (R == 5 || R == 4) : (R < 17 || wide);
+    return plan == 1 ? (R == 16 || R == 8) : plan == 2 ? (R == 5 || R == 8) : plan == 3 ? (R == 5 || R == 4) : (R < 17 || wide);      // (plan 4: every small radix + the chirp-z pass)
 }
 __host__ inline int cf_plan_of(const ChanFftGeom &g) {
     if (g.os2 || g.wide_odd) return 0;
@@ -421,7 +549,11 @@ CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
     float2 *s_tw = s_x + (size_t)M * TFs;                            // W_M^i
     float2 *s_dc = s_tw + M;                                         // channel 0 of the tile
     float2 *s_post = s_dc + TF;                                      // OS2: post factor of the channel at each position
-    int *s_pa = reinterpret_cast<int *>(s_post + (OS2 ? M : 0));     // position -> output row of its channel (the channel itself unless the rows are packed), or -1 when it has no consumer
+    // chirp-z plan (PLAN 4): the work array and its three tables sit between the post factors' place and the row list; `post` carries the tables
+    float2 *s_ws = s_post + (OS2 ? M : 0);
+    const size_t blue_ws = (PLAN == 4 && g.bp) ? (size_t)(M / g.bp) * g.bL * TFs : 0;
+    float2 *s_wl = s_ws + blue_ws, *s_bh = s_wl + ((PLAN == 4) ? g.bL : 0), *s_c = s_bh + ((PLAN == 4) ? g.bL : 0);
+    int *s_pa = reinterpret_cast<int *>(s_c + ((PLAN == 4) ? g.bp : 0));     // position -> output row of its channel (the channel itself unless the rows are packed), or -1 when it has no consumer
     const int tid = threadIdx.x, nthr = blockDim.x;
     for (int i = tid; i < M; i += nthr) {
         const int ch = perm[i];
@@ -430,6 +562,7 @@ CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
         s_pa[i] = !OS2 ? row : (row < 0 ? -1 : ((row << 1) | (ch & 1)));      // (oversampled: the channel's parity rides along, cf_last_item)
         if (OS2) s_post[i] = post[ch];
     }
+    if constexpr (PLAN == 4) for (int i = tid; i < 2 * g.bL + g.bp; i += nthr) s_wl[i] = post[i];
 
     const int64_t ntiles = (n_frames + TF - 1) >> g.lgTF;
     const int half = M >> 1, nfir = half * (TF / kCfSeg);
@@ -485,6 +618,7 @@ CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
         for (int p = 0; p < g.npass; ++p) {
             const bool lastp = p == g.npass - 1;
             float2 *dcs = dc_ends ? s_dc : nullptr;
+            if constexpr (PLAN == 4) if (p == 0) { cf_blue_pass(g, s_x, s_ws, s_tw, s_wl, s_bh, s_c, tid, nthr); lds_barrier(); continue; }
 #define CSDR_CF_CASE(R_)                                                                                                                         \
             case R_:                                                                                                                             \
                 if constexpr (cf_plan_has(PLAN, R_, WIDE)) {                                                                                     \
