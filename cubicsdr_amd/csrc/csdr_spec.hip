@@ -34,6 +34,8 @@ struct csdr_spec {
     uint64_t seq = 0;
     hipEvent_t ev_fft_done[2] = {nullptr, nullptr}, ev_avg_done[2] = {nullptr, nullptr};
     bool avg_pending[2] = {false, false};
+    const float2 *carry_fold_src = nullptr;  // contiguous mode, fused chain: the samples behind the last whole frame, copied to `carry` by the display launch (> 0: pending, -1: done)
+    int carry_fold_n = 0;
     int tmp_reader = -1;                     // magnitude copy whose ev_avg_done also covers a reader of `tmp` on lane AVG (the fused chain's row pass), -1: none
     DevBuf<double> ma, maa;
     DevBuf<float2> ext_w, ext;
@@ -357,12 +359,22 @@ static int spec_post_range(csdr_spec *s, const float *mag, int f0, int cnt, int 
         const int npairs = kS3C / 2;
         CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_rows256_ema, dim3(npairs), dim3(kR2Threads), kR2Lds, s->tmp.p + (size_t)f0 * g.N, cnt, g, (double)s->avg_rate, s->tw4096.p,
                     s->ma.p, s->maa.p, s->pairsum.p + f0 * F, s->first_b.p + f0, s->ext_w.p + (size_t)f0 * npairs);
-        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_extrema, dim3(cnt), dim3(256), (size_t)(256 / 64) * sizeof(float2), s->ext_w.p + (size_t)f0 * npairs, npairs, s->ext.p + f0);
         const SpecScalars *st_in = s->scal.p + s->scal_parity;
-        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_trackers, dim3(cnt), dim3(kDispThreads), kTrackLds, s->ext.p + f0, cnt, st_in, s->scal.p + (s->scal_parity ^ 1),
-                    s->fo.p + f0, s->fsc.p + f0, cnt, (const SpecFrameOut *)nullptr);
+        if (f0 == 0 && cnt <= kTrackSmallFrames) {
+            // a short batch (the one-block call: 7 or 8 frames): extrema and trackers in one launch
+            CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_trackers, dim3(cnt), dim3(kDispThreads), kTrackLds + (size_t)cnt * sizeof(float2), s->ext.p, cnt, st_in,
+                        s->scal.p + (s->scal_parity ^ 1), s->fo.p, s->fsc.p, cnt, (const SpecFrameOut *)nullptr, s->ext_w.p, npairs, s->ext.p);
+        } else {
+            CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_extrema, dim3(cnt), dim3(256), (size_t)(256 / 64) * sizeof(float2), s->ext_w.p + (size_t)f0 * npairs, npairs, s->ext.p + f0);
+            CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_trackers, dim3(cnt), dim3(kDispThreads), kTrackLds, s->ext.p + f0, cnt, st_in, s->scal.p + (s->scal_parity ^ 1),
+                        s->fo.p + f0, s->fsc.p + f0, cnt, (const SpecFrameOut *)nullptr, (const float2 *)nullptr, 0, (float2 *)nullptr);
+        }
+        // (the carry of a contiguous stream rides on the display launch: csdr_spec_process sets carry_src for a batch whose range starts at frame 0)
+        const bool carry_here = f0 == 0 && s->carry_fold_n > 0;
         CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_DISPLAY, spec_display_p256, dim3(64, cnt), dim3(kDispThreads), 32 * 33 * sizeof(float),
-                    s->pairsum.p + f0 * F, s->first_b.p + f0, s->fsc.p + f0, g, s->scale, s->points.p + f0 * F);
+                    s->pairsum.p + f0 * F, s->first_b.p + f0, s->fsc.p + f0, g, s->scale, s->points.p + f0 * F,
+                    carry_here ? s->carry_fold_src : (const float2 *)nullptr, carry_here ? s->carry.p : (float2 *)nullptr, carry_here ? s->carry_fold_n : 0);
+        if (carry_here) s->carry_fold_n = -1;                        // done
         s->scal_parity ^= 1;
         CSDR_HIP_TRY(hipGetLastError());
         return CSDR_OK;
@@ -385,7 +397,7 @@ static int spec_post_range(csdr_spec *s, const float *mag, int f0, int cnt, int 
     }
     // trackers of every frame (closed form, one workgroup per frame), then the display: the transposing path takes one tile per workgroup
     CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_trackers, dim3(cnt), dim3(kDispThreads), kTrackLds, s->ext.p + f0, cnt, st_in, s->scal.p + (s->scal_parity ^ 1),
-                s->fo.p + f0, s->fsc.p + f0, hold ? pk_from : cnt, hold ? s->pfo.p + f0 : (const SpecFrameOut *)nullptr);
+                s->fo.p + f0, s->fsc.p + f0, hold ? pk_from : cnt, hold ? s->pfo.p + f0 : (const SpecFrameOut *)nullptr, (const float2 *)nullptr, 0, (float2 *)nullptr);
     const int npairs = g.Ra == 1 ? 1 : (g.Ra >> 1) * g.Rb;
     const bool transposing = !view && g.Ra > 1 && npairs <= kDispMaxPairs;
     const size_t disp_lds = transposing ? disp_lds_bytes(npairs, g.lgRa - 1 + g.lgRb, hold) : kDispLdsPlain;
@@ -722,6 +734,11 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
     const bool first_input_has_frame = !(mode == CSDR_SPEC_LINES && nf < n_blocks);
     const int n_inputs = mode == CSDR_SPEC_CONTIGUOUS ? nf : n_blocks;
     if (nf == 0 && n_inputs > 0) { if (int rc = spec_post_frames(s, nullptr, 0, n_inputs, first_input_has_frame)) return rc; }
+    s->carry_fold_n = 0;
+    if (mode == CSDR_SPEC_CONTIGUOUS && nf > 0 && s->fused_now) {      // the fused chain's display launch takes the carry copy along (spec_post_range)
+        const int rem = (int)(s->carry_len + n - (int64_t)nf * N);
+        if (rem > 0) { s->carry_fold_src = x + (n - rem); s->carry_fold_n = rem; }
+    }
     if (nf > 0)
         if (int rc = spec_fft_then(s, fs, nf, [&](float *mag) { return spec_post_frames(s, mag, nf, n_inputs, first_input_has_frame); })) return rc;
     if (mode == CSDR_SPEC_LINES) if (int rc = spec_lines_end(s, lines_x, block_len, lines_n)) return rc;
@@ -731,9 +748,10 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
         const int rem = (int)(total - (int64_t)nf * N);
         if (nf == 0) {
             CSDR_HIP_TRY(hipMemcpyAsync(s->carry.p + s->carry_len, x, (size_t)n * sizeof(float2), hipMemcpyDeviceToDevice, st));
-        } else if (rem > 0) {
+        } else if (rem > 0 && s->carry_fold_n != -1) {               // (-1: the display launch of this call has taken it)
             CSDR_HIP_TRY(hipMemcpyAsync(s->carry.p, x + (n - rem), (size_t)rem * sizeof(float2), hipMemcpyDeviceToDevice, st));
         }
+        s->carry_fold_n = 0;
         s->carry_len = rem;
     }
     s->last_view = false;                                                        // :631

@@ -765,13 +765,28 @@ struct SpecFrameScal { double pc, pf, fl; };  // point_ceil, point_floor, fft_fl
 //                maa_f = a^(f+1) maa_in + b (f+1) a^(f+1) ma_in + b^2 sum_i (f-i+1) a^(f-i) c_i      (maa uses the NEW ma)
 // as parallel weighted sums over i <= f (double; equal to the serial loop to ~1e-15 relative); the last frame publishes the end
 // state (ping-pong copy).
+// (ext_w != nullptr -- short batches, the one-block call of the real-time shape: the per-frame extrema are formed HERE from the averaging pass's
+//  per-tile values, every workgroup for the frames up to its own, into LDS behind the reduction scratch: one launch less in a chain of 5 us launches)
+constexpr int kTrackSmallFrames = 32;
 CSDR_KERNEL_SPEC __launch_bounds__(kDispThreads) void spec_trackers(const float2 *__restrict__ ext, int nf, const SpecScalars *__restrict__ st_in,
                                                               SpecScalars *__restrict__ st_out, SpecFrameOut *__restrict__ fo,
-                                                              SpecFrameScal *__restrict__ fsc, int pk_from, const SpecFrameOut *__restrict__ pfo) {
+                                                              SpecFrameScal *__restrict__ fsc, int pk_from, const SpecFrameOut *__restrict__ pfo,
+                                                              const float2 *__restrict__ ext_w, int ntiles, float2 *__restrict__ ext_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *s_sum = reinterpret_cast<double *>(smem);          // reduction scratch [waves][4]
     const int f = blockIdx.x, tid = threadIdx.x;
     const SpecScalars s_in = *st_in;
+    if (ext_w) {
+        float2 *s_ext = reinterpret_cast<float2 *>(smem + kTrackLds);      // [nf <= kTrackSmallFrames]
+        for (int i = tid >> 6; i <= f; i += kDispThreads / 64) {            // a wave per frame (spec_extrema's arithmetic: max from 0, min from 3e38)
+            float mx = 0.f, mn = 3.0e38f;
+            for (int w0 = tid & 63; w0 < ntiles; w0 += 64) { const float2 v = ext_w[(int64_t)i * ntiles + w0]; mx = fmaxf(mx, v.x); mn = fminf(mn, v.y); }
+            for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_down(mx, o, 64)); mn = fminf(mn, __shfl_down(mn, o, 64)); }
+            if ((tid & 63) == 0) { s_ext[i] = make_float2(mx, mn); if (i == f && ext_out) ext_out[f] = make_float2(mx, mn); }
+        }
+        __syncthreads();
+        ext = s_ext;
+    }
     double w_c = 0.0, w_c2 = 0.0, w_d = 0.0, w_d2 = 0.0;
     for (int i = tid; i <= f; i += kDispThreads) {
         const float2 e = ext[i];

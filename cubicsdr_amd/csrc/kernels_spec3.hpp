@@ -266,9 +266,14 @@ CSDR_KERNEL __launch_bounds__(kR2Threads) void spec_rows256_ema(const float2 *__
 
 // ---- K16 for the pair-row order of spec_rows256_ema: pairsum[f][pair][k2], display point x = (pair + 256 k2 - N / 4) mod F.
 // grid = (8 x 8 tiles of 32 pairs x 32 k2, frames); reads 32 runs of 128 bytes, writes 32 runs of 128 bytes.
+// (carry_n > 0: the workgroups of frame 0 also move the samples behind the batch's last whole frame to the carry buffer -- the last launch of a call's chain
+//  takes the copy that was a 4 us transfer of its own; nothing of this launch reads either buffer)
 CSDR_KERNEL __launch_bounds__(kDispThreads) void spec_display_p256(const float *__restrict__ pairsum, const float *__restrict__ first_b,
-                                                                  const SpecFrameScal *__restrict__ fsc, SpecGeom g, float sf, float *__restrict__ points) {
+                                                                  const SpecFrameScal *__restrict__ fsc, SpecGeom g, float sf, float *__restrict__ points,
+                                                                  const float2 *__restrict__ carry_src, float2 *__restrict__ carry_dst, int carry_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (carry_n > 0 && blockIdx.y == 0)
+        for (int i = (int)(blockIdx.x * kDispThreads + threadIdx.x); i < carry_n; i += (int)(gridDim.x * kDispThreads)) carry_dst[i] = carry_src[i];
     float *s_y = reinterpret_cast<float *>(smem);                    // [32 k2][33]
     const int f = blockIdx.y, tid = threadIdx.x, F = g.F;
     const int npairs = kS3C / 2;
