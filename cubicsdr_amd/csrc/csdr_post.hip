@@ -123,7 +123,8 @@ typedef void (*chanfft_kernel_t)(const float2 *, const float2 *, float2 *, const
 static chanfft_kernel_t chanfft_kernel(const ChanFftGeom &g) {
     if (g.os2) return g.wide_odd ? chan_analyze_fft<true, true> : chan_analyze_fft<false, true>;
     if (g.wide_odd) return chan_analyze_fft<true, false>;
-    if (g.bp) return chan_analyze_fft<false, false, 4>;            // a prime factor >= 29: the instance with the chirp-z pass
+    if (g.bp) return chan_analyze_fft<false, false, 4>;            // a prime factor >= 97: the instance with the chirp-z pass
+    if (g.dp) return chan_analyze_fft<false, false, 5>;            // a prime factor 29 .. 89: the instance with the direct prime pass
     switch (lab_int("CSDR_CHANFFT_PLAN", 1) ? cf_plan_of(g) : 0) {      // the BASELINE channel counts have an instance of their own (only their radices: fewer registers)
         case 1: return chan_analyze_fft<false, false, 1>;
         case 2: return chan_analyze_fft<false, false, 2>;
@@ -228,8 +229,8 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
             for (int i = 0; i < M; i++) twM[(size_t)i] = W(i, M);
             if (int rc = p->perm.reserve(fperm.size())) return rc;
             CSDR_HIP_TRY(hipMemcpyAsync(p->perm.p, fperm.data(), fperm.size() * sizeof(int), hipMemcpyHostToDevice, st));
-            if (p->fgeom.bp) {      // tables of the chirp-z pass: they travel in the place of firpfbch2's post factors (never both)
-                const std::vector<float2> bt = chanfft_blue_tables(p->fgeom);
+            if (p->fgeom.bp || p->fgeom.dp) {      // tables of the chirp-z / direct prime pass: they travel in the place of firpfbch2's post factors (never both)
+                const std::vector<float2> bt = p->fgeom.bp ? chanfft_blue_tables(p->fgeom) : chanfft_direct_tables(p->fgeom);
                 if (int rc = p->post2.reserve(bt.size())) return rc;
                 CSDR_HIP_TRY(hipMemcpy(p->post2.p, bt.data(), bt.size() * sizeof(float2), hipMemcpyHostToDevice));
             }
@@ -380,7 +381,7 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
             const int wgs = std::min(ntiles, std::max(1, c->wg_slots(kf, fg.threads, lds) * lab_int("CSDR_CHANFFT_PCT", 100) / 100));
             CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, kf, dim3(wgs), dim3(fg.threads), lds, x, hist, hist_new, p->taps.p,
                         p->twM.p, p->perm.p, p->active.p, fg, n_frames, out, p->chan_stride, fused_ends ? p->tile_end.p : (d2 *)nullptr, p->dc_c,
-                        (p->mode == CSDR_POST_PFBCH2 || fg.bp) ? p->post2.p : (const float2 *)nullptr);
+                        (p->mode == CSDR_POST_PFBCH2 || fg.bp || fg.dp) ? p->post2.p : (const float2 *)nullptr);
         } else if (g.p2) {
             // persistent workgroups: as many as are resident at once, each walks over tiles blockIdx.x, + gridDim.x, ...
             const chan_p2_kernel_t k2 = chan_p2_kernel(g);

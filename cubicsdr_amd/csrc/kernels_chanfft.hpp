@@ -56,7 +56,12 @@ struct ChanFftGeom {
     // pass 0 is its bp-point transform, run as a chirp-z convolution of length bL (the power of two >= 2 bp - 1) in a work array beside the tile
     int bp, bL, blgL;                     // 0: no such factor
     int bnpass, bradix[4], bspan[4];      // the bL-point transform: radices 16 / 8 / 4 / 2, span of sub-pass k inside bL
+    // a prime factor 29 .. 89: pass 0 is its direct transform in the conjugate-pair form of chan_analyze_p2's transform phase (lane = (column, frame),
+    // wave = four output pairs, (cos, sin) rows wave-uniform), out of place into a second tile
+    int dp, dnk, dPA;                     // the prime (0: none), groups of four output-pair slots, pitch of a (cos, sin) row
+    unsigned magic_s0;                    // floor(2^32 / (M / dp)) + 1
 };
+constexpr int kCfDirectKP = 4;
 // (measured, profiles/r06_chirpz_channel_counts.txt: the convolution costs 2.2 - 2.6 x the factor's own data in LDS work space and six to eight trips through
 //  it; against the two-factor direct-DFT kernel it wins from p ~ 100 on -- M = 202: 1.0 against 1.3 ms, M = 398: 1.2 against 3.6 ms -- and loses below
 //  -- M = 134: 1.5 against 0.7 ms; smaller primes stay on chan_analyze)
@@ -64,7 +69,7 @@ constexpr int kCfBlueMinPrime = 97, kCfBlueMaxPrime = 509;
 
 __host__ __device__ inline size_t chanfft_lds_bytes(const ChanFftGeom &g) {
     // (oversampled: + the M post factors; chirp-z pass: + the work array of M / bp transforms of bL points per frame, W_bL, the transformed chirp, the chirp)
-    const size_t blue = g.bp ? (size_t)(g.M / g.bp) * g.bL * g.TFs + 2 * (size_t)g.bL + g.bp : 0;
+    const size_t blue = g.bp ? (size_t)(g.M / g.bp) * g.bL * g.TFs + 2 * (size_t)g.bL + g.bp : g.dp ? (size_t)g.M * g.TFs : 0;      // (direct prime pass: the second tile)
     return ((size_t)g.M * g.TFs + g.M + g.TF + (g.os2 ? g.M : 0) + blue) * sizeof(float2) + (size_t)g.M * sizeof(int);
 }
 
@@ -85,10 +90,15 @@ __host__ inline bool chanfft_plan(int M, size_t lds_limit, int force_tf, int for
     for (int p : {5, 7, 11, 13, 17, 19, 23}) while (m % p == 0) { m /= p; rad.push_back(p); if (p >= 17) g.wide_odd = 1; }
     if (m != 1) {
         // what is left: ONE prime >= 29 can go through the chirp-z pass (critically sampled bank, no 17 / 19 / 23 beside it: one kernel instance)
-        bool prime = m >= kCfBlueMinPrime && m <= kCfBlueMaxPrime;
+        bool prime = m >= 29 && m <= kCfBlueMaxPrime;
         for (int d = 3; prime && d * d <= m; d += 2) prime = m % d != 0;
         if (!prime || os2 || g.wide_odd) return false;
-        g.bp = m;
+        if (m < kCfBlueMinPrime) {                // the direct pass
+            g.dp = m;
+            const int H = (m - 1) / 2;
+            g.dnk = (H + 1 + kCfDirectKP - 1) / kCfDirectKP; g.dPA = g.dnk * kCfDirectKP;
+            g.magic_s0 = (unsigned)((1ull << 32) / (unsigned)(M / m)) + 1u;
+        } else g.bp = m;
         g.blgL = 0; while ((1 << g.blgL) < 2 * m - 1) ++g.blgL;
         g.bL = 1 << g.blgL;
         g.bnpass = (g.blgL + 3) / 4;
@@ -117,6 +127,14 @@ __host__ inline bool chanfft_plan(int M, size_t lds_limit, int force_tf, int for
     if (g.bp) { g.radix[0] = g.bp; g.span[0] = M / g.bp; }        // (chanfft_lds_bytes of a chirp-z plan)
     while (tf < 256 && 141 * tf * M <= 100 * target) tf <<= 1;    // the power of two nearest target / M (on a log scale)
     while (tf > (os2 ? 2 * kCfSeg : kCfSeg) && !fits(tf)) tf >>= 1;      // (oversampled: eight frames of EACH lattice per tile at least)
+    bool dp_wide = false;
+    if (g.dp) {
+        // direct prime pass (two sweeps in profiles/r06_prime_channel_counts.txt): the largest tile that leaves two workgroups per CU; where that fills less
+        // than a wave with (column, frame) lanes, twice the tile and 1024 threads instead
+        tf = 32;
+        while (tf > kCfSeg && (!fits(tf) || chanfft_lds_bytes(g) > 80 * 1024)) tf >>= 1;
+        if ((M / g.dp) * tf < 64 && fits(2 * tf)) { tf *= 2; dp_wide = true; }
+    }
     if (g.bp) { tf = M >= 280 ? 16 : 8; while (tf > kCfSeg && !fits(tf)) tf >>= 1; }      // chirp-z plans: small tiles, several workgroups per CU (sweep in profiles/r06_chirpz_channel_counts.txt)
     if (force_tf >= kCfSeg && !(force_tf & (force_tf - 1)) && fits(force_tf)) tf = force_tf;
     if (!fits(tf)) return false;
@@ -126,6 +144,7 @@ __host__ inline bool chanfft_plan(int M, size_t lds_limit, int force_tf, int for
     g.threads = 256;
     while (g.threads < kCfMaxThreads && g.threads < fir_items) g.threads <<= 1;
     if (g.bp) g.threads = M >= 280 ? 1024 : 512;
+    if (g.dp) g.threads = dp_wide ? 1024 : 512;
     if (force_threads >= 64 && force_threads <= kCfMaxThreads && !(force_threads & 63)) g.threads = force_threads;
     g.xcd = M >= 64;             // (C4: + 5 %, M = 20: nothing)
     // pos = sum_p r_p s_p holds channel k = r_0 + R_0 (r_1 + R_1 (r_2 + ...)) after the last pass
@@ -136,6 +155,18 @@ __host__ inline bool chanfft_plan(int M, size_t lds_limit, int force_tf, int for
         perm[pos] = k;
     }
     return true;
+}
+
+// (cos, sin)(2 pi k(q) c / p) of the direct prime pass at [(c - 1) dPA + q], c = 1 .. (p - 1) / 2; slot q: k = q + 1 (q < H), k = 0 (q == H: (1, 0)), (0, 0) beyond
+__host__ inline std::vector<float2> chanfft_direct_tables(const ChanFftGeom &g) {
+    const int p = g.dp, H = (p - 1) / 2;
+    std::vector<float2> t((size_t)H * g.dPA, make_float2(0.f, 0.f));
+    for (int c = 1; c <= H; ++c) for (int q = 0; q <= H; ++q) {
+        const int k = q < H ? q + 1 : 0;
+        const double a = 2.0 * M_PI * (double)(((int64_t)c * k) % p) / (double)p;
+        t[(size_t)(c - 1) * g.dPA + q] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    return t;
 }
 
 // tables of the chirp-z pass, in double on the host: W_L^i (L), the transformed chirp filter at the positions the forward sub-passes leave the
@@ -386,6 +417,65 @@ __device__ __forceinline__ void cf_blue_pass(const ChanFftGeom &g, float2 *s_x, 
     for (int k = g.bnpass - 1; k >= 0; --k) { cf_blue_dispatch(g, k, true, s_x, s_ws, s_tw, s_wl, s_bh, s_c, tid, nthr); if (k) lds_barrier(); }
 }
 
+// pass 0 of a plan with a prime factor dp = 29 .. 89, rows j + s0 q of s_x -> rows j + s0 r of s_y:  y[r] = W_M^(j r) sum_q x[q] W_dp^(q r).
+// Step A forms s_c = x_c + x_{dp-c} and d_c = x_c - x_{dp-c} in place (rows c and dp - c of every column); step B is chan_analyze_p2's transform phase:
+// a lane owns one (column j, frame t), a wave four output-pair slots; P_k = x_0 + sum_c s_c cos, Q_k = sum_c d_c sin with the (cos, sin) rows wave-uniform
+// (scalar loads); y_k = P_k - j Q_k, y_{dp-k} = P_k + j Q_k, times the pass's twiddle, into the second tile (another wave still reads the first).
+template <int KP>
+__device__ __forceinline__ void cf_prime_pass(const ChanFftGeom &g, float2 *s_x, float2 *s_y, const float2 *s_tw, const float2 *__restrict__ cs, int tid, int nthr) {
+    const int TF = g.TF, TFs = g.TFs, p = g.dp, s0 = g.M / p, H = (p - 1) >> 1;
+    for (int it = tid; it < ((s0 * H) << g.lgTF); it += nthr) {
+        const int t = it & (TF - 1);
+        const unsigned rest = (unsigned)it >> g.lgTF, c1 = s0 == 1 ? rest : __umulhi(rest, g.magic_s0), j = rest - c1 * (unsigned)s0;
+        float2 *pa = s_x + (size_t)(j + s0 * (c1 + 1)) * TFs + t, *pb = s_x + (size_t)(j + s0 * (p - 1 - c1)) * TFs + t;
+        const float2 a = *pa, b = *pb;
+        *pa = make_float2(a.x + b.x, a.y + b.y); *pb = make_float2(a.x - b.x, a.y - b.y);
+    }
+    lds_barrier();
+    const int lane = tid & 63, wave = wave_uniform(tid >> 6), nw = nthr >> 6;
+    const int n_li = s0 << g.lgTF, lgroups = (n_li + 63) >> 6, tasks = lgroups * g.dnk;
+    for (int task = wave; task < tasks; task += nw) {
+        const int sg = task / lgroups, lg = task - sg * lgroups;          // (wave-uniform)
+        const int li = min(lg * 64 + lane, n_li - 1);
+        const bool live = lg * 64 + lane < n_li;
+        const int t = li & (TF - 1), j = li >> g.lgTF;
+        const float2 *col = s_x + (size_t)j * TFs + t;
+        const int rs = s0 * TFs;                                           // row c of this column: col + c rs
+        const float2 x0 = col[0];
+        float2 P[KP], Q[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) { P[k] = x0; Q[k] = make_float2(0.f, 0.f); }
+        const float2 *w = cs + sg * KP;
+        float2 sa = col[rs], da = col[(size_t)(p - 1) * rs];
+        for (int c = 1; c <= H; ++c) {
+            const int cn = min(c + 1, H);
+            const float2 sn = col[(size_t)cn * rs], dn = col[(size_t)(p - cn) * rs];      // the next term's rows, requested before this term's arithmetic
+            float2 e[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) e[k] = w[k];
+            w += g.dPA;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                P[k].x = fmaf(sa.x, e[k].x, P[k].x); P[k].y = fmaf(sa.y, e[k].x, P[k].y);
+                Q[k].x = fmaf(da.x, e[k].y, Q[k].x); Q[k].y = fmaf(da.y, e[k].y, Q[k].y);
+            }
+            sa = sn; da = dn;
+        }
+        float2 *ycol = s_y + (size_t)j * TFs + t;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int q = sg * KP + k;                                         // (wave-uniform)
+            if (q < H) {
+                const int kk = q + 1, kn = p - kk;
+                if (live) {
+                    ycol[(size_t)kk * rs] = cmul(make_float2(P[k].x + Q[k].y, P[k].y - Q[k].x), s_tw[j * kk]);      // j r < M
+                    ycol[(size_t)kn * rs] = cmul(make_float2(P[k].x - Q[k].y, P[k].y + Q[k].x), s_tw[j * kn]);
+                }
+            } else if (q == H) { if (live) ycol[0] = P[k]; }
+        }
+    }
+}
+
 // one butterfly of the last pass (span 1): results go to their channel rows
 // (OS2, the oversampled bank: s_pa holds (row << 1) | (channel is odd) -- -1 stays -1 --, s_post the post factor W_M^k / M of firpfbch2 of the channel at
 //  each position; odd channels change sign in the frames of odd parity, design::channelizer2_post)
@@ -551,7 +641,7 @@ CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
     float2 *s_post = s_dc + TF;                                      // OS2: post factor of the channel at each position
     // chirp-z plan (PLAN 4): the work array and its three tables sit between the post factors' place and the row list; `post` carries the tables
     float2 *s_ws = s_post + (OS2 ? M : 0);
-    const size_t blue_ws = (PLAN == 4 && g.bp) ? (size_t)(M / g.bp) * g.bL * TFs : 0;
+    const size_t blue_ws = (PLAN == 4 && g.bp) ? (size_t)(M / g.bp) * g.bL * TFs : (PLAN == 5 && g.dp) ? (size_t)M * TFs : 0;      // (PLAN 5, direct prime pass: the second tile)
     float2 *s_wl = s_ws + blue_ws, *s_bh = s_wl + ((PLAN == 4) ? g.bL : 0), *s_c = s_bh + ((PLAN == 4) ? g.bL : 0);
     int *s_pa = reinterpret_cast<int *>(s_c + ((PLAN == 4) ? g.bp : 0));     // position -> output row of its channel (the channel itself unless the rows are packed), or -1 when it has no consumer
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -615,15 +705,17 @@ CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
 
         // ---- FFT passes: item = (butterfly bf, frame t), lanes along t.  The radix is a property of the PASS: one dispatch per pass, the item loop
         // inside it has a compile-time radix (and an instance built for a plan -- PLAN != 0 -- carries only its own radices: registers sized by the plan)
+        float2 *s_t = s_x;                                          // the tile the passes work on (a direct prime pass moves it to the second array)
         for (int p = 0; p < g.npass; ++p) {
             const bool lastp = p == g.npass - 1;
             float2 *dcs = dc_ends ? s_dc : nullptr;
             if constexpr (PLAN == 4) if (p == 0) { cf_blue_pass(g, s_x, s_ws, s_tw, s_wl, s_bh, s_c, tid, nthr); lds_barrier(); continue; }
+            if constexpr (PLAN == 5) if (p == 0) { cf_prime_pass<kCfDirectKP>(g, s_x, s_ws, s_tw, post, tid, nthr); lds_barrier(); s_t = s_ws; continue; }
 #define CSDR_CF_CASE(R_)                                                                                                                         \
             case R_:                                                                                                                             \
                 if constexpr (cf_plan_has(PLAN, R_, WIDE)) {                                                                                     \
-                    if (lastp) cf_run_pass<R_, true, OS2>(g, p, s_x, s_tw, s_pa, dcs, s_post, tid, nthr, nf, out + f0, out_stride);               \
-                    else cf_run_pass<R_, false, OS2>(g, p, s_x, s_tw, s_pa, dcs, s_post, tid, nthr, nf, out + f0, out_stride);                    \
+                    if (lastp) cf_run_pass<R_, true, OS2>(g, p, s_t, s_tw, s_pa, dcs, s_post, tid, nthr, nf, out + f0, out_stride);               \
+                    else cf_run_pass<R_, false, OS2>(g, p, s_t, s_tw, s_pa, dcs, s_post, tid, nthr, nf, out + f0, out_stride);                    \
                 }                                                                                                                                \
                 break;
             switch (g.radix[p]) {

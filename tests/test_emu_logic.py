@@ -211,7 +211,7 @@ def test_emu_channelizer_m_twice_odd(ctx, fs, M, block):
     G.test_channelizer_m_twice_odd(ctx, fs, M, block)
 
 
-@pytest.mark.parametrize("M,frames", [pytest.param(M, fr, marks=() if M in (4, 20, 200, 56, 32, 68, 202) and fr != 3 else full) for M, fr in G.FFT_SIZES])
+@pytest.mark.parametrize("M,frames", [pytest.param(M, fr, marks=() if M in (4, 20, 200, 56, 32, 68, 202, 116) and fr != 3 else full) for M, fr in G.FFT_SIZES])
 def test_emu_channelizer_fft_sizes(ctx, M, frames):
     """the mixed-radix FFT channelizer (kernels_chanfft.hpp): tile walk, FIR windows across the history, every pass's indexing"""
     G.test_channelizer_fft_sizes(ctx, M, frames)

@@ -145,7 +145,7 @@ def test_channelizer_m_twice_odd(ctx, fs, M, block):
 # instance (round 5); 116 = 4 * 29 and 2048 (no 8-frame tile in 160 KB) stay on chan_analyze
 FFT_SIZES = [(2, 700), (4, 1000), (8, 515), (12, 300), (16, 260), (20, 777), (24, 130), (28, 100), (36, 70), (40, 300), (44, 65), (52, 40), (56, 66),
              (72, 50), (80, 129), (100, 90), (112, 33), (126 * 2, 20), (200, 100), (256, 37), (360, 20), (1024, 40), (2048, 19), (68, 30), (32, 5), (200, 3),
-             (76, 45), (92, 33), (136, 40), (204, 25), (116, 21), (134, 20), (146, 19), (202, 18), (398, 17), (174, 20), (194, 16), (388, 12), (254, 14), (326, 13)]
+             (76, 45), (92, 33), (136, 40), (204, 25), (116, 21), (134, 20), (146, 19), (202, 18), (398, 17), (174, 20), (194, 16), (388, 12), (254, 14), (326, 13), (232, 16), (290, 12), (348, 10), (178, 19), (356, 9)]
 
 
 @pytest.mark.parametrize("M,frames", FFT_SIZES)
@@ -155,11 +155,23 @@ def test_channelizer_fft_sizes(ctx, M, frames):
     chans = None if M <= 256 else sorted({c for c in (0, 1, 2, 3, M // 4 - 1, M // 4, M // 2 - 1, M // 2, M // 2 + 1, M - 2, M - 1, M, 77, 500, 333) if c <= M})
     from cubicsdr_amd.engine import SDRPost
     probe = SDRPost(ctx, 500000 * M, M, M * frames)
-    # (a prime factor >= 97 -- 202, 398 ... -- takes the chirp-z pass of the FFT kernel since round 6; smaller primes are faster on the direct-DFT kernel)
-    slow = M == 2048 or any(M % q == 0 for q in (29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83, 89))
-    assert probe.kernel_name == ("chan_analyze" if slow else "chan_analyze_fft"), probe.kernel_name
+    # (round 6: a prime factor 29 .. 89 -- 116, 134, 174 ... -- takes the direct prime pass of the FFT kernel, one >= 97 -- 202, 398 ... -- its chirp-z pass)
+    assert probe.kernel_name == ("chan_analyze" if M == 2048 else "chan_analyze_fft"), probe.kernel_name
     probe.close()
     _channelizer_case(ctx, 500000 * M, M, M * frames, chans=chans)
+
+
+def test_every_even_channel_count_up_to_400_takes_a_fast_kernel(ctx):
+    """getOptimalChannelCount (SoapySDRThread.cpp:676-693) returns any even number: every one of the 200 up to 400 runs the FFT channelizer or, for
+    M = 2 x odd <= 126, chan_analyze_p2 -- since round 6 also the 64 counts with a prime factor >= 29 (direct prime pass below 97, chirp-z pass from there)"""
+    from cubicsdr_amd.engine import SDRPost
+    slow = []
+    for M in range(2, 401, 2):
+        probe = SDRPost(ctx, 500000 * M, M, M * 16)
+        if probe.kernel_name not in ("chan_analyze_fft", "chan_analyze_p2"):
+            slow.append((M, probe.kernel_name))
+        probe.close()
+    assert not slow, slow
 
 
 def test_channelizer_batched_equals_blockwise(ctx):
