@@ -123,8 +123,8 @@ typedef void (*chanfft_kernel_t)(const float2 *, const float2 *, float2 *, const
 static chanfft_kernel_t chanfft_kernel(const ChanFftGeom &g) {
     if (g.os2) return g.wide_odd ? chan_analyze_fft<true, true> : chan_analyze_fft<false, true>;
     if (g.wide_odd) return chan_analyze_fft<true, false>;
-    if (g.bp) return chan_analyze_fft<false, false, 4>;            // a prime factor >= 97: the instance with the chirp-z pass
-    if (g.dp) return chan_analyze_fft<false, false, 5>;            // a prime factor 29 .. 89: the instance with the direct prime pass
+    if (g.bp) return chan_analyze_fft<false, false, 4>;            // a prime factor >= 157: the instance with the chirp-z pass
+    if (g.dp) return chan_analyze_fft<false, false, 5>;            // a prime factor 29 .. 151: the instance with the direct prime pass
     switch (lab_int("CSDR_CHANFFT_PLAN", 1) ? cf_plan_of(g) : 0) {      // the BASELINE channel counts have an instance of their own (only their radices: fewer registers)
         case 1: return chan_analyze_fft<false, false, 1>;
         case 2: return chan_analyze_fft<false, false, 2>;

@@ -56,16 +56,19 @@ struct ChanFftGeom {
     // pass 0 is its bp-point transform, run as a chirp-z convolution of length bL (the power of two >= 2 bp - 1) in a work array beside the tile
     int bp, bL, blgL;                     // 0: no such factor
     int bnpass, bradix[4], bspan[4];      // the bL-point transform: radices 16 / 8 / 4 / 2, span of sub-pass k inside bL
-    // a prime factor 29 .. 89: pass 0 is its direct transform in the conjugate-pair form of chan_analyze_p2's transform phase (lane = (column, frame),
+    // a prime factor 29 .. 151: pass 0 is its direct transform in the conjugate-pair form of chan_analyze_p2's transform phase (lane = (column, frame),
     // wave = four output pairs, (cos, sin) rows wave-uniform), out of place into a second tile
     int dp, dnk, dPA;                     // the prime (0: none), groups of four output-pair slots, pitch of a (cos, sin) row
     unsigned magic_s0;                    // floor(2^32 / (M / dp)) + 1
 };
 constexpr int kCfDirectKP = 4;
-// (measured, profiles/r06_chirpz_channel_counts.txt: the convolution costs 2.2 - 2.6 x the factor's own data in LDS work space and six to eight trips through
-//  it; against the two-factor direct-DFT kernel it wins from p ~ 100 on -- M = 202: 1.0 against 1.3 ms, M = 398: 1.2 against 3.6 ms -- and loses below
-//  -- M = 134: 1.5 against 0.7 ms; smaller primes stay on chan_analyze)
-constexpr int kCfBlueMinPrime = 97, kCfBlueMaxPrime = 509;
+// (measured, profiles/r06_chirpz_channel_counts.txt: the convolution costs 2.2 - 2.6 x the factor's own data in LDS work space and six trips through it;
+//  against the direct prime pass below it wins from p ~ 157 on -- M = 326: 1.23 against 1.26 ms, M = 398: 1.07 against 1.31 ms -- and loses below --
+//  M = 254: 0.79 against 0.59 ms, M = 194: 1.01 against 0.60 ms)
+#ifndef CSDR_CF_BLUE_MIN
+#define CSDR_CF_BLUE_MIN 157
+#endif
+constexpr int kCfBlueMinPrime = CSDR_CF_BLUE_MIN, kCfBlueMaxPrime = 509;
 
 __host__ __device__ inline size_t chanfft_lds_bytes(const ChanFftGeom &g) {
     // (oversampled: + the M post factors; chirp-z pass: + the work array of M / bp transforms of bL points per frame, W_bL, the transformed chirp, the chirp)
