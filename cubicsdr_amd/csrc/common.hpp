@@ -245,6 +245,14 @@ __device__ __forceinline__ float wave_min_to_lane63(float v) {
     return v;
 }
 #endif
+// v_mfma_f32_16x16x4_f32: D = A B + C on one wave, 16 x 16 outputs, four terms; lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15] and holds
+// D[4 (l >> 4) + r][l & 15] in element r.  Exact f32: a k-ordered fmaf chain per output, bit for bit what the vector pipe computes.
+#if defined(__AMDGCN__)
+typedef float csdr_f32x4 __attribute__((ext_vector_type(4)));
+#else
+typedef float csdr_f32x4 __attribute__((vector_size(16)));
+#endif
+__device__ __forceinline__ csdr_f32x4 csdr_mfma16(float a, float b, csdr_f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 // 16 bytes that are only guaranteed 8-byte aligned (two adjacent complex samples at an odd sample offset)
 struct __attribute__((aligned(8))) f4u { float x, y, z, w; };
 

@@ -463,7 +463,7 @@ extern "C" int csdr_bank_execute(csdr_bank *b, const csdr_post *post) {
             // each when merged) 0.318 -> 0.334 ms: not merged.  (Round 3's merged launch was slower: it had no pairing to pay for the two bodies.)
             int n5 = 0, n6 = 0;
             for (int i = 0; i < n_run; ++i) { const int d = key[3 * (size_t)i + 2]; n5 += d == 5; n6 += d == 6; }
-            static const int fe_resident = std::max(1, c->wg_slots(demod_frontend_s56<2048>, kFeThreads + 64, fes_lds_bytes<6, 2048>()));      // (one device type per process)
+            const int fe_resident = std::max(1, c->wg_slots(demod_frontend_s56<2048>, kFeThreads + 64, fes_lds_bytes<6, 2048>()));      // (memoised per context: another device, another answer)
             const bool merge56 = n5 > 0 && n6 > 0 && 4 * (n5 + n6) <= fe_resident && lab_int("CSDR_FE_MERGE56", 1) != 0;
             b->grp_merged56 = merge56;
             auto klass = [&](int i) { const int d = key[3 * (size_t)i + 2]; return (d == 5 && merge56) ? 6 : d; };

@@ -53,6 +53,9 @@ extern "C" void csdr_post_destroy(csdr_post *p) {
     delete p;
 }
 
+#ifndef CSDR_CHAN_MX_DEFAULT
+#define CSDR_CHAN_MX_DEFAULT 1          // (A/B builds: -DCSDR_CHAN_MX_DEFAULT=0 keeps the vector form of chan_analyze_p2's transform phase for every A)
+#endif
 // geometry of the channelizer kernel for M channels (see kernels_post.hpp)
 static int chan_geometry(int M, int hop, ChanGeom &g) {
     memset(&g, 0, sizeof g);
@@ -80,8 +83,8 @@ static int chan_geometry(int M, int hop, ChanGeom &g) {
         g.nkA = (slots + g.KA - 1) / g.KA;
         g.PA = g.nkA * g.KA;
         g.TF = kP2Frames; g.lgTF = 6; g.S = M; g.taps_lds = 0; g.stage_in = 1; g.threads = kP2Threads;
-        // (Round 3 also built this transform on the fp32 matrix pipe -- v_mfma_f32_16x16x4_f32, four variants, bit-identical results, all slower
-        // than the vector form: 0.58 - 0.69 against 0.54 - 0.57 ms on C3, DESIGN 10.3 -- and kept the round-2 DFT phase as a switch; both are gone.)
+        // the A-point transforms on the fp32 matrix pipe where they fill two row tiles of sixteen outputs (A >= 33: M = 66 ... 126)
+        g.mx = (g.A >= 33 && lab_int("CSDR_CHAN_MX", CSDR_CHAN_MX_DEFAULT) != 0) ? 1 : 0;
         return CSDR_OK;
     }
     g.taps_lds = (M <= 512) ? 1 : 0;
@@ -112,6 +115,7 @@ typedef void (*chan_p2_kernel_t)(const float2 *, const float2 *, float2 *, const
 static chan_p2_kernel_t chan_p2_kernel(const ChanGeom &g) {
 #define CSDR_P2_CASE(K_) case K_: return chan_analyze_p2<K_>
     // (A <= 63: at most 32 slots over eight waves = at most four per pass; wider passes were instances nothing ever launched -- one of them spilled)
+    if (g.mx) return chan_analyze_p2<4, true>;
     switch (g.KA) {
         CSDR_P2_CASE(1); CSDR_P2_CASE(2); CSDR_P2_CASE(3);
         default: return chan_analyze_p2<4>;
@@ -173,7 +177,7 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
         p->chan_stride = q * 16;
     }
     if (lab_int("CSDR_ROW_PAD", 1) == 0) p->chan_stride = ((int64_t)max_blocks * (max_block_len / p->hop) + 1) & ~(int64_t)1;      // the round-3 pitch (A/B)
-    const int out_off_kb = lab_int("CSDR_OUT_OFFSET_KB", -1);                                  // (measurement build: where the output starts inside its allocation;
+    const int out_off_kb = std::min(8192, lab_int("CSDR_OUT_OFFSET_KB", -1));                                  // (measurement build: where the output starts inside its allocation;
     p->out_off = (size_t)std::max(0, out_off_kb) * 128;                                        //  the allocation itself is the same for every offset up to 8 MB)
     if (int rc = p->out.reserve((size_t)p->chan_stride * M * csdr_post::kPostBufs + (out_off_kb >= 0 ? (size_t)1 << 20 : 0))) return rc;
     if (int rc = p->dc_state.reserve(2)) return rc;
@@ -209,6 +213,10 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
         if (g.p2) {   // slot q: output pair k = q + 1 (q < H), k = 0 as (1, 0) (q == H), unused (0, 0) beyond
             const int H = (g.A - 1) / 2;
             twA.assign((size_t)H * g.PA, make_float2(0.f, 0.f));
+            if (g.mx) {                                          // the matrix-pipe form's coefficient fragments travel in the table's place
+                twA.assign((size_t)2 * kMxSteps * 64, make_float2(0.f, 0.f));
+                chan_mx_table(g.A, reinterpret_cast<float *>(twA.data()));
+            } else
             for (int c = 1; c <= H; c++) for (int q = 0; q <= H; q++) {
                 const int k = q < H ? q + 1 : 0;
                 const double a = 2.0 * M_PI * (double)(((int64_t)c * k) % g.A) / (double)g.A;
@@ -249,7 +257,7 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
         CSDR_HIP_TRY(hipMemsetAsync(p->hist0.p, 0, H * sizeof(float2), st));
         CSDR_HIP_TRY(hipMemsetAsync(p->hist1.p, 0, H * sizeof(float2), st));
         CSDR_HIP_TRY(hipStreamSynchronize(st));   // host vectors above go out of scope
-        const size_t lds = p->use_fft ? chanfft_lds_bytes(p->fgeom) : g.p2 ? chan_p2_lds_bytes(M) : chan_lds_bytes(g);
+        const size_t lds = p->use_fft ? chanfft_lds_bytes(p->fgeom) : g.p2 ? chan_p2_lds_bytes(M, g.mx != 0) : chan_lds_bytes(g);
         if (lds > 64 * 1024) CSDR_HIP_TRY(hipFuncSetAttribute(p->use_fft ? (const void *)chanfft_kernel(p->fgeom) : g.p2 ? (const void *)chan_p2_kernel(g) : (const void *)chan_kernel(g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     p->hist_parity = 0;
@@ -386,10 +394,10 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
             // persistent workgroups: as many as are resident at once, each walks over tiles blockIdx.x, + gridDim.x, ...
             const chan_p2_kernel_t k2 = chan_p2_kernel(g);
             const int chan_pct = std::max(10, std::min(100, lab_int("CSDR_CHAN_PCT", 100)));
-            const int wgs = std::min(ntiles, std::max(1, c->wg_slots(k2, g.threads, chan_p2_lds_bytes(M)) * chan_pct / 100));
+            const int wgs = std::min(ntiles, std::max(1, c->wg_slots(k2, g.threads, chan_p2_lds_bytes(M, g.mx != 0)) * chan_pct / 100));
             g.xcd = lab_int("CSDR_CHAN_XCD", g.xcd);
             if (lab_int("CSDR_LAB_TRACE", 0)) fprintf(stderr, "[csdr lab] chan_analyze_p2 x=%p out=%p hist=%p taps=%p cs=%p twM=%p wgs=%d xcd=%d\n", (const void *)x, (void *)out, (void *)hist, (void *)p->taps.p, (void *)p->twA.p, (void *)p->twM.p, wgs, g.xcd);
-            CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, k2, dim3(wgs), dim3(g.threads), chan_p2_lds_bytes(M), x, hist, hist_new, p->taps.p,
+            CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, k2, dim3(wgs), dim3(g.threads), chan_p2_lds_bytes(M, g.mx != 0), x, hist, hist_new, p->taps.p,
                         p->twA.p, p->twM.p, p->active.p, g, n_frames, out, p->chan_stride, fused_ends ? p->tile_end.p : (d2 *)nullptr, p->dc_c);
         } else {
         const chan_kernel_t kern = chan_kernel(g);

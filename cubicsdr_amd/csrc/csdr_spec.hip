@@ -370,10 +370,13 @@ static int spec_post_range(csdr_spec *s, const float *mag, int f0, int cnt, int 
                         s->fo.p + f0, s->fsc.p + f0, cnt, (const SpecFrameOut *)nullptr, (const float2 *)nullptr, 0, (float2 *)nullptr);
         }
         // (the carry of a contiguous stream rides on the display launch: csdr_spec_process sets carry_src for a batch whose range starts at frame 0)
-        const bool carry_here = f0 == 0 && s->carry_fold_n > 0;
-        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_DISPLAY, spec_display_p256, dim3(64, cnt), dim3(kDispThreads), 32 * 33 * sizeof(float),
-                    s->pairsum.p + f0 * F, s->first_b.p + f0, s->fsc.p + f0, g, s->scale, s->points.p + f0 * F,
-                    carry_here ? s->carry_fold_src : (const float2 *)nullptr, carry_here ? s->carry.p : (float2 *)nullptr, carry_here ? s->carry_fold_n : 0);
+        const bool carry_here = f0 == 0 && s->carry_fold_n > 0 && cnt <= kTrackSmallFrames;      // (a long batch keeps its own transfer: the copy inside the launch cost it 16 us)
+        if (carry_here)
+            CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_DISPLAY, spec_display_p256<true>, dim3(64, cnt), dim3(kDispThreads), 32 * 33 * sizeof(float),
+                        s->pairsum.p + f0 * F, s->first_b.p + f0, s->fsc.p + f0, g, s->scale, s->points.p + f0 * F, s->carry_fold_src, s->carry.p, s->carry_fold_n);
+        else
+            CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_DISPLAY, spec_display_p256<false>, dim3(64, cnt), dim3(kDispThreads), 32 * 33 * sizeof(float),
+                        s->pairsum.p + f0 * F, s->first_b.p + f0, s->fsc.p + f0, g, s->scale, s->points.p + f0 * F, (const float2 *)nullptr, (float2 *)nullptr, 0);
         if (carry_here) s->carry_fold_n = -1;                        // done
         s->scal_parity ^= 1;
         CSDR_HIP_TRY(hipGetLastError());

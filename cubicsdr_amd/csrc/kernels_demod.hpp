@@ -1019,11 +1019,11 @@ struct ModemConsts {
 };
 
 // sum / maximum over the ONE wave of a modem / audio workgroup (kAudioThreads): valid in thread 0
-__device__ inline double block_sum_double(double v, double *) {
+__device__ inline double wave_sum_double(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
 }
-__device__ inline float block_max_float(float v, float *) {
+__device__ inline float wave_max_float(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
     return v;
 }
@@ -1261,8 +1261,8 @@ __device__ __forceinline__ void demod_modem_body(
             lmax = fmaxf(lmax, v);
         }
     }
-    const float bm = block_max_float(lmax, s_redf);
-    const double bs = block_sum_double(lsum, s_red);
+    const float bm = wave_max_float(lmax);
+    const double bs = wave_sum_double(lsum);
     if (tid == 0) {
         cfg.blockmax[b] = bm;
         cfg.bout[b].level_accum = bs;
@@ -1396,8 +1396,8 @@ __device__ __forceinline__ void demod_audio_body(
             lpk = fmaxf(lpk, fabsf(v));
             lsum += (double)fabsf(v);
         }
-        const float pk = block_max_float(lpk, s_redf);
-        const double sm = block_sum_double(lsum, s_red);
+        const float pk = wave_max_float(lpk);
+        const double sm = wave_sum_double(lsum);
         if (tid == 0) {
             cfg.bout[b].audio_peak = pk; cfg.bout[b].level_accum = sm; cfg.bout[b].level_count = n_audio;
         }
@@ -1416,8 +1416,8 @@ __device__ __forceinline__ void demod_audio_body(
             lpk = fmaxf(lpk, fmaxf(fabsf(x.x), fabsf(x.y)));
             lsum += sqrt((double)x.x * (double)x.x + (double)x.y * (double)x.y);
         }
-        const float pk = block_max_float(lpk, s_redf);
-        const double sm = block_sum_double(lsum, s_red);
+        const float pk = wave_max_float(lpk);
+        const double sm = wave_sum_double(lsum);
         if (tid == 0) { cfg.bout[b].audio_peak = pk; cfg.bout[b].level_accum = sm; cfg.bout[b].level_count = n_iq; }
         return;
     }
@@ -1639,8 +1639,8 @@ __device__ __forceinline__ void demod_audio_body(
             const float2 x = iq[jb0 + i];
             lsum += sqrt((double)x.x * (double)x.x + (double)x.y * (double)x.y);
         }
-    const float pk = block_max_float(lpk, s_redf);
-    const double sm = block_sum_double(lsum, s_red);
+    const float pk = wave_max_float(lpk);
+    const double sm = wave_sum_double(lsum);
     if (tid == 0 && !plain) {                                    // (FM stereo: fms_out sets the peak of the finished stereo frames)
         cfg.bout[b].audio_peak = pk;
         cfg.bout[b].level_accum = sm;

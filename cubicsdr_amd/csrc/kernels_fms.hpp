@@ -189,7 +189,7 @@ CSDR_KERNEL __launch_bounds__(64) void fms_out(const SlotCfg *__restrict__ cfgs,
         out[i] = make_float2(al, ar);
         lpk = fmaxf(lpk, fmaxf(fabsf(al), fabsf(ar)));
     }
-    const float pk = block_max_float(lpk, s_redf);
+    const float pk = wave_max_float(lpk);
     if (tid == 0) cfg.bout[b].audio_peak = pk;
     if (b == NB - 1) {
         const int A = pl[NB].q0 << ush;

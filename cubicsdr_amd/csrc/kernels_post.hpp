@@ -208,6 +208,7 @@ struct ChanGeom {
     int oddA;                 // 1: A is odd (>= 3) and phase 1 uses the conjugate-pair form: KA / nkA / PA then count output PAIRS (k, A - k)
     int threads;              // workgroup size (whole waves, 256..512): chosen so each phase splits evenly over the waves
     int p2;                   // 1: M = 2 A, A odd <= 63, critically sampled: chan_analyze_p2 (KA = slots per pass, nkA = passes, PA = row pitch)
+    int mx;                   // chan_analyze_p2: 1 = the A-point transforms run on the fp32 matrix pipe (A >= 33: chan_analyze_p2<.., true>)
     int xcd;                  // chan_analyze_p2: 1 = the workgroups of one XCD (blockIdx.x % 8) take CONSECUTIVE tiles of a round (grid a multiple of 8)
 };
 __host__ __device__ inline size_t chan_zin_floats2(const ChanGeom &g) {      // Z array, or the staged input tile if larger
@@ -534,7 +535,28 @@ constexpr int kP2DftPrio = CSDR_P2_PRIO_DFT;            // (A/B builds: -DCSDR_P
 constexpr int kP2EarlyRows = 8;          // rows of the next tile's FIR window requested before the DFT phase (the first frame's whole window); the other seven after it
 constexpr int kP2Threads = 64 * kP2Waves;
 constexpr int kP2MaxA = 63;
-__host__ __device__ inline size_t chan_p2_lds_bytes(int M) { return (size_t)kP2Frames * M * sizeof(float2); }
+// (the matrix-pipe form keeps two small tables behind the rows: the per-output constants of its epilogue and the tile's channel-0 samples)
+constexpr int kMxSteps = 8;            // K steps of four terms: n = 0 .. 31 (H <= 31)
+constexpr int kMxRows = 32;            // two row tiles of sixteen outputs: k = 0 .. 31
+__host__ __device__ inline size_t chan_p2_lds_bytes(int M, bool mx = false) {
+    return (size_t)kP2Frames * M * sizeof(float2) + (mx ? (size_t)kMxRows * (sizeof(float4) + 4 * sizeof(int)) + kP2Frames * sizeof(float2) : 0);
+}
+// coefficient fragments of the matrix-pipe form, [2 (cos | sin)][2 row tiles][kMxSteps][64 lanes]: lane l of step J holds the coefficient of output
+// k = 16 rt + (l & 15) and term n = 4 J + (l >> 4) -- the A operand of v_mfma_f32_16x16x4_f32 (A[i = l & 15][k = l >> 4]); term 0 is x_0 (cos = 1, sin = 0),
+// terms and outputs past H are zero.  The angles are the vector form's expression, so the products are the same products.
+__host__ inline void chan_mx_table(int A, float *tab /* [2][2][kMxSteps][64] */) {
+    const int H = (A - 1) / 2;
+    for (int kind = 0; kind < 2; ++kind) for (int rt = 0; rt < 2; ++rt) for (int J = 0; J < kMxSteps; ++J) for (int l = 0; l < 64; ++l) {
+        const int k = 16 * rt + (l & 15), n = 4 * J + (l >> 4);
+        float v = 0.f;
+        if (k <= H && n <= H) {
+            const double ang = 2.0 * M_PI * (double)(((long long)n * k) % A) / (double)A;
+            if (kind == 0) v = n == 0 ? 1.0f : (float)std::cos(ang);
+            else v = n == 0 ? 0.0f : (float)std::sin(ang);
+        }
+        tab[(((size_t)kind * 2 + rt) * kMxSteps + J) * 64 + l] = v;
+    }
+}
 // store to a wave-uniform row base plus a 32-bit per-lane byte offset (scalar-base addressing: no 64-bit address arithmetic per lane)
 __device__ __forceinline__ void store_row(float2 *row_base, unsigned byte_off, float2 v) {
     *reinterpret_cast<float2 *>(reinterpret_cast<char *>(row_base) + byte_off) = v;
@@ -547,6 +569,16 @@ __device__ __forceinline__ void store_row_nt(float2 *row_base, unsigned byte_off
     __builtin_nontemporal_store(t, reinterpret_cast<csdr_v2f *>(reinterpret_cast<char *>(row_base) + byte_off));
 #else
     store_row(row_base, byte_off, v);
+#endif
+}
+// streaming-hint store through a per-lane address (the matrix-pipe form: a store instruction covers four channel rows)
+__device__ __forceinline__ void store_nt(float2 *p, float2 v) {
+#if defined(__AMDGCN__)
+    typedef float csdr_v2f __attribute__((ext_vector_type(2)));
+    const csdr_v2f t = {v.x, v.y};
+    __builtin_nontemporal_store(t, reinterpret_cast<csdr_v2f *>(p));
+#else
+    *p = v;
 #endif
 }
 // one term of the conjugate-pair sums for KP slots and both c2: s = x_c + x_{A-c} (the FIR phase left it at row c), d = x_c - x_{A-c}
@@ -616,7 +648,9 @@ __device__ __forceinline__ void chan_p2_request_window(const float2 *__restrict_
     }
 }
 
-template <int KP>
+// MX = true (A >= 33: two row tiles of outputs): the transform phase runs on the fp32 matrix pipe -- see "DFT on the matrix pipe" below; `cs` then is
+// the coefficient-fragment table of chan_mx_table().
+template <int KP, bool MX = false>
 CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
     const float2 *__restrict__ x, const float2 *__restrict__ hist, float2 *__restrict__ hist_new,
     const float *__restrict__ tapsT,      // [8][M]
@@ -637,6 +671,28 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
         for (int64_t j = tid0; j < Hs; j += kP2Threads) {
             const int64_t gsrc = n - Hs + j;
             hist_new[j] = gsrc >= 0 ? x[gsrc] : hist[gsrc + Hs];
+        }
+    }
+    // matrix-pipe form: this wave's coefficient fragments stay in registers for the whole launch (persistent workgroup); the constants of the
+    // epilogue (W_M^k of an output and of its partner A - k, the four output rows) sit in LDS behind the rows, one entry per output k
+    float mxc[kMxSteps], mxs[kMxSteps];
+    float4 *epi_w = reinterpret_cast<float4 *>(smem + (size_t)kP2Frames * M * sizeof(float2));
+    int4 *epi_on = reinterpret_cast<int4 *>(epi_w + kMxRows);
+    float2 *s_y0 = reinterpret_cast<float2 *>(epi_on + kMxRows);                  // channel 0 of the tile (the DC blocker's end value)
+    if constexpr (MX) {
+        const float *tab = reinterpret_cast<const float *>(cs) + (size_t)(wave >> 2) * kMxSteps * 64 + lane0;
+#pragma unroll
+        for (int J = 0; J < kMxSteps; ++J) { mxc[J] = tab[J * 64]; mxs[J] = tab[(2 * kMxSteps + J) * 64]; }
+        if (tid0 < kMxRows) {
+            const int k = tid0, kn = A - k;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            int4 on = make_int4(0, 0, 0, 0);
+            if (k <= H) {
+                const float2 wk = twM[2 * k + 1];
+                w.x = wk.x; w.y = wk.y; on.x = active[k]; on.y = active[k + A];
+                if (k > 0) { const float2 wn = twM[2 * kn + 1]; w.z = wn.x; w.w = wn.y; on.z = active[kn]; on.w = active[kn + A]; }      // k = 0 has no conjugate partner
+            }
+            epi_w[k] = w; epi_on[k] = on;                      // (read behind the first tile's barrier)
         }
     }
     float4 win[2 * kChanTaps - 1];                              // this wave's FIR window of the tile: input rows f0 + ta - 7 .. f0 + ta + 7
@@ -702,7 +758,52 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
         // the next tile's window is on its way while this one is transformed (into the registers the FIR has just finished with)
         chan_p2_request_window<0, kP2EarlyRows>(x, hist, M, A, n_frames, tile + tstep, tile + tstep < tend, wave, lane, win);
         wave_priority(kP2DftPrio);
-        {   // ---- DFT: lane = frame t; wave = pass of KP output-pair slots
+        if constexpr (MX) {
+            // ---- DFT on the matrix pipe.  The conjugate-pair sums are two real matrix products per component:
+            //        P[k][t] = sum_n Cos[k][n] s_n[t]      Q[k][t] = sum_n Sin[k][n] d_n[t]        k, n = 0 .. H   (s_0 = x_0, Cos[k][0] = 1, Sin[k][0] = 0)
+            //      for the four components (c2 = 0 / 1) x (re / im) of s and d: eight products, tiled 16 (k) x 16 (t) x 4 (n) on v_mfma_f32_16x16x4_f32.
+            //      Wave = (row tile rt = wave >> 2: k = 16 rt .. 16 rt + 15, column tile ct = wave & 3: frames 16 ct .. 16 ct + 15); lane (q = lane >> 4,
+            //      j = lane & 15) feeds term n = 4 J + q of frame t = 16 ct + j in step J -- the two ds_read_b128 of rows n (s_n, left there by the FIR phase)
+            //      and A - n (d_n) are the B operands of all eight products -- and receives outputs k = 16 rt + 4 q + r (r = 0..3) of that frame for all
+            //      eight, so the radix-2 butterfly and the stores stay in-lane.  An MFMA is a k-ordered fmaf chain: the accumulation order (n ascending,
+            //      starting from x_0) is the vector form's, and so are the results, bit for bit.  64 MFMAs (2048 matrix-pipe cycles) per wave and tile
+            //      in place of 465 packed multiply-adds on the vector pipe, 16 LDS reads in place of 61 per pass.
+            const int q = lane >> 4, t = 16 * (wave & 3) + (lane & 15), rt = wave >> 2;
+            const float4 *row = rows + t * A;
+            const bool tv = t < nf;
+            csdr_f32x4 P0r = {0.f, 0.f, 0.f, 0.f}, P0i = P0r, P1r = P0r, P1i = P0r, Q0r = P0r, Q0i = P0r, Q1r = P0r, Q1i = P0r;
+            float4 a = row[q], b = row[q ? A - q : 0];                // step 0: n = q (the sine of term 0 is zero: any finite operand)
+#pragma unroll
+            for (int J = 0; J < kMxSteps; ++J) {
+                float4 a2 = a, b2 = b;
+                if (J + 1 < kMxSteps) { const int n2 = 4 * (J + 1) + q; a2 = row[n2]; b2 = row[A - n2]; }      // the next step's rows are requested ahead of this step's products (rows past H: zero coefficients)
+                P0r = csdr_mfma16(mxc[J], a.x, P0r); P0i = csdr_mfma16(mxc[J], a.y, P0i);
+                P1r = csdr_mfma16(mxc[J], a.z, P1r); P1i = csdr_mfma16(mxc[J], a.w, P1i);
+                Q0r = csdr_mfma16(mxs[J], b.x, Q0r); Q0i = csdr_mfma16(mxs[J], b.y, Q0i);
+                Q1r = csdr_mfma16(mxs[J], b.z, Q1r); Q1i = csdr_mfma16(mxs[J], b.w, Q1i);
+                a = a2; b = b2;
+            }
+            // each accumulator holds four outputs k of one frame: a store instruction of the wave covers four channel rows, 128 contiguous bytes of each
+            float2 *ob = out + f0 + t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * rt + 4 * q + r;
+                const float4 w = epi_w[k];
+                const int4 on = epi_on[k];
+                const float2 P0 = make_float2(P0r[r], P0i[r]), Q0 = make_float2(Q0r[r], Q0i[r]), P1 = make_float2(P1r[r], P1i[r]), Q1 = make_float2(Q1r[r], Q1i[r]);
+                const float2 z0k = make_float2(P0.x + Q0.y, P0.y - Q0.x), z0n = make_float2(P0.x - Q0.y, P0.y + Q0.x);
+                const float2 u = cmul(make_float2(P1.x + Q1.y, P1.y - Q1.x), make_float2(w.x, w.y));
+                const float2 v = cmul(make_float2(P1.x - Q1.y, P1.y + Q1.x), make_float2(w.z, w.w));
+                const float2 y0 = make_float2(z0k.x + u.x, z0k.y + u.y);
+                if (tv) {
+                    if (on.x) { if (k) store_nt(ob + (int64_t)(on.x - 1) * out_stride, y0); else ob[(int64_t)(on.x - 1) * out_stride] = y0; }      // (channel 0 is read again by the DC blocker)
+                    if (on.y) store_nt(ob + (int64_t)(on.y - 1) * out_stride, make_float2(z0k.x - u.x, z0k.y - u.y));
+                    if (on.z) store_nt(ob + (int64_t)(on.z - 1) * out_stride, make_float2(z0n.x + v.x, z0n.y + v.y));
+                    if (on.w) store_nt(ob + (int64_t)(on.w - 1) * out_stride, make_float2(z0n.x - v.x, z0n.y - v.y));
+                }
+                if (r == 0 && dc_ends && k == 0) s_y0[t] = y0;        // k = 0: Q = 0, W = 1 -- y0 = P0 + P1 as in the vector form
+            }
+        } else {   // ---- DFT: lane = frame t; wave = pass of KP output-pair slots
             const int t = lane;
             const float4 *row = rows + t * A;
             const bool tv = t < nf;
@@ -758,6 +859,18 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
         chan_p2_request_window<kP2EarlyRows, 2 * kChanTaps - 1>(x, hist, M, A, n_frames, tile + tstep, tile + tstep < tend, wave, lane0, win);
         wave_priority(0);
         lds_barrier();                                      // the rows are free for the next tile
+        if constexpr (MX) {
+            if (dc_ends && wave == 0) {
+                // v_end = sum_t c^(nf-1-t) y0[t], added up in the vector form's order (one wave, lane = frame); the next write of s_y0 is behind the next tile's first barrier
+                const int t = lane0;
+                const bool tv = t < nf;
+                const float2 y0 = s_y0[t];
+                const double wgt = tv ? dc_pow(dc_c, nf - 1 - t) : 0.0;
+                double vx = tv ? wgt * (double)y0.x : 0.0, vy = tv ? wgt * (double)y0.y : 0.0;
+                for (int s2 = 32; s2 > 0; s2 >>= 1) { vx += __shfl_down(vx, s2, 64); vy += __shfl_down(vy, s2, 64); }
+                if (lane0 == 0) dc_ends[tile] = d2{vx, vy};
+            }
+        }
     }
 }
 

@@ -268,11 +268,12 @@ CSDR_KERNEL __launch_bounds__(kR2Threads) void spec_rows256_ema(const float2 *__
 // grid = (8 x 8 tiles of 32 pairs x 32 k2, frames); reads 32 runs of 128 bytes, writes 32 runs of 128 bytes.
 // (carry_n > 0: the workgroups of frame 0 also move the samples behind the batch's last whole frame to the carry buffer -- the last launch of a call's chain
 //  takes the copy that was a 4 us transfer of its own; nothing of this launch reads either buffer)
+template <bool CARRY /* the short-batch instance that takes the carry copy along */>
 CSDR_KERNEL __launch_bounds__(kDispThreads) void spec_display_p256(const float *__restrict__ pairsum, const float *__restrict__ first_b,
                                                                   const SpecFrameScal *__restrict__ fsc, SpecGeom g, float sf, float *__restrict__ points,
                                                                   const float2 *__restrict__ carry_src, float2 *__restrict__ carry_dst, int carry_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (carry_n > 0 && blockIdx.y == 0)
+    if constexpr (CARRY) if (carry_n > 0 && blockIdx.y == 0)
         for (int i = (int)(blockIdx.x * kDispThreads + threadIdx.x); i < carry_n; i += (int)(gridDim.x * kDispThreads)) carry_dst[i] = carry_src[i];
     float *s_y = reinterpret_cast<float *>(smem);                    // [32 k2][33]
     const int f = blockIdx.y, tid = threadIdx.x, F = g.F;

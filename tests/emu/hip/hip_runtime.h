@@ -39,6 +39,8 @@ struct float4 { float x, y, z, w; };
 struct double2 { double x, y; };
 struct int2 { int x, y; };
 struct uint2 { unsigned x, y; };
+struct int4 { int x, y, z, w; };
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline double2 make_double2(double x, double y) { return double2{x, y}; }
