@@ -532,14 +532,17 @@ constexpr int kP2Waves = 8;
 #endif
 constexpr int kP2ReqPrio = CSDR_P2_REQ_PRIO;
 constexpr int kP2DftPrio = CSDR_P2_PRIO_DFT;            // (A/B builds: -DCSDR_P2_PRIO_DFT=0 is the round-5 kernel)
-constexpr int kP2EarlyRows = 8;          // rows of the next tile's FIR window requested before the DFT phase (the first frame's whole window); the other seven after it
+#ifndef CSDR_P2_EARLY
+#define CSDR_P2_EARLY 8
+#endif
+constexpr int kP2EarlyRows = CSDR_P2_EARLY;          // rows of the next tile's FIR window requested before the DFT phase (the first frame's whole window); the other seven after it
 constexpr int kP2Threads = 64 * kP2Waves;
 constexpr int kP2MaxA = 63;
 // (the matrix-pipe form keeps two small tables behind the rows: the per-output constants of its epilogue and the tile's channel-0 samples)
 constexpr int kMxSteps = 8;            // K steps of four terms: n = 0 .. 31 (H <= 31)
 constexpr int kMxRows = 32;            // two row tiles of sixteen outputs: k = 0 .. 31
 __host__ __device__ inline size_t chan_p2_lds_bytes(int M, bool mx = false) {
-    return (size_t)kP2Frames * M * sizeof(float2) + (mx ? (size_t)kMxRows * (sizeof(float4) + 4 * sizeof(int)) + kP2Frames * sizeof(float2) : 0);
+    return (size_t)kP2Frames * M * sizeof(float2) + (mx ? (size_t)kMxRows * (sizeof(float4) + 4 * sizeof(int)) + kP2Frames * sizeof(float2) + (size_t)(kChanTaps / 2) * (M / 2) * sizeof(float4) : 0);
 }
 // coefficient fragments of the matrix-pipe form, [2 (cos | sin)][2 row tiles][kMxSteps][64 lanes]: lane l of step J holds the coefficient of output
 // k = 16 rt + (l & 15) and term n = 4 J + (l >> 4) -- the A operand of v_mfma_f32_16x16x4_f32 (A[i = l & 15][k = l >> 4]); term 0 is x_0 (cos = 1, sin = 0),
@@ -679,7 +682,13 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
     float4 *epi_w = reinterpret_cast<float4 *>(smem + (size_t)kP2Frames * M * sizeof(float2));
     int4 *epi_on = reinterpret_cast<int4 *>(epi_w + kMxRows);
     float2 *s_y0 = reinterpret_cast<float2 *>(epi_on + kMxRows);                  // channel 0 of the tile (the DC blocker's end value)
+    float4 *s_taps = reinterpret_cast<float4 *>(s_y0 + kP2Frames);                // [4][A]: taps 2 j and 2 j + 1 of a column pair
     if constexpr (MX) {
+        for (int i = tid0; i < (kChanTaps / 2) * A; i += kP2Threads) {
+            const int j = i / A, lc = i - j * A;
+            const float2 h0 = *reinterpret_cast<const float2 *>(tapsT + (2 * j) * M + 2 * lc), h1 = *reinterpret_cast<const float2 *>(tapsT + (2 * j + 1) * M + 2 * lc);
+            s_taps[i] = make_float4(h0.x, h0.y, h1.x, h1.y);
+        }
         const float *tab = reinterpret_cast<const float *>(cs) + (size_t)(wave >> 2) * kMxSteps * 64 + lane0;
 #pragma unroll
         for (int J = 0; J < kMxSteps; ++J) { mxc[J] = tab[J * 64]; mxs[J] = tab[(2 * kMxSteps + J) * 64]; }
@@ -692,8 +701,9 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
                 w.x = wk.x; w.y = wk.y; on.x = active[k]; on.y = active[k + A];
                 if (k > 0) { const float2 wn = twM[2 * kn + 1]; w.z = wn.x; w.w = wn.y; on.z = active[kn]; on.w = active[kn + A]; }      // k = 0 has no conjugate partner
             }
-            epi_w[k] = w; epi_on[k] = on;                      // (read behind the first tile's barrier)
+            epi_w[k] = w; epi_on[k] = on;
         }
+        __syncthreads();
     }
     float4 win[2 * kChanTaps - 1];                              // this wave's FIR window of the tile: input rows f0 + ta - 7 .. f0 + ta + 7
     // tile walk: workgroup b takes tiles b, b + grid, ...; with `xcd` the workgroups that share an L2 (b % 8: the dispatcher's round robin over the
@@ -712,7 +722,11 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
         opaque(lane); opaque(tid);
         const bool col = lane < A;
         float2 h[kChanTaps];
-        {   // (lanes past the last column read the last column's taps: nothing of theirs is stored, and a guarded load is compiled behind a
+        if constexpr (MX) {   // from the workgroup's LDS copy: four 16-byte reads, no global round trip behind the window's
+            const int lc = min(lane, A - 1);
+#pragma unroll
+            for (int n = 0; n < kChanTaps; n += 2) { const float4 v = s_taps[(n >> 1) * A + lc]; h[n] = make_float2(v.x, v.y); h[n + 1] = make_float2(v.z, v.w); }
+        } else {   // (lanes past the last column read the last column's taps: nothing of theirs is stored, and a guarded load is compiled behind a
             // wait for everything in flight -- eight serialised round trips per tile)
             const int lc = min(lane, A - 1);
 #pragma unroll
@@ -733,7 +747,7 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
                     acc.x = fmaf(h[n].x, v.x, acc.x); acc.y = fmaf(h[n].x, v.y, acc.y);
                     acc.z = fmaf(h[n].y, v.z, acc.z); acc.w = fmaf(h[n].y, v.w, acc.w);
                 }
-                {                                             // columns c and A - c trade: s_c = x_c + x_{A-c} at row c, d_c = x_c - x_{A-c} at row A - c
+                if constexpr (!MX) {                          // columns c and A - c trade: s_c = x_c + x_{A-c} at row c, d_c = x_c - x_{A-c} at row A - c
                     // (one component at a time: a float4 of partner values at once is one more spilled float4 in this phase)
                     // p + sg acc with sg = +1 on the s lanes, -1 on the d lanes: ONE multiply-add per component in place of two selects, an add and a subtract
                     // (x + y and fma(1, x, y) are the same single rounding: bit-identical); the lanes outside 1 .. A - 1 keep their own value
@@ -772,15 +786,19 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
             const float4 *row = rows + t * A;
             const bool tv = t < nf;
             csdr_f32x4 P0r = {0.f, 0.f, 0.f, 0.f}, P0i = P0r, P1r = P0r, P1i = P0r, Q0r = P0r, Q0i = P0r, Q1r = P0r, Q1i = P0r;
-            float4 a = row[q], b = row[q ? A - q : 0];                // step 0: n = q (the sine of term 0 is zero: any finite operand)
+            // s_n = x_n + x_{A-n}, d_n = x_n - x_{A-n} are formed here from the two rows (each rounded once, as the vector form's lane trade does in its FIR
+            // phase: the same values); term 0 is x_0 itself
+            float4 a = row[q], b = q ? row[A - q] : make_float4(0.f, 0.f, 0.f, 0.f);      // step 0: n = q
 #pragma unroll
             for (int J = 0; J < kMxSteps; ++J) {
                 float4 a2 = a, b2 = b;
                 if (J + 1 < kMxSteps) { const int n2 = 4 * (J + 1) + q; a2 = row[n2]; b2 = row[A - n2]; }      // the next step's rows are requested ahead of this step's products (rows past H: zero coefficients)
-                P0r = csdr_mfma16(mxc[J], a.x, P0r); P0i = csdr_mfma16(mxc[J], a.y, P0i);
-                P1r = csdr_mfma16(mxc[J], a.z, P1r); P1i = csdr_mfma16(mxc[J], a.w, P1i);
-                Q0r = csdr_mfma16(mxs[J], b.x, Q0r); Q0i = csdr_mfma16(mxs[J], b.y, Q0i);
-                Q1r = csdr_mfma16(mxs[J], b.z, Q1r); Q1i = csdr_mfma16(mxs[J], b.w, Q1i);
+                const float4 sv = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+                const float4 dv = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+                P0r = csdr_mfma16(mxc[J], sv.x, P0r); P0i = csdr_mfma16(mxc[J], sv.y, P0i);
+                P1r = csdr_mfma16(mxc[J], sv.z, P1r); P1i = csdr_mfma16(mxc[J], sv.w, P1i);
+                Q0r = csdr_mfma16(mxs[J], dv.x, Q0r); Q0i = csdr_mfma16(mxs[J], dv.y, Q0i);
+                Q1r = csdr_mfma16(mxs[J], dv.z, Q1r); Q1i = csdr_mfma16(mxs[J], dv.w, Q1i);
                 a = a2; b = b2;
             }
             // each accumulator holds four outputs k of one frame: a store instruction of the wave covers four channel rows, 128 contiguous bytes of each
