@@ -205,7 +205,8 @@ def test_emu_fm_stereo_settings(ctx):
     print(G._fms_case(ctx, 2400000, 4, 20000, 4, 2, bw=50000, audio_rate=48000, demph=50, seed=37))
 
 
-@pytest.mark.parametrize("fs,M,block", [(5000000, 10, 10 * 130), pytest.param(7000000, 14, 14 * 70, marks=full), (6100000, 122, 122 * 150)])
+@pytest.mark.parametrize("fs,M,block", [(5000000, 10, 10 * 130), pytest.param(7000000, 14, 14 * 70, marks=full), (6100000, 122, 122 * 150), (6300000, 126, 126 * 70),
+                                        pytest.param(3300000, 66, 66 * 80, marks=full)])
 def test_emu_channelizer_m_twice_odd(ctx, fs, M, block):
     """M = 2 A, A odd: the one-lane-per-frame kernel with its mover wave (ragged and whole 64-frame tiles, carried history)"""
     G.test_channelizer_m_twice_odd(ctx, fs, M, block)

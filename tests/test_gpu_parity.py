@@ -133,10 +133,12 @@ def _channelizer_case(ctx, fs, M, block, chans=None, nblocks=3):
     return worst
 
 
-@pytest.mark.parametrize("fs,M,block", [(5000000, 10, 83340), (7000000, 14, 14 * 70), (61440000, 122, 122 * 150), (61440000, 122, 1024068)])
+@pytest.mark.parametrize("fs,M,block", [(5000000, 10, 83340), (7000000, 14, 14 * 70), (61440000, 122, 122 * 150), (61440000, 122, 1024068),
+                                        (33000000, 66, 66 * 150), (47000000, 94, 94 * 97), (63000000, 126, 126 * 131), (31000000, 62, 62 * 140)])
 def test_channelizer_m_twice_odd(ctx, fs, M, block):
     """M = 2 A with A odd (10, 14, 122 = the 61.44 MS/s channel count, SoapySDRThread.cpp:676-693) runs the one-lane-per-frame
-    kernel (chan_analyze_p2): whole and ragged 64-frame tiles."""
+    kernel (chan_analyze_p2): whole and ragged 64-frame tiles.  A >= 33 (M = 66: one output in the second row tile, 94, 122, 126: all 32 outputs
+    and all 32 terms in use) is the matrix-pipe form of its transform phase, M = 62 the largest count of the vector form."""
     _channelizer_case(ctx, fs, M, block)
 
 
