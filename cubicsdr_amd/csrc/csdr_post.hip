@@ -238,7 +238,7 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
             if (int rc = p->perm.reserve(fperm.size())) return rc;
             CSDR_HIP_TRY(hipMemcpyAsync(p->perm.p, fperm.data(), fperm.size() * sizeof(int), hipMemcpyHostToDevice, st));
             if (p->fgeom.bp || p->fgeom.dp) {      // tables of the chirp-z / direct prime pass: they travel in the place of firpfbch2's post factors (never both)
-                const std::vector<float2> bt = p->fgeom.bp ? chanfft_blue_tables(p->fgeom) : chanfft_direct_tables(p->fgeom);
+                const std::vector<float2> bt = p->fgeom.bp ? chanfft_blue_tables(p->fgeom) : kCfPrimeMx ? chanfft_direct_mx_tables(p->fgeom) : chanfft_direct_tables(p->fgeom);
                 if (int rc = p->post2.reserve(bt.size())) return rc;
                 CSDR_HIP_TRY(hipMemcpy(p->post2.p, bt.data(), bt.size() * sizeof(float2), hipMemcpyHostToDevice));
             }

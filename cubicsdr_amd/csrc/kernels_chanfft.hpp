@@ -56,17 +56,23 @@ struct ChanFftGeom {
     // pass 0 is its bp-point transform, run as a chirp-z convolution of length bL (the power of two >= 2 bp - 1) in a work array beside the tile
     int bp, bL, blgL;                     // 0: no such factor
     int bnpass, bradix[4], bspan[4];      // the bL-point transform: radices 16 / 8 / 4 / 2, span of sub-pass k inside bL
-    // a prime factor 29 .. 151: pass 0 is its direct transform in the conjugate-pair form of chan_analyze_p2's transform phase (lane = (column, frame),
-    // wave = four output pairs, (cos, sin) rows wave-uniform), out of place into a second tile
+    // a prime factor 29 .. 199: pass 0 is its direct transform in the conjugate-pair form of chan_analyze_p2's transform phase, out of place into a second
+    // tile -- on the fp32 matrix pipe (cf_prime_pass_mx; the vector form -- lane = (column, frame), wave = four output pairs, (cos, sin) rows wave-uniform -- is
+    // kept for A/B builds)
     int dp, dnk, dPA;                     // the prime (0: none), groups of four output-pair slots, pitch of a (cos, sin) row
     unsigned magic_s0;                    // floor(2^32 / (M / dp)) + 1
 };
 constexpr int kCfDirectKP = 4;
+#ifndef CSDR_CF_PRIME_MX
+#define CSDR_CF_PRIME_MX 1
+#endif
+constexpr bool kCfPrimeMx = CSDR_CF_PRIME_MX != 0;      // the direct prime pass on the fp32 matrix pipe (A/B builds: -DCSDR_CF_PRIME_MX=0 is the vector form)
 // (measured, profiles/r06_chirpz_channel_counts.txt: the convolution costs 2.2 - 2.6 x the factor's own data in LDS work space and six trips through it;
-//  against the direct prime pass below it wins from p ~ 157 on -- M = 326: 1.23 against 1.26 ms, M = 398: 1.07 against 1.31 ms -- and loses below --
-//  M = 254: 0.79 against 0.59 ms, M = 194: 1.01 against 0.60 ms)
+//  against the VECTOR form of the direct prime pass it won from p ~ 157 on.  Against the matrix-pipe form of that pass (cf_prime_pass_mx,
+//  profiles/r06_prime_mx.txt) it loses for every prime the fragments' registers reach -- M = 314: 1.27 against 0.67 ms, M = 398: 1.06 against 0.73 ms --
+//  so it now starts at p = 211, i.e. M >= 422: beyond the counts getOptimalChannelCount returns for rates up to 200 MS/s)
 #ifndef CSDR_CF_BLUE_MIN
-#define CSDR_CF_BLUE_MIN 157
+#define CSDR_CF_BLUE_MIN 211
 #endif
 constexpr int kCfBlueMinPrime = CSDR_CF_BLUE_MIN, kCfBlueMaxPrime = 509;
 
@@ -170,6 +176,29 @@ __host__ inline std::vector<float2> chanfft_direct_tables(const ChanFftGeom &g) 
         t[(size_t)(c - 1) * g.dPA + q] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
     return t;
+}
+
+// The same pass on the fp32 matrix pipe (cf_prime_pass_mx): coefficient fragments [2 (cos | sin)][row tile][step][64 lanes] -- lane l of step J holds the
+// coefficient of output k = 16 rt + (l & 15) and term n = 4 J + (l >> 4), the A operand of v_mfma_f32_16x16x4_f32; term 0 is x_0 (cos = 1, sin = 0),
+// outputs and terms past H are zero.  The angles are the vector form's expression: the products are the same products.
+__host__ __device__ inline int chanfft_mx_row_tiles(int p) { return ((p - 1) / 2 + 16) / 16; }      // outputs k = 0 .. H
+__host__ __device__ inline int chanfft_mx_steps(int p) { return ((p - 1) / 2 + 4) / 4; }            // terms n = 0 .. H, four per step
+constexpr int kCfMxMaxSteps = 25;                                                                   // p <= 199
+__host__ inline std::vector<float2> chanfft_direct_mx_tables(const ChanFftGeom &g) {
+    const int p = g.dp, H = (p - 1) / 2, RT = chanfft_mx_row_tiles(p), KS = chanfft_mx_steps(p);
+    std::vector<float> t((size_t)2 * RT * KS * 64, 0.f);
+    for (int kind = 0; kind < 2; ++kind) for (int rt = 0; rt < RT; ++rt) for (int J = 0; J < KS; ++J) for (int l = 0; l < 64; ++l) {
+        const int k = 16 * rt + (l & 15), n = 4 * J + (l >> 4);
+        float v = 0.f;
+        if (k <= H && n <= H) {
+            const double a = 2.0 * M_PI * (double)(((int64_t)n * k) % p) / (double)p;
+            v = kind == 0 ? (n == 0 ? 1.0f : (float)std::cos(a)) : (n == 0 ? 0.0f : (float)std::sin(a));
+        }
+        t[(((size_t)kind * RT + rt) * KS + J) * 64 + l] = v;
+    }
+    std::vector<float2> r((t.size() + 1) / 2);
+    memcpy(r.data(), t.data(), t.size() * sizeof(float));
+    return r;
 }
 
 // tables of the chirp-z pass, in double on the host: W_L^i (L), the transformed chirp filter at the positions the forward sub-passes leave the
@@ -479,6 +508,70 @@ __device__ __forceinline__ void cf_prime_pass(const ChanFftGeom &g, float2 *s_x,
     }
 }
 
+// The direct prime pass on the fp32 matrix pipe.  P = Cos s and Q = Sin d are real matrix products per component (re / im), tiled 16 (k) x 16 (columns) x 4
+// (terms) on v_mfma_f32_16x16x4_f32: a wave takes (row tile of sixteen outputs, column tile of sixteen (column j, frame t) lanes); lane (q = lane >> 4,
+// i = lane & 15) feeds term n = 4 J + q of its column in step J -- s_n = x_n + x_{p-n} and d_n formed from the two rows as they are read, so step A and
+// its barrier are gone -- and receives outputs k = 16 rt + 4 q + r of that column.  An MFMA is a k-ordered fmaf chain: with the terms in ascending
+// order the sums are the vector form's, bit for bit.  The coefficient fragments of a wave's row tile (2 x steps registers) are fetched once per tile.
+__device__ __forceinline__ void cf_prime_pass_mx(const ChanFftGeom &g, float2 *s_x, float2 *s_y, const float2 *s_tw, const float *__restrict__ tab, int tid, int nthr) {
+    const int TF = g.TF, TFs = g.TFs, p = g.dp, s0 = g.M / p, H = (p - 1) >> 1;
+    const int RT = chanfft_mx_row_tiles(p), KS = chanfft_mx_steps(p);
+    int lane = tid & 63;
+    opaque(lane);                                                          // (what is derived from it -- fragment and column addresses -- is formed here, per tile, instead of being carried, spilled, across the FIR phase)
+    const int wave = wave_uniform(tid >> 6), nw = nthr >> 6;
+    const int n_li = s0 << g.lgTF, CT = (n_li + 15) >> 4, tasks = RT * CT;
+    const int q = lane >> 4, rs = s0 * TFs;
+    constexpr int kCh = 5, kNch = (kCfMxMaxSteps + kCh - 1) / kCh;      // the coefficient fragments arrive in chunks of five steps, one chunk ahead of the products (all of them at once do not fit the registers)
+    for (int task = wave; task < tasks; task += nw) {
+        const int ct = task / RT, rt = task - ct * RT;                     // (wave-uniform) neighbouring waves share a column tile's rows
+        const float *tc = tab + (size_t)rt * KS * 64 + lane, *ts = tab + ((size_t)RT + rt) * KS * 64 + lane;
+        const int li = min(16 * ct + (lane & 15), n_li - 1);
+        const bool live = 16 * ct + (lane & 15) < n_li;
+        const int t = li & (TF - 1), j = li >> g.lgTF;
+        const float2 *col = s_x + (size_t)j * TFs + t;
+        csdr_f32x4 Pr = {0.f, 0.f, 0.f, 0.f}, Pi = Pr, Qr = Pr, Qi = Pr;
+        float2 a = col[(size_t)q * rs], b = q ? col[(size_t)(p - q) * rs] : make_float2(0.f, 0.f);      // step 0: n = q
+        float mc[2][kCh], ms[2][kCh];                                      // two register sets: chunk c + 1 is on its way while chunk c is multiplied
+#pragma unroll
+        for (int i = 0; i < kCh; ++i) { const int J = min(i, KS - 1); mc[0][i] = tc[J * 64]; ms[0][i] = ts[J * 64]; }
+#pragma unroll
+        for (int c = 0; c < kNch; ++c) {
+            if (c * kCh < KS) {                                            // (wave-uniform)
+                if ((c + 1) * kCh < KS) {
+#pragma unroll
+                    for (int i = 0; i < kCh; ++i) { const int J = min((c + 1) * kCh + i, KS - 1); mc[(c + 1) & 1][i] = tc[J * 64]; ms[(c + 1) & 1][i] = ts[J * 64]; }
+                }
+#pragma unroll
+                for (int i = 0; i < kCh; ++i) {
+                    const int J = c * kCh + i;
+                    if (J < KS) {                                          // (wave-uniform)
+                        float2 a2 = a, b2 = b;
+                        if (J + 1 < KS) { const int n2 = 4 * (J + 1) + q; a2 = col[(size_t)n2 * rs]; b2 = col[(size_t)(p - n2) * rs]; }      // (n2 <= H + 3 < p: a row of the tile; past H the coefficients are zero)
+                        const float2 sv = make_float2(a.x + b.x, a.y + b.y), dv = make_float2(a.x - b.x, a.y - b.y);
+                        Pr = csdr_mfma16(mc[c & 1][i], sv.x, Pr); Pi = csdr_mfma16(mc[c & 1][i], sv.y, Pi);
+                        Qr = csdr_mfma16(ms[c & 1][i], dv.x, Qr); Qi = csdr_mfma16(ms[c & 1][i], dv.y, Qi);
+                        a = a2; b = b2;
+                    }
+                }
+            }
+        }
+        float2 *ycol = s_y + (size_t)j * TFs + t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 16 * rt + 4 * q + r;
+            if (live && k <= H) {
+                const float2 P = make_float2(Pr[r], Pi[r]), Q = make_float2(Qr[r], Qi[r]);
+                if (k == 0) ycol[0] = P;
+                else {
+                    const int kn = p - k;
+                    ycol[(size_t)k * rs] = cmul(make_float2(P.x + Q.y, P.y - Q.x), s_tw[j * k]);        // j r < M
+                    ycol[(size_t)kn * rs] = cmul(make_float2(P.x - Q.y, P.y + Q.x), s_tw[j * kn]);
+                }
+            }
+        }
+    }
+}
+
 // one butterfly of the last pass (span 1): results go to their channel rows
 // (OS2, the oversampled bank: s_pa holds (row << 1) | (channel is odd) -- -1 stays -1 --, s_post the post factor W_M^k / M of firpfbch2 of the channel at
 //  each position; odd channels change sign in the frames of odd parity, design::channelizer2_post)
@@ -713,7 +806,11 @@ CSDR_KERNEL __launch_bounds__(kCfMaxThreads) void chan_analyze_fft(
             const bool lastp = p == g.npass - 1;
             float2 *dcs = dc_ends ? s_dc : nullptr;
             if constexpr (PLAN == 4) if (p == 0) { cf_blue_pass(g, s_x, s_ws, s_tw, s_wl, s_bh, s_c, tid, nthr); lds_barrier(); continue; }
-            if constexpr (PLAN == 5) if (p == 0) { cf_prime_pass<kCfDirectKP>(g, s_x, s_ws, s_tw, post, tid, nthr); lds_barrier(); s_t = s_ws; continue; }
+            if constexpr (PLAN == 5) if (p == 0) {
+                if (kCfPrimeMx) cf_prime_pass_mx(g, s_x, s_ws, s_tw, reinterpret_cast<const float *>(post), tid, nthr);
+                else cf_prime_pass<kCfDirectKP>(g, s_x, s_ws, s_tw, post, tid, nthr);
+                lds_barrier(); s_t = s_ws; continue;
+            }
 #define CSDR_CF_CASE(R_)                                                                                                                         \
             case R_:                                                                                                                             \
                 if constexpr (cf_plan_has(PLAN, R_, WIDE)) {                                                                                     \

@@ -1057,10 +1057,8 @@ __device__ __forceinline__ void demod_modem_body(
     const BlockPlan *__restrict__ plans, int NB, int cap_stream, const ModemConsts *__restrict__ mc, const float *__restrict__ sintab,
     const float *__restrict__ arms_all, int cap_cw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *s_a = reinterpret_cast<float *>(smem);              // AM: |x| ; SSB: real part stream
-    float *s_b = s_a + cap_stream;                             // SSB: imag part stream (two more streams follow: the filtered pair)
-    double *s_red = reinterpret_cast<double *>(s_b + 3 * cap_stream);   // (CW carves the same memory differently, see below)
-    float *s_redf = reinterpret_cast<float *>(s_red + 4);
+    float *s_a = reinterpret_cast<float *>(smem);              // AM: |x| ; SSB: real part stream (the imaginary part and the filtered pair follow, cap_stream apart)
+    // (the block sum and maximum are wave reductions -- wave_sum_double / wave_max_float: no LDS scratch)
 
     const int tid = threadIdx.x;
     constexpr int nthr = kAudioThreads;
@@ -1144,8 +1142,6 @@ __device__ __forceinline__ void demod_modem_body(
         const int n_audio = (int)(A1 - A0);
         float2 *s_iq = reinterpret_cast<float2 *>(smem);          // staged IQ window [kCwIqWin]
         float2 *w0 = s_iq + kCwIqWin, *w1 = w0 + cap_cw;          // ping-pong stage arrays
-        s_red = reinterpret_cast<double *>(w1 + cap_cw);
-        s_redf = reinterpret_cast<float *>(s_red + 4);
         const float *arms = arms_all + (size_t)au.arms_idx * kArms * kArmTaps;
         int64_t lo[kMaxHb + 1], hi[kMaxHb + 1];
         lo[aS] = A0 - H; hi[aS] = A1;
@@ -1358,8 +1354,6 @@ __device__ __forceinline__ void demod_audio_body(
     float *s_w0 = reinterpret_cast<float *>(smem);
     float *s_w1 = s_w0 + cap_out;
     float *s_d = s_w1 + cap_out;                               // scaled demodulator samples [jlo, jhi)
-    double *s_red = reinterpret_cast<double *>(s_d + cap_win);
-    float *s_redf = reinterpret_cast<float *>(s_red + 4);
 
     const int tid = threadIdx.x;
     constexpr int nthr = kAudioThreads;

@@ -166,7 +166,6 @@ CSDR_KERNEL __launch_bounds__(64) void fms_out(const SlotCfg *__restrict__ cfgs,
     const BlockPlan *pl = plans + (size_t)slot * (NB + 1);
     const int L = cfg.fms_fir_len, H = L - 1;
     float *s_l = reinterpret_cast<float *>(smem), *s_rt = s_l + cap_au + kFmsFirMax, *s_g = s_rt + cap_au + kFmsFirMax;
-    float *s_redf = s_g + kFmsFirMax;
     // audio samples of this block per channel: one per arbitrary-stage output of the two audio resamplers, 2^S each when they interpolate
     const int ush = cfg.rs_au.interp ? cfg.rs_au.S : 0;
     const int a0 = pl[b].q0 << ush, n = (pl[b + 1].q0 << ush) - a0;

@@ -147,7 +147,7 @@ def test_channelizer_m_twice_odd(ctx, fs, M, block):
 # instance (round 5); 116 = 4 * 29 and 2048 (no 8-frame tile in 160 KB) stay on chan_analyze
 FFT_SIZES = [(2, 700), (4, 1000), (8, 515), (12, 300), (16, 260), (20, 777), (24, 130), (28, 100), (36, 70), (40, 300), (44, 65), (52, 40), (56, 66),
              (72, 50), (80, 129), (100, 90), (112, 33), (126 * 2, 20), (200, 100), (256, 37), (360, 20), (1024, 40), (2048, 19), (68, 30), (32, 5), (200, 3),
-             (76, 45), (92, 33), (136, 40), (204, 25), (116, 21), (134, 20), (146, 19), (202, 18), (398, 17), (174, 20), (194, 16), (388, 12), (254, 14), (326, 13), (232, 16), (290, 12), (348, 10), (178, 19), (356, 9)]
+             (76, 45), (92, 33), (136, 40), (204, 25), (116, 21), (134, 20), (146, 19), (202, 18), (398, 17), (174, 20), (194, 16), (388, 12), (254, 14), (326, 13), (232, 16), (290, 12), (348, 10), (178, 19), (356, 9), (422, 9), (446, 8)]
 
 
 @pytest.mark.parametrize("M,frames", FFT_SIZES)
@@ -157,7 +157,7 @@ def test_channelizer_fft_sizes(ctx, M, frames):
     chans = None if M <= 256 else sorted({c for c in (0, 1, 2, 3, M // 4 - 1, M // 4, M // 2 - 1, M // 2, M // 2 + 1, M - 2, M - 1, M, 77, 500, 333) if c <= M})
     from cubicsdr_amd.engine import SDRPost
     probe = SDRPost(ctx, 500000 * M, M, M * frames)
-    # (round 6: a prime factor 29 .. 89 -- 116, 134, 174 ... -- takes the direct prime pass of the FFT kernel, one >= 97 -- 202, 398 ... -- its chirp-z pass)
+    # (round 6: a prime factor 29 .. 199 -- 116, 134, 174 ... 398 -- takes the direct prime pass of the FFT kernel, on the fp32 matrix pipe; one >= 211 -- 422, 446 -- its chirp-z pass)
     assert probe.kernel_name == ("chan_analyze" if M == 2048 else "chan_analyze_fft"), probe.kernel_name
     probe.close()
     _channelizer_case(ctx, 500000 * M, M, M * frames, chans=chans)
