@@ -1680,6 +1680,7 @@ CSDR_KERNEL_BANK __launch_bounds__(kAudioThreads) void demod_modem_audio1(
         demod_modem_body(cfgs, dyns, slot, 0, plans, 1, cap_stream, mc, sintab, arms_all, cap_cw);
 #if defined(__AMDGCN__)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // the wave's global stores (the modem's output, the gain) before its loads of them
+        __builtin_amdgcn_s_dcache_inv();                            // ... also where the compiler reads a wave-uniform one of them (the block's gain) through the scalar cache, which vector stores do not update
 #endif
         __syncthreads();
     }
