@@ -53,9 +53,9 @@ def test_emu_channelizer_m6(ctx):
     G.test_channelizer_matches_firpfbch(ctx, 3000000, 6, 50004)
 
 
-@full
-def test_emu_channelizer_batched(ctx):
-    G.test_channelizer_batched_equals_blockwise(ctx)
+@pytest.mark.parametrize("fs,M,block", [pytest.param(2400000, 4, 40000, marks=full), (6100000, 122, 122 * 70), (6100000, 122, 122 * 3)])
+def test_emu_channelizer_batched(ctx, fs, M, block):
+    G.test_channelizer_batched_equals_blockwise(ctx, fs, M, block)
 
 
 def test_emu_channelizer2_m6(ctx):
