@@ -177,7 +177,7 @@ def test_every_even_channel_count_up_to_400_takes_a_fast_kernel(ctx):
 
 
 @pytest.mark.parametrize("fs,M,block", [(2400000, 4, 40000), (61440000, 122, 122 * 70), (61440000, 122, 122 * 3), (63000000, 126, 126 * 129)])
-def test_channelizer_batched_equals_blockwise(ctx, fs=2400000, M=4, block=40000):
+def test_channelizer_batched_equals_blockwise(ctx, fs, M, block):
     """one call over four blocks = four calls over one block each, bit for bit: the carried history, tiles that end inside a block (M = 122 / 126: the
     matrix-pipe form of chan_analyze_p2, 64-frame tiles over 70-, 3- and 129-frame blocks -- a block shorter than the FIR's reach included)"""
     from cubicsdr_amd.engine import SDRPost
