@@ -53,6 +53,9 @@ extern "C" void csdr_post_destroy(csdr_post *p) {
     delete p;
 }
 
+#ifndef CSDR_P2_OS2_MIN_A
+#define CSDR_P2_OS2_MIN_A 19          // firpfbch2 with M / 2 odd: the smallest A = M / 2 that takes chan_analyze_p2 (M >= 38: 1.2 - 2.5 x the two-factor kernel, which wins below: profiles/r06_chan2_p2.txt)
+#endif
 #ifndef CSDR_CHAN_MX_DEFAULT
 #define CSDR_CHAN_MX_DEFAULT 1          // (A/B builds: -DCSDR_CHAN_MX_DEFAULT=0 keeps the vector form of chan_analyze_p2's transform phase for every A)
 #endif
@@ -74,7 +77,13 @@ static int chan_geometry(int M, int hop, ChanGeom &g) {
         g.nkA = (H + 3) / 4; g.KA = (H + g.nkA - 1) / g.nkA; g.PA = g.nkA * g.KA;
     }
     g.magicM = (unsigned)((1ull << 32) / (unsigned)M) + 1u;
-    if (hop == M && g.B == 2 && g.oddA && g.A <= 63 && !lab_int("CSDR_CHAN_GENERIC", 0)) {
+    // M = 2 A with A odd <= 63: chan_analyze_p2.  Critically sampled where A is prime (a composite A factors over the FFT kernel's radices, which is
+    // faster); firpfbch2 (hop == M / 2: every frame but one in two starts at an odd sample offset) for every odd A, in the kernel's matrix-pipe form with
+    // the two lattices of frames dealt to its waves.
+    const bool twice_odd = (M & 3) == 2 && M / 2 >= 3 && M / 2 <= kP2MaxA;
+    const bool p2_os2 = twice_odd && M / 2 >= CSDR_P2_OS2_MIN_A && hop * 2 == M && CSDR_CHAN_MX_DEFAULT && lab_int("CSDR_CHAN_P2_OS2", 1);
+    if (p2_os2) { g.B = 2; g.A = M / 2; g.oddA = 1; }
+    if ((p2_os2 || (hop == M && g.B == 2 && g.oddA && g.A <= kP2MaxA)) && !lab_int("CSDR_CHAN_GENERIC", 0)) {
         // whole transform of a frame inside one lane (kernels_post.hpp, chan_analyze_p2): (A - 1) / 2 output pairs + the k = 0
         // pseudo pair, split evenly over (up to) four passes of at most eight slots
         const int slots = (g.A - 1) / 2 + 1;
@@ -84,7 +93,7 @@ static int chan_geometry(int M, int hop, ChanGeom &g) {
         g.PA = g.nkA * g.KA;
         g.TF = kP2Frames; g.lgTF = 6; g.S = M; g.taps_lds = 0; g.stage_in = 1; g.threads = kP2Threads;
         // the A-point transforms on the fp32 matrix pipe where they fill two row tiles of sixteen outputs (A >= 33: M = 66 ... 126)
-        g.mx = (g.A >= 33 && lab_int("CSDR_CHAN_MX", CSDR_CHAN_MX_DEFAULT) != 0) ? 1 : 0;
+        g.mx = (hop != M || (g.A >= 33 && lab_int("CSDR_CHAN_MX", CSDR_CHAN_MX_DEFAULT) != 0)) ? 1 : 0;
         return CSDR_OK;
     }
     g.taps_lds = (M <= 512) ? 1 : 0;
@@ -111,11 +120,11 @@ static int chan_geometry(int M, int hop, ChanGeom &g) {
 typedef void (*chan_kernel_t)(const float2 *, const float2 *, float2 *, const float *, const float2 *, const float2 *, const float2 *,
                               const int *, ChanGeom, int64_t, float2 *, int64_t, d2 *, double, const float2 *);
 typedef void (*chan_p2_kernel_t)(const float2 *, const float2 *, float2 *, const float *, const float2 *, const float2 *, const int *, ChanGeom,
-                                 int64_t, float2 *, int64_t, d2 *, double);
+                                 int64_t, float2 *, int64_t, d2 *, double, const float2 *);
 static chan_p2_kernel_t chan_p2_kernel(const ChanGeom &g) {
 #define CSDR_P2_CASE(K_) case K_: return chan_analyze_p2<K_>
     // (A <= 63: at most 32 slots over eight waves = at most four per pass; wider passes were instances nothing ever launched -- one of them spilled)
-    if (g.mx) return chan_analyze_p2<4, true>;
+    if (g.mx) return g.hop != g.M ? chan_analyze_p2<4, true, true> : chan_analyze_p2<4, true>;
     switch (g.KA) {
         CSDR_P2_CASE(1); CSDR_P2_CASE(2); CSDR_P2_CASE(3);
         default: return chan_analyze_p2<4>;
@@ -257,7 +266,7 @@ extern "C" int csdr_post_configure(csdr_post *p, int64_t sample_rate, int num_ch
         CSDR_HIP_TRY(hipMemsetAsync(p->hist0.p, 0, H * sizeof(float2), st));
         CSDR_HIP_TRY(hipMemsetAsync(p->hist1.p, 0, H * sizeof(float2), st));
         CSDR_HIP_TRY(hipStreamSynchronize(st));   // host vectors above go out of scope
-        const size_t lds = p->use_fft ? chanfft_lds_bytes(p->fgeom) : g.p2 ? chan_p2_lds_bytes(M, g.mx != 0) : chan_lds_bytes(g);
+        const size_t lds = p->use_fft ? chanfft_lds_bytes(p->fgeom) : g.p2 ? chan_p2_lds_bytes(M, g.mx != 0, g.hop != M) : chan_lds_bytes(g);
         if (lds > 64 * 1024) CSDR_HIP_TRY(hipFuncSetAttribute(p->use_fft ? (const void *)chanfft_kernel(p->fgeom) : g.p2 ? (const void *)chan_p2_kernel(g) : (const void *)chan_kernel(g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     p->hist_parity = 0;
@@ -394,11 +403,12 @@ extern "C" int csdr_post_execute(csdr_post *p, const float *iq, int iq_is_dev, i
             // persistent workgroups: as many as are resident at once, each walks over tiles blockIdx.x, + gridDim.x, ...
             const chan_p2_kernel_t k2 = chan_p2_kernel(g);
             const int chan_pct = std::max(10, std::min(100, lab_int("CSDR_CHAN_PCT", 100)));
-            const int wgs = std::min(ntiles, std::max(1, c->wg_slots(k2, g.threads, chan_p2_lds_bytes(M, g.mx != 0)) * chan_pct / 100));
+            const int wgs = std::min(ntiles, std::max(1, c->wg_slots(k2, g.threads, chan_p2_lds_bytes(M, g.mx != 0, g.hop != M)) * chan_pct / 100));
             g.xcd = lab_int("CSDR_CHAN_XCD", g.xcd);
             if (lab_int("CSDR_LAB_TRACE", 0)) fprintf(stderr, "[csdr lab] chan_analyze_p2 x=%p out=%p hist=%p taps=%p cs=%p twM=%p wgs=%d xcd=%d\n", (const void *)x, (void *)out, (void *)hist, (void *)p->taps.p, (void *)p->twA.p, (void *)p->twM.p, wgs, g.xcd);
-            CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, k2, dim3(wgs), dim3(g.threads), chan_p2_lds_bytes(M, g.mx != 0), x, hist, hist_new, p->taps.p,
-                        p->twA.p, p->twM.p, p->active.p, g, n_frames, out, p->chan_stride, fused_ends ? p->tile_end.p : (d2 *)nullptr, p->dc_c);
+            CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, k2, dim3(wgs), dim3(g.threads), chan_p2_lds_bytes(M, g.mx != 0, g.hop != M), x, hist, hist_new, p->taps.p,
+                        p->twA.p, p->twM.p, p->active.p, g, n_frames, out, p->chan_stride, fused_ends ? p->tile_end.p : (d2 *)nullptr, p->dc_c,
+                        p->mode == CSDR_POST_PFBCH2 ? p->post2.p : (const float2 *)nullptr);
         } else {
         const chan_kernel_t kern = chan_kernel(g);
         CSDR_LAUNCH(c, LANE_POST, KID_CHAN_ANALYZE, kern, dim3(ntiles), dim3(g.threads), chan_lds_bytes(g), x, hist, hist_new, p->taps.p,

@@ -546,8 +546,9 @@ constexpr int kP2MaxA = 63;
 // (the matrix-pipe form keeps two small tables behind the rows: the per-output constants of its epilogue and the tile's channel-0 samples)
 constexpr int kMxSteps = 8;            // K steps of four terms: n = 0 .. 31 (H <= 31)
 constexpr int kMxRows = 32;            // two row tiles of sixteen outputs: k = 0 .. 31
-__host__ __device__ inline size_t chan_p2_lds_bytes(int M, bool mx = false) {
-    return (size_t)kP2Frames * M * sizeof(float2) + (mx ? (size_t)kMxRows * (sizeof(float4) + 4 * sizeof(int)) + kP2Frames * sizeof(float2) + (size_t)(kChanTaps / 2) * (M / 2) * sizeof(float4) : 0);
+__host__ __device__ inline size_t chan_p2_lds_bytes(int M, bool mx = false, bool os2 = false) {
+    return (size_t)kP2Frames * M * sizeof(float2) + (mx ? (size_t)kMxRows * (sizeof(float4) + 4 * sizeof(int)) + kP2Frames * sizeof(float2) + (size_t)(kChanTaps / 2) * (M / 2) * sizeof(float4) : 0) +
+           (os2 ? (size_t)4 * kMxRows * sizeof(float4) : 0);
 }
 // coefficient fragments of the matrix-pipe form, [2 (cos | sin)][2 row tiles][kMxSteps][64 lanes]: lane l of step J holds the coefficient of output
 // k = 16 rt + (l & 15) and term n = 4 J + (l >> 4) -- the A operand of v_mfma_f32_16x16x4_f32 (A[i = l & 15][k = l >> 4]); term 0 is x_0 (cos = 1, sin = 0),
@@ -639,15 +640,41 @@ __device__ __forceinline__ void chan_p2_accumulate(const float4 *row, const int 
 // f0 + ta - 7 .. f0 + ta + 7; lane = column pair, a row is 16 A contiguous bytes per wave.  Rows in front of the batch come from the carried
 // history, rows past its end are zero (their frames are never stored).  The row index and the source select are wave-uniform: fifteen
 // plain loads under one lane mask, nothing between them.
-template <int J0 = 0, int J1 = 2 * kChanTaps - 1>
+template <int J0 = 0, int J1 = 2 * kChanTaps - 1, bool OS2 = false>
 __device__ __forceinline__ void chan_p2_request_window(const float2 *__restrict__ x, const float2 *__restrict__ hist, int M, int A, int64_t n_frames,
                                                        int64_t tile, bool valid, int wave, int lane, float4 (&win)[2 * kChanTaps - 1], bool mir = false) {
     // (mir: the window is held in descending order -- win[j] = row r0 + 14 - j.  The matrix-pipe form's odd waves do that, so that the seven rows a wave
     //  shares with each neighbour are requested at the same positions of the sequence by both -- the early rows with the wave above, the late ones with
     //  the wave below -- and the second request meets the first in the cache: 10.7 -> 8.9 B/sample fetched)
-    const int64_t r0 = tile * kP2Frames + (int64_t)wave * kChanTaps - (kChanTaps - 1);      // input row of win[0] (win[14] when mirrored)
+    // OS2 (firpfbch2, frames hop by A = M / 2): the frames of even and of odd index are two lattices of rows M apart, the odd one's rows start A samples
+    // later; wave = (lattice l = wave & 1, eight frames of it): row r of lattice l holds the samples r M + (l - 1) A .. + M - 1 (frame f = 2 r + l ends with
+    // it), the history is the 7.5 M samples in front of the batch.  Row 0 of lattice 0 lies half in the history: the lane of its middle pair reads one
+    // sample from each side.
     const bool col = lane < A;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (OS2) {
+        const int l = wave & 1;
+        const int64_t r0 = tile * (kP2Frames / 2) + (int64_t)(wave >> 1) * kChanTaps - (kChanTaps - 1);
+        const int64_t Hs = (int64_t)kChanTaps * M - A;
+#pragma unroll
+        for (int j = J0; j < J1; ++j) {
+            const int64_t r = r0 + (mir ? 2 * kChanTaps - 2 - j : j);               // wave-uniform
+            const int64_t s0 = r * M + (int64_t)(l - 1) * A;                        // first sample of the row (batch-relative)
+            win[j] = z4;
+            if (valid && 2 * r + l < n_frames) {                                    // (wave-uniform)
+                if (s0 >= 0 || s0 + M <= 0) {
+                    const float2 *src = s0 >= 0 ? x + s0 : hist + (s0 + Hs);
+                    if (col) { const f4u v = *reinterpret_cast<const f4u *>(src + 2 * lane); win[j] = make_float4(v.x, v.y, v.z, v.w); }
+                } else if (col) {                                                   // the row that straddles the batch's start (s0 = - A)
+                    const int64_t sa = s0 + 2 * lane, sb = sa + 1;
+                    const float2 a = sa >= 0 ? x[sa] : hist[sa + Hs], b = sb >= 0 ? x[sb] : hist[sb + Hs];
+                    win[j] = make_float4(a.x, a.y, b.x, b.y);
+                }
+            }
+        }
+        return;
+    }
+    const int64_t r0 = tile * kP2Frames + (int64_t)wave * kChanTaps - (kChanTaps - 1);      // input row of win[0] (win[14] when mirrored)
 #pragma unroll
     for (int j = J0; j < J1; ++j) {
         const int64_t r = r0 + (mir ? 2 * kChanTaps - 2 - j : j);                   // wave-uniform
@@ -661,24 +688,26 @@ __device__ __forceinline__ void chan_p2_request_window(const float2 *__restrict_
 
 // MX = true (A >= 33: two row tiles of outputs): the transform phase runs on the fp32 matrix pipe -- see "DFT on the matrix pipe" below; `cs` then is
 // the coefficient-fragment table of chan_mx_table().
-template <int KP, bool MX = false>
+// OS2 (matrix-pipe form only): firpfbch2 -- frames hop by A = M / 2, `post` = [2 frame parities][M] output factors (design::channelizer2_post).
+template <int KP, bool MX = false, bool OS2 = false>
 CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
     const float2 *__restrict__ x, const float2 *__restrict__ hist, float2 *__restrict__ hist_new,
     const float *__restrict__ tapsT,      // [8][M]
     const float2 *__restrict__ cs,        // [(A-1)/2][PA]: (cos, sin)(2 pi k(q) c / A) at [(c - 1) PA + q]; slot q: k = q + 1 (q < H), k = 0 (q == H), else (0, 0)
     const float2 *__restrict__ twM,       // [A][2]: exp(-j 2 pi k1 c2 / M) at [2 k1 + c2]
     const int *__restrict__ active, ChanGeom g, int64_t n_frames,
-    float2 *__restrict__ out, int64_t out_stride, d2 *__restrict__ dc_ends, double dc_c) {
+    float2 *__restrict__ out, int64_t out_stride, d2 *__restrict__ dc_ends, double dc_c, const float2 *__restrict__ post) {
+    static_assert(!OS2 || MX, "the oversampled bank exists in the matrix-pipe form only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *rows = reinterpret_cast<float4 *>(smem);          // X[t] at rows + t A
     const int M = g.M, A = g.A, H = (A - 1) >> 1;
     const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = wave_uniform(tid0 >> 6);
     const int64_t n_tiles = (n_frames + kP2Frames - 1) / kP2Frames;
-    const int64_t Hs = (int64_t)(kChanTaps - 1) * M;          // samples in front of a tile's own first row = carried history length
+    const int64_t Hs = (int64_t)kChanTaps * M - (OS2 ? A : M);   // samples in front of a tile's own first row = carried history length (7 M; oversampled 7.5 M)
     // the workgroup that finishes last in program order is unknown: the new input history is written by workgroup 0 up front
     // (it only reads x / hist, which nobody writes during this launch)
     if (blockIdx.x == 0) {
-        const int64_t n = n_frames * M;
+        const int64_t n = n_frames * (OS2 ? A : M);
         for (int64_t j = tid0; j < Hs; j += kP2Threads) {
             const int64_t gsrc = n - Hs + j;
             hist_new[j] = gsrc >= 0 ? x[gsrc] : hist[gsrc + Hs];
@@ -691,6 +720,19 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
     int4 *epi_on = reinterpret_cast<int4 *>(epi_w + kMxRows);
     float2 *s_y0 = reinterpret_cast<float2 *>(epi_on + kMxRows);                  // channel 0 of the tile (the DC blocker's end value)
     float4 *s_taps = reinterpret_cast<float4 *>(s_y0 + kP2Frames);                // [4][A]: taps 2 j and 2 j + 1 of a column pair
+    float4 *epi_post = s_taps + (kChanTaps / 2) * A;                              // OS2: [2 parities][32 outputs k][2]: post factors of rows (k, k + A), (A - k, 2 A - k)
+    if constexpr (OS2) {
+        if (tid0 < 2 * kMxRows) {
+            const int par = tid0 >> 5, k = tid0 & 31, kn = A - k;
+            float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
+            if (k <= H) {
+                const float2 *pr = post + (size_t)par * M;
+                pa = make_float4(pr[k].x, pr[k].y, pr[k + A].x, pr[k + A].y);
+                if (k > 0) pb = make_float4(pr[kn].x, pr[kn].y, pr[kn + A].x, pr[kn + A].y);
+            }
+            epi_post[2 * tid0] = pa; epi_post[2 * tid0 + 1] = pb;
+        }
+    }
     if constexpr (MX) {
         for (int i = tid0; i < (kChanTaps / 2) * A; i += kP2Threads) {
             const int j = i / A, lc = i - j * A;
@@ -722,7 +764,8 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
         const int64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
         tile = (int64_t)blockIdx.x * per; tstep = 1; tend = min(n_tiles, tile + per);
     }
-    chan_p2_request_window<>(x, hist, M, A, n_frames, tile, tile < tend, wave, lane0, win, MX && kP2Mirror && (wave & 1));
+    const bool mirw = MX && kP2Mirror && (((OS2 ? wave >> 1 : wave) & 1) != 0);      // (the neighbours that share rows: the next wave, oversampled the next wave of the same lattice)
+    chan_p2_request_window<0, 2 * kChanTaps - 1, OS2>(x, hist, M, A, n_frames, tile, tile < tend, wave, lane0, win, mirw);
     for (; tile < tend; tile += tstep) {
         const int64_t f0 = tile * kP2Frames;
         const int nf = (int)min((int64_t)kP2Frames, n_frames - f0);
@@ -744,7 +787,8 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
         {
             constexpr int kRange = kP2Frames / kP2Waves;
             static_assert(kRange == kChanTaps, "a wave's range is eight frames: its window is fifteen rows");
-            const int ta = wave * kRange;
+            // tile-local frame of the wave's i-th output: eight consecutive ones, or (oversampled) eight of its lattice
+            const int ta = OS2 ? 2 * kRange * (wave >> 1) + (wave & 1) : wave * kRange, ts = OS2 ? 2 : 1;
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
             auto fir_frame = [&](const int i, auto mirrored) -> float4 {      // tap n multiplies input row t - n = window row i + 7 - n
                 float4 acc = z4;
@@ -758,11 +802,11 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
                 }
                 return acc;
             };
-            if (MX && kP2Mirror && (wave & 1)) {              // (wave-uniform) the mirrored window of an odd wave: nothing but the stores follows a frame's sum
+            if (mirw) {                                       // (wave-uniform) the mirrored window: nothing but the stores follows a frame's sum
 #pragma unroll
                 for (int i = kRange - 1; i >= 0; --i) {       // last frame first: its window is the eight rows that were requested early
                     const float4 acc = fir_frame(i, std::true_type{});
-                    if (col) rows[(ta + i) * A + lane] = acc;
+                    if (col) rows[(ta + ts * i) * A + lane] = acc;
                     sched_fence();
                 }
             } else
@@ -782,7 +826,7 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
                     p = __shfl(acc.z, pl, 64); acc.z = is_sd ? fmaf(sg, acc.z, p) : acc.z;
                     p = __shfl(acc.w, pl, 64); acc.w = is_sd ? fmaf(sg, acc.w, p) : acc.w;
                 }
-                if (col) rows[(ta + i) * A + lane] = acc;
+                if (col) rows[(ta + ts * i) * A + lane] = acc;
                 sched_fence();                                // frame after frame
             }
         }
@@ -792,7 +836,7 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
         // instead costs 1 %); the window requests one step above it (- 1.5 %)
         wave_priority(kP2ReqPrio);
         // the next tile's window is on its way while this one is transformed (into the registers the FIR has just finished with)
-        chan_p2_request_window<0, kP2EarlyRows>(x, hist, M, A, n_frames, tile + tstep, tile + tstep < tend, wave, lane, win, MX && kP2Mirror && (wave & 1));
+        chan_p2_request_window<0, kP2EarlyRows, OS2>(x, hist, M, A, n_frames, tile + tstep, tile + tstep < tend, wave, lane, win, mirw);
         wave_priority(kP2DftPrio);
         if constexpr (MX) {
             // ---- DFT on the matrix pipe.  The conjugate-pair sums are two real matrix products per component:
@@ -809,22 +853,32 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
             const bool tv = t < nf;
             csdr_f32x4 P0r = {0.f, 0.f, 0.f, 0.f}, P0i = P0r, P1r = P0r, P1i = P0r, Q0r = P0r, Q0i = P0r, Q1r = P0r, Q1i = P0r;
             // s_n = x_n + x_{A-n}, d_n = x_n - x_{A-n} are formed here from the two rows (each rounded once, as the vector form's lane trade does in its FIR
-            // phase: the same values); term 0 is x_0 itself
-            float4 a = row[q], b = q ? row[A - q] : make_float4(0.f, 0.f, 0.f, 0.f);      // step 0: n = q
+            // phase: the same values); term 0 is x_0 itself.  Terms past H have zero coefficients: they read a row of the frame all the same (a finite operand).
+            // (A < 33 -- the oversampled bank's small counts: the second row tile holds no output, its waves sit the phase out; steps past the last term are skipped)
+            const int KS = (H + 4) >> 2;                               // ceil((H + 1) / 4) steps, (wave-uniform)
+            const bool rt_live = 16 * rt <= H;
+            auto row_s = [&](int n) { return row[min(n, A - 1)]; };
+            auto row_d = [&](int n) { return row[n >= 1 && n < A ? A - n : 1]; };
+            float4 a = row_s(q), b = q ? row_d(q) : make_float4(0.f, 0.f, 0.f, 0.f);      // step 0: n = q
+            if (rt_live) {
 #pragma unroll
             for (int J = 0; J < kMxSteps; ++J) {
-                float4 a2 = a, b2 = b;
-                if (J + 1 < kMxSteps) { const int n2 = 4 * (J + 1) + q; a2 = row[n2]; b2 = row[A - n2]; }      // the next step's rows are requested ahead of this step's products (rows past H: zero coefficients)
-                const float4 sv = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-                const float4 dv = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
-                P0r = csdr_mfma16(mxc[J], sv.x, P0r); P0i = csdr_mfma16(mxc[J], sv.y, P0i);
-                P1r = csdr_mfma16(mxc[J], sv.z, P1r); P1i = csdr_mfma16(mxc[J], sv.w, P1i);
-                Q0r = csdr_mfma16(mxs[J], dv.x, Q0r); Q0i = csdr_mfma16(mxs[J], dv.y, Q0i);
-                Q1r = csdr_mfma16(mxs[J], dv.z, Q1r); Q1i = csdr_mfma16(mxs[J], dv.w, Q1i);
-                a = a2; b = b2;
+                if (J < KS) {
+                    float4 a2 = a, b2 = b;
+                    if (J + 1 < kMxSteps) { const int n2 = 4 * (J + 1) + q; a2 = row_s(n2); b2 = row_d(n2); }      // the next step's rows are requested ahead of this step's products
+                    const float4 sv = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+                    const float4 dv = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+                    P0r = csdr_mfma16(mxc[J], sv.x, P0r); P0i = csdr_mfma16(mxc[J], sv.y, P0i);
+                    P1r = csdr_mfma16(mxc[J], sv.z, P1r); P1i = csdr_mfma16(mxc[J], sv.w, P1i);
+                    Q0r = csdr_mfma16(mxs[J], dv.x, Q0r); Q0i = csdr_mfma16(mxs[J], dv.y, Q0i);
+                    Q1r = csdr_mfma16(mxs[J], dv.z, Q1r); Q1i = csdr_mfma16(mxs[J], dv.w, Q1i);
+                    a = a2; b = b2;
+                }
+            }
             }
             // each accumulator holds four outputs k of one frame: a store instruction of the wave covers four channel rows, 128 contiguous bytes of each
             float2 *ob = out + f0 + t;
+            if (rt_live)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = 16 * rt + 4 * q + r;
@@ -834,12 +888,18 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
                 const float2 z0k = make_float2(P0.x + Q0.y, P0.y - Q0.x), z0n = make_float2(P0.x - Q0.y, P0.y + Q0.x);
                 const float2 u = cmul(make_float2(P1.x + Q1.y, P1.y - Q1.x), make_float2(w.x, w.y));
                 const float2 v = cmul(make_float2(P1.x - Q1.y, P1.y + Q1.x), make_float2(w.z, w.w));
-                const float2 y0 = make_float2(z0k.x + u.x, z0k.y + u.y);
+                float2 y0 = make_float2(z0k.x + u.x, z0k.y + u.y), y1 = make_float2(z0k.x - u.x, z0k.y - u.y);
+                float2 y2 = make_float2(z0n.x + v.x, z0n.y + v.y), y3 = make_float2(z0n.x - v.x, z0n.y - v.y);
+                if constexpr (OS2) {                                // firpfbch2: times the channel's post factor of this frame's parity (tiles start on even frames)
+                    const float4 pa = epi_post[2 * (32 * (t & 1) + k)], pb = epi_post[2 * (32 * (t & 1) + k) + 1];
+                    y0 = cmul(y0, make_float2(pa.x, pa.y)); y1 = cmul(y1, make_float2(pa.z, pa.w));
+                    y2 = cmul(y2, make_float2(pb.x, pb.y)); y3 = cmul(y3, make_float2(pb.z, pb.w));
+                }
                 if (tv) {
                     if (on.x) { if (k) store_nt(ob + (int64_t)(on.x - 1) * out_stride, y0); else ob[(int64_t)(on.x - 1) * out_stride] = y0; }      // (channel 0 is read again by the DC blocker)
-                    if (on.y) store_nt(ob + (int64_t)(on.y - 1) * out_stride, make_float2(z0k.x - u.x, z0k.y - u.y));
-                    if (on.z) store_nt(ob + (int64_t)(on.z - 1) * out_stride, make_float2(z0n.x + v.x, z0n.y + v.y));
-                    if (on.w) store_nt(ob + (int64_t)(on.w - 1) * out_stride, make_float2(z0n.x - v.x, z0n.y - v.y));
+                    if (on.y) store_nt(ob + (int64_t)(on.y - 1) * out_stride, y1);
+                    if (on.z) store_nt(ob + (int64_t)(on.z - 1) * out_stride, y2);
+                    if (on.w) store_nt(ob + (int64_t)(on.w - 1) * out_stride, y3);
                 }
                 if (r == 0 && dc_ends && k == 0) s_y0[t] = y0;        // k = 0: Q = 0, W = 1 -- y0 = P0 + P1 as in the vector form
             }
@@ -896,7 +956,7 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
         }
         wave_priority(kP2ReqPrio);
         // the rest of the next window (the transform above leaves no room for all fifteen rows: they would be spilled -- which waits for them)
-        chan_p2_request_window<kP2EarlyRows, 2 * kChanTaps - 1>(x, hist, M, A, n_frames, tile + tstep, tile + tstep < tend, wave, lane0, win, MX && kP2Mirror && (wave & 1));
+        chan_p2_request_window<kP2EarlyRows, 2 * kChanTaps - 1, OS2>(x, hist, M, A, n_frames, tile + tstep, tile + tstep < tend, wave, lane0, win, mirw);
         wave_priority(0);
         lds_barrier();                                      // the rows are free for the next tile
         if constexpr (MX) {

@@ -205,8 +205,8 @@ def test_emu_fm_stereo_settings(ctx):
     print(G._fms_case(ctx, 2400000, 4, 20000, 4, 2, bw=50000, audio_rate=48000, demph=50, seed=37))
 
 
-@pytest.mark.parametrize("fs,M,block", [(5000000, 10, 10 * 130), pytest.param(7000000, 14, 14 * 70, marks=full), (6100000, 122, 122 * 150), (6300000, 126, 126 * 70),
-                                        pytest.param(3300000, 66, 66 * 80, marks=full)])
+@pytest.mark.parametrize("fs,M,block", [(5000000, 10, 10 * 130), pytest.param(7000000, 14, 14 * 70, marks=full), (6100000, 122, 122 * 150), (5900000, 118, 118 * 70),
+                                        pytest.param(3700000, 74, 74 * 80, marks=full)])
 def test_emu_channelizer_m_twice_odd(ctx, fs, M, block):
     """M = 2 A, A odd: the one-lane-per-frame kernel with its mover wave (ragged and whole 64-frame tiles, carried history)"""
     G.test_channelizer_m_twice_odd(ctx, fs, M, block)
@@ -218,7 +218,8 @@ def test_emu_channelizer_fft_sizes(ctx, M, frames):
     G.test_channelizer_fft_sizes(ctx, M, frames)
 
 
-@pytest.mark.parametrize("fs,M,block", [(4000000, 8, 8 * 77), pytest.param(20000000, 40, 40 * 61, marks=full), pytest.param(34000000, 68, 68 * 45, marks=full)])
+@pytest.mark.parametrize("fs,M,block", [(4000000, 8, 8 * 77), pytest.param(20000000, 40, 40 * 61, marks=full), pytest.param(34000000, 68, 68 * 45, marks=full),
+                                        (6100000, 122, 122 * 77), (1900000, 38, 38 * 100), pytest.param(6300000, 126, 126 * 9, marks=full), pytest.param(1700000, 34, 34 * 130, marks=full)])
 def test_emu_channelizer2_fft(ctx, fs, M, block):
     """firpfbch2 inside the FFT channelizer (round 5): the two lattices of frames, windows across the 7.5 M history, post factors and the sign of odd channels"""
     G.test_channelizer2_matches_firpfbch2(ctx, fs, M, block)

@@ -55,7 +55,9 @@ def test_channelizer_matches_firpfbch(ctx, fs, M, block):
                                          # round 5: the oversampled hop inside the FFT channelizer (M % 4 == 0 and a 16-frame tile fits): whole and ragged tiles, one to
                                          # three passes, a wide-odd factor, blocks shorter than a tile
                                          (4000000, 8, 8 * 517), (20000000, 40, 40 * 301), (100000000, 200, 200 * 77), (128000000, 256, 256 * 53),
-                                         (34000000, 68, 68 * 45), (56000000, 112, 112 * 5)])
+                                         (34000000, 68, 68 * 45), (56000000, 112, 112 * 5),
+                                         # round 6: M / 2 odd on chan_analyze_p2 (ragged tiles, a block shorter than a tile, the first and the last count of the range)
+                                         (61440000, 122, 122 * 77), (61440000, 122, 122 * 9), (33000000, 66, 66 * 100), (63000000, 126, 126 * 65), (19000000, 38, 38 * 130), (17000000, 34, 34 * 130)])
 def test_channelizer2_matches_firpfbch2(ctx, fs, M, block):
     """SDRPostPFBCH2 (runPFBCH2, SDRPostThread.cpp:472-512): firpfbch2 hands out M samples per M/2 inputs, every channel at
     twice the channel spacing; M/2 odd (6, 122) starts every other frame at an odd sample offset; M = 1024 takes the
@@ -66,7 +68,9 @@ def test_channelizer2_matches_firpfbch2(ctx, fs, M, block):
     x = [synth_iq(block, fs, center, [("NBFM", center + 123456)], seed=41 + b, t0=b * block) for b in range(3)]
     ref = RefSDRPost(_backend(), fs, M, oversampled=True)
     post = SDRPost(ctx, fs, M, block, max_blocks=1, oversampled=True)
-    assert post.kernel_name == ("chan_analyze_fft" if M % 4 == 0 and M < 1024 else "chan_analyze"), post.kernel_name
+    # (round 6: M / 2 odd from M = 38 on -- the 61.44 MS/s count 122 among them -- runs the matrix-pipe form of chan_analyze_p2, the two lattices of frames dealt to its waves)
+    want_kernel = "chan_analyze_fft" if M % 4 == 0 and M < 1024 else "chan_analyze_p2" if (M // 2) % 2 == 1 and 38 <= M <= 126 else "chan_analyze"
+    assert post.kernel_name == want_kernel, post.kernel_name
     chans = range(M + 1) if M <= 122 else sorted({c for c in (0, 1, 2, M // 2 - 1, M // 2, M // 2 + 1, M - 1, M, 77, 511, 512, 513, 1023, 1024) if c <= M})
     want_all = {ch: [] for ch in chans}
     for b in range(3):
@@ -134,11 +138,15 @@ def _channelizer_case(ctx, fs, M, block, chans=None, nblocks=3):
 
 
 @pytest.mark.parametrize("fs,M,block", [(5000000, 10, 83340), (7000000, 14, 14 * 70), (61440000, 122, 122 * 150), (61440000, 122, 1024068),
-                                        (33000000, 66, 66 * 150), (47000000, 94, 94 * 97), (63000000, 126, 126 * 131), (31000000, 62, 62 * 140)])
+                                        (37000000, 74, 74 * 150), (47000000, 94, 94 * 97), (59000000, 118, 118 * 131), (31000000, 62, 62 * 140)])
 def test_channelizer_m_twice_odd(ctx, fs, M, block):
-    """M = 2 A with A odd (10, 14, 122 = the 61.44 MS/s channel count, SoapySDRThread.cpp:676-693) runs the one-lane-per-frame
-    kernel (chan_analyze_p2): whole and ragged 64-frame tiles.  A >= 33 (M = 66: one output in the second row tile, 94, 122, 126: all 32 outputs
-    and all 32 terms in use) is the matrix-pipe form of its transform phase, M = 62 the largest count of the vector form."""
+    """M = 2 A with A an odd prime (10, 14, 122 = the 61.44 MS/s channel count, SoapySDRThread.cpp:676-693) runs the one-lane-per-frame
+    kernel (chan_analyze_p2): whole and ragged 64-frame tiles.  A >= 33 (M = 74: three outputs in the second row tile, 94, 118, 122: 31 of the 32
+    outputs and terms in use) is the matrix-pipe form of its transform phase, M = 62 the largest count of the vector form."""
+    from cubicsdr_amd.engine import SDRPost
+    probe = SDRPost(ctx, fs, M, block)
+    assert probe.kernel_name == "chan_analyze_p2", probe.kernel_name
+    probe.close()
     _channelizer_case(ctx, fs, M, block)
 
 
@@ -176,10 +184,10 @@ def test_every_even_channel_count_up_to_400_takes_a_fast_kernel(ctx):
     assert not slow, slow
 
 
-@pytest.mark.parametrize("fs,M,block", [(2400000, 4, 40000), (61440000, 122, 122 * 70), (61440000, 122, 122 * 3), (63000000, 126, 126 * 129)])
+@pytest.mark.parametrize("fs,M,block", [(2400000, 4, 40000), (61440000, 122, 122 * 70), (61440000, 122, 122 * 3), (59000000, 118, 118 * 129)])
 def test_channelizer_batched_equals_blockwise(ctx, fs, M, block):
     """one call over four blocks = four calls over one block each, bit for bit: the carried history, tiles that end inside a block (M = 122 / 126: the
-    matrix-pipe form of chan_analyze_p2, 64-frame tiles over 70-, 3- and 129-frame blocks -- a block shorter than the FIR's reach included)"""
+    matrix-pipe form of chan_analyze_p2 at M = 122 / 118, 64-frame tiles over 70-, 3- and 129-frame blocks -- a block shorter than the FIR's reach included)"""
     from cubicsdr_amd.engine import SDRPost
     center = 100000000
     x = synth_iq(4 * block, fs, center, [("NBFM", center + 200000)], seed=5)
