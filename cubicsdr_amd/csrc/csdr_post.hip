@@ -53,6 +53,9 @@ extern "C" void csdr_post_destroy(csdr_post *p) {
     delete p;
 }
 
+#ifndef CSDR_P2_MX_MIN_A
+#define CSDR_P2_MX_MIN_A 11           // critically sampled bank: the smallest A whose transforms go to the matrix pipe (M = 22 ... 62: 1.03 - 1.25 x the vector form, which keeps M = 6 / 10 / 14: profiles/r06_mx_channelizer.txt)
+#endif
 #ifndef CSDR_P2_OS2_MIN_A
 #define CSDR_P2_OS2_MIN_A 19          // firpfbch2 with M / 2 odd: the smallest A = M / 2 that takes chan_analyze_p2 (M >= 38: 1.2 - 2.5 x the two-factor kernel, which wins below: profiles/r06_chan2_p2.txt)
 #endif
@@ -92,8 +95,8 @@ static int chan_geometry(int M, int hop, ChanGeom &g) {
         g.nkA = (slots + g.KA - 1) / g.KA;
         g.PA = g.nkA * g.KA;
         g.TF = kP2Frames; g.lgTF = 6; g.S = M; g.taps_lds = 0; g.stage_in = 1; g.threads = kP2Threads;
-        // the A-point transforms on the fp32 matrix pipe where they fill two row tiles of sixteen outputs (A >= 33: M = 66 ... 126)
-        g.mx = (hop != M || (g.A >= 33 && lab_int("CSDR_CHAN_MX", CSDR_CHAN_MX_DEFAULT) != 0)) ? 1 : 0;
+        // the A-point transforms on the fp32 matrix pipe (A >= 11; below 33 one row tile of sixteen outputs: half of the waves sit the phase out)
+        g.mx = (hop != M || (g.A >= CSDR_P2_MX_MIN_A && lab_int("CSDR_CHAN_MX", CSDR_CHAN_MX_DEFAULT) != 0)) ? 1 : 0;
         return CSDR_OK;
     }
     g.taps_lds = (M <= 512) ? 1 : 0;
@@ -125,10 +128,14 @@ static chan_p2_kernel_t chan_p2_kernel(const ChanGeom &g) {
 #define CSDR_P2_CASE(K_) case K_: return chan_analyze_p2<K_>
     // (A <= 63: at most 32 slots over eight waves = at most four per pass; wider passes were instances nothing ever launched -- one of them spilled)
     if (g.mx) return g.hop != g.M ? chan_analyze_p2<4, true, true> : chan_analyze_p2<4, true>;
+#if CSDR_CHAN_MX_DEFAULT == 0 || defined(CSDR_LAB)      // (A/B builds: the vector form for every A)
     switch (g.KA) {
         CSDR_P2_CASE(1); CSDR_P2_CASE(2); CSDR_P2_CASE(3);
         default: return chan_analyze_p2<4>;
     }
+#else
+    return chan_analyze_p2<1>;                          // A <= 9: at most five slots over eight waves
+#endif
 #undef CSDR_P2_CASE
 }
 typedef void (*chanfft_kernel_t)(const float2 *, const float2 *, float2 *, const float *, const float2 *, const int *, const int *, ChanFftGeom, int64_t,

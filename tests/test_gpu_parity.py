@@ -138,11 +138,12 @@ def _channelizer_case(ctx, fs, M, block, chans=None, nblocks=3):
 
 
 @pytest.mark.parametrize("fs,M,block", [(5000000, 10, 83340), (7000000, 14, 14 * 70), (61440000, 122, 122 * 150), (61440000, 122, 1024068),
-                                        (37000000, 74, 74 * 150), (47000000, 94, 94 * 97), (59000000, 118, 118 * 131), (31000000, 62, 62 * 140)])
+                                        (37000000, 74, 74 * 150), (47000000, 94, 94 * 97), (59000000, 118, 118 * 131), (31000000, 62, 62 * 140), (11000000, 22, 22 * 300)])
 def test_channelizer_m_twice_odd(ctx, fs, M, block):
     """M = 2 A with A an odd prime (10, 14, 122 = the 61.44 MS/s channel count, SoapySDRThread.cpp:676-693) runs the one-lane-per-frame
-    kernel (chan_analyze_p2): whole and ragged 64-frame tiles.  A >= 33 (M = 74: three outputs in the second row tile, 94, 118, 122: 31 of the 32
-    outputs and terms in use) is the matrix-pipe form of its transform phase, M = 62 the largest count of the vector form."""
+    kernel (chan_analyze_p2): whole and ragged 64-frame tiles.  From A = 11 (M = 22) on its transform phase runs on the matrix pipe: one row tile of
+    outputs up to M = 62, two from M = 74 (three outputs in the second tile; 94, 118, 122: 31 of the 32 outputs and terms in use); M = 10 / 14 are the
+    vector form."""
     from cubicsdr_amd.engine import SDRPost
     probe = SDRPost(ctx, fs, M, block)
     assert probe.kernel_name == "chan_analyze_p2", probe.kernel_name
