@@ -174,7 +174,9 @@ def measured_traffic(cfg_name):
                 base = "demod_frontend_s" + name.split("<")[1].split(",")[0].strip()          # demod_frontend_s<6, 2048, true> -> demod_frontend_s6
             if base == "demod_frontend_s56" or name.startswith("demod_frontend_s56"):
                 base = "demod_frontend_s56"
-            base = {"demod_frontend": "demod_frontend_generic", "spec_fft_rows4096": "spec_fft_rows", "chan_analyze_p2": "chan_analyze", "chan_analyze_fft": "chan_analyze"}.get(base, base)
+            # (profile ids of the library, common.hpp CsdrKernelId: the fused spectrum chain's kernels run under the ids of the stages they replace)
+            base = {"demod_frontend": "demod_frontend_generic", "spec_fft_rows4096": "spec_fft_rows", "chan_analyze_p2": "chan_analyze", "chan_analyze_fft": "chan_analyze",
+                    "spec_cols512p": "spec_fft_radix", "spec_rows256_ema": "spec_average", "spec_display_p256": "spec_display"}.get(base, base)
             out[base] = out.get(base, 0.0) + (2.0 * v["FETCH_SIZE_KiB_avg_per_launch"] + v["WRITE_SIZE_KiB_avg_per_launch"]) * 1024.0 / blocks
     return out, os.path.relpath(files[-1], ROOT)
 
