@@ -843,8 +843,8 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
             //        P[k][t] = sum_n Cos[k][n] s_n[t]      Q[k][t] = sum_n Sin[k][n] d_n[t]        k, n = 0 .. H   (s_0 = x_0, Cos[k][0] = 1, Sin[k][0] = 0)
             //      for the four components (c2 = 0 / 1) x (re / im) of s and d: eight products, tiled 16 (k) x 16 (t) x 4 (n) on v_mfma_f32_16x16x4_f32.
             //      Wave = (row tile rt = wave >> 2: k = 16 rt .. 16 rt + 15, column tile ct = wave & 3: frames 16 ct .. 16 ct + 15); lane (q = lane >> 4,
-            //      j = lane & 15) feeds term n = 4 J + q of frame t = 16 ct + j in step J -- the two ds_read_b128 of rows n (s_n, left there by the FIR phase)
-            //      and A - n (d_n) are the B operands of all eight products -- and receives outputs k = 16 rt + 4 q + r (r = 0..3) of that frame for all
+            //      j = lane & 15) feeds term n = 4 J + q of frame t = 16 ct + j in step J -- the two ds_read_b128 of rows n and A - n (x_n, x_{A-n}: their sum and
+            //      difference) are the B operands of all eight products -- and receives outputs k = 16 rt + 4 q + r (r = 0..3) of that frame for all
             //      eight, so the radix-2 butterfly and the stores stay in-lane.  An MFMA is a k-ordered fmaf chain: the accumulation order (n ascending,
             //      starting from x_0) is the vector form's, and so are the results, bit for bit.  64 MFMAs (2048 matrix-pipe cycles) per wave and tile
             //      in place of 465 packed multiply-adds on the vector pipe, 16 LDS reads in place of 61 per pass.
@@ -862,19 +862,19 @@ CSDR_KERNEL __launch_bounds__(kP2Threads, 4) void chan_analyze_p2(
             float4 a = row_s(q), b = q ? row_d(q) : make_float4(0.f, 0.f, 0.f, 0.f);      // step 0: n = q
             if (rt_live) {
 #pragma unroll
-            for (int J = 0; J < kMxSteps; ++J) {
-                if (J < KS) {
-                    float4 a2 = a, b2 = b;
-                    if (J + 1 < kMxSteps) { const int n2 = 4 * (J + 1) + q; a2 = row_s(n2); b2 = row_d(n2); }      // the next step's rows are requested ahead of this step's products
-                    const float4 sv = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-                    const float4 dv = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
-                    P0r = csdr_mfma16(mxc[J], sv.x, P0r); P0i = csdr_mfma16(mxc[J], sv.y, P0i);
-                    P1r = csdr_mfma16(mxc[J], sv.z, P1r); P1i = csdr_mfma16(mxc[J], sv.w, P1i);
-                    Q0r = csdr_mfma16(mxs[J], dv.x, Q0r); Q0i = csdr_mfma16(mxs[J], dv.y, Q0i);
-                    Q1r = csdr_mfma16(mxs[J], dv.z, Q1r); Q1i = csdr_mfma16(mxs[J], dv.w, Q1i);
-                    a = a2; b = b2;
+                for (int J = 0; J < kMxSteps; ++J) {
+                    if (J < KS) {
+                        float4 a2 = a, b2 = b;
+                        if (J + 1 < kMxSteps) { const int n2 = 4 * (J + 1) + q; a2 = row_s(n2); b2 = row_d(n2); }      // the next step's rows are requested ahead of this step's products
+                        const float4 sv = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+                        const float4 dv = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+                        P0r = csdr_mfma16(mxc[J], sv.x, P0r); P0i = csdr_mfma16(mxc[J], sv.y, P0i);
+                        P1r = csdr_mfma16(mxc[J], sv.z, P1r); P1i = csdr_mfma16(mxc[J], sv.w, P1i);
+                        Q0r = csdr_mfma16(mxs[J], dv.x, Q0r); Q0i = csdr_mfma16(mxs[J], dv.y, Q0i);
+                        Q1r = csdr_mfma16(mxs[J], dv.z, Q1r); Q1i = csdr_mfma16(mxs[J], dv.w, Q1i);
+                        a = a2; b = b2;
+                    }
                 }
-            }
             }
             // each accumulator holds four outputs k of one frame: a store instruction of the wave covers four channel rows, 128 contiguous bytes of each
             float2 *ob = out + f0 + t;
