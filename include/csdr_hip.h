@@ -121,7 +121,7 @@ int  csdr_post_set_active_channels(csdr_post *post, const int *channels, int n);
 int64_t csdr_post_channel_bandwidth(const csdr_post *post);                  /* chanBw (:408) */
 int64_t csdr_post_channel_rate(const csdr_post *post);                       /* sampleRate stamped on the channel data (:344): chanBw, 2*chanBw for PFBCH2 */
 int     csdr_post_num_channels(const csdr_post *post);
-const char *csdr_post_kernel_name(const csdr_post *post);                    /* diagnostic: the kernel runPFBCH's transform (:449-451) maps to for this channel count: "dc_blocker" (single channel), "chan_analyze_p2" (M = 2 * odd), "chan_analyze_fft" (small factors), "chan_analyze" (any other even M, firpfbch2) */
+const char *csdr_post_kernel_name(const csdr_post *post);                    /* diagnostic: the kernel runPFBCH's transform (:449-451) maps to for this channel count: "dc_blocker" (single channel), "chan_analyze_p2" (M = 2 * prime <= 122; firpfbch2 with M / 2 odd, 38 <= M <= 126), "chan_analyze_fft" (small factors, one prime factor 29 .. 509; firpfbch2 with M % 4 == 0), "chan_analyze" (any other even M) */
 int64_t csdr_post_channel_center(const csdr_post *post, int i);              /* chanCenters[i], i in [0, M] (:116-124) */
 int     csdr_post_channel_at(const csdr_post *post, int64_t frequency);      /* getChannelAt (:128-139) */
 /* copy one channel's samples of the last execute to the host (tests / demod-visual tap); ch == M is the wrap
