@@ -215,7 +215,8 @@ extern "C" int csdr_spec_setup(csdr_spec *s, int fft_size, int max_frames) {
     s->fused_ok = N == kS3N && !npot && lab_int("CSDR_SPEC_FUSED", 1) != 0;
     if (s->fused_ok) {
         CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_cols512p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kP1Lds));
-        CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_rows256_ema, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kR2Lds));
+        CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_rows256_ema<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kR2Lds));
+        CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_rows256_ema<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kR2Lds));
     }
     if (g.Ra > 1 && disp_lds_bytes((g.Ra >> 1) * g.Rb, ilog2(g.Ra) - 1 + ilog2(g.Rb), true) > 64 * 1024)      // the display tiles of 2^21-point frames with peak hold
         CSDR_HIP_TRY(hipFuncSetAttribute((const void *)spec_display<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)disp_lds_bytes((g.Ra >> 1) * g.Rb, ilog2(g.Ra) - 1 + ilog2(g.Rb), true)));
@@ -355,28 +356,40 @@ static int spec_post_range(csdr_spec *s, const float *mag, int f0, int cnt, int 
     const bool hold = pk_from < cnt, view = s->view_frame;
     const bool bins = hold || view;                                  // per-bin averaged values are kept (maaf)
     if (s->fused_now) {
-        if (hold || view) return fail(CSDR_ESTATE, "internal: the fused spectrum pass was chosen for a batch that holds peaks");
+        if (view) return fail(CSDR_ESTATE, "internal: the fused spectrum pass was chosen for a zoomed view");
         const int npairs = kS3C / 2;
-        CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_rows256_ema, dim3(npairs), dim3(kR2Threads), kR2Lds, s->tmp.p + (size_t)f0 * g.N, cnt, g, (double)s->avg_rate, s->tw4096.p,
-                    s->ma.p, s->maa.p, s->pairsum.p + f0 * F, s->first_b.p + f0, s->ext_w.p + (size_t)f0 * npairs);
+        // (peak hold live in this range -- frames >= pk_from hold: the row pass keeps the held maxima of its bins, round 6; else the plain instance)
+        if (hold)
+            CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_rows256_ema<true>, dim3(npairs), dim3(kR2Threads), kR2Lds, s->tmp.p + (size_t)f0 * g.N, cnt, g, (double)s->avg_rate, s->tw4096.p,
+                        s->ma.p, s->maa.p, s->pairsum.p + f0 * F, s->first_b.p + f0, s->ext_w.p + (size_t)f0 * npairs, s->peak.p, s->peaksum.p + f0 * F, s->peak_b.p + f0, pk_from);
+        else
+            CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_AVG, spec_rows256_ema<false>, dim3(npairs), dim3(kR2Threads), kR2Lds, s->tmp.p + (size_t)f0 * g.N, cnt, g, (double)s->avg_rate, s->tw4096.p,
+                        s->ma.p, s->maa.p, s->pairsum.p + f0 * F, s->first_b.p + f0, s->ext_w.p + (size_t)f0 * npairs, (double *)nullptr, (float *)nullptr, (float *)nullptr, cnt);
         const SpecScalars *st_in = s->scal.p + s->scal_parity;
-        if (f0 == 0 && cnt <= kTrackSmallFrames) {
+        if (!hold && f0 == 0 && cnt <= kTrackSmallFrames) {
             // a short batch (the one-block call: 7 or 8 frames): extrema and trackers in one launch
             CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_trackers, dim3(cnt), dim3(kDispThreads), kTrackLds + (size_t)cnt * sizeof(float2), s->ext.p, cnt, st_in,
                         s->scal.p + (s->scal_parity ^ 1), s->fo.p, s->fsc.p, cnt, (const SpecFrameOut *)nullptr, s->ext_w.p, npairs, s->ext.p);
         } else {
             CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_extrema, dim3(cnt), dim3(256), (size_t)(256 / 64) * sizeof(float2), s->ext_w.p + (size_t)f0 * npairs, npairs, s->ext.p + f0);
+            if (hold) CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_MISC, spec_peak_trackers, dim3(1), dim3(64), 0, s->ext.p + f0, cnt, pk_from, st_in, s->pk.p, s->pfo.p + f0);
             CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_TRACK, spec_trackers, dim3(cnt), dim3(kDispThreads), kTrackLds, s->ext.p + f0, cnt, st_in, s->scal.p + (s->scal_parity ^ 1),
-                        s->fo.p + f0, s->fsc.p + f0, cnt, (const SpecFrameOut *)nullptr, (const float2 *)nullptr, 0, (float2 *)nullptr);
+                        s->fo.p + f0, s->fsc.p + f0, hold ? pk_from : cnt, hold ? s->pfo.p + f0 : (const SpecFrameOut *)nullptr, (const float2 *)nullptr, 0, (float2 *)nullptr);
         }
         // (the carry of a contiguous stream rides on the display launch: csdr_spec_process sets carry_src for a batch whose range starts at frame 0)
-        const bool carry_here = f0 == 0 && s->carry_fold_n > 0 && cnt <= kTrackSmallFrames;      // (a long batch keeps its own transfer: the copy inside the launch cost it 16 us)
-        if (carry_here)
+        const bool carry_here = !hold && f0 == 0 && s->carry_fold_n > 0 && cnt <= kTrackSmallFrames;      // (a long batch keeps its own transfer: the copy inside the launch cost it 16 us)
+        if (hold)
+            CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_DISPLAY, (spec_display_p256<false, true>), dim3(64, cnt), dim3(kDispThreads), 32 * 33 * sizeof(float),
+                        s->pairsum.p + f0 * F, s->first_b.p + f0, s->fsc.p + f0, g, s->scale, s->points.p + f0 * F, (const float2 *)nullptr, (float2 *)nullptr, 0,
+                        s->peaksum.p + f0 * F, s->peak_b.p + f0, s->hold_points.p + f0 * F, pk_from);
+        else if (carry_here)
             CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_DISPLAY, spec_display_p256<true>, dim3(64, cnt), dim3(kDispThreads), 32 * 33 * sizeof(float),
-                        s->pairsum.p + f0 * F, s->first_b.p + f0, s->fsc.p + f0, g, s->scale, s->points.p + f0 * F, s->carry_fold_src, s->carry.p, s->carry_fold_n);
+                        s->pairsum.p + f0 * F, s->first_b.p + f0, s->fsc.p + f0, g, s->scale, s->points.p + f0 * F, s->carry_fold_src, s->carry.p, s->carry_fold_n,
+                        (const float *)nullptr, (const float *)nullptr, (float *)nullptr, 0);
         else
             CSDR_LAUNCH(c, LANE_AVG, KID_SPEC_DISPLAY, spec_display_p256<false>, dim3(64, cnt), dim3(kDispThreads), 32 * 33 * sizeof(float),
-                        s->pairsum.p + f0 * F, s->first_b.p + f0, s->fsc.p + f0, g, s->scale, s->points.p + f0 * F, (const float2 *)nullptr, (float2 *)nullptr, 0);
+                        s->pairsum.p + f0 * F, s->first_b.p + f0, s->fsc.p + f0, g, s->scale, s->points.p + f0 * F, (const float2 *)nullptr, (float2 *)nullptr, 0,
+                        (const float *)nullptr, (const float *)nullptr, (float *)nullptr, 0);
         if (carry_here) s->carry_fold_n = -1;                        // done
         s->scal_parity ^= 1;
         CSDR_HIP_TRY(hipGetLastError());
@@ -441,7 +454,7 @@ static int spec_post_frames(csdr_spec *s, const float *mag, int nf, int n_inputs
         if (int rc = s->peak.reserve(2 * F)) return rc;
         if (int rc = s->pk.reserve(1)) return rc;
         if (s->peak_hold) {
-            if (int rc = s->maaf.reserve(nfF)) return rc;
+            if (!s->fused_now) if (int rc = s->maaf.reserve(nfF)) return rc;      // (the fused chain keeps the held maxima in its row pass: no per-bin copy)
             if (int rc = s->peaksum.reserve(nfF)) return rc;
             if (int rc = s->peak_b.reserve(s->max_frames)) return rc;
             if (int rc = s->hold_points.reserve(nfF)) return rc;
@@ -696,8 +709,9 @@ extern "C" int csdr_spec_process(csdr_spec *s, const float *iq, int iq_is_dev, i
     hipStream_t st = c->lanes[LANE_FFT];
     const SpecGeom &g = s->g;
     const int N = g.N;
-    // full-span view, no peak hold set or pending: the 512 x 256 chain with the averaging fused into its row pass
-    s->fused_now = s->fused_ok && !s->peak_hold && s->peak_reset == 0;
+    // full-span view: the 512 x 256 chain with the averaging fused into its row pass (since round 6 with peak hold too: CSDR_SPEC_FUSED_HOLD=0 is the
+    // earlier rule -- a batch with peak hold set or pending on the three-kernel chain)
+    s->fused_now = s->fused_ok && ((!s->peak_hold && s->peak_reset == 0) || lab_int("CSDR_SPEC_FUSED_HOLD", 1) != 0);
     const int64_t n = (int64_t)n_blocks * block_len;
     const float2 *x = (const float2 *)iq;
     if (int rc = c->lane_begin(LANE_FFT)) return rc;

@@ -1,5 +1,5 @@
-// kernels_spec3.hpp -- the spectrum chain of the headline size N = 2^17 = 512 x 256 (BASELINE config 3: fftSize 65536), full-span view without
-// peak hold: TWO transform passes with the magnitudes and the double averaging fused into the second one.
+// kernels_spec3.hpp -- the spectrum chain of the headline size N = 2^17 = 512 x 256 (BASELINE config 3: fftSize 65536), full-span view (with or
+// without peak hold): TWO transform passes with the magnitudes and the double averaging fused into the second one.
 //
 // Replaces (reference file:line): fft_execute SpectrumVisualProcessor.cpp:439 (liquid's radix-2 plan, :177), magnitude + fftshift :441-452, the
 // double EMA and the running extrema :494-511; the display loop :532-576 for the order the second pass leaves its pair sums in.
@@ -130,9 +130,14 @@ constexpr size_t kR2Lds = kR2LdsXchg + kR2LdsMag + kR2LdsExt + kR2LdsPart;
 // Z: [frames][512][256] (pass 1).  pairsum[f][pair][k2] (float), ext_w[f][pair] = (max, min) of the float-rounded averaged bins of the row pair,
 // first_b[f] = the averaged second bin of display point 0.  ma / maa: the averagers, at spec_state_index(g, x) of the geometry `g` the three-kernel
 // chain uses for this size (the two chains trade places when peak hold or the zoomed view is switched: one state layout).
+// HOLD (peak hold live, SpectrumVisualProcessor.cpp:247-273, :506-510): the frames >= pk_from also raise the held maximum of their two bins (the running
+// maximum of the float-rounded averaged values, spec_peak_track's statements) -- peak[x] / peak[F + x] by display point -- and leave peaksum[f][pair][k2] in
+// the pair-sum's order, peak_b[f] = the held second bin of display point 0.
+template <bool HOLD>
 CSDR_KERNEL __launch_bounds__(kR2Threads) void spec_rows256_ema(const float2 *__restrict__ Z, int nf, SpecGeom g, double rate, const float2 *__restrict__ tw4096,
                                                                double *__restrict__ ma, double *__restrict__ maa, float *__restrict__ pairsum,
-                                                               float *__restrict__ first_b, float2 *__restrict__ ext_w) {
+                                                               float *__restrict__ first_b, float2 *__restrict__ ext_w,
+                                                               double *__restrict__ peak, float *__restrict__ peaksum, float *__restrict__ peak_b, int pk_from) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6);
     cpx *s_xch = reinterpret_cast<cpx *>(smem);
@@ -190,6 +195,8 @@ CSDR_KERNEL __launch_bounds__(kR2Threads) void spec_rows256_ema(const float2 *__
     const int x = (int)(((ka - kS3N / 2) & (kS3N - 1)) >> 1);
     const int64_t si = spec_state_index(g, x);
     AvgState s = {ma[si], maa[si], ma[F + si], maa[F + si]};
+    double pka = 0.0, pkb = 0.0;
+    if constexpr (HOLD) { pka = peak[x]; pkb = peak[F + x]; }
     float *ex = s_ex + (size_t)w * 2 * kR2ExtFrames * 64;
     auto publish = [&](int r) {                                    // the per-frame extrema of round r, left in LDS one barrier ago
         const int nfr = min(kR2Round, nf - r * kR2Round);
@@ -213,11 +220,13 @@ CSDR_KERNEL __launch_bounds__(kR2Threads) void spec_rows256_ema(const float2 *__
             for (int i = 0; i < kR2Round; ++i) { xa[i] = mg[(2 * i) * kR2MagPitch]; xb[i] = mg[(2 * i + 1) * kR2MagPitch]; }
             const AvgState s_in = s;
             float ps[kR2Round], mxs[kR2Round], mns[kR2Round], fbv[kR2Round];
+            float fav[HOLD ? kR2Round : 1];                                                // HOLD: the first bin's rounded value too (the second is fbv)
 #pragma unroll
             for (int i = 0; i < kR2Round; ++i) {
                 if (i < nfr) avg_step_fast(s, (double)xa[i], (double)xb[i], rate);        // (block-uniform guard)
                 const float fa = (float)s.maa_a, fbb = (float)s.maa_b;                     // float rounding is monotonic: extrema of the rounded values
                 ps[i] = (float)(s.maa_a + s.maa_b); fbv[i] = fbb;
+                if constexpr (HOLD) fav[i] = fa;
                 mxs[i] = fmaxf(fa, fbb); mns[i] = fminf(fa, fbb);
             }
             // A magnitude that is not finite (a NaN / Inf IQ sample), or a NaN state entering the round, leaves a state that is not finite at the
@@ -231,7 +240,21 @@ CSDR_KERNEL __launch_bounds__(kR2Threads) void spec_rows256_ema(const float2 *__
                     if (i < nfr) avg_step(s, (double)xa[i], (double)xb[i], rate);
                     const float fa = (float)s.maa_a, fbb = (float)s.maa_b;
                     ps[i] = (float)(s.maa_a + s.maa_b); fbv[i] = fbb;
+                    if constexpr (HOLD) fav[i] = fa;
                     mxs[i] = fmaxf(fa, fbb); mns[i] = fminf(fa, fbb);                       // (fmaxf / fminf skip a NaN operand, as the reference's comparisons do)
+                }
+            }
+            if constexpr (HOLD) {
+                // the held maxima, frame after frame (spec_peak_track: a NaN never replaces a held value -- the comparison is false)
+#pragma unroll
+                for (int i = 0; i < kR2Round; ++i) {
+                    const int f = fb + i;
+                    if (i < nfr && f >= pk_from) {
+                        if ((double)fav[i] > pka) pka = (double)fav[i];
+                        if ((double)fbv[i] > pkb) pkb = (double)fbv[i];
+                        stf(peaksum + (int64_t)f * F, (unsigned)(pair * kS3R + tid) * 4u, (float)(pka + pkb));
+                        if (x == 0) peak_b[f] = (float)pkb;
+                    }
                 }
             }
 #pragma unroll
@@ -262,16 +285,20 @@ CSDR_KERNEL __launch_bounds__(kR2Threads) void spec_rows256_ema(const float2 *__
     }
     publish(nrounds - 1);
     ma[si] = s.ma_a; maa[si] = s.maa_a; ma[F + si] = s.ma_b; maa[F + si] = s.maa_b;
+    if constexpr (HOLD) { peak[x] = pka; peak[F + x] = pkb; }
 }
 
 // ---- K16 for the pair-row order of spec_rows256_ema: pairsum[f][pair][k2], display point x = (pair + 256 k2 - N / 4) mod F.
 // grid = (8 x 8 tiles of 32 pairs x 32 k2, frames); reads 32 runs of 128 bytes, writes 32 runs of 128 bytes.
 // (carry_n > 0: the workgroups of frame 0 also move the samples behind the batch's last whole frame to the carry buffer -- the last launch of a call's chain
 //  takes the copy that was a 4 us transfer of its own; nothing of this launch reads either buffer)
-template <bool CARRY /* the short-batch instance that takes the carry copy along */>
+// HOLD: frames >= pk_from also form spectrum_hold_points from the held sums, with the frame's own scalars (:539-556)
+template <bool CARRY /* the short-batch instance that takes the carry copy along */, bool HOLD = false>
 CSDR_KERNEL __launch_bounds__(kDispThreads) void spec_display_p256(const float *__restrict__ pairsum, const float *__restrict__ first_b,
                                                                   const SpecFrameScal *__restrict__ fsc, SpecGeom g, float sf, float *__restrict__ points,
-                                                                  const float2 *__restrict__ carry_src, float2 *__restrict__ carry_dst, int carry_n) {
+                                                                  const float2 *__restrict__ carry_src, float2 *__restrict__ carry_dst, int carry_n,
+                                                                  const float *__restrict__ peaksum = nullptr, const float *__restrict__ peak_b = nullptr,
+                                                                  float *__restrict__ hold_points = nullptr, int pk_from = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if constexpr (CARRY) if (carry_n > 0 && blockIdx.y == 0)
         for (int i = (int)(blockIdx.x * kDispThreads + threadIdx.x); i < carry_n; i += (int)(gridDim.x * kDispThreads)) carry_dst[i] = carry_src[i];
@@ -301,6 +328,29 @@ CSDR_KERNEL __launch_bounds__(kDispThreads) void spec_display_p256(const float *
         const int j = (tid >> 5) + 8 * u, i = tid & 31;              // 32 consecutive display points per k2
         const int x = (p0 + i + npairs * (t0 + j) - (int)(g.N >> 2)) & (F - 1);
         st_stream(points + (int64_t)f * F + x, s_y[j * 33 + i]);
+    }
+    if constexpr (HOLD) {
+        if (f < pk_from) return;                                     // (block-uniform)
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = (tid >> 5) + 8 * u, j = tid & 31;
+            a[u] = peaksum[(int64_t)f * F + (int64_t)(p0 + i) * kS3R + t0 + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = (tid >> 5) + 8 * u, j = tid & 31;
+            const int x = (p0 + i + npairs * (t0 + j) - (int)(g.N >> 2)) & (F - 1);
+            const double pacc = (x == 0) ? fl + (double)peak_b[f] : (double)a[u];
+            s_y[j * 33 + i] = log1p_fast((float)(pacc * 0.5 - pf)) * inv_den * sf;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = (tid >> 5) + 8 * u, i = tid & 31;
+            const int x = (p0 + i + npairs * (t0 + j) - (int)(g.N >> 2)) & (F - 1);
+            st_stream(hold_points + (int64_t)f * F + x, s_y[j * 33 + i]);
+        }
     }
 }
 

@@ -1037,8 +1037,8 @@ def test_spectrum_chain_switch_on_five_streams_without_host_waits():
 def test_spectrum_headline_small_calls_and_chain_switch(ctx):
     """the fused two-pass chain of the headline size (N = 2^17) in the real-time shape: ONE 1/60 s block per call (7 or 8 frames: partial
     rounds of the row pass, one frame group per column workgroup, a partial frame carried from call to call) produces exactly the frames ONE
-    batch over the same samples does; and switching peak hold on moves the stream onto the three-kernel chain and back with the averagers
-    where they were (one state layout for both chains): every frame against the reference's class."""
+    batch over the same samples does; and peak hold switched on and off in the stream (since round 6 inside the fused chain: the row pass keeps the held
+    maxima, the reset falls inside a call): every frame and every held line against the reference's class."""
     from cubicsdr_amd.engine import SpectrumProcessor
     F, fs, block = 65536, 61440000, 1024068
     nb = 5
@@ -1059,7 +1059,7 @@ def test_spectrum_headline_small_calls_and_chain_switch(ctx):
         assert rel_err(got[k][0], want[k][0]) < 1e-6, k
         assert abs(got[k][1] - want[k][1]) <= 1e-12 * abs(want[k][1]) and abs(got[k][2] - want[k][2]) <= 1e-12 * max(abs(want[k][2]), 1e-30), k
     one.close(); calls.close()
-    # chain switch: 2 blocks fused, 2 blocks with peak hold (the three-kernel chain), 1 block fused again
+    # 2 blocks plain, 2 blocks with peak hold, 1 block plain again
     import oracle.ref_modems as RM
     if not (_backend() == "ref" and RM.spectrum_available()):
         return                                   # (the chain switch is checked against the reference's own class only)
@@ -1067,7 +1067,7 @@ def test_spectrum_headline_small_calls_and_chain_switch(ctx):
     cpp.set_center(0); cpp.set_bandwidth(fs)
     label = "reference class"
     sp = SpectrumProcessor(ctx, F, max_frames=10)
-    worst, k = 0.0, 0
+    worst, k, worst_hold, held = 0.0, 0, 0.0, 0
     for b in range(nb):
         if b == 2:
             sp.set_peak_hold(True); cpp.set_peak_hold(True)
@@ -1076,12 +1076,16 @@ def test_spectrum_headline_small_calls_and_chain_switch(ctx):
         n = sp.process(x[b * block:(b + 1) * block], 1, block, contiguous=True)
         for i in range(n):
             pts, ce, fl = sp.fetch(i)
-            wp, wce, wfl, _ = cpp.process(x[k * 2 * F:(k + 1) * 2 * F], 0, fs)
+            hold = sp.fetch_hold(i)
+            wp, wce, wfl, whold = cpp.process(x[k * 2 * F:(k + 1) * 2 * F], 0, fs)
             worst = max(worst, rel_err(pts, wp))
             assert abs(ce - wce) <= TOL * abs(wce) and abs(fl - wfl) <= TOL * abs(wce), (b, i)       # (both on the ceiling's scale, as in _spectrum_contiguous_batches)
+            assert (hold is None) == (whold is None), (b, i)
+            if hold is not None:
+                worst_hold = max(worst_hold, rel_err(hold, whold)); held += 1
             k += 1
-    print("headline spectrum across chain switches (%s): %d frames, worst points %.3g" % (label, k, worst))
-    assert worst < TOL
+    print("headline spectrum across peak-hold switches (%s): %d frames, worst points %.3g, %d held lines, worst %.3g" % (label, k, worst, held, worst_hold))
+    assert worst < TOL and worst_hold < TOL and held >= 10
     sp.close(); cpp.close()
     # another averaging rate and scale factor through the fused chain (setFFTAverageRate / setScaleFactor)
     cpp = RM.RefSpectrumCpp(F, fs)
