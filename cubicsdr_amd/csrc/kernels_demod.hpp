@@ -465,6 +465,10 @@ constexpr int kFeTabLen = 1024 + 256;
 #ifndef CSDR_FE_PRIO_TAIL
 #define CSDR_FE_PRIO_TAIL 2
 #endif
+#ifndef CSDR_FE_SCHED3
+#define CSDR_FE_SCHED3 1
+#endif
+constexpr bool kFeSched3 = CSDR_FE_SCHED3 != 0;      // tail-wave instances: three barrier intervals per chunk (A/B builds: -DCSDR_FE_SCHED3=0 is the four-interval schedule)
 constexpr int kFePrioStage = CSDR_FE_PRIO_STAGE, kFePrioTail = CSDR_FE_PRIO_TAIL;      // (A/B builds: both 0 is the round-5 kernel)
 // Where entry i of the oscillator table sits in LDS: row i >> 5 keeps its 32 words, its columns are rotated by rot * row.  The table reads of a wave are
 // an arithmetic progression of the demodulator's phase increment over 32 banks: in the plain order thirty-two lanes meet 3.6 times per bank on average
@@ -738,6 +742,104 @@ __device__ __forceinline__ void fes_body(
             fe_fetch_chunk<NPF>(pf, chan, hist, hist_len, rel0 + 2 * tid, total, inside);
         }
         __syncthreads();
+        if constexpr (kFeSched3) {
+            // THREE barrier intervals per chunk (round 6, third session): the next chunk's mix rides in the interval of the last block-wide stage (the stage-0
+            // arrays are free once stage 0 has read them and their tail has moved), the carry of that stage's input tail in stage 0's interval:
+            //   workers      | B1 | stage 0 (k) + carry E(BLK-1) | Ba | stage 1 (k) + carry E0 | Bb | stage 2 (k) + carry E1, mix (k + 1), loads (k + 2) |
+            //   tail wave    | B1 | stage BLK of chunk k - 1     | Ba | next piece             | Bb | last stage -> Z, resampler                        |
+            // The tail's input region is written in the last interval of chunk k - 1 and read in the first of chunk k; a closing barrier after the last chunk
+            // stands for the B1 of a chunk that does not come.
+            static_assert(BLK == 3, "the three-interval schedule is written for three block-wide stages");
+            if (!tailw) {
+                {
+                    const int64_t rel0 = u_lo - (int64_t)dyn.buf0;
+                    fes_mix_chunk<S, CH, NPF>(pf, rel0, dyn, sgn, tab, LE, LO, tid);
+                    if (1 < nch) {
+                        const int64_t reln = rel0 + CH;
+                        const bool inside = reln >= 0 && reln + CH <= total;
+                        fe_fetch_chunk<NPF>(pf, chan, hist, hist_len, reln + 2 * tid, total, inside);
+                    }
+                }
+                for (int k = 0; k < nch; ++k) {
+                    __syncthreads();                                                            // B1
+                    wave_priority(kFePrioStage);
+                    if (k > 0) fes_carry_tail<(CH >> BLK)>(LE, LO, fes_off<CH>(BLK - 1), fes_offo<S, CH>(BLK - 1));      // the tail of stage 2's input: its consumer finished before B1
+                    FesStages<S, CH, 0, BLK - 1, false>::run(LE, LO, LZ, hb, zeta, tid);        // stage 0 | Ba | stage 1 + carry E0 | Bb
+                    {
+                        constexpr int E = BLK - 1, CNT = CH >> (E + 1), M = fes_m(S, E);
+                        fes_stage_pairs<M, CNT>(LE + fes_off<CH>(E) + kFeTail, LO + fes_offo<S, CH>(E) + kFeTail, hb + E * kHbMaxM,
+                                                LE + fes_off<CH>(E + 1) + kFeTail, LO + fes_offo<S, CH>(E + 1) + kFeTail, tid);
+                        fes_carry_tail<(CH >> E)>(LE, LO, fes_off<CH>(E - 1), fes_offo<S, CH>(E - 1));
+                    }
+                    wave_priority(0);
+                    if (k + 1 < nch) {
+                        const int64_t rel1 = u_lo + (int64_t)(k + 1) * CH - (int64_t)dyn.buf0;
+                        fes_mix_chunk<S, CH, NPF>(pf, rel1, dyn, sgn, tab, LE, LO, tid);
+                        if (k + 2 < nch) {
+                            const int64_t reln = rel1 + CH;
+                            const bool inside = reln >= 0 && reln + CH <= total;
+                            fe_fetch_chunk<NPF>(pf, chan, hist, hist_len, reln + 2 * tid, total, inside);
+                        }
+                    }
+                }
+                __syncthreads();                                                                // the tail's B1 of the chunk that does not come
+            } else {
+                for (int k = 0; k <= nch; ++k) {
+                    const bool have = k >= 1, bar = k < nch;          // chunk k - 1 has a tail to run; the workers are at chunk k
+                    const int64_t uc = u_lo + (int64_t)(k - 1) * CH;
+                    const int64_t kz0 = uc >> S;
+                    int64_t jmine = 0, jhi = 0;
+                    int kj = 0;
+                    float2 hv[kArmTaps / 2];
+                    if (have) {
+                        const int64_t ja = resamp_first_out(kz0, dyn.phase0, step), jb = resamp_first_out(kz0 + CZ, dyn.phase0, step);
+                        const int64_t jlo = ja < j0 ? j0 : ja;
+                        jhi = jb > j1 ? j1 : jb;
+                        jmine = jlo + ltid;                           // CZ <= 64 chain outputs, rate < 1: at most one per lane
+                        if (jmine < jhi) {
+                            const int64_t Pj = (int64_t)dyn.phase0 + jmine * (int64_t)step;
+                            kj = (int)((Pj >> 24) - kz0);
+                            const float2 *h2 = reinterpret_cast<const float2 *>(arms + (int)((Pj & 0xFFFFFF) >> 16) * kArmTaps);
+#pragma unroll
+                            for (int t = 0; t < kArmTaps / 2; ++t) hv[t] = h2[t];
+                        }
+                    }
+                    __syncthreads();                                                            // B1 (after the last chunk: the closing barrier)
+                    if (have) FesStages<S, CH, BLK, BLK + 1, true>::run(LE, LO, LZ, hb, zeta, ltid);      // stage BLK of chunk k - 1 and the carry of its input
+                    if (bar) __syncthreads();                                                   // Ba
+                    if constexpr (NT == 3) {
+                        if (have) { wave_sync(); FesStages<S, CH, BLK + 1, BLK + 2, true>::run(LE, LO, LZ, hb, zeta, ltid); }   // middle tail stage
+                    } else if (have) {
+                        if (k >= 2 && ltid < kFeZTail) LZ[ltid] = LZ[CZ + ltid];                // Z tail of the chunk before
+                        wave_sync();
+                        FesStages<S, CH, S - 1, S, true>::run(LE, LO, LZ, hb, zeta, ltid);      // stage S-1 -> Z
+                    }
+                    if (bar) __syncthreads();                                                   // Bb
+                    if constexpr (NT == 3) {
+                        if (have) {
+                            if (k >= 2 && ltid < kFeZTail) LZ[ltid] = LZ[CZ + ltid];
+                            wave_sync();
+                            FesStages<S, CH, S - 1, S, true>::run(LE, LO, LZ, hb, zeta, ltid);
+                        }
+                    }
+                    if (have) {
+                        wave_sync();
+                        if (jmine < jhi) {
+                            const float2 *z = LZ + kFeZTail + kj - (kArmTaps - 1);
+                            float ar = 0.f, ai = 0.f;
+#pragma unroll
+                            for (int t = 0; t < kArmTaps / 2; ++t) {
+                                ar = fmaf(hv[t].x, z[2 * t].x, ar); ai = fmaf(hv[t].x, z[2 * t].y, ai);
+                                ar = fmaf(hv[t].y, z[2 * t + 1].x, ar); ai = fmaf(hv[t].y, z[2 * t + 1].y, ai);
+                            }
+                            iq_cur[kIqHist + jmine] = make_float2(ar, ai);
+                        }
+                        wave_sync();
+                    }
+                }
+            }
+            return;
+        }
         if (!tailw) {
             for (int k = 0; k < nch; ++k) {
                 const int64_t uc = u_lo + (int64_t)k * CH;
