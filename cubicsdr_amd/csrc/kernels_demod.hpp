@@ -650,7 +650,9 @@ __device__ __forceinline__ void fes_mix_chunk(const float4 (&pf)[NPF], int64_t r
 }
 
 // TW (S = 5, 6): a FIFTH wave owns the one-wave tail (the last two -- depth 6: three -- stages and the arbitrary resampler).  It works one chunk behind
-// the four worker waves, one piece per barrier interval, so the workers never wait for the tail at the head of the next chunk:
+// the four worker waves, one piece per barrier interval, so the workers never wait for the tail at the head of the next chunk.  Since round 6 a chunk is
+// THREE barrier intervals (kFeSched3, the schedule written out inside fes_body: the next chunk's mix rides beside stage 2); the four-interval one it
+// replaced (A/B builds: -DCSDR_FE_SCHED3=0) was:
 //   workers      mix k | B1 | stage 0 | B2 | stage 1 | B3 | stage 2 (writes the tail's input of chunk k) | B4
 //   tail wave    stage S-2 of chunk k-1 (+ its carry) | B1 | Z tail, stage S-1 | B2 | resampler | B3 | - | B4
 // The tail's input region is read before B1 of chunk k and rewritten only after B3 of chunk k; everything else it touches
